@@ -1,0 +1,127 @@
+/*
+ * vision3d_hip.h -- C ABI of libvision3d_hip.so, the MI355X (gfx950) implementation of the
+ * vision3d point-cloud hot path.
+ *
+ * Conventions:
+ *   - plain pointers + sizes, no torch types.  Every pointer is a DEVICE pointer unless its name ends
+ *     in `_host`.  The caller owns every buffer, including workspaces (query the *_workspace() size
+ *     first); the library never allocates or frees across this boundary (the v3d_second_plan object
+ *     below owns a private arena for its own lifetime).
+ *   - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it -- no call
+ *     synchronises the device, data-dependent sizes are returned through device-side counters.
+ *   - return value: 0 = ok; < 0 = invalid argument (V3D_E*); > 0 = hipError_t from the runtime.
+ *   - stateless and re-entrant: no global mutable state; concurrent calls on different streams are
+ *     safe (reference ops are called from 6 DataLoader worker processes, train.py:18).
+ *   - row-major contiguous inputs of exactly the stated dtype (reference: raw data_ptr use without
+ *     .contiguous(), box_iou_rotated_cuda.cu:81-82).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference root).
+ */
+#ifndef VISION3D_HIP_H
+#define VISION3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V3D_OK 0
+#define V3D_EINVAL (-1)     /* bad size / null pointer / unsupported shape */
+#define V3D_EWORKSPACE (-2) /* workspace too small */
+#define V3D_EUNSUPPORTED (-3)
+
+typedef void* v3d_stream_t;
+
+/* ---- version probes: vision3d/ops/csrc/vision.cpp:14-58 (get_cuda_version/get_compiler_version) */
+const char* v3d_version(void);          /* "vision3d_hip x.y (gfx950)" */
+int v3d_hip_runtime_version(void);      /* hipRuntimeGetVersion, replaces cuda_version.cu:6-8 */
+const char* v3d_compiler_version(void); /* "clang M.m.p" */
+const char* v3d_error_string(int code);
+
+/* ---- A2: pairwise rotated BEV IoU.
+ * Replaces detectron2::box_iou_rotated (ops/csrc/box_iou_rotated/box_iou_rotated.h:20-32,
+ * box_iou_rotated_cuda.cu:65-121).  boxes (.,5) f32 = (xc, yc, w, h, angle_DEGREES); ious (M,N) f32.
+ * Arithmetic follows the HOST branch of box_iou_rotated_utils.h (the CPU path is the parity target). */
+int v3d_box_iou_rotated(const float* boxes1, int M, const float* boxes2, int N, float* ious, v3d_stream_t stream);
+
+/* ---- A3: greedy rotated NMS.
+ * Replaces detectron2::nms_rotated (ops/csrc/nms_rotated/nms_rotated.h:22-36; CPU semantics
+ * nms_rotated_cpu.cpp:7-59: suppress when IoU >= thr).  keep (N) i64 receives indices into the
+ * ORIGINAL arrays in decreasing-score order (ties: lower index first); *n_keep (device i32) the count.
+ * The score sort, the IoU bitmask and the sequential reduction all run on the device. */
+size_t v3d_nms_rotated_workspace(int N);
+int v3d_nms_rotated(const float* boxes, const float* scores, int N, float iou_threshold, int64_t* keep,
+                    int32_t* n_keep, void* workspace, size_t workspace_bytes, v3d_stream_t stream);
+
+/* ---- A11: points in cuboids / rectangles.
+ * Replaces core/geometry.py:27-65 (PointsInCuboids._get_mask when use_z != 0,
+ * PointsNotInRectangles._get_mask otherwise).  points (N,C>=3) f32, boxes (n,7) f32
+ * (x,y,z,w,l,h,yaw_rad); mask (N,n) u8. */
+int v3d_points_in_boxes(const float* points, int N, int C, const float* boxes, int n, int use_z, uint8_t* mask,
+                        v3d_stream_t stream);
+
+/* ---- T1 (+A5, A6): voxelizer fused with the VoxelFeatureExtractor mean.
+ * Replaces spconv.utils.VoxelGenerator.generate as driven by core/preprocess.py:17-33 (per-frame
+ * voxelisation, batch index prefixed, frames concatenated) and detector/layers.py:10-17.
+ * points (n_points,C) f32 = the frames concatenated; frame_offsets_host (B+1) i32 on the HOST.
+ * voxel_size_host[3] (x,y,z), bounds_host[6] (x0,y0,z0,x1,y1,z1).
+ * Outputs sized for B*max_voxels rows: voxels (.,max_pts,C) f32 zero padded [may be NULL],
+ * coords (.,4) i32 = (b,z,y,x), occupancy (.) i32, mean (.,C) f32 [may be NULL]; *n_voxels (device i32).
+ * Order: frame-major, first-touch order of the input points within a frame; the first max_pts points
+ * of a voxel (in input order) are kept -- identical to the sequential reference loop. */
+size_t v3d_voxelize_workspace(int n_points);
+int v3d_voxelize(const float* points, int n_points, int C, const int32_t* frame_offsets_host, int B,
+                 const float* voxel_size_host, const float* bounds_host, int max_pts, int max_voxels, float* voxels,
+                 int32_t* coords, int32_t* occupancy, float* mean, int32_t* n_voxels, void* workspace,
+                 size_t workspace_bytes, v3d_stream_t stream);
+
+/* ---- T3: sparse-convolution rulebooks (spconv ops.get_indice_pairs, reached through
+ * spconv.SubMConv3d / SparseConv3d at detector/sparse_cnn.py:15-30,153-175).
+ * coords (cap,4) i32 (b,z,y,x); *n (device i32) active rows.  The rulebook is an output-stationary
+ * neighbour table nbr (K, cap_out) i32, k-major: nbr[k*cap_out + o] = input row feeding output row o
+ * through kernel offset k (k = (kz*ky_n + ky)*kx_n + kx), or -1.
+ *   subm:   output sites == input sites (cap_out == cap).
+ *   sparse: out sites = { (i + pad - k)/stride integral, in range }, numbered in first-touch order of
+ *           the ticket sequence t = i*K + k; coords_out (cap_out,4), *n_out (device i32, clipped to
+ *           cap_out; bit 0 of *overflow is set when clipped). */
+size_t v3d_rulebook_workspace(int cap_in, int cap_out, int K);
+int v3d_rulebook_subm(const int32_t* coords, const int32_t* n, int cap, const int32_t* spatial_shape_host,
+                      const int32_t* ksize_host, int32_t* nbr, void* workspace, size_t workspace_bytes,
+                      v3d_stream_t stream);
+int v3d_rulebook_sparse(const int32_t* coords_in, const int32_t* n_in, int cap_in,
+                        const int32_t* spatial_shape_host, const int32_t* ksize_host, const int32_t* stride_host,
+                        const int32_t* padding_host, int32_t* coords_out, int32_t* n_out, int cap_out, int32_t* nbr,
+                        int32_t* overflow, void* workspace, size_t workspace_bytes, v3d_stream_t stream);
+
+/* ---- T3: sparse convolution forward (spconv ops.indice_conv) with optional fused per-channel affine
+ * (BatchNorm1d in eval mode folded to scale/shift, sparse_cnn.py:18,27) and ReLU.
+ * in (>=n_in,Cin) f32, weight (K,Cin,Cout) f32 [= spconv's (k0,k1,k2,Cin,Cout)], out (cap_out,Cout).
+ * out[o,:] = act( (sum_k in[nbr[k,o],:] @ weight[k]) * scale + shift ).  Deterministic (no atomics).
+ * algo: 0 = auto, 1 = scalar reference kernel, 2 = LDS-staged MFMA kernel (needs Cin%4==0, Cout%16==0). */
+int v3d_sparse_conv_fwd(const float* in, const float* weight, const int32_t* nbr, const int32_t* n_out, int cap_out,
+                        int K, int Cin, int Cout, const float* scale, const float* shift, int relu, float* out,
+                        int algo, v3d_stream_t stream);
+
+/* ---- T2: SparseConvTensor.dense() (detector/sparse_cnn.py:128-133): zero-fill + scatter.
+ * feat (cap,C), coords (cap,4), *n rows -> dense (B,C,D,H,W) f32. */
+int v3d_densify(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
+                const int32_t* spatial_shape_host, float* dense, v3d_stream_t stream);
+
+/* ---- T4/T5: pointnet2 ops (pointnet2_utils.furthest_point_sample / gather_operation / ball_query /
+ * grouping_operation; call sites detector/model.py:46-66, detector/roi_grid_pool.py:64-72). */
+size_t v3d_fps_workspace(int B, int N);
+int v3d_furthest_point_sample(const float* xyz, int B, int N, int K, int32_t* idx, void* workspace,
+                              size_t workspace_bytes, v3d_stream_t stream);
+int v3d_gather_points(const float* feat, const int32_t* idx, int B, int C, int N, int K, float* out,
+                      v3d_stream_t stream);
+int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M, float radius, int nsample,
+                   int32_t* idx, v3d_stream_t stream);
+int v3d_group_points(const float* feat, const int32_t* idx, int B, int C, int N, int M, int nsample, float* out,
+                     v3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISION3D_HIP_H */

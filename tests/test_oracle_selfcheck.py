@@ -1,0 +1,133 @@
+"""CPU: self-consistency checks that pin the "parity unpinned" parts of oracle/ (voxelizer, sparse conv,
+pointnet2 ops) to independent statements of the same maths:
+  (i)  sparse conv == torch.nn.functional.conv3d on the densified grid, masked to the active set;
+  (ii) voxel set == np.floor((p - lo) / vs) in fp32 + np.unique;
+  (iii) FPS / ball query == O(N^2) numpy loops."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from vision3d_amd import synth
+
+
+def random_sparse(rng, b, shape, n, c):
+    keys = rng.choice(b * shape[0] * shape[1] * shape[2], n, replace=False)
+    bb, rem = np.divmod(keys, shape[0] * shape[1] * shape[2])
+    z, rem = np.divmod(rem, shape[1] * shape[2])
+    y, x = np.divmod(rem, shape[2])
+    order = np.argsort(bb, kind="stable")
+    coords = np.stack([bb, z, y, x], 1)[order].astype(np.int32)
+    return coords, rng.standard_normal((n, c)).astype(np.float32)
+
+
+def dense_of(feats, coords, b, shape):
+    d = np.zeros((b, feats.shape[1], *shape), np.float32)
+    d[coords[:, 0], :, coords[:, 1], coords[:, 2], coords[:, 3]] = feats
+    return d
+
+
+def test_subm_conv_equals_dense_conv3d(oracle):
+    rng = np.random.default_rng(0)
+    shape, b, cin, cout = [9, 14, 12], 2, 5, 7
+    coords, feats = random_sparse(rng, b, shape, 300, cin)
+    w = rng.standard_normal((3, 3, 3, cin, cout)).astype(np.float32)
+    nbr = oracle.subm_rulebook(coords, shape, 3)
+    out = oracle.sparse_conv_fwd(feats, w, nbr)
+    ref = F.conv3d(torch.from_numpy(dense_of(feats, coords, b, shape)), torch.from_numpy(w).permute(4, 3, 0, 1, 2), padding=1)
+    ref_rows = ref.numpy()[coords[:, 0], :, coords[:, 1], coords[:, 2], coords[:, 3]]
+    np.testing.assert_allclose(out, ref_rows, rtol=1e-4, atol=1e-4)
+
+
+def _check_strided(oracle, shape, ks, st, pd, seed):
+    rng = np.random.default_rng(seed)
+    b, cin, cout = 2, 4, 6
+    coords, feats = random_sparse(rng, b, shape, 250, cin)
+    w = rng.standard_normal((*ks, cin, cout)).astype(np.float32)
+    oc, nbr, oshape = oracle.sparse_rulebook(coords, shape, ks, st, pd)
+    out = oracle.sparse_conv_fwd(feats, w, nbr)
+    ref = F.conv3d(torch.from_numpy(dense_of(feats, coords, b, shape)), torch.from_numpy(w).permute(4, 3, 0, 1, 2),
+                   stride=st, padding=pd).numpy()
+    assert list(ref.shape[2:]) == oshape
+    got = dense_of(out, oc, b, oshape)
+    np.testing.assert_allclose(got, ref * (np.abs(got).sum(1, keepdims=True) > 0), rtol=1e-4, atol=1e-4)
+    # every dense output with a contributing input is an active output site (site set is complete)
+    occ = F.conv3d(torch.from_numpy((np.abs(dense_of(feats, coords, b, shape)).sum(1, keepdims=True) > 0).astype(np.float32)),
+                   torch.ones(1, 1, *ks), stride=st, padding=pd).numpy()[:, 0] > 0
+    act = np.zeros_like(occ)
+    act[oc[:, 0], oc[:, 1], oc[:, 2], oc[:, 3]] = True
+    np.testing.assert_array_equal(act, occ)
+    assert len(np.unique(oc, axis=0)) == len(oc)
+    # first-touch numbering: the outputs of frame 0 precede those of frame 1
+    assert np.all(np.diff(oc[:, 0]) >= 0)
+
+
+def test_strided_conv_equals_dense_conv3d(oracle):
+    _check_strided(oracle, [9, 14, 12], [3, 3, 3], [2, 2, 2], [1, 1, 1], 1)
+    _check_strided(oracle, [11, 12, 10], [3, 3, 3], [2, 2, 2], [0, 1, 1], 2)
+    _check_strided(oracle, [5, 12, 10], [3, 1, 1], [2, 1, 1], [0, 0, 0], 3)
+
+
+def test_fused_affine_relu(oracle):
+    rng = np.random.default_rng(4)
+    coords, feats = random_sparse(rng, 1, [6, 8, 8], 100, 4)
+    w = rng.standard_normal((3, 3, 3, 4, 8)).astype(np.float32)
+    nbr = oracle.subm_rulebook(coords, [6, 8, 8], 3)
+    sc, sh = rng.uniform(0.5, 2, 8).astype(np.float32), rng.standard_normal(8).astype(np.float32)
+    plain = oracle.sparse_conv_fwd(feats, w, nbr)
+    np.testing.assert_allclose(oracle.sparse_conv_fwd(feats, w, nbr, sc, sh, True), np.maximum(plain * sc + sh, 0), rtol=1e-6, atol=1e-6)
+
+
+def test_voxelizer_set_equals_numpy(oracle):
+    cloud = synth.make_cloud(3)
+    vs, lo = np.array([0.05, 0.05, 0.1], np.float32), np.array(synth.KITTI_BOUNDS[:3], np.float32)
+    vox, coors, num = oracle.voxelize(cloud, vs, synth.KITTI_BOUNDS, 5, 20000)
+    c = np.floor((cloud[:, :3] - lo) / vs).astype(np.int64)
+    grid = np.array([1408, 1600, 40])
+    ok = np.all((c >= 0) & (c < grid), 1)
+    uniq, first, counts = np.unique(c[ok][:, ::-1], axis=0, return_index=True, return_counts=True)
+    assert len(uniq) == len(coors)
+    order = np.argsort(first)                      # first-touch order
+    np.testing.assert_array_equal(coors, uniq[order].astype(np.int32))
+    np.testing.assert_array_equal(num, np.minimum(counts[order], 5))
+    # slot 0 of every voxel is its first toucher
+    np.testing.assert_array_equal(vox[:, 0], cloud[ok][first[order]])
+    assert (vox[np.arange(5)[None] >= num[:, None]] == 0).all()  # padded slots are zero
+
+
+def test_voxelizer_max_voxels_and_bounds(oracle):
+    cloud = synth.make_cloud(1)[:4000]
+    cloud[::7, 0] = 70.4      # exactly on the upper bound -> dropped (half-open)
+    cloud[::11, 2] = -3.0001  # below
+    _, coors_all, _ = oracle.voxelize(cloud, [0.05, 0.05, 0.1], synth.KITTI_BOUNDS, 5, 20000)
+    _, coors_cap, _ = oracle.voxelize(cloud, [0.05, 0.05, 0.1], synth.KITTI_BOUNDS, 5, 1000)
+    assert len(coors_cap) == 1000 and len(coors_all) > 1000
+    np.testing.assert_array_equal(coors_cap, coors_all[:1000])
+    assert coors_all[:, 2].max() < 1408 and coors_all.min() >= 0
+
+
+def test_fps_and_ball_query_vs_numpy(oracle):
+    rng = np.random.default_rng(7)
+    xyz = rng.uniform(-5, 5, (2, 500, 3)).astype(np.float32)
+    idx = oracle.fps(xyz, 40)
+    for b in range(2):
+        temp = np.full(500, 1e10, np.float32)
+        last, ref = 0, [0]
+        for _ in range(39):
+            d = ((xyz[b] - xyz[b, last]) ** 2).astype(np.float32)
+            d = (d[:, 0] + d[:, 1]) + d[:, 2]
+            temp = np.minimum(temp, d)
+            last = int(np.argmax(temp))
+            ref.append(last)
+        np.testing.assert_array_equal(idx[b], ref)
+    new_xyz = xyz[:, :50]
+    bq = oracle.ball_query(1.5, 8, xyz, new_xyz)
+    for b in range(2):
+        for j in range(50):
+            d = ((new_xyz[b, j] - xyz[b]) ** 2).astype(np.float32)
+            hits = np.nonzero(((d[:, 0] + d[:, 1]) + d[:, 2]) < np.float32(1.5) ** 2)[0][:8]
+            ref = np.full(8, hits[0] if len(hits) else 0)
+            ref[:len(hits)] = hits
+            np.testing.assert_array_equal(bq[b, j], ref)
+    feat = rng.standard_normal((2, 6, 500)).astype(np.float32)
+    np.testing.assert_array_equal(oracle.group(feat, bq), np.stack([feat[b][:, bq[b]] for b in range(2)]))
+    np.testing.assert_array_equal(oracle.gather(feat, idx), np.stack([feat[b][:, idx[b]] for b in range(2)]))

@@ -1,0 +1,111 @@
+"""ctypes binding of libvision3d_hip.so (the C ABI declared in include/vision3d_hip.h).
+
+This is the only place the package touches native code.  There is NO fallback: if the shared library
+is missing or a tensor is not on the GPU, the call raises -- the product path never routes through a
+CPU implementation (oracle/ is test infrastructure and is not importable from here).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvision3d_hip.so")
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/vision3d_hip.h one to one
+_SIGNATURES = {
+    "v3d_version": (C.c_char_p, []),
+    "v3d_hip_runtime_version": (_i, []),
+    "v3d_compiler_version": (C.c_char_p, []),
+    "v3d_error_string": (C.c_char_p, [_i]),
+    "v3d_box_iou_rotated": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "v3d_nms_rotated_workspace": (_sz, [_i]),
+    "v3d_nms_rotated": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "v3d_points_in_boxes": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "v3d_voxelize_workspace": (_sz, [_i]),
+    "v3d_voxelize": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "v3d_rulebook_workspace": (_sz, [_i, _i, _i]),
+    "v3d_rulebook_subm": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "v3d_rulebook_sparse": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "v3d_sparse_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "v3d_densify": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "v3d_fps_workspace": (_sz, [_i, _i]),
+    "v3d_furthest_point_sample": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "v3d_gather_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "v3d_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
+    "v3d_group_points": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the native library; raises loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C vision3d_amd/csrc).  vision3d_amd has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().v3d_error_string(int(code)).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def require_gpu(name, *tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(f"{name}: tensors must live on the GPU (vision3d_amd has no CPU path); got {t.device}")
+
+
+def as_f32(name, t):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def as_i32(name, t):
+    if t.dtype != torch.int32:
+        raise RuntimeError(f"{name}: expected int32, got {t.dtype}")
+    return t.contiguous()
+
+
+def host_i32(values):
+    """Small host-side int32 array argument (spatial shapes, kernel sizes, frame offsets)."""
+    arr = (C.c_int32 * len(values))(*[int(v) for v in values])
+    return arr
+
+
+def host_f32(values):
+    return (C.c_float * len(values))(*[float(v) for v in values])
+
+
+def workspace(nbytes, device):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)

@@ -1,0 +1,306 @@
+// iou_nms.hip -- rotated BEV IoU (A2), rotated NMS (A3) and points-in-boxes (A11) for gfx950.
+//
+// Replaces vision3d/ops/csrc/box_iou_rotated/box_iou_rotated_cuda.cu and
+// vision3d/ops/csrc/nms_rotated/nms_rotated_cuda.cu (+ the numpy core/geometry.py masks).
+// Design notes (wave64):
+//   * the double-precision sin/cos of a box depends on its angle only -> every box is "prepped"
+//     exactly once (BoxPrep), never once per pair as in the reference kernels;
+//   * NMS bitmask words ARE wave ballots: lane = column inside a 64-wide column block, one
+//     __ballot() yields the 64-bit suppression word the reference builds with a 64-step loop;
+//   * the greedy reduction stays on the device (the reference copies the mask to the host,
+//     nms_rotated_cuda.cu:106-128): per 64-box block the diagonal word is resolved with register
+//     readlanes, then the kept rows are OR-ed into the remaining words by all lanes in parallel;
+//   * the descending score sort is an in-LDS bitonic network on (score, index) keys.
+#include "v3d_common.h"
+#include "rotated_iou.h"
+
+using v3d::BoxPrep;
+
+// ------------------------------------------------------------------------------------------------
+// pairwise IoU
+// ------------------------------------------------------------------------------------------------
+#define IOU_ROWS 32
+
+__global__ __launch_bounds__(V3D_BLOCK) void box_iou_rotated_kernel(const float* __restrict__ b1, int M,
+                                                                    const float* __restrict__ b2, int N,
+                                                                    float* __restrict__ out) {
+  __shared__ BoxPrep rows[IOU_ROWS];
+  const int row0 = blockIdx.y * IOU_ROWS;
+  const int nrows = min(IOU_ROWS, M - row0);
+  if ((int)threadIdx.x < nrows) rows[threadIdx.x] = v3d::prep_box(b1 + 5 * (size_t)(row0 + threadIdx.x));
+  __syncthreads();
+  const int j = blockIdx.x * V3D_BLOCK + threadIdx.x;
+  if (j >= N) return;
+  const BoxPrep bj = v3d::prep_box(b2 + 5 * (size_t)j);
+  for (int r = 0; r < nrows; r++) out[(size_t)(row0 + r) * N + j] = v3d::iou_prepped(rows[r], bj);
+}
+
+extern "C" int v3d_box_iou_rotated(const float* boxes1, int M, const float* boxes2, int N, float* ious,
+                                   v3d_stream_t stream) {
+  if (M < 0 || N < 0) return V3D_EINVAL;
+  if (M == 0 || N == 0) return V3D_OK;
+  if (!boxes1 || !boxes2 || !ious) return V3D_EINVAL;
+  dim3 grid(v3d_ceil_div(N, V3D_BLOCK), v3d_ceil_div(M, IOU_ROWS));
+  if (grid.y > 65535) return V3D_EUNSUPPORTED;
+  hipLaunchKernelGGL(box_iou_rotated_kernel, grid, dim3(V3D_BLOCK), 0, (hipStream_t)stream, boxes1, M, boxes2, N,
+                     ious);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NMS step 1: sort keys.  key = (~orderable(score) << 32) | index, ascending u64 order ==
+// descending score, ties by ascending index.  Padding keys are all ones (sort last).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned orderable(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ void nms_make_keys_kernel(const float* __restrict__ scores, int N, int Npad,
+                                     unsigned long long* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Npad) return;
+  keys[i] = i < N ? (((unsigned long long)(~orderable(scores[i]))) << 32) | (unsigned)i : ~0ull;
+}
+
+// whole bitonic network inside one block's LDS (Npad <= 4096 -> 32 KiB)
+__global__ __launch_bounds__(1024) void bitonic_lds_kernel(unsigned long long* __restrict__ keys, int Npad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
+  for (int i = threadIdx.x; i < Npad; i += blockDim.x) sk[i] = keys[i];
+  __syncthreads();
+  for (int k = 2; k <= Npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < Npad; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = sk[i], b = sk[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            sk[i] = b;
+            sk[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < Npad; i += blockDim.x) keys[i] = sk[i];
+}
+
+// one (k, j) compare-exchange pass over global memory (Npad > 4096)
+__global__ void bitonic_global_step_kernel(unsigned long long* __restrict__ keys, int Npad, int j, int k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Npad) return;
+  const int ixj = i ^ j;
+  if (ixj > i) {
+    const unsigned long long a = keys[i], b = keys[ixj];
+    const bool up = (i & k) == 0;
+    if ((a > b) == up) {
+      keys[i] = b;
+      keys[ixj] = a;
+    }
+  }
+}
+
+// NMS step 2: order + prepped boxes in sorted order
+__global__ void nms_gather_kernel(const unsigned long long* __restrict__ keys, const float* __restrict__ boxes,
+                                  int N, int* __restrict__ order, BoxPrep* __restrict__ prep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int src = (int)(keys[i] & 0xFFFFFFFFu);
+  order[i] = src;
+  prep[i] = v3d::prep_box(boxes + 5 * (size_t)src);
+}
+
+// NMS step 3: suppression bitmask.  mask[i*nwords + cb] bit c  <=>  IoU(sorted i, sorted cb*64+c) >= thr
+// and cb*64+c > i.  Block = 4 waves; blockIdx.x = column block, blockIdx.y = group of 64 rows; each
+// wave walks its share of the 64 rows, lane = column, word = ballot.
+__global__ __launch_bounds__(V3D_BLOCK) void nms_mask_kernel(const BoxPrep* __restrict__ prep, int N, int nwords,
+                                                             float thr, unsigned long long* __restrict__ mask) {
+  const int cb = blockIdx.x, rg = blockIdx.y;
+  if (rg > cb) return;  // strictly lower block-triangle is never read
+  __shared__ BoxPrep rows[64];
+  const int row0 = rg * 64;
+  if (threadIdx.x < 64 && row0 + (int)threadIdx.x < N) rows[threadIdx.x] = prep[row0 + threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = cb * 64 + lane;
+  BoxPrep bc;
+  if (col < N) bc = prep[col];
+  const int nrows = min(64, N - row0);
+  for (int r = w; r < nrows; r += V3D_BLOCK / V3D_WAVE) {
+    const int row = row0 + r;
+    bool hit = false;
+    if (col < N && col > row) hit = v3d::iou_prepped(rows[r], bc) >= thr;
+    const unsigned long long word = __ballot(hit);
+    if (lane == 0) mask[(size_t)row * nwords + cb] = word;
+  }
+}
+
+// NMS step 4: greedy reduction on the device.
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(V3D_BLOCK) void nms_reduce_kernel(const unsigned long long* __restrict__ mask,
+                                                               const int* __restrict__ order, int N, int nwords,
+                                                               unsigned long long* __restrict__ remv /*nwords*/,
+                                                               long long* __restrict__ keep, int* __restrict__ n_keep) {
+  __shared__ unsigned long long kept_s;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int w = tid; w < nwords; w += V3D_BLOCK) remv[w] = 0ull;
+  __syncthreads();
+  int nk = 0;  // meaningful in wave 0
+  for (int b = 0; b < nwords; b++) {
+    if (tid < 64) {
+      const int i = b * 64 + lane;
+      const unsigned long long diag = i < N ? mask[(size_t)i * nwords + b] : 0ull;
+      unsigned long long r = remv[b];
+      unsigned long long kept = 0ull;
+      const int lim = min(64, N - b * 64);
+      for (int j = 0; j < lim; j++) {
+        if (!((r >> j) & 1ull)) {
+          kept |= 1ull << j;
+          r |= readlane64(diag, j);
+        }
+      }
+      if ((kept >> lane) & 1ull) keep[nk + __popcll(kept & ((1ull << lane) - 1ull))] = (long long)order[i];
+      nk += __popcll(kept);
+      if (lane == 0) kept_s = kept;
+    }
+    __syncthreads();
+    const unsigned long long kept = kept_s;
+    for (int w = b + 1 + tid; w < nwords; w += V3D_BLOCK) {
+      unsigned long long acc = remv[w];
+      unsigned long long bits = kept;
+      while (bits) {
+        const int j = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        acc |= mask[(size_t)(b * 64 + j) * nwords + w];
+      }
+      remv[w] = acc;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *n_keep = nk;
+}
+
+static inline int next_pow2(int n) {
+  int p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+extern "C" size_t v3d_nms_rotated_workspace(int N) {
+  if (N <= 0) return 256;
+  const size_t npad = (size_t)next_pow2(N), nwords = (size_t)(N + 63) / 64;
+  return v3d_align(npad * 8) + v3d_align((size_t)N * 4) + v3d_align((size_t)N * sizeof(BoxPrep)) +
+         v3d_align((size_t)N * nwords * 8) + v3d_align(nwords * 8) + 256;
+}
+
+extern "C" int v3d_nms_rotated(const float* boxes, const float* scores, int N, float iou_threshold, int64_t* keep,
+                               int32_t* n_keep, void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (N < 0 || !n_keep) return V3D_EINVAL;
+  if (N == 0) {
+    V3D_CHECK_HIP(hipMemsetAsync(n_keep, 0, sizeof(int32_t), st));
+    return V3D_OK;
+  }
+  if (!boxes || !scores || !keep || !workspace) return V3D_EINVAL;
+  const int npad = next_pow2(N), nwords = (N + 63) / 64;
+  V3dArena ar(workspace, workspace_bytes);
+  unsigned long long* keys = ar.take<unsigned long long>(npad);
+  int* order = ar.take<int>(N);
+  BoxPrep* prep = ar.take<BoxPrep>(N);
+  unsigned long long* mask = ar.take<unsigned long long>((size_t)N * nwords);
+  unsigned long long* remv = ar.take<unsigned long long>(nwords);
+  if (!ar.ok()) return V3D_EWORKSPACE;
+
+  hipLaunchKernelGGL(nms_make_keys_kernel, dim3(v3d_ceil_div(npad, 256)), dim3(256), 0, st, scores, N, npad, keys);
+  if (npad <= 4096) {
+    hipLaunchKernelGGL(bitonic_lds_kernel, dim3(1), dim3(1024), (size_t)npad * 8, st, keys, npad);
+  } else {
+    for (int k = 2; k <= npad; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1)
+        hipLaunchKernelGGL(bitonic_global_step_kernel, dim3(v3d_ceil_div(npad, 256)), dim3(256), 0, st, keys, npad, j, k);
+  }
+  hipLaunchKernelGGL(nms_gather_kernel, dim3(v3d_ceil_div(N, 256)), dim3(256), 0, st, keys, boxes, N, order, prep);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords), dim3(V3D_BLOCK), 0, st, prep, N, nwords, iou_threshold,
+                     mask);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(V3D_BLOCK), 0, st, mask, order, N, nwords, remv,
+                     (long long*)keep, n_keep);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// points in boxes (core/geometry.py:4-65).  Corner arithmetic in fp64 exactly where numpy promotes
+// (geometry.py:21); cos/sin evaluated on the float32 yaw.  One thread per point, boxes staged in LDS.
+// ------------------------------------------------------------------------------------------------
+struct PibBox {
+  double cx[4], cy[4];
+  float zlo, zhi;
+};
+#define PIB_BOXES 64
+
+__global__ __launch_bounds__(V3D_BLOCK) void points_in_boxes_kernel(const float* __restrict__ pts, int N, int C,
+                                                                    const float* __restrict__ boxes, int n, int use_z,
+                                                                    uint8_t* __restrict__ mask) {
+  __shared__ PibBox sb[PIB_BOXES];
+  const int i = blockIdx.x * V3D_BLOCK + threadIdx.x;
+  float px = 0.f, py = 0.f, pz = 0.f;
+  if (i < N) {
+    px = pts[(size_t)i * C];
+    py = pts[(size_t)i * C + 1];
+    pz = pts[(size_t)i * C + 2];
+  }
+  for (int b0 = 0; b0 < n; b0 += PIB_BOXES) {
+    const int nb = min(PIB_BOXES, n - b0);
+    __syncthreads();
+    if ((int)threadIdx.x < nb) {
+      const float* bx = boxes + 7 * (size_t)(b0 + threadIdx.x);
+      const float cf = cosf(bx[6]), sf = sinf(bx[6]);
+      const double ux[4] = {-0.5, 0.5, 0.5, -0.5}, uy[4] = {-0.5, -0.5, 0.5, 0.5};
+      PibBox pb;
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const double lx = (double)bx[3] * ux[v], ly = (double)bx[4] * uy[v];
+        pb.cx[v] = ((double)cf * lx + (double)(-sf) * ly) + (double)bx[0];
+        pb.cy[v] = ((double)sf * lx + (double)cf * ly) + (double)bx[1];
+      }
+      pb.zlo = bx[2] - bx[5] / 2;
+      pb.zhi = bx[2] + bx[5] / 2;
+      sb[threadIdx.x] = pb;
+    }
+    __syncthreads();
+    if (i < N) {
+      for (int b = 0; b < nb; b++) {
+        const PibBox& pb = sb[b];
+        bool in = true;
+        if (use_z) in = (pz > pb.zlo) && (pz < pb.zhi);
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          const int pv = (v + 3) & 3;
+          const double sx = -(pb.cx[v] - pb.cx[pv]), sy = -(pb.cy[v] - pb.cy[pv]);
+          const double vx = pb.cx[v] - (double)px, vy = pb.cy[v] - (double)py;
+          in = in && (sx * vy - sy * vx > 0);
+        }
+        mask[(size_t)i * n + b0 + b] = in ? 1 : 0;
+      }
+    }
+  }
+}
+
+extern "C" int v3d_points_in_boxes(const float* points, int N, int C, const float* boxes, int n, int use_z,
+                                   uint8_t* mask, v3d_stream_t stream) {
+  if (N < 0 || n < 0 || C < 3) return V3D_EINVAL;
+  if (N == 0 || n == 0) return V3D_OK;
+  if (!points || !boxes || !mask) return V3D_EINVAL;
+  hipLaunchKernelGGL(points_in_boxes_kernel, dim3(v3d_ceil_div(N, V3D_BLOCK)), dim3(V3D_BLOCK), 0, (hipStream_t)stream,
+                     points, N, C, boxes, n, use_z, mask);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}

@@ -1,0 +1,112 @@
+// v3d_common.h -- shared device helpers for libvision3d_hip (gfx950 only, wave64 throughout).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vision3d_hip.h"
+
+#define V3D_WAVE 64
+#define V3D_BLOCK 256
+
+#define V3D_CHECK_LAUNCH()                        \
+  do {                                            \
+    hipError_t e_ = hipGetLastError();            \
+    if (e_ != hipSuccess) return (int)e_;         \
+  } while (0)
+#define V3D_CHECK_HIP(x)                          \
+  do {                                            \
+    hipError_t e_ = (x);                          \
+    if (e_ != hipSuccess) return (int)e_;         \
+  } while (0)
+
+static inline int v3d_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline size_t v3d_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Bump allocator over a caller-provided workspace.
+struct V3dArena {
+  char* base;
+  size_t size, off;
+  V3dArena(void* p, size_t n) : base((char*)p), size(n), off(0) {}
+  template <typename T>
+  T* take(size_t count) {
+    size_t bytes = v3d_align(count * sizeof(T));
+    if (off + bytes > size) { off = size + 1; return nullptr; }
+    T* r = (T*)(base + off);
+    off += bytes;
+    return r;
+  }
+  bool ok() const { return off <= size; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Open-addressing hash table  key(u64) -> slot.  Per-slot payloads live in caller-owned arrays
+// indexed by slot.  Capacity is a power of two >= 2x the number of keys.  EMPTY = all ones, so the
+// whole table (and any 0xFF-initialised payload) is reset by ONE hipMemsetAsync.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned long long v3d_key_t;
+#define V3D_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+struct V3dHash {
+  v3d_key_t* keys;
+  unsigned mask;  // capacity - 1
+};
+
+static inline unsigned v3d_hash_capacity(long long n_items) {
+  unsigned cap = 1024;
+  while ((long long)cap < 2 * n_items) cap <<= 1;
+  return cap;
+}
+
+__device__ __forceinline__ unsigned v3d_hash_start(v3d_key_t key, unsigned mask) {
+  return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+}
+
+// insert-or-find; returns the slot holding `key`, or -1 if the table is full (probing is bounded by
+// the capacity so a mis-sized table can never spin forever)
+__device__ __forceinline__ int v3d_hash_insert(const V3dHash h, v3d_key_t key) {
+  unsigned s = v3d_hash_start(key, h.mask);
+  for (unsigned probes = 0; probes <= h.mask; probes++) {
+    v3d_key_t prev = atomicCAS(&h.keys[s], V3D_EMPTY_KEY, key);
+    if (prev == V3D_EMPTY_KEY || prev == key) return (int)s;
+    s = (s + 1) & h.mask;
+  }
+  return -1;
+}
+
+// lookup in a table completed by an EARLIER kernel; returns slot or -1
+__device__ __forceinline__ int v3d_hash_find(const V3dHash h, v3d_key_t key) {
+  unsigned s = v3d_hash_start(key, h.mask);
+  for (unsigned probes = 0; probes <= h.mask; probes++) {
+    v3d_key_t k = h.keys[s];
+    if (k == key) return (int)s;
+    if (k == V3D_EMPTY_KEY) return -1;
+    s = (s + 1) & h.mask;
+  }
+  return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave64 ballot + popcount compaction.  One flag per thread, 256-thread blocks.
+// Returns the exclusive rank of this thread's flag inside the block; `total` = flags set in the block.
+// `lds` must hold >= 4 ints and is free for reuse on return.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int v3d_block_rank(bool flag, int& total, int* lds) {
+  const unsigned long long m = __ballot(flag);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) lds[w] = __popcll(m);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < V3D_BLOCK / V3D_WAVE; i++) {
+    const int c = lds[i];
+    if (i < w) off += c;
+    tot += c;
+  }
+  __syncthreads();
+  total = tot;
+  return off + r;
+}
+
+// Items handled by one block of the chunked flag scans (256 threads x 8 rounds).
+#define V3D_SCAN_CHUNK 2048

@@ -1,0 +1,270 @@
+// voxelize.hip -- device voxelizer fused with the VoxelFeatureExtractor mean (T1 + A5 + A6).
+//
+// Replaces spconv.utils.VoxelGenerator.generate as driven by vision3d/core/preprocess.py:17-33
+// (host C++ loop over points + a 360 MB dense index grid per call) and detector/layers.py:10-17.
+//
+// The sequential reference semantics (voxel ids in first-touch order of the input points, the first
+// max_pts points of a voxel kept in input order) are reproduced EXACTLY by a parallel formulation:
+//   K1 insert : every point inserts its linear voxel key into a hash table; per slot an
+//               atomicMin keeps the smallest point index (the "first toucher") and an atomicExch
+//               threads the point onto the slot's linked list.
+//   K2 count  : flag[i] = "point i is the first toucher of its voxel"; per-2048-chunk popcounts
+//               (wave64 ballots).
+//   K3 scan   : exclusive scan of the chunk counts (+ per-frame voxel bases, for max_voxels).
+//   K4 emit   : rank of a first toucher (chunk offset + ballot prefix) == voxel id of the
+//               sequential loop.  The same thread walks its voxel's list, keeps the max_pts smallest
+//               point indices (== first-come order), writes coords/occupancy/points and the mean.
+// No host synchronisation: the voxel count stays in device memory.
+#include "v3d_common.h"
+
+#define VOX_MAX_FRAMES 64
+#define VOX_MAX_PTS 8
+
+struct VoxParams {
+  float vs[3], lo[3];
+  int grid[3];
+  int max_pts, max_voxels, C, B, n_points;
+  int frame_off[VOX_MAX_FRAMES + 1];
+};
+
+__device__ __forceinline__ int frame_of(const VoxParams& p, int i) {
+  int b = 0;
+  while (b + 1 < p.B && i >= p.frame_off[b + 1]) b++;
+  return b;
+}
+
+__global__ __launch_bounds__(V3D_BLOCK) void vox_insert_kernel(const float* __restrict__ pts, const VoxParams p,
+                                                               const V3dHash h, unsigned* __restrict__ first,
+                                                               int* __restrict__ head, int* __restrict__ pt_slot,
+                                                               int* __restrict__ next) {
+  for (int i = blockIdx.x * V3D_BLOCK + threadIdx.x; i < p.n_points; i += gridDim.x * V3D_BLOCK) {
+    const float* q = pts + (size_t)i * p.C;
+    int c[3];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      // true IEEE division in fp32: bit-exact voxel indices
+      const float f = floorf((q[j] - p.lo[j]) / p.vs[j]);
+      ok = ok && (f >= 0.0f) && (f < (float)p.grid[j]);
+      c[j] = (int)f;
+    }
+    if (!ok) {
+      pt_slot[i] = -1;
+      continue;
+    }
+    const int b = frame_of(p, i);
+    const v3d_key_t key = (((v3d_key_t)b * p.grid[2] + c[2]) * p.grid[1] + c[1]) * p.grid[0] + c[0];
+    const int s = v3d_hash_insert(h, key);
+    if (s < 0) {  // unreachable: the table holds 2x n_points slots
+      pt_slot[i] = -1;
+      continue;
+    }
+    atomicMin(&first[s], (unsigned)i);
+    next[i] = atomicExch(&head[s], i);
+    pt_slot[i] = s;
+  }
+}
+
+__device__ __forceinline__ bool vox_is_first(const int* pt_slot, const unsigned* first, int i, int n) {
+  if (i >= n) return false;
+  const int s = pt_slot[i];
+  return s >= 0 && first[s] == (unsigned)i;
+}
+
+__global__ __launch_bounds__(V3D_BLOCK) void vox_count_kernel(const int* __restrict__ pt_slot,
+                                                              const unsigned* __restrict__ first, int n,
+                                                              int* __restrict__ chunk_counts) {
+  __shared__ int lds[4];
+  const int base = blockIdx.x * V3D_SCAN_CHUNK;
+  int cnt = 0;
+  for (int r = 0; r < V3D_SCAN_CHUNK / V3D_BLOCK; r++) {
+    int tot;
+    v3d_block_rank(vox_is_first(pt_slot, first, base + r * V3D_BLOCK + threadIdx.x, n), tot, lds);
+    cnt += tot;
+  }
+  if (threadIdx.x == 0) chunk_counts[blockIdx.x] = cnt;
+}
+
+// single block: exclusive scan of chunk counts, then per-frame bases.
+// frame_base[b] = number of first-touch points before frame b's first point; out_base[b] = first output
+// row of frame b after clipping every earlier frame to max_voxels; n_voxels = total rows.
+__global__ __launch_bounds__(1024) void vox_scan_kernel(int* __restrict__ chunk_counts, int n_chunks,
+                                                        const int* __restrict__ pt_slot,
+                                                        const unsigned* __restrict__ first, const VoxParams p,
+                                                        int* __restrict__ frame_base, int* __restrict__ out_base,
+                                                        int* __restrict__ n_voxels) {
+  __shared__ int part[1024];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < n_chunks; c0 += 1024) {
+    const int idx = c0 + tid;
+    const int v = idx < n_chunks ? chunk_counts[idx] : 0;
+    part[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+      const int t = tid >= d ? part[tid - d] : 0;
+      __syncthreads();
+      part[tid] += t;
+      __syncthreads();
+    }
+    const int carry = carry_s;
+    if (idx < n_chunks) chunk_counts[idx] = carry + part[tid] - v;  // exclusive
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + part[1023];
+    __syncthreads();
+  }
+  // per-frame bases: wave w handles frames w, w+16, ...
+  const int lane = tid & 63, w = tid >> 6;
+  for (int b = w; b <= p.B; b += 16) {
+    const int pos = p.frame_off[b];
+    int val;
+    if (pos >= p.n_points) {
+      val = carry_s;
+    } else {
+      const int chunk = pos / V3D_SCAN_CHUNK;
+      int cnt = 0;
+      for (int i = chunk * V3D_SCAN_CHUNK + lane; i < pos; i += 64) cnt += vox_is_first(pt_slot, first, i, p.n_points);
+      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+      val = chunk_counts[chunk] + cnt;
+    }
+    if (lane == 0) frame_base[b] = val;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int b = 0; b < p.B; b++) {
+      out_base[b] = acc;
+      acc += min(frame_base[b + 1] - frame_base[b], p.max_voxels);
+    }
+    out_base[p.B] = acc;
+    *n_voxels = acc;
+  }
+}
+
+__global__ __launch_bounds__(V3D_BLOCK) void vox_emit_kernel(const float* __restrict__ pts, const VoxParams p,
+                                                             const int* __restrict__ pt_slot,
+                                                             const unsigned* __restrict__ first,
+                                                             const int* __restrict__ head, const int* __restrict__ next,
+                                                             const int* __restrict__ chunk_offsets,
+                                                             const int* __restrict__ frame_base,
+                                                             const int* __restrict__ out_base,
+                                                             float* __restrict__ voxels, int* __restrict__ coords,
+                                                             int* __restrict__ occupancy, float* __restrict__ mean) {
+  __shared__ int lds[4];
+  const int base = blockIdx.x * V3D_SCAN_CHUNK;
+  int running = chunk_offsets[blockIdx.x];
+  for (int r = 0; r < V3D_SCAN_CHUNK / V3D_BLOCK; r++) {
+    const int i = base + r * V3D_BLOCK + threadIdx.x;
+    const bool flag = vox_is_first(pt_slot, first, i, p.n_points);
+    int tot;
+    const int rank = running + v3d_block_rank(flag, tot, lds);
+    running += tot;
+    if (!flag) continue;
+    const int b = frame_of(p, i);
+    const int local = rank - frame_base[b];
+    if (local >= p.max_voxels) continue;  // `continue` variant of the max_voxels rule
+    const int v = out_base[b] + local;
+    // voxel coordinates from the first toucher itself
+    const float* q = pts + (size_t)i * p.C;
+    int c[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) c[j] = (int)floorf((q[j] - p.lo[j]) / p.vs[j]);
+    reinterpret_cast<int4*>(coords)[v] = make_int4(b, c[2], c[1], c[0]);
+    // the max_pts smallest point indices on this voxel's list, ascending (first-come order)
+    int best[VOX_MAX_PTS];
+#pragma unroll
+    for (int k = 0; k < VOX_MAX_PTS; k++) best[k] = 0x7FFFFFFF;
+    int cnt = 0;
+    for (int j = head[pt_slot[i]]; j >= 0; j = next[j]) {
+      cnt++;
+      int x = j;
+#pragma unroll
+      for (int k = 0; k < VOX_MAX_PTS; k++) {  // sorted insert by compare-exchange
+        const int lo_ = min(best[k], x);
+        x = max(best[k], x);
+        best[k] = lo_;
+      }
+    }
+    const int occ = min(cnt, p.max_pts);
+    occupancy[v] = occ;
+    for (int ch = 0; ch < p.C; ch++) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < VOX_MAX_PTS; k++) {
+        if (k < p.max_pts) {
+          const float val = k < occ ? pts[(size_t)best[k] * p.C + ch] : 0.f;
+          if (voxels) voxels[((size_t)v * p.max_pts + k) * p.C + ch] = val;
+          s += val;
+        }
+      }
+      if (mean) mean[(size_t)v * p.C + ch] = s / (float)occ;
+    }
+  }
+}
+
+extern "C" size_t v3d_voxelize_workspace(int n_points) {
+  const size_t n = (size_t)(n_points > 0 ? n_points : 1);
+  const size_t cap = v3d_hash_capacity((long long)n);
+  const size_t chunks = (n + V3D_SCAN_CHUNK - 1) / V3D_SCAN_CHUNK;
+  return v3d_align(cap * 8) + 2 * v3d_align(cap * 4) + 2 * v3d_align(n * 4) + v3d_align(chunks * 4) +
+         2 * v3d_align((VOX_MAX_FRAMES + 1) * 4) + 256;
+}
+
+extern "C" int v3d_voxelize(const float* points, int n_points, int C, const int32_t* frame_offsets_host, int B,
+                            const float* voxel_size_host, const float* bounds_host, int max_pts, int max_voxels,
+                            float* voxels, int32_t* coords, int32_t* occupancy, float* mean, int32_t* n_voxels,
+                            void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n_points < 0 || C < 3 || B < 1 || B > VOX_MAX_FRAMES || max_pts < 1 || max_pts > VOX_MAX_PTS || max_voxels < 1)
+    return V3D_EINVAL;
+  if (!frame_offsets_host || !voxel_size_host || !bounds_host || !coords || !occupancy || !n_voxels) return V3D_EINVAL;
+  if (frame_offsets_host[0] != 0 || frame_offsets_host[B] != n_points) return V3D_EINVAL;
+  if (n_points == 0) {
+    V3D_CHECK_HIP(hipMemsetAsync(n_voxels, 0, sizeof(int32_t), st));
+    return V3D_OK;
+  }
+  if (!points || !workspace) return V3D_EINVAL;
+  VoxParams p;
+  for (int j = 0; j < 3; j++) {
+    p.vs[j] = voxel_size_host[j];
+    p.lo[j] = bounds_host[j];
+    p.grid[j] = (int)lroundf((bounds_host[3 + j] - bounds_host[j]) / voxel_size_host[j]);
+    if (p.grid[j] < 1) return V3D_EINVAL;
+  }
+  p.max_pts = max_pts;
+  p.max_voxels = max_voxels;
+  p.C = C;
+  p.B = B;
+  p.n_points = n_points;
+  for (int b = 0; b <= B; b++) {
+    p.frame_off[b] = frame_offsets_host[b];
+    if (b > 0 && p.frame_off[b] < p.frame_off[b - 1]) return V3D_EINVAL;
+  }
+  const unsigned cap = v3d_hash_capacity(n_points);
+  const int chunks = v3d_ceil_div(n_points, V3D_SCAN_CHUNK);
+  V3dArena ar(workspace, workspace_bytes);
+  // keys | first | head are contiguous: ONE memset(0xFF) resets all three (EMPTY / UINT_MAX / -1)
+  v3d_key_t* keys = ar.take<v3d_key_t>(cap);
+  unsigned* first = ar.take<unsigned>(cap);
+  int* head = ar.take<int>(cap);
+  int* pt_slot = ar.take<int>(n_points);
+  int* next = ar.take<int>(n_points);
+  int* chunk_counts = ar.take<int>(chunks);
+  int* frame_base = ar.take<int>(VOX_MAX_FRAMES + 1);
+  int* out_base = ar.take<int>(VOX_MAX_FRAMES + 1);
+  if (!ar.ok()) return V3D_EWORKSPACE;
+  V3D_CHECK_HIP(hipMemsetAsync(keys, 0xFF, (size_t)((char*)head - (char*)keys) + (size_t)cap * 4, st));
+  V3dHash h{keys, cap - 1};
+  const int ins_blocks = min(v3d_ceil_div(n_points, V3D_BLOCK), 2048);
+  hipLaunchKernelGGL(vox_insert_kernel, dim3(ins_blocks), dim3(V3D_BLOCK), 0, st, points, p, h, first, head, pt_slot,
+                     next);
+  hipLaunchKernelGGL(vox_count_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, pt_slot, first, n_points, chunk_counts);
+  hipLaunchKernelGGL(vox_scan_kernel, dim3(1), dim3(1024), 0, st, chunk_counts, chunks, pt_slot, first, p, frame_base,
+                     out_base, n_voxels);
+  hipLaunchKernelGGL(vox_emit_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, points, p, pt_slot, first, head, next,
+                     chunk_counts, frame_base, out_base, voxels, coords, occupancy, mean);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}

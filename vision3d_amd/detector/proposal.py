@@ -1,0 +1,110 @@
+"""BEV proposal head and its loss (interface of vision3d/detector/proposal.py:10-141).
+
+ProposalLayer: 1x1 class/box heads -> (B, n_cls, n_yaw, ny, nx[, 7]); inference = sigmoid, top-k per
+(frame, class), VoxelNet decode, multi-class rotated NMS (IoU 0.01) and per-class score threshold.
+Index bookkeeping tensors are created on the scores' device (the reference mixes CPU and GPU tensors,
+legal only in torch 1.4 -- SURVEY.md H9).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..core.box_encode import decode
+from ..ops import batched_nms_rotated, sigmoid_focal_loss
+
+
+class ProposalLayer(nn.Module):
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        n_anchor = cfg.NUM_CLASSES * cfg.NUM_YAW
+        self.conv_cls = nn.Conv2d(cfg.PROPOSAL.C_IN, n_anchor, 1)
+        self.conv_reg = nn.Conv2d(cfg.PROPOSAL.C_IN, n_anchor * cfg.BOX_DOF, 1)
+        self.TOPK, self.DOF = cfg.PROPOSAL.TOPK, cfg.BOX_DOF
+        self._init_weights()
+
+    def _init_weights(self):
+        # focal-prior bias exactly as the reference writes it: +1.005 (proposal.py:27)
+        nn.init.constant_(self.conv_cls.bias, (-math.log(1 - .01) / .01))
+        nn.init.constant_(self.conv_reg.bias, 0)
+        nn.init.normal_(self.conv_cls.weight, std=0.01)
+        nn.init.normal_(self.conv_reg.weight, std=0.01)
+
+    def _generate_group_idx(self, B, n_cls, device=None):
+        """(batch_idx, class_idx, group_idx), each (B * n_cls * TOPK,), group = class + n_cls * batch."""
+        b = torch.arange(B, device=device).view(B, 1, 1).expand(B, n_cls, self.TOPK)
+        c = torch.arange(n_cls, device=device).view(1, n_cls, 1).expand(B, n_cls, self.TOPK)
+        return b.reshape(-1), c.reshape(-1), (c + n_cls * b).reshape(-1)
+
+    def _above_score_thresh(self, scores, class_idx):
+        thresh = scores.new_tensor([a["score_thresh"] for a in self.cfg.ANCHORS])
+        return scores > thresh[class_idx]
+
+    def _multiclass_batch_nms(self, boxes, scores):
+        B, n_cls = scores.shape[:2]
+        scores = scores.reshape(-1)
+        boxes = boxes.reshape(-1, self.DOF)
+        bev = boxes[:, [0, 1, 3, 4, 6]].contiguous()
+        batch_idx, class_idx, group_idx = self._generate_group_idx(B, n_cls, scores.device)
+        keep = batched_nms_rotated(bev, scores, group_idx, iou_threshold=0.01)
+        boxes, batch_idx, class_idx, scores = (x[keep] for x in (boxes, batch_idx, class_idx, scores))
+        mask = self._above_score_thresh(scores, class_idx)
+        return [x[mask] for x in (boxes, batch_idx, class_idx, scores)]
+
+    def _decode(self, reg_map, anchors, anchor_idx):
+        B, n_cls = reg_map.shape[:2]
+        gidx = anchor_idx[..., None].expand(-1, -1, -1, self.DOF)
+        deltas = reg_map.reshape(B, n_cls, -1, self.DOF).gather(2, gidx)
+        anc = anchors.reshape(1, n_cls, -1, self.DOF).expand(B, -1, -1, -1).gather(2, gidx)
+        return decode(deltas, anc)
+
+    def inference(self, feature_map, anchors):
+        """-> (boxes (K,7), batch_idx (K,), class_idx (K,), scores (K,)), by decreasing score."""
+        cls_map, reg_map = self(feature_map)
+        score_map = cls_map.sigmoid_()
+        B, n_cls = score_map.shape[:2]
+        scores, anchor_idx = score_map.view(B, n_cls, -1).topk(self.TOPK, -1)
+        boxes = self._decode(reg_map, anchors, anchor_idx)
+        return self._multiclass_batch_nms(boxes, scores)
+
+    def reshape_cls(self, cls_map):
+        B, _, ny, nx = cls_map.shape
+        return cls_map.view(B, self.cfg.NUM_CLASSES, self.cfg.NUM_YAW, ny, nx)
+
+    def reshape_reg(self, reg_map):
+        B, _, ny, nx = reg_map.shape
+        return reg_map.view(B, self.cfg.NUM_CLASSES, self.cfg.BOX_DOF, -1, ny, nx).permute(0, 1, 3, 4, 5, 2)
+
+    def forward(self, feature_map):
+        return self.reshape_cls(self.conv_cls(feature_map)), self.reshape_reg(self.conv_reg(feature_map))
+
+
+class ProposalLoss(nn.Module):
+    """Focal classification + smooth-L1 box loss, both divided by max(#positives, 1)
+    (proposal.py:100-141).  (P, G, M) = (predicted, ground truth, mask)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+
+    @staticmethod
+    def masked_sum(loss, mask):
+        return (loss * mask.type_as(loss)).sum()
+
+    def reg_loss(self, P_reg, G_reg, M_reg):
+        per = F.smooth_l1_loss(P_reg, G_reg, reduction="none")
+        total = per[..., 0:3] + per[..., 3:6] + per[..., 6:7] / math.pi
+        return self.masked_sum(total, M_reg)
+
+    def cls_loss(self, P_cls, G_cls, M_cls):
+        return self.masked_sum(sigmoid_focal_loss(P_cls, G_cls.float(), reduction="none"), M_cls)
+
+    def forward(self, item):
+        G_cls, M_cls, P_cls, G_reg, M_reg, P_reg = (item[k] for k in ("G_cls", "M_cls", "P_cls", "G_reg", "M_reg", "P_reg"))
+        normalizer = M_reg.type_as(P_reg).sum().clamp_(min=1)
+        cls_loss = self.cls_loss(P_cls, G_cls, M_cls) / normalizer
+        reg_loss = self.reg_loss(P_reg, G_reg, M_reg) / normalizer
+        return dict(cls_loss=cls_loss, reg_loss=reg_loss, loss=cls_loss + self.cfg.TRAIN.LAMBDA * reg_loss)

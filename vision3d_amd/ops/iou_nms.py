@@ -1,0 +1,83 @@
+"""Rotated BEV IoU / NMS -- the `vision3d.ops` names (vision3d/ops/iou_nms.py:9,38-134) on MI355X.
+
+Boxes are (x_ctr, y_ctr, width, height, angle_degrees) float32.  The detector feeds yaw in radians to
+these degree-based ops; that behaviour is part of the reference and is preserved.
+All arithmetic runs in libvision3d_hip.so (csrc/iou_nms.hip); there is no CPU path.
+"""
+import torch
+
+from .. import _lib as L
+
+
+def box_iou_rotated(boxes1, boxes2):
+    """IoU matrix (M, N) float32.  Mirrors `vision3d._C.box_iou_rotated` (csrc/vision.cpp:63): float32
+    only (box_iou_rotated_cuda.cu:68), inputs row-major contiguous."""
+    L.require_gpu("box_iou_rotated", boxes1, boxes2)
+    b1, b2 = L.as_f32("box_iou_rotated", boxes1), L.as_f32("box_iou_rotated", boxes2)
+    if b1.dim() != 2 or b2.dim() != 2 or b1.shape[-1] != 5 or b2.shape[-1] != 5:
+        raise RuntimeError("box_iou_rotated: expected (M,5) and (N,5)")
+    m, n = b1.shape[0], b2.shape[0]
+    out = torch.empty((m, n), dtype=torch.float32, device=b1.device)
+    with torch.cuda.device(b1.device):
+        L.check(L.lib().v3d_box_iou_rotated(L.ptr(b1), m, L.ptr(b2), n, L.ptr(out), L.stream_ptr()), "box_iou_rotated")
+    return out
+
+
+def box_iou_rotated_3d(boxes1, boxes2):
+    raise NotImplementedError  # vision3d/ops/iou_nms.py:12-13
+
+
+def nms_rotated_padded(boxes, scores, iou_threshold):
+    """Device-resident result: (keep (N,) int64 padded, n_keep (1,) int32) -- no host synchronisation."""
+    L.require_gpu("nms_rotated", boxes, scores)
+    b, s = L.as_f32("nms_rotated", boxes), L.as_f32("nms_rotated", scores)
+    if b.dim() != 2 or b.shape[-1] != 5 or s.shape != (b.shape[0],):
+        raise RuntimeError("nms_rotated: expected boxes (N,5) and scores (N,)")
+    n = b.shape[0]
+    keep = torch.empty((n,), dtype=torch.int64, device=b.device)
+    n_keep = torch.zeros((1,), dtype=torch.int32, device=b.device)
+    if n:
+        lib = L.lib()
+        ws = L.workspace(lib.v3d_nms_rotated_workspace(n), b.device)
+        with torch.cuda.device(b.device):
+            L.check(lib.v3d_nms_rotated(L.ptr(b), L.ptr(s), n, float(iou_threshold), L.ptr(keep), L.ptr(n_keep),
+                                        L.ptr(ws), ws.numel(), L.stream_ptr()), "nms_rotated")
+    return keep, n_keep
+
+
+def nms_rotated(boxes, scores, iou_threshold):
+    """Indices kept by greedy rotated NMS, by decreasing score (vision3d/ops/iou_nms.py:38-85).
+    Suppression rule of the reference CPU path: IoU >= threshold (nms_rotated_cpu.cpp:53)."""
+    keep, n_keep = nms_rotated_padded(boxes, scores, iou_threshold)
+    return keep[: int(n_keep.item())]
+
+
+def batched_nms_rotated(boxes, scores, idxs, iou_threshold):
+    """Per-category NMS through the coordinate-offset trick (vision3d/ops/iou_nms.py:90-134): every
+    category is shifted by idx * (max_coord - min_coord + 1) so categories never overlap."""
+    assert boxes.shape[-1] == 5
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    hi = (torch.max(boxes[:, 0], boxes[:, 1]) + torch.max(boxes[:, 2], boxes[:, 3]) / 2).max()
+    lo = (torch.min(boxes[:, 0], boxes[:, 1]) - torch.min(boxes[:, 2], boxes[:, 3]) / 2).min()
+    shifted = boxes.clone()
+    shifted[:, :2] += (idxs.to(boxes) * (hi - lo + 1))[:, None]
+    return nms_rotated(shifted, scores, iou_threshold)
+
+
+def nms(boxes, scores, iou_threshold):
+    """Axis-aligned NMS on (x1,y1,x2,y2) (the torchvision name re-exported at iou_nms.py:6; never called
+    by the detector).  Served by the rotated kernel with angle 0."""
+    xy = (boxes[:, :2] + boxes[:, 2:4]) / 2
+    wh = boxes[:, 2:4] - boxes[:, :2]
+    rot = torch.cat((xy, wh, torch.zeros_like(xy[:, :1])), dim=1)
+    return nms_rotated(rot, scores, iou_threshold)
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    """Axis-aligned per-category NMS (iou_nms.py:16-33)."""
+    assert boxes.shape[-1] == 4
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    offsets = idxs.to(boxes) * (boxes.max() + 1)
+    return nms(boxes + offsets[:, None], scores, iou_threshold)

@@ -1,0 +1,49 @@
+"""SparseSequential (spconv.SparseSequential): children named "0", "1", ...; sparse modules consume
+the SparseConvTensor, plain nn.Modules are applied to `.features` (detector/sparse_cnn.py:15-30).
+
+In eval mode the pattern [sparse conv, BatchNorm1d, ReLU] is executed as ONE kernel launch: the
+batch-norm is folded to a per-channel scale/shift in the conv epilogue together with the ReLU.
+"""
+import torch
+from torch import nn
+
+from .conv import _SparseConvBase
+from .tensor import SparseConvTensor
+
+
+def fold_batchnorm(bn):
+    """BatchNorm (eval) -> (scale, shift) with y = x * scale + shift."""
+    inv = torch.rsqrt(bn.running_var + bn.eps)
+    gamma = bn.weight if bn.weight is not None else torch.ones_like(inv)
+    beta = bn.bias if bn.bias is not None else torch.zeros_like(inv)
+    scale = (gamma * inv).detach()
+    shift = (beta - bn.running_mean * gamma * inv).detach()
+    return scale.contiguous(), shift.contiguous()
+
+
+class SparseSequential(nn.Sequential):
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, _SparseConvBase):
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                nxt2 = mods[i + 2] if i + 2 < len(mods) else None
+                if (isinstance(nxt, nn.BatchNorm1d) and not nxt.training and nxt.track_running_stats):
+                    scale, shift = fold_batchnorm(nxt)
+                    relu = isinstance(nxt2, nn.ReLU)
+                    x = m(x, scale, shift, relu)
+                    i += 3 if relu else 2
+                    continue
+                x = m(x)
+            elif isinstance(m, SparseSequential):
+                x = m(x)
+            elif isinstance(x, SparseConvTensor):
+                if x.features.shape[0] > 0:
+                    x = x.replace_feature(m(x.features))
+            else:
+                x = m(x)
+            i += 1
+        return x
