@@ -1,0 +1,190 @@
+"""bench.py -- frames/sec of the SECOND forward on synthetic 16k-point KITTI-range clouds (BASELINE.json).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch (bs=1/GPU, configs[1]): device voxelizer + VFE ->
+14-layer sparse 3-D conv backbone -> .dense() BEV -> dense RPN -> proposal head (top-k, decode, rotated
+NMS).  The cloud is resident in HBM before the timed region.  Frames are independent, so N GPUs run N
+replicas on different frames with no data-path collective (weak scaling); the only communication is the
+timing barrier / max-reduce.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      the dominant kernel (spconv_fwd_mfma<64,64>, 8 launches/frame): algorithmic bytes
+                A_min = 4*(N_in*Cin + N_out*Cout + K*Cin*Cout) + 8*R per launch divided
+                by its average duration measured with HIP events on the launch stream, vs 8 TB/s.
+  cpu_baseline  oracle/ (scalar C sparse path + torch CPU dense path, 1 thread) timed on the host on a
+                bounded sample of the same workload -- N=1, rank 0 only.  Baseline only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (configs[1] = 1)")
+    ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    return ap.parse_args()
+
+
+def layer_algorithmic_bytes(stats):
+    """A_min of one sparse layer, fp32."""
+    return 4 * (stats["n_in"] * stats["cin"] + stats["n_out"] * stats["cout"] + stats["K"] * stats["cin"] * stats["cout"]) \
+        + 8 * stats["pairs"]
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (vision3d_amd has no CPU path)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")  # RCCL; used for the barrier and the max-reduce only
+
+    from vision3d_amd import synth
+    from vision3d_amd.core import AnchorGenerator, Preprocessor
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.detector import Second
+    from vision3d_amd.spconv.conv import _SparseConvBase
+
+    cfg = second_car_cfg()
+    torch.manual_seed(0)
+    model = Second(cfg).cuda().eval()
+    pre = Preprocessor(cfg, seed=0)
+    anchors = AnchorGenerator(cfg).anchors.cuda()
+    # frame-parallel sharding: rank r owns frames r*B .. r*B+B-1 of the synthetic stream
+    clouds_np = [synth.make_cloud(rank * args.batch + i, args.points) for i in range(args.batch)]
+    clouds = [torch.from_numpy(c).cuda() for c in clouds_np]
+
+    def step():
+        with torch.no_grad():
+            item = pre(dict(points=clouds, anchors=anchors))
+            return model.inference(item)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames = world * args.steps * args.batch
+    value = frames / elapsed
+
+    # ---- per-kernel timing of the sparse backbone with HIP events on the launch stream (rank 0)
+    roofline, stages = None, None
+    if rank == 0:
+        conv_mods = [m for m in model.cnn.modules() if isinstance(m, _SparseConvBase)]
+        rec = {id(m): [] for m in conv_mods}
+        info = {}
+        import vision3d_amd.spconv.conv as convmod
+        orig = convmod.sparse_conv_forward
+
+        def timed(features, weight, rb, scale=None, shift=None, relu=False, algo=0):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(features, weight, rb, scale, shift, relu, algo)
+            e1.record()
+            cin, cout = weight.shape[-2], weight.shape[-1]
+            key = len(timed.calls) % len(conv_mods)
+            timed.calls.append((key, e0, e1))
+            info[key] = dict(cin=cin, cout=cout, K=rb.nbr.shape[0], n_in=features.shape[0], n_out=rb.n, nbr=rb.nbr, cap=rb.cap)
+            return r
+        timed.calls = []
+        convmod.sparse_conv_forward = timed
+        reps = max(5, min(args.steps, 20))
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        convmod.sparse_conv_forward = orig
+        per_layer = {}
+        for key, e0, e1 in timed.calls:
+            per_layer.setdefault(key, []).append(e0.elapsed_time(e1) * 1e-3)
+        layers = []
+        for key in sorted(per_layer):
+            st = dict(info[key])
+            nbr = st.pop("nbr")
+            st["pairs"] = int((nbr[:, :st["n_out"]] >= 0).sum().item())
+            st.pop("cap")
+            st["t_avg_us"] = 1e6 * float(np.mean(per_layer[key]))
+            st["bytes"] = layer_algorithmic_bytes(st)
+            st["gbs"] = st["bytes"] / (st["t_avg_us"] * 1e-6) / 1e9
+            layers.append(st)
+        dom = [l for l in layers if l["cin"] == 64 and l["cout"] == 64]
+        dom_bytes = float(np.mean([l["bytes"] for l in dom]))
+        dom_t = float(np.mean([l["t_avg_us"] for l in dom])) * 1e-6
+        achieved = dom_bytes / dom_t / 1e9
+        roofline = dict(bound="hbm", kernel="spconv_fwd_mfma<64,64>", launches_per_frame=len(dom) // max(1, 1),
+                        bytes_per_launch=dom_bytes, avg_us=dom_t * 1e6, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=None)
+        tot_bytes = sum(l["bytes"] for l in layers)
+        tot_t = sum(l["t_avg_us"] for l in layers) * 1e-6
+        stages = dict(sparse_conv_launches=len(layers), sparse_conv_us=tot_t * 1e6, sparse_conv_algorithmic_MB=tot_bytes / 1e6,
+                      sparse_conv_gbs=tot_bytes / tot_t / 1e9,
+                      layers=[{k: (round(v, 2) if isinstance(v, float) else v) for k, v in l.items()} for l in layers])
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import second_cpu
+        torch.set_num_threads(1)
+        sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        n_frames, t_cpu = 0, 0.0
+        while n_frames < args.cpu_frames and t_cpu < 30.0:
+            cloud = synth.make_cloud(100 + n_frames, args.points)
+            c0 = time.perf_counter()
+            ref = second_cpu.second_forward(sd, [cloud], cfg.VOXEL_SIZE, cfg.GRID_BOUNDS, cfg.MAX_OCCUPANCY, cfg.MAX_VOXELS)
+            second_cpu.proposals(ref["cls"], ref["reg"], anchors.cpu().numpy(), 1, 2, 7, cfg.PROPOSAL.TOPK,
+                                 [a["score_thresh"] for a in cfg.ANCHORS])
+            t_cpu += time.perf_counter() - c0
+            n_frames += 1
+        cpu_baseline = dict(value=n_frames / t_cpu, unit="frames/s", cores=1, kind="port",
+                            sample=f"{n_frames} frame(s) of the same 16k-pt workload, oracle/ (scalar C sparse path + torch CPU "
+                                   f"dense path, 1 thread), {t_cpu:.1f} s")
+
+    if rank == 0:
+        line = dict(metric="frames/sec SECOND fwd, 16k-pt KITTI cloud", value=value, unit="frames/s", n_gpus=world,
+                    steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
+                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                    config=dict(workload="SECOND (VoxelNet spconv backbone + BEV head) forward, bs=1, 16384-pt synthetic "
+                                         "KITTI-range cloud per GPU (BASELINE configs[1])",
+                                frames_per_gpu_per_step=args.batch, points_per_frame=args.points,
+                                parallelism=f"frame-parallel replicas x{world}", path="eager python -> C ABI"),
+                    roofline=roofline, cpu_baseline=cpu_baseline, stages=stages,
+                    n_proposals=int(out[0].shape[0]))
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,42 @@
+"""Helpers shared by the -m gpu parity tests."""
+import numpy as np
+import torch
+
+FEATURE_RTOL = 1e-4  # BASELINE.json north_star: "within 1e-4 rel for float features"
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def assert_features_close(got, ref, what=""):
+    """|got - ref| <= 1e-4 * |ref| + 1e-4 * rms(ref) elementwise, and max-norm error <= 1e-4 of max|ref|.
+    (fp32 sums in a different association order; the absolute floor is tied to the tensor's own scale.)"""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    if ref.size == 0:
+        return
+    scale = max(np.sqrt((ref ** 2).mean()), 1e-30)
+    err = np.abs(got - ref)
+    bad = err > FEATURE_RTOL * np.abs(ref) + FEATURE_RTOL * scale
+    assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} elements off, max err {err.max():.3e}, scale {scale:.3e}"
+    assert err.max() <= FEATURE_RTOL * max(np.abs(ref).max(), 1e-30) * 1.0 + 1e-30 or err.max() <= FEATURE_RTOL * scale, what
+
+
+def randomize_bn(model, seed=0):
+    """Non-trivial eval-mode BatchNorm statistics so the fused scale/shift epilogues are exercised."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 0.5 + 0.75)
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.5 + 0.75)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+
+
+def numpy_state_dict(model):
+    return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}

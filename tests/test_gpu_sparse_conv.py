@@ -1,0 +1,121 @@
+"""GPU parity: hash rulebooks (bit-exact vs oracle/) and sparse convolution forward (both kernels, every
+SECOND layer shape) within 1e-4 relative of oracle/, plus .dense() exact."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import assert_features_close, dev
+from vision3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def kitti_coords(oracle, seeds):
+    from oracle import second_cpu
+    clouds = [synth.make_cloud(s) for s in seeds]
+    _, coords, _ = second_cpu.voxelize_batch(clouds, [0.05, 0.05, 0.1], synth.KITTI_BOUNDS, 5, 20000)
+    return coords
+
+
+def make_tensor(coords, feats, shape, b):
+    from vision3d_amd.spconv import SparseConvTensor
+    return SparseConvTensor(dev(feats, torch.float32), dev(coords, torch.int32), shape, b)
+
+
+def test_rulebooks_bit_exact_through_the_backbone(oracle):
+    """subm + strided rulebooks for all four stage transitions of SpMiddleFHD, batch of 2."""
+    from vision3d_amd.spconv.conv import build_sparse_rulebook, build_subm_rulebook
+    coords = kitti_coords(oracle, [0, 1])
+    shape = [41, 1600, 1408]
+    specs = [([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [0, 1, 1]),
+             ([3, 1, 1], [2, 1, 1], [0, 0, 0])]
+    for ks, st, pd in specs:
+        x = make_tensor(coords, np.zeros((len(coords), 1), np.float32), shape, 2)
+        rb = build_subm_rulebook(x, [3, 3, 3])
+        np.testing.assert_array_equal(rb.nbr.cpu().numpy().T, oracle.subm_rulebook(coords, shape, 3))
+        rs = build_sparse_rulebook(x, ks, st, pd)
+        oc, onbr, oshape = oracle.sparse_rulebook(coords, shape, ks, st, pd)
+        assert rs.n == len(oc) and rs.out_shape == oshape
+        np.testing.assert_array_equal(rs.out_indices.cpu().numpy(), oc)
+        np.testing.assert_array_equal(rs.nbr[:, :rs.n].cpu().numpy().T, onbr)
+        coords, shape = oc, oshape
+    assert shape == [2, 200, 176]
+
+
+@pytest.mark.parametrize("cin,cout", [(4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64)])
+@pytest.mark.parametrize("algo", [1, 2])
+def test_subm_conv_forward(oracle, cin, cout, algo):
+    from vision3d_amd.spconv.conv import build_subm_rulebook, sparse_conv_forward
+    rng = np.random.default_rng(cin * 100 + cout)
+    coords = kitti_coords(oracle, [2])[:6000]
+    feats = rng.standard_normal((len(coords), cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(cin * 9)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32) * 0.1
+    x = make_tensor(coords, feats, [41, 1600, 1408], 1)
+    rb = build_subm_rulebook(x, [3, 3, 3])
+    nbr = oracle.subm_rulebook(coords, [41, 1600, 1408], 3)
+    got = sparse_conv_forward(x.features, dev(w), rb, dev(sc), dev(sh), True, algo).cpu().numpy()
+    assert_features_close(got, oracle.sparse_conv_fwd(feats, w, nbr, sc, sh, True), f"subm {cin}->{cout} algo {algo} fused")
+    got = sparse_conv_forward(x.features, dev(w), rb, None, None, False, algo).cpu().numpy()
+    assert_features_close(got, oracle.sparse_conv_fwd(feats, w, nbr), f"subm {cin}->{cout} algo {algo} plain")
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_strided_conv_forward_ragged_tail(oracle, algo):
+    """Strided layers incl. the (3,1,1) one; row counts not multiples of the 64-row tile; batch 2."""
+    from vision3d_amd.spconv.conv import build_sparse_rulebook, sparse_conv_forward
+    rng = np.random.default_rng(9)
+    coords = kitti_coords(oracle, [3, 4])[:7001]
+    shape = [41, 1600, 1408]
+    for (cin, cout, ks, st, pd) in [(16, 32, [3, 3, 3], [2, 2, 2], [1, 1, 1]), (64, 64, [3, 1, 1], [2, 1, 1], [0, 0, 0])]:
+        feats = rng.standard_normal((len(coords), cin)).astype(np.float32)
+        w = (rng.standard_normal((*ks, cin, cout)) / np.sqrt(cin * 3)).astype(np.float32)
+        x = make_tensor(coords, feats, shape, 2)
+        rb = build_sparse_rulebook(x, ks, st, pd)
+        oc, onbr, _ = oracle.sparse_rulebook(coords, shape, ks, st, pd)
+        got = sparse_conv_forward(x.features, dev(w), rb, None, None, True, algo).cpu().numpy()
+        assert_features_close(got, oracle.sparse_conv_fwd(feats, w, onbr, relu=True), f"strided {cin}->{cout} algo {algo}")
+
+
+def test_tiny_and_empty_inputs(oracle):
+    from vision3d_amd import spconv
+    conv = spconv.SubMConv3d(4, 16, 3, indice_key="k", bias=False).cuda()
+    for n in (0, 1, 63, 65):
+        coords = np.stack([np.zeros(n), np.arange(n) % 7, np.arange(n), np.arange(n) * 2], 1).astype(np.int32)
+        feats = np.random.default_rng(n).standard_normal((n, 4)).astype(np.float32)
+        out = conv(make_tensor(coords, feats, [8, 80, 160], 1))
+        assert out.features.shape == (n, 16)
+        if n:
+            ref = oracle.sparse_conv_fwd(feats, conv.weight.detach().cpu().numpy(), oracle.subm_rulebook(coords, [8, 80, 160], 3))
+            assert_features_close(out.features.cpu().numpy(), ref, f"tiny n={n}")
+    assert out.dense().shape == (1, 16, 8, 80, 160)
+
+
+def test_densify_exact(oracle):
+    rng = np.random.default_rng(3)
+    coords = kitti_coords(oracle, [5, 6])
+    oc, _, osh = oracle.sparse_rulebook(coords, [41, 1600, 1408], 3, 2, 1)
+    oc2, _, osh2 = oracle.sparse_rulebook(oc, osh, 3, 2, 1)
+    oc3, _, osh3 = oracle.sparse_rulebook(oc2, osh2, 3, 2, [0, 1, 1])
+    feats = rng.standard_normal((len(oc3), 64)).astype(np.float32)
+    got = make_tensor(oc3, feats, osh3, 2).dense().cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.densify(feats, oc3, 2, osh3))
+
+
+def test_sparse_sequential_fuses_and_matches_unfused(oracle):
+    """conv+BN(eval)+ReLU through SparseSequential (one launch) == conv, then torch BN, then ReLU."""
+    from gpu_util import randomize_bn
+    from vision3d_amd.detector.sparse_cnn import make_sparse_conv_layer, make_subm_layer
+    torch.manual_seed(0)
+    coords = kitti_coords(oracle, [7])[:5000]
+    feats = np.random.default_rng(1).standard_normal((len(coords), 16)).astype(np.float32)
+    for layer in (make_subm_layer(16, 32, 3, indice_key="a"), make_sparse_conv_layer(16, 32, 3, 2, padding=1)):
+        layer = layer.cuda().eval()
+        randomize_bn(layer)
+        x = make_tensor(coords, feats, [41, 1600, 1408], 1)
+        fused = layer(x)
+        raw = layer[0](x)
+        with torch.no_grad():
+            ref = torch.relu(layer[1](raw.features))
+        assert_features_close(fused.features.cpu().numpy(), ref.cpu().numpy(), "fused vs unfused")
+        np.testing.assert_array_equal(fused.indices.cpu().numpy(), raw.indices.cpu().numpy())

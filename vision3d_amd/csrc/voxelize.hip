@@ -177,7 +177,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void vox_emit_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < VOX_MAX_PTS; k++) best[k] = 0x7FFFFFFF;
     int cnt = 0;
-    for (int j = head[pt_slot[i]]; j >= 0; j = next[j]) {
+    for (int j = head[pt_slot[i]], guard = 0; j >= 0 && guard < p.n_points; j = next[j], guard++) {
       cnt++;
       int x = j;
 #pragma unroll

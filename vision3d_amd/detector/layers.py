@@ -21,8 +21,9 @@ class BEVFeatureGatherer(nn.Module):
     def __init__(self, cfg, voxel_offset, base_voxel_size):
         super().__init__()
         self.cfg = cfg
-        self.pixel_offset = voxel_offset[:2]
-        self.base_pixel_size = base_voxel_size[:2]
+        # own buffers (not views of the CNN's): they must follow .cuda()/.to() with the module
+        self.register_buffer("pixel_offset", voxel_offset[:2].detach().clone(), persistent=False)
+        self.register_buffer("base_pixel_size", base_voxel_size[:2].detach().clone(), persistent=False)
 
     def normalize_indices(self, indices, H, W):
         dims = indices.new_tensor([W - 1, H - 1])
