@@ -99,7 +99,8 @@ int v3d_rulebook_sparse(const int32_t* coords_in, const int32_t* n_in, int cap_i
  * (BatchNorm1d in eval mode folded to scale/shift, sparse_cnn.py:18,27) and ReLU.
  * in (>=n_in,Cin) f32, weight (K,Cin,Cout) f32 [= spconv's (k0,k1,k2,Cin,Cout)], out (cap_out,Cout).
  * out[o,:] = act( (sum_k in[nbr[k,o],:] @ weight[k]) * scale + shift ).  Deterministic (no atomics).
- * algo: 0 = auto, 1 = scalar reference kernel, 2 = LDS-staged MFMA kernel (needs Cin%4==0, Cout%16==0). */
+ * algo: 0 = auto, 1 = scalar reference kernel, 2 = LDS-staged MFMA kernel, 3 = wave-autonomous MFMA kernel
+ * (2 and 3 need Cin%4==0, Cout%16==0 and a compiled (Cin,Cout) instance). */
 int v3d_sparse_conv_fwd(const float* in, const float* weight, const int32_t* nbr, const int32_t* n_out, int cap_out,
                         int K, int Cin, int Cout, const float* scale, const float* shift, int relu, float* out,
                         int algo, v3d_stream_t stream);

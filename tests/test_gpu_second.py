@@ -55,7 +55,8 @@ def test_second_forward_matches_cpu_restatement(seeds):
     item2 = {k: v for k, v in item.items() if k != "voxel_mean"}
     with torch.no_grad():
         f2 = model.vfe(item2["features"], item2["occupancy"])
-    np.testing.assert_array_equal(f2.cpu().numpy(), item["voxel_mean"].cpu().numpy())
+    # torch's own reduction may associate the 5-slot sum differently: 1 ulp, not exact
+    np.testing.assert_allclose(f2.cpu().numpy(), item["voxel_mean"].cpu().numpy(), rtol=1e-6, atol=1e-7)
 
 
 def test_proposal_layer_inference_matches_reference_golden(golden_core):
@@ -90,6 +91,11 @@ def test_second_inference_end_to_end():
     anchors = AnchorGenerator(cfg).anchors
     item = Preprocessor(cfg)(dict(points=[synth.make_cloud(4), synth.make_cloud(5)], anchors=anchors.cuda()))
     with torch.no_grad():
+        # rescale the class head so logits have unit spread: saturated sigmoids (exact fp32 ties among
+        # the top-k) would make the CPU/GPU top-k order, hence the NMS outcome, ambiguous
+        logits = model.head.conv_cls(model.feature_extract(item))
+        model.head.conv_cls.weight.mul_(1.0 / logits.std())
+        model.head.conv_cls.bias.zero_()
         boxes, bidx, cidx, scores = model.inference(item)
         cls_map, reg_map = model.head(model.feature_extract(item))
     cls = cls_map.reshape(2, 2, 200, 176).cpu().numpy()
@@ -103,6 +109,7 @@ def test_second_inference_end_to_end():
         np.testing.assert_allclose(scores.cpu().numpy(), rs, rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(boxes.cpu().numpy(), rb, rtol=1e-4, atol=1e-4)
     else:  # a sigmoid-ulp tie flipped a top-k boundary: the two detection sets must still nearly coincide
+        print("GPU scores", scores.cpu().numpy()[:12], "CPU scores", rs[:12])
         assert abs(len(rb) - len(boxes)) <= 2, (len(rb), len(boxes))
 
 

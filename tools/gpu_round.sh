@@ -15,7 +15,7 @@ tail -c 6000 gpurun_out/bench.json | tee -a gpurun_out/summary.txt; tail -5 gpur
 if [ "${DO_PROF:-1}" = "1" ]; then
   echo "== rocprofv3 kernel stats" | tee -a gpurun_out/summary.txt
   export TMPDIR=/tmp
-  timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/prof_bench.json 2> gpurun_out/prof.err; echo "rocprof rc=$?" | tee -a gpurun_out/summary.txt
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/prof_bench.json 2> gpurun_out/prof.err; echo "rocprof rc=$?" | tee -a gpurun_out/summary.txt
   find gpurun_out/prof -name "*kernel_stats*" | head -3 | tee -a gpurun_out/summary.txt
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "$f" | tee -a gpurun_out/summary.txt
   # keep the trace small: drop the raw per-dispatch csv if huge

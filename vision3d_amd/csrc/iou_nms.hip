@@ -114,28 +114,23 @@ __global__ void nms_gather_kernel(const unsigned long long* __restrict__ keys, c
 }
 
 // NMS step 3: suppression bitmask.  mask[i*nwords + cb] bit c  <=>  IoU(sorted i, sorted cb*64+c) >= thr
-// and cb*64+c > i.  Block = 4 waves; blockIdx.x = column block, blockIdx.y = group of 64 rows; each
-// wave walks its share of the 64 rows, lane = column, word = ballot.
-__global__ __launch_bounds__(V3D_BLOCK) void nms_mask_kernel(const BoxPrep* __restrict__ prep, int N, int nwords,
-                                                             float thr, unsigned long long* __restrict__ mask) {
-  const int cb = blockIdx.x, rg = blockIdx.y;
-  if (rg > cb) return;  // strictly lower block-triangle is never read
-  __shared__ BoxPrep rows[64];
-  const int row0 = rg * 64;
-  if (threadIdx.x < 64 && row0 + (int)threadIdx.x < N) rows[threadIdx.x] = prep[row0 + threadIdx.x];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// and cb*64+c > i.  One wave per (row, column block): lane = column, the 64-bit word IS the ballot.
+// Every pair is evaluated by its own lane, so the latency of the inference shape (N = 100) is one IoU
+// evaluation, not a 16- or 64-step loop (reference: nms_rotated_cuda.cu:53-65).
+__global__ __launch_bounds__(V3D_WAVE) void nms_mask_kernel(const BoxPrep* __restrict__ prep, int N, int nwords,
+                                                            float thr, unsigned long long* __restrict__ mask) {
+  const int cb = blockIdx.x, row = blockIdx.y;
+  if (cb < (row >> 6)) return;  // words left of the diagonal block are never read
+  const int lane = threadIdx.x;
   const int col = cb * 64 + lane;
-  BoxPrep bc;
-  if (col < N) bc = prep[col];
-  const int nrows = min(64, N - row0);
-  for (int r = w; r < nrows; r += V3D_BLOCK / V3D_WAVE) {
-    const int row = row0 + r;
-    bool hit = false;
-    if (col < N && col > row) hit = v3d::iou_prepped(rows[r], bc) >= thr;
-    const unsigned long long word = __ballot(hit);
-    if (lane == 0) mask[(size_t)row * nwords + cb] = word;
+  bool hit = false;
+  if (col < N && col > row) {
+    const BoxPrep br = prep[row];  // same address in every lane: one broadcast load
+    const BoxPrep bc = prep[col];
+    hit = v3d::iou_prepped(br, bc) >= thr;
   }
+  const unsigned long long word = __ballot(hit);
+  if (lane == 0) mask[(size_t)row * nwords + cb] = word;
 }
 
 // NMS step 4: greedy reduction on the device.
@@ -228,8 +223,8 @@ extern "C" int v3d_nms_rotated(const float* boxes, const float* scores, int N, f
         hipLaunchKernelGGL(bitonic_global_step_kernel, dim3(v3d_ceil_div(npad, 256)), dim3(256), 0, st, keys, npad, j, k);
   }
   hipLaunchKernelGGL(nms_gather_kernel, dim3(v3d_ceil_div(N, 256)), dim3(256), 0, st, keys, boxes, N, order, prep);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords), dim3(V3D_BLOCK), 0, st, prep, N, nwords, iou_threshold,
-                     mask);
+  if (N > 65535) return V3D_EUNSUPPORTED;  // grid.y limit
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, N), dim3(V3D_WAVE), 0, st, prep, N, nwords, iou_threshold, mask);
   hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(V3D_BLOCK), 0, st, mask, order, N, nwords, remv,
                      (long long*)keep, n_keep);
   V3D_CHECK_LAUNCH();

@@ -17,7 +17,8 @@
 //             16x16 results added into the tile's fp32 accumulator in LDS (each (row, col) has one
 //             owner per offset -> plain read-modify-write);
 //   epilogue  scale/shift/ReLU, coalesced float4 stores.
-// Kernel `spconv_fwd_scalar` (algo 1) is the simple VALU statement of the same sum, kept as the
+// Kernel `spconv_fwd_wave` (algo 3, the default) removes the per-offset barriers of algo 2: see its
+// header comment.  Kernel `spconv_fwd_scalar` (algo 1) is the simple VALU statement of the same sum, kept as the
 // on-device cross-check and for channel counts the MFMA tiling does not cover.
 #include "v3d_common.h"
 
@@ -229,6 +230,196 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_mfma(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------- algo 3: wave-autonomous MFMA
+// One workgroup = one 64-row output tile, 8 waves.  Wave (g, nb) owns the 16 output columns
+// [16 nb, 16 nb + 16) and the kernel offsets of k-group g (NB * G = 8, NB = Cout/16): inside the main
+// loop a wave never synchronises with another wave -- no barrier, no shared operand staging:
+//   * A (gathered input rows) and B (weights) go straight global -> VGPR.  The MFMA reduction index is
+//     PERMUTED so that lane (r = lane&15, q = lane>>4) holds Cin/4 CONTIGUOUS floats of row r
+//     (A[r][q*T + t], T = Cin/4: whole float4 loads, the four q-lanes cover the row's line) and B
+//     lane (q, j) holds W[k][q*T + t][16 nb + j]; step t of the chain multiplies the matching slices.
+//     Any permutation of the reduction index is legal as long as A and B agree.
+//   * the next (offset, 16-row block) operands are in flight while the current block's MFMAs run
+//     (two-deep register pipeline).
+//   * results are added into the wave's private slice of the LDS accumulator acc[g][row][col]
+//     (ds_add_f32; one owner per element -> deterministic); the epilogue sums the G partials in
+//     fixed order, applies scale/shift/ReLU and stores coalesced float4.
+#define SPW_WAVES 8
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const float* __restrict__ in,
+                                                                       const float* __restrict__ W,
+                                                                       const int* __restrict__ nbr,
+                                                                       const int* __restrict__ n_ptr, int cap, int K,
+                                                                       const float* __restrict__ scale,
+                                                                       const float* __restrict__ shift, int relu,
+                                                                       float* __restrict__ out) {
+  constexpr int NB = COUT / 16;
+  constexpr int G = SPW_WAVES / NB;
+  constexpr int T = CIN / 4;  // MFMA steps; also floats of one row held per lane
+  constexpr int NT = SPW_WAVES * V3D_WAVE;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* acc = smem;                                      // [G][64][COUT]
+  int* list_in = (int*)(acc + G * SPC_TM * COUT);         // [K][64]
+  int* cnt_pad = list_in + K * SPC_TM;                    // [K]
+  unsigned char* list_row = (unsigned char*)(cnt_pad + K);  // [K][64]
+
+  const int n = min(*n_ptr, cap);
+  const int row0 = blockIdx.x * SPC_TM;
+  if (row0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  for (int i = tid; i < G * SPC_TM * COUT; i += NT) acc[i] = 0.f;
+  for (int k = wave; k < K; k += SPW_WAVES) {
+    const int row = row0 + lane;
+    const int v = row < n ? nbr[(size_t)k * cap + row] : -1;
+    const unsigned long long m = __ballot(v >= 0);
+    const int c = __popcll(m);
+    const int cp = (c + 15) & ~15;
+    const int pos = __popcll(m & ((1ull << lane) - 1ull));
+    if (v >= 0) {
+      list_in[k * SPC_TM + pos] = v;
+      list_row[k * SPC_TM + pos] = (unsigned char)lane;
+    }
+    if (lane >= c && lane < cp) {
+      list_in[k * SPC_TM + lane] = -1;
+      list_row[k * SPC_TM + lane] = 255;
+    }
+    if (lane == 0) cnt_pad[k] = cp;
+  }
+  __syncthreads();
+
+  const int g = wave / NB, nb = wave % NB;
+  const int kper = (K + G - 1) / G;
+  const int k_lo = g * kper, k_hi = min(K, k_lo + kper);
+  const int r = lane & 15, q = lane >> 4;
+  float* my_acc = acc + (size_t)g * SPC_TM * COUT + nb * 16 + r;
+
+  float a0[T], a1[T], b0[T], b1[T];
+  auto load_a = [&](int k, int rblk, float (&a)[T]) {
+    const int src = list_in[k * SPC_TM + rblk * 16 + r];
+    if (src >= 0) {
+      const float* p = in + (size_t)src * CIN + q * T;
+      if constexpr (T % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < T / 4; i++) {
+          const float4 v = reinterpret_cast<const float4*>(p)[i];
+          a[4 * i] = v.x;
+          a[4 * i + 1] = v.y;
+          a[4 * i + 2] = v.z;
+          a[4 * i + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < T; t++) a[t] = p[t];
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < T; t++) a[t] = 0.f;
+    }
+  };
+  auto load_b = [&](int k, float (&b)[T]) {
+    const float* p = W + ((size_t)k * CIN + q * T) * COUT + nb * 16 + r;
+#pragma unroll
+    for (int t = 0; t < T; t++) b[t] = p[(size_t)t * COUT];
+  };
+  // next non-empty (k, rblk) after (k, rblk); k == k_hi means "done"
+  auto advance = [&](int& k, int& rblk) {
+    rblk++;
+    if (k < k_hi && rblk * 16 < cnt_pad[k]) return;
+    rblk = 0;
+    do {
+      k++;
+    } while (k < k_hi && cnt_pad[k] == 0);
+  };
+
+  int k = k_lo - 1, rblk = 0;
+  do {
+    k++;
+  } while (k < k_hi && cnt_pad[k] == 0);
+  if (k < k_hi) {
+    load_a(k, rblk, a0);
+    load_b(k, b0);
+  }
+  while (k < k_hi) {
+    int kn = k, rn = rblk;
+    advance(kn, rn);
+    if (kn < k_hi) {  // operands of the next block in flight during this block's MFMAs
+      load_a(kn, rn, a1);
+      if (kn != k) load_b(kn, b1);
+    }
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (T >= 2) {
+#pragma unroll
+      for (int t = 0; t < T; t += 2) {  // two independent accumulator chains hide the MFMA latency
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b0[t], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t + 1], b0[t + 1], d1, 0, 0, 0);
+      }
+      d0 += d1;
+    } else {
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0], b0[0], d0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int trow = list_row[k * SPC_TM + rblk * 16 + q * 4 + rr];
+      if (trow != 255)
+        __hip_atomic_fetch_add(my_acc + trow * COUT, d0[rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (kn < k_hi) {
+#pragma unroll
+      for (int t = 0; t < T; t++) a0[t] = a1[t];
+      if (kn != k) {
+#pragma unroll
+        for (int t = 0; t < T; t++) b0[t] = b1[t];
+      }
+    }
+    k = kn;
+    rblk = rn;
+  }
+  __syncthreads();
+
+  for (int idx = tid; idx < SPC_TM * (COUT / 4); idx += NT) {
+    const int rw = idx / (COUT / 4), c4 = idx % (COUT / 4);
+    if (row0 + rw >= n) continue;
+    float4 v = *reinterpret_cast<const float4*>(acc + rw * COUT + c4 * 4);
+#pragma unroll
+    for (int gg = 1; gg < G; gg++) {
+      const float4 u = *reinterpret_cast<const float4*>(acc + ((size_t)gg * SPC_TM + rw) * COUT + c4 * 4);
+      v.x += u.x;
+      v.y += u.y;
+      v.z += u.z;
+      v.w += u.w;
+    }
+    if (scale) {
+      const float4 sc = *reinterpret_cast<const float4*>(scale + c4 * 4);
+      const float4 sh = *reinterpret_cast<const float4*>(shift + c4 * 4);
+      v.x = v.x * sc.x + sh.x;
+      v.y = v.y * sc.y + sh.y;
+      v.z = v.z * sc.z + sh.z;
+      v.w = v.w * sc.w + sh.w;
+    }
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f);
+      v.y = fmaxf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f);
+      v.w = fmaxf(v.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(out + (size_t)(row0 + rw) * COUT + c4 * 4) = v;
+  }
+}
+
+template <int CIN, int COUT>
+static int launch_wave(const float* in, const float* W, const int* nbr, const int* n_ptr, int cap, int K,
+                       const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
+  constexpr int G = SPW_WAVES / (COUT / 16);
+  const size_t lds = (size_t)G * SPC_TM * COUT * 4 + (size_t)K * SPC_TM * 4 + (size_t)K * 4 + (size_t)K * SPC_TM + 64;
+  if (lds > 64 * 1024) return V3D_EUNSUPPORTED;
+  hipLaunchKernelGGL((spconv_fwd_wave<CIN, COUT>), dim3(v3d_ceil_div(cap, SPC_TM)), dim3(SPW_WAVES * V3D_WAVE), lds, st,
+                     in, W, nbr, n_ptr, cap, K, scale, shift, relu, out);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 template <int CIN, int COUT>
 static int launch_mfma(const float* in, const float* W, const int* nbr, const int* n_ptr, int cap, int K,
                        const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
@@ -250,7 +441,23 @@ extern "C" int v3d_sparse_conv_fwd(const float* in, const float* weight, const i
   hipStream_t st = (hipStream_t)stream;
   if (!in || !weight || !nbr || !n_out || !out || cap_out < 1 || K < 1 || Cin < 1 || Cout < 1) return V3D_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return V3D_EINVAL;
-  if (algo < 0 || algo > 2) return V3D_EINVAL;
+  if (algo < 0 || algo > 3) return V3D_EINVAL;
+  if (algo == 0 || algo == 3) {
+    int rc = V3D_EUNSUPPORTED;
+#define V3D_TRY(ci, co) \
+  if (Cin == ci && Cout == co) rc = launch_wave<ci, co>(in, weight, nbr, n_out, cap_out, K, scale, shift, relu, out, st);
+    V3D_TRY(4, 16)
+    V3D_TRY(16, 16)
+    V3D_TRY(16, 32)
+    V3D_TRY(32, 32)
+    V3D_TRY(32, 64)
+    V3D_TRY(64, 64)
+    V3D_TRY(4, 32)
+    V3D_TRY(64, 128)
+    V3D_TRY(128, 128)
+#undef V3D_TRY
+    if (rc != V3D_EUNSUPPORTED || algo == 3) return rc;
+  }
   if (algo == 0 || algo == 2) {
     int rc = V3D_EUNSUPPORTED;
 #define V3D_TRY(ci, co) \

@@ -23,6 +23,18 @@ def fold_batchnorm(bn):
 
 class SparseSequential(nn.Sequential):
 
+    def _folded(self, bn):
+        """Folded (scale, shift) of an eval-mode BatchNorm, cached until one of its tensors changes
+        (tensor._version is bumped by every in-place update, load_state_dict included)."""
+        cache = self.__dict__.setdefault("_fold_cache", {})
+        tensors = (bn.running_mean, bn.running_var, bn.weight, bn.bias)
+        stamp = tuple((t.data_ptr(), t._version) for t in tensors if t is not None) + (bn.eps,)
+        hit = cache.get(id(bn))
+        if hit is None or hit[0] != stamp:
+            hit = (stamp,) + fold_batchnorm(bn)
+            cache[id(bn)] = hit
+        return hit[1], hit[2]
+
     def forward(self, x):
         mods = list(self._modules.values())
         i = 0
@@ -32,7 +44,7 @@ class SparseSequential(nn.Sequential):
                 nxt = mods[i + 1] if i + 1 < len(mods) else None
                 nxt2 = mods[i + 2] if i + 2 < len(mods) else None
                 if (isinstance(nxt, nn.BatchNorm1d) and not nxt.training and nxt.track_running_stats):
-                    scale, shift = fold_batchnorm(nxt)
+                    scale, shift = self._folded(nxt)
                     relu = isinstance(nxt2, nn.ReLU)
                     x = m(x, scale, shift, relu)
                     i += 3 if relu else 2
