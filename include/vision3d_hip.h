@@ -122,6 +122,48 @@ int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M, 
 int v3d_group_points(const float* feat, const int32_t* idx, int B, int C, int N, int M, int nsample, float* out,
                      v3d_stream_t stream);
 
+/* ---- Fused sparse-backbone plan: voxelizer -> [rulebooks + sparse conv layers] -> .dense().
+ * The native form of the sparse half of Second.feature_extract (detector/second.py:20-24,41-46 over
+ * detector/sparse_cnn.py:151-175): created once per model, every forward only ENQUEUES kernels on
+ * `stream` -- no host synchronisation, counts stay in device memory, one coordinate hash per stage is
+ * shared by the strided rulebook that creates the stage and the submanifold rulebook that follows.
+ * The plan owns its arena (hipMalloc at create, hipFree at destroy) and private copies of the layer
+ * parameters (set_layer copies device -> device).  Not thread-safe per plan; use one plan per stream. */
+typedef struct v3d_backbone v3d_backbone;
+typedef struct {
+  int32_t subm;                            /* 1 = SubMConv3d, 0 = SparseConv3d */
+  int32_t cin, cout;
+  int32_t ksize[3], stride[3], padding[3]; /* z, y, x */
+  int32_t key;                             /* >= 0: submanifold layers with equal key share a rulebook (indice_key) */
+  int32_t relu;                            /* fused ReLU */
+} v3d_layer_desc;
+typedef struct {
+  float voxel_size[3];                     /* x, y, z */
+  float bounds[6];                         /* x0,y0,z0,x1,y1,z1 */
+  int32_t max_pts, max_voxels;             /* per voxel / per frame */
+  int32_t point_channels;                  /* C of the input points == Cin of layer 0 */
+  int32_t grid_shape[3];                   /* D,H,W of the CNN input grid (sparse_cnn.py:40-45: z + 1) */
+  int32_t max_batch, max_points;           /* capacities: frames per forward, total points per forward */
+  int32_t n_layers;
+  float growth;                            /* active-site capacity of later stages = growth * voxel capacity (<=0: 2.0) */
+} v3d_backbone_config;
+int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_layer_desc* layers, v3d_backbone** out);
+void v3d_backbone_destroy(v3d_backbone* plan);
+size_t v3d_backbone_arena_bytes(const v3d_backbone* plan);
+int v3d_backbone_num_layers(const v3d_backbone* plan);
+/* weight (K,Cin,Cout) f32; scale/shift (Cout) or both NULL (no affine). */
+int v3d_backbone_set_layer(v3d_backbone* plan, int layer, const float* weight, const float* scale, const float* shift,
+                           v3d_stream_t stream);
+/* points (n_points,C) f32 = frames concatenated; dense_out (B, Cout_last*D, H, W) f32 or NULL. */
+int v3d_backbone_forward(v3d_backbone* plan, const float* points, int n_points, const int32_t* frame_offsets_host,
+                         int B, float* dense_out, v3d_stream_t stream);
+/* Device-resident results of the last forward: layer = -1 -> voxelizer output (mean features, coords);
+ * layer >= 0 -> that layer's output rows.  *n_rows_dev is a device int32; cap = row capacity. */
+int v3d_backbone_layer_output(v3d_backbone* plan, int layer, float** features, int32_t** coords,
+                              int32_t** n_rows_dev, int* cap, int* channels, int32_t* shape_host);
+int32_t* v3d_backbone_occupancy(v3d_backbone* plan);       /* (cap0) i32, voxel occupancies of the last forward */
+int32_t* v3d_backbone_overflow_flags(v3d_backbone* plan);  /* (n_layers+1) i32 device flags, nonzero = capacity hit */
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,7 +36,27 @@ _SIGNATURES = {
     "v3d_gather_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "v3d_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "v3d_group_points": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "v3d_backbone_create": (_i, [_vp, _vp, _vp]),
+    "v3d_backbone_destroy": (None, [_vp]),
+    "v3d_backbone_arena_bytes": (_sz, [_vp]),
+    "v3d_backbone_num_layers": (_i, [_vp]),
+    "v3d_backbone_set_layer": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "v3d_backbone_forward": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "v3d_backbone_layer_output": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "v3d_backbone_occupancy": (_vp, [_vp]),
+    "v3d_backbone_overflow_flags": (_vp, [_vp]),
 }
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("subm", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32 * 3),
+                ("stride", C.c_int32 * 3), ("padding", C.c_int32 * 3), ("key", C.c_int32), ("relu", C.c_int32)]
+
+
+class BackboneConfig(C.Structure):
+    _fields_ = [("voxel_size", C.c_float * 3), ("bounds", C.c_float * 6), ("max_pts", C.c_int32),
+                ("max_voxels", C.c_int32), ("point_channels", C.c_int32), ("grid_shape", C.c_int32 * 3),
+                ("max_batch", C.c_int32), ("max_points", C.c_int32), ("n_layers", C.c_int32), ("growth", C.c_float)]
 
 _lib = None
 

@@ -11,7 +11,7 @@
 // parallel: ticket t = i*K + k, per output-hash slot an atomicMin keeps the smallest ticket, and a
 // wave64 ballot/popcount scan over "ticket t is its slot's minimum" yields exactly the sequential
 // numbering.  Everything is sized by capacities; live counts stay in device memory.
-#include "v3d_common.h"
+#include "v3d_internal.h"
 
 struct RbGeom {
   int in_shape[3];   // D, H, W of the input grid
@@ -208,6 +208,71 @@ static int fill_geom(RbGeom& g, const int32_t* shape, const int32_t* ks, const i
   return V3D_OK;
 }
 
+// ---- internal (C++) entry points shared by the C ABI wrappers below and the fused backbone plan
+// (second_plan.hip).  A V3dRbHash is a coordinate hash of ONE active-site set: keys[hcap] + vals[hcap]
+// (vals[slot] = row index).  The strided rulebook leaves exactly such a hash of its OUTPUT sites behind,
+// which is the table the next stage's submanifold rulebook needs -- the plan reuses it.
+int v3d_i_hash_build(const int32_t* coords, const int32_t* n, int cap, const int32_t* shape, V3dRbHash h, hipStream_t st) {
+  RbGeom g;
+  const int32_t ones[3] = {1, 1, 1};
+  int rc = fill_geom(g, shape, ones, nullptr, nullptr);
+  if (rc) return rc;
+  V3D_CHECK_HIP(hipMemsetAsync(h.keys, 0xFF, (size_t)h.hcap * 8, st));
+  V3dHash hh{h.keys, h.hcap - 1};
+  hipLaunchKernelGGL(rb_hash_build_kernel, dim3(min(v3d_ceil_div(cap, V3D_BLOCK), 2048)), dim3(V3D_BLOCK), 0, st,
+                     (const int4*)coords, n, cap, g, hh, h.vals);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+int v3d_i_subm_nbr(const int32_t* coords, const int32_t* n, int cap, const int32_t* shape, const int32_t* ksize,
+                   V3dRbHash h, int32_t* nbr, hipStream_t st) {
+  RbGeom g;
+  int rc = fill_geom(g, shape, ksize, nullptr, nullptr);
+  if (rc) return rc;
+  for (int j = 0; j < 3; j++)
+    if (!(g.ks[j] & 1)) return V3D_EINVAL;  // submanifold needs odd kernels
+  V3dHash hh{h.keys, h.hcap - 1};
+  hipLaunchKernelGGL(rb_subm_nbr_kernel, dim3(v3d_ceil_div(cap, V3D_BLOCK), g.K), dim3(V3D_BLOCK), 0, st,
+                     (const int4*)coords, n, cap, g, hh, h.vals, nbr);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+// scratch: first_ticket[out.hcap] (must directly follow out.keys and precede out.vals in memory so that ONE
+// memset resets keys|first_ticket|vals), cand_slot[cap_in*K], chunk_counts[ceil(cap_in*K/2048)].
+int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap_in, const int32_t* shape,
+                          const int32_t* ksize, const int32_t* stride, const int32_t* padding, int32_t* coords_out,
+                          int32_t* n_out, int cap_out, int32_t* nbr, int32_t* overflow, V3dRbHash out,
+                          unsigned* first_ticket, int* cand_slot, int* chunk_counts, int32_t* out_shape, hipStream_t st) {
+  RbGeom g;
+  int rc = fill_geom(g, shape, ksize, stride, padding);
+  if (rc) return rc;
+  if (out_shape)
+    for (int j = 0; j < 3; j++) out_shape[j] = g.out_shape[j];
+  const long long tickets = (long long)cap_in * g.K;
+  if (tickets >= (1ll << 31)) return V3D_EUNSUPPORTED;
+  const int chunks = v3d_ceil_div(tickets, V3D_SCAN_CHUNK);
+  if ((char*)first_ticket != (char*)out.keys + (size_t)out.hcap * 8 || (char*)out.vals != (char*)first_ticket + (size_t)out.hcap * 4)
+    return V3D_EINVAL;
+  V3D_CHECK_HIP(hipMemsetAsync(out.keys, 0xFF, (size_t)out.hcap * 16, st));
+  V3D_CHECK_HIP(hipMemsetAsync(nbr, 0xFF, (size_t)g.K * cap_out * 4, st));
+  V3D_CHECK_HIP(hipMemsetAsync(overflow, 0, 4, st));
+  V3dHash h{out.keys, out.hcap - 1};
+  const int tblocks = min(v3d_ceil_div(tickets, V3D_BLOCK), 4096);
+  hipLaunchKernelGGL(rb_candidates_kernel, dim3(tblocks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in,
+                     g, h, first_ticket, cand_slot, overflow);
+  hipLaunchKernelGGL(rb_count_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, cand_slot, first_ticket, n_in, cap_in, g.K,
+                     chunk_counts);
+  hipLaunchKernelGGL(rb_scan_kernel, dim3(1), dim3(1024), 0, st, chunk_counts, chunks, cap_out, n_out, overflow);
+  hipLaunchKernelGGL(rb_emit_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in, g,
+                     cand_slot, first_ticket, chunk_counts, cap_out, (int4*)coords_out, out.vals);
+  hipLaunchKernelGGL(rb_fill_nbr_kernel, dim3(tblocks), dim3(V3D_BLOCK), 0, st, n_in, cap_in, g.K, cand_slot, out.vals,
+                     cap_out, nbr);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 extern "C" size_t v3d_rulebook_workspace(int cap_in, int cap_out, int K) {
   const size_t ci = (size_t)(cap_in > 0 ? cap_in : 1), co = (size_t)(cap_out > 0 ? cap_out : 1);
   const size_t hcap = v3d_hash_capacity((long long)(ci > co ? ci : co));
@@ -221,25 +286,16 @@ extern "C" int v3d_rulebook_subm(const int32_t* coords, const int32_t* n, int ca
                                  v3d_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!coords || !n || cap < 1 || !spatial_shape_host || !ksize_host || !nbr || !workspace) return V3D_EINVAL;
-  RbGeom g;
-  int rc = fill_geom(g, spatial_shape_host, ksize_host, nullptr, nullptr);
-  if (rc) return rc;
-  for (int j = 0; j < 3; j++)
-    if (!(g.ks[j] & 1)) return V3D_EINVAL;  // submanifold needs odd kernels
   const unsigned hcap = v3d_hash_capacity(cap);
   V3dArena ar(workspace, workspace_bytes);
-  v3d_key_t* keys = ar.take<v3d_key_t>(hcap);
-  int* vals = ar.take<int>(hcap);
+  V3dRbHash h;
+  h.keys = ar.take<v3d_key_t>(hcap);
+  h.vals = ar.take<int>(hcap);
+  h.hcap = hcap;
   if (!ar.ok()) return V3D_EWORKSPACE;
-  V3D_CHECK_HIP(hipMemsetAsync(keys, 0xFF, (size_t)hcap * 8, st));
-  V3dHash h{keys, hcap - 1};
-  const int blocks = v3d_ceil_div(cap, V3D_BLOCK);
-  hipLaunchKernelGGL(rb_hash_build_kernel, dim3(min(blocks, 2048)), dim3(V3D_BLOCK), 0, st, (const int4*)coords, n,
-                     cap, g, h, vals);
-  hipLaunchKernelGGL(rb_subm_nbr_kernel, dim3(blocks, g.K), dim3(V3D_BLOCK), 0, st, (const int4*)coords, n, cap, g, h,
-                     vals, nbr);
-  V3D_CHECK_LAUNCH();
-  return V3D_OK;
+  int rc = v3d_i_hash_build(coords, n, cap, spatial_shape_host, h, st);
+  if (rc) return rc;
+  return v3d_i_subm_nbr(coords, n, cap, spatial_shape_host, ksize_host, h, nbr, st);
 }
 
 extern "C" int v3d_rulebook_sparse(const int32_t* coords_in, const int32_t* n_in, int cap_in,
@@ -251,34 +307,22 @@ extern "C" int v3d_rulebook_sparse(const int32_t* coords_in, const int32_t* n_in
   if (!coords_in || !n_in || cap_in < 1 || cap_out < 1 || !spatial_shape_host || !ksize_host || !stride_host ||
       !padding_host || !coords_out || !n_out || !nbr || !overflow || !workspace)
     return V3D_EINVAL;
-  RbGeom g;
-  int rc = fill_geom(g, spatial_shape_host, ksize_host, stride_host, padding_host);
-  if (rc) return rc;
   const unsigned hcap = v3d_hash_capacity(cap_in > cap_out ? cap_in : cap_out);
-  const long long tickets = (long long)cap_in * g.K;
+  long long K = (long long)ksize_host[0] * ksize_host[1] * ksize_host[2];
+  if (K < 1) return V3D_EINVAL;
+  const long long tickets = (long long)cap_in * K;
   const int chunks = v3d_ceil_div(tickets, V3D_SCAN_CHUNK);
   V3dArena ar(workspace, workspace_bytes);
-  // keys | first_ticket | vals contiguous -> one memset(0xFF): EMPTY / UINT_MAX / -1
-  v3d_key_t* keys = ar.take<v3d_key_t>(hcap);
+  // keys | first_ticket | vals contiguous -> one memset(0xFF): EMPTY / UINT_MAX / -1 (hcap*4 is a multiple of 256)
+  V3dRbHash h;
+  h.keys = ar.take<v3d_key_t>(hcap);
   unsigned* first_ticket = ar.take<unsigned>(hcap);
-  int* vals = ar.take<int>(hcap);
+  h.vals = ar.take<int>(hcap);
+  h.hcap = hcap;
   int* cand_slot = ar.take<int>((size_t)tickets);
   int* chunk_counts = ar.take<int>(chunks);
   if (!ar.ok()) return V3D_EWORKSPACE;
-  V3D_CHECK_HIP(hipMemsetAsync(keys, 0xFF, (size_t)((char*)vals - (char*)keys) + (size_t)hcap * 4, st));
-  V3D_CHECK_HIP(hipMemsetAsync(nbr, 0xFF, (size_t)g.K * cap_out * 4, st));
-  V3D_CHECK_HIP(hipMemsetAsync(overflow, 0, 4, st));
-  V3dHash h{keys, hcap - 1};
-  const int tblocks = min(v3d_ceil_div(tickets, V3D_BLOCK), 4096);
-  hipLaunchKernelGGL(rb_candidates_kernel, dim3(tblocks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in,
-                     g, h, first_ticket, cand_slot, overflow);
-  hipLaunchKernelGGL(rb_count_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, cand_slot, first_ticket, n_in, cap_in, g.K,
-                     chunk_counts);
-  hipLaunchKernelGGL(rb_scan_kernel, dim3(1), dim3(1024), 0, st, chunk_counts, chunks, cap_out, n_out, overflow);
-  hipLaunchKernelGGL(rb_emit_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in, g,
-                     cand_slot, first_ticket, chunk_counts, cap_out, (int4*)coords_out, vals);
-  hipLaunchKernelGGL(rb_fill_nbr_kernel, dim3(tblocks), dim3(V3D_BLOCK), 0, st, n_in, cap_in, g.K, cand_slot, vals,
-                     cap_out, nbr);
-  V3D_CHECK_LAUNCH();
-  return V3D_OK;
+  return v3d_i_sparse_rulebook(coords_in, n_in, cap_in, spatial_shape_host, ksize_host, stride_host, padding_host,
+                               coords_out, n_out, cap_out, nbr, overflow, h, first_ticket, cand_slot, chunk_counts,
+                               nullptr, st);
 }

@@ -24,6 +24,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// development-only ablation switches for spconv_fwd_wave (0 in production); see tools/microbench.py
+static int g_v3d_debug_flags = 0;
+static int g_v3d_debug_repeat = 1;  // launch each conv kernel this many times (timing harness only)
+extern "C" void v3d_debug_set_flags(int flags) { g_v3d_debug_flags = flags; }
+extern "C" void v3d_debug_set_repeat(int n) { g_v3d_debug_repeat = n < 1 ? 1 : n; }
+
 // ---------------------------------------------------------------------------------- algo 1: scalar
 __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_scalar(const float* __restrict__ in,
                                                                const float* __restrict__ W,
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
                                                                        const int* __restrict__ n_ptr, int cap, int K,
                                                                        const float* __restrict__ scale,
                                                                        const float* __restrict__ shift, int relu,
-                                                                       float* __restrict__ out) {
+                                                                       float* __restrict__ out, int dbg) {
   constexpr int NB = COUT / 16;
   constexpr int G = SPW_WAVES / NB;
   constexpr int T = CIN / 4;  // MFMA steps; also floats of one row held per lane
@@ -289,15 +295,21 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
   }
   __syncthreads();
 
-  const int g = wave / NB, nb = wave % NB;
+  // Everything that steers the main loop is made wave-uniform (SGPR) on purpose: the wave id through
+  // readfirstlane, the per-offset counts through one register per lane + readlane.  The loop then runs
+  // on scalar branches instead of exec-mask juggling, and needs no LDS traffic for its control.
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  const int g = uwave / NB, nb = uwave % NB;
   const int kper = (K + G - 1) / G;
   const int k_lo = g * kper, k_hi = min(K, k_lo + kper);
   const int r = lane & 15, q = lane >> 4;
   float* my_acc = acc + (size_t)g * SPC_TM * COUT + nb * 16 + r;
+  const int cnt_reg = lane < K ? cnt_pad[lane] : 0;  // K <= 64: lane k holds cnt_pad[k]
+  auto count_of = [&](int k) { return __builtin_amdgcn_readlane(cnt_reg, k); };
 
   float a0[T], a1[T], b0[T], b1[T];
   auto load_a = [&](int k, int rblk, float (&a)[T]) {
-    const int src = list_in[k * SPC_TM + rblk * 16 + r];
+    const int src = (dbg & 1) ? -1 : list_in[k * SPC_TM + rblk * 16 + r];
     if (src >= 0) {
       const float* p = in + (size_t)src * CIN + q * T;
       if constexpr (T % 4 == 0) {
@@ -319,24 +331,28 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
     }
   };
   auto load_b = [&](int k, float (&b)[T]) {
-    const float* p = W + ((size_t)k * CIN + q * T) * COUT + nb * 16 + r;
+    const float* p = W + ((size_t)((dbg & 2) ? 0 : k) * CIN + q * T) * COUT + nb * 16 + r;
+    if (dbg & 16) {
+#pragma unroll
+      for (int t = 0; t < T; t++) b[t] = 1.0f;
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < T; t++) b[t] = p[(size_t)t * COUT];
   };
-  // next non-empty (k, rblk) after (k, rblk); k == k_hi means "done"
+  // next non-empty (k, rblk) after (k, rblk); k == k_hi means "done".  Scalar code only.
   auto advance = [&](int& k, int& rblk) {
     rblk++;
-    if (k < k_hi && rblk * 16 < cnt_pad[k]) return;
+    if (rblk * 16 < count_of(k)) return;
     rblk = 0;
     do {
       k++;
-    } while (k < k_hi && cnt_pad[k] == 0);
+    } while (k < k_hi && count_of(k) == 0);
   };
 
-  int k = k_lo - 1, rblk = 0;
-  do {
-    k++;
-  } while (k < k_hi && cnt_pad[k] == 0);
+  int k = k_lo, rblk = 0;
+  while (k < k_hi && count_of(k) == 0) k++;
+  if (dbg & 64) k = k_hi;
   if (k < k_hi) {
     load_a(k, rblk, a0);
     load_b(k, b0);
@@ -344,12 +360,20 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
   while (k < k_hi) {
     int kn = k, rn = rblk;
     advance(kn, rn);
-    if (kn < k_hi) {  // operands of the next block in flight during this block's MFMAs
+    const bool more = kn < k_hi, newk = kn != k;
+    // tile rows of this block's 4 result rows: 4 bytes, one aligned 32-bit LDS read
+    const unsigned rows4 = *reinterpret_cast<const unsigned*>(list_row + k * SPC_TM + rblk * 16 + q * 4);
+    if (more) {  // operands of the next block in flight during this block's MFMAs
       load_a(kn, rn, a1);
-      if (kn != k) load_b(kn, b1);
+      if (newk) load_b(kn, b1);
     }
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (T >= 2) {
+    if (dbg & 4) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; t++) sacc += a0[t] * b0[t];
+      d0[0] = sacc;
+    } else if constexpr (T >= 2) {
 #pragma unroll
       for (int t = 0; t < T; t += 2) {  // two independent accumulator chains hide the MFMA latency
         d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b0[t], d0, 0, 0, 0);
@@ -359,16 +383,25 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
     } else {
       d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0], b0[0], d0, 0, 0, 0);
     }
+    // accumulate: this wave is the only owner of acc[g][:, 16 nb .. 16 nb + 16) and a tile row occurs
+    // at most once per offset -> plain read-modify-write (LDS float atomics are ~0.4 us each here)
+    if (!(dbg & 32)) {
+      float old[4];
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-      const int trow = list_row[k * SPC_TM + rblk * 16 + q * 4 + rr];
-      if (trow != 255)
-        __hip_atomic_fetch_add(my_acc + trow * COUT, d0[rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int rr = 0; rr < 4; rr++) {
+        const unsigned trow = (rows4 >> (8 * rr)) & 255u;
+        old[rr] = trow != 255u ? my_acc[trow * COUT] : 0.f;
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const unsigned trow = (rows4 >> (8 * rr)) & 255u;
+        if (trow != 255u) my_acc[trow * COUT] = old[rr] + d0[rr];
+      }
     }
-    if (kn < k_hi) {
+    if (more) {
 #pragma unroll
       for (int t = 0; t < T; t++) a0[t] = a1[t];
-      if (kn != k) {
+      if (newk) {
 #pragma unroll
         for (int t = 0; t < T; t++) b0[t] = b1[t];
       }
@@ -414,8 +447,9 @@ static int launch_wave(const float* in, const float* W, const int* nbr, const in
   constexpr int G = SPW_WAVES / (COUT / 16);
   const size_t lds = (size_t)G * SPC_TM * COUT * 4 + (size_t)K * SPC_TM * 4 + (size_t)K * 4 + (size_t)K * SPC_TM + 64;
   if (lds > 64 * 1024) return V3D_EUNSUPPORTED;
-  hipLaunchKernelGGL((spconv_fwd_wave<CIN, COUT>), dim3(v3d_ceil_div(cap, SPC_TM)), dim3(SPW_WAVES * V3D_WAVE), lds, st,
-                     in, W, nbr, n_ptr, cap, K, scale, shift, relu, out);
+  for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
+    hipLaunchKernelGGL((spconv_fwd_wave<CIN, COUT>), dim3(v3d_ceil_div(cap, SPC_TM)), dim3(SPW_WAVES * V3D_WAVE), lds, st,
+                       in, W, nbr, n_ptr, cap, K, scale, shift, relu, out, g_v3d_debug_flags);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -429,8 +463,9 @@ static int launch_mfma(const float* in, const float* W, const int* nbr, const in
   if (lds > 64 * 1024) {
     V3D_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL(kern, dim3(v3d_ceil_div(cap, SPC_TM)), dim3(V3D_BLOCK), lds, st, in, W, nbr, n_ptr, cap, K, scale,
-                     shift, relu, out);
+  for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
+    hipLaunchKernelGGL(kern, dim3(v3d_ceil_div(cap, SPC_TM)), dim3(V3D_BLOCK), lds, st, in, W, nbr, n_ptr, cap, K, scale,
+                       shift, relu, out);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -475,8 +510,9 @@ extern "C" int v3d_sparse_conv_fwd(const float* in, const float* weight, const i
   }
   const long long total = (long long)cap_out * Cout;
   const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
-  hipLaunchKernelGGL(spconv_fwd_scalar, dim3(blocks > 8192 ? 8192 : blocks), dim3(V3D_BLOCK), 0, st, in, weight, nbr,
-                     n_out, cap_out, K, Cin, Cout, scale, shift, relu, out);
+  for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
+    hipLaunchKernelGGL(spconv_fwd_scalar, dim3(blocks > 8192 ? 8192 : blocks), dim3(V3D_BLOCK), 0, st, in, weight, nbr,
+                       n_out, cap_out, K, Cin, Cout, scale, shift, relu, out);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }

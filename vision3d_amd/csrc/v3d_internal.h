@@ -1,0 +1,17 @@
+// v3d_internal.h -- C++ entry points shared inside libvision3d_hip (not part of the C ABI).
+#pragma once
+#include "v3d_common.h"
+
+struct V3dRbHash {
+  v3d_key_t* keys;
+  int* vals;
+  unsigned hcap;  // power of two
+};
+
+int v3d_i_hash_build(const int32_t* coords, const int32_t* n, int cap, const int32_t* shape, V3dRbHash h, hipStream_t st);
+int v3d_i_subm_nbr(const int32_t* coords, const int32_t* n, int cap, const int32_t* shape, const int32_t* ksize,
+                   V3dRbHash h, int32_t* nbr, hipStream_t st);
+int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap_in, const int32_t* shape,
+                          const int32_t* ksize, const int32_t* stride, const int32_t* padding, int32_t* coords_out,
+                          int32_t* n_out, int cap_out, int32_t* nbr, int32_t* overflow, V3dRbHash out,
+                          unsigned* first_ticket, int* cand_slot, int* chunk_counts, int32_t* out_shape, hipStream_t st);

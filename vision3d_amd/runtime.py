@@ -1,0 +1,161 @@
+"""Native runtime objects: the fused sparse-backbone plan (csrc/second_plan.hip).
+
+`BackbonePlan(cnn, cfg)` mirrors one `SparseCNNBase` module (detector/sparse_cnn.py) inside
+libvision3d_hip.so: voxelizer + every sparse layer (BatchNorm folded, ReLU fused) + .dense(), enqueued
+by ONE C call per forward with no host synchronisation.  Parameters are re-uploaded automatically when
+the module's tensors change (load_state_dict, optimizer step)."""
+import ctypes as C
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+from .spconv.conv import _SparseConvBase
+from .spconv.modules import fold_batchnorm
+
+
+def flatten_sparse_layers(module):
+    """[(conv, bn|None, relu: bool)] in execution order from a tree of SparseSequential."""
+    mods = []
+
+    def walk(m):
+        if isinstance(m, _SparseConvBase) or not isinstance(m, nn.Sequential):
+            mods.append(m)
+        else:
+            for c in m.children():
+                walk(c)
+    walk(module)
+    out, i = [], 0
+    while i < len(mods):
+        m = mods[i]
+        if not isinstance(m, _SparseConvBase):
+            raise NotImplementedError(f"BackbonePlan: unsupported module {type(m).__name__} outside a conv-BN-ReLU group")
+        bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d) else None
+        j = i + (2 if bn is not None else 1)
+        relu = j < len(mods) and isinstance(mods[j], nn.ReLU)
+        out.append((m, bn, relu))
+        i = j + (1 if relu else 0)
+    return out
+
+
+class BackbonePlan(object):
+
+    def __init__(self, cnn, cfg, max_batch=1, max_points=None, growth=2.0, device=None):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.cfg = cfg
+        self.layers = flatten_sparse_layers(cnn.blocks)
+        self.grid_shape = [int(s) for s in cnn.grid_shape]
+        self.max_batch = int(max_batch)
+        self.max_points = int(max_points if max_points is not None else 16384 * max_batch)
+        keys = {}
+        descs = (L.LayerDesc * len(self.layers))()
+        for d, (conv, bn, relu) in zip(descs, self.layers):
+            d.subm, d.cin, d.cout = int(conv.subm), conv.in_channels, conv.out_channels
+            d.ksize[:] = conv.kernel_size
+            d.stride[:] = conv.stride
+            d.padding[:] = conv.padding
+            d.key = -1 if conv.indice_key is None else keys.setdefault(conv.indice_key, len(keys))
+            d.relu = int(relu)
+        c = L.BackboneConfig()
+        c.voxel_size[:] = [float(v) for v in cfg.VOXEL_SIZE]
+        c.bounds[:] = [float(v) for v in cfg.GRID_BOUNDS]
+        c.max_pts, c.max_voxels, c.point_channels = cfg.MAX_OCCUPANCY, cfg.MAX_VOXELS, cfg.C_IN
+        c.grid_shape[:] = self.grid_shape
+        c.max_batch, c.max_points, c.n_layers, c.growth = self.max_batch, self.max_points, len(self.layers), float(growth)
+        self._handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(L.lib().v3d_backbone_create(C.byref(c), descs, C.byref(self._handle)), "backbone_create")
+        self.out_channels = self.layers[-1][0].out_channels
+        shape = list(self.grid_shape)
+        for conv, _, _ in self.layers:
+            if not conv.subm:
+                shape = [(shape[j] + 2 * conv.padding[j] - conv.kernel_size[j]) // conv.stride[j] + 1 for j in range(3)]
+        self.out_shape = shape
+        self._stamp = None
+        self._keep = []
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                L.lib().v3d_backbone_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    def _param_stamp(self):
+        st = []
+        for conv, bn, _ in self.layers:
+            ts = [conv.weight, conv.bias] + ([bn.running_mean, bn.running_var, bn.weight, bn.bias] if bn is not None else [])
+            st.append(tuple((t.data_ptr(), t._version) for t in ts if t is not None))
+        return tuple(st)
+
+    def sync_weights(self):
+        """Upload folded parameters if any module tensor changed since the last upload."""
+        stamp = self._param_stamp()
+        if stamp == self._stamp:
+            return
+        lib = L.lib()
+        keep = []
+        with torch.cuda.device(self.device), torch.no_grad():
+            for i, (conv, bn, _) in enumerate(self.layers):
+                w = conv.weight.detach().to(self.device, torch.float32).reshape(-1, conv.in_channels, conv.out_channels).contiguous()
+                scale = shift = None
+                if bn is not None:
+                    if bn.training:
+                        raise RuntimeError("BackbonePlan runs eval-mode BatchNorm only (call model.eval())")
+                    scale, shift = fold_batchnorm(bn)
+                if conv.bias is not None:
+                    b = conv.bias.detach()
+                    shift = b if shift is None else shift + b * scale
+                    scale = torch.ones_like(b) if scale is None else scale
+                if scale is not None:
+                    scale, shift = scale.to(self.device).contiguous(), shift.to(self.device).contiguous()
+                keep += [w, scale, shift]
+                L.check(lib.v3d_backbone_set_layer(self._handle, i, L.ptr(w), L.ptr(scale), L.ptr(shift), L.stream_ptr()),
+                        "backbone_set_layer")
+        self._keep = keep  # sources stay alive until the async copies have been consumed
+        self._stamp = stamp
+
+    def forward(self, points, frame_offsets, out=None):
+        """points (sum N, C) float32 cuda (frames concatenated), frame_offsets: host ints (B+1).
+        Returns the BEV map (B, C_out * D, H, W); nothing is synchronised."""
+        self.sync_weights()
+        pts = L.as_f32("backbone", points)
+        b = len(frame_offsets) - 1
+        d, h, w = self.out_shape
+        if out is None:
+            out = torch.empty((b, self.out_channels * d, h, w), dtype=torch.float32, device=pts.device)
+        with torch.cuda.device(pts.device):
+            L.check(L.lib().v3d_backbone_forward(self._handle, L.ptr(pts), pts.shape[0], L.host_i32(frame_offsets), b,
+                                                 L.ptr(out), L.stream_ptr()), "backbone_forward")
+        return out
+
+    def layer_output(self, layer):
+        """(features (cap, C) view, coords (cap, 4) view, n_rows device int32 (1,), shape) of the last forward;
+        layer = -1 is the voxelizer output.  Views alias the plan's arena: valid until the next forward."""
+        f, c, n = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        cap, ch = C.c_int(), C.c_int()
+        shape = (C.c_int32 * 3)()
+        L.check(L.lib().v3d_backbone_layer_output(self._handle, layer, C.byref(f), C.byref(c), C.byref(n), C.byref(cap),
+                                                  C.byref(ch), shape), "backbone_layer_output")
+        return _view(f.value, (cap.value, ch.value), torch.float32, self.device), \
+            _view(c.value, (cap.value, 4), torch.int32, self.device), _view(n.value, (1,), torch.int32, self.device), list(shape)
+
+    def overflow(self):
+        ptr = L.lib().v3d_backbone_overflow_flags(self._handle)
+        return _view(ptr, (len(self.layers) + 1,), torch.int32, self.device)
+
+
+class _DevMem(object):
+    """Minimal __cuda_array_interface__ carrier so torch can alias plan-owned device memory."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=2)
+
+
+def _view(ptr, shape, dtype, device):
+    typestr = {torch.float32: "<f4", torch.int32: "<i4"}[dtype]
+    with torch.cuda.device(device):
+        return torch.as_tensor(_DevMem(ptr, shape, typestr), device=device)
