@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--path", choices=["fused", "eager"], default="fused",
                     help="fused: native backbone plan (one C call per frame); eager: per-op python -> C ABI")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch event timing pass (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=3)
     return ap.parse_args()
 
@@ -107,7 +108,7 @@ def main():
 
     # ---- per-kernel timing of the sparse backbone with HIP events on the launch stream (rank 0)
     roofline, stages = None, None
-    if rank == 0:
+    if rank == 0 and not args.no_roofline:
         conv_mods = [m for m in model.cnn.modules() if isinstance(m, _SparseConvBase)]
         rec = {id(m): [] for m in conv_mods}
         info = {}

@@ -218,7 +218,7 @@ int v3d_i_hash_build(const int32_t* coords, const int32_t* n, int cap, const int
   int rc = fill_geom(g, shape, ones, nullptr, nullptr);
   if (rc) return rc;
   V3D_CHECK_HIP(hipMemsetAsync(h.keys, 0xFF, (size_t)h.hcap * 8, st));
-  V3dHash hh{h.keys, h.hcap - 1};
+  V3dHash hh = v3d_make_hash(h.keys, h.hcap);
   hipLaunchKernelGGL(rb_hash_build_kernel, dim3(min(v3d_ceil_div(cap, V3D_BLOCK), 2048)), dim3(V3D_BLOCK), 0, st,
                      (const int4*)coords, n, cap, g, hh, h.vals);
   V3D_CHECK_LAUNCH();
@@ -232,7 +232,7 @@ int v3d_i_subm_nbr(const int32_t* coords, const int32_t* n, int cap, const int32
   if (rc) return rc;
   for (int j = 0; j < 3; j++)
     if (!(g.ks[j] & 1)) return V3D_EINVAL;  // submanifold needs odd kernels
-  V3dHash hh{h.keys, h.hcap - 1};
+  V3dHash hh = v3d_make_hash(h.keys, h.hcap);
   hipLaunchKernelGGL(rb_subm_nbr_kernel, dim3(v3d_ceil_div(cap, V3D_BLOCK), g.K), dim3(V3D_BLOCK), 0, st,
                      (const int4*)coords, n, cap, g, hh, h.vals, nbr);
   V3D_CHECK_LAUNCH();
@@ -258,7 +258,7 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
   V3D_CHECK_HIP(hipMemsetAsync(out.keys, 0xFF, (size_t)out.hcap * 16, st));
   V3D_CHECK_HIP(hipMemsetAsync(nbr, 0xFF, (size_t)g.K * cap_out * 4, st));
   V3D_CHECK_HIP(hipMemsetAsync(overflow, 0, 4, st));
-  V3dHash h{out.keys, out.hcap - 1};
+  V3dHash h = v3d_make_hash(out.keys, out.hcap);
   const int tblocks = min(v3d_ceil_div(tickets, V3D_BLOCK), 4096);
   hipLaunchKernelGGL(rb_candidates_kernel, dim3(tblocks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in,
                      g, h, first_ticket, cand_slot, overflow);

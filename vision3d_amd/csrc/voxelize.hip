@@ -256,7 +256,7 @@ extern "C" int v3d_voxelize(const float* points, int n_points, int C, const int3
   int* out_base = ar.take<int>(VOX_MAX_FRAMES + 1);
   if (!ar.ok()) return V3D_EWORKSPACE;
   V3D_CHECK_HIP(hipMemsetAsync(keys, 0xFF, (size_t)((char*)head - (char*)keys) + (size_t)cap * 4, st));
-  V3dHash h{keys, cap - 1};
+  V3dHash h = v3d_make_hash(keys, cap);
   const int ins_blocks = min(v3d_ceil_div(n_points, V3D_BLOCK), 2048);
   hipLaunchKernelGGL(vox_insert_kernel, dim3(ins_blocks), dim3(V3D_BLOCK), 0, st, points, p, h, first, head, pt_slot,
                      next);
