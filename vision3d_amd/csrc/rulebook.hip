@@ -87,7 +87,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_candidates_kernel(const int4* __
     if (rb_candidate(c, k, g, oz, oy, ox)) {
       s = v3d_hash_insert(h, rb_key(c.x, oz, oy, ox, g.out_shape));
       if (s >= 0) atomicMin(&first_ticket[s], (unsigned)t);
-      else atomicOr(overflow, 1);
+      else atomicExch(overflow, 1);
     }
     cand_slot[t] = s;
   }
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(1024) void rb_scan_kernel(int* __restrict__ chunk_c
   }
   if (tid == 0) {
     const int total = carry_s;
-    if (total > cap_out) atomicOr(overflow, 1);
+    if (total > cap_out) atomicExch(overflow, 1);
     *n_out = min(total, cap_out);
   }
 }
@@ -212,12 +212,13 @@ static int fill_geom(RbGeom& g, const int32_t* shape, const int32_t* ks, const i
 // (second_plan.hip).  A V3dRbHash is a coordinate hash of ONE active-site set: keys[hcap] + vals[hcap]
 // (vals[slot] = row index).  The strided rulebook leaves exactly such a hash of its OUTPUT sites behind,
 // which is the table the next stage's submanifold rulebook needs -- the plan reuses it.
-int v3d_i_hash_build(const int32_t* coords, const int32_t* n, int cap, const int32_t* shape, V3dRbHash h, hipStream_t st) {
+int v3d_i_hash_build(const int32_t* coords, const int32_t* n, int cap, const int32_t* shape, V3dRbHash h, int clear,
+                     hipStream_t st) {
   RbGeom g;
   const int32_t ones[3] = {1, 1, 1};
   int rc = fill_geom(g, shape, ones, nullptr, nullptr);
   if (rc) return rc;
-  V3D_CHECK_HIP(hipMemsetAsync(h.keys, 0xFF, (size_t)h.hcap * 8, st));
+  if (clear) V3D_CHECK_HIP(hipMemsetAsync(h.keys, 0xFF, (size_t)h.hcap * 8, st));
   V3dHash hh = v3d_make_hash(h.keys, h.hcap);
   hipLaunchKernelGGL(rb_hash_build_kernel, dim3(min(v3d_ceil_div(cap, V3D_BLOCK), 2048)), dim3(V3D_BLOCK), 0, st,
                      (const int4*)coords, n, cap, g, hh, h.vals);
@@ -244,7 +245,8 @@ int v3d_i_subm_nbr(const int32_t* coords, const int32_t* n, int cap, const int32
 int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap_in, const int32_t* shape,
                           const int32_t* ksize, const int32_t* stride, const int32_t* padding, int32_t* coords_out,
                           int32_t* n_out, int cap_out, int32_t* nbr, int32_t* overflow, V3dRbHash out,
-                          unsigned* first_ticket, int* cand_slot, int* chunk_counts, int32_t* out_shape, hipStream_t st) {
+                          unsigned* first_ticket, int* cand_slot, int* chunk_counts, int32_t* out_shape, int clear,
+                          hipStream_t st) {
   RbGeom g;
   int rc = fill_geom(g, shape, ksize, stride, padding);
   if (rc) return rc;
@@ -255,9 +257,11 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
   const int chunks = v3d_ceil_div(tickets, V3D_SCAN_CHUNK);
   if ((char*)first_ticket != (char*)out.keys + (size_t)out.hcap * 8 || (char*)out.vals != (char*)first_ticket + (size_t)out.hcap * 4)
     return V3D_EINVAL;
-  V3D_CHECK_HIP(hipMemsetAsync(out.keys, 0xFF, (size_t)out.hcap * 16, st));
-  V3D_CHECK_HIP(hipMemsetAsync(nbr, 0xFF, (size_t)g.K * cap_out * 4, st));
-  V3D_CHECK_HIP(hipMemsetAsync(overflow, 0, 4, st));
+  if (clear) {  // overflow flag convention: <= 0 (0 or -1) = fine, 1 = a capacity was hit
+    V3D_CHECK_HIP(hipMemsetAsync(out.keys, 0xFF, (size_t)out.hcap * 16, st));
+    V3D_CHECK_HIP(hipMemsetAsync(nbr, 0xFF, (size_t)g.K * cap_out * 4, st));
+    V3D_CHECK_HIP(hipMemsetAsync(overflow, 0, 4, st));
+  }
   V3dHash h = v3d_make_hash(out.keys, out.hcap);
   const int tblocks = min(v3d_ceil_div(tickets, V3D_BLOCK), 4096);
   hipLaunchKernelGGL(rb_candidates_kernel, dim3(tblocks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in,
@@ -293,7 +297,7 @@ extern "C" int v3d_rulebook_subm(const int32_t* coords, const int32_t* n, int ca
   h.vals = ar.take<int>(hcap);
   h.hcap = hcap;
   if (!ar.ok()) return V3D_EWORKSPACE;
-  int rc = v3d_i_hash_build(coords, n, cap, spatial_shape_host, h, st);
+  int rc = v3d_i_hash_build(coords, n, cap, spatial_shape_host, h, 1, st);
   if (rc) return rc;
   return v3d_i_subm_nbr(coords, n, cap, spatial_shape_host, ksize_host, h, nbr, st);
 }
@@ -324,5 +328,5 @@ extern "C" int v3d_rulebook_sparse(const int32_t* coords_in, const int32_t* n_in
   if (!ar.ok()) return V3D_EWORKSPACE;
   return v3d_i_sparse_rulebook(coords_in, n_in, cap_in, spatial_shape_host, ksize_host, stride_host, padding_host,
                                coords_out, n_out, cap_out, nbr, overflow, h, first_ticket, cand_slot, chunk_counts,
-                               nullptr, st);
+                               nullptr, 1, st);
 }

@@ -52,7 +52,9 @@ struct v3d_backbone {
   // strided-rulebook scratch
   int* cand_slot = nullptr;
   int* chunk_counts = nullptr;
-  int32_t* overflow = nullptr;  // one flag per layer
+  int32_t* overflow = nullptr;  // one flag per layer (<= 0 fine, 1 = capacity hit)
+  char* ff_begin = nullptr;     // arena region reset to 0xFF by one memset per forward
+  size_t ff_bytes = 0;
   int out_channels = 0;
 };
 
@@ -134,25 +136,37 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
 
   // ---- pass 2: size and carve the arena (two passes over the same carving code)
   auto carve = [&](V3dArena& ar) {
+    // ---- everything that must read 0xFF at the start of a forward is contiguous: ONE memset per frame
+    p->ff_begin = ar.base + ar.off;
     p->vox_ws_bytes = v3d_voxelize_workspace(cfg->max_points);
     p->vox_ws = ar.take<char>(p->vox_ws_bytes);
-    p->occupancy = ar.take<int32_t>(p->stages[0].cap);
-    p->mean = ar.take<float>((size_t)p->stages[0].cap * cfg->point_channels);
     for (auto& st : p->stages) {
-      st.coords = ar.take<int32_t>((size_t)st.cap * 4);
-      st.n_dev = ar.take<int32_t>(1);
       st.hash.hcap = v3d_hash_capacity(st.cap);
       st.hash.keys = ar.take<v3d_key_t>(st.hash.hcap);
       st.first_ticket = ar.take<unsigned>(st.hash.hcap);
       st.hash.vals = ar.take<int>(st.hash.hcap);
     }
     p->nbr.resize(p->nbr_cap.size());
-    std::vector<int> rbK(p->nbr_cap.size(), 1);
-    for (auto& L : p->layers) rbK[L.rulebook] = L.K;
-    for (size_t i = 0; i < p->nbr.size(); i++) p->nbr[i] = ar.take<int32_t>((size_t)rbK[i] * p->nbr_cap[i]);
+    std::vector<int> rbK(p->nbr_cap.size(), 1), rbSparse(p->nbr_cap.size(), 0);
+    for (auto& L : p->layers) {
+      rbK[L.rulebook] = L.K;
+      if (!L.d.subm) rbSparse[L.rulebook] = 1;
+    }
+    for (size_t i = 0; i < p->nbr.size(); i++)
+      if (rbSparse[i]) p->nbr[i] = ar.take<int32_t>((size_t)rbK[i] * p->nbr_cap[i]);  // strided tables start as -1
+    p->overflow = ar.take<int32_t>(p->layers.size() + 1);
+    p->ff_bytes = (size_t)((ar.base + ar.off) - p->ff_begin);
+    // ---- the rest needs no per-frame initialisation
+    for (size_t i = 0; i < p->nbr.size(); i++)
+      if (!rbSparse[i]) p->nbr[i] = ar.take<int32_t>((size_t)rbK[i] * p->nbr_cap[i]);
+    p->occupancy = ar.take<int32_t>(p->stages[0].cap);
+    p->mean = ar.take<float>((size_t)p->stages[0].cap * cfg->point_channels);
+    for (auto& st : p->stages) {
+      st.coords = ar.take<int32_t>((size_t)st.cap * 4);
+      st.n_dev = ar.take<int32_t>(1);
+    }
     p->cand_slot = ar.take<int>((size_t)max_tickets);
     p->chunk_counts = ar.take<int>((size_t)(max_tickets / V3D_SCAN_CHUNK + 2));
-    p->overflow = ar.take<int32_t>(p->layers.size() + 1);
     for (auto& L : p->layers) {
       L.weight = ar.take<float>((size_t)L.K * L.d.cin * L.d.cout);
       L.scale = ar.take<float>(L.d.cout);
@@ -170,7 +184,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
   V3dArena ar(p->arena, p->arena_bytes);
   carve(ar);
   if (!ar.ok()) { (void)hipFree(p->arena); delete p; return V3D_EWORKSPACE; }
-  e = hipMemset(p->overflow, 0, (p->layers.size() + 1) * 4);
+  e = hipMemset(p->ff_begin, 0xFF, p->ff_bytes);
   if (e != hipSuccess) { (void)hipFree(p->arena); delete p; return (int)e; }
   *out = p;
   return V3D_OK;
@@ -206,8 +220,10 @@ extern "C" int v3d_backbone_forward(v3d_backbone* p, const float* points, int n_
   hipStream_t st = (hipStream_t)stream;
   const v3d_backbone_config& c = p->cfg;
   PlanStage& s0 = p->stages[0];
-  int rc = v3d_voxelize(points, n_points, c.point_channels, frame_offsets_host, B, c.voxel_size, c.bounds, c.max_pts,
-                        c.max_voxels, nullptr, s0.coords, p->occupancy, p->mean, s0.n_dev, p->vox_ws, p->vox_ws_bytes, st);
+  V3D_CHECK_HIP(hipMemsetAsync(p->ff_begin, 0xFF, p->ff_bytes, st));  // all hash tables, strided nbr tables, flags
+  int rc = v3d_i_voxelize(points, n_points, c.point_channels, frame_offsets_host, B, c.voxel_size, c.bounds, c.max_pts,
+                          c.max_voxels, nullptr, s0.coords, p->occupancy, p->mean, s0.n_dev, p->vox_ws, p->vox_ws_bytes, 0,
+                          st);
   if (rc) return rc;
   bool hash0_done = false;
   const float* feat = p->mean;
@@ -218,7 +234,7 @@ extern "C" int v3d_backbone_forward(v3d_backbone* p, const float* points, int n_
     if (L.builds_rulebook) {
       if (L.d.subm) {
         if (!si.hash_ready_by_sparse && !(L.stage_in == 0 && hash0_done)) {
-          rc = v3d_i_hash_build(si.coords, si.n_dev, si.cap, si.shape, si.hash, st);
+          rc = v3d_i_hash_build(si.coords, si.n_dev, si.cap, si.shape, si.hash, 0, st);
           if (rc) return rc;
           if (L.stage_in == 0) hash0_done = true;
         }
@@ -226,7 +242,7 @@ extern "C" int v3d_backbone_forward(v3d_backbone* p, const float* points, int n_
       } else {
         rc = v3d_i_sparse_rulebook(si.coords, si.n_dev, si.cap, si.shape, L.d.ksize, L.d.stride, L.d.padding, so.coords,
                                    so.n_dev, so.cap, p->nbr[L.rulebook], p->overflow + l, so.hash, so.first_ticket,
-                                   p->cand_slot, p->chunk_counts, nullptr, st);
+                                   p->cand_slot, p->chunk_counts, nullptr, 0, st);
       }
       if (rc) return rc;
     }

@@ -8,10 +8,17 @@ struct V3dRbHash {
   unsigned hcap;  // power of two
 };
 
-int v3d_i_hash_build(const int32_t* coords, const int32_t* n, int cap, const int32_t* shape, V3dRbHash h, hipStream_t st);
+// `clear` = 0 on any of these: the caller has pre-filled the tables with 0xFF itself (one arena-wide memset).
+int v3d_i_voxelize(const float* points, int n_points, int C, const int32_t* frame_offsets_host, int B,
+                   const float* voxel_size_host, const float* bounds_host, int max_pts, int max_voxels, float* voxels,
+                   int32_t* coords, int32_t* occupancy, float* mean, int32_t* n_voxels, void* workspace,
+                   size_t workspace_bytes, int clear_tables, hipStream_t st);
+int v3d_i_hash_build(const int32_t* coords, const int32_t* n, int cap, const int32_t* shape, V3dRbHash h, int clear,
+                     hipStream_t st);
 int v3d_i_subm_nbr(const int32_t* coords, const int32_t* n, int cap, const int32_t* shape, const int32_t* ksize,
                    V3dRbHash h, int32_t* nbr, hipStream_t st);
 int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap_in, const int32_t* shape,
                           const int32_t* ksize, const int32_t* stride, const int32_t* padding, int32_t* coords_out,
                           int32_t* n_out, int cap_out, int32_t* nbr, int32_t* overflow, V3dRbHash out,
-                          unsigned* first_ticket, int* cand_slot, int* chunk_counts, int32_t* out_shape, hipStream_t st);
+                          unsigned* first_ticket, int* cand_slot, int* chunk_counts, int32_t* out_shape, int clear,
+                          hipStream_t st);

@@ -15,10 +15,13 @@
 //               sequential loop.  The same thread walks its voxel's list, keeps the max_pts smallest
 //               point indices (== first-come order), writes coords/occupancy/points and the mean.
 // No host synchronisation: the voxel count stays in device memory.
-#include "v3d_common.h"
+#include "v3d_internal.h"
 
 #define VOX_MAX_FRAMES 64
 #define VOX_MAX_PTS 8
+// points per block of the count/emit kernels: ONE 256-thread round, so the per-voxel list walks of a
+// whole frame run concurrently (a 2048-point chunk serialised 8 latency-bound rounds per block)
+#define VOX_CHUNK 256
 
 struct VoxParams {
   float vs[3], lo[3];
@@ -75,9 +78,9 @@ __global__ __launch_bounds__(V3D_BLOCK) void vox_count_kernel(const int* __restr
                                                               const unsigned* __restrict__ first, int n,
                                                               int* __restrict__ chunk_counts) {
   __shared__ int lds[4];
-  const int base = blockIdx.x * V3D_SCAN_CHUNK;
+  const int base = blockIdx.x * VOX_CHUNK;
   int cnt = 0;
-  for (int r = 0; r < V3D_SCAN_CHUNK / V3D_BLOCK; r++) {
+  for (int r = 0; r < VOX_CHUNK / V3D_BLOCK; r++) {
     int tot;
     v3d_block_rank(vox_is_first(pt_slot, first, base + r * V3D_BLOCK + threadIdx.x, n), tot, lds);
     cnt += tot;
@@ -123,9 +126,9 @@ __global__ __launch_bounds__(1024) void vox_scan_kernel(int* __restrict__ chunk_
     if (pos >= p.n_points) {
       val = carry_s;
     } else {
-      const int chunk = pos / V3D_SCAN_CHUNK;
+      const int chunk = pos / VOX_CHUNK;
       int cnt = 0;
-      for (int i = chunk * V3D_SCAN_CHUNK + lane; i < pos; i += 64) cnt += vox_is_first(pt_slot, first, i, p.n_points);
+      for (int i = chunk * VOX_CHUNK + lane; i < pos; i += 64) cnt += vox_is_first(pt_slot, first, i, p.n_points);
       for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
       val = chunk_counts[chunk] + cnt;
     }
@@ -153,9 +156,9 @@ __global__ __launch_bounds__(V3D_BLOCK) void vox_emit_kernel(const float* __rest
                                                              float* __restrict__ voxels, int* __restrict__ coords,
                                                              int* __restrict__ occupancy, float* __restrict__ mean) {
   __shared__ int lds[4];
-  const int base = blockIdx.x * V3D_SCAN_CHUNK;
+  const int base = blockIdx.x * VOX_CHUNK;
   int running = chunk_offsets[blockIdx.x];
-  for (int r = 0; r < V3D_SCAN_CHUNK / V3D_BLOCK; r++) {
+  for (int r = 0; r < VOX_CHUNK / V3D_BLOCK; r++) {
     const int i = base + r * V3D_BLOCK + threadIdx.x;
     const bool flag = vox_is_first(pt_slot, first, i, p.n_points);
     int tot;
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void vox_emit_kernel(const float* __rest
 extern "C" size_t v3d_voxelize_workspace(int n_points) {
   const size_t n = (size_t)(n_points > 0 ? n_points : 1);
   const size_t cap = v3d_hash_capacity((long long)n);
-  const size_t chunks = (n + V3D_SCAN_CHUNK - 1) / V3D_SCAN_CHUNK;
+  const size_t chunks = (n + VOX_CHUNK - 1) / VOX_CHUNK;
   return v3d_align(cap * 8) + 2 * v3d_align(cap * 4) + 2 * v3d_align(n * 4) + v3d_align(chunks * 4) +
          2 * v3d_align((VOX_MAX_FRAMES + 1) * 4) + 256;
 }
@@ -216,7 +219,16 @@ extern "C" int v3d_voxelize(const float* points, int n_points, int C, const int3
                             const float* voxel_size_host, const float* bounds_host, int max_pts, int max_voxels,
                             float* voxels, int32_t* coords, int32_t* occupancy, float* mean, int32_t* n_voxels,
                             void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
+  return v3d_i_voxelize(points, n_points, C, frame_offsets_host, B, voxel_size_host, bounds_host, max_pts, max_voxels,
+                        voxels, coords, occupancy, mean, n_voxels, workspace, workspace_bytes, 1, (hipStream_t)stream);
+}
+
+// clear_tables = 0: the caller has already filled the head of the workspace (hash keys | first | head) with
+// 0xFF, e.g. as part of one arena-wide memset (second_plan.hip).
+int v3d_i_voxelize(const float* points, int n_points, int C, const int32_t* frame_offsets_host, int B,
+                   const float* voxel_size_host, const float* bounds_host, int max_pts, int max_voxels, float* voxels,
+                   int32_t* coords, int32_t* occupancy, float* mean, int32_t* n_voxels, void* workspace,
+                   size_t workspace_bytes, int clear_tables, hipStream_t st) {
   if (n_points < 0 || C < 3 || B < 1 || B > VOX_MAX_FRAMES || max_pts < 1 || max_pts > VOX_MAX_PTS || max_voxels < 1)
     return V3D_EINVAL;
   if (!frame_offsets_host || !voxel_size_host || !bounds_host || !coords || !occupancy || !n_voxels) return V3D_EINVAL;
@@ -243,7 +255,7 @@ extern "C" int v3d_voxelize(const float* points, int n_points, int C, const int3
     if (b > 0 && p.frame_off[b] < p.frame_off[b - 1]) return V3D_EINVAL;
   }
   const unsigned cap = v3d_hash_capacity(n_points);
-  const int chunks = v3d_ceil_div(n_points, V3D_SCAN_CHUNK);
+  const int chunks = v3d_ceil_div(n_points, VOX_CHUNK);
   V3dArena ar(workspace, workspace_bytes);
   // keys | first | head are contiguous: ONE memset(0xFF) resets all three (EMPTY / UINT_MAX / -1)
   v3d_key_t* keys = ar.take<v3d_key_t>(cap);
@@ -255,7 +267,8 @@ extern "C" int v3d_voxelize(const float* points, int n_points, int C, const int3
   int* frame_base = ar.take<int>(VOX_MAX_FRAMES + 1);
   int* out_base = ar.take<int>(VOX_MAX_FRAMES + 1);
   if (!ar.ok()) return V3D_EWORKSPACE;
-  V3D_CHECK_HIP(hipMemsetAsync(keys, 0xFF, (size_t)((char*)head - (char*)keys) + (size_t)cap * 4, st));
+  if (clear_tables)
+    V3D_CHECK_HIP(hipMemsetAsync(keys, 0xFF, (size_t)((char*)head - (char*)keys) + (size_t)cap * 4, st));
   V3dHash h = v3d_make_hash(keys, cap);
   const int ins_blocks = min(v3d_ceil_div(n_points, V3D_BLOCK), 2048);
   hipLaunchKernelGGL(vox_insert_kernel, dim3(ins_blocks), dim3(V3D_BLOCK), 0, st, points, p, h, first, head, pt_slot,

@@ -144,8 +144,9 @@ class BackbonePlan(object):
             _view(c.value, (cap.value, 4), torch.int32, self.device), _view(n.value, (1,), torch.int32, self.device), list(shape)
 
     def overflow(self):
+        """(n_layers + 1,) int32 device flags of the last forward: 1 where a capacity was hit."""
         ptr = L.lib().v3d_backbone_overflow_flags(self._handle)
-        return _view(ptr, (len(self.layers) + 1,), torch.int32, self.device)
+        return (_view(ptr, (len(self.layers) + 1,), torch.int32, self.device) > 0).to(torch.int32)
 
 
 class _DevMem(object):

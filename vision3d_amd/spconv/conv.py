@@ -63,7 +63,7 @@ def build_sparse_rulebook(x, ksize, stride, padding):
     else:
         nbr.fill_(-1)
     n_host, ovf = torch.stack((n_out, overflow)).flatten().tolist()
-    if ovf:
+    if ovf > 0:
         raise RuntimeError("sparse rulebook overflow (internal capacity bound violated)")
     return Rulebook(nbr, cap_out, n_host, n_out, coords_out[:n_host], out_shape)
 
