@@ -38,8 +38,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (configs[1] = 1)")
     ap.add_argument("--points", type=int, default=16384)
-    ap.add_argument("--path", choices=["fused", "eager"], default="fused",
-                    help="fused: native backbone plan (one C call per frame); eager: per-op python -> C ABI")
+    ap.add_argument("--path", choices=["native", "fused", "eager"], default="native",
+                    help="native: backbone plan + MFMA dense head; fused: backbone plan + torch (MIOpen) RPN; "
+                         "eager: per-op python -> C ABI")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch event timing pass (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=3)
@@ -80,8 +81,10 @@ def main():
 
     def step():
         with torch.no_grad():
+            if args.path == "native":
+                return model.inference_points(clouds, anchors, dense="mfma")
             if args.path == "fused":
-                return model.inference_points(clouds, anchors)
+                return model.inference_points(clouds, anchors, dense="torch")
             item = pre(dict(points=clouds, anchors=anchors))
             return model.inference(item)
 
@@ -180,12 +183,13 @@ def main():
     if rank == 0:
         line = dict(metric="frames/sec SECOND fwd, 16k-pt KITTI cloud", value=value, unit="frames/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
-                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                    scaling="weak", vs_baseline=None, dtype=("f32 (sparse backbone: fp32 MFMA; dense head: bf16x3 split = fp32-class)" if args.path == "native" else "f32"), data="synthetic",
                     config=dict(workload="SECOND (VoxelNet spconv backbone + BEV head) forward, bs=1, 16384-pt synthetic "
                                          "KITTI-range cloud per GPU (BASELINE configs[1])",
                                 frames_per_gpu_per_step=args.batch, points_per_frame=args.points,
                                 parallelism=f"frame-parallel replicas x{world}",
-                                path=("native backbone plan + torch RPN" if args.path == "fused" else "eager python -> C ABI")),
+                                path={"native": "native backbone plan + bf16x3 MFMA dense head", "fused": "native backbone plan + torch RPN",
+                                      "eager": "eager python -> C ABI"}[args.path]),
                     roofline=roofline, cpu_baseline=cpu_baseline, stages=stages,
                     n_proposals=int(out[0].shape[0]))
         print(json.dumps(line))

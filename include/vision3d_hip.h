@@ -164,6 +164,28 @@ int v3d_backbone_layer_output(v3d_backbone* plan, int layer, float** features, i
 int32_t* v3d_backbone_occupancy(v3d_backbone* plan);       /* (cap0) i32, voxel occupancies of the last forward */
 int32_t* v3d_backbone_overflow_flags(v3d_backbone* plan);  /* (n_layers+1) i32 device flags, nonzero = capacity hit */
 
+/* ---- A8/A9: dense 2-D convolutions of the BEV head on the matrix cores (csrc/dense_conv.hip).
+ * Replaces nn.Conv2d + BatchNorm2d(eval) + ReLU (detector/second.py:58-94) and the 1x1 heads
+ * (detector/proposal.py:19-22).  "bf16 x 3" split precision: x = hi + lo (two bf16), products evaluated as
+ * hi*hi + hi*lo + lo*hi with fp32 accumulation => fp32-class accuracy.  Activations are exchanged as two
+ * bf16 NHWC planes (B,H,W,C) "hi" and "lo"; weights are packed once with v3d_conv2d_pack_weights.
+ * Cin % 32 == 0, ksize in {1,3} (stride 1, "same" zero padding).  Outputs: split NHWC planes (Cout % 8 == 0)
+ * and/or fp32 NCHW (B,Cout,H,W). */
+size_t v3d_conv2d_weight_image_bytes(int Cin, int Cout, int ksize);
+/* weight (Cout,Cin,k,k) f32; optional per-output-channel scale (folded BatchNorm) multiplied in. */
+int v3d_conv2d_pack_weights(const float* weight, const float* scale, int Cout, int Cin, int ksize, void* image,
+                            v3d_stream_t stream);
+int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias, int relu,
+                           int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo, float* y_nchw,
+                           v3d_stream_t stream);
+/* .dense() of the last sparse stage straight into that input format: planes (B,H,W,C*D), channel = c*D + z. */
+int v3d_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
+                           const int32_t* spatial_shape_host, void* out_hi, void* out_lo, v3d_stream_t stream);
+int v3d_nchw_to_split_nhwc(const float* x, int B, int C, int H, int W, void* out_hi, void* out_lo, v3d_stream_t stream);
+/* v3d_backbone_forward with a choice of output formats (any may be NULL): fp32 (B,C*D,H,W) and/or split planes. */
+int v3d_backbone_forward2(v3d_backbone* plan, const float* points, int n_points, const int32_t* frame_offsets_host,
+                          int B, float* dense_nchw, void* dense_hi, void* dense_lo, v3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

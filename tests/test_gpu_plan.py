@@ -75,7 +75,7 @@ def test_inference_points_equals_item_path():
     anchors = AnchorGenerator(cfg).anchors.cuda()
     clouds = [torch.from_numpy(synth.make_cloud(s)).cuda() for s in (1, 2)]
     with torch.no_grad():
-        a = model.inference_points(clouds, anchors)
+        a = model.inference_points(clouds, anchors, dense="torch")   # same dense kernels as the item path
         b = model.inference(Preprocessor(cfg)(dict(points=[c.clone() for c in clouds], anchors=anchors)))
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())

@@ -1,0 +1,347 @@
+// dense_conv.hip -- dense 2-D convolutions of the BEV head (A8: RPN, A9: 1x1 heads) on the matrix cores.
+//
+// Reference: nn.Conv2d + BatchNorm2d + ReLU stacks (vision3d/detector/second.py:58-94) and the 1x1 heads
+// (detector/proposal.py:19-22), executed by cuDNN in fp32.  This is the only genuinely dense, GEMM-shaped
+// part of the model (63.4 GFLOP/frame), so it is the part that goes to MFMA (BASELINE.json north_star).
+//
+// Precision: "bf16 x 3".  Every fp32 operand is split once into hi = bf16(x), lo = bf16(x - hi) and the
+// product is evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation (v_mfma_f32_16x16x32_bf16).  The
+// dropped lo*lo term and the 16-bit residual of each operand are ~2^-17 relative per product, i.e.
+// fp32-class accuracy (tests: <= 1e-4 of the fp32 reference through all 7 layers) at 3/16 of the
+// fp32-MFMA cost.  Activations travel between layers ALREADY split (two bf16 NHWC planes = the bytes of
+// one fp32 tensor), weights are split and packed once per model, so the inner loop has no conversions.
+//
+// Kernel: implicit GEMM, M = B*H*W pixels (flattened), N = Cout, K = taps * Cin.
+//   workgroup  64 pixels x 128 couts, 4 waves as 2 (pixel halves) x 2 (cout halves); wave tile 32 x 64
+//              = 2 x 4 MFMA fragments, 8 fp32 accumulators (32 VGPRs)
+//   k-step     32 input channels of one tap: A (64 px x 32 ch x {hi,lo}) gathered with zero halo,
+//              B (32 ch x 128 cout x {hi,lo}) copied linearly from the pre-packed weight image
+//   LDS        fragment-major images: the 16 bytes a lane needs sit at lane*16 inside its fragment, so
+//              every ds_read_b128 is lane-linear (conflict free); double buffered, one barrier per k-step;
+//              global loads of step s+1 are in flight (registers) during the 24 MFMAs of step s
+//   epilogue   accumulators -> LDS (fp32) -> bias + ReLU -> either the next layer's split bf16 NHWC planes
+//              (16-byte stores) or fp32 NCHW for the consumer outside this file.
+#include "v3d_internal.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bf16_t;  // storage type at the C ABI
+
+#define DC_BM 64
+#define DC_BN 128
+#define DC_KC 32  // input channels per k-step
+#define DC_THREADS 256
+
+__device__ __forceinline__ bf16_t f32_to_bf16_rne(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7F800000u) == 0x7F800000u) return (bf16_t)(u >> 16);  // inf / nan: truncate
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
+  hi = f32_to_bf16_rne(x);
+  lo = f32_to_bf16_rne(x - bf16_to_f32(hi));
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights (Cout, Cin, kh, kw) fp32 [+ per-cout scale folded in] -> packed split image
+// image[s][plane][nf][kg][j][e]  with  s = tap*(Cin/32) + chunk, plane in {hi, lo}, nf = cout/16,
+// kg = (cin%32)/8, j = cout%16, e = cin%8   -- exactly the byte order of the B tile in LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ void dc_pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int Cin,
+                                       int ks, int CoutPad, bf16_t* __restrict__ img) {
+  const int taps = ks * ks, chunks = Cin / DC_KC;
+  const long long total = (long long)taps * chunks * (CoutPad / 16) * 4 * 16 * 8;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    long long r = t;
+    const int e = (int)(r % 8); r /= 8;
+    const int j = (int)(r % 16); r /= 16;
+    const int kg = (int)(r % 4); r /= 4;
+    const int nf = (int)(r % (CoutPad / 16)); r /= (CoutPad / 16);
+    const int chunk = (int)(r % chunks); r /= chunks;
+    const int tap = (int)r;
+    const int co = nf * 16 + j, ci = chunk * DC_KC + kg * 8 + e;
+    float v = 0.f;
+    if (co < Cout) {
+      v = w[((size_t)co * Cin + ci) * taps + tap];
+      if (scale) v *= scale[co];
+    }
+    bf16_t hi, lo;
+    split_bf16(v, hi, lo);
+    const size_t step = (size_t)tap * chunks + chunk;
+    const size_t plane_elems = (size_t)(CoutPad / 16) * 4 * 16 * 8;
+    const size_t off = ((size_t)(nf * 4 + kg) * 16 + j) * 8 + e;
+    img[step * 2 * plane_elems + off] = hi;
+    img[step * 2 * plane_elems + plane_elems + off] = lo;
+  }
+}
+
+extern "C" size_t v3d_conv2d_weight_image_bytes(int Cin, int Cout, int ksize) {
+  const int pad = (Cout + DC_BN - 1) / DC_BN * DC_BN;
+  return (size_t)ksize * ksize * (Cin / DC_KC) * 2 * (size_t)pad * DC_KC * sizeof(bf16_t);
+}
+
+extern "C" int v3d_conv2d_pack_weights(const float* weight, const float* scale, int Cout, int Cin, int ksize,
+                                       void* image, v3d_stream_t stream) {
+  if (!weight || !image || Cout < 1 || Cin < DC_KC || Cin % DC_KC || (ksize != 1 && ksize != 3)) return V3D_EINVAL;
+  const int pad = (Cout + DC_BN - 1) / DC_BN * DC_BN;
+  hipLaunchKernelGGL(dc_pack_weights_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, weight, scale, Cout, Cin, ksize,
+                     pad, (bf16_t*)image);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// .dense() straight into the conv input format: zero planes + scatter of split values.
+// out[(b*H + y)*W + x][c*D + z]  (the reference's (B, C*D, H, W) view, channels innermost)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(V3D_BLOCK) void densify_split_kernel(const float* __restrict__ feat,
+                                                                  const int4* __restrict__ coords,
+                                                                  const int* __restrict__ n_ptr, int cap, int C, int D,
+                                                                  int H, int Wd, bf16_t* __restrict__ hi,
+                                                                  bf16_t* __restrict__ lo) {
+  const int n = min(*n_ptr, cap);
+  const long long total = (long long)n * C;
+  for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * V3D_BLOCK) {
+    const int i = (int)(t / C), ch = (int)(t % C);
+    const int4 c = coords[i];
+    const size_t o = (((size_t)c.x * H + c.z) * Wd + c.w) * ((size_t)C * D) + (size_t)ch * D + c.y;
+    bf16_t h, l;
+    split_bf16(feat[t], h, l);
+    hi[o] = h;
+    lo[o] = l;
+  }
+}
+
+extern "C" int v3d_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
+                                      const int32_t* spatial_shape_host, void* out_hi, void* out_lo,
+                                      v3d_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!feat || !coords || !n || cap < 1 || B < 1 || C < 1 || !spatial_shape_host || !out_hi || !out_lo) return V3D_EINVAL;
+  const int D = spatial_shape_host[0], H = spatial_shape_host[1], Wd = spatial_shape_host[2];
+  const size_t bytes = (size_t)B * H * Wd * C * D * sizeof(bf16_t);
+  V3D_CHECK_HIP(hipMemsetAsync(out_hi, 0, bytes, st));
+  V3D_CHECK_HIP(hipMemsetAsync(out_lo, 0, bytes, st));
+  const long long total = (long long)cap * C;
+  const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
+  hipLaunchKernelGGL(densify_split_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(V3D_BLOCK), 0, st, feat,
+                     (const int4*)coords, n, cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+// fp32 NCHW -> split NHWC planes (entry for callers that hold a torch-style tensor)
+__global__ void nchw_to_split_nhwc_kernel(const float* __restrict__ x, int B, int C, int HW, bf16_t* __restrict__ hi,
+                                          bf16_t* __restrict__ lo) {
+  const long long total = (long long)B * C * HW;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(t % C);
+    const long long bp = t / C;  // b*HW + p
+    const int b = (int)(bp / HW), p = (int)(bp % HW);
+    bf16_t h, l;
+    split_bf16(x[((size_t)b * C + c) * HW + p], h, l);
+    hi[t] = h;
+    lo[t] = l;
+  }
+}
+
+extern "C" int v3d_nchw_to_split_nhwc(const float* x, int B, int C, int H, int W, void* out_hi, void* out_lo,
+                                      v3d_stream_t stream) {
+  if (!x || !out_hi || !out_lo || B < 1 || C < 1 || H < 1 || W < 1) return V3D_EINVAL;
+  hipLaunchKernelGGL(nchw_to_split_nhwc_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, B, C, H * W,
+                     (bf16_t*)out_hi, (bf16_t*)out_lo);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the convolution
+// ------------------------------------------------------------------------------------------------
+struct DcParams {
+  int B, H, W, Cin, Cout, CoutPad, ks, relu;
+  int M;          // B*H*W
+  int cout_store; // channels actually written
+};
+
+template <int KS>
+__global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16_t* __restrict__ x_hi,
+                                                                      const bf16_t* __restrict__ x_lo,
+                                                                      const bf16_t* __restrict__ w_img,
+                                                                      const float* __restrict__ bias, const DcParams p,
+                                                                      bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo,
+                                                                      float* __restrict__ y_nchw) {
+  // LDS: 2 x (A 8 KB + B 16 KB) for the loop; reused as a 64 x 128 fp32 tile (32 KB) by the epilogue
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (8192 + 16384)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;  // pixel half / cout half
+  const int m0 = blockIdx.x * DC_BM;
+  const int n0 = blockIdx.y * DC_BN;
+  const int chunks = p.Cin / DC_KC;
+  const int steps = KS * KS * chunks;
+
+  // ---- this thread's A-gather role: pixel a_px of the tile, 16-byte part a_kg of the 64-byte channel slice
+  const int a_px = tid >> 2, a_kg = tid & 3;
+  const int am = m0 + a_px;
+  const bool a_live = am < p.M;
+  int a_b = 0, a_h = 0, a_w = 0;
+  if (a_live) {
+    a_b = am / (p.H * p.W);
+    const int rem = am - a_b * p.H * p.W;
+    a_h = rem / p.W;
+    a_w = rem - a_h * p.W;
+  }
+  // LDS destination of that 16-byte piece inside an A image (fragment-major): ((f*4 + kg)*16 + r)*16 bytes
+  const int a_dst = (((a_px >> 4) * 4 + a_kg) * 16 + (a_px & 15)) * 16;
+
+  uint4 ra[2], rb[4];
+  auto load_step = [&](int s) {
+    const int tap = s / chunks, chunk = s - tap * chunks;
+    const int dy = KS == 3 ? tap / 3 - 1 : 0, dx = KS == 3 ? tap % 3 - 1 : 0;
+    const int hh = a_h + dy, ww = a_w + dx;
+    const bool ok = a_live && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
+    if (ok) {
+      const size_t off = (((size_t)a_b * p.H + hh) * p.W + ww) * p.Cin + chunk * DC_KC + a_kg * 8;
+      ra[0] = *reinterpret_cast<const uint4*>(x_hi + off);
+      ra[1] = *reinterpret_cast<const uint4*>(x_lo + off);
+    } else {
+      ra[0] = make_uint4(0, 0, 0, 0);
+      ra[1] = make_uint4(0, 0, 0, 0);
+    }
+    // B: 16 KB of this (step, cout tile): [plane][nf 8][kg 4][j 16][8] -> plane stride = CoutPad/16*4*16*8 elems
+    const size_t plane_elems = (size_t)(p.CoutPad / 16) * 4 * 16 * 8;
+    const bf16_t* wb = w_img + (size_t)s * 2 * plane_elems + (size_t)(n0 / 16) * 4 * 16 * 8;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int q = tid + i * DC_THREADS;      // 0..1023 16-byte pieces: plane = q / 512
+      const int plane = q >> 9, within = q & 511;
+      rb[i] = *reinterpret_cast<const uint4*>(wb + (size_t)plane * plane_elems + (size_t)within * 8);
+    }
+  };
+  auto store_step = [&](int buf) {
+    unsigned char* A = smem + buf * (8192 + 16384);
+    unsigned char* Bm = A + 8192;
+    *reinterpret_cast<uint4*>(A + a_dst) = ra[0];          // hi plane
+    *reinterpret_cast<uint4*>(A + 4096 + a_dst) = ra[1];   // lo plane
+#pragma unroll
+    for (int i = 0; i < 4; i++) *reinterpret_cast<uint4*>(Bm + (size_t)(tid + i * DC_THREADS) * 16) = rb[i];
+  };
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+  for (int s = 0; s < steps; s++) {
+    const int buf = s & 1;
+    if (s + 1 < steps) load_step(s + 1);  // global loads in flight during the MFMAs
+    const unsigned char* A = smem + buf * (8192 + 16384);
+    const unsigned char* Bm = A + 8192;
+    bf16x8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int f = wr * 2 + i;
+      ah[i] = *reinterpret_cast<const bf16x8*>(A + (f * 64 + lane) * 16);
+      al[i] = *reinterpret_cast<const bf16x8*>(A + 4096 + (f * 64 + lane) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int nf = wc * 4 + j;
+      bh[j] = *reinterpret_cast<const bf16x8*>(Bm + (nf * 64 + lane) * 16);
+      bl[j] = *reinterpret_cast<const bf16x8*>(Bm + 8192 + (nf * 64 + lane) * 16);
+    }
+    // term-major order: 8 independent accumulators between two uses of the same one
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    if (s + 1 < steps) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS tile [64 px][128 + 4 pad] fp32
+  float* tile = reinterpret_cast<float*>(smem);
+  constexpr int TS = DC_BN + 4;
+  static_assert(DC_BM * TS * 4 <= 2 * (8192 + 16384), "epilogue tile must fit the loop buffers");
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = wr * 32 + i * 16 + (lane >> 4) * 4 + r;  // D: row = (lane>>4)*4 + r, col = lane&15
+        const int col = wc * 64 + j * 16 + (lane & 15);
+        tile[row * TS + col] = acc[i][j][r];
+      }
+  __syncthreads();
+  if (y_hi) {  // split bf16 NHWC planes: thread handles 8 consecutive couts of one pixel, 16-byte stores
+    for (int q = tid; q < DC_BM * (DC_BN / 8); q += DC_THREADS) {
+      const int row = q / (DC_BN / 8), c8 = q % (DC_BN / 8);
+      const int m = m0 + row, co = n0 + c8 * 8;
+      if (m >= p.M || co >= p.cout_store) continue;
+      union { bf16_t h[8]; uint4 v; } uh, ul;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float v = tile[row * TS + c8 * 8 + e] + (bias ? bias[co + e] : 0.f);
+        if (p.relu) v = fmaxf(v, 0.f);
+        split_bf16(v, uh.h[e], ul.h[e]);
+      }
+      *reinterpret_cast<uint4*>(y_hi + (size_t)m * p.cout_store + co) = uh.v;
+      *reinterpret_cast<uint4*>(y_lo + (size_t)m * p.cout_store + co) = ul.v;
+    }
+  }
+  if (y_nchw) {  // fp32 (B, cout_store, H, W): thread handles 4 consecutive pixels of one cout
+    const int HW = p.H * p.W;
+    for (int q = tid; q < (DC_BM / 4) * DC_BN; q += DC_THREADS) {
+      const int col = q / (DC_BM / 4), r4 = q % (DC_BM / 4);
+      const int co = n0 + col;
+      if (co >= p.cout_store) continue;
+      const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int m = m0 + r4 * 4 + e;
+        if (m >= p.M) continue;
+        float v = tile[(r4 * 4 + e) * TS + col] + bv;
+        if (p.relu) v = fmaxf(v, 0.f);
+        const int b = m / HW, pix = m - b * HW;
+        y_nchw[((size_t)b * p.cout_store + co) * HW + pix] = v;
+      }
+    }
+  }
+}
+
+extern "C" int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
+                                      int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
+                                      float* y_nchw, v3d_stream_t stream) {
+  if (!x_hi || !x_lo || !weight_image || B < 1 || H < 1 || W < 1 || Cout < 1) return V3D_EINVAL;
+  if (Cin < DC_KC || Cin % DC_KC || (ksize != 1 && ksize != 3)) return V3D_EUNSUPPORTED;
+  if ((y_hi == nullptr) != (y_lo == nullptr) || (!y_hi && !y_nchw)) return V3D_EINVAL;
+  if (y_hi && (Cout % 8)) return V3D_EUNSUPPORTED;
+  DcParams p;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ks = ksize; p.relu = relu;
+  p.CoutPad = (Cout + DC_BN - 1) / DC_BN * DC_BN;
+  p.M = B * H * W;
+  p.cout_store = Cout;
+  dim3 grid(v3d_ceil_div(p.M, DC_BM), p.CoutPad / DC_BN);
+  hipStream_t st = (hipStream_t)stream;
+  if (ksize == 3)
+    hipLaunchKernelGGL(conv2d_bf16x3_kernel<3>, grid, dim3(DC_THREADS), 0, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+                       (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo, y_nchw);
+  else
+    hipLaunchKernelGGL(conv2d_bf16x3_kernel<1>, grid, dim3(DC_THREADS), 0, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+                       (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo, y_nchw);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}

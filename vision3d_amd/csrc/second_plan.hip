@@ -215,6 +215,12 @@ extern "C" int v3d_backbone_set_layer(v3d_backbone* p, int layer, const float* w
 
 extern "C" int v3d_backbone_forward(v3d_backbone* p, const float* points, int n_points,
                                     const int32_t* frame_offsets_host, int B, float* dense_out, v3d_stream_t stream) {
+  return v3d_backbone_forward2(p, points, n_points, frame_offsets_host, B, dense_out, nullptr, nullptr, stream);
+}
+
+extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n_points,
+                                     const int32_t* frame_offsets_host, int B, float* dense_out, void* dense_hi,
+                                     void* dense_lo, v3d_stream_t stream) {
   if (!p || !frame_offsets_host || B < 1 || B > p->cfg.max_batch || n_points < 0 || n_points > p->cfg.max_points)
     return V3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -254,6 +260,11 @@ extern "C" int v3d_backbone_forward(v3d_backbone* p, const float* points, int n_
   if (dense_out) {
     PlanStage& sl = p->stages.back();
     rc = v3d_densify(feat, sl.coords, sl.n_dev, sl.cap, B, p->out_channels, sl.shape, dense_out, st);
+    if (rc) return rc;
+  }
+  if (dense_hi || dense_lo) {
+    PlanStage& sl = p->stages.back();
+    rc = v3d_densify_nhwc_split(feat, sl.coords, sl.n_dev, sl.cap, B, p->out_channels, sl.shape, dense_hi, dense_lo, st);
     if (rc) return rc;
   }
   return V3D_OK;

@@ -64,6 +64,14 @@ class ProposalLayer(nn.Module):
     def inference(self, feature_map, anchors):
         """-> (boxes (K,7), batch_idx (K,), class_idx (K,), scores (K,)), by decreasing score."""
         cls_map, reg_map = self(feature_map)
+        return self.inference_from_maps(cls_map, reg_map, anchors)
+
+    def maps_from_fused(self, maps):
+        """(B, n_anchor*(1+DOF), H, W) = [cls | reg] channels of the fused 1x1 head -> (cls_map, reg_map)."""
+        n_anchor = self.cfg.NUM_CLASSES * self.cfg.NUM_YAW
+        return self.reshape_cls(maps[:, :n_anchor].contiguous()), self.reshape_reg(maps[:, n_anchor:].contiguous())
+
+    def inference_from_maps(self, cls_map, reg_map, anchors):
         score_map = cls_map.sigmoid_()
         B, n_cls = score_map.shape[:2]
         scores, anchor_idx = score_map.view(B, n_cls, -1).topk(self.TOPK, -1)

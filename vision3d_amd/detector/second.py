@@ -133,6 +133,32 @@ class Second(nn.Module):
         plan = self.backbone_plan(len(clouds), cap_pts)
         return plan.forward(flat, offsets)
 
-    def inference_points(self, clouds, anchors):
-        """Same result as `inference(Preprocessor(cfg)(...))` without materialising the intermediate dict."""
-        return self.head.inference(self.rpn(self.bev_from_points(clouds)), anchors)
+    def _plan_for(self, clouds):
+        offsets = [0]
+        for c in clouds:
+            offsets.append(offsets[-1] + int(c.shape[0]))
+        flat = clouds[0] if len(clouds) == 1 else torch.cat(clouds, dim=0)
+        cap_pts = 1 << max(14, (offsets[-1] - 1).bit_length())
+        return self.backbone_plan(len(clouds), cap_pts), flat, offsets
+
+    def dense_plan(self):
+        from ..runtime import DenseHeadPlan
+        if "_dense_plan" not in self.__dict__:
+            self.__dict__["_dense_plan"] = DenseHeadPlan(self.rpn, self.head)
+        return self.__dict__["_dense_plan"]
+
+    def head_maps_from_points(self, clouds):
+        """Fully native feature path: raw points -> (cls_map, reg_map); the BEV map never leaves the split
+        bf16 NHWC format between the sparse backbone and the 8 MFMA convolutions."""
+        plan, flat, offsets = self._plan_for(clouds)
+        hi, lo = plan.forward_split(flat, offsets)
+        return self.head.maps_from_fused(self.dense_plan().forward(hi, lo))
+
+    def inference_points(self, clouds, anchors, dense="mfma"):
+        """Same result as `inference(Preprocessor(cfg)(...))` without materialising the intermediate dict.
+        dense = "mfma": RPN + heads on the hand-written bf16x3 MFMA convolution (csrc/dense_conv.hip);
+        dense = "torch": fp32 nn.Conv2d (MIOpen) -- the comparison point."""
+        if dense == "torch":
+            return self.head.inference(self.rpn(self.bev_from_points(clouds)), anchors)
+        cls_map, reg_map = self.head_maps_from_points(clouds)
+        return self.head.inference_from_maps(cls_map, reg_map, anchors)

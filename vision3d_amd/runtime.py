@@ -132,6 +132,19 @@ class BackbonePlan(object):
                                                  L.ptr(out), L.stream_ptr()), "backbone_forward")
         return out
 
+    def forward_split(self, points, frame_offsets):
+        """Same as forward() but the BEV map comes out as the dense head's input format: two bf16 NHWC
+        planes (B, H, W, C_out*D) hi/lo (stored as int16)."""
+        self.sync_weights()
+        pts = L.as_f32("backbone", points)
+        b = len(frame_offsets) - 1
+        d, h, w = self.out_shape
+        hi, lo = split_planes_like(b, h, w, self.out_channels * d, pts.device)
+        with torch.cuda.device(pts.device):
+            L.check(L.lib().v3d_backbone_forward2(self._handle, L.ptr(pts), pts.shape[0], L.host_i32(frame_offsets), b, 0,
+                                                  L.ptr(hi), L.ptr(lo), L.stream_ptr()), "backbone_forward2")
+        return hi, lo
+
     def layer_output(self, layer):
         """(features (cap, C) view, coords (cap, 4) view, n_rows device int32 (1,), shape) of the last forward;
         layer = -1 is the voxelizer output.  Views alias the plan's arena: valid until the next forward."""
@@ -160,3 +173,106 @@ def _view(ptr, shape, dtype, device):
     typestr = {torch.float32: "<f4", torch.int32: "<i4"}[dtype]
     with torch.cuda.device(device):
         return torch.as_tensor(_DevMem(ptr, shape, typestr), device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense BEV head on the matrix cores (csrc/dense_conv.hip)
+# ------------------------------------------------------------------------------------------------
+def split_planes_like(b, h, w, c, device):
+    """Two bf16 NHWC planes ("hi", "lo") stored as int16."""
+    return (torch.empty((b, h, w, c), dtype=torch.int16, device=device),
+            torch.empty((b, h, w, c), dtype=torch.int16, device=device))
+
+
+def conv2d_split(x_hi, x_lo, image, bias, relu, cin, cout, ksize, out_split=True, out_nchw=False):
+    """One bf16x3 convolution on split NHWC planes; returns (y_hi, y_lo) and/or fp32 (B,cout,H,W)."""
+    b, h, w, c = x_hi.shape
+    assert c == cin
+    dev = x_hi.device
+    y_hi = y_lo = y = None
+    if out_split:
+        y_hi, y_lo = split_planes_like(b, h, w, cout, dev)
+    if out_nchw:
+        y = torch.empty((b, cout, h, w), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        L.check(L.lib().v3d_conv2d_nhwc_bf16x3(L.ptr(x_hi), L.ptr(x_lo), L.ptr(image), L.ptr(bias), int(bool(relu)), b, h, w,
+                                               cin, cout, ksize, L.ptr(y_hi), L.ptr(y_lo), L.ptr(y), L.stream_ptr()),
+                "conv2d_nhwc_bf16x3")
+    return (y_hi, y_lo), y
+
+
+def pack_conv_weight(weight, scale=None):
+    """(Cout,Cin,k,k) fp32 [* per-cout scale] -> packed split image (uint8 tensor)."""
+    w = weight.detach().to(torch.float32).contiguous()
+    cout, cin, k, _ = w.shape
+    lib = L.lib()
+    img = torch.empty(int(lib.v3d_conv2d_weight_image_bytes(cin, cout, k)), dtype=torch.uint8, device=w.device)
+    sc = None if scale is None else scale.detach().to(torch.float32).contiguous()
+    with torch.cuda.device(w.device):
+        L.check(lib.v3d_conv2d_pack_weights(L.ptr(w), L.ptr(sc), cout, cin, k, L.ptr(img), L.stream_ptr()), "conv2d_pack_weights")
+    return img
+
+
+def to_split_nhwc(x):
+    """fp32 (B,C,H,W) -> split planes (entry point for tensors that come from torch)."""
+    x = L.as_f32("to_split_nhwc", x)
+    b, c, h, w = x.shape
+    hi, lo = split_planes_like(b, h, w, c, x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().v3d_nchw_to_split_nhwc(L.ptr(x), b, c, h, w, L.ptr(hi), L.ptr(lo), L.stream_ptr()), "nchw_to_split_nhwc")
+    return hi, lo
+
+
+class DenseHeadPlan(object):
+    """RPN (conv+BN+ReLU stack, detector/second.py:58-94) + the two 1x1 heads (proposal.py:19-22) as 8
+    bf16x3 MFMA convolutions with folded BatchNorm; weights re-packed automatically when tensors change."""
+
+    def __init__(self, rpn, head):
+        self.rpn, self.head = rpn, head
+        self._stamp = None
+        self.layers = []
+
+    def _pairs(self):
+        mods = list(self.rpn.down_block) + list(self.rpn.up_block)
+        convs = [m for m in mods if isinstance(m, nn.Conv2d)]
+        bns = [m for m in mods if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+        assert len(convs) == len(bns)
+        return list(zip(convs, bns))
+
+    def sync_weights(self):
+        pairs = self._pairs()
+        tensors = [t for c, b in pairs for t in (c.weight, b.running_mean, b.running_var, b.weight, b.bias)]
+        tensors += [self.head.conv_cls.weight, self.head.conv_cls.bias, self.head.conv_reg.weight, self.head.conv_reg.bias]
+        stamp = tuple((t.data_ptr(), t._version) for t in tensors)
+        if stamp == self._stamp:
+            return
+        layers = []
+        with torch.no_grad():
+            for conv, bn in pairs:
+                if bn.training:
+                    raise RuntimeError("DenseHeadPlan runs eval-mode BatchNorm only")
+                k = conv.kernel_size[0]
+                if k not in (1, 3) or conv.stride != (1, 1) or conv.bias is not None:
+                    raise NotImplementedError("DenseHeadPlan: RPN convs must be 1x1/3x3, stride 1, bias-free")
+                scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+                layers.append(dict(img=pack_conv_weight(conv.weight, scale), bias=shift, relu=True, cin=conv.in_channels,
+                                   cout=conv.out_channels, k=k))
+            w = torch.cat((self.head.conv_cls.weight, self.head.conv_reg.weight), 0)
+            bias = torch.cat((self.head.conv_cls.bias, self.head.conv_reg.bias), 0).float().contiguous()
+            layers.append(dict(img=pack_conv_weight(w), bias=bias, relu=False, cin=w.shape[1], cout=w.shape[0], k=1))
+        self.layers, self._stamp = layers, stamp
+
+    def forward(self, x_hi, x_lo, want_features=False):
+        """split BEV planes -> fp32 head maps (B, n_cls*n_yaw*(1+DOF), H, W) [+ fp32 RPN features]."""
+        self.sync_weights()
+        feats = None
+        for i, ly in enumerate(self.layers[:-1]):
+            last = i == len(self.layers) - 2
+            (x_hi, x_lo), f = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"],
+                                           out_split=True, out_nchw=want_features and last)
+            feats = f if last else feats
+        ly = self.layers[-1]
+        _, maps = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"],
+                               out_split=False, out_nchw=True)
+        return (maps, feats) if want_features else maps
