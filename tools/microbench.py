@@ -72,3 +72,14 @@ with torch.no_grad():
     print("torch conv2d 128->128 3x3 fp32 gpu/host us: %.1f / %.1f" % timeit(lambda: conv(inp), 100))
     convb, inpb = conv.bfloat16(), inp.bfloat16()
     print("torch conv2d 128->128 3x3 bf16 gpu/host us: %.1f / %.1f" % timeit(lambda: convb(inpb), 100))
+# dense conv: hand-written bf16x3 MFMA kernel vs MIOpen, GPU-bound loops
+from vision3d_amd.runtime import conv2d_split, pack_conv_weight, to_split_nhwc
+hi, lo = to_split_nhwc(inp)
+img = pack_conv_weight(conv.float().weight)
+bias = torch.zeros(128, device="cuda")
+lib = L.lib()
+yh, yl = torch.empty_like(hi), torch.empty_like(lo)
+def dc():
+    lib.v3d_conv2d_nhwc_bf16x3(hi.data_ptr(), lo.data_ptr(), img.data_ptr(), bias.data_ptr(), 1, 1, 200, 176, 128, 128, 3,
+                               yh.data_ptr(), yl.data_ptr(), 0, L.stream_ptr())
+print("v3d conv2d 128->128 3x3 bf16x3 gpu/host us: %.1f / %.1f" % timeit(dc, 200))

@@ -26,6 +26,9 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short bf16_t;  // storage type at the C ABI
+// native vector type for the 16-byte staging registers: HIP's uint4 is a struct with a union inside and an
+// array of them is NOT promoted to registers (it round-tripped through scratch every k-step: 142 us/conv)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define DC_BM 64
 #define DC_BN 128
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
   // LDS destination of that 16-byte piece inside an A image (fragment-major): ((f*4 + kg)*16 + r)*16 bytes
   const int a_dst = (((a_px >> 4) * 4 + a_kg) * 16 + (a_px & 15)) * 16;
 
-  uint4 ra[2], rb[4];
+  u32x4 ra0, ra1, rb0, rb1, rb2, rb3;
   auto load_step = [&](int s) {
     const int tap = s / chunks, chunk = s - tap * chunks;
     const int dy = KS == 3 ? tap / 3 - 1 : 0, dx = KS == 3 ? tap % 3 - 1 : 0;
@@ -202,29 +205,31 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
     const bool ok = a_live && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
     if (ok) {
       const size_t off = (((size_t)a_b * p.H + hh) * p.W + ww) * p.Cin + chunk * DC_KC + a_kg * 8;
-      ra[0] = *reinterpret_cast<const uint4*>(x_hi + off);
-      ra[1] = *reinterpret_cast<const uint4*>(x_lo + off);
+      ra0 = *reinterpret_cast<const u32x4*>(x_hi + off);
+      ra1 = *reinterpret_cast<const u32x4*>(x_lo + off);
     } else {
-      ra[0] = make_uint4(0, 0, 0, 0);
-      ra[1] = make_uint4(0, 0, 0, 0);
+      ra0 = u32x4{0, 0, 0, 0};
+      ra1 = u32x4{0, 0, 0, 0};
     }
     // B: 16 KB of this (step, cout tile): [plane][nf 8][kg 4][j 16][8] -> plane stride = CoutPad/16*4*16*8 elems
     const size_t plane_elems = (size_t)(p.CoutPad / 16) * 4 * 16 * 8;
     const bf16_t* wb = w_img + (size_t)s * 2 * plane_elems + (size_t)(n0 / 16) * 4 * 16 * 8;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int q = tid + i * DC_THREADS;      // 0..1023 16-byte pieces: plane = q / 512
-      const int plane = q >> 9, within = q & 511;
-      rb[i] = *reinterpret_cast<const uint4*>(wb + (size_t)plane * plane_elems + (size_t)within * 8);
-    }
+    // 1024 16-byte pieces, piece q = tid + 256 i: plane = q / 512 (i = 0,1 -> hi; i = 2,3 -> lo)
+    const bf16_t* wlo = wb + plane_elems;
+    rb0 = *reinterpret_cast<const u32x4*>(wb + (size_t)tid * 8);
+    rb1 = *reinterpret_cast<const u32x4*>(wb + (size_t)(tid + 256) * 8);
+    rb2 = *reinterpret_cast<const u32x4*>(wlo + (size_t)tid * 8);
+    rb3 = *reinterpret_cast<const u32x4*>(wlo + (size_t)(tid + 256) * 8);
   };
   auto store_step = [&](int buf) {
     unsigned char* A = smem + buf * (8192 + 16384);
     unsigned char* Bm = A + 8192;
-    *reinterpret_cast<uint4*>(A + a_dst) = ra[0];          // hi plane
-    *reinterpret_cast<uint4*>(A + 4096 + a_dst) = ra[1];   // lo plane
-#pragma unroll
-    for (int i = 0; i < 4; i++) *reinterpret_cast<uint4*>(Bm + (size_t)(tid + i * DC_THREADS) * 16) = rb[i];
+    *reinterpret_cast<u32x4*>(A + a_dst) = ra0;          // hi plane
+    *reinterpret_cast<u32x4*>(A + 4096 + a_dst) = ra1;   // lo plane
+    *reinterpret_cast<u32x4*>(Bm + tid * 16) = rb0;
+    *reinterpret_cast<u32x4*>(Bm + (tid + 256) * 16) = rb1;
+    *reinterpret_cast<u32x4*>(Bm + (tid + 512) * 16) = rb2;
+    *reinterpret_cast<u32x4*>(Bm + (tid + 768) * 16) = rb3;
   };
 
   f32x4 acc[2][4];
@@ -291,15 +296,23 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
       const int row = q / (DC_BN / 8), c8 = q % (DC_BN / 8);
       const int m = m0 + row, co = n0 + c8 * 8;
       if (m >= p.M || co >= p.cout_store) continue;
-      union { bf16_t h[8]; uint4 v; } uh, ul;
+      u32x4 vh, vl;
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        float v = tile[row * TS + c8 * 8 + e] + (bias ? bias[co + e] : 0.f);
-        if (p.relu) v = fmaxf(v, 0.f);
-        split_bf16(v, uh.h[e], ul.h[e]);
+      for (int e2 = 0; e2 < 4; e2++) {  // two channels per 32-bit word
+        bf16_t h0, l0, h1, l1;
+        float v0 = tile[row * TS + c8 * 8 + 2 * e2] + (bias ? bias[co + 2 * e2] : 0.f);
+        float v1 = tile[row * TS + c8 * 8 + 2 * e2 + 1] + (bias ? bias[co + 2 * e2 + 1] : 0.f);
+        if (p.relu) {
+          v0 = fmaxf(v0, 0.f);
+          v1 = fmaxf(v1, 0.f);
+        }
+        split_bf16(v0, h0, l0);
+        split_bf16(v1, h1, l1);
+        vh[e2] = (unsigned)h0 | ((unsigned)h1 << 16);
+        vl[e2] = (unsigned)l0 | ((unsigned)l1 << 16);
       }
-      *reinterpret_cast<uint4*>(y_hi + (size_t)m * p.cout_store + co) = uh.v;
-      *reinterpret_cast<uint4*>(y_lo + (size_t)m * p.cout_store + co) = ul.v;
+      *reinterpret_cast<u32x4*>(y_hi + (size_t)m * p.cout_store + co) = vh;
+      *reinterpret_cast<u32x4*>(y_lo + (size_t)m * p.cout_store + co) = vl;
     }
   }
   if (y_nchw) {  // fp32 (B, cout_store, H, W): thread handles 4 consecutive pixels of one cout
