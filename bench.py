@@ -10,7 +10,7 @@ replicas on different frames with no data-path collective (weak scaling); the on
 timing barrier / max-reduce.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      the dominant kernel (spconv_fwd_wave<64,64>, 8 launches/frame): algorithmic bytes
+  roofline      the dominant kernel (spconv_fwd_rows<64,64>, 8 launches/frame): algorithmic bytes
                 A_min = 4*(N_in*Cin + N_out*Cout + K*Cin*Cout) + 8*R per launch divided
                 by its average duration measured with HIP events on the launch stream, vs 8 TB/s.
   cpu_baseline  oracle/ (scalar C sparse path + torch CPU dense path, 1 thread) timed on the host on a
@@ -153,7 +153,7 @@ def main():
         dom_bytes = float(np.mean([l["bytes"] for l in dom]))
         dom_t = float(np.mean([l["t_avg_us"] for l in dom])) * 1e-6
         achieved = dom_bytes / dom_t / 1e9
-        roofline = dict(bound="hbm", kernel="spconv_fwd_wave<64,64>", launches_per_frame=len(dom) // max(1, 1),
+        roofline = dict(bound="hbm", kernel="spconv_fwd_rows<64,64>", launches_per_frame=len(dom) // max(1, 1),
                         bytes_per_launch=dom_bytes, avg_us=dom_t * 1e6, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=None)
         tot_bytes = sum(l["bytes"] for l in layers)
@@ -183,7 +183,7 @@ def main():
     if rank == 0:
         line = dict(metric="frames/sec SECOND fwd, 16k-pt KITTI cloud", value=value, unit="frames/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
-                    scaling="weak", vs_baseline=None, dtype=("f32 (sparse backbone: fp32 MFMA; dense head: bf16x3 split = fp32-class)" if args.path == "native" else "f32"), data="synthetic",
+                    scaling="weak", vs_baseline=None, dtype="bf16x3 (fp32 operands split hi+lo, 3 bf16 MFMAs, fp32 accumulate: fp32-class, parity 1e-4)", data="synthetic",
                     config=dict(workload="SECOND (VoxelNet spconv backbone + BEV head) forward, bs=1, 16384-pt synthetic "
                                          "KITTI-range cloud per GPU (BASELINE configs[1])",
                                 frames_per_gpu_per_step=args.batch, points_per_frame=args.points,

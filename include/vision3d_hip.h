@@ -105,6 +105,15 @@ int v3d_sparse_conv_fwd(const float* in, const float* weight, const int32_t* nbr
                         int K, int Cin, int Cout, const float* scale, const float* shift, int relu, float* out,
                         int algo, v3d_stream_t stream);
 
+/* Split-precision variant (algo 4): weights are split into bf16 hi/lo and packed once per layer, the
+ * forward runs on v_mfma_f32_16x16x32_bf16 as hi*hi + hi*lo + lo*hi with fp32 accumulation (fp32-class
+ * accuracy, ~1e-5 relative); one wave owns 16 output rows with register accumulators.  Cout % 16 == 0. */
+size_t v3d_sparse_conv_weight_image_bytes(int K, int Cin, int Cout);
+int v3d_sparse_conv_pack_weights(const float* weight, int K, int Cin, int Cout, void* image, v3d_stream_t stream);
+int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
+                               int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
+                               float* out, v3d_stream_t stream);
+
 /* ---- T2: SparseConvTensor.dense() (detector/sparse_cnn.py:128-133): zero-fill + scatter.
  * feat (cap,C), coords (cap,4), *n rows -> dense (B,C,D,H,W) f32. */
 int v3d_densify(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
@@ -146,6 +155,7 @@ typedef struct {
   int32_t max_batch, max_points;           /* capacities: frames per forward, total points per forward */
   int32_t n_layers;
   float growth;                            /* active-site capacity of later stages = growth * voxel capacity (<=0: 2.0) */
+  int32_t conv_algo;                       /* 0 = default; 3 = fp32-MFMA wave kernel; 4 = bf16x3 row-owner kernel */
 } v3d_backbone_config;
 int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_layer_desc* layers, v3d_backbone** out);
 void v3d_backbone_destroy(v3d_backbone* plan);

@@ -43,7 +43,7 @@ def test_rulebooks_bit_exact_through_the_backbone(oracle):
 
 
 @pytest.mark.parametrize("cin,cout", [(4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64)])
-@pytest.mark.parametrize("algo", [1, 2, 3])
+@pytest.mark.parametrize("algo", [1, 2, 3, 4])
 def test_subm_conv_forward(oracle, cin, cout, algo):
     from vision3d_amd.spconv.conv import build_subm_rulebook, sparse_conv_forward
     rng = np.random.default_rng(cin * 100 + cout)
@@ -60,7 +60,7 @@ def test_subm_conv_forward(oracle, cin, cout, algo):
     assert_features_close(got, oracle.sparse_conv_fwd(feats, w, nbr), f"subm {cin}->{cout} algo {algo} plain")
 
 
-@pytest.mark.parametrize("algo", [1, 2, 3])
+@pytest.mark.parametrize("algo", [1, 2, 3, 4])
 def test_strided_conv_forward_ragged_tail(oracle, algo):
     """Strided layers incl. the (3,1,1) one; row counts not multiples of the 64-row tile; batch 2."""
     from vision3d_amd.spconv.conv import build_sparse_rulebook, sparse_conv_forward

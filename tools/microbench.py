@@ -46,17 +46,17 @@ def conv_time(feat, wt, rb, s1, s2, algo, flags=0):
     g, h = timeit(lambda: sparse_conv_forward(feat, wt, rb, s1, s2, True, algo), 10, 2)
     raw.v3d_debug_set_flags(0); raw.v3d_debug_set_repeat(1)
     return g / REP
-for algo in (1, 2, 3):
+for algo in (1, 2, 3, 4):
     print("conv 64->64 algo %d: %.2f us/launch" % (algo, conv_time(x2.features, w, rbs, sc, sh, algo)))
 for flags, what in ((1, "no A loads"), (2, "B always k=0"), (16, "no B loads"), (17, "no A, no B loads"), (4, "no MFMA"), (21, "no A/B/MFMA"), (21+32, "no A/B/MFMA/dsadd"), (64, "no main loop"), (32, "no ds_add only")):
     print("  algo3 ablation %-18s: %.2f us" % (what, conv_time(x2.features, w, rbs, sc, sh, 3, flags)))
 x1s = build_subm_rulebook(x1, [3, 3, 3])
 w32 = torch.randn(27, 32, 32, device="cuda") * 0.05
-for algo in (2, 3):
+for algo in (2, 3, 4):
     print("conv 32->32 (n=%d) algo %d: %.2f us" % (x1s.n, algo, conv_time(x1.features, w32, x1s, None, None, algo)))
 xs = build_subm_rulebook(x, [3, 3, 3])
 w4 = torch.randn(27, 4, 16, device="cuda")
-for algo in (2, 3):
+for algo in (2, 3, 4):
     print("conv 4->16 (n=%d) algo %d: %.2f us" % (xs.n, algo, conv_time(x.features, w4, xs, None, None, algo)))
 # NMS at the inference shape
 from vision3d_amd.ops.iou_nms import nms_rotated_padded

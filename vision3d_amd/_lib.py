@@ -30,6 +30,9 @@ _SIGNATURES = {
     "v3d_rulebook_subm": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "v3d_rulebook_sparse": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "v3d_sparse_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "v3d_sparse_conv_weight_image_bytes": (_sz, [_i, _i, _i]),
+    "v3d_sparse_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "v3d_sparse_conv_fwd_packed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "v3d_densify": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "v3d_fps_workspace": (_sz, [_i, _i]),
     "v3d_furthest_point_sample": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
@@ -62,7 +65,8 @@ class LayerDesc(C.Structure):
 class BackboneConfig(C.Structure):
     _fields_ = [("voxel_size", C.c_float * 3), ("bounds", C.c_float * 6), ("max_pts", C.c_int32),
                 ("max_voxels", C.c_int32), ("point_channels", C.c_int32), ("grid_shape", C.c_int32 * 3),
-                ("max_batch", C.c_int32), ("max_points", C.c_int32), ("n_layers", C.c_int32), ("growth", C.c_float)]
+                ("max_batch", C.c_int32), ("max_points", C.c_int32), ("n_layers", C.c_int32), ("growth", C.c_float),
+                ("conv_algo", C.c_int32)]
 
 _lib = None
 

@@ -23,6 +23,7 @@ struct PlanLayer {
   int rulebook;             // index into nbr tables
   bool builds_rulebook;
   float *weight, *scale, *shift, *out;
+  void* wimg;  // split + packed weights for the bf16x3 kernel
   int has_affine;
 };
 
@@ -169,6 +170,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
     p->chunk_counts = ar.take<int>((size_t)(max_tickets / V3D_SCAN_CHUNK + 2));
     for (auto& L : p->layers) {
       L.weight = ar.take<float>((size_t)L.K * L.d.cin * L.d.cout);
+      L.wimg = ar.take<char>(v3d_sparse_conv_weight_image_bytes(L.K, L.d.cin, L.d.cout));
       L.scale = ar.take<float>(L.d.cout);
       L.shift = ar.take<float>(L.d.cout);
       L.out = ar.take<float>((size_t)p->stages[L.stage_out].cap * L.d.cout);
@@ -206,6 +208,10 @@ extern "C" int v3d_backbone_set_layer(v3d_backbone* p, int layer, const float* w
   PlanLayer& L = p->layers[layer];
   V3D_CHECK_HIP(hipMemcpyAsync(L.weight, weight, (size_t)L.K * L.d.cin * L.d.cout * 4, hipMemcpyDeviceToDevice, st));
   L.has_affine = scale != nullptr;
+  if (L.d.cout % 16 == 0) {
+    int rc = v3d_sparse_conv_pack_weights(L.weight, L.K, L.d.cin, L.d.cout, L.wimg, stream);
+    if (rc) return rc;
+  }
   if (scale) {
     V3D_CHECK_HIP(hipMemcpyAsync(L.scale, scale, (size_t)L.d.cout * 4, hipMemcpyDeviceToDevice, st));
     V3D_CHECK_HIP(hipMemcpyAsync(L.shift, shift, (size_t)L.d.cout * 4, hipMemcpyDeviceToDevice, st));
@@ -252,8 +258,15 @@ extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n
       }
       if (rc) return rc;
     }
-    rc = v3d_sparse_conv_fwd(feat, L.weight, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout,
-                             L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr, L.d.relu, L.out, 0, st);
+    rc = V3D_EUNSUPPORTED;
+    // default (0): bf16x3 row-owner kernel where the reduction dim fills an MFMA (Cin >= 16), fp32 wave kernel else
+    if (c.conv_algo == 4 || (c.conv_algo == 0 && L.d.cin >= 16))
+      rc = v3d_sparse_conv_fwd_packed(feat, L.wimg, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout,
+                                      L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr, L.d.relu, L.out, st);
+    if (rc == V3D_EUNSUPPORTED)
+      rc = v3d_sparse_conv_fwd(feat, L.weight, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout,
+                               L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr, L.d.relu, L.out,
+                               (c.conv_algo == 4 || c.conv_algo == 0) ? 3 : c.conv_algo, st);
     if (rc) return rc;
     feat = L.out;
   }

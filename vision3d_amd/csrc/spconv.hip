@@ -454,6 +454,216 @@ static int launch_wave(const float* in, const float* W, const int* nbr, const in
   return V3D_OK;
 }
 
+// ---------------------------------------------------------------------------------- algo 4: row-owner bf16x3 MFMA
+// One WAVE owns 16 consecutive output rows x all Cout columns; accumulators stay in registers for the whole
+// kernel (output-stationary in the strictest sense): no LDS accumulators, no compaction lists, no barriers
+// in the loop, no atomics -- the ablation of algo 3 showed that machinery, not the MFMAs, was the cost.
+// Rows without a neighbour under offset k simply contribute a zero A row; the ~3x redundant matrix work
+// that causes is affordable because the products run on v_mfma_f32_16x16x32_bf16 in "bf16 x 3" split
+// precision (x = hi + lo; hi*hi + hi*lo + lo*hi, fp32 accumulate: fp32-class accuracy at 3/16 of the
+// fp32-MFMA cost -- same scheme as csrc/dense_conv.hip).  Weights are split and packed ONCE per layer
+// into the exact fragment order (v3d_sparse_conv_pack_weights), activations are split in registers.
+// Per offset a lane issues 2*KI float4 loads of its gathered row slice and KI*NB*2 16-byte loads of packed
+// weights; operands of offset k+1 are in flight while offset k multiplies (two register sets).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf16_rne_bits(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7F800000u) == 0x7F800000u) return u >> 16;
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// split 8 fp32 into packed bf16 hi / lo fragments
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8_t& hi, bf16x8_t& lo) {
+  u32x4_t h, l;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const unsigned h0 = bf16_rne_bits(x[2 * i]), h1 = bf16_rne_bits(x[2 * i + 1]);
+    const unsigned l0 = bf16_rne_bits(x[2 * i] - __uint_as_float(h0 << 16));
+    const unsigned l1 = bf16_rne_bits(x[2 * i + 1] - __uint_as_float(h1 << 16));
+    h[i] = h0 | (h1 << 16);
+    l[i] = l0 | (l1 << 16);
+  }
+  hi = __builtin_bit_cast(bf16x8_t, h);
+  lo = __builtin_bit_cast(bf16x8_t, l);
+}
+
+// packed weights: img[k][ki][nb][plane][lane][8]: lane (j = lane&15, kg = lane>>4) holds
+// W[k][cin = ki*32 + kg*8 + e][cout = nb*16 + j], e < 8 (zero beyond Cin)
+__global__ void spconv_pack_weights_kernel(const float* __restrict__ W, int K, int Cin, int Cout, unsigned short* __restrict__ img) {
+  const int KI = (Cin + 31) / 32, NB = Cout / 16;
+  const long long total = (long long)K * KI * NB * 64 * 8;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    long long r = t;
+    const int e = (int)(r % 8); r /= 8;
+    const int lane = (int)(r % 64); r /= 64;
+    const int nb = (int)(r % NB); r /= NB;
+    const int ki = (int)(r % KI); r /= KI;
+    const int k = (int)r;
+    const int cin = ki * 32 + (lane >> 4) * 8 + e, cout = nb * 16 + (lane & 15);
+    const float v = cin < Cin ? W[((size_t)k * Cin + cin) * Cout + cout] : 0.f;
+    const unsigned h = bf16_rne_bits(v);
+    const unsigned l = bf16_rne_bits(v - __uint_as_float(h << 16));
+    const size_t base = ((((size_t)k * KI + ki) * NB + nb) * 2) * 512 + (size_t)lane * 8 + e;
+    img[base] = (unsigned short)h;
+    img[base + 512] = (unsigned short)l;
+  }
+}
+
+extern "C" size_t v3d_sparse_conv_weight_image_bytes(int K, int Cin, int Cout) {
+  return (size_t)K * ((Cin + 31) / 32) * (Cout / 16) * 2 * 512 * sizeof(unsigned short);
+}
+
+extern "C" int v3d_sparse_conv_pack_weights(const float* weight, int K, int Cin, int Cout, void* image, v3d_stream_t stream) {
+  if (!weight || !image || K < 1 || Cin < 1 || Cout < 16 || Cout % 16) return V3D_EINVAL;
+  hipLaunchKernelGGL(spconv_pack_weights_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, weight, K, Cin, Cout,
+                     (unsigned short*)image);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __restrict__ in,
+                                                             const unsigned short* __restrict__ wimg,
+                                                             const int* __restrict__ nbr, const int* __restrict__ n_ptr,
+                                                             int cap, int K, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int relu,
+                                                             float* __restrict__ out) {
+  // workgroup = 16 output rows; its 4 waves split the K kernel offsets (wave w takes k = w, w+4, ...), keep
+  // private register accumulators and meet ONCE, in the epilogue, where the 4 partial tiles are summed in a
+  // fixed order (deterministic).  4x more waves in flight and a 4x shorter dependent chain per wave than one
+  // wave walking all offsets -- at KITTI size the kernel is latency-, not throughput-bound.
+  constexpr int KI = (CIN + 31) / 32, NB = COUT / 16;
+  constexpr int NF = KI * NB * 2;  // 16-byte weight fragments per offset per lane
+  constexpr int NW = V3D_BLOCK / V3D_WAVE;
+  extern __shared__ __attribute__((aligned(16))) float smem_rows[];
+  float* part = smem_rows;                                  // [NW][NB][4][64] partial accumulators
+  int* nbr_s = (int*)(part + NW * NB * 4 * 64);             // [K][16]
+  const int n = min(*n_ptr, cap);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * 16;
+  if (row0 >= n) return;
+  const int r = lane & 15, kg = lane >> 4;
+  for (int k = tid >> 4; k < K; k += V3D_BLOCK / 16)
+    nbr_s[k * 16 + r] = (row0 + r < n) ? nbr[(size_t)k * cap + row0 + r] : -1;
+  __syncthreads();
+
+  float araw[2][KI][8];
+  u32x4_t braw[2][NF];
+  auto load_ops = [&](int k, float (&a)[KI][8], u32x4_t (&b)[NF]) {
+    const int src = nbr_s[k * 16 + r];
+#pragma unroll
+    for (int ki = 0; ki < KI; ki++) {
+      const int c0 = ki * 32 + kg * 8;
+      if (src >= 0 && c0 < CIN) {
+        const float* p = in + (size_t)src * CIN + c0;
+        if constexpr (CIN % 8 == 0) {
+          const float4 v0 = reinterpret_cast<const float4*>(p)[0], v1 = reinterpret_cast<const float4*>(p)[1];
+          a[ki][0] = v0.x; a[ki][1] = v0.y; a[ki][2] = v0.z; a[ki][3] = v0.w;
+          a[ki][4] = v1.x; a[ki][5] = v1.y; a[ki][6] = v1.z; a[ki][7] = v1.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; e++) a[ki][e] = (c0 + e < CIN) ? p[e] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) a[ki][e] = 0.f;
+      }
+    }
+    const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(wimg) + (size_t)k * NF * 64 + lane;
+#pragma unroll
+    for (int f = 0; f < NF; f++) b[f] = wp[(size_t)f * 64];
+  };
+
+  f32x4 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto multiply = [&](const float (&a)[KI][8], const u32x4_t (&b)[NF]) {
+#pragma unroll
+    for (int ki = 0; ki < KI; ki++) {
+      bf16x8_t ah, al;
+      split8(a[ki], ah, al);
+#pragma unroll
+      for (int j = 0; j < NB; j++)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NB; j++)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2 + 1]), acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NB; j++)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), acc[j], 0, 0, 0);
+    }
+  };
+
+  // this wave's offsets: wave, wave + NW, ...   (two register sets: operands of the next offset in flight)
+  if (wave < K) load_ops(wave, araw[0], braw[0]);
+  for (int k = wave; k < K; k += 2 * NW) {
+    if (k + NW < K) load_ops(k + NW, araw[1], braw[1]);
+    multiply(araw[0], braw[0]);
+    if (k + NW < K) {
+      if (k + 2 * NW < K) load_ops(k + 2 * NW, araw[0], braw[0]);
+      multiply(araw[1], braw[1]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; j++)
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) part[((wave * NB + j) * 4 + rr) * 64 + lane] = acc[j][rr];
+  __syncthreads();
+
+  // epilogue: wave w finishes column blocks j = w, w + NW, ...;  D[row = kg*4 + rr][col = r]
+  for (int j = wave; j < NB; j += NW) {
+    const int col = j * 16 + r;
+    const float sc = scale ? scale[col] : 1.f, sh = scale ? shift[col] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      float v = part[((0 * NB + j) * 4 + rr) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < NW; w++) v += part[((w * NB + j) * 4 + rr) * 64 + lane];
+      const int row = row0 + kg * 4 + rr;
+      if (row < n) {
+        if (scale) v = v * sc + sh;
+        if (relu) v = fmaxf(v, 0.f);
+        out[(size_t)row * COUT + col] = v;
+      }
+    }
+  }
+}
+
+template <int CIN, int COUT>
+static int launch_rows(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
+                       const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
+  const size_t lds = (size_t)4 * (COUT / 16) * 4 * 64 * 4 + (size_t)K * 16 * 4;
+  for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
+    hipLaunchKernelGGL((spconv_fwd_rows<CIN, COUT>), dim3(v3d_ceil_div(cap, 16)), dim3(V3D_BLOCK), lds, st, in,
+                       (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+// Forward with PRE-PACKED split weights (v3d_sparse_conv_pack_weights): the bf16x3 row-owner kernel.
+extern "C" int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr,
+                                          const int32_t* n_out, int cap_out, int K, int Cin, int Cout, const float* scale,
+                                          const float* shift, int relu, float* out, v3d_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!in || !weight_image || !nbr || !n_out || !out || cap_out < 1 || K < 1) return V3D_EINVAL;
+  if ((scale == nullptr) != (shift == nullptr)) return V3D_EINVAL;
+#define V3D_TRY(ci, co) \
+  if (Cin == ci && Cout == co) return launch_rows<ci, co>(in, weight_image, nbr, n_out, cap_out, K, scale, shift, relu, out, st);
+  V3D_TRY(4, 16)
+  V3D_TRY(16, 16)
+  V3D_TRY(16, 32)
+  V3D_TRY(32, 32)
+  V3D_TRY(32, 64)
+  V3D_TRY(64, 64)
+  V3D_TRY(4, 32)
+  V3D_TRY(64, 128)
+  V3D_TRY(128, 128)
+#undef V3D_TRY
+  return V3D_EUNSUPPORTED;
+}
+
 template <int CIN, int COUT>
 static int launch_mfma(const float* in, const float* W, const int* nbr, const int* n_ptr, int cap, int K,
                        const float* scale, const float* shift, int relu, float* out, hipStream_t st) {

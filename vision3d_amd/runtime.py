@@ -41,7 +41,7 @@ def flatten_sparse_layers(module):
 
 class BackbonePlan(object):
 
-    def __init__(self, cnn, cfg, max_batch=1, max_points=None, growth=2.0, device=None):
+    def __init__(self, cnn, cfg, max_batch=1, max_points=None, growth=2.0, device=None, conv_algo=0):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.cfg = cfg
         self.layers = flatten_sparse_layers(cnn.blocks)
@@ -63,6 +63,7 @@ class BackbonePlan(object):
         c.max_pts, c.max_voxels, c.point_channels = cfg.MAX_OCCUPANCY, cfg.MAX_VOXELS, cfg.C_IN
         c.grid_shape[:] = self.grid_shape
         c.max_batch, c.max_points, c.n_layers, c.growth = self.max_batch, self.max_points, len(self.layers), float(growth)
+        c.conv_algo = int(conv_algo)
         self._handle = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(L.lib().v3d_backbone_create(C.byref(c), descs, C.byref(self._handle)), "backbone_create")

@@ -81,11 +81,38 @@ def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False
         return out
     sc = None if scale is None else L.as_f32("sparse_conv", scale)
     sh = None if shift is None else L.as_f32("sparse_conv", shift)
+    if algo == 0:  # default: bf16x3 row-owner kernel once the reduction dim fills an MFMA, fp32 wave kernel below
+        algo = 4 if (cin >= 16 and cout % 16 == 0) else 3
+    if algo == 4:  # bf16x3 row-owner kernel on pre-packed split weights (packed image cached per weight version)
+        img = _packed_image(weight, w, k, cin, cout)
+        with torch.cuda.device(feat.device):
+            L.check(L.lib().v3d_sparse_conv_fwd_packed(L.ptr(feat), L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k,
+                                                       cin, cout, L.ptr(sc), L.ptr(sh), int(bool(relu)), L.ptr(out),
+                                                       L.stream_ptr()), "sparse_conv_fwd_packed")
+        return out
     with torch.cuda.device(feat.device):
         L.check(L.lib().v3d_sparse_conv_fwd(L.ptr(feat), L.ptr(w), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k, cin,
                                             cout, L.ptr(sc), L.ptr(sh), int(bool(relu)), L.ptr(out), int(algo),
                                             L.stream_ptr()), "sparse_conv_fwd")
     return out
+
+
+_PACK_CACHE = {}
+
+
+def _packed_image(weight, w_flat, k, cin, cout):
+    key = (weight.data_ptr(), weight._version, k, cin, cout)
+    img = _PACK_CACHE.get(key)
+    if img is None:
+        lib = L.lib()
+        img = torch.empty(int(lib.v3d_sparse_conv_weight_image_bytes(k, cin, cout)), dtype=torch.uint8, device=w_flat.device)
+        with torch.cuda.device(w_flat.device):
+            L.check(lib.v3d_sparse_conv_pack_weights(L.ptr(w_flat), k, cin, cout, L.ptr(img), L.stream_ptr()),
+                    "sparse_conv_pack_weights")
+        if len(_PACK_CACHE) > 256:
+            _PACK_CACHE.clear()
+        _PACK_CACHE[key] = img
+    return img
 
 
 class _SparseConvBase(nn.Module):
