@@ -114,6 +114,9 @@ int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_image, const 
                                int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
                                float* out, v3d_stream_t stream);
 
+/* Timing harness (bench.py, tools/): every subsequent sparse-conv launch is issued n times back to back. */
+void v3d_debug_set_repeat(int n);
+
 /* ---- T2: SparseConvTensor.dense() (detector/sparse_cnn.py:128-133): zero-fill + scatter.
  * feat (cap,C), coords (cap,4), *n rows -> dense (B,C,D,H,W) f32. */
 int v3d_densify(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,

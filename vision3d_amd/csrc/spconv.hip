@@ -459,9 +459,9 @@ static int launch_wave(const float* in, const float* W, const int* nbr, const in
 // kernel (output-stationary in the strictest sense): no LDS accumulators, no compaction lists, no barriers
 // in the loop, no atomics -- the ablation of algo 3 showed that machinery, not the MFMAs, was the cost.
 // Rows without a neighbour under offset k simply contribute a zero A row; the ~3x redundant matrix work
-// that causes is affordable because the products run on v_mfma_f32_16x16x32_bf16 in "bf16 x 3" split
-// precision (x = hi + lo; hi*hi + hi*lo + lo*hi, fp32 accumulate: fp32-class accuracy at 3/16 of the
-// fp32-MFMA cost -- same scheme as csrc/dense_conv.hip).  Weights are split and packed ONCE per layer
+// that causes is affordable because the products run on v_mfma_f32_16x16x32_bf16 in split precision
+// (activations = hi + mid + lo, weights = hi + lo, 4 bf16 MFMAs per product tile, fp32 accumulate: fp32-class
+// accuracy at 1/4 of the fp32-MFMA cost -- the scheme of csrc/dense_conv.hip with one more activation term).  Weights are split and packed ONCE per layer
 // into the exact fragment order (v3d_sparse_conv_pack_weights), activations are split in registers.
 // Per offset a lane issues 2*KI float4 loads of its gathered row slice and KI*NB*2 16-byte loads of packed
 // weights; operands of offset k+1 are in flight while offset k multiplies (two register sets).
@@ -473,18 +473,26 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float f) {
   if ((u & 0x7F800000u) == 0x7F800000u) return u >> 16;
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
-// split 8 fp32 into packed bf16 hi / lo fragments
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8_t& hi, bf16x8_t& lo) {
-  u32x4_t h, l;
+// split 8 fp32 ACTIVATIONS into three packed bf16 fragments hi + mid + lo (24 significant bits: exact
+// up to fp32 rounding).  Weights carry two (hi + lo, 16 bits).  The product is evaluated as
+//   hi*Whi + hi*Wlo + mid*Whi + lo*Whi      (mid*Wlo ~ 2^-26 is dropped)
+// so the only representation error left is the weights' 2^-18 residual: half the error of a 2x2-term
+// split for one more MFMA, which the latency-bound sparse kernel does not notice.
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
+  u32x4_t h, m, l;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const unsigned h0 = bf16_rne_bits(x[2 * i]), h1 = bf16_rne_bits(x[2 * i + 1]);
-    const unsigned l0 = bf16_rne_bits(x[2 * i] - __uint_as_float(h0 << 16));
-    const unsigned l1 = bf16_rne_bits(x[2 * i + 1] - __uint_as_float(h1 << 16));
+    const float x0 = x[2 * i], x1 = x[2 * i + 1];
+    const unsigned h0 = bf16_rne_bits(x0), h1 = bf16_rne_bits(x1);
+    const float r0 = x0 - __uint_as_float(h0 << 16), r1 = x1 - __uint_as_float(h1 << 16);
+    const unsigned m0 = bf16_rne_bits(r0), m1 = bf16_rne_bits(r1);
+    const unsigned l0 = bf16_rne_bits(r0 - __uint_as_float(m0 << 16)), l1 = bf16_rne_bits(r1 - __uint_as_float(m1 << 16));
     h[i] = h0 | (h1 << 16);
+    m[i] = m0 | (m1 << 16);
     l[i] = l0 | (l1 << 16);
   }
   hi = __builtin_bit_cast(bf16x8_t, h);
+  mid = __builtin_bit_cast(bf16x8_t, m);
   lo = __builtin_bit_cast(bf16x8_t, l);
 }
 
@@ -582,11 +590,14 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
   auto multiply = [&](const float (&a)[KI][8], const u32x4_t (&b)[NF]) {
 #pragma unroll
     for (int ki = 0; ki < KI; ki++) {
-      bf16x8_t ah, al;
-      split8(a[ki], ah, al);
+      bf16x8_t ah, am, al;
+      split8(a[ki], ah, am, al);
+#pragma unroll
+      for (int j = 0; j < NB; j++)  // smallest terms first
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), acc[j], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < NB; j++)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), acc[j], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < NB; j++)
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2 + 1]), acc[j], 0, 0, 0);

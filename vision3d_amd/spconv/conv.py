@@ -68,7 +68,7 @@ def build_sparse_rulebook(x, ksize, stride, padding):
     return Rulebook(nbr, cap_out, n_host, n_out, coords_out[:n_host], out_shape)
 
 
-def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False, algo=0):
+def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False, algo=0, packed=None):
     """out (rb.n, Cout) = act((sum_k features[nbr[k]] @ weight[k]) * scale + shift)."""
     feat = L.as_f32("sparse_conv", features)
     cin, cout = weight.shape[-2], weight.shape[-1]
@@ -84,7 +84,7 @@ def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False
     if algo == 0:  # default: bf16x3 row-owner kernel once the reduction dim fills an MFMA, fp32 wave kernel below
         algo = 4 if (cin >= 16 and cout % 16 == 0) else 3
     if algo == 4:  # bf16x3 row-owner kernel on pre-packed split weights (packed image cached per weight version)
-        img = _packed_image(weight, w, k, cin, cout)
+        img = packed if packed is not None else pack_sparse_weight(w, k, cin, cout)
         with torch.cuda.device(feat.device):
             L.check(L.lib().v3d_sparse_conv_fwd_packed(L.ptr(feat), L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k,
                                                        cin, cout, L.ptr(sc), L.ptr(sh), int(bool(relu)), L.ptr(out),
@@ -97,21 +97,13 @@ def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False
     return out
 
 
-_PACK_CACHE = {}
-
-
-def _packed_image(weight, w_flat, k, cin, cout):
-    key = (weight.data_ptr(), weight._version, k, cin, cout)
-    img = _PACK_CACHE.get(key)
-    if img is None:
-        lib = L.lib()
-        img = torch.empty(int(lib.v3d_sparse_conv_weight_image_bytes(k, cin, cout)), dtype=torch.uint8, device=w_flat.device)
-        with torch.cuda.device(w_flat.device):
-            L.check(lib.v3d_sparse_conv_pack_weights(L.ptr(w_flat), k, cin, cout, L.ptr(img), L.stream_ptr()),
-                    "sparse_conv_pack_weights")
-        if len(_PACK_CACHE) > 256:
-            _PACK_CACHE.clear()
-        _PACK_CACHE[key] = img
+def pack_sparse_weight(w_flat, k, cin, cout):
+    """(K,Cin,Cout) fp32 -> split bf16 fragments in MFMA order (csrc/spconv.hip spconv_pack_weights_kernel)."""
+    lib = L.lib()
+    img = torch.empty(int(lib.v3d_sparse_conv_weight_image_bytes(k, cin, cout)), dtype=torch.uint8, device=w_flat.device)
+    with torch.cuda.device(w_flat.device):
+        L.check(lib.v3d_sparse_conv_pack_weights(L.ptr(w_flat), k, cin, cout, L.ptr(img), L.stream_ptr()),
+                "sparse_conv_pack_weights")
     return img
 
 
@@ -141,6 +133,18 @@ class _SparseConvBase(nn.Module):
         if self.bias is not None:
             nn.init.uniform_(self.bias, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
 
+    def _packed_weight(self):
+        """Split/packed weight image, cached ON THE MODULE and refreshed when the parameter changes."""
+        w = self.weight
+        stamp = (w.data_ptr(), w._version, str(w.device))
+        cache = self.__dict__.get("_pack_cache")
+        if cache is None or cache[0] != stamp:
+            k = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+            flat = w.detach().to(torch.float32).reshape(k, self.in_channels, self.out_channels).contiguous()
+            cache = (stamp, pack_sparse_weight(flat, k, self.in_channels, self.out_channels))
+            self.__dict__["_pack_cache"] = cache
+        return cache[1]
+
     def rulebook(self, x):
         rb = x.find_indice_pair(self.indice_key)
         if rb is None:
@@ -161,7 +165,10 @@ class _SparseConvBase(nn.Module):
             shift = b if shift is None else shift + b * scale
             if scale is None:
                 scale = torch.ones_like(b)
-        feats = sparse_conv_forward(x.features.detach(), self.weight.detach(), rb, scale, shift, relu, self.algo)
+        packed = None
+        if self.algo in (0, 4) and self.in_channels >= 16 and self.out_channels % 16 == 0:
+            packed = self._packed_weight()
+        feats = sparse_conv_forward(x.features.detach(), self.weight.detach(), rb, scale, shift, relu, self.algo, packed)
         out = SparseConvTensor(feats, rb.out_indices, rb.out_shape, x.batch_size)
         out.indice_dict = x.indice_dict
         out._n_dev = rb.n_dev
