@@ -37,10 +37,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (configs[1] = 1)")
-    ap.add_argument("--points", type=int, default=16384)
-    ap.add_argument("--path", choices=["native", "fused", "eager"], default="native",
-                    help="native: backbone plan + MFMA dense head; fused: backbone plan + torch (MIOpen) RPN; "
-                         "eager: per-op python -> C ABI")
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--workload", choices=["kitti", "waymo"], default="kitti",
+                    help="kitti: BASELINE configs[1] (16k-pt KITTI-range cloud, the headline metric); "
+                         "waymo: configs[4] (180k-pt sweep, +-75.2 m, 0.05 m voxels: the HBM stress case)")
+    ap.add_argument("--path", choices=["graph", "native", "fused", "eager"], default="graph",
+                    help="graph: native path captured in one HIP graph; native: backbone plan + MFMA dense head; "
+                         "fused: backbone plan + torch (MIOpen) RPN; eager: per-op python -> C ABI")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch event timing pass (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=3)
@@ -55,31 +58,46 @@ def layer_algorithmic_bytes(stats):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from vision3d_amd import dist_util
+    rank, local, world = dist_util.env_world()
     assert torch.cuda.is_available(), "bench.py needs a GPU (vision3d_amd has no CPU path)"
     torch.cuda.set_device(local)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl")  # RCCL; used for the barrier and the max-reduce only
+    dist_util.init_from_env("nccl")  # RCCL; used for the barrier and the max-reduce only (frames are independent)
+    import torch.distributed as dist
 
     from vision3d_amd import synth
     from vision3d_amd.core import AnchorGenerator, Preprocessor
-    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.core.config import second_car_cfg, waymo_range_cfg
     from vision3d_amd.detector import Second
 
-    cfg = second_car_cfg()
+    waymo = args.workload == "waymo"
+    cfg = waymo_range_cfg() if waymo else second_car_cfg()
+    if args.points is None:
+        args.points = 180000 if waymo else 16384
     torch.manual_seed(0)
     model = Second(cfg).cuda().eval()
     pre = Preprocessor(cfg, seed=0)
-    anchors = AnchorGenerator(cfg).anchors.cuda()
+    acfg = cfg
+    if waymo:  # the reference's anchor grid truncates 150.4/0.4 (fp32) to 375 cells while the BEV map has 376:
+        acfg = cfg.clone()  # nudge the bounds so the anchor grid matches the map (throughput stress only)
+        acfg.GRID_BOUNDS = [cfg.GRID_BOUNDS[0], cfg.GRID_BOUNDS[1], cfg.GRID_BOUNDS[2], cfg.GRID_BOUNDS[3] + 0.02,
+                            cfg.GRID_BOUNDS[4] + 0.02, cfg.GRID_BOUNDS[5]]
+    anchors = AnchorGenerator(acfg).anchors.cuda()
     # frame-parallel sharding: rank r owns frames r*B .. r*B+B-1 of the synthetic stream
-    clouds_np = [synth.make_cloud(rank * args.batch + i, args.points) for i in range(args.batch)]
+    make = (lambda seed, n: synth.make_waymo_cloud(seed, n)) if waymo else (lambda seed, n: synth.make_cloud(seed, n))
+    clouds_np = [make(fid, args.points) for fid in
+                 [rank * args.batch + i for i in range(args.batch)]]  # = dist_util.shard_frames(world*B, rank, world)
     clouds = [torch.from_numpy(c).cuda() for c in clouds_np]
+
+    graphed = None
+    if args.path == "graph":
+        with torch.no_grad():
+            graphed = model.graphed_inference(anchors, [c.shape[0] for c in clouds])
 
     def step():
         with torch.no_grad():
+            if graphed is not None:
+                return graphed(clouds)
             if args.path == "native":
                 return model.inference_points(clouds, anchors, dense="mfma")
             if args.path == "fused":
@@ -101,10 +119,7 @@ def main():
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = dist_util.max_over_ranks(elapsed, world, device="cuda")
     frames = world * args.steps * args.batch
     value = frames / elapsed
 
@@ -161,13 +176,13 @@ def main():
                       layers=[{k: (round(v, 2) if isinstance(v, float) else v) for k, v in l.items()} for l in layers])
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not waymo:
         from oracle import second_cpu
         torch.set_num_threads(1)
         sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
         n_frames, t_cpu = 0, 0.0
         while n_frames < args.cpu_frames and t_cpu < 30.0:
-            cloud = synth.make_cloud(100 + n_frames, args.points)
+            cloud = make(100 + n_frames, args.points)
             c0 = time.perf_counter()
             ref = second_cpu.second_forward(sd, [cloud], cfg.VOXEL_SIZE, cfg.GRID_BOUNDS, cfg.MAX_OCCUPANCY, cfg.MAX_VOXELS)
             second_cpu.proposals(ref["cls"], ref["reg"], anchors.cpu().numpy(), 1, 2, 7, cfg.PROPOSAL.TOPK,
@@ -179,14 +194,17 @@ def main():
                                    f"dense path, 1 thread), {t_cpu:.1f} s")
 
     if rank == 0:
-        line = dict(metric="frames/sec SECOND fwd, 16k-pt KITTI cloud", value=value, unit="frames/s", n_gpus=world,
+        wl = ("SECOND forward, bs=1, 180000-pt synthetic Waymo-range sweep per GPU, 0.05 m voxels over +-75.2 m "
+              "(BASELINE configs[4])") if waymo else ("SECOND (VoxelNet spconv backbone + BEV head) forward, bs=1, 16384-pt "
+                                                      "synthetic KITTI-range cloud per GPU (BASELINE configs[1])")
+        line = dict(metric=("frames/sec SECOND fwd, 180k-pt Waymo-range sweep" if waymo else "frames/sec SECOND fwd, 16k-pt KITTI cloud"), value=value, unit="frames/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
                     scaling="weak", vs_baseline=None, dtype="bf16x3 (fp32 operands split hi+lo, 3 bf16 MFMAs, fp32 accumulate: fp32-class, parity 1e-4)", data="synthetic",
-                    config=dict(workload="SECOND (VoxelNet spconv backbone + BEV head) forward, bs=1, 16384-pt synthetic "
-                                         "KITTI-range cloud per GPU (BASELINE configs[1])",
+                    config=dict(workload=wl,
                                 frames_per_gpu_per_step=args.batch, points_per_frame=args.points,
                                 parallelism=f"frame-parallel replicas x{world}",
-                                path={"native": "native backbone plan + bf16x3 MFMA dense head", "fused": "native backbone plan + torch RPN",
+                                path={"graph": "native backbone plan + bf16x3 MFMA dense head, one HIP graph per frame",
+                                      "native": "native backbone plan + bf16x3 MFMA dense head", "fused": "native backbone plan + torch RPN",
                                       "eager": "eager python -> C ABI"}[args.path]),
                     roofline=roofline, cpu_baseline=cpu_baseline, stages=stages,
                     n_proposals=int(out[0].shape[0]))

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..core.box_encode import decode
-from ..ops import batched_nms_rotated, sigmoid_focal_loss
+from ..ops import batched_nms_rotated, batched_nms_rotated_padded, sigmoid_focal_loss
 
 
 class ProposalLayer(nn.Module):
@@ -70,6 +70,27 @@ class ProposalLayer(nn.Module):
         """(B, n_anchor*(1+DOF), H, W) = [cls | reg] channels of the fused 1x1 head -> (cls_map, reg_map)."""
         n_anchor = self.cfg.NUM_CLASSES * self.cfg.NUM_YAW
         return self.reshape_cls(maps[:, :n_anchor].contiguous()), self.reshape_reg(maps[:, n_anchor:].contiguous())
+
+    def proposals_padded(self, cls_map, reg_map, anchors):
+        """Everything up to (and including) NMS with NO host synchronisation: returns the B*n_cls*TOPK
+        candidates (boxes, batch_idx, class_idx, scores) plus (keep padded, n_keep) on the device.  This is
+        the part that can live inside a captured HIP graph; `finalize` does the variable-length selection."""
+        score_map = cls_map.sigmoid()
+        B, n_cls = score_map.shape[:2]
+        scores, anchor_idx = score_map.reshape(B, n_cls, -1).topk(self.TOPK, -1)
+        boxes = self._decode(reg_map, anchors, anchor_idx).reshape(-1, self.DOF)
+        scores = scores.reshape(-1)
+        batch_idx, class_idx, group_idx = self._generate_group_idx(B, n_cls, scores.device)
+        # column select without a host-built index tensor (an H2D copy is illegal during graph capture)
+        bev = torch.stack((boxes[:, 0], boxes[:, 1], boxes[:, 3], boxes[:, 4], boxes[:, 6]), dim=1)
+        keep, n_keep = batched_nms_rotated_padded(bev, scores, group_idx, 0.01)
+        return boxes, batch_idx, class_idx, scores, keep, n_keep
+
+    def finalize(self, boxes, batch_idx, class_idx, scores, keep, n_keep):
+        keep = keep[: int(n_keep.item())]
+        boxes, batch_idx, class_idx, scores = (x[keep] for x in (boxes, batch_idx, class_idx, scores))
+        mask = self._above_score_thresh(scores, class_idx)
+        return [x[mask] for x in (boxes, batch_idx, class_idx, scores)]
 
     def inference_from_maps(self, cls_map, reg_map, anchors):
         score_map = cls_map.sigmoid_()

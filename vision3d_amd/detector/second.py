@@ -93,7 +93,12 @@ class Second(nn.Module):
         super().__init__()
         self.vfe = VoxelFeatureExtractor()
         self.cnn = Middle(cfg)
-        self.rpn = RPN()
+        # BEV channels = 64 x (z extent after the last sparse stage): 128 for the KITTI grid, as hard-coded in
+        # the reference (second.py:52); other ranges (e.g. the Waymo-range stress config: 3 z-slices) follow.
+        z = self.cnn.grid_shape[0]
+        for k, st, pd in ((3, 2, 1), (3, 2, 1), (3, 2, 0), (3, 2, 0)):
+            z = (z + 2 * pd - k) // st + 1
+        self.rpn = RPN(C_in=64 * z)
         self.head = ProposalLayer(cfg)
         self.cfg = cfg
 
@@ -153,6 +158,14 @@ class Second(nn.Module):
         plan, flat, offsets = self._plan_for(clouds)
         hi, lo = plan.forward_split(flat, offsets)
         return self.head.maps_from_fused(self.dense_plan().forward(hi, lo))
+
+    def graphed_inference(self, anchors, frame_sizes):
+        """Capture raw points -> candidates+NMS as ONE HIP graph for a fixed batch geometry (frame_sizes = points
+        per frame).  Returns `run(clouds) -> (boxes, batch_idx, class_idx, scores)`; each call copies the clouds
+        into a static buffer, replays the graph (a single launch for ~150 kernels) and does the final
+        variable-length selection.  Re-capture (call again) when the geometry changes."""
+        from .graph import GraphedSecond
+        return GraphedSecond(self, anchors, frame_sizes)
 
     def inference_points(self, clouds, anchors, dense="mfma"):
         """Same result as `inference(Preprocessor(cfg)(...))` without materialising the intermediate dict.

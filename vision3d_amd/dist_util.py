@@ -1,0 +1,61 @@
+"""Frame-parallel multi-GPU plumbing: one process per GPU, frames are independent units.
+
+The reference is single-process/single-GPU (training.md:6); SURVEY.md section 8(e): inference shards
+frames across ranks with NO data-path collective; the only communication is a barrier and a max-reduce
+of the elapsed time (bench.py), and -- for the train configuration -- one flat gradient all-reduce.
+Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* when world > 1; returns (rank, local, world)."""
+    rank, local, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"))
+    return rank, local, world
+
+
+def shard_frames(n_frames_total, rank, world):
+    """Contiguous block of frame ids owned by `rank` (frames r*B .. r*B+B-1 for equal shards)."""
+    per = (n_frames_total + world - 1) // world
+    lo = min(rank * per, n_frames_total)
+    return list(range(lo, min(lo + per, n_frames_total)))
+
+
+def barrier(world):
+    if world > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, world, device="cpu"):
+    """MAX-reduce of a python float (the bench contract: step time = slowest rank)."""
+    if world == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def allreduce_gradients_flat(params, world):
+    """ONE collective per step: gradients flattened into a single bucket, summed over ranks, divided by the
+    world size and scattered back (~1.83 M parameters = 7.3 MB fp32 -- latency-, not
+    bandwidth-bound over xGMI, so a single flat bucket beats per-tensor reductions)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if world == 1 or not grads:
+        return 0
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(world)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+    return flat.numel()

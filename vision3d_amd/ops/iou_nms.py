@@ -65,6 +65,17 @@ def batched_nms_rotated(boxes, scores, idxs, iou_threshold):
     return nms_rotated(shifted, scores, iou_threshold)
 
 
+def batched_nms_rotated_padded(boxes, scores, idxs, iou_threshold):
+    """batched_nms_rotated without the host read: (keep (N,) int64 padded, n_keep (1,) int32), both on the
+    device -- the form used inside captured HIP graphs."""
+    assert boxes.shape[-1] == 5
+    hi = (torch.max(boxes[:, 0], boxes[:, 1]) + torch.max(boxes[:, 2], boxes[:, 3]) / 2).max()
+    lo = (torch.min(boxes[:, 0], boxes[:, 1]) - torch.min(boxes[:, 2], boxes[:, 3]) / 2).min()
+    shifted = boxes.clone()
+    shifted[:, :2] += (idxs.to(boxes) * (hi - lo + 1))[:, None]
+    return nms_rotated_padded(shifted, scores, iou_threshold)
+
+
 def nms(boxes, scores, iou_threshold):
     """Axis-aligned NMS on (x1,y1,x2,y2) (the torchvision name re-exported at iou_nms.py:6; never called
     by the detector).  Served by the rotated kernel with angle 0."""
