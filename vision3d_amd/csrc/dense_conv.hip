@@ -16,9 +16,11 @@
 //              = 2 x 4 MFMA fragments, 8 fp32 accumulators (32 VGPRs)
 //   k-step     32 input channels of one tap: A (64 px x 32 ch x {hi,lo}) gathered with zero halo,
 //              B (32 ch x 128 cout x {hi,lo}) copied linearly from the pre-packed weight image
-//   LDS        fragment-major images: the 16 bytes a lane needs sit at lane*16 inside its fragment, so
-//              every ds_read_b128 is lane-linear (conflict free); double buffered, one barrier per k-step;
-//              global loads of step s+1 are in flight (registers) during the 24 MFMAs of step s
+//   LDS        B: fragment-major image (lane-linear ds_read_b128); A: pixel-major rows with an XOR swizzle that is
+//              conflict-free for the coalesced writes and the fragment reads; double buffered, one barrier per
+//              k-step; global loads run two k-steps ahead in two register sets.  (An 8-wave variant of the same
+//              tile measured 70 us vs 57.6 us: the limiter is L1/L2 fill bandwidth -- weights are re-streamed per
+//              64-pixel tile -- not latency.)
 //   epilogue   accumulators -> LDS (fp32) -> bias + ReLU -> either the next layer's split bf16 NHWC planes
 //              (16-byte stores) or fp32 NCHW for the consumer outside this file.
 #include "v3d_internal.h"
@@ -178,7 +180,16 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (8192 + 16384)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;  // pixel half / cout half
-  const int m0 = blockIdx.x * DC_BM;
+  // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (private L2s);
+  // remap so each XCD walks a CONTIGUOUS run of pixel tiles -- neighbouring tiles share two of their three
+  // input rows (the 3x3 halo), which then hit in that XCD's L2 instead of being fetched by eight of them.
+  const int nt = gridDim.x;
+  int mtile = blockIdx.x;
+  {
+    const int q = nt / 8, rmd = nt % 8, xcd = mtile % 8, idx = mtile / 8;
+    mtile = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;  // bijective for any nt
+  }
+  const int m0 = mtile * DC_BM;
   const int n0 = blockIdx.y * DC_BN;
   const int chunks = p.Cin / DC_KC;
   const int steps = KS * KS * chunks;
@@ -194,42 +205,55 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
     a_h = rem / p.W;
     a_w = rem - a_h * p.W;
   }
-  // LDS destination of that 16-byte piece inside an A image (fragment-major): ((f*4 + kg)*16 + r)*16 bytes
-  const int a_dst = (((a_px >> 4) * 4 + a_kg) * 16 + (a_px & 15)) * 16;
+  // A image in LDS: pixel-major rows of 64 B (4 slots of 16 B) with the slot XOR-swizzled by bit 3 of the row:
+  //   slot(px, kg) = px*4 + (kg ^ ((px & 8) >> 2))
+  // found by exhaustive search to be conflict-free for BOTH access patterns: the coalesced writer (8 consecutive
+  // lanes = 2 pixels x 4 parts -> 8 distinct 16-byte slots mod 128 B) and the MFMA fragment reader (each
+  // ds_read_b128 lane group of 16 -> 16 distinct slots mod 256 B).  A fragment-major image had 4-way write
+  // conflicts (35 % of all LDS cycles, PMC SQ_LDS_BANK_CONFLICT 4.2 M -> 0.4 M).
+  const int a_dst = (a_px * 4 + (a_kg ^ ((a_px & 8) >> 2))) * 16;
 
-  u32x4 ra0, ra1, rb0, rb1, rb2, rb3;
-  auto load_step = [&](int s) {
-    const int tap = s / chunks, chunk = s - tap * chunks;
+  // staging registers: TWO sets -- the loads of step s+2 are issued while step s multiplies; step s+1's operands
+  // (issued one step earlier) are written to the other LDS buffer at the end of step s
+  struct Stage { u32x4 a0, a1, b0, b1, b2, b3; };
+  Stage R0, R1;
+  int ld_tap = 0, ld_chunk = 0;  // (tap, chunk) of the next step to load: steps are loaded strictly in order, so two
+                                 // counters replace a per-step integer division
+  auto load_step = [&](int s, Stage& R) {
+    const int tap = ld_tap, chunk = ld_chunk;
+    if (++ld_chunk == chunks) {
+      ld_chunk = 0;
+      ++ld_tap;
+    }
     const int dy = KS == 3 ? tap / 3 - 1 : 0, dx = KS == 3 ? tap % 3 - 1 : 0;
     const int hh = a_h + dy, ww = a_w + dx;
     const bool ok = a_live && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
     if (ok) {
       const size_t off = (((size_t)a_b * p.H + hh) * p.W + ww) * p.Cin + chunk * DC_KC + a_kg * 8;
-      ra0 = *reinterpret_cast<const u32x4*>(x_hi + off);
-      ra1 = *reinterpret_cast<const u32x4*>(x_lo + off);
+      R.a0 = *reinterpret_cast<const u32x4*>(x_hi + off);
+      R.a1 = *reinterpret_cast<const u32x4*>(x_lo + off);
     } else {
-      ra0 = u32x4{0, 0, 0, 0};
-      ra1 = u32x4{0, 0, 0, 0};
+      R.a0 = u32x4{0, 0, 0, 0};
+      R.a1 = u32x4{0, 0, 0, 0};
     }
     // B: 16 KB of this (step, cout tile): [plane][nf 8][kg 4][j 16][8] -> plane stride = CoutPad/16*4*16*8 elems
     const size_t plane_elems = (size_t)(p.CoutPad / 16) * 4 * 16 * 8;
     const bf16_t* wb = w_img + (size_t)s * 2 * plane_elems + (size_t)(n0 / 16) * 4 * 16 * 8;
-    // 1024 16-byte pieces, piece q = tid + 256 i: plane = q / 512 (i = 0,1 -> hi; i = 2,3 -> lo)
     const bf16_t* wlo = wb + plane_elems;
-    rb0 = *reinterpret_cast<const u32x4*>(wb + (size_t)tid * 8);
-    rb1 = *reinterpret_cast<const u32x4*>(wb + (size_t)(tid + 256) * 8);
-    rb2 = *reinterpret_cast<const u32x4*>(wlo + (size_t)tid * 8);
-    rb3 = *reinterpret_cast<const u32x4*>(wlo + (size_t)(tid + 256) * 8);
+    R.b0 = *reinterpret_cast<const u32x4*>(wb + (size_t)tid * 8);
+    R.b1 = *reinterpret_cast<const u32x4*>(wb + (size_t)(tid + 256) * 8);
+    R.b2 = *reinterpret_cast<const u32x4*>(wlo + (size_t)tid * 8);
+    R.b3 = *reinterpret_cast<const u32x4*>(wlo + (size_t)(tid + 256) * 8);
   };
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, const Stage& R) {
     unsigned char* A = smem + buf * (8192 + 16384);
     unsigned char* Bm = A + 8192;
-    *reinterpret_cast<u32x4*>(A + a_dst) = ra0;          // hi plane
-    *reinterpret_cast<u32x4*>(A + 4096 + a_dst) = ra1;   // lo plane
-    *reinterpret_cast<u32x4*>(Bm + tid * 16) = rb0;
-    *reinterpret_cast<u32x4*>(Bm + (tid + 256) * 16) = rb1;
-    *reinterpret_cast<u32x4*>(Bm + (tid + 512) * 16) = rb2;
-    *reinterpret_cast<u32x4*>(Bm + (tid + 768) * 16) = rb3;
+    *reinterpret_cast<u32x4*>(A + a_dst) = R.a0;          // hi plane
+    *reinterpret_cast<u32x4*>(A + 4096 + a_dst) = R.a1;   // lo plane
+    *reinterpret_cast<u32x4*>(Bm + tid * 16) = R.b0;
+    *reinterpret_cast<u32x4*>(Bm + (tid + 256) * 16) = R.b1;
+    *reinterpret_cast<u32x4*>(Bm + (tid + 512) * 16) = R.b2;
+    *reinterpret_cast<u32x4*>(Bm + (tid + 768) * 16) = R.b3;
   };
 
   f32x4 acc[2][4];
@@ -238,20 +262,16 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_step(0);
-  store_step(0);
-  __syncthreads();
-  for (int s = 0; s < steps; s++) {
-    const int buf = s & 1;
-    if (s + 1 < steps) load_step(s + 1);  // global loads in flight during the MFMAs
+  auto multiply = [&](int buf) {
     const unsigned char* A = smem + buf * (8192 + 16384);
     const unsigned char* Bm = A + 8192;
     bf16x8 ah[2], al[2], bh[4], bl[4];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      const int f = wr * 2 + i;
-      ah[i] = *reinterpret_cast<const bf16x8*>(A + (f * 64 + lane) * 16);
-      al[i] = *reinterpret_cast<const bf16x8*>(A + 4096 + (f * 64 + lane) * 16);
+      const int px = (wr * 2 + i) * 16 + (lane & 15);  // fragment row of this lane
+      const int off = (px * 4 + ((lane >> 4) ^ ((lane & 8) >> 2))) * 16;
+      ah[i] = *reinterpret_cast<const bf16x8*>(A + off);
+      al[i] = *reinterpret_cast<const bf16x8*>(A + 4096 + off);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -272,8 +292,26 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
     for (int i = 0; i < 2; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-    if (s + 1 < steps) store_step(buf ^ 1);
+  };
+
+  // prologue: step 0 -> LDS buffer 0, step 1 in flight in R1
+  load_step(0, R0);
+  if (steps > 1) load_step(1, R1);
+  store_step(0, R0);
+  __syncthreads();
+  // step s: issue loads(s+2) -> multiply(s) -> store(s+1) (its loads were issued during step s-1: two multiplies
+  // of cover) -> barrier.  Unrolled by two so each register set / LDS buffer has a fixed role.
+  for (int s = 0; s < steps; s += 2) {
+    if (s + 2 < steps) load_step(s + 2, R0);
+    multiply(0);
+    if (s + 1 < steps) store_step(1, R1);
     __syncthreads();
+    if (s + 1 < steps) {
+      if (s + 3 < steps) load_step(s + 3, R1);
+      multiply(1);
+      if (s + 2 < steps) store_step(0, R0);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: accumulators -> LDS tile [64 px][128 + 4 pad] fp32
