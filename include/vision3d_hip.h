@@ -114,6 +114,17 @@ int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_image, const 
                                int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
                                float* out, v3d_stream_t stream);
 
+/* ---- T3 backward (spconv indice_conv backward; the reference trains through it at train.py:65).
+ * Data gradient: dX[i] = sum_k dY[nbrT[k][i]] @ W[k]^T -- the forward entry points above on the TRANSPOSED
+ * rulebook (v3d_rulebook_transpose; a submanifold table is its own transpose with the offsets reversed) and the
+ * transposed weights.  Weight gradient: dW[k] = sum_{pairs} X[i]^T dY[o], exact-fp32 MFMA, deterministic. */
+int v3d_rulebook_transpose(const int32_t* nbr, const int32_t* n_out, int cap_out, int K, int cap_in, int32_t* nbr_t,
+                           v3d_stream_t stream);
+size_t v3d_sparse_conv_bwd_weight_workspace(int K, int Cin, int Cout);
+int v3d_sparse_conv_bwd_weight(const float* X, const float* dY, const int32_t* nbr, const int32_t* n_out, int cap_out,
+                               int K, int Cin, int Cout, float* dW, void* workspace, size_t workspace_bytes,
+                               v3d_stream_t stream);
+
 /* Timing harness (bench.py, tools/): every subsequent sparse-conv launch is issued n times back to back. */
 void v3d_debug_set_repeat(int n);
 

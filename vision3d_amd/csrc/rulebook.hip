@@ -330,3 +330,30 @@ extern "C" int v3d_rulebook_sparse(const int32_t* coords_in, const int32_t* n_in
                                coords_out, n_out, cap_out, nbr, overflow, h, first_ticket, cand_slot, chunk_counts,
                                nullptr, 1, st);
 }
+
+// ---------------------------------------------------------------------------------- transposed table (backward)
+// nbrT[k][i] = o  <=>  nbr[k][o] = i.  Every (input row, offset) feeds at most one output row, so the scatter has
+// no collisions.  Used by the data-gradient of strided layers: dX[i] = sum_k dY[nbrT[k][i]] @ W[k]^T is the same
+// output-stationary gather as the forward pass (submanifold tables are their own transpose with k reversed).
+__global__ __launch_bounds__(V3D_BLOCK) void rb_transpose_kernel(const int* __restrict__ nbr, const int* __restrict__ n_out_ptr,
+                                                                 int cap_out, int K, int cap_in, int* __restrict__ nbrT) {
+  const int n = min(*n_out_ptr, cap_out);
+  const long long total = (long long)K * n;
+  for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * V3D_BLOCK) {
+    const int k = (int)(t / n), o = (int)(t % n);
+    const int i = nbr[(size_t)k * cap_out + o];
+    if (i >= 0 && i < cap_in) nbrT[(size_t)k * cap_in + i] = o;
+  }
+}
+
+extern "C" int v3d_rulebook_transpose(const int32_t* nbr, const int32_t* n_out, int cap_out, int K, int cap_in,
+                                      int32_t* nbr_t, v3d_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!nbr || !n_out || !nbr_t || cap_out < 1 || cap_in < 1 || K < 1) return V3D_EINVAL;
+  V3D_CHECK_HIP(hipMemsetAsync(nbr_t, 0xFF, (size_t)K * cap_in * 4, st));
+  const long long total = (long long)K * cap_out;
+  hipLaunchKernelGGL(rb_transpose_kernel, dim3(min(v3d_ceil_div(total, V3D_BLOCK), 4096)), dim3(V3D_BLOCK), 0, st, nbr, n_out,
+                     cap_out, K, cap_in, nbr_t);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}

@@ -669,6 +669,8 @@ extern "C" int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_im
   V3D_TRY(32, 64)
   V3D_TRY(64, 64)
   V3D_TRY(4, 32)
+  V3D_TRY(32, 16)
+  V3D_TRY(64, 32)
   V3D_TRY(64, 128)
   V3D_TRY(128, 128)
 #undef V3D_TRY
@@ -709,6 +711,8 @@ extern "C" int v3d_sparse_conv_fwd(const float* in, const float* weight, const i
     V3D_TRY(32, 64)
     V3D_TRY(64, 64)
     V3D_TRY(4, 32)
+    V3D_TRY(32, 16)
+    V3D_TRY(64, 32)
     V3D_TRY(64, 128)
     V3D_TRY(128, 128)
 #undef V3D_TRY
@@ -734,6 +738,93 @@ extern "C" int v3d_sparse_conv_fwd(const float* in, const float* weight, const i
   for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
     hipLaunchKernelGGL(spconv_fwd_scalar, dim3(blocks > 8192 ? 8192 : blocks), dim3(V3D_BLOCK), 0, st, in, weight, nbr,
                        n_out, cap_out, K, Cin, Cout, scale, shift, relu, out);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+// ---------------------------------------------------------------------------------- backward: weight gradient
+// dW[k][ci][co] = sum over pairs (i = nbr[k][o] >= 0) of X[i][ci] * dY[o][co]      (spconv indice_conv backward,
+// SURVEY.md section 8a T3).  A reduction over rows -> exact-fp32 MFMA v_mfma_f32_16x16x4_f32 with the PAIR index
+// as the MFMA reduction dimension: lane (r = lane&15, p = lane>>4) feeds A[ci = r][p] = X[row_p][ci0 + r] and
+// B[p][co = r] = dY[o_p][co0 + r]; both are 64-byte coalesced row slices.  grid = (K, SPLITS): block (k, s) walks
+// its slice of output rows four at a time, its 4 waves share the 16x16 output tiles round-robin; the SPLITS
+// partial matrices are summed in a fixed order by a second tiny kernel (deterministic, no atomics).
+#define BW_SPLITS 8
+
+__global__ __launch_bounds__(V3D_BLOCK) void spconv_bwd_weight_kernel(const float* __restrict__ X,
+                                                                      const float* __restrict__ dY,
+                                                                      const int* __restrict__ nbr,
+                                                                      const int* __restrict__ n_ptr, int cap, int Cin,
+                                                                      int Cout, float* __restrict__ partial /*[S][K][Cin][Cout]*/) {
+  const int n = min(*n_ptr, cap);
+  const int k = blockIdx.x, sidx = blockIdx.y, K = gridDim.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, p = lane >> 4;
+  const int ci_tiles = (Cin + 15) / 16, co_tiles = Cout / 16, tiles = ci_tiles * co_tiles;
+  const int rows_per = ((n + BW_SPLITS - 1) / BW_SPLITS + 3) & ~3;
+  const int o_lo = sidx * rows_per, o_hi = min(n, o_lo + rows_per);
+  float* outp = partial + ((size_t)sidx * K + k) * Cin * Cout;
+  for (int t0 = wave; t0 < tiles; t0 += 4 * 4) {  // each wave keeps up to 4 tiles (t0, t0+4, t0+8, t0+12) in registers
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int o0 = o_lo; o0 < o_hi; o0 += 4) {
+      const int o = o0 + p;
+      const int src = o < o_hi ? nbr[(size_t)k * cap + o] : -1;
+      if (__ballot(src >= 0) == 0ull) continue;  // none of the four rows has a neighbour under this offset
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int t = t0 + 4 * q;
+        if (t < tiles) {
+          const int ct = t / co_tiles, ot = t % co_tiles;
+          const int ci = ct * 16 + r;
+          const float a = (src >= 0 && ci < Cin) ? X[(size_t)src * Cin + ci] : 0.f;
+          const float b = src >= 0 ? dY[(size_t)o * Cout + ot * 16 + r] : 0.f;
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int t = t0 + 4 * q;
+      if (t < tiles) {
+        const int ct = t / co_tiles, ot = t % co_tiles;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {  // D[row = p*4 + rr][col = r]
+          const int ci = ct * 16 + p * 4 + rr;
+          if (ci < Cin) outp[(size_t)ci * Cout + ot * 16 + r] = acc[q][rr];
+        }
+      }
+    }
+  }
+}
+
+__global__ void spconv_bwd_weight_reduce_kernel(const float* __restrict__ partial, long long elems, float* __restrict__ dW) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+#pragma unroll
+    for (int sp = 0; sp < BW_SPLITS; sp++) s += partial[(size_t)sp * elems + i];
+    dW[i] = s;
+  }
+}
+
+extern "C" size_t v3d_sparse_conv_bwd_weight_workspace(int K, int Cin, int Cout) {
+  return (size_t)BW_SPLITS * K * Cin * Cout * sizeof(float) + 256;
+}
+
+// X (>= n_in, Cin) forward input, dY (cap_out, Cout) output gradient, nbr (K, cap_out) the FORWARD rulebook.
+extern "C" int v3d_sparse_conv_bwd_weight(const float* X, const float* dY, const int32_t* nbr, const int32_t* n_out,
+                                          int cap_out, int K, int Cin, int Cout, float* dW, void* workspace,
+                                          size_t workspace_bytes, v3d_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!X || !dY || !nbr || !n_out || !dW || !workspace || cap_out < 1 || K < 1 || Cin < 1 || Cout < 16 || Cout % 16)
+    return V3D_EINVAL;
+  if (workspace_bytes < v3d_sparse_conv_bwd_weight_workspace(K, Cin, Cout)) return V3D_EWORKSPACE;
+  hipLaunchKernelGGL(spconv_bwd_weight_kernel, dim3(K, BW_SPLITS), dim3(V3D_BLOCK), 0, st, X, dY, nbr, n_out, cap_out, Cin,
+                     Cout, (float*)workspace);
+  const long long elems = (long long)K * Cin * Cout;
+  hipLaunchKernelGGL(spconv_bwd_weight_reduce_kernel, dim3((int)((elems + 255) / 256)), dim3(256), 0, st,
+                     (const float*)workspace, elems, dW);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }

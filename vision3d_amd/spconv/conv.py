@@ -1,10 +1,12 @@
-"""SubMConv3d / SparseConv3d: rulebook (csrc/rulebook.hip) + fused forward (csrc/spconv.hip).
+"""SubMConv3d / SparseConv3d: rulebook (csrc/rulebook.hip) + fused forward (csrc/spconv.hip) + autograd.
 
 Weight layout is spconv-1.x's (k0, k1, k2, Cin, Cout), so a reference-trained state_dict
 (`cnn.blocks.{b}.{l}.0.weight`) loads unchanged.  Semantics: cross-correlation,
 identical to nn.Conv3d with weight.permute(4, 3, 0, 1, 2) (tests/test_sparse_conv_oracle.py).
 
-Forward only in this round: the output carries no autograd graph (training kernels are the next row).
+When gradients are required (training) the layer runs through spconv/functional.py (data gradient = the same
+gather kernel on the transposed rulebook, weight gradient = deterministic MFMA reduction); inference keeps the
+fused conv + folded-BatchNorm + ReLU launch.
 """
 import math
 
@@ -160,6 +162,19 @@ class _SparseConvBase(nn.Module):
         """`scale/shift/relu` are the fused epilogue used by SparseSequential for conv+BN(eval)+ReLU."""
         assert isinstance(x, SparseConvTensor)
         rb = self.rulebook(x)
+        if torch.is_grad_enabled() and (self.weight.requires_grad or x.features.requires_grad):
+            from .functional import sparse_conv_autograd
+            feats = sparse_conv_autograd(x.features, self.weight, rb, self.subm, self.algo)
+            if self.bias is not None:
+                feats = feats + self.bias
+            if scale is not None:
+                feats = feats * scale + shift
+            if relu:
+                feats = torch.relu(feats)
+            out = SparseConvTensor(feats, rb.out_indices, rb.out_shape, x.batch_size)
+            out.indice_dict = x.indice_dict
+            out._n_dev = rb.n_dev
+            return out
         if self.bias is not None:  # fold the bias into the affine epilogue
             b = self.bias.detach()
             shift = b if shift is None else shift + b * scale

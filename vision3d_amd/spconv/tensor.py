@@ -4,6 +4,12 @@ import torch
 from .. import _lib as L
 
 
+def _dense_scatter(out, idx, features):
+    out = out.permute(0, 2, 3, 4, 1).contiguous()          # (B, D, H, W, C): one row per site
+    out = out.index_put((idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]), features)
+    return out.permute(0, 4, 1, 2, 3).contiguous()
+
+
 class Rulebook(object):
     """Output-stationary neighbour table of one sparse convolution geometry.
 
@@ -51,6 +57,13 @@ class SparseConvTensor(object):
 
     def dense(self, channels_first=True):
         """Scatter into zeros: (B, C, D, H, W) (or (B, D, H, W, C)); detector/sparse_cnn.py:130."""
+        if torch.is_grad_enabled() and self.features.requires_grad:
+            # training: differentiable scatter (gradient = gather of the dense gradient at the active sites)
+            n, c = self.features.shape
+            d, h, w = self.spatial_shape
+            out = self.features.new_zeros((self.batch_size, c, d, h, w))
+            out = _dense_scatter(out, self.indices.long(), self.features)
+            return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
         feat = L.as_f32("dense", self.features)
         n, c = feat.shape
         d, h, w = self.spatial_shape
