@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--path", choices=["graph", "native", "fused", "eager"], default="graph",
                     help="graph: native path captured in one HIP graph; native: backbone plan + MFMA dense head; "
                          "fused: backbone plan + torch (MIOpen) RPN; eager: per-op python -> C ABI")
+    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
+                    help="forward: the headline metric; train: BASELINE configs[2] (SECOND train step, bs=8/GPU, gradient "
+                         "all-reduce over RCCL) -- a secondary line, same JSON contract")
+    ap.add_argument("--no-amp", action="store_true", help="train mode: keep the dense RPN/head in fp32 (default bf16 autocast)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch event timing pass (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=3)
@@ -56,8 +60,83 @@ def layer_algorithmic_bytes(stats):
         + 8 * stats["pairs"]
 
 
+def train_main(args):
+    """configs[2]: one optimiser step of SECOND per GPU batch; gradients all-reduced (flat bucket) over RCCL.
+
+    step = device voxelizer -> sparse backbone (autograd through the HIP kernels) -> dense RPN/head (torch, bf16
+    autocast) -> ProposalLoss -> backward -> all-reduce -> clip_grad_norm_(35) -> Adam   (reference train.py:58-70)."""
+    from vision3d_amd import dist_util, synth
+    from vision3d_amd.core import Preprocessor, ProposalTargetAssigner
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.detector import ProposalLoss, Second
+    import torch.distributed as dist
+    rank, local, world = dist_util.env_world()
+    torch.cuda.set_device(local)
+    dist_util.init_from_env("nccl")
+    cfg = second_car_cfg()
+    if args.points is None:
+        args.points = 16384
+    bs = args.batch if args.batch > 1 else 8
+    torch.manual_seed(0)
+    model = Second(cfg).cuda().train()
+    loss_fn = ProposalLoss(cfg)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, betas=(0.9, 0.99), weight_decay=0.01)
+    pre, assigner = Preprocessor(cfg, seed=0), ProposalTargetAssigner(cfg)
+    fids = [rank * bs + i for i in range(bs)]
+    clouds = [torch.from_numpy(synth.make_cloud(f, args.points)).cuda() for f in fids]
+    targets = []
+    for f in fids:
+        gt = torch.from_numpy(synth.make_gt_boxes(f))
+        targets.append(assigner(dict(boxes=gt, class_idx=torch.zeros(len(gt), dtype=torch.long),
+                                     box_ignore=torch.zeros(len(gt), dtype=torch.bool))))
+    tgt = {k: torch.stack([t[k] for t in targets]).cuda() for k in ("G_cls", "G_reg", "M_cls", "M_reg")}
+    params = [p for p in model.parameters() if p.requires_grad]
+    amp = not args.no_amp
+
+    def step():
+        item = pre(dict(points=clouds))
+        item.update(tgt)
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            losses = loss_fn(model(item))
+        losses["loss"].backward()
+        dist_util.allreduce_gradients_flat(params, world)
+        torch.nn.utils.clip_grad_norm_(params, max_norm=35)
+        opt.step()
+        return losses["loss"].detach()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = dist_util.max_over_ranks(time.perf_counter() - t0, world, device="cuda")
+    if rank == 0:
+        print(json.dumps(dict(
+            metric="frames/sec SECOND train step, 16k-pt KITTI cloud", value=world * bs * args.steps / elapsed, unit="frames/s",
+            n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
+            scaling="weak", vs_baseline=None,
+            dtype=("bf16 autocast dense RPN/head; " if amp else "fp32 dense RPN/head; ") + "sparse convs bf16-split MFMA fwd/dX, fp32 MFMA dW",
+            data="synthetic",
+            config=dict(workload="SECOND train step (BASELINE configs[2]): fwd + ProposalLoss + bwd + grad all-reduce + clip + Adam",
+                        frames_per_gpu_per_step=bs, points_per_frame=args.points, parallelism=f"data-parallel x{world}, flat-bucket all-reduce"),
+            roofline=None, cpu_baseline=None, final_loss=float(loss))))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.mode == "train":
+        return train_main(args)
     from vision3d_amd import dist_util
     rank, local, world = dist_util.env_world()
     assert torch.cuda.is_available(), "bench.py needs a GPU (vision3d_amd has no CPU path)"

@@ -744,72 +744,146 @@ extern "C" int v3d_sparse_conv_fwd(const float* in, const float* weight, const i
 
 // ---------------------------------------------------------------------------------- backward: weight gradient
 // dW[k][ci][co] = sum over pairs (i = nbr[k][o] >= 0) of X[i][ci] * dY[o][co]      (spconv indice_conv backward,
-// SURVEY.md section 8a T3).  A reduction over rows -> exact-fp32 MFMA v_mfma_f32_16x16x4_f32 with the PAIR index
+// SURVEY.md section 8a T3).  A reduction over pairs -> exact-fp32 MFMA v_mfma_f32_16x16x4_f32 with the PAIR index
 // as the MFMA reduction dimension: lane (r = lane&15, p = lane>>4) feeds A[ci = r][p] = X[row_p][ci0 + r] and
-// B[p][co = r] = dY[o_p][co0 + r]; both are 64-byte coalesced row slices.  grid = (K, SPLITS): block (k, s) walks
-// its slice of output rows four at a time, its 4 waves share the 16x16 output tiles round-robin; the SPLITS
-// partial matrices are summed in a fixed order by a second tiny kernel (deterministic, no atomics).
-#define BW_SPLITS 8
+// B[p][co = r] = dY[o_p][co0 + r]; both are 64-byte row slices.
+//
+// grid = (row slabs S, K offsets, channel tile groups).  Each wave owns a quarter of its block's slab: it reads
+// 64 rulebook entries at a time (coalesced), COMPACTS the live pairs with ballot/popcount into a wave-private LDS
+// queue, and consumes the queue 16 pairs at a time -- so the MFMAs only ever see live pairs (a 3x3x3 offset is
+// populated for ~10-40 % of the rows).  The TI x TJ accumulator tiles stay in registers for the whole slab; the 4
+// waves are summed through LDS in wave order and the S slab partials by a second tiny kernel in slab order:
+// deterministic, no atomics.
+#define BW_MAX_SPLITS 64
+#define BW_Q 128
 
-__global__ __launch_bounds__(V3D_BLOCK) void spconv_bwd_weight_kernel(const float* __restrict__ X,
-                                                                      const float* __restrict__ dY,
-                                                                      const int* __restrict__ nbr,
-                                                                      const int* __restrict__ n_ptr, int cap, int Cin,
-                                                                      int Cout, float* __restrict__ partial /*[S][K][Cin][Cout]*/) {
+template <int TI, int TJ>
+__global__ __launch_bounds__(V3D_BLOCK) void spconv_bwd_weight_tiles(const float* __restrict__ X,
+                                                                     const float* __restrict__ dY,
+                                                                     const int* __restrict__ nbr,
+                                                                     const int* __restrict__ n_ptr, int cap, int Cin,
+                                                                     int Cout, int rows_per_block, int groups_j,
+                                                                     float* __restrict__ partial /*[S][K][Cin][Cout]*/) {
+  __shared__ int q_src[4][BW_Q];
+  __shared__ int q_out[4][BW_Q];
+  __shared__ float red[TI * TJ * 256];
   const int n = min(*n_ptr, cap);
-  const int k = blockIdx.x, sidx = blockIdx.y, K = gridDim.x;
+  const int slab = blockIdx.x, k = blockIdx.y, K = gridDim.y;
+  const int lo = slab * rows_per_block;
+  if (lo >= n) return;  // the reduce kernel only reads the live slabs
+  const int hi = min(n, lo + rows_per_block);
+  const int ci_base = (blockIdx.z / groups_j) * TI * 16, co_base = (blockIdx.z % groups_j) * TJ * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, p = lane >> 4;
-  const int ci_tiles = (Cin + 15) / 16, co_tiles = Cout / 16, tiles = ci_tiles * co_tiles;
-  const int rows_per = ((n + BW_SPLITS - 1) / BW_SPLITS + 3) & ~3;
-  const int o_lo = sidx * rows_per, o_hi = min(n, o_lo + rows_per);
-  float* outp = partial + ((size_t)sidx * K + k) * Cin * Cout;
-  for (int t0 = wave; t0 < tiles; t0 += 4 * 4) {  // each wave keeps up to 4 tiles (t0, t0+4, t0+8, t0+12) in registers
-    f32x4 acc[4];
+  const int rows_per_wave = rows_per_block >> 2;  // a multiple of 64
+  const int wlo = lo + wave * rows_per_wave, whi = min(hi, wlo + rows_per_wave);
+  const int* __restrict__ nk = nbr + (size_t)k * cap;
+  int* qs = q_src[wave];
+  int* qo = q_out[wave];
+
+  f32x4 acc[TI][TJ];
 #pragma unroll
-    for (int q = 0; q < 4; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int o0 = o_lo; o0 < o_hi; o0 += 4) {
-      const int o = o0 + p;
-      const int src = o < o_hi ? nbr[(size_t)k * cap + o] : -1;
-      if (__ballot(src >= 0) == 0ull) continue;  // none of the four rows has a neighbour under this offset
+  for (int t = 0; t < TI; t++)
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int t = t0 + 4 * q;
-        if (t < tiles) {
-          const int ct = t / co_tiles, ot = t % co_tiles;
-          const int ci = ct * 16 + r;
-          const float a = (src >= 0 && ci < Cin) ? X[(size_t)src * Cin + ci] : 0.f;
-          const float b = src >= 0 ? dY[(size_t)o * Cout + ot * 16 + r] : 0.f;
-          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
-        }
+    for (int u = 0; u < TJ; u++) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // 16 queue entries from `base`, the first `valid` of them live
+  auto consume = [&](int base, int valid) {
+    float a[4][TI], b[4][TJ];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+      const int e = 4 * s4 + p;
+      const bool ok = e < valid;
+      const int src = ok ? qs[base + e] : 0, o = ok ? qo[base + e] : 0;
+#pragma unroll
+      for (int t = 0; t < TI; t++) {
+        const int ci = ci_base + 16 * t + r;
+        a[s4][t] = (ok && ci < Cin) ? X[(size_t)src * Cin + ci] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < TJ; u++) {
+        const int co = co_base + 16 * u + r;
+        b[s4][u] = (ok && co < Cout) ? dY[(size_t)o * Cout + co] : 0.f;
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int t = t0 + 4 * q;
-      if (t < tiles) {
-        const int ct = t / co_tiles, ot = t % co_tiles;
+    for (int s4 = 0; s4 < 4; s4++)
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {  // D[row = p*4 + rr][col = r]
-          const int ci = ct * 16 + p * 4 + rr;
-          if (ci < Cin) outp[(size_t)ci * Cout + ot * 16 + r] = acc[q][rr];
-        }
-      }
+      for (int t = 0; t < TI; t++)
+#pragma unroll
+        for (int u = 0; u < TJ; u++) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4][t], b[s4][u], acc[t][u], 0, 0, 0);
+  };
+
+  int cnt = 0;  // wave-uniform queue length
+  int src_next = (wlo < whi && wlo + lane < whi) ? nk[wlo + lane] : -1;
+  for (int o0 = wlo; o0 < whi; o0 += 64) {
+    const int src = src_next;
+    const int o = o0 + lane;
+    src_next = (o + 64 < whi) ? nk[o + 64] : -1;  // next 64 entries in flight while this batch is consumed
+    const unsigned long long live = __ballot(src >= 0);
+    if (src >= 0) {
+      const int pos = cnt + __popcll(live & ((1ull << lane) - 1ull));
+      qs[pos] = src;
+      qo[pos] = o;
     }
+    cnt += __popcll(live);
+    int g = 0;
+    for (; cnt - g >= 16; g += 16) consume(g, 16);
+    if (g) {  // move the < 16 leftovers to the front (sources >= 16 > destinations: disjoint)
+      const int rem = cnt - g;
+      int ms = 0, mo = 0;
+      if (lane < rem) { ms = qs[g + lane]; mo = qo[g + lane]; }
+      if (lane < rem) { qs[lane] = ms; qo[lane] = mo; }
+      cnt = rem;
+    }
+  }
+  if (cnt > 0) consume(0, cnt);
+
+  // block reduction in wave order through LDS, then one coalesced store of the slab partial
+  for (int w = 0; w < 4; w++) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < TI; t++)
+#pragma unroll
+        for (int u = 0; u < TJ; u++)
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int idx = (((t * TJ + u) * 4 + rr) << 6) + lane;
+            red[idx] = w == 0 ? acc[t][u][rr] : red[idx] + acc[t][u][rr];
+          }
+    }
+    __syncthreads();
+  }
+  float* outp = partial + ((size_t)slab * K + k) * Cin * Cout;
+  for (int idx = threadIdx.x; idx < TI * TJ * 256; idx += V3D_BLOCK) {
+    const int l = idx & 63, rr = (idx >> 6) & 3, tu = idx >> 8;
+    const int ci = ci_base + 16 * (tu / TJ) + (l >> 4) * 4 + rr;  // D[row = p*4 + rr][col = r]
+    const int co = co_base + 16 * (tu % TJ) + (l & 15);
+    if (ci < Cin && co < Cout) outp[(size_t)ci * Cout + co] = red[idx];
   }
 }
 
-__global__ void spconv_bwd_weight_reduce_kernel(const float* __restrict__ partial, long long elems, float* __restrict__ dW) {
+__global__ void spconv_bwd_weight_reduce_kernel(const float* __restrict__ partial, const int* __restrict__ n_ptr, int cap,
+                                                int rows_per_block, long long elems, float* __restrict__ dW) {
+  const int n = min(*n_ptr, cap);
+  const int slabs = (n + rows_per_block - 1) / rows_per_block;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (long long)gridDim.x * blockDim.x) {
     float s = 0.f;
-#pragma unroll
-    for (int sp = 0; sp < BW_SPLITS; sp++) s += partial[(size_t)sp * elems + i];
+    for (int sp = 0; sp < slabs; sp++) s += partial[(size_t)sp * elems + i];
     dW[i] = s;
   }
 }
 
 extern "C" size_t v3d_sparse_conv_bwd_weight_workspace(int K, int Cin, int Cout) {
-  return (size_t)BW_SPLITS * K * Cin * Cout * sizeof(float) + 256;
+  return (size_t)BW_MAX_SPLITS * K * Cin * Cout * sizeof(float) + 256;
+}
+
+template <int TI, int TJ>
+static void launch_bwd_weight(const float* X, const float* dY, const int* nbr, const int* n_out, int cap, int K, int Cin,
+                              int Cout, int rows_per_block, int slabs, float* partial, hipStream_t st) {
+  const int gi = ((Cin + 15) / 16 + TI - 1) / TI, gj = ((Cout + 15) / 16 + TJ - 1) / TJ;
+  hipLaunchKernelGGL((spconv_bwd_weight_tiles<TI, TJ>), dim3(slabs, K, gi * gj), dim3(V3D_BLOCK), 0, st, X, dY, nbr, n_out,
+                     cap, Cin, Cout, rows_per_block, gj, partial);
 }
 
 // X (>= n_in, Cin) forward input, dY (cap_out, Cout) output gradient, nbr (K, cap_out) the FORWARD rulebook.
@@ -817,14 +891,21 @@ extern "C" int v3d_sparse_conv_bwd_weight(const float* X, const float* dY, const
                                           int cap_out, int K, int Cin, int Cout, float* dW, void* workspace,
                                           size_t workspace_bytes, v3d_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (!X || !dY || !nbr || !n_out || !dW || !workspace || cap_out < 1 || K < 1 || Cin < 1 || Cout < 16 || Cout % 16)
+  if (!X || !dY || !nbr || !n_out || !dW || !workspace || cap_out < 1 || K < 1 || K > 65535 || Cin < 1 || Cout < 1)
     return V3D_EINVAL;
   if (workspace_bytes < v3d_sparse_conv_bwd_weight_workspace(K, Cin, Cout)) return V3D_EWORKSPACE;
-  hipLaunchKernelGGL(spconv_bwd_weight_kernel, dim3(K, BW_SPLITS), dim3(V3D_BLOCK), 0, st, X, dY, nbr, n_out, cap_out, Cin,
-                     Cout, (float*)workspace);
+  int rows_per_block = ((cap_out + BW_MAX_SPLITS - 1) / BW_MAX_SPLITS + 255) & ~255;
+  if (rows_per_block < 256) rows_per_block = 256;
+  const int slabs = (cap_out + rows_per_block - 1) / rows_per_block;
+  const int ti = Cin > 32 ? 4 : (Cin > 16 ? 2 : 1), tj = Cout > 32 ? 4 : (Cout > 16 ? 2 : 1);
+  float* partial = (float*)workspace;
+#define BW_CASE(A, B)                                                                                              \
+  if (ti == A && tj == B) launch_bwd_weight<A, B>(X, dY, nbr, n_out, cap_out, K, Cin, Cout, rows_per_block, slabs, partial, st)
+  BW_CASE(1, 1); BW_CASE(1, 2); BW_CASE(1, 4); BW_CASE(2, 1); BW_CASE(2, 2); BW_CASE(2, 4); BW_CASE(4, 1); BW_CASE(4, 2); BW_CASE(4, 4);
+#undef BW_CASE
   const long long elems = (long long)K * Cin * Cout;
   hipLaunchKernelGGL(spconv_bwd_weight_reduce_kernel, dim3((int)((elems + 255) / 256)), dim3(256), 0, st,
-                     (const float*)workspace, elems, dW);
+                     (const float*)workspace, n_out, cap_out, rows_per_block, elems, dW);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
