@@ -55,6 +55,19 @@ size_t v3d_nms_rotated_workspace(int N);
 int v3d_nms_rotated(const float* boxes, const float* scores, int N, float iou_threshold, int64_t* keep,
                     int32_t* n_keep, void* workspace, size_t workspace_bytes, v3d_stream_t stream);
 
+/* ---- Proposal stage of the BEV head, fused on the device.
+ * Replaces ProposalLayer.inference after the 1x1 heads (detector/proposal.py:39-80: sigmoid, top-k per (frame, class),
+ * core/box_encode.py:13-21 decode, ops/iou_nms.py:90-134 coordinate-offset batched rotated NMS, per-class score cut).
+ * head_maps (B, n_cls*n_yaw*8, H, W) f32 = [class logits (c, yaw) | box deltas (c, dof, yaw)] channels (the
+ * conv_cls | conv_reg outputs concatenated); anchors (n_cls, n_yaw, H, W, 7) f32; score_thresh_host (n_cls) on the
+ * HOST.  Outputs are padded to N = B*n_cls*topk rows, sorted by decreasing score; *n_out (device i32) = rows valid.
+ * Candidate order inside a group: (score descending, anchor index ascending).  No host synchronisation. */
+size_t v3d_proposals_workspace(int B, int n_cls, int topk);
+int v3d_proposals(const float* head_maps, const float* anchors, int B, int n_cls, int n_yaw, int H, int W, int topk,
+                  const float* score_thresh_host, float iou_threshold, float* out_boxes, int64_t* out_batch_idx,
+                  int64_t* out_class_idx, float* out_scores, int32_t* n_out, void* workspace, size_t workspace_bytes,
+                  v3d_stream_t stream);
+
 /* ---- A11: points in cuboids / rectangles.
  * Replaces core/geometry.py:27-65 (PointsInCuboids._get_mask when use_z != 0,
  * PointsNotInRectangles._get_mask otherwise).  points (N,C>=3) f32, boxes (n,7) f32
@@ -127,6 +140,8 @@ int v3d_sparse_conv_bwd_weight(const float* X, const float* dY, const int32_t* n
 
 /* Timing harness (bench.py, tools/): every subsequent sparse-conv launch is issued n times back to back. */
 void v3d_debug_set_repeat(int n);
+/* Debug/benchmark aid: force the row-tile count of the packed sparse kernel (0 = automatic, 1, 2, 4). */
+void v3d_debug_set_rows_mt(int mt);
 
 /* ---- T2: SparseConvTensor.dense() (detector/sparse_cnn.py:128-133): zero-fill + scatter.
  * feat (cap,C), coords (cap,4), *n rows -> dense (B,C,D,H,W) f32. */

@@ -87,7 +87,7 @@ def test_tiny_and_empty_inputs(oracle):
         assert out.features.shape == (n, 16)
         if n:
             ref = oracle.sparse_conv_fwd(feats, conv.weight.detach().cpu().numpy(), oracle.subm_rulebook(coords, [8, 80, 160], 3))
-            assert_features_close(out.features.cpu().numpy(), ref, f"tiny n={n}")
+            assert_features_close(out.features.detach().cpu().numpy(), ref, f"tiny n={n}")
     assert out.dense().shape == (1, 16, 8, 80, 160)
 
 
@@ -98,7 +98,7 @@ def test_densify_exact(oracle):
     oc2, _, osh2 = oracle.sparse_rulebook(oc, osh, 3, 2, 1)
     oc3, _, osh3 = oracle.sparse_rulebook(oc2, osh2, 3, 2, [0, 1, 1])
     feats = rng.standard_normal((len(oc3), 64)).astype(np.float32)
-    got = make_tensor(oc3, feats, osh3, 2).dense().cpu().numpy()
+    got = make_tensor(oc3, feats, osh3, 2).dense().detach().cpu().numpy()
     np.testing.assert_array_equal(got, oracle.densify(feats, oc3, 2, osh3))
 
 
@@ -117,5 +117,5 @@ def test_sparse_sequential_fuses_and_matches_unfused(oracle):
         raw = layer[0](x)
         with torch.no_grad():
             ref = torch.relu(layer[1](raw.features))
-        assert_features_close(fused.features.cpu().numpy(), ref.cpu().numpy(), "fused vs unfused")
+        assert_features_close(fused.features.detach().cpu().numpy(), ref.cpu().numpy(), "fused vs unfused")
         np.testing.assert_array_equal(fused.indices.cpu().numpy(), raw.indices.cpu().numpy())

@@ -23,6 +23,8 @@ _SIGNATURES = {
     "v3d_box_iou_rotated": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "v3d_nms_rotated_workspace": (_sz, [_i]),
     "v3d_nms_rotated": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "v3d_proposals_workspace": (_sz, [_i, _i, _i]),
+    "v3d_proposals": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "v3d_points_in_boxes": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "v3d_voxelize_workspace": (_sz, [_i]),
     "v3d_voxelize": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -34,6 +36,7 @@ _SIGNATURES = {
     "v3d_sparse_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "v3d_sparse_conv_fwd_packed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "v3d_debug_set_repeat": (None, [_i]),
+    "v3d_debug_set_rows_mt": (None, [_i]),
     "v3d_rulebook_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "v3d_sparse_conv_bwd_weight_workspace": (_sz, [_i, _i, _i]),
     "v3d_sparse_conv_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

@@ -201,7 +201,7 @@ extern "C" int v3d_nms_rotated(const float* boxes, const float* scores, int N, f
   hipStream_t st = (hipStream_t)stream;
   if (N < 0 || !n_keep) return V3D_EINVAL;
   if (N == 0) {
-    V3D_CHECK_HIP(hipMemsetAsync(n_keep, 0, sizeof(int32_t), st));
+    V3D_CHECK_HIP(v3d_fill_async(n_keep, 0, sizeof(int32_t), st));
     return V3D_OK;
   }
   if (!boxes || !scores || !keep || !workspace) return V3D_EINVAL;

@@ -218,7 +218,7 @@ int v3d_i_hash_build(const int32_t* coords, const int32_t* n, int cap, const int
   const int32_t ones[3] = {1, 1, 1};
   int rc = fill_geom(g, shape, ones, nullptr, nullptr);
   if (rc) return rc;
-  if (clear) V3D_CHECK_HIP(hipMemsetAsync(h.keys, 0xFF, (size_t)h.hcap * 8, st));
+  if (clear) V3D_CHECK_HIP(v3d_fill_async(h.keys, 0xFF, (size_t)h.hcap * 8, st));
   V3dHash hh = v3d_make_hash(h.keys, h.hcap);
   hipLaunchKernelGGL(rb_hash_build_kernel, dim3(min(v3d_ceil_div(cap, V3D_BLOCK), 2048)), dim3(V3D_BLOCK), 0, st,
                      (const int4*)coords, n, cap, g, hh, h.vals);
@@ -258,9 +258,9 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
   if ((char*)first_ticket != (char*)out.keys + (size_t)out.hcap * 8 || (char*)out.vals != (char*)first_ticket + (size_t)out.hcap * 4)
     return V3D_EINVAL;
   if (clear) {  // overflow flag convention: <= 0 (0 or -1) = fine, 1 = a capacity was hit
-    V3D_CHECK_HIP(hipMemsetAsync(out.keys, 0xFF, (size_t)out.hcap * 16, st));
-    V3D_CHECK_HIP(hipMemsetAsync(nbr, 0xFF, (size_t)g.K * cap_out * 4, st));
-    V3D_CHECK_HIP(hipMemsetAsync(overflow, 0, 4, st));
+    V3D_CHECK_HIP(v3d_fill_async(out.keys, 0xFF, (size_t)out.hcap * 16, st));
+    V3D_CHECK_HIP(v3d_fill_async(nbr, 0xFF, (size_t)g.K * cap_out * 4, st));
+    V3D_CHECK_HIP(v3d_fill_async(overflow, 0, 4, st));
   }
   V3dHash h = v3d_make_hash(out.keys, out.hcap);
   const int tblocks = min(v3d_ceil_div(tickets, V3D_BLOCK), 4096);
@@ -350,7 +350,7 @@ extern "C" int v3d_rulebook_transpose(const int32_t* nbr, const int32_t* n_out, 
                                       int32_t* nbr_t, v3d_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!nbr || !n_out || !nbr_t || cap_out < 1 || cap_in < 1 || K < 1) return V3D_EINVAL;
-  V3D_CHECK_HIP(hipMemsetAsync(nbr_t, 0xFF, (size_t)K * cap_in * 4, st));
+  V3D_CHECK_HIP(v3d_fill_async(nbr_t, 0xFF, (size_t)K * cap_in * 4, st));
   const long long total = (long long)K * cap_out;
   hipLaunchKernelGGL(rb_transpose_kernel, dim3(min(v3d_ceil_div(total, V3D_BLOCK), 4096)), dim3(V3D_BLOCK), 0, st, nbr, n_out,
                      cap_out, K, cap_in, nbr_t);

@@ -232,7 +232,7 @@ extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n
   hipStream_t st = (hipStream_t)stream;
   const v3d_backbone_config& c = p->cfg;
   PlanStage& s0 = p->stages[0];
-  V3D_CHECK_HIP(hipMemsetAsync(p->ff_begin, 0xFF, p->ff_bytes, st));  // all hash tables, strided nbr tables, flags
+  V3D_CHECK_HIP(v3d_fill_async(p->ff_begin, 0xFF, p->ff_bytes, st));  // all hash tables, strided nbr tables, flags
   int rc = v3d_i_voxelize(points, n_points, c.point_channels, frame_offsets_host, B, c.voxel_size, c.bounds, c.max_pts,
                           c.max_voxels, nullptr, s0.coords, p->occupancy, p->mean, s0.n_dev, p->vox_ws, p->vox_ws_bytes, 0,
                           st);

@@ -478,18 +478,22 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float f) {
 //   hi*Whi + hi*Wlo + mid*Whi + lo*Whi      (mid*Wlo ~ 2^-26 is dropped)
 // so the only representation error left is the weights' 2^-18 residual: half the error of a 2x2-term
 // split for one more MFMA, which the latency-bound sparse kernel does not notice.
+// hi is rounded to nearest even (so |mid| <= 2^-9 |x| and the dropped mid*Wlo term stays ~2^-26); mid and lo are
+// plain truncations of the exact remainders -- x - hi has <= 16 significant bits, so hi + mid + lo == x exactly
+// either way, and truncation is 2 VALU ops per element instead of 8 (the split, not the MFMA, was the issue-
+// slot limiter of this kernel).  The two bf16 halves of a dword are merged with one v_perm_b32.
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
   u32x4_t h, m, l;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const float x0 = x[2 * i], x1 = x[2 * i + 1];
-    const unsigned h0 = bf16_rne_bits(x0), h1 = bf16_rne_bits(x1);
-    const float r0 = x0 - __uint_as_float(h0 << 16), r1 = x1 - __uint_as_float(h1 << 16);
-    const unsigned m0 = bf16_rne_bits(r0), m1 = bf16_rne_bits(r1);
-    const unsigned l0 = bf16_rne_bits(r0 - __uint_as_float(m0 << 16)), l1 = bf16_rne_bits(r1 - __uint_as_float(m1 << 16));
-    h[i] = h0 | (h1 << 16);
-    m[i] = m0 | (m1 << 16);
-    l[i] = l0 | (l1 << 16);
+    const unsigned u0 = __float_as_uint(x[2 * i]), u1 = __float_as_uint(x[2 * i + 1]);
+    const unsigned h0 = (u0 + 0x7FFFu + ((u0 >> 16) & 1u)) & 0xFFFF0000u, h1 = (u1 + 0x7FFFu + ((u1 >> 16) & 1u)) & 0xFFFF0000u;
+    const float r0 = x[2 * i] - __uint_as_float(h0), r1 = x[2 * i + 1] - __uint_as_float(h1);
+    const unsigned m0 = __float_as_uint(r0) & 0xFFFF0000u, m1 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float l0 = r0 - __uint_as_float(m0), l1 = r1 - __uint_as_float(m1);
+    h[i] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);  // (h1 & 0xFFFF0000) | (h0 >> 16)
+    m[i] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    l[i] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
   }
   hi = __builtin_bit_cast(bf16x8_t, h);
   mid = __builtin_bit_cast(bf16x8_t, m);
@@ -642,9 +646,167 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
   }
 }
 
+// Same algorithm with MT (2 or 4) row tiles per workgroup: every wave still owns the offsets k = w, w+4, ... but
+// multiplies each W[k] fragment set, once in registers, against MT gathered 16-row tiles -- the L2->CU weight
+// stream (the measured limiter of the 16-row kernel: 442 KB per block at 64->64) shrinks MT-fold.  A operands
+// are double-buffered per tile, B per offset; the 4 wave partials are summed through LDS in wave order.
+template <int CIN, int COUT, int MT>
+__global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_mt(const float* __restrict__ in,
+                                                                const unsigned short* __restrict__ wimg,
+                                                                const int* __restrict__ nbr, const int* __restrict__ n_ptr,
+                                                                int cap, int K, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int relu,
+                                                                float* __restrict__ out) {
+  static_assert(MT == 2 || MT == 4, "even tile counts only (static A-buffer parity)");
+  constexpr int KI = (CIN + 31) / 32, NB = COUT / 16;
+  constexpr int NF = KI * NB * 2;
+  constexpr int NW = V3D_BLOCK / V3D_WAVE;
+  constexpr int RB = 16 * MT;
+  extern __shared__ __attribute__((aligned(16))) float smem_rows[];
+  float* red = smem_rows;                          // [MT][NB][4][64] running sum over waves
+  int* nbr_s = (int*)(red + MT * NB * 4 * 64);     // [K][RB]
+  const int n = min(*n_ptr, cap);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * RB;
+  if (row0 >= n) return;
+  const int r = lane & 15, kg = lane >> 4;
+  for (int t = tid; t < K * RB; t += V3D_BLOCK) {
+    const int k = t / RB, rr = t % RB;
+    nbr_s[t] = (row0 + rr < n) ? nbr[(size_t)k * cap + row0 + rr] : -1;
+  }
+  __syncthreads();
+
+  float araw[2][KI][8];
+  u32x4_t braw[2][NF];
+  auto load_a = [&](int k, int m, float (&a)[KI][8]) {
+    const int src = nbr_s[k * RB + m * 16 + r];
+#pragma unroll
+    for (int ki = 0; ki < KI; ki++) {
+      const int c0 = ki * 32 + kg * 8;
+      if (src >= 0 && c0 < CIN) {
+        const float* p = in + (size_t)src * CIN + c0;
+        if constexpr (CIN % 8 == 0) {
+          const float4 v0 = reinterpret_cast<const float4*>(p)[0], v1 = reinterpret_cast<const float4*>(p)[1];
+          a[ki][0] = v0.x; a[ki][1] = v0.y; a[ki][2] = v0.z; a[ki][3] = v0.w;
+          a[ki][4] = v1.x; a[ki][5] = v1.y; a[ki][6] = v1.z; a[ki][7] = v1.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; e++) a[ki][e] = (c0 + e < CIN) ? p[e] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) a[ki][e] = 0.f;
+      }
+    }
+  };
+  auto load_b = [&](int k, u32x4_t (&b)[NF]) {
+    const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(wimg) + (size_t)k * NF * 64 + lane;
+#pragma unroll
+    for (int f = 0; f < NF; f++) b[f] = wp[(size_t)f * 64];
+  };
+
+  f32x4 acc[MT][NB];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int j = 0; j < NB; j++) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto multiply = [&](const float (&a)[KI][8], const u32x4_t (&b)[NF], f32x4 (&c)[NB]) {
+#pragma unroll
+    for (int ki = 0; ki < KI; ki++) {
+      bf16x8_t ah, am, al;
+      split8(a[ki], ah, am, al);
+#pragma unroll
+      for (int j = 0; j < NB; j++)  // smallest terms first
+        c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), c[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NB; j++)
+        c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), c[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NB; j++)
+        c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2 + 1]), c[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NB; j++)
+        c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), c[j], 0, 0, 0);
+    }
+  };
+  // one offset: MT tiles against bcur; the next offset's B and first A tile are fetched while it runs
+  auto offset_step = [&](int k, const u32x4_t (&bcur)[NF], u32x4_t (&bnext)[NF]) {
+    const bool more = k + NW < K;
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+      if (m + 1 < MT) load_a(k, m + 1, araw[(m + 1) & 1]);
+      else if (more) load_a(k + NW, 0, araw[0]);
+      if (m == 0 && more) load_b(k + NW, bnext);
+      multiply(araw[m & 1], bcur, acc[m]);
+    }
+  };
+  if (wave < K) {
+    load_b(wave, braw[0]);
+    load_a(wave, 0, araw[0]);
+  }
+  for (int k = wave; k < K; k += 2 * NW) {
+    offset_step(k, braw[0], braw[1]);
+    if (k + NW < K) offset_step(k + NW, braw[1], braw[0]);
+  }
+
+  for (int w = 0; w < NW; w++) {
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int idx = (((m * NB + j) * 4 + rr) << 6) + lane;
+            red[idx] = w == 0 ? acc[m][j][rr] : red[idx] + acc[m][j][rr];
+          }
+    }
+    __syncthreads();
+  }
+  // epilogue: D[row = kg*4 + rr][col = r] of tile m, column block j
+  for (int t = wave; t < MT * NB; t += NW) {
+    const int m = t / NB, j = t % NB;
+    const int col = j * 16 + r;
+    const float sc = scale ? scale[col] : 1.f, sh = scale ? shift[col] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      float v = red[((t * 4 + rr) << 6) + lane];
+      const int row = row0 + m * 16 + kg * 4 + rr;
+      if (row < n) {
+        if (scale) v = v * sc + sh;
+        if (relu) v = fmaxf(v, 0.f);
+        out[(size_t)row * COUT + col] = v;
+      }
+    }
+  }
+}
+
+int g_v3d_rows_mt = 0;  // 0 = pick from the capacity, 1 / 2 / 4 = force (microbenchmarks)
+extern "C" void v3d_debug_set_rows_mt(int mt) { g_v3d_rows_mt = mt; }
+
+template <int CIN, int COUT, int MT>
+static void launch_rows_mt(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
+                           const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
+  const size_t lds = (size_t)MT * (COUT / 16) * 4 * 64 * 4 + (size_t)K * 16 * MT * 4;
+  for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
+    hipLaunchKernelGGL((spconv_fwd_rows_mt<CIN, COUT, MT>), dim3(v3d_ceil_div(cap, 16 * MT)), dim3(V3D_BLOCK), lds, st, in,
+                       (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out);
+}
+
 template <int CIN, int COUT>
 static int launch_rows(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
                        const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
+  if constexpr (CIN >= 32 && CIN <= 64 && COUT <= 64) {  // weight stream >= 27 x 4 KB per block: share it across more rows when there are enough of them
+    int mt = g_v3d_rows_mt;
+    if (mt == 0) mt = 1;  // measured (tools/mb_rows_mt.py, 8k..134k rows): the 16-row kernel wins everywhere -- see DESIGN.md
+    if (mt == 2 || mt == 4) {
+      if (mt == 2) launch_rows_mt<CIN, COUT, 2>(in, wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, st);
+      else launch_rows_mt<CIN, COUT, 4>(in, wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, st);
+      V3D_CHECK_LAUNCH();
+      return V3D_OK;
+    }
+  }
   const size_t lds = (size_t)4 * (COUT / 16) * 4 * 64 * 4 + (size_t)K * 16 * 4;
   for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
     hipLaunchKernelGGL((spconv_fwd_rows<CIN, COUT>), dim3(v3d_ceil_div(cap, 16)), dim3(V3D_BLOCK), lds, st, in,
@@ -933,7 +1095,7 @@ extern "C" int v3d_densify(const float* feat, const int32_t* coords, const int32
   if (!feat || !coords || !n || cap < 1 || B < 1 || C < 1 || !spatial_shape_host || !dense) return V3D_EINVAL;
   const int D = spatial_shape_host[0], H = spatial_shape_host[1], Wd = spatial_shape_host[2];
   if (D < 1 || H < 1 || Wd < 1) return V3D_EINVAL;
-  V3D_CHECK_HIP(hipMemsetAsync(dense, 0, (size_t)B * C * D * H * Wd * sizeof(float), st));
+  V3D_CHECK_HIP(v3d_fill_async(dense, 0, (size_t)B * C * D * H * Wd * sizeof(float), st));
   const long long total = (long long)cap * C;
   const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
   hipLaunchKernelGGL(densify_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(V3D_BLOCK), 0, st, feat,

@@ -22,6 +22,32 @@
 static inline int v3d_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t v3d_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// Byte fill as an ordinary KERNEL node.  hipMemsetAsync inside a captured graph becomes a memset node whose fill
+// pattern was observed to be clobbered between replays on ROCm 7.2 when only blit copies ran in between (tables
+// came back zero-filled instead of 0xFF: tools/_dbg_graph.py) -- a kernel's arguments live in the graph itself.
+static __global__ __launch_bounds__(256) void v3d_fill_kernel(unsigned* __restrict__ p, size_t nwords, unsigned v) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
+  if (((uintptr_t)p & 15) == 0) {
+    const size_t nvec = nwords >> 2;
+    uint4* p4 = reinterpret_cast<uint4*>(p);
+    for (size_t i = tid; i < nvec; i += nthreads) p4[i] = make_uint4(v, v, v, v);
+    for (size_t i = (nvec << 2) + tid; i < nwords; i += nthreads) p[i] = v;
+  } else {
+    for (size_t i = tid; i < nwords; i += nthreads) p[i] = v;
+  }
+}
+static inline hipError_t v3d_fill_async(void* ptr, int byte, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  if ((((uintptr_t)ptr) & 3) || (bytes & 3)) return hipMemsetAsync(ptr, byte, bytes, st);
+  const unsigned b = (unsigned)byte & 0xFFu, v = b | (b << 8) | (b << 16) | (b << 24);
+  const size_t nwords = bytes >> 2;
+  size_t blocks = (nwords / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(v3d_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned*)ptr, nwords, v);
+  return hipGetLastError();
+}
+
 // Bump allocator over a caller-provided workspace.
 struct V3dArena {
   char* base;

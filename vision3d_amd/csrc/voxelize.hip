@@ -234,7 +234,7 @@ int v3d_i_voxelize(const float* points, int n_points, int C, const int32_t* fram
   if (!frame_offsets_host || !voxel_size_host || !bounds_host || !coords || !occupancy || !n_voxels) return V3D_EINVAL;
   if (frame_offsets_host[0] != 0 || frame_offsets_host[B] != n_points) return V3D_EINVAL;
   if (n_points == 0) {
-    V3D_CHECK_HIP(hipMemsetAsync(n_voxels, 0, sizeof(int32_t), st));
+    V3D_CHECK_HIP(v3d_fill_async(n_voxels, 0, sizeof(int32_t), st));
     return V3D_OK;
   }
   if (!points || !workspace) return V3D_EINVAL;
@@ -268,7 +268,7 @@ int v3d_i_voxelize(const float* points, int n_points, int C, const int32_t* fram
   int* out_base = ar.take<int>(VOX_MAX_FRAMES + 1);
   if (!ar.ok()) return V3D_EWORKSPACE;
   if (clear_tables)
-    V3D_CHECK_HIP(hipMemsetAsync(keys, 0xFF, (size_t)((char*)head - (char*)keys) + (size_t)cap * 4, st));
+    V3D_CHECK_HIP(v3d_fill_async(keys, 0xFF, (size_t)((char*)head - (char*)keys) + (size_t)cap * 4, st));
   V3dHash h = v3d_make_hash(keys, cap);
   const int ins_blocks = min(v3d_ceil_div(n_points, V3D_BLOCK), 2048);
   hipLaunchKernelGGL(vox_insert_kernel, dim3(ins_blocks), dim3(V3D_BLOCK), 0, st, points, p, h, first, head, pt_slot,

@@ -30,8 +30,7 @@ class GraphedSecond(object):
 
     def _body(self):
         hi, lo = self.plan.forward_split(self.static_points, self.offsets)
-        cls_map, reg_map = self.model.head.maps_from_fused(self.dense.forward(hi, lo))
-        return self.model.head.proposals_padded(cls_map, reg_map, self.anchors)
+        return self.model.head.native_proposals(self.dense.forward(hi, lo), self.anchors)
 
     def load(self, clouds):
         assert len(clouds) == len(self.frame_sizes)
@@ -46,4 +45,4 @@ class GraphedSecond(object):
     def __call__(self, clouds):
         self.load(clouds)
         self.graph.replay()
-        return self.model.head.finalize(*self.outputs)
+        return self.model.head.finalize_native(*self.outputs)

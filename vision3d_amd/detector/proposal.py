@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import _lib as L
 from ..core.box_encode import decode
 from ..ops import batched_nms_rotated, batched_nms_rotated_padded, sigmoid_focal_loss
 
@@ -85,6 +86,41 @@ class ProposalLayer(nn.Module):
         bev = torch.stack((boxes[:, 0], boxes[:, 1], boxes[:, 3], boxes[:, 4], boxes[:, 6]), dim=1)
         keep, n_keep = batched_nms_rotated_padded(bev, scores, group_idx, 0.01)
         return boxes, batch_idx, class_idx, scores, keep, n_keep
+
+    def native_proposals(self, head_maps, anchors):
+        """The whole stage after the 1x1 heads in libvision3d_hip.so (csrc/proposal.hip: 8 launches, no host
+        sync): head_maps (B, n_anchor*(1+DOF), H, W) = [cls | reg] channels of the fused head.  Returns padded
+        (boxes (N,7), batch_idx, class_idx, scores, n_out (1,) int32 on the device); capturable in a HIP graph."""
+        cfg = self.cfg
+        L.require_gpu("proposals", head_maps, anchors)
+        maps, anc = L.as_f32("proposals", head_maps), L.as_f32("proposals", anchors)
+        B, ctot, H, W = maps.shape
+        n_cls, n_yaw = cfg.NUM_CLASSES, cfg.NUM_YAW
+        if ctot != n_cls * n_yaw * (1 + self.DOF) or self.DOF != 7 or anc.numel() != n_cls * n_yaw * H * W * 7:
+            raise RuntimeError("proposals: head map / anchor grid shapes disagree")
+        N = B * n_cls * self.TOPK
+        dev = maps.device
+        boxes = torch.empty((N, 7), dtype=torch.float32, device=dev)
+        batch_idx = torch.empty((N,), dtype=torch.int64, device=dev)
+        class_idx = torch.empty((N,), dtype=torch.int64, device=dev)
+        scores = torch.empty((N,), dtype=torch.float32, device=dev)
+        n_out = torch.zeros((1,), dtype=torch.int32, device=dev)
+        lib = L.lib()
+        ws = L.workspace(lib.v3d_proposals_workspace(B, n_cls, self.TOPK), dev)
+        thresh = L.host_f32([a["score_thresh"] for a in cfg.ANCHORS[:n_cls]])
+        with torch.cuda.device(dev):
+            L.check(lib.v3d_proposals(L.ptr(maps), L.ptr(anc), B, n_cls, n_yaw, H, W, self.TOPK, thresh, 0.01, L.ptr(boxes),
+                                      L.ptr(batch_idx), L.ptr(class_idx), L.ptr(scores), L.ptr(n_out), L.ptr(ws), ws.numel(),
+                                      L.stream_ptr()), "proposals")
+        return boxes, batch_idx, class_idx, scores, n_out
+
+    @staticmethod
+    def finalize_native(boxes, batch_idx, class_idx, scores, n_out):
+        n = int(n_out.item())  # the one host read of the frame (the reference synchronises inside its NMS)
+        return [boxes[:n], batch_idx[:n], class_idx[:n], scores[:n]]
+
+    def inference_native(self, head_maps, anchors):
+        return self.finalize_native(*self.native_proposals(head_maps, anchors))
 
     def finalize(self, boxes, batch_idx, class_idx, scores, keep, n_keep):
         keep = keep[: int(n_keep.item())]

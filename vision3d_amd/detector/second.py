@@ -155,9 +155,13 @@ class Second(nn.Module):
     def head_maps_from_points(self, clouds):
         """Fully native feature path: raw points -> (cls_map, reg_map); the BEV map never leaves the split
         bf16 NHWC format between the sparse backbone and the 8 MFMA convolutions."""
+        return self.head.maps_from_fused(self.fused_head_from_points(clouds))
+
+    def fused_head_from_points(self, clouds):
+        """raw points -> (B, n_anchor*(1+DOF), H, W) fp32: the [cls | reg] output of the fused 1x1 head."""
         plan, flat, offsets = self._plan_for(clouds)
         hi, lo = plan.forward_split(flat, offsets)
-        return self.head.maps_from_fused(self.dense_plan().forward(hi, lo))
+        return self.dense_plan().forward(hi, lo)
 
     def graphed_inference(self, anchors, frame_sizes):
         """Capture raw points -> candidates+NMS as ONE HIP graph for a fixed batch geometry (frame_sizes = points
@@ -167,11 +171,15 @@ class Second(nn.Module):
         from .graph import GraphedSecond
         return GraphedSecond(self, anchors, frame_sizes)
 
-    def inference_points(self, clouds, anchors, dense="mfma"):
+    def inference_points(self, clouds, anchors, dense="mfma", proposals="native"):
         """Same result as `inference(Preprocessor(cfg)(...))` without materialising the intermediate dict.
         dense = "mfma": RPN + heads on the hand-written bf16x3 MFMA convolution (csrc/dense_conv.hip);
-        dense = "torch": fp32 nn.Conv2d (MIOpen) -- the comparison point."""
+        dense = "torch": fp32 nn.Conv2d (MIOpen) -- the comparison point.
+        proposals = "native": top-k / decode / NMS / score cut in csrc/proposal.hip; "torch": the op-by-op
+        statement of proposal.py:61-80 (ties in the top-k are then torch.topk's)."""
         if dense == "torch":
             return self.head.inference(self.rpn(self.bev_from_points(clouds)), anchors)
+        if proposals == "native":
+            return self.head.inference_native(self.fused_head_from_points(clouds), anchors)
         cls_map, reg_map = self.head_maps_from_points(clouds)
         return self.head.inference_from_maps(cls_map, reg_map, anchors)
