@@ -1,5 +1,5 @@
 // Fused proposal stage of the BEV head: sigmoid -> top-k per (frame, class) -> VoxelNet decode -> batched rotated
-// NMS -> per-class score cut, entirely on the device, in 8 launches, no host synchronisation.
+// NMS -> per-class score cut, entirely on the device, in 9 launches, no host synchronisation.
 //
 // Reference: vision3d/detector/proposal.py:39-80 (ProposalLayer.inference / _multiclass_batch_nms),
 // core/box_encode.py:13-21 (decode), ops/iou_nms.py:90-134 (coordinate-offset batched NMS).  The torch statement
@@ -20,6 +20,7 @@
 #define PROP_WAVES (PROP_THREADS / 64)
 #define PROP_MAX_TOPK 1024
 #define PROP_MAX_CLS 16
+#define PROP_CHUNKS 32  // level-1 slices per (frame, class) group
 
 struct PropGeom {
   int B, n_cls, n_yaw, HW, topk, ctot;  // ctot = n_cls*n_yaw*(1+7) channels of the fused head map
@@ -32,81 +33,96 @@ __device__ __forceinline__ unsigned prop_logit_key(float x) {                   
   return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
 
-// One workgroup per (frame, class) group.  Radix select (4 x 8 bits) of the topk-th largest LOGIT -- integer
-// work only; the sigmoid is evaluated once per element in the collection pass, where membership is decided on
-// the score itself: every element with score > S_T, then the lowest-index elements with score == S_T.
-__global__ __launch_bounds__(PROP_THREADS) void prop_topk_kernel(const float* __restrict__ maps, PropGeom g,
-                                                                 float* __restrict__ cand_score,
-                                                                 int* __restrict__ cand_anchor) {
+// Exact top-K of one index range under the total order (score descending, index ascending), by one workgroup.
+//   LEVEL 1: elements are LOGITS x[i]; radix select (4 x 8 bits) of the K-th largest logit is integer work only, the
+//            sigmoid is evaluated in the collection passes, where membership is decided on the fp32 score itself:
+//            every element with score > S_T, then the lowest-index elements with score == S_T.
+//   LEVEL 2: elements are (score, index) candidates emitted by level 1, chunk after chunk -- position order equals
+//            index order among equal scores, so the same "lowest position first" rule applies.
+// Output: K rows sorted by the total order; a range shorter than K is padded with (score -1, index -1) sentinels.
+template <int LEVEL>
+__device__ void prop_select(const float* __restrict__ x, const int* __restrict__ xi, int n, int idx_base, int K,
+                            float* __restrict__ out_score, int* __restrict__ out_idx) {
   __shared__ int hist[256];
   __shared__ unsigned sh_prefix;
   __shared__ int sh_need;
   __shared__ int sh_count;               // number of collected candidates
   __shared__ int sh_eq[PROP_WAVES + 1];  // score == S_T per wave region, then exclusive prefix
   __shared__ unsigned long long cand[PROP_MAX_TOPK];
-  const int grp = blockIdx.x, b = grp / g.n_cls, c = grp % g.n_cls;
-  const int n = g.n_yaw * g.HW;
-  const float* x = maps + ((size_t)b * g.ctot + (size_t)c * g.n_yaw) * g.HW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = g.topk;
+  const int Ke = min(K, n);  // rows that can be real
+  auto score_of = [&](int i) -> float { return LEVEL == 1 ? prop_sigmoid(x[i]) : x[i]; };
+  auto index_of = [&](int i) -> unsigned { return LEVEL == 1 ? (unsigned)(idx_base + i) : (unsigned)i; };
 
-  unsigned prefix = 0, pmask = 0;
-  int need = K;
-  for (int pass = 0; pass < 4; pass++) {
-    const int shift = 24 - 8 * pass;
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += PROP_THREADS) {
-      const int i = i0 + tid;
-      const unsigned key = i < n ? prop_logit_key(x[i]) : 0u;
-      bool active = i < n && (key & pmask) == prefix;
-      const int digit = (key >> shift) & 255;
-      // head logits cluster around the focal prior: one LDS atomic per distinct digit per wave, not per lane
-      unsigned long long todo = __ballot(active);
-      while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int d0 = __shfl(digit, leader);
-        const unsigned long long same = __ballot(active && digit == d0);
-        if (lane == leader) atomicAdd(&hist[d0], __popcll(same));
-        if (active && digit == d0) active = false;
-        todo &= ~same;
+  float s_t = 0.f;
+  if (Ke > 0) {
+    unsigned prefix = 0, pmask = 0;
+    int need = Ke;
+    for (int pass = 0; pass < 4; pass++) {
+      const int shift = 24 - 8 * pass;
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      for (int i0 = 0; i0 < n; i0 += PROP_THREADS) {
+        const int i = i0 + tid;
+        const unsigned key = i < n ? prop_logit_key(x[i]) : 0u;
+        const bool active = i < n && (key & pmask) == prefix;
+        const int digit = (key >> shift) & 255;
+        // head logits cluster around the focal prior: the most common digit of a wave costs ONE LDS atomic, the
+        // stragglers go in directly (distinct addresses do not serialise)
+        const unsigned long long todo = __ballot(active);
+        if (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const int d0 = __shfl(digit, leader);
+          const unsigned long long same = __ballot(active && digit == d0);
+          if (lane == leader) atomicAdd(&hist[d0], __popcll(same));
+          if (active && digit != d0) atomicAdd(&hist[digit], 1);
+        }
       }
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int cum = 0, sel = 0;
-      for (int bin = 255; bin >= 0; bin--) {
-        const int h = hist[bin];
-        if (cum + h >= need) { sel = bin; break; }
-        cum += h;
+      __syncthreads();
+      {  // suffix sums S[b] = #elements with digit >= b, 256 threads: the digit with S[b] >= need > S[b+1] holds the K-th
+        const int h = tid < 256 ? hist[tid] : 0;
+        int v = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int t = __shfl_down(v, off);
+          if (lane + off < 64) v += t;
+        }
+        if (tid < 256 && lane == 0) sh_eq[wave] = v;
+        __syncthreads();
+        if (tid < 256) {
+          int above = 0;
+          for (int w = wave + 1; w < 4; w++) above += sh_eq[w];
+          const int S = v + above, S_next = S - h;
+          if (S >= need && S_next < need) {
+            sh_prefix = prefix | ((unsigned)tid << shift);
+            sh_need = need - S_next;
+          }
+        }
       }
-      sh_prefix = prefix | ((unsigned)sel << shift);
-      sh_need = need - cum;
+      __syncthreads();
+      prefix = sh_prefix;
+      need = sh_need;
+      pmask |= 255u << shift;
+      __syncthreads();
     }
-    __syncthreads();
-    prefix = sh_prefix;
-    need = sh_need;
-    pmask |= 255u << shift;
-    __syncthreads();
+    // prefix = key of the Ke-th largest element; its score is the membership threshold
+    const unsigned tbits = (prefix & 0x80000000u) ? (prefix ^ 0x80000000u) : ~prefix;
+    s_t = LEVEL == 1 ? prop_sigmoid(__uint_as_float(tbits)) : __uint_as_float(tbits);
   }
-  // prefix = key of the K-th largest logit; its score is the membership threshold
-  const unsigned tkey = prefix;
-  const unsigned tbits = (tkey & 0x80000000u) ? (tkey ^ 0x80000000u) : ~tkey;
-  const float s_t = prop_sigmoid(__uint_as_float(tbits));
-
   if (tid == 0) sh_count = 0;
   __syncthreads();
-  // wave w owns the contiguous index region [w*R, (w+1)*R): "lowest index first" among ties is then a per-wave
-  // running count plus a prefix over the 16 regions
+  // wave w owns the contiguous region [w*R, (w+1)*R): "lowest index first" among ties is then a per-wave running
+  // count plus a prefix over the 16 regions
   const int R = ((n + PROP_WAVES - 1) / PROP_WAVES + 63) & ~63;
-  const int lo = wave * R, hi = min(n, lo + R);
+  const int lo = min(n, wave * R), hi = min(n, lo + R);
   int eq_here = 0;
   for (int i0 = lo; i0 < hi; i0 += 64) {
     const int i = i0 + lane;
-    const float s = i < hi ? prop_sigmoid(x[i]) : -1.f;
+    const float s = i < hi ? score_of(i) : -2.f;
     if (s > s_t) {
       const int slot = atomicAdd(&sh_count, 1);
-      if (slot < PROP_MAX_TOPK) cand[slot] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+      if (slot < PROP_MAX_TOPK)
+        cand[slot] = ((unsigned long long)prop_logit_key(s) << 32) | (unsigned)(0xFFFFFFFFu - index_of(i));
     }
     eq_here += __popcll(__ballot(s == s_t));
   }
@@ -119,26 +135,26 @@ __global__ __launch_bounds__(PROP_THREADS) void prop_topk_kernel(const float* __
       sh_eq[w] = run;
       run += e;
     }
-    sh_eq[PROP_WAVES] = sh_count;  // number of strictly-greater candidates (< K by construction)
+    sh_eq[PROP_WAVES] = min(sh_count, PROP_MAX_TOPK);  // strictly greater than the threshold (< Ke by construction)
   }
   __syncthreads();
   const int n_gt = sh_eq[PROP_WAVES];
-  const int need_eq = K - n_gt;  // >= 1
-  int seen = sh_eq[wave];        // ties before this wave's region
+  const int need_eq = Ke - n_gt;
+  int seen = sh_eq[wave];  // ties before this wave's region
   for (int i0 = lo; i0 < hi && seen < need_eq; i0 += 64) {
     const int i = i0 + lane;
-    const float s = i < hi ? prop_sigmoid(x[i]) : -1.f;
+    const float s = i < hi ? score_of(i) : -2.f;
     const unsigned long long eq = __ballot(s == s_t);
     const int rank = seen + __popcll(eq & ((1ull << lane) - 1ull));
     if (s == s_t && rank < need_eq && n_gt + rank < PROP_MAX_TOPK)
-      cand[n_gt + rank] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+      cand[n_gt + rank] = ((unsigned long long)prop_logit_key(s) << 32) | (unsigned)(0xFFFFFFFFu - index_of(i));
     seen += __popcll(eq);
   }
   __syncthreads();
-  // bitonic sort of the K candidates, descending on (score bits, ~index): scores are >= 0 so bits order them
+  // bitonic sort of the candidates, descending on (ordered score key, ~position); zero keys (padding) sink
   int npad = 1;
   while (npad < K) npad <<= 1;
-  for (int i = K + tid; i < npad; i += PROP_THREADS) cand[i] = 0ull;
+  for (int i = Ke + tid; i < npad; i += PROP_THREADS) cand[i] = 0ull;
   __syncthreads();
   for (int k = 2; k <= npad; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -153,10 +169,39 @@ __global__ __launch_bounds__(PROP_THREADS) void prop_topk_kernel(const float* __
       __syncthreads();
     }
   for (int i = tid; i < K; i += PROP_THREADS) {
-    const unsigned long long v = cand[i];
-    cand_score[(size_t)grp * K + i] = __uint_as_float((unsigned)(v >> 32));
-    cand_anchor[(size_t)grp * K + i] = (int)(0xFFFFFFFFu - (unsigned)(v & 0xFFFFFFFFull));
+    if (i < Ke) {
+      const unsigned long long v = cand[i];
+      const unsigned kbits = (unsigned)(v >> 32);
+      const unsigned pos = 0xFFFFFFFFu - (unsigned)(v & 0xFFFFFFFFull);
+      out_score[i] = __uint_as_float((kbits & 0x80000000u) ? (kbits ^ 0x80000000u) : ~kbits);
+      out_idx[i] = LEVEL == 1 ? (int)pos : xi[pos];
+    } else {
+      out_score[i] = -1.f;
+      out_idx[i] = -1;
+    }
   }
+}
+
+// level 1: grid (chunks, groups).  Each workgroup selects the top-K of its slice of the group's n_yaw*H*W anchors.
+__global__ __launch_bounds__(PROP_THREADS) void prop_topk_chunk_kernel(const float* __restrict__ maps, PropGeom g, int chunk_len,
+                                                                       float* __restrict__ part_score,
+                                                                       int* __restrict__ part_idx) {
+  const int chunk = blockIdx.x, chunks = gridDim.x, grp = blockIdx.y, b = grp / g.n_cls, c = grp % g.n_cls;
+  const int n = g.n_yaw * g.HW;
+  const float* x = maps + ((size_t)b * g.ctot + (size_t)c * g.n_yaw) * g.HW;
+  const int lo = min(n, chunk * chunk_len), m = min(n, lo + chunk_len) - lo;
+  const size_t o = ((size_t)grp * chunks + chunk) * g.topk;
+  prop_select<1>(x + lo, nullptr, m, lo, g.topk, part_score + o, part_idx + o);
+}
+
+// level 2: one workgroup per group merges the chunks' candidates
+__global__ __launch_bounds__(PROP_THREADS) void prop_topk_merge_kernel(const float* __restrict__ part_score,
+                                                                       const int* __restrict__ part_idx, int chunks, int K,
+                                                                       float* __restrict__ cand_score,
+                                                                       int* __restrict__ cand_anchor) {
+  const int grp = blockIdx.x;
+  const size_t o = (size_t)grp * chunks * K;
+  prop_select<2>(part_score + o, part_idx + o, chunks * K, 0, K, cand_score + (size_t)grp * K, cand_anchor + (size_t)grp * K);
 }
 
 // One workgroup decodes all N = B*n_cls*topk candidates (core/box_encode.py:13-21), reduces the coordinate range
@@ -275,7 +320,8 @@ static size_t prop_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t v3d_proposals_workspace(int B, int n_cls, int topk) {
   const size_t N = (size_t)B * n_cls * topk;
-  return prop_align(N * 4) * 2 /*cand score, anchor*/ + prop_align(N * 7 * 4) + prop_align(N * 8) * 3 /*batch, class, keep*/ +
+  return prop_align(N * 4) * 2 /*cand score, anchor*/ + prop_align(N * PROP_CHUNKS * 4) * 2 /*level-1 lists*/ +
+         prop_align(N * 7 * 4) + prop_align(N * 8) * 3 /*batch, class, keep*/ +
          prop_align(N * 5 * 4) + 256 /*n_keep*/ + prop_align(v3d_nms_rotated_workspace((int)N)) + 1024;
 }
 
@@ -299,6 +345,8 @@ extern "C" int v3d_proposals(const float* head_maps, const float* anchors, int B
   auto take = [&](size_t bytes) { char* q = p; p += prop_align(bytes); return (void*)q; };
   float* cand_score = (float*)take(N * 4);
   int* cand_anchor = (int*)take(N * 4);
+  float* part_score = (float*)take(N * PROP_CHUNKS * 4);
+  int* part_idx = (int*)take(N * PROP_CHUNKS * 4);
   float* boxes = (float*)take(N * 7 * 4);
   long long* bidx = (long long*)take(N * 8);
   long long* cidx = (long long*)take(N * 8);
@@ -308,7 +356,14 @@ extern "C" int v3d_proposals(const float* head_maps, const float* anchors, int B
   const size_t nms_bytes = v3d_nms_rotated_workspace((int)N);
   void* nms_ws = take(nms_bytes);
 
-  hipLaunchKernelGGL(prop_topk_kernel, dim3(B * n_cls), dim3(PROP_THREADS), 0, st, head_maps, g, cand_score, cand_anchor);
+  const int n_per_group = n_yaw * H * W;
+  int chunks = n_per_group / (4 * topk);  // every slice keeps >= 4K elements
+  chunks = chunks < 1 ? 1 : (chunks > PROP_CHUNKS ? PROP_CHUNKS : chunks);
+  const int chunk_len = ((n_per_group + chunks - 1) / chunks + 63) & ~63;
+  hipLaunchKernelGGL(prop_topk_chunk_kernel, dim3(chunks, B * n_cls), dim3(PROP_THREADS), 0, st, head_maps, g, chunk_len,
+                     part_score, part_idx);
+  hipLaunchKernelGGL(prop_topk_merge_kernel, dim3(B * n_cls), dim3(PROP_THREADS), 0, st, part_score, part_idx, chunks, topk,
+                     cand_score, cand_anchor);
   hipLaunchKernelGGL(prop_decode_kernel, dim3(1), dim3(PROP_THREADS), 0, st, head_maps, anchors, g, cand_anchor, boxes, bidx,
                      cidx, bev);
   const int rc = v3d_nms_rotated(bev, cand_score, (int)N, iou_threshold, (int64_t*)keep, n_keep, nms_ws, nms_bytes, stream);
