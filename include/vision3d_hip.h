@@ -142,6 +142,8 @@ int v3d_sparse_conv_bwd_weight(const float* X, const float* dY, const int32_t* n
 void v3d_debug_set_repeat(int n);
 /* Debug/benchmark aid: force the row-tile count of the packed sparse kernel (0 = automatic, 1, 2, 4). */
 void v3d_debug_set_rows_mt(int mt);
+/* Debug/benchmark aid: dense convolution kernel choice (0 = automatic, 1 = 64-pixel tile, 2 = 144-pixel tile). */
+void v3d_debug_set_dense_variant(int v);
 
 /* ---- T2: SparseConvTensor.dense() (detector/sparse_cnn.py:128-133): zero-fill + scatter.
  * feat (cap,C), coords (cap,4), *n rows -> dense (B,C,D,H,W) f32. */

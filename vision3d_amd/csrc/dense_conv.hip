@@ -373,6 +373,334 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Large-tile variant (Cin % 128 == 0): 144 pixels x 128 couts per workgroup, wave-specialised.
+//
+// Why: the 64-pixel kernel above is bound by LDS and L1-fill bandwidth, not by the matrix cores -- per k-step each
+// wave issues 12 ds_read_b128 for 24 MFMAs and the block re-streams the whole 590 KB weight image for only 64
+// pixels (550 blocks x 864 KB through the 64 B/clk TCPs, three scheduling rounds on 256 CUs).  Here
+//   * 35 200 BEV pixels = 245 workgroups = ONE round on 256 CUs, weights streamed 245x instead of 550x;
+//   * waves 0-3 are MATRIX waves, side by side along Cout: each owns ALL 144 pixels x 32 couts (9 x 2 fragments,
+//     72 accumulator registers); A fragments come from LDS (requested three 6-MFMA steps ahead), its private B
+//     fragments straight from the packed image in L2 (no LDS, no duplication between waves), each of the four
+//     k-substep register sets refilled for the next stage as soon as its last MFMA has issued;
+//   * waves 4-7 are LOADER waves: while the matrix waves multiply stage s they gather stage s+1 (all 128 input
+//     channels of one tap, 72 KB, zero halo) global -> registers -> the other LDS buffer.  With one workgroup per
+//     CU nothing else could overlap the gather latency and the 13-cycle ds_write_b128s with the MFMAs (measured
+//     with the cycle-counter stamps below: 15 us fixed + 22 us multiply + 13 us exposed gather when one set of
+//     4 waves did both);
+//   * one barrier per stage (9 per 3x3 convolution at Cin = 128).
+// ------------------------------------------------------------------------------------------------
+#define DL_BM 144
+#define DL_MT (DL_BM / 16)
+#define DL_KC 128
+#define DL_SS (DL_KC / 32)  // MFMA k-substeps per stage
+#define DL_THREADS 512
+#define DL_A_PLANE (DL_BM * DL_KC * 2)  // bytes of one plane of one stage: 36 KB
+#define DL_STAGE (2 * DL_A_PLANE)       // hi + lo
+#define DL_TS (DC_BN + 4)
+#define DL_SMEM (DL_BM * DL_TS * 4 > 2 * DL_STAGE ? DL_BM * DL_TS * 4 : 2 * DL_STAGE)
+
+#ifndef DL_DBG
+#define DL_DBG 0
+#endif
+#ifndef DL_TIMELINE
+#define DL_TIMELINE 0  // 1: cycle-counter stamps of one workgroup (tools/mb_dense.py prints them)
+#endif
+#if DL_TIMELINE
+__device__ unsigned long long dl_tl[2][64];
+extern "C" int v3d_debug_dense_timeline(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dl_tl), sizeof(dl_tl));
+}
+#define DL_STAMP(role, idx) do { if (blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == 4)) dl_tl[role][idx] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DL_STAMP(role, idx)
+#endif
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// (v0, v1) -> packed bf16 hi pair and lo pair (hi = RNE(v), lo = RNE(v - hi)) on the hardware converter
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
+  const bf16x2_t h = __builtin_convertvector(f32x2_t{v0, v1}, bf16x2_t);
+  hi = __builtin_bit_cast(unsigned, h);
+  const float r0 = v0 - __uint_as_float(hi << 16), r1 = v1 - __uint_as_float(hi & 0xFFFF0000u);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t));
+}
+
+template <int KS>
+__global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const bf16_t* __restrict__ x_hi,
+                                                                         const bf16_t* __restrict__ x_lo,
+                                                                         const bf16_t* __restrict__ w_img,
+                                                                         const float* __restrict__ bias, const DcParams p,
+                                                                         bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo,
+                                                                         float* __restrict__ y_nchw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_l[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 4;
+  const int nt = gridDim.x;
+  int mtile = blockIdx.x;
+  {  // XCD-aware order (see the 64-pixel kernel)
+    const int q = nt / 8, rmd = nt % 8, xcd = mtile % 8, idx = mtile / 8;
+    mtile = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;
+  }
+  const int m0 = mtile * DL_BM;
+  const int n0 = blockIdx.y * DC_BN;
+  const int chunks = p.Cin / DL_KC;  // 128-channel stages per tap
+  const int stages = KS * KS * chunks;
+  // LDS image of one plane: pixel rows of 256 B (16 parts of 16 B), the part slot XOR-ed with px & 15.  Every row
+  // aliases the same 64 banks, so the XOR alone has to separate the 16 lanes of a ds_read_b128 group (16 pixels,
+  // parts p and p^1: the pixel sets of the two parts never differ in bit 0 only) and the 8 lanes of a
+  // ds_write_b128 group (8 parts of one pixel).
+  auto a_slot = [](int px, int part) { return px * 256 + ((part ^ (px & 15)) << 4); };
+
+  f32x4 acc[DL_MT][2];
+#pragma unroll
+  for (int i = 0; i < DL_MT; i++) {
+    acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  if (loader) {
+    // ---- gather role: part a_part (16 B = 8 channels) of the 9 pixels a_px0 + 16*j
+    const int lt = tid - 256;
+    const int a_part = lt & 15, a_px0 = lt >> 4;
+    int a_pix[DL_MT], a_hw[DL_MT];  // flattened pixel index (-1: beyond M), packed (h << 16 | w)
+    {  // one division for the first pixel, the other eight follow by stepping 16 columns (W >= 16 is checked by the host)
+      const int m = m0 + a_px0;
+      const int b = m / (p.H * p.W), rem = m - b * p.H * p.W;
+      int h = rem / p.W, w = rem - h * p.W;
+#pragma unroll
+      for (int j = 0; j < DL_MT; j++) {
+        const int mj = m + 16 * j;
+        a_pix[j] = mj < p.M ? mj : -1;
+        a_hw[j] = mj < p.M ? ((h << 16) | w) : 0;
+        w += 16;
+        if (w >= p.W) {
+          w -= p.W;
+          if (++h == p.H) h = 0;
+        }
+      }
+    }
+    int tap = 0, chunk = 0;
+    auto gather = [&](int buf) {  // this thread's 18 pieces of stage (tap, chunk): all loads in flight, then the stores
+      const int dy = KS == 3 ? tap / 3 - 1 : 0, dx = KS == 3 ? tap % 3 - 1 : 0;
+      u32x4 ra[DL_MT][2];
+      bool ok[DL_MT];
+#pragma unroll
+      for (int j = 0; j < DL_MT; j++) {  // branch-free: out-of-image taps read the (valid) centre pixel, zeroed after
+        const int hh = (a_hw[j] >> 16) + dy, ww = (a_hw[j] & 0xFFFF) + dx;
+        ok[j] = a_pix[j] >= 0 && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
+        const int src = ok[j] ? a_pix[j] + dy * p.W + dx : (a_pix[j] >= 0 ? a_pix[j] : 0);
+        const size_t off = (size_t)src * p.Cin + chunk * DL_KC + a_part * 8;
+        ra[j][0] = *reinterpret_cast<const u32x4*>(x_hi + off);
+        ra[j][1] = *reinterpret_cast<const u32x4*>(x_lo + off);
+      }
+      unsigned char* A = smem_l + buf * DL_STAGE;
+      const u32x4 z = u32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < DL_MT; j++) {
+        const int px = a_px0 + 16 * j;
+        *reinterpret_cast<u32x4*>(A + a_slot(px, a_part)) = ok[j] ? ra[j][0] : z;
+        *reinterpret_cast<u32x4*>(A + DL_A_PLANE + a_slot(px, a_part)) = ok[j] ? ra[j][1] : z;
+      }
+      if (++chunk == chunks) {
+        chunk = 0;
+        ++tap;
+      }
+    };
+    DL_STAMP(1, 0);
+    gather(0);
+    DL_STAMP(1, 1);
+    __syncthreads();
+    DL_STAMP(1, 2);
+    for (int s = 0; s < stages; s++) {
+      if (s + 1 < stages) gather((s + 1) & 1);
+      if (s < 8) DL_STAMP(1, 3 + 2 * s);
+      __syncthreads();
+      if (s < 8) DL_STAMP(1, 4 + 2 * s);
+    }
+    DL_STAMP(1, 30);
+  } else {
+    // ---- matrix role
+    const size_t plane_elems = (size_t)(p.CoutPad / 16) * 4 * 16 * 8;
+    u32x4 cb[DL_SS][4];  // B fragments per k-substep: [n-tile*2 + plane]
+    int tap = 0, chunk = 0;  // stage whose B fragments are requested next
+    auto load_b = [&](int ss) {
+      const size_t step = (size_t)tap * (p.Cin / DC_KC) + (size_t)chunk * DL_SS + ss;  // 32-channel step of the image
+      const bf16_t* wb = w_img + step * 2 * plane_elems + ((size_t)(n0 / 16 + wave * 2) * 64 + lane) * 8;
+#pragma unroll
+      for (int nt2 = 0; nt2 < 2; nt2++) {
+        cb[ss][nt2 * 2 + 0] = *reinterpret_cast<const u32x4*>(wb + (size_t)nt2 * 512);
+        cb[ss][nt2 * 2 + 1] = *reinterpret_cast<const u32x4*>(wb + plane_elems + (size_t)nt2 * 512);
+      }
+    };
+    auto next_stage = [&]() {
+      if (++chunk == chunks) {
+        chunk = 0;
+        ++tap;
+      }
+    };
+    // 36 (k-substep, pixel-tile) pairs per stage, two per step.  A step issues its 12 MFMAs term-major over FOUR
+    // accumulators, so an accumulator is re-used every 4th MFMA (64 clocks): with two accumulators alternating the
+    // dependent-issue latency (~40 clocks) stalled every MFMA (measured 25 instead of 16 clocks per MFMA).  The A
+    // fragments of step u+2 are requested before step u's MFMAs issue (ring of 3 slots).
+    auto multiply = [&](int buf, bool more, bool stamp) {
+      const unsigned char* A = smem_l + buf * DL_STAGE;
+      constexpr int NSTEP = DL_SS * DL_MT / 2;
+      bf16x8 fh[3][2], fl[3][2];
+      auto frag = [&](int t, bf16x8& h, bf16x8& l) {
+        const int ss = t / DL_MT, i = t % DL_MT;
+        const int off = a_slot(i * 16 + (lane & 15), ss * 4 + (lane >> 4));
+        h = *reinterpret_cast<const bf16x8*>(A + off);
+        l = *reinterpret_cast<const bf16x8*>(A + DL_A_PLANE + off);
+      };
+      frag(0, fh[0][0], fl[0][0]);
+      frag(1, fh[0][1], fl[0][1]);
+      frag(2, fh[1][0], fl[1][0]);
+      frag(3, fh[1][1], fl[1][1]);
+      if (DL_DBG & 4) {
+        frag(4, fh[2][0], fl[2][0]);
+        frag(5, fh[2][1], fl[2][1]);
+      }
+#pragma unroll
+      for (int u = 0; u < NSTEP; u++) {
+        if (u + 2 < NSTEP && !(DL_DBG & 4)) {
+          frag(2 * u + 4, fh[(u + 2) % 3][0], fl[(u + 2) % 3][0]);
+          frag(2 * u + 5, fh[(u + 2) % 3][1], fl[(u + 2) % 3][1]);
+        }
+        const int t0 = 2 * u, t1 = 2 * u + 1;
+        const int s0 = t0 / DL_MT, i0 = t0 % DL_MT, s1 = t1 / DL_MT, i1 = t1 % DL_MT;
+        const bf16x8 b0h0 = __builtin_bit_cast(bf16x8, cb[s0][0]), b0l0 = __builtin_bit_cast(bf16x8, cb[s0][1]);
+        const bf16x8 b0h1 = __builtin_bit_cast(bf16x8, cb[s0][2]), b0l1 = __builtin_bit_cast(bf16x8, cb[s0][3]);
+        const bf16x8 b1h0 = __builtin_bit_cast(bf16x8, cb[s1][0]), b1l0 = __builtin_bit_cast(bf16x8, cb[s1][1]);
+        const bf16x8 b1h1 = __builtin_bit_cast(bf16x8, cb[s1][2]), b1l1 = __builtin_bit_cast(bf16x8, cb[s1][3]);
+        const bf16x8 a0h = fh[u % 3][0], a0l = fl[u % 3][0], a1h = fh[u % 3][1], a1l = fl[u % 3][1];
+        acc[i0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, b0h0, acc[i0][0], 0, 0, 0);
+        acc[i0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, b0h1, acc[i0][1], 0, 0, 0);
+        acc[i1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, b1h0, acc[i1][0], 0, 0, 0);
+        acc[i1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, b1h1, acc[i1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[i0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0l0, acc[i0][0], 0, 0, 0);
+        acc[i0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0l1, acc[i0][1], 0, 0, 0);
+        acc[i1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1l0, acc[i1][0], 0, 0, 0);
+        acc[i1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1l1, acc[i1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[i0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0h0, acc[i0][0], 0, 0, 0);
+        acc[i0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0h1, acc[i0][1], 0, 0, 0);
+        acc[i1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1h0, acc[i1][0], 0, 0, 0);
+        acc[i1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1h1, acc[i1][1], 0, 0, 0);
+        // a substep's B registers are free once its last tile has issued: refill them for the next stage
+        // (unconditionally -- the last stage re-reads its own fragments: a branch here makes the compiler's
+        // s_waitcnt bookkeeping merge two histories and wait for vmcnt(0) in the middle of the stage, 1350 clocks)
+        if (i0 == DL_MT - 1 && !(DL_DBG & 8)) load_b(s0);
+        if (i1 == DL_MT - 1 && !(DL_DBG & 8)) load_b(s1);
+        __builtin_amdgcn_sched_barrier(0);
+#if DL_TIMELINE
+        if (stamp && (u == 0 || u == 1 || u == 8 || u == 16 || u == 17)) DL_STAMP(0, 40 + u);
+#endif
+      }
+    };
+    DL_STAMP(0, 0);
+#pragma unroll
+    for (int ss = 0; ss < DL_SS; ss++) load_b(ss);
+    if (stages > 1) next_stage();
+    DL_STAMP(0, 1);
+    __syncthreads();
+    DL_STAMP(0, 2);
+    for (int s = 0; s < stages; s++) {
+      const bool more = s + 1 < stages;
+      multiply(s & 1, more, s == 3);
+      if (s + 2 < stages) next_stage();  // (tap, chunk) = stage s+2, clamped to the last one
+      if (s < 8) DL_STAMP(0, 3 + 2 * s);
+      __syncthreads();
+      if (s < 8) DL_STAMP(0, 4 + 2 * s);
+    }
+    DL_STAMP(0, 30);
+  }
+
+  DL_STAMP(loader ? 1 : 0, 31);
+  // ---- epilogue (all 8 waves): accumulators -> LDS tile [144 px][128 + 4] fp32 -> bias + ReLU -> outputs
+  float* tile = reinterpret_cast<float*>(smem_l);
+  // this thread's output role: 8 consecutive couts (y_hi requires Cout % 8 == 0); the two bias vectors are requested
+  // before the accumulator exchange so their latency hides behind it
+  f32x4 eb0 = f32x4{0.f, 0.f, 0.f, 0.f}, eb1 = eb0;
+  {
+    const int co = n0 + (tid & 15) * 8;
+    if (bias && y_hi && co < p.cout_store) {
+      eb0 = *reinterpret_cast<const f32x4*>(bias + co);
+      eb1 = *reinterpret_cast<const f32x4*>(bias + co + 4);
+    }
+  }
+  if (!loader) {
+#pragma unroll
+    for (int i = 0; i < DL_MT; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = i * 16 + (lane >> 4) * 4 + r;
+          const int col = wave * 32 + j * 16 + (lane & 15);
+          tile[row * DL_TS + col] = acc[i][j][r];
+        }
+  }
+  __syncthreads();
+  DL_STAMP(loader ? 1 : 0, 32);
+  if (y_hi) {  // thread = 8 consecutive couts (fixed) of pixel rows r, r+32, ...: two 16-byte LDS reads, two 16-byte stores
+    const int c8 = tid & 15, co = n0 + c8 * 8;
+    if (co < p.cout_store) {
+#pragma unroll
+      for (int k = 0; k < (DL_BM + 31) / 32; k++) {
+        const int row = (tid >> 4) + 32 * k;
+        const int m = m0 + row;
+        if (row < DL_BM && m < p.M) {
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + row * DL_TS + c8 * 8);
+          const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + row * DL_TS + c8 * 8 + 4);
+          float v[8] = {t0[0] + eb0[0], t0[1] + eb0[1], t0[2] + eb0[2], t0[3] + eb0[3],
+                        t1[0] + eb1[0], t1[1] + eb1[1], t1[2] + eb1[2], t1[3] + eb1[3]};
+          u32x4 vh, vl;
+#pragma unroll
+          for (int e2 = 0; e2 < 4; e2++) {
+            float v0 = v[2 * e2], v1 = v[2 * e2 + 1];
+            if (p.relu) {
+              v0 = fmaxf(v0, 0.f);
+              v1 = fmaxf(v1, 0.f);
+            }
+            unsigned h, l;
+            split_pair(v0, v1, h, l);
+            vh[e2] = h;
+            vl[e2] = l;
+          }
+          *reinterpret_cast<u32x4*>(y_hi + (size_t)m * p.cout_store + co) = vh;
+          *reinterpret_cast<u32x4*>(y_lo + (size_t)m * p.cout_store + co) = vl;
+        }
+      }
+    }
+  }
+  if (y_nchw) {
+    const int HW = p.H * p.W;
+    for (int q = tid; q < (DL_BM / 4) * DC_BN; q += DL_THREADS) {
+      const int col = q / (DL_BM / 4), r4 = q % (DL_BM / 4);
+      const int co = n0 + col;
+      if (co >= p.cout_store) continue;
+      const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int m = m0 + r4 * 4 + e;
+        if (m >= p.M) continue;
+        float v = tile[(r4 * 4 + e) * DL_TS + col] + bv;
+        if (p.relu) v = fmaxf(v, 0.f);
+        const int b = m / HW, pix = m - b * HW;
+        y_nchw[((size_t)b * p.cout_store + co) * HW + pix] = v;
+      }
+    }
+  }
+  DL_STAMP(loader ? 1 : 0, 33);
+}
+
+int g_v3d_dense_variant = 0;  // 0 = automatic, 1 = 64-pixel kernel, 2 = 144-pixel kernel (microbenchmarks / tests)
+extern "C" void v3d_debug_set_dense_variant(int v) { g_v3d_dense_variant = v; }
+
 extern "C" int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
                                       int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
                                       float* y_nchw, v3d_stream_t stream) {
@@ -385,8 +713,18 @@ extern "C" int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const 
   p.CoutPad = (Cout + DC_BN - 1) / DC_BN * DC_BN;
   p.M = B * H * W;
   p.cout_store = Cout;
-  dim3 grid(v3d_ceil_div(p.M, DC_BM), p.CoutPad / DC_BN);
   hipStream_t st = (hipStream_t)stream;
+  const bool large_ok = Cin % DL_KC == 0 && H < 32768 && W < 65536 && W >= 16;  // else: the 64-pixel kernel
+  if (large_ok && (g_v3d_dense_variant == 2 || (g_v3d_dense_variant == 0 && Cout > 32))) {
+    dim3 lgrid(v3d_ceil_div(p.M, DL_BM), p.CoutPad / DC_BN);
+    auto kern = ksize == 3 ? conv2d_bf16x3_large_kernel<3> : conv2d_bf16x3_large_kernel<1>;
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, DL_SMEM));
+    hipLaunchKernelGGL(kern, lgrid, dim3(DL_THREADS), DL_SMEM, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+                       (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo, y_nchw);
+    V3D_CHECK_LAUNCH();
+    return V3D_OK;
+  }
+  dim3 grid(v3d_ceil_div(p.M, DC_BM), p.CoutPad / DC_BN);
   if (ksize == 3)
     hipLaunchKernelGGL(conv2d_bf16x3_kernel<3>, grid, dim3(DC_THREADS), 0, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
                        (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo, y_nchw);
