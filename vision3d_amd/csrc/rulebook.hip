@@ -100,11 +100,14 @@ __device__ __forceinline__ bool rb_is_first(const int* cand_slot, const unsigned
   return s >= 0 && first_ticket[s] == (unsigned)t;
 }
 
-__global__ __launch_bounds__(V3D_BLOCK) void rb_count_kernel(const int* __restrict__ cand_slot,
-                                                             const unsigned* __restrict__ first_ticket,
-                                                             const int* __restrict__ n_ptr, int cap_in, int K,
-                                                             int* __restrict__ chunk_counts) {
-  __shared__ int lds[4];
+// count + scan in ONE launch (the highest-index block scans the published counts, v3d_common.h): chunk_counts
+// (-1 at launch) become exclusive offsets, the total is clipped to cap_out
+__global__ __launch_bounds__(V3D_BLOCK) void rb_count_scan_kernel(const int* __restrict__ cand_slot,
+                                                                  const unsigned* __restrict__ first_ticket,
+                                                                  const int* __restrict__ n_ptr, int cap_in, int K,
+                                                                  int* __restrict__ chunk_counts, int n_chunks, int cap_out,
+                                                                  int* __restrict__ n_out, int* __restrict__ overflow) {
+  __shared__ int lds[8];
   const long long nt = (long long)min(*n_ptr, cap_in) * K;
   const long long base = (long long)blockIdx.x * V3D_SCAN_CHUNK;
   int cnt = 0;
@@ -115,36 +118,10 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_count_kernel(const int* __restri
       cnt += tot;
     }
   }
-  if (threadIdx.x == 0) chunk_counts[blockIdx.x] = cnt;
-}
-
-// single block: exclusive scan of chunk counts; total clipped to cap_out
-__global__ __launch_bounds__(1024) void rb_scan_kernel(int* __restrict__ chunk_counts, int n_chunks, int cap_out,
-                                                       int* __restrict__ n_out, int* __restrict__ overflow) {
-  __shared__ int part[1024];
-  __shared__ int carry_s;
-  const int tid = threadIdx.x;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int c0 = 0; c0 < n_chunks; c0 += 1024) {
-    const int idx = c0 + tid;
-    const int v = idx < n_chunks ? chunk_counts[idx] : 0;
-    part[tid] = v;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-      const int t = tid >= d ? part[tid - d] : 0;
-      __syncthreads();
-      part[tid] += t;
-      __syncthreads();
-    }
-    const int carry = carry_s;
-    if (idx < n_chunks) chunk_counts[idx] = carry + part[tid] - v;
-    __syncthreads();
-    if (tid == 1023) carry_s = carry + part[1023];
-    __syncthreads();
-  }
-  if (tid == 0) {
-    const int total = carry_s;
+  if (threadIdx.x == 0) v3d_publish_count(chunk_counts + blockIdx.x, cnt);
+  if (blockIdx.x != gridDim.x - 1) return;
+  const int total = v3d_block_exclusive_scan_global(chunk_counts, n_chunks, lds);
+  if (threadIdx.x == 0) {
     if (total > cap_out) atomicExch(overflow, 1);
     *n_out = min(total, cap_out);
   }
@@ -177,19 +154,45 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_emit_kernel(const int4* __restri
   }
 }
 
-// nbr[k][out] = i for every live ticket (nbr pre-filled with -1)
+// nbr[k][out] = i for every live ticket (nbr pre-filled with -1).  The same launch can carry the submanifold table
+// of the OUTPUT sites (the next layer's rulebook): both only need what rb_emit left behind (coords_out, vals), so
+// blocks [0, fill_blocks) fill and the remaining (row block, offset) pairs look up neighbours -- one launch saved
+// per stage.
 __global__ __launch_bounds__(V3D_BLOCK) void rb_fill_nbr_kernel(const int* __restrict__ n_ptr, int cap_in, int K,
                                                                 const int* __restrict__ cand_slot,
                                                                 const int* __restrict__ vals, int cap_out,
-                                                                int* __restrict__ nbr) {
-  const long long nt = (long long)min(*n_ptr, cap_in) * K;
-  for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < nt; t += (long long)gridDim.x * V3D_BLOCK) {
-    const int s = cand_slot[t];
-    if (s < 0) continue;
-    const int o = vals[s];
-    if (o < 0) continue;  // clipped by cap_out
-    nbr[(size_t)(t % K) * cap_out + o] = (int)(t / K);
+                                                                int* __restrict__ nbr, int fill_blocks,
+                                                                const int4* __restrict__ coords_out,
+                                                                const int* __restrict__ n_out_ptr, const RbGeom sg,
+                                                                const V3dHash sh, int* __restrict__ subm_nbr) {
+  if ((int)blockIdx.x < fill_blocks) {
+    const long long nt = (long long)min(*n_ptr, cap_in) * K;
+    for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < nt; t += (long long)fill_blocks * V3D_BLOCK) {
+      const int s = cand_slot[t];
+      if (s < 0) continue;
+      const int o = vals[s];
+      if (o < 0) continue;  // clipped by cap_out
+      nbr[(size_t)(t % K) * cap_out + o] = (int)(t / K);
+    }
+    return;
   }
+  // ---- submanifold table of the output sites (same arithmetic as rb_subm_nbr_kernel)
+  const int idx = blockIdx.x - fill_blocks;
+  const int nbx = (cap_out + V3D_BLOCK - 1) / V3D_BLOCK;
+  const int k = idx / nbx, o = (idx % nbx) * V3D_BLOCK + threadIdx.x;
+  const int n = min(*n_out_ptr, cap_out);
+  if (o >= n) return;
+  const int kx = k % sg.ks[2], ky = (k / sg.ks[2]) % sg.ks[1], kz = k / (sg.ks[2] * sg.ks[1]);
+  const int4 c = coords_out[o];
+  const int z = c.y + kz - sg.ks[0] / 2, y = c.z + ky - sg.ks[1] / 2, x = c.w + kx - sg.ks[2] / 2;
+  int v = -1;
+  if (2 * k + 1 == sg.K) {
+    v = o;
+  } else if (z >= 0 && z < sg.in_shape[0] && y >= 0 && y < sg.in_shape[1] && x >= 0 && x < sg.in_shape[2]) {
+    const int s = v3d_hash_find(sh, rb_key(c.x, z, y, x, sg.in_shape));
+    if (s >= 0) v = vals[s];
+  }
+  subm_nbr[(size_t)k * cap_out + o] = v;
 }
 
 // ---------------------------------------------------------------------------------- host side
@@ -246,7 +249,7 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
                           const int32_t* ksize, const int32_t* stride, const int32_t* padding, int32_t* coords_out,
                           int32_t* n_out, int cap_out, int32_t* nbr, int32_t* overflow, V3dRbHash out,
                           unsigned* first_ticket, int* cand_slot, int* chunk_counts, int32_t* out_shape, int clear,
-                          hipStream_t st) {
+                          const int32_t* next_subm_ksize, int32_t* next_subm_nbr, hipStream_t st) {
   RbGeom g;
   int rc = fill_geom(g, shape, ksize, stride, padding);
   if (rc) return rc;
@@ -261,18 +264,27 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
     V3D_CHECK_HIP(v3d_fill_async(out.keys, 0xFF, (size_t)out.hcap * 16, st));
     V3D_CHECK_HIP(v3d_fill_async(nbr, 0xFF, (size_t)g.K * cap_out * 4, st));
     V3D_CHECK_HIP(v3d_fill_async(overflow, 0, 4, st));
+    V3D_CHECK_HIP(v3d_fill_async(chunk_counts, 0xFF, (size_t)chunks * 4, st));  // -1 = "count not published yet"
   }
   V3dHash h = v3d_make_hash(out.keys, out.hcap);
   const int tblocks = min(v3d_ceil_div(tickets, V3D_BLOCK), 4096);
   hipLaunchKernelGGL(rb_candidates_kernel, dim3(tblocks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in,
                      g, h, first_ticket, cand_slot, overflow);
-  hipLaunchKernelGGL(rb_count_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, cand_slot, first_ticket, n_in, cap_in, g.K,
-                     chunk_counts);
-  hipLaunchKernelGGL(rb_scan_kernel, dim3(1), dim3(1024), 0, st, chunk_counts, chunks, cap_out, n_out, overflow);
+  hipLaunchKernelGGL(rb_count_scan_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, cand_slot, first_ticket, n_in, cap_in, g.K,
+                     chunk_counts, chunks, cap_out, n_out, overflow);
   hipLaunchKernelGGL(rb_emit_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in, g,
                      cand_slot, first_ticket, chunk_counts, cap_out, (int4*)coords_out, out.vals);
-  hipLaunchKernelGGL(rb_fill_nbr_kernel, dim3(tblocks), dim3(V3D_BLOCK), 0, st, n_in, cap_in, g.K, cand_slot, out.vals,
-                     cap_out, nbr);
+  RbGeom sg = g;
+  int subm_blocks = 0;
+  if (next_subm_ksize && next_subm_nbr) {
+    rc = fill_geom(sg, g.out_shape, next_subm_ksize, nullptr, nullptr);
+    if (rc) return rc;
+    for (int j = 0; j < 3; j++)
+      if (!(sg.ks[j] & 1)) return V3D_EINVAL;
+    subm_blocks = v3d_ceil_div(cap_out, V3D_BLOCK) * sg.K;
+  }
+  hipLaunchKernelGGL(rb_fill_nbr_kernel, dim3(tblocks + subm_blocks), dim3(V3D_BLOCK), 0, st, n_in, cap_in, g.K, cand_slot,
+                     out.vals, cap_out, nbr, tblocks, (const int4*)coords_out, n_out, sg, h, next_subm_nbr);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -328,7 +340,7 @@ extern "C" int v3d_rulebook_sparse(const int32_t* coords_in, const int32_t* n_in
   if (!ar.ok()) return V3D_EWORKSPACE;
   return v3d_i_sparse_rulebook(coords_in, n_in, cap_in, spatial_shape_host, ksize_host, stride_host, padding_host,
                                coords_out, n_out, cap_out, nbr, overflow, h, first_ticket, cand_slot, chunk_counts,
-                               nullptr, 1, st);
+                               nullptr, 1, nullptr, nullptr, st);
 }
 
 // ---------------------------------------------------------------------------------- transposed table (backward)

@@ -25,6 +25,7 @@ struct PlanLayer {
   float *weight, *scale, *shift, *out;
   void* wimg;  // split + packed weights for the bf16x3 kernel
   int has_affine;
+  int* chunk_counts;  // strided layers: published per-chunk counts -> offsets (inside the per-frame 0xFF region)
 };
 
 struct PlanStage {
@@ -52,7 +53,6 @@ struct v3d_backbone {
   float* mean = nullptr;
   // strided-rulebook scratch
   int* cand_slot = nullptr;
-  int* chunk_counts = nullptr;
   int32_t* overflow = nullptr;  // one flag per layer (<= 0 fine, 1 = capacity hit)
   char* ff_begin = nullptr;     // arena region reset to 0xFF by one memset per forward
   size_t ff_bytes = 0;
@@ -156,6 +156,8 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
     for (size_t i = 0; i < p->nbr.size(); i++)
       if (rbSparse[i]) p->nbr[i] = ar.take<int32_t>((size_t)rbK[i] * p->nbr_cap[i]);  // strided tables start as -1
     p->overflow = ar.take<int32_t>(p->layers.size() + 1);
+    for (auto& L : p->layers)  // strided layers: per-layer count slots, -1 = "not published" at the start of a frame
+      if (!L.d.subm) L.chunk_counts = ar.take<int>((size_t)((long long)p->stages[L.stage_in].cap * L.K / V3D_SCAN_CHUNK + 2));
     p->ff_bytes = (size_t)((ar.base + ar.off) - p->ff_begin);
     // ---- the rest needs no per-frame initialisation
     for (size_t i = 0; i < p->nbr.size(); i++)
@@ -167,7 +169,6 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       st.n_dev = ar.take<int32_t>(1);
     }
     p->cand_slot = ar.take<int>((size_t)max_tickets);
-    p->chunk_counts = ar.take<int>((size_t)(max_tickets / V3D_SCAN_CHUNK + 2));
     for (auto& L : p->layers) {
       L.weight = ar.take<float>((size_t)L.K * L.d.cin * L.d.cout);
       L.wimg = ar.take<char>(v3d_sparse_conv_weight_image_bytes(L.K, L.d.cin, L.d.cout));
@@ -233,17 +234,20 @@ extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n
   const v3d_backbone_config& c = p->cfg;
   PlanStage& s0 = p->stages[0];
   V3D_CHECK_HIP(v3d_fill_async(p->ff_begin, 0xFF, p->ff_bytes, st));  // all hash tables, strided nbr tables, flags
+  // the voxelizer also fills stage 0's coordinate hash (what rb_hash_build would do in a launch of its own)
+  const bool vox_hash = !p->layers.empty() && p->layers[0].d.subm && p->layers[0].builds_rulebook;
   int rc = v3d_i_voxelize(points, n_points, c.point_channels, frame_offsets_host, B, c.voxel_size, c.bounds, c.max_pts,
                           c.max_voxels, nullptr, s0.coords, p->occupancy, p->mean, s0.n_dev, p->vox_ws, p->vox_ws_bytes, 0,
-                          st);
+                          vox_hash ? &s0.hash : nullptr, s0.shape, st);
   if (rc) return rc;
-  bool hash0_done = false;
+  bool hash0_done = vox_hash;
+  std::vector<char> rb_done(p->layers.size(), 0);
   const float* feat = p->mean;
   for (size_t l = 0; l < p->layers.size(); l++) {
     PlanLayer& L = p->layers[l];
     PlanStage& si = p->stages[L.stage_in];
     PlanStage& so = p->stages[L.stage_out];
-    if (L.builds_rulebook) {
+    if (L.builds_rulebook && !rb_done[l]) {
       if (L.d.subm) {
         if (!si.hash_ready_by_sparse && !(L.stage_in == 0 && hash0_done)) {
           rc = v3d_i_hash_build(si.coords, si.n_dev, si.cap, si.shape, si.hash, 0, st);
@@ -252,9 +256,15 @@ extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n
         }
         rc = v3d_i_subm_nbr(si.coords, si.n_dev, si.cap, si.shape, L.d.ksize, si.hash, p->nbr[L.rulebook], st);
       } else {
+        // the next layer's submanifold table (over THIS layer's output sites) rides in the same last launch
+        const bool fuse = l + 1 < p->layers.size() && p->layers[l + 1].d.subm && p->layers[l + 1].builds_rulebook &&
+                          p->layers[l + 1].stage_in == L.stage_out;
         rc = v3d_i_sparse_rulebook(si.coords, si.n_dev, si.cap, si.shape, L.d.ksize, L.d.stride, L.d.padding, so.coords,
                                    so.n_dev, so.cap, p->nbr[L.rulebook], p->overflow + l, so.hash, so.first_ticket,
-                                   p->cand_slot, p->chunk_counts, nullptr, 0, st);
+                                   p->cand_slot, L.chunk_counts, nullptr, 0,
+                                   fuse ? p->layers[l + 1].d.ksize : nullptr,
+                                   fuse ? p->nbr[p->layers[l + 1].rulebook] : nullptr, st);
+        if (fuse) rb_done[l + 1] = 1;
       }
       if (rc) return rc;
     }

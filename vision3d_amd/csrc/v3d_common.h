@@ -143,5 +143,55 @@ __device__ __forceinline__ int v3d_block_rank(bool flag, int& total, int* lds) {
   return off + r;
 }
 
+// count -> scan in ONE launch without fences: counts[] is pre-set to -1 (part of the frame's 0xFF fill); every block
+// PUBLISHES its count with an agent-scope atomic store, and the block with the highest index -- dispatched after all
+// the others, so everything it waits for is already running or done -- reads them with agent-scope loads, spinning
+// on entries that are still -1, and scans.  (A fence + arrival-counter variant cost 15 us per launch in L2
+// write-backs; this one costs the same as the plain count kernel and saves the dependent scan launch.)
+__device__ __forceinline__ void v3d_publish_count(int* slot, int value) {
+  __hip_atomic_store(slot, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int v3d_load_coherent(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int v3d_wait_count(const int* slot) {
+  int v = v3d_load_coherent(slot);
+  while (v < 0) {
+    __builtin_amdgcn_s_sleep(1);
+    v = v3d_load_coherent(slot);
+  }
+  return v;
+}
+
+// In-place exclusive scan of the published counts[0..n) by ONE 256-thread block (the highest-index block of a count
+// kernel); returns the grand total to every thread.  `lds` >= 8 ints.
+__device__ __forceinline__ int v3d_block_exclusive_scan_global(int* counts, int n, int* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int carry = 0;
+  for (int c0 = 0; c0 < n; c0 += V3D_BLOCK) {
+    const int idx = c0 + tid;
+    const int v = idx < n ? v3d_wait_count(counts + idx) : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) lds[w] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < V3D_BLOCK / V3D_WAVE; i++) {
+      const int c = lds[i];
+      if (i < w) woff += c;
+      tot += c;
+    }
+    if (idx < n) v3d_publish_count(counts + idx, carry + woff + incl - v);
+    carry += tot;
+    __syncthreads();
+  }
+  return carry;
+}
+
 // Items handled by one block of the chunked flag scans (256 threads x 8 rounds).
 #define V3D_SCAN_CHUNK 2048

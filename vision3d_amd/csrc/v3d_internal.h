@@ -12,7 +12,9 @@ struct V3dRbHash {
 int v3d_i_voxelize(const float* points, int n_points, int C, const int32_t* frame_offsets_host, int B,
                    const float* voxel_size_host, const float* bounds_host, int max_pts, int max_voxels, float* voxels,
                    int32_t* coords, int32_t* occupancy, float* mean, int32_t* n_voxels, void* workspace,
-                   size_t workspace_bytes, int clear_tables, hipStream_t st);
+                   size_t workspace_bytes, int clear_tables, const V3dRbHash* site_hash /*nullable: also insert every
+                   emitted voxel into this (pre-cleared) coordinate hash*/,
+                   const int32_t* site_shape /*(D, H, W) of the grid that hash is keyed on*/, hipStream_t st);
 int v3d_i_hash_build(const int32_t* coords, const int32_t* n, int cap, const int32_t* shape, V3dRbHash h, int clear,
                      hipStream_t st);
 int v3d_i_subm_nbr(const int32_t* coords, const int32_t* n, int cap, const int32_t* shape, const int32_t* ksize,
@@ -20,5 +22,7 @@ int v3d_i_subm_nbr(const int32_t* coords, const int32_t* n, int cap, const int32
 int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap_in, const int32_t* shape,
                           const int32_t* ksize, const int32_t* stride, const int32_t* padding, int32_t* coords_out,
                           int32_t* n_out, int cap_out, int32_t* nbr, int32_t* overflow, V3dRbHash out,
-                          unsigned* first_ticket, int* cand_slot, int* chunk_counts, int32_t* out_shape, int clear,
-                          hipStream_t st);
+                          unsigned* first_ticket, int* cand_slot, int* chunk_counts /*reads -1 at launch unless clear*/,
+                          int32_t* out_shape, int clear,
+                          const int32_t* next_subm_ksize /*nullable: also build the submanifold table of the OUTPUT sites*/,
+                          int32_t* next_subm_nbr, hipStream_t st);

@@ -74,72 +74,55 @@ __device__ __forceinline__ bool vox_is_first(const int* pt_slot, const unsigned*
   return s >= 0 && first[s] == (unsigned)i;
 }
 
-__global__ __launch_bounds__(V3D_BLOCK) void vox_count_kernel(const int* __restrict__ pt_slot,
-                                                              const unsigned* __restrict__ first, int n,
-                                                              int* __restrict__ chunk_counts) {
-  __shared__ int lds[4];
+// count + scan in ONE launch: every block counts the first touchers of its chunk and publishes the count; the
+// highest-index block turns the counts into exclusive offsets (v3d_common.h) and derives the per-frame bases.
+// chunk_counts must read -1 at launch.
+// frame_base[b] = number of first-touch points before frame b's first point; out_base[b] = first output
+// row of frame b after clipping every earlier frame to max_voxels; n_voxels = total rows.
+__global__ __launch_bounds__(V3D_BLOCK) void vox_count_scan_kernel(const int* __restrict__ pt_slot,
+                                                                   const unsigned* __restrict__ first, const VoxParams p,
+                                                                   int* __restrict__ chunk_counts, int n_chunks,
+                                                                   int* __restrict__ frame_base, int* __restrict__ out_base,
+                                                                   int* __restrict__ n_voxels) {
+  __shared__ int lds[8];
+  __shared__ int fb_s[VOX_MAX_FRAMES + 1];
   const int base = blockIdx.x * VOX_CHUNK;
   int cnt = 0;
   for (int r = 0; r < VOX_CHUNK / V3D_BLOCK; r++) {
     int tot;
-    v3d_block_rank(vox_is_first(pt_slot, first, base + r * V3D_BLOCK + threadIdx.x, n), tot, lds);
+    v3d_block_rank(vox_is_first(pt_slot, first, base + r * V3D_BLOCK + threadIdx.x, p.n_points), tot, lds);
     cnt += tot;
   }
-  if (threadIdx.x == 0) chunk_counts[blockIdx.x] = cnt;
-}
+  if (threadIdx.x == 0) v3d_publish_count(chunk_counts + blockIdx.x, cnt);
+  if (blockIdx.x != gridDim.x - 1) return;
 
-// single block: exclusive scan of chunk counts, then per-frame bases.
-// frame_base[b] = number of first-touch points before frame b's first point; out_base[b] = first output
-// row of frame b after clipping every earlier frame to max_voxels; n_voxels = total rows.
-__global__ __launch_bounds__(1024) void vox_scan_kernel(int* __restrict__ chunk_counts, int n_chunks,
-                                                        const int* __restrict__ pt_slot,
-                                                        const unsigned* __restrict__ first, const VoxParams p,
-                                                        int* __restrict__ frame_base, int* __restrict__ out_base,
-                                                        int* __restrict__ n_voxels) {
-  __shared__ int part[1024];
-  __shared__ int carry_s;
-  const int tid = threadIdx.x;
-  if (tid == 0) carry_s = 0;
+  const int total = v3d_block_exclusive_scan_global(chunk_counts, n_chunks, lds);
   __syncthreads();
-  for (int c0 = 0; c0 < n_chunks; c0 += 1024) {
-    const int idx = c0 + tid;
-    const int v = idx < n_chunks ? chunk_counts[idx] : 0;
-    part[tid] = v;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
-      const int t = tid >= d ? part[tid - d] : 0;
-      __syncthreads();
-      part[tid] += t;
-      __syncthreads();
-    }
-    const int carry = carry_s;
-    if (idx < n_chunks) chunk_counts[idx] = carry + part[tid] - v;  // exclusive
-    __syncthreads();
-    if (tid == 1023) carry_s = carry + part[1023];
-    __syncthreads();
-  }
-  // per-frame bases: wave w handles frames w, w+16, ...
-  const int lane = tid & 63, w = tid >> 6;
-  for (int b = w; b <= p.B; b += 16) {
+  // per-frame bases: wave w handles frames w, w+4, ...
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int b = w; b <= p.B; b += V3D_BLOCK / V3D_WAVE) {
     const int pos = p.frame_off[b];
     int val;
     if (pos >= p.n_points) {
-      val = carry_s;
+      val = total;
     } else {
       const int chunk = pos / VOX_CHUNK;
-      int cnt = 0;
-      for (int i = chunk * VOX_CHUNK + lane; i < pos; i += 64) cnt += vox_is_first(pt_slot, first, i, p.n_points);
-      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-      val = chunk_counts[chunk] + cnt;
+      int c = 0;
+      for (int i = chunk * VOX_CHUNK + lane; i < pos; i += 64) c += vox_is_first(pt_slot, first, i, p.n_points);
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+      val = v3d_load_coherent(chunk_counts + chunk) + c;
     }
-    if (lane == 0) frame_base[b] = val;
+    if (lane == 0) {
+      frame_base[b] = val;
+      fb_s[b] = val;
+    }
   }
   __syncthreads();
   if (tid == 0) {
     int acc = 0;
     for (int b = 0; b < p.B; b++) {
       out_base[b] = acc;
-      acc += min(frame_base[b + 1] - frame_base[b], p.max_voxels);
+      acc += min(fb_s[b + 1] - fb_s[b], p.max_voxels);
     }
     out_base[p.B] = acc;
     *n_voxels = acc;
@@ -154,7 +137,9 @@ __global__ __launch_bounds__(V3D_BLOCK) void vox_emit_kernel(const float* __rest
                                                              const int* __restrict__ frame_base,
                                                              const int* __restrict__ out_base,
                                                              float* __restrict__ voxels, int* __restrict__ coords,
-                                                             int* __restrict__ occupancy, float* __restrict__ mean) {
+                                                             int* __restrict__ occupancy, float* __restrict__ mean,
+                                                             const V3dHash site_hash, int* __restrict__ site_vals,
+                                                             int site_d, int site_h, int site_w) {
   __shared__ int lds[4];
   const int base = blockIdx.x * VOX_CHUNK;
   int running = chunk_offsets[blockIdx.x];
@@ -175,6 +160,12 @@ __global__ __launch_bounds__(V3D_BLOCK) void vox_emit_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 3; j++) c[j] = (int)floorf((q[j] - p.lo[j]) / p.vs[j]);
     reinterpret_cast<int4*>(coords)[v] = make_int4(b, c[2], c[1], c[0]);
+    if (site_vals) {  // the coordinate hash the first submanifold rulebook needs (saves the rb_hash_build launch)
+      // key over the RULEBOOK's grid (D, H, W), which may be larger than the voxel grid (SECOND pads z by one)
+      const v3d_key_t key = (((v3d_key_t)b * site_d + c[2]) * site_h + c[1]) * site_w + c[0];
+      const int hs = v3d_hash_insert(site_hash, key);
+      if (hs >= 0) site_vals[hs] = v;
+    }
     // the max_pts smallest point indices on this voxel's list, ascending (first-come order)
     int best[VOX_MAX_PTS];
 #pragma unroll
@@ -220,7 +211,8 @@ extern "C" int v3d_voxelize(const float* points, int n_points, int C, const int3
                             float* voxels, int32_t* coords, int32_t* occupancy, float* mean, int32_t* n_voxels,
                             void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
   return v3d_i_voxelize(points, n_points, C, frame_offsets_host, B, voxel_size_host, bounds_host, max_pts, max_voxels,
-                        voxels, coords, occupancy, mean, n_voxels, workspace, workspace_bytes, 1, (hipStream_t)stream);
+                        voxels, coords, occupancy, mean, n_voxels, workspace, workspace_bytes, 1, nullptr, nullptr,
+                        (hipStream_t)stream);
 }
 
 // clear_tables = 0: the caller has already filled the head of the workspace (hash keys | first | head) with
@@ -228,7 +220,8 @@ extern "C" int v3d_voxelize(const float* points, int n_points, int C, const int3
 int v3d_i_voxelize(const float* points, int n_points, int C, const int32_t* frame_offsets_host, int B,
                    const float* voxel_size_host, const float* bounds_host, int max_pts, int max_voxels, float* voxels,
                    int32_t* coords, int32_t* occupancy, float* mean, int32_t* n_voxels, void* workspace,
-                   size_t workspace_bytes, int clear_tables, hipStream_t st) {
+                   size_t workspace_bytes, int clear_tables, const V3dRbHash* site_hash, const int32_t* site_shape,
+                   hipStream_t st) {
   if (n_points < 0 || C < 3 || B < 1 || B > VOX_MAX_FRAMES || max_pts < 1 || max_pts > VOX_MAX_PTS || max_voxels < 1)
     return V3D_EINVAL;
   if (!frame_offsets_host || !voxel_size_host || !bounds_host || !coords || !occupancy || !n_voxels) return V3D_EINVAL;
@@ -267,17 +260,21 @@ int v3d_i_voxelize(const float* points, int n_points, int C, const int32_t* fram
   int* frame_base = ar.take<int>(VOX_MAX_FRAMES + 1);
   int* out_base = ar.take<int>(VOX_MAX_FRAMES + 1);
   if (!ar.ok()) return V3D_EWORKSPACE;
-  if (clear_tables)
+  if (clear_tables) {
     V3D_CHECK_HIP(v3d_fill_async(keys, 0xFF, (size_t)((char*)head - (char*)keys) + (size_t)cap * 4, st));
+    V3D_CHECK_HIP(v3d_fill_async(chunk_counts, 0xFF, (size_t)chunks * 4, st));  // -1 = "count not published yet"
+  }
   V3dHash h = v3d_make_hash(keys, cap);
   const int ins_blocks = min(v3d_ceil_div(n_points, V3D_BLOCK), 2048);
   hipLaunchKernelGGL(vox_insert_kernel, dim3(ins_blocks), dim3(V3D_BLOCK), 0, st, points, p, h, first, head, pt_slot,
                      next);
-  hipLaunchKernelGGL(vox_count_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, pt_slot, first, n_points, chunk_counts);
-  hipLaunchKernelGGL(vox_scan_kernel, dim3(1), dim3(1024), 0, st, chunk_counts, chunks, pt_slot, first, p, frame_base,
-                     out_base, n_voxels);
+  hipLaunchKernelGGL(vox_count_scan_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, pt_slot, first, p, chunk_counts, chunks,
+                     frame_base, out_base, n_voxels);
+  V3dHash sh = v3d_make_hash(site_hash ? site_hash->keys : keys, site_hash ? site_hash->hcap : cap);
   hipLaunchKernelGGL(vox_emit_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, points, p, pt_slot, first, head, next,
-                     chunk_counts, frame_base, out_base, voxels, coords, occupancy, mean);
+                     chunk_counts, frame_base, out_base, voxels, coords, occupancy, mean, sh,
+                     (site_hash && site_shape) ? site_hash->vals : (int*)nullptr, site_shape ? site_shape[0] : 0,
+                     site_shape ? site_shape[1] : 0, site_shape ? site_shape[2] : 0);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
