@@ -63,6 +63,21 @@ def test_native_matches_torch_statement_and_oracle(oracle, B, multi):
     np.testing.assert_allclose(out[3].cpu().numpy(), cpu[3], rtol=1e-5, atol=1e-7)
 
 
+def test_many_groups_fall_back_to_the_torch_statement():
+    """B * n_cls * TOPK > 1024 candidates exceed the one-workgroup sort: inference_native routes to the op-by-op path."""
+    from vision3d_amd.detector.proposal import ProposalLayer
+    cfg = multi_class_cfg()
+    head = ProposalLayer(cfg).cuda()
+    anchors = AnchorGenerator(cfg).anchors
+    H, W = anchors.shape[2:4]
+    assert head.native_supported(3) and not head.native_supported(4)
+    maps = dev(make_maps(cfg, 4, H, W, seed=77))
+    out = head.inference_native(maps, anchors.cuda())
+    ref = head.inference_from_maps(*head.maps_from_fused(maps), anchors.cuda())
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+
+
 def test_candidate_order_with_ties():
     """All-equal and saturated logits: candidates are the lowest anchor indices, in index order; nothing reads
     out of bounds; duplicates of one box collapse to a single keep."""

@@ -126,8 +126,12 @@ extern "C" int v3d_densify_nhwc_split(const float* feat, const int32_t* coords, 
   if (!feat || !coords || !n || cap < 1 || B < 1 || C < 1 || !spatial_shape_host || !out_hi || !out_lo) return V3D_EINVAL;
   const int D = spatial_shape_host[0], H = spatial_shape_host[1], Wd = spatial_shape_host[2];
   const size_t bytes = (size_t)B * H * Wd * C * D * sizeof(bf16_t);
-  V3D_CHECK_HIP(v3d_fill_async(out_hi, 0, bytes, st));
-  V3D_CHECK_HIP(v3d_fill_async(out_lo, 0, bytes, st));
+  if ((char*)out_lo == (char*)out_hi + bytes) {  // planes allocated back to back: one launch
+    V3D_CHECK_HIP(v3d_fill_async(out_hi, 0, 2 * bytes, st));
+  } else {
+    V3D_CHECK_HIP(v3d_fill_async(out_hi, 0, bytes, st));
+    V3D_CHECK_HIP(v3d_fill_async(out_lo, 0, bytes, st));
+  }
   const long long total = (long long)cap * C;
   const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
   hipLaunchKernelGGL(densify_split_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(V3D_BLOCK), 0, st, feat,

@@ -189,6 +189,20 @@ static inline int next_pow2(int n) {
   return p;
 }
 
+// Internal: mask + greedy reduction on boxes that are ALREADY sorted and prepped (csrc/proposal.hip fuses decode,
+// key sort and box prep into one launch).  mask: N * ceil(N/64) words, remv: ceil(N/64) words.
+int v3d_i_nms_sorted(const void* prep_sorted, const int* order, int N, float iou_threshold, int64_t* keep, int32_t* n_keep,
+                     unsigned long long* mask, unsigned long long* remv, hipStream_t st) {
+  if (N < 1 || N > 65535) return V3D_EUNSUPPORTED;
+  const int nwords = (N + 63) / 64;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, N), dim3(V3D_WAVE), 0, st, (const BoxPrep*)prep_sorted, N, nwords,
+                     iou_threshold, mask);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(V3D_BLOCK), 0, st, mask, order, N, nwords, remv, (long long*)keep,
+                     n_keep);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 extern "C" size_t v3d_nms_rotated_workspace(int N) {
   if (N <= 0) return 256;
   const size_t npad = (size_t)next_pow2(N), nwords = (size_t)(N + 63) / 64;

@@ -1,5 +1,5 @@
 // Fused proposal stage of the BEV head: sigmoid -> top-k per (frame, class) -> VoxelNet decode -> batched rotated
-// NMS -> per-class score cut, entirely on the device, in 9 launches, no host synchronisation.
+// NMS -> per-class score cut, entirely on the device, in 6 launches, no host synchronisation.
 //
 // Reference: vision3d/detector/proposal.py:39-80 (ProposalLayer.inference / _multiclass_batch_nms),
 // core/box_encode.py:13-21 (decode), ops/iou_nms.py:90-134 (coordinate-offset batched NMS).  The torch statement
@@ -14,7 +14,8 @@
 #include <stdint.h>
 
 #include "../../include/vision3d_hip.h"
-#include "v3d_common.h"
+#include "rotated_iou.h"
+#include "v3d_internal.h"
 
 #define PROP_THREADS 1024
 #define PROP_WAVES (PROP_THREADS / 64)
@@ -204,23 +205,31 @@ __global__ __launch_bounds__(PROP_THREADS) void prop_topk_merge_kernel(const flo
   prop_select<2>(part_score + o, part_idx + o, chunks * K, 0, K, cand_score + (size_t)grp * K, cand_anchor + (size_t)grp * K);
 }
 
-// One workgroup decodes all N = B*n_cls*topk candidates (core/box_encode.py:13-21), reduces the coordinate range
-// and writes the group-shifted BEV boxes the batched NMS runs on (ops/iou_nms.py:127-133: offset = group *
-// (max_coord - min_coord + 1), added to x and y).
-__global__ __launch_bounds__(PROP_THREADS) void prop_decode_kernel(const float* __restrict__ maps,
-                                                                   const float* __restrict__ anchors, PropGeom g,
-                                                                   const int* __restrict__ cand_anchor,
-                                                                   float* __restrict__ boxes /*(N,7)*/,
-                                                                   long long* __restrict__ batch_idx,
-                                                                   long long* __restrict__ class_idx,
-                                                                   float* __restrict__ bev /*(N,5) shifted*/) {
+// One workgroup: decode all N = B*n_cls*topk candidates (core/box_encode.py:13-21), reduce the coordinate range,
+// shift the BEV boxes by group (ops/iou_nms.py:127-133: offset = group * (max_coord - min_coord + 1), added to x and
+// y), sort (score descending, index ascending) in LDS and emit the NMS inputs in sorted order -- what were four
+// launches (decode, keys, bitonic sort, gather + box prep).  N <= 1024.
+__global__ __launch_bounds__(PROP_THREADS) void prop_decode_sort_kernel(const float* __restrict__ maps,
+                                                                        const float* __restrict__ anchors, PropGeom g,
+                                                                        const int* __restrict__ cand_anchor,
+                                                                        const float* __restrict__ cand_score,
+                                                                        float* __restrict__ boxes /*(N,7)*/,
+                                                                        long long* __restrict__ batch_idx,
+                                                                        long long* __restrict__ class_idx,
+                                                                        int* __restrict__ order,
+                                                                        v3d::BoxPrep* __restrict__ prep) {
   __shared__ float red_hi[PROP_WAVES], red_lo[PROP_WAVES];
+  __shared__ unsigned long long keys[PROP_THREADS];
+  __shared__ float sbev[PROP_THREADS][5];
   const int N = g.B * g.n_cls * g.topk;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int n_anchor = g.n_cls * g.n_yaw;
   float hi = -INFINITY, lo = INFINITY;
-  for (int t = tid; t < N; t += PROP_THREADS) {
-    const int grp = t / g.topk, b = grp / g.n_cls, c = grp % g.n_cls;
+  float o[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int grp = 0;
+  if (t < N) {
+    grp = t / g.topk;
+    const int b = grp / g.n_cls, c = grp % g.n_cls;
     const int a = cand_anchor[t], yaw_i = a / g.HW, pix = a % g.HW;
     float d[7], an[7];
 #pragma unroll
@@ -229,7 +238,6 @@ __global__ __launch_bounds__(PROP_THREADS) void prop_decode_kernel(const float* 
       an[q] = anchors[((size_t)c * g.n_yaw * g.HW + a) * 7 + q];
     }
     const float diag = sqrtf(an[3] * an[3] + an[4] * an[4]);
-    float o[7];
     o[0] = d[0] * diag + an[0];
     o[1] = d[1] * diag + an[1];
     o[2] = d[2] * an[5] + an[2];
@@ -241,8 +249,8 @@ __global__ __launch_bounds__(PROP_THREADS) void prop_decode_kernel(const float* 
     for (int q = 0; q < 7; q++) boxes[(size_t)t * 7 + q] = o[q];
     batch_idx[t] = b;
     class_idx[t] = c;
-    hi = fmaxf(hi, fmaxf(o[0], o[1]) + fmaxf(o[3], o[4]) / 2.f);
-    lo = fminf(lo, fminf(o[0], o[1]) - fminf(o[3], o[4]) / 2.f);
+    hi = fmaxf(o[0], o[1]) + fmaxf(o[3], o[4]) / 2.f;
+    lo = fminf(o[0], o[1]) - fminf(o[3], o[4]) / 2.f;
   }
   for (int off = 32; off > 0; off >>= 1) {
     hi = fmaxf(hi, __shfl_xor(hi, off));
@@ -253,16 +261,39 @@ __global__ __launch_bounds__(PROP_THREADS) void prop_decode_kernel(const float* 
   hi = red_hi[0];
   lo = red_lo[0];
   for (int w = 1; w < PROP_WAVES; w++) { hi = fmaxf(hi, red_hi[w]); lo = fminf(lo, red_lo[w]); }
-  const float span = (hi - lo) + 1.f;
-  for (int t = tid; t < N; t += PROP_THREADS) {  // re-reads this thread's own rows
-    const int grp = t / g.topk;
-    const float shift = (float)grp * span;
-    const float* o = boxes + (size_t)t * 7;
-    bev[(size_t)t * 5 + 0] = o[0] + shift;
-    bev[(size_t)t * 5 + 1] = o[1] + shift;
-    bev[(size_t)t * 5 + 2] = o[3];
-    bev[(size_t)t * 5 + 3] = o[4];
-    bev[(size_t)t * 5 + 4] = o[6];
+  const float shift = (float)grp * ((hi - lo) + 1.f);
+  sbev[t][0] = o[0] + shift;
+  sbev[t][1] = o[1] + shift;
+  sbev[t][2] = o[3];
+  sbev[t][3] = o[4];
+  sbev[t][4] = o[6];
+  // key = (~orderable(score) << 32) | index, ascending == the order v3d_nms_rotated sorts in; padding sorts last
+  unsigned long long key = ~0ull;
+  if (t < N) {
+    const unsigned u = __float_as_uint(cand_score[t]);
+    const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    key = ((unsigned long long)(~ord) << 32) | (unsigned)t;
+  }
+  keys[t] = key;
+  __syncthreads();
+  int npad = 1;
+  while (npad < N) npad <<= 1;
+  for (int k = 2; k <= npad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (t < npad) {
+        const int p = t ^ j;
+        if (p > t) {
+          const unsigned long long a = keys[t], bb = keys[p];
+          const bool up = (t & k) == 0;
+          if ((a > bb) == up) { keys[t] = bb; keys[p] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  if (t < N) {
+    const int src = (int)(keys[t] & 0xFFFFFFFFull);
+    order[t] = src;
+    prep[t] = v3d::prep_box(sbev[src]);
   }
 }
 
@@ -322,7 +353,8 @@ extern "C" size_t v3d_proposals_workspace(int B, int n_cls, int topk) {
   const size_t N = (size_t)B * n_cls * topk;
   return prop_align(N * 4) * 2 /*cand score, anchor*/ + prop_align(N * PROP_CHUNKS * 4) * 2 /*level-1 lists*/ +
          prop_align(N * 7 * 4) + prop_align(N * 8) * 3 /*batch, class, keep*/ +
-         prop_align(N * 5 * 4) + 256 /*n_keep*/ + prop_align(v3d_nms_rotated_workspace((int)N)) + 1024;
+         prop_align(N * 5 * 4) + 256 /*n_keep*/ + prop_align(v3d_nms_rotated_workspace((int)N)) + prop_align(N * 4) /*order*/ +
+         prop_align(N * sizeof(v3d::BoxPrep)) + 1024;
 }
 
 extern "C" int v3d_proposals(const float* head_maps, const float* anchors, int B, int n_cls, int n_yaw, int H, int W,
@@ -335,6 +367,7 @@ extern "C" int v3d_proposals(const float* head_maps, const float* anchors, int B
     return V3D_EINVAL;
   if (B < 1 || n_cls < 1 || n_cls > PROP_MAX_CLS || n_yaw < 1 || H < 1 || W < 1 || topk < 1 || topk > PROP_MAX_TOPK)
     return V3D_EINVAL;
+  if ((long long)B * n_cls * topk > PROP_THREADS) return V3D_EUNSUPPORTED;  // candidates of ALL groups are sorted by one block
   if ((long long)n_yaw * H * W < topk) return V3D_EINVAL;  // torch.topk raises as well
   if (workspace_bytes < v3d_proposals_workspace(B, n_cls, topk)) return V3D_EWORKSPACE;
   PropGeom g;
@@ -364,10 +397,18 @@ extern "C" int v3d_proposals(const float* head_maps, const float* anchors, int B
                      part_score, part_idx);
   hipLaunchKernelGGL(prop_topk_merge_kernel, dim3(B * n_cls), dim3(PROP_THREADS), 0, st, part_score, part_idx, chunks, topk,
                      cand_score, cand_anchor);
-  hipLaunchKernelGGL(prop_decode_kernel, dim3(1), dim3(PROP_THREADS), 0, st, head_maps, anchors, g, cand_anchor, boxes, bidx,
-                     cidx, bev);
-  const int rc = v3d_nms_rotated(bev, cand_score, (int)N, iou_threshold, (int64_t*)keep, n_keep, nms_ws, nms_bytes, stream);
-  if (rc != V3D_OK) return rc;
+  if (N > PROP_THREADS) return V3D_EUNSUPPORTED;  // one workgroup decodes and sorts all candidates
+  int* order = (int*)take(N * 4);
+  v3d::BoxPrep* prep = (v3d::BoxPrep*)take(N * sizeof(v3d::BoxPrep));
+  hipLaunchKernelGGL(prop_decode_sort_kernel, dim3(1), dim3(PROP_THREADS), 0, st, head_maps, anchors, g, cand_anchor,
+                     cand_score, boxes, bidx, cidx, order, prep);
+  {
+    const size_t nwords = (N + 63) / 64;
+    unsigned long long* mask = (unsigned long long*)nms_ws;  // N*nwords + nwords words <= v3d_nms_rotated_workspace(N)
+    const int rc = v3d_i_nms_sorted(prep, order, (int)N, iou_threshold, (int64_t*)keep, n_keep, mask, mask + N * nwords, st);
+    if (rc != V3D_OK) return rc;
+  }
+  (void)bev;
   hipLaunchKernelGGL(prop_finalize_kernel, dim3(1), dim3(PROP_THREADS), 0, st, keep, n_keep, g, boxes, bidx, cidx, cand_score,
                      out_boxes, (long long*)out_batch_idx, (long long*)out_class_idx, out_scores, n_out);
   V3D_CHECK_LAUNCH();

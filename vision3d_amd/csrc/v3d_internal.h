@@ -26,3 +26,7 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
                           int32_t* out_shape, int clear,
                           const int32_t* next_subm_ksize /*nullable: also build the submanifold table of the OUTPUT sites*/,
                           int32_t* next_subm_nbr, hipStream_t st);
+
+// iou_nms.hip: mask + greedy reduction on boxes already sorted by (score desc, index asc) and prepped (BoxPrep rows)
+int v3d_i_nms_sorted(const void* prep_sorted, const int* order, int N, float iou_threshold, int64_t* keep, int32_t* n_keep,
+                     unsigned long long* mask, unsigned long long* remv, hipStream_t st);

@@ -30,7 +30,12 @@ class GraphedSecond(object):
 
     def _body(self):
         hi, lo = self.plan.forward_split(self.static_points, self.offsets)
-        return self.model.head.native_proposals(self.dense.forward(hi, lo), self.anchors)
+        head = self.model.head
+        maps = self.dense.forward(hi, lo)
+        self.native = head.native_supported(len(self.frame_sizes))
+        if self.native:
+            return head.native_proposals(maps, self.anchors)
+        return head.proposals_padded(*head.maps_from_fused(maps), self.anchors)
 
     def load(self, clouds):
         assert len(clouds) == len(self.frame_sizes)
@@ -45,4 +50,5 @@ class GraphedSecond(object):
     def __call__(self, clouds):
         self.load(clouds)
         self.graph.replay()
-        return self.model.head.finalize_native(*self.outputs)
+        head = self.model.head
+        return head.finalize_native(*self.outputs) if self.native else head.finalize(*self.outputs)

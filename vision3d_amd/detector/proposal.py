@@ -87,6 +87,10 @@ class ProposalLayer(nn.Module):
         keep, n_keep = batched_nms_rotated_padded(bev, scores, group_idx, 0.01)
         return boxes, batch_idx, class_idx, scores, keep, n_keep
 
+    def native_supported(self, batch_size):
+        """csrc/proposal.hip sorts the candidates of all (frame, class) groups in one workgroup: <= 1024 of them."""
+        return batch_size * self.cfg.NUM_CLASSES * self.TOPK <= 1024 and self.DOF == 7 and self.cfg.NUM_CLASSES <= 16
+
     def native_proposals(self, head_maps, anchors):
         """The whole stage after the 1x1 heads in libvision3d_hip.so (csrc/proposal.hip: 8 launches, no host
         sync): head_maps (B, n_anchor*(1+DOF), H, W) = [cls | reg] channels of the fused head.  Returns padded
@@ -104,7 +108,7 @@ class ProposalLayer(nn.Module):
         batch_idx = torch.empty((N,), dtype=torch.int64, device=dev)
         class_idx = torch.empty((N,), dtype=torch.int64, device=dev)
         scores = torch.empty((N,), dtype=torch.float32, device=dev)
-        n_out = torch.zeros((1,), dtype=torch.int32, device=dev)
+        n_out = torch.empty((1,), dtype=torch.int32, device=dev)  # always written by the last kernel
         lib = L.lib()
         ws = L.workspace(lib.v3d_proposals_workspace(B, n_cls, self.TOPK), dev)
         thresh = L.host_f32([a["score_thresh"] for a in cfg.ANCHORS[:n_cls]])
@@ -120,6 +124,9 @@ class ProposalLayer(nn.Module):
         return [boxes[:n], batch_idx[:n], class_idx[:n], scores[:n]]
 
     def inference_native(self, head_maps, anchors):
+        if not self.native_supported(head_maps.shape[0]):  # many frames x classes: the op-by-op statement
+            cls_map, reg_map = self.maps_from_fused(head_maps)
+            return self.inference_from_maps(cls_map, reg_map, anchors)
         return self.finalize_native(*self.native_proposals(head_maps, anchors))
 
     def finalize(self, boxes, batch_idx, class_idx, scores, keep, n_keep):

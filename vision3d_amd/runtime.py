@@ -181,8 +181,8 @@ def _view(ptr, shape, dtype, device):
 # ------------------------------------------------------------------------------------------------
 def split_planes_like(b, h, w, c, device):
     """Two bf16 NHWC planes ("hi", "lo") stored as int16."""
-    return (torch.empty((b, h, w, c), dtype=torch.int16, device=device),
-            torch.empty((b, h, w, c), dtype=torch.int16, device=device))
+    both = torch.empty((2, b, h, w, c), dtype=torch.int16, device=device)  # contiguous: one fill clears both planes
+    return both[0], both[1]
 
 
 def conv2d_split(x_hi, x_lo, image, bias, relu, cin, cout, ksize, out_split=True, out_nchw=False):
