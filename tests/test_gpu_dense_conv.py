@@ -25,7 +25,7 @@ def dense_variant(request):
 
 @pytest.mark.parametrize("b,h,w,cin,cout,k", [(2, 37, 29, 64, 128, 3), (1, 20, 16, 128, 128, 3), (1, 33, 50, 128, 128, 1),
                                              (3, 9, 7, 32, 256, 3), (1, 40, 31, 128, 16, 1), (1, 61, 53, 256, 128, 1),
-                                             (2, 24, 12, 128, 256, 3)])
+                                             (2, 24, 12, 128, 256, 3), (1, 30, 44, 192, 128, 3), (1, 19, 23, 64, 64, 3), (1, 25, 17, 96, 128, 1)])
 def test_conv_matches_torch_fp32(b, h, w, cin, cout, k, dense_variant):
     from vision3d_amd.runtime import conv2d_split, pack_conv_weight, to_split_nhwc
     g = torch.Generator().manual_seed(cin * 7 + cout + k)

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
 }
 
 // ------------------------------------------------------------------------------------------------
-// Large-tile variant (Cin % 128 == 0): 144 pixels x 128 couts per workgroup, wave-specialised.
+// Large-tile variant (Cin >= 64, a multiple of 32): 144 pixels x 128 couts per workgroup, wave-specialised.
 //
 // Why: the 64-pixel kernel above is bound by LDS and L1-fill bandwidth, not by the matrix cores -- per k-step each
 // wave issues 12 ds_read_b128 for 24 MFMAs and the block re-streams the whole 590 KB weight image for only 64
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
   }
   const int m0 = mtile * DL_BM;
   const int n0 = blockIdx.y * DC_BN;
-  const int chunks = p.Cin / DL_KC;  // 128-channel stages per tap
+  const int chunks = (p.Cin + DL_KC - 1) / DL_KC;  // 128-channel stages per tap (the last one may be partial: zero-filled)
   const int stages = KS * KS * chunks;
   // LDS image of one plane: pixel rows of 256 B (16 parts of 16 B), the part slot XOR-ed with px & 15.  Every row
   // aliases the same 64 banks, so the XOR alone has to separate the 16 lanes of a ds_read_b128 group (16 pixels,
@@ -494,9 +494,10 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
 #pragma unroll
       for (int j = 0; j < DL_MT; j++) {  // branch-free: out-of-image taps read the (valid) centre pixel, zeroed after
         const int hh = (a_hw[j] >> 16) + dy, ww = (a_hw[j] & 0xFFFF) + dx;
-        ok[j] = a_pix[j] >= 0 && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
+        const int ch = chunk * DL_KC + a_part * 8;  // beyond Cin in a partial last stage: zero rows (B is clamped)
+        ok[j] = a_pix[j] >= 0 && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W && ch < p.Cin;
         const int src = ok[j] ? a_pix[j] + dy * p.W + dx : (a_pix[j] >= 0 ? a_pix[j] : 0);
-        const size_t off = (size_t)src * p.Cin + chunk * DL_KC + a_part * 8;
+        const size_t off = (size_t)src * p.Cin + (ch < p.Cin ? ch : 0);
         ra[j][0] = *reinterpret_cast<const u32x4*>(x_hi + off);
         ra[j][1] = *reinterpret_cast<const u32x4*>(x_lo + off);
       }
@@ -531,7 +532,8 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
     u32x4 cb[DL_SS][4];  // B fragments per k-substep: [n-tile*2 + plane]
     int tap = 0, chunk = 0;  // stage whose B fragments are requested next
     auto load_b = [&](int ss) {
-      const size_t step = (size_t)tap * (p.Cin / DC_KC) + (size_t)chunk * DL_SS + ss;  // 32-channel step of the image
+      const int steps32 = p.Cin / DC_KC;  // 32-channel steps per tap in the packed image
+      const size_t step = (size_t)tap * steps32 + min(chunk * DL_SS + ss, steps32 - 1);  // clamped: its A rows are zero
       const bf16_t* wb = w_img + step * 2 * plane_elems + ((size_t)(n0 / 16 + wave * 2) * 64 + lane) * 8;
 #pragma unroll
       for (int nt2 = 0; nt2 < 2; nt2++) {
@@ -718,7 +720,7 @@ extern "C" int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const 
   p.M = B * H * W;
   p.cout_store = Cout;
   hipStream_t st = (hipStream_t)stream;
-  const bool large_ok = Cin % DL_KC == 0 && H < 32768 && W < 65536 && W >= 16;  // else: the 64-pixel kernel
+  const bool large_ok = Cin >= 64 && H < 32768 && W < 65536 && W >= 16;  // (Cin % 32 == 0 checked above) else: the 64-pixel kernel
   if (large_ok && (g_v3d_dense_variant == 2 || (g_v3d_dense_variant == 0 && Cout > 32))) {
     dim3 lgrid(v3d_ceil_div(p.M, DL_BM), p.CoutPad / DC_BN);
     auto kern = ksize == 3 ? conv2d_bf16x3_large_kernel<3> : conv2d_bf16x3_large_kernel<1>;
