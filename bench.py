@@ -208,7 +208,7 @@ def main():
     value = frames / elapsed
 
     # ---- per-kernel timing of the sparse backbone with HIP events on the launch stream (rank 0)
-    roofline, stages = None, None
+    roofline, stages, roofline_dense = None, None, None
     if rank == 0 and not args.no_roofline:
         # One eager pass captures the exact operands of the 14 sparse-conv launches of this frame; every launch
         # is then re-issued REP times back to back on the launch stream inside one HIP-event bracket
@@ -253,6 +253,28 @@ def main():
         roofline = dict(bound="hbm", kernel="spconv_fwd_rows<64,64>", launches_per_frame=len(dom),
                         bytes_per_launch=dom_bytes, avg_us=dom_t * 1e6, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=None)
+        # the other large kernel of the frame: the 3x3 RPN convolution (MFMA-bound).  Algorithmic flops = 2*M*Cout*9*Cin;
+        # the kernel issues 3 bf16 MFMA terms per product (split precision), so `issued` = 3x `achieved`.
+        from vision3d_amd.runtime import conv2d_split, pack_conv_weight, to_split_nhwc
+        ny, nx = anchors.shape[2:4]
+        cdim = cfg.PROPOSAL.C_IN
+        xh, xl = to_split_nhwc(torch.randn(args.batch, cdim, ny, nx, device="cuda"))
+        img = pack_conv_weight(torch.randn(cdim, cdim, 3, 3, device="cuda") / (9 * cdim) ** 0.5)
+        bz = torch.zeros(cdim, device="cuda")
+        for _ in range(3):
+            conv2d_split(xh, xl, img, bz, True, cdim, cdim, 3, out_split=True, out_nchw=False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            conv2d_split(xh, xl, img, bz, True, cdim, cdim, 3, out_split=True, out_nchw=False)
+        e1.record()
+        torch.cuda.synchronize()
+        t_dense = e0.elapsed_time(e1) * 1e-3 / 20
+        fl = 2.0 * args.batch * ny * nx * cdim * cdim * 9
+        roofline_dense = dict(bound="mfma", kernel="conv2d_bf16x3_large_kernel<3>", launches_per_frame=6, flops_per_launch=fl,
+                              avg_us=t_dense * 1e6, achieved=fl / t_dense / 1e12, issued=3 * fl / t_dense / 1e12, peak=2500.0,
+                              unit="TFLOP/s", frac=fl / t_dense / 1e12 / 2500.0, frac_issued=3 * fl / t_dense / 1e12 / 2500.0,
+                              note="peak = dense bf16 MFMA; 3 bf16 terms per fp32-class product")
         tot_bytes = sum(l["bytes"] for l in layers)
         tot_t = sum(l["t_avg_us"] for l in layers) * 1e-6
         stages = dict(sparse_conv_launches=len(layers), sparse_conv_us=tot_t * 1e6, sparse_conv_algorithmic_MB=tot_bytes / 1e6,
@@ -290,7 +312,7 @@ def main():
                                 path={"graph": "native backbone plan + bf16x3 MFMA dense head, one HIP graph per frame",
                                       "native": "native backbone plan + bf16x3 MFMA dense head", "fused": "native backbone plan + torch RPN",
                                       "eager": "eager python -> C ABI"}[args.path]),
-                    roofline=roofline, cpu_baseline=cpu_baseline, stages=stages,
+                    roofline=roofline, cpu_baseline=cpu_baseline, roofline_dense=roofline_dense, stages=stages,
                     n_proposals=int(out[0].shape[0]))
         print(json.dumps(line))
     if world > 1:

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
 //     fragments straight from the packed image in L2 (no LDS, no duplication between waves), each of the four
 //     k-substep register sets refilled for the next stage as soon as its last MFMA has issued;
 //   * waves 4-7 are LOADER waves: while the matrix waves multiply stage s they gather stage s+1 (all 128 input
-//     channels of one tap, 72 KB, zero halo) global -> registers -> the other LDS buffer.  With one workgroup per
+//     channels of one tap, 72 KB, zero halo) into the other LDS buffer with global_load_lds_dwordx4 (LDS-DMA).  With one workgroup per
 //     CU nothing else could overlap the gather latency and the 13-cycle ds_write_b128s with the MFMAs (measured
 //     with the cycle-counter stamps below: 15 us fixed + 22 us multiply + 13 us exposed gather when one set of
 //     4 waves did both);
@@ -420,6 +420,8 @@ extern "C" int v3d_debug_dense_timeline(unsigned long long* host_out) {
 #else
 #define DL_STAMP(role, idx)
 #endif
+
+__device__ __attribute__((aligned(16))) const unsigned dl_zero16[4] = {0u, 0u, 0u, 0u};  // halo source of the LDS-DMA gather
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -466,48 +468,46 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
   }
 
   if (loader) {
-    // ---- gather role: part a_part (16 B = 8 channels) of the 9 pixels a_px0 + 16*j
-    const int lt = tid - 256;
-    const int a_part = lt & 15, a_px0 = lt >> 4;
-    int a_pix[DL_MT], a_hw[DL_MT];  // flattened pixel index (-1: beyond M), packed (h << 16 | w)
-    {  // one division for the first pixel, the other eight follow by stepping 16 columns (W >= 16 is checked by the host)
-      const int m = m0 + a_px0;
+    // ---- gather role, LDS-DMA: one global_load_lds_dwordx4 moves 64 lanes x 16 B = four 256-byte pixel rows of one
+    // plane straight into LDS (wave-uniform base + lane*16, no VGPR round trip, no ds_write, no select).  The LDS
+    // image is swizzled, so the permutation goes on the SOURCE side: lane L of a row block feeds slot L%16 of pixel
+    // L/16 with channel part (L%16) ^ (px & 15).  Halo / out-of-range lanes read a 16-byte block of zeros.
+    const int lw = wave - 4;
+    const int sub = lane >> 4, slot = lane & 15;
+    int a_pix[DL_MT], a_hw[DL_MT];  // this lane's 9 pixels: px = (lw*9 + j)*4 + sub; flattened index (-1: beyond M), (h << 16 | w)
+    {
+      const int m = m0 + lw * DL_MT * 4 + sub;
       const int b = m / (p.H * p.W), rem = m - b * p.H * p.W;
       int h = rem / p.W, w = rem - h * p.W;
 #pragma unroll
       for (int j = 0; j < DL_MT; j++) {
-        const int mj = m + 16 * j;
+        const int mj = m + 4 * j;
         a_pix[j] = mj < p.M ? mj : -1;
         a_hw[j] = mj < p.M ? ((h << 16) | w) : 0;
-        w += 16;
+        w += 4;
         if (w >= p.W) {
           w -= p.W;
           if (++h == p.H) h = 0;
         }
       }
     }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
     int tap = 0, chunk = 0;
-    auto gather = [&](int buf) {  // this thread's 18 pieces of stage (tap, chunk): all loads in flight, then the stores
+    auto gather = [&](int buf) {
       const int dy = KS == 3 ? tap / 3 - 1 : 0, dx = KS == 3 ? tap % 3 - 1 : 0;
-      u32x4 ra[DL_MT][2];
-      bool ok[DL_MT];
-#pragma unroll
-      for (int j = 0; j < DL_MT; j++) {  // branch-free: out-of-image taps read the (valid) centre pixel, zeroed after
-        const int hh = (a_hw[j] >> 16) + dy, ww = (a_hw[j] & 0xFFFF) + dx;
-        const int ch = chunk * DL_KC + a_part * 8;  // beyond Cin in a partial last stage: zero rows (B is clamped)
-        ok[j] = a_pix[j] >= 0 && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W && ch < p.Cin;
-        const int src = ok[j] ? a_pix[j] + dy * p.W + dx : (a_pix[j] >= 0 ? a_pix[j] : 0);
-        const size_t off = (size_t)src * p.Cin + (ch < p.Cin ? ch : 0);
-        ra[j][0] = *reinterpret_cast<const u32x4*>(x_hi + off);
-        ra[j][1] = *reinterpret_cast<const u32x4*>(x_lo + off);
-      }
-      unsigned char* A = smem_l + buf * DL_STAGE;
-      const u32x4 z = u32x4{0, 0, 0, 0};
+      unsigned char* A = smem_l + buf * DL_STAGE + lw * DL_MT * 1024;
 #pragma unroll
       for (int j = 0; j < DL_MT; j++) {
-        const int px = a_px0 + 16 * j;
-        *reinterpret_cast<u32x4*>(A + a_slot(px, a_part)) = ok[j] ? ra[j][0] : z;
-        *reinterpret_cast<u32x4*>(A + DL_A_PLANE + a_slot(px, a_part)) = ok[j] ? ra[j][1] : z;
+        const int px = (lw * DL_MT + j) * 4 + sub;
+        const int ch = chunk * DL_KC + ((slot ^ (px & 15)) << 3);
+        const int hh = (a_hw[j] >> 16) + dy, ww = (a_hw[j] & 0xFFFF) + dx;
+        const bool ok = a_pix[j] >= 0 && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W && ch < p.Cin;
+        const size_t off = (size_t)(a_pix[j] + dy * p.W + dx) * p.Cin + ch;
+        const bf16_t* sh = ok ? x_hi + off : reinterpret_cast<const bf16_t*>(dl_zero16);
+        const bf16_t* sl = ok ? x_lo + off : reinterpret_cast<const bf16_t*>(dl_zero16);
+        __builtin_amdgcn_global_load_lds((gptr_t)sh, (lptr_t)(A + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)sl, (lptr_t)(A + DL_A_PLANE + j * 1024), 16, 0, 0);
       }
       if (++chunk == chunks) {
         chunk = 0;
