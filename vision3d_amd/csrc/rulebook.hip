@@ -100,6 +100,22 @@ __device__ __forceinline__ bool rb_is_first(const int* cand_slot, const unsigned
   return s >= 0 && first_ticket[s] == (unsigned)t;
 }
 
+#define RB_PER_THREAD (V3D_SCAN_CHUNK / V3D_BLOCK)  // 8 consecutive tickets per thread
+static_assert(RB_PER_THREAD == 8, "rb_first_flags loads two int4");
+// bit r set <=> ticket t0 + r is the first toucher of its output slot.  t0 is a multiple of 8 -> 32-byte aligned loads.
+__device__ __forceinline__ unsigned rb_first_flags(const int* __restrict__ cand_slot, const unsigned* __restrict__ first_ticket,
+                                                   long long t0, long long nt) {
+  if (t0 >= nt) return 0u;
+  const int4 a = *reinterpret_cast<const int4*>(cand_slot + t0);  // cand_slot is sized to whole chunks
+  const int4 b = *reinterpret_cast<const int4*>(cand_slot + t0 + 4);
+  const int s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned flags = 0u;
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    if (t0 + r < nt && s[r] >= 0 && first_ticket[s[r]] == (unsigned)(t0 + r)) flags |= 1u << r;
+  return flags;
+}
+
 // count + scan in ONE launch (the highest-index block scans the published counts, v3d_common.h): chunk_counts
 // (-1 at launch) become exclusive offsets, the total is clipped to cap_out
 __global__ __launch_bounds__(V3D_BLOCK) void rb_count_scan_kernel(const int* __restrict__ cand_slot,
@@ -111,12 +127,13 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_count_scan_kernel(const int* __r
   const long long nt = (long long)min(*n_ptr, cap_in) * K;
   const long long base = (long long)blockIdx.x * V3D_SCAN_CHUNK;
   int cnt = 0;
-  if (base < nt) {  // block-uniform
-    for (int r = 0; r < V3D_SCAN_CHUNK / V3D_BLOCK; r++) {
-      int tot;
-      v3d_block_rank(rb_is_first(cand_slot, first_ticket, base + r * V3D_BLOCK + threadIdx.x, nt), tot, lds);
-      cnt += tot;
-    }
+  if (base < nt) {  // block-uniform.  Thread = RB_PER_THREAD consecutive tickets (two 16-byte loads), ONE block reduction
+    const unsigned flags = rb_first_flags(cand_slot, first_ticket, base + (long long)threadIdx.x * RB_PER_THREAD, nt);
+    int mine = __popc(flags);
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    cnt = lds[0] + lds[1] + lds[2] + lds[3];
   }
   if (threadIdx.x == 0) v3d_publish_count(chunk_counts + blockIdx.x, cnt);
   if (blockIdx.x != gridDim.x - 1) return;
@@ -137,20 +154,35 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_emit_kernel(const int4* __restri
   const long long nt = (long long)min(*n_ptr, cap_in) * g.K;
   const long long base = (long long)blockIdx.x * V3D_SCAN_CHUNK;
   if (base >= nt) return;  // block-uniform
-  int running = chunk_offsets[blockIdx.x];
-  for (int r = 0; r < V3D_SCAN_CHUNK / V3D_BLOCK; r++) {
-    const long long t = base + r * V3D_BLOCK + threadIdx.x;
-    const bool flag = rb_is_first(cand_slot, first_ticket, t, nt);
-    int tot;
-    const int rank = running + v3d_block_rank(flag, tot, lds);
-    running += tot;
-    if (!flag || rank >= cap_out) continue;
-    const int i = (int)(t / g.K), k = (int)(t % g.K);
-    const int4 c = coords[i];
-    int oz, oy, ox;
-    rb_candidate(c, k, g, oz, oy, ox);
-    coords_out[rank] = make_int4(c.x, oz, oy, ox);
-    vals[cand_slot[t]] = rank;
+  // thread = 8 consecutive tickets: ranks follow from ONE block-wide exclusive scan of the per-thread counts
+  const long long t0 = base + (long long)threadIdx.x * RB_PER_THREAD;
+  const unsigned flags = rb_first_flags(cand_slot, first_ticket, t0, nt);
+  const int mine = __popc(flags);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) lds[w] = incl;
+  __syncthreads();
+  int rank = chunk_offsets[blockIdx.x] + incl - mine;
+  for (int i = 0; i < w; i++) rank += lds[i];
+  unsigned f = flags;
+  while (f) {
+    const int r = __ffs(f) - 1;
+    f &= f - 1;
+    if (rank < cap_out) {
+      const long long t = t0 + r;
+      const int i = (int)(t / g.K), k = (int)(t % g.K);
+      const int4 c = coords[i];
+      int oz, oy, ox;
+      rb_candidate(c, k, g, oz, oy, ox);
+      coords_out[rank] = make_int4(c.x, oz, oy, ox);
+      vals[cand_slot[t]] = rank;
+    }
+    rank++;
   }
 }
 
