@@ -32,7 +32,7 @@ class GraphedSecond(object):
         hi, lo = self.plan.forward_split(self.static_points, self.offsets)
         head = self.model.head
         maps = self.dense.forward(hi, lo)
-        self.native = head.native_supported(len(self.frame_sizes))
+        self.native = head.native_supported(len(self.frame_sizes), self.anchors.numel() // (7 * self.model.cfg.NUM_CLASSES))
         if self.native:
             return head.native_proposals(maps, self.anchors)
         return head.proposals_padded(*head.maps_from_fused(maps), self.anchors)

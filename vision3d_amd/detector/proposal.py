@@ -87,9 +87,13 @@ class ProposalLayer(nn.Module):
         keep, n_keep = batched_nms_rotated_padded(bev, scores, group_idx, 0.01)
         return boxes, batch_idx, class_idx, scores, keep, n_keep
 
-    def native_supported(self, batch_size):
-        """csrc/proposal.hip sorts the candidates of all (frame, class) groups in one workgroup: <= 1024 of them."""
-        return batch_size * self.cfg.NUM_CLASSES * self.TOPK <= 1024 and self.DOF == 7 and self.cfg.NUM_CLASSES <= 16
+    def native_supported(self, batch_size, anchors_per_class=None):
+        """csrc/proposal.hip sorts the candidates of all (frame, class) groups in one workgroup (<= 1024 of them) and
+        selects each group's top-k in two levels of <= 40 register-resident slices of <= 8192 anchors."""
+        ok = batch_size * self.cfg.NUM_CLASSES * self.TOPK <= 1024 and self.DOF == 7 and self.cfg.NUM_CLASSES <= 16
+        if anchors_per_class is not None:
+            ok = ok and anchors_per_class <= 8192 * min(40, 4096 // self.TOPK)
+        return ok
 
     def native_proposals(self, head_maps, anchors):
         """The whole stage after the 1x1 heads in libvision3d_hip.so (csrc/proposal.hip: 8 launches, no host
@@ -124,7 +128,7 @@ class ProposalLayer(nn.Module):
         return [boxes[:n], batch_idx[:n], class_idx[:n], scores[:n]]
 
     def inference_native(self, head_maps, anchors):
-        if not self.native_supported(head_maps.shape[0]):  # many frames x classes: the op-by-op statement
+        if not self.native_supported(head_maps.shape[0], anchors.numel() // (7 * self.cfg.NUM_CLASSES)):  # too large: op-by-op
             cls_map, reg_map = self.maps_from_fused(head_maps)
             return self.inference_from_maps(cls_map, reg_map, anchors)
         return self.finalize_native(*self.native_proposals(head_maps, anchors))
