@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--path", choices=["graph", "native", "fused", "eager"], default="graph",
                     help="graph: native path captured in one HIP graph; native: backbone plan + MFMA dense head; "
                          "fused: backbone plan + torch (MIOpen) RPN; eager: per-op python -> C ABI")
-    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
+    ap.add_argument("--mode", choices=["forward", "train", "pvrcnn"], default="forward",
                     help="forward: the headline metric; train: BASELINE configs[2] (SECOND train step, bs=8/GPU, gradient "
                          "all-reduce over RCCL) -- a secondary line, same JSON contract")
     ap.add_argument("--no-channels-last", action="store_true", help="train mode: keep the dense RPN/head in NCHW")
@@ -138,10 +138,68 @@ def train_main(args):
         dist.destroy_process_group()
 
 
+def pvrcnn_main(args):
+    """configs[3]: PV-RCNN stage 2 on SECOND proposals -- FPS keypoints (16 384 -> 2 048), 5-level voxel-set abstraction
+    (ball query + group + shared MLP + max), BEV bilinear gather, RoI-grid pooling of 100 proposals, refinement MLP.
+    Stage-1 outputs (sparse feature volumes, BEV map, proposals) are resident before the timed region."""
+    from vision3d_amd import dist_util, synth
+    from vision3d_amd.core import Preprocessor
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.detector import PV_RCNN
+    import torch.distributed as dist
+    rank, local, world = dist_util.env_world()
+    torch.cuda.set_device(local)
+    dist_util.init_from_env("nccl")
+    cfg = second_car_cfg()
+    torch.manual_seed(0)
+    model = PV_RCNN(cfg).cuda().eval()
+    bs = args.batch
+    clouds = [synth.make_cloud(rank * bs + i, args.points or 16384) for i in range(bs)]
+    with torch.no_grad():
+        item = model.proposal(Preprocessor(cfg, seed=0)(dict(points=clouds)))
+        gts = [synth.make_gt_boxes(rank * bs + i) for i in range(bs)]
+        n_prop = 100
+        props = torch.from_numpy(np.stack([np.resize(g, (n_prop, 7)) for g in gts])).cuda()
+
+        def step():
+            item["keypoints"] = model.sample_keypoints(item["points"])
+            pf = model.point_feature_extract(item, item["_cnn_features"], item["_bev_map"])
+            pooled = model.roi_grid_pool(props, item["keypoints"], pf)
+            return model.refinement_layer(None, pooled, props)
+
+        def fence():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            out = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        fence()
+    elapsed = dist_util.max_over_ranks(time.perf_counter() - t0, world, device="cuda")
+    if rank == 0:
+        print(json.dumps(dict(
+            metric="frames/sec PV-RCNN stage 2, 16k-pt KITTI cloud", value=world * bs * args.steps / elapsed, unit="frames/s",
+            n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
+            scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+            config=dict(workload="PV-RCNN stage 2 (BASELINE configs[3]): FPS 2048 keypoints + 5-level VSA + BEV gather + "
+                                 "RoI-grid pool (100 proposals) + refinement MLP", frames_per_gpu_per_step=bs,
+                        points_per_frame=args.points or 16384, parallelism=f"frame-parallel replicas x{world}"),
+            roofline=None, cpu_baseline=None)))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.mode == "train":
         return train_main(args)
+    if args.mode == "pvrcnn":
+        return pvrcnn_main(args)
     from vision3d_amd import dist_util
     rank, local, world = dist_util.env_world()
     assert torch.cuda.is_available(), "bench.py needs a GPU (vision3d_amd has no CPU path)"

@@ -8,8 +8,8 @@
 //     once).  Arg-max per step = wave64 shuffle reduction on a packed (distance, ~index) key + one LDS
 //     exchange between the 16 waves; ties resolve to the LOWEST index (the reference's block
 //     reduction leaves ties unspecified).
-//   * ball query: one thread per query, database points streamed through LDS tiles shared by the
-//     workgroup; first-nsample-in-index-order semantics with first-hit prefill.
+//   * ball query: one WAVE per query (ballot = hit mask, popcount prefix = slot), database points streamed through
+//     LDS tiles shared by the workgroup; first-nsample-in-index-order semantics with first-hit prefill.
 #include "v3d_common.h"
 
 // ------------------------------------------------------------------------------------------ FPS
@@ -36,7 +36,14 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
   int last = 0;
   for (int s = 1; s < K; s++) {
     const float lx = p[3 * last], ly = p[3 * last + 1], lz = p[3 * last + 2];  // uniform -> scalar loads
-    unsigned long long best = 0ull;
+    // per-thread arg-max on plain floats (strict > keeps the lowest of this thread's indices on ties: n grows with j);
+    // the 64-bit (distance, ~index) key is built once per thread, for the cross-lane exchange only.
+    // Measured and NOT adopted (all bit-exact, none faster than this 1.9 us/step; the step is a latency chain of
+    // scalar load -> update -> wave reduction -> barrier -> 16 LDS reads, not a throughput problem): float2 packed
+    // distance math (v_pk_*), DPP instead of ds_bpermute reductions, winner coordinates through LDS instead of the
+    // dependent global load (2.6-2.9 us/step with the 16-way coordinate select it needs).
+    float bd = -1.f;
+    int bn = 0;
 #pragma unroll
     for (int j = 0; j < PPT; j++) {
       const int n = tid + j * FPS_THREADS;
@@ -45,11 +52,13 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
         const float d = dx * dx + dy * dy + dz * dz;
         const float d2 = fminf(d, td[j]);
         td[j] = d2;
-        // d2 >= 0 -> its bit pattern is monotone; ~n makes the lowest index win ties
-        const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)(~n);
-        best = key > best ? key : best;
+        const bool better = d2 > bd;
+        bd = better ? d2 : bd;
+        bn = better ? n : bn;
       }
     }
+    // d2 >= 0 -> its bit pattern is monotone; ~n makes the lowest index win ties
+    unsigned long long best = bd >= 0.f ? (((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)(~bn)) : 0ull;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const unsigned lo = __shfl_xor((unsigned)best, o), hi = __shfl_xor((unsigned)(best >> 32), o);
@@ -120,45 +129,75 @@ extern "C" int v3d_gather_points(const float* feat, const int32_t* idx, int B, i
 }
 
 // ------------------------------------------------------------------------------------------ ball query
-#define BQ_TILE 1024
+// One WAVE per query: 64 database points are tested per step, the hit mask is a ballot, slots follow from popcount
+// prefixes -- index order is lane order, so "the first nsample points inside the ball, in index order" needs no
+// sorting.  (One THREAD per query left 8 workgroups on a 256-CU chip scanning 16 384 points each from LDS: 1.09 ms
+// per call.)  A workgroup = 4 waves x BQ_QPW queries; the database streams through LDS tiles shared by all of them
+// and the scan stops as soon as every query of the workgroup is full.
+#define BQ_TILE 2048
+#define BQ_QPW 2  // queries per wave
 
 __global__ __launch_bounds__(V3D_BLOCK) void ball_query_kernel(const float* __restrict__ xyz,
                                                                const float* __restrict__ new_xyz, int N, int M,
                                                                float r2, int ns, int* __restrict__ idx) {
   __shared__ float tile[BQ_TILE * 3];
+  __shared__ int open_queries;
   const int b = blockIdx.y;
-  const int j = blockIdx.x * V3D_BLOCK + threadIdx.x;
-  const bool live = j < M;
-  float qx = 0.f, qy = 0.f, qz = 0.f;
-  if (live) {
-    const float* q = new_xyz + ((size_t)b * M + j) * 3;
-    qx = q[0];
-    qy = q[1];
-    qz = q[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q0 = (blockIdx.x * (V3D_BLOCK / V3D_WAVE) + wave) * BQ_QPW;
+  float qx[BQ_QPW], qy[BQ_QPW], qz[BQ_QPW];
+  int cnt[BQ_QPW], first[BQ_QPW];
+#pragma unroll
+  for (int u = 0; u < BQ_QPW; u++) {
+    const int j = q0 + u;
+    const float* q = new_xyz + ((size_t)b * M + (j < M ? j : 0)) * 3;
+    qx[u] = q[0];
+    qy[u] = q[1];
+    qz[u] = q[2];
+    cnt[u] = j < M ? 0 : ns;  // a query beyond M is "full" from the start
+    first[u] = 0;
   }
-  int* o = idx + ((size_t)b * M + (live ? j : 0)) * ns;
-  int cnt = 0;
   const float* base = xyz + (size_t)b * N * 3;
   for (int n0 = 0; n0 < N; n0 += BQ_TILE) {
     const int tn = min(BQ_TILE, N - n0);
     __syncthreads();
+    if (threadIdx.x == 0) open_queries = 0;
     for (int t = threadIdx.x; t < tn * 3; t += V3D_BLOCK) tile[t] = base[(size_t)n0 * 3 + t];
     __syncthreads();
-    if (live && cnt < ns) {
-      for (int t = 0; t < tn; t++) {
-        const float dx = qx - tile[3 * t], dy = qy - tile[3 * t + 1], dz = qz - tile[3 * t + 2];
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        if (d2 < r2) {
-          if (cnt == 0)
-            for (int s = 0; s < ns; s++) o[s] = n0 + t;
-          o[cnt++] = n0 + t;
-          if (cnt >= ns) break;
+#pragma unroll
+    for (int u = 0; u < BQ_QPW; u++) {
+      int* o = idx + ((size_t)b * M + (q0 + u < M ? q0 + u : 0)) * ns;
+      for (int t0 = 0; t0 < tn && cnt[u] < ns; t0 += 64) {  // cnt is wave-uniform
+        const int t = t0 + lane;
+        bool hit = false;
+        if (t < tn) {
+          const float dx = qx[u] - tile[3 * t], dy = qy[u] - tile[3 * t + 1], dz = qz[u] - tile[3 * t + 2];
+          hit = dx * dx + dy * dy + dz * dz < r2;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+          if (cnt[u] == 0) first[u] = n0 + t0 + __ffsll((long long)m) - 1;
+          const int pos = cnt[u] + __popcll(m & ((1ull << lane) - 1ull));
+          if (hit && pos < ns) o[pos] = n0 + t;
+          cnt[u] = min(ns, cnt[u] + __popcll(m));
         }
       }
     }
+    bool any_open = false;
+#pragma unroll
+    for (int u = 0; u < BQ_QPW; u++) any_open = any_open || cnt[u] < ns;
+    if (lane == 0 && any_open) atomicOr(&open_queries, 1);
+    __syncthreads();
+    if (open_queries == 0) break;  // workgroup-uniform
   }
-  if (live && cnt == 0)
-    for (int s = 0; s < ns; s++) o[s] = 0;
+  // unfilled slots repeat the first hit (pointnet2 pre-fills all nsample slots with it); no hit at all -> index 0
+#pragma unroll
+  for (int u = 0; u < BQ_QPW; u++) {
+    if (q0 + u < M) {
+      int* o = idx + ((size_t)b * M + q0 + u) * ns;
+      for (int sidx = cnt[u] + lane; sidx < ns; sidx += 64) o[sidx] = first[u];
+    }
+  }
 }
 
 extern "C" int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M, float radius, int nsample,
@@ -166,7 +205,7 @@ extern "C" int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int
   if (B < 0 || N < 1 || M < 0 || nsample < 1) return V3D_EINVAL;
   if (B == 0 || M == 0) return V3D_OK;
   if (!xyz || !new_xyz || !idx) return V3D_EINVAL;
-  hipLaunchKernelGGL(ball_query_kernel, dim3(v3d_ceil_div(M, V3D_BLOCK), B), dim3(V3D_BLOCK), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(ball_query_kernel, dim3(v3d_ceil_div(M, (V3D_BLOCK / V3D_WAVE) * BQ_QPW), B), dim3(V3D_BLOCK), 0, (hipStream_t)stream,
                      xyz, new_xyz, N, M, radius * radius, nsample, idx);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
