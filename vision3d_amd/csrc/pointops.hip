@@ -15,65 +15,86 @@
 // ------------------------------------------------------------------------------------------ FPS
 #define FPS_THREADS 1024
 
+// Wave64 / row-of-16 max and min reductions on the DPP data path (VALU latency; __shfl_xor goes through ds_bpermute,
+// ~90 clocks per hop).  max/min are idempotent, so lanes whose DPP source is out of range simply combine with their
+// own value.  quad swaps, row_shr:4, row_shr:8 leave lane 15 of every row with the row result; row_bcast:15 and
+// row_bcast:31 carry it on to lane 63.
+#define V3D_DPP_I(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xf, 0xf, false)
+template <bool FULL>
+__device__ __forceinline__ float v3d_dpp_max_f32(float v) {
+#define STEP(ctrl) v = fmaxf(v, __int_as_float(V3D_DPP_I(__float_as_int(v), ctrl)))
+  STEP(0xb1); STEP(0x4e); STEP(0x114); STEP(0x118);
+  if (FULL) { STEP(0x142); STEP(0x143); }
+#undef STEP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), FULL ? 63 : 15));
+}
+template <bool FULL>
+__device__ __forceinline__ int v3d_dpp_min_i32(int v) {
+#define STEP(ctrl) v = min(v, V3D_DPP_I(v, ctrl))
+  STEP(0xb1); STEP(0x4e); STEP(0x114); STEP(0x118);
+  if (FULL) { STEP(0x142); STEP(0x143); }
+#undef STEP
+  return __builtin_amdgcn_readlane(v, FULL ? 63 : 15);
+}
+
 template <int PPT>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restrict__ xyz, int N, int K,
                                                           int* __restrict__ idx) {
-  __shared__ unsigned long long wave_best[2][FPS_THREADS / V3D_WAVE];
+  // One step (cycle-counter probe of the ds_bpermute / 64-bit-key version: update 2 200, wave reduce 1 050, barrier,
+  // block scan 650-1 250 clocks): per-thread arg-max on plain floats, then (max distance, min index among its
+  // holders) by two DPP reductions per wave, one LDS slot per wave, ONE barrier, and the same two reductions over the
+  // 16 slots held by lanes 0-15.  Ties resolve to the lowest index at every level.
+  __shared__ float wave_d[2][FPS_THREADS / V3D_WAVE];
+  __shared__ int wave_n[2][FPS_THREADS / V3D_WAVE];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* p = xyz + (size_t)b * N * 3;
   int* out = idx + (size_t)b * K;
-  float px[PPT], py[PPT], pz[PPT], td[PPT];
+  // coordinates as float2 pairs: gfx950 runs v_pk_add_f32 / v_pk_mul_f32 on two points per lane and instruction
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  constexpr int PP = (PPT + 1) / 2;
+  f2 px[PP], py[PP], pz[PP];
+  float td[2 * PP];
 #pragma unroll
-  for (int j = 0; j < PPT; j++) {
+  for (int j = 0; j < 2 * PP; j++) {
     const int n = tid + j * FPS_THREADS;  // strided ownership: coalesced initial load
-    const bool ok = n < N;
-    px[j] = ok ? p[3 * n] : 0.f;
-    py[j] = ok ? p[3 * n + 1] : 0.f;
-    pz[j] = ok ? p[3 * n + 2] : 0.f;
-    td[j] = 1e10f;
+    const bool ok = n < N && j < PPT;
+    px[j >> 1][j & 1] = ok ? p[3 * n] : 0.f;
+    py[j >> 1][j & 1] = ok ? p[3 * n + 1] : 0.f;
+    pz[j >> 1][j & 1] = ok ? p[3 * n + 2] : 0.f;
+    td[j] = ok ? 1e10f : -1.f;  // fminf keeps -1 forever: a slot without a point can never win (distances are >= 0)
   }
   if (tid == 0) out[0] = 0;
   int last = 0;
   for (int s = 1; s < K; s++) {
     const float lx = p[3 * last], ly = p[3 * last + 1], lz = p[3 * last + 2];  // uniform -> scalar loads
-    // per-thread arg-max on plain floats (strict > keeps the lowest of this thread's indices on ties: n grows with j);
-    // the 64-bit (distance, ~index) key is built once per thread, for the cross-lane exchange only.
-    // Measured and NOT adopted (all bit-exact, none faster than this 1.9 us/step; the step is a latency chain of
-    // scalar load -> update -> wave reduction -> barrier -> 16 LDS reads, not a throughput problem): float2 packed
-    // distance math (v_pk_*), DPP instead of ds_bpermute reductions, winner coordinates through LDS instead of the
-    // dependent global load (2.6-2.9 us/step with the 16-way coordinate select it needs).
+    const f2 lx2 = {lx, lx}, ly2 = {ly, ly}, lz2 = {lz, lz};
     float bd = -1.f;
-    int bn = 0;
+    int bn = 0x7FFFFFFF;
 #pragma unroll
-    for (int j = 0; j < PPT; j++) {
-      const int n = tid + j * FPS_THREADS;
-      if (n < N) {
-        const float dx = px[j] - lx, dy = py[j] - ly, dz = pz[j] - lz;
-        const float d = dx * dx + dy * dy + dz * dz;
-        const float d2 = fminf(d, td[j]);
+    for (int jj = 0; jj < PP; jj++) {
+      const f2 dx = px[jj] - lx2, dy = py[jj] - ly2, dz = pz[jj] - lz2;
+      const f2 d = dx * dx + dy * dy + dz * dz;  // (dx*dx + dy*dy) + dz*dz without contraction: the scalar form's bits
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int j = 2 * jj + h;
+        const float d2 = fminf(d[h], td[j]);
         td[j] = d2;
-        const bool better = d2 > bd;
+        const bool better = d2 > bd;  // strict: the lowest of this thread's indices wins ties (n grows with j)
         bd = better ? d2 : bd;
-        bn = better ? n : bn;
+        bn = better ? tid + j * FPS_THREADS : bn;
       }
     }
-    // d2 >= 0 -> its bit pattern is monotone; ~n makes the lowest index win ties
-    unsigned long long best = bd >= 0.f ? (((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)(~bn)) : 0ull;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const unsigned lo = __shfl_xor((unsigned)best, o), hi = __shfl_xor((unsigned)(best >> 32), o);
-      const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-      best = other > best ? other : best;
+    const float wd = v3d_dpp_max_f32<true>(bd);
+    const int wn = v3d_dpp_min_i32<true>(bd == wd ? bn : 0x7FFFFFFF);
+    if (lane == 0) {
+      wave_d[s & 1][wave] = wd;
+      wave_n[s & 1][wave] = wn;
     }
-    if (lane == 0) wave_best[s & 1][wave] = best;
-    __syncthreads();  // double-buffered slot: one barrier per step suffices
-    unsigned long long all = wave_best[s & 1][0];
-#pragma unroll
-    for (int w = 1; w < FPS_THREADS / V3D_WAVE; w++) {
-      const unsigned long long v = wave_best[s & 1][w];
-      all = v > all ? v : all;
-    }
-    last = (int)(~(unsigned)(all & 0xFFFFFFFFu));
+    __syncthreads();  // double-buffered slots: one barrier per step suffices
+    const float sd = wave_d[s & 1][lane & 15];
+    const int sn = wave_n[s & 1][lane & 15];
+    const float ad = v3d_dpp_max_f32<false>(sd);
+    last = v3d_dpp_min_i32<false>(sd == ad ? sn : 0x7FFFFFFF);
     if (tid == 0) out[s] = last;
   }
 }
