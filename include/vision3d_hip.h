@@ -68,6 +68,20 @@ int v3d_proposals(const float* head_maps, const float* anchors, int B, int n_cls
                   int64_t* out_class_idx, float* out_scores, int32_t* n_out, void* workspace, size_t workspace_bytes,
                   v3d_stream_t stream);
 
+/* ---- A13: anchor <-> ground-truth target assignment, fused around the rotated-IoU core.
+ * Replaces ProposalTargetAssigner.forward (core/proposal_targets.py:10-88) + Matcher (ops/matcher.py:55-130) +
+ * box_encode.encode (core/box_encode.py:26-36) without materialising the (n_gt x anchors) IoU matrix.
+ * gt_boxes (n_gt,7) f32, gt_class (n_gt) i64, anchors (n_cls, A, 7) f32; iou_thresh_host (n_cls, 2) = [lo, hi] on
+ * the HOST: best IoU < lo -> label 0, [lo, hi) -> ignored, >= hi -> +1; allow_low_quality: every anchor attaining
+ * some ground truth's best IoU (ties included) is positive.  Outputs (n_cls, A): G_cls i8 in {0,1}, M_cls u8
+ * (0 = ignored), G_reg (.,7) f32 VoxelNet encoding at positives / 0, M_reg u8 = positives; matches (nullable) i64 =
+ * index of the best ground truth (first maximal).  box_ignore is not an input: the reference never applies it. */
+size_t v3d_assign_targets_workspace(int n_gt, int n_cls, int anchors_per_class);
+int v3d_assign_targets(const float* gt_boxes, const int64_t* gt_class, int n_gt, const float* anchors, int n_cls,
+                       int anchors_per_class, const float* iou_thresh_host, int allow_low_quality, int8_t* G_cls, uint8_t* M_cls,
+                       float* G_reg, uint8_t* M_reg, int64_t* matches, void* workspace, size_t workspace_bytes,
+                       v3d_stream_t stream);
+
 /* ---- A11: points in cuboids / rectangles.
  * Replaces core/geometry.py:27-65 (PointsInCuboids._get_mask when use_z != 0,
  * PointsNotInRectangles._get_mask otherwise).  points (N,C>=3) f32, boxes (n,7) f32
