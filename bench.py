@@ -308,9 +308,17 @@ def main():
         dom_bytes = float(np.mean([l["bytes"] for l in dom]))
         dom_t = float(np.mean([l["t_avg_us"] for l in dom])) * 1e-6
         achieved = dom_bytes / dom_t / 1e9
+        # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed summary of the
+        # two rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_h_pmc_traffic.txt) is
+        # attached when the workload is the one it was collected on, else null
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path) and not waymo and args.batch == 1 and args.points == 16384:
+            pmc = json.load(open(pmc_path))
+            traffic, traffic_src = pmc["spconv_fwd_rows<64,64>"]["traffic_bytes"], pmc["source"]
         roofline = dict(bound="hbm", kernel="spconv_fwd_rows<64,64>", launches_per_frame=len(dom),
                         bytes_per_launch=dom_bytes, avg_us=dom_t * 1e6, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None)
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src)
         # the other large kernel of the frame: the 3x3 RPN convolution (MFMA-bound).  Algorithmic flops = 2*M*Cout*9*Cin;
         # the kernel issues 3 bf16 MFMA terms per product (split precision), so `issued` = 3x `achieved`.
         from vision3d_amd.runtime import conv2d_split, pack_conv_weight, to_split_nhwc
