@@ -134,12 +134,15 @@ int v3d_sparse_conv_fwd(const float* in, const float* weight, const int32_t* nbr
 
 /* Split-precision variant (algo 4): weights are split into bf16 hi/lo and packed once per layer, the
  * forward runs on v_mfma_f32_16x16x32_bf16 as hi*hi + hi*lo + lo*hi with fp32 accumulation (fp32-class
- * accuracy, ~1e-5 relative); one wave owns 16 output rows with register accumulators.  Cout % 16 == 0. */
+ * accuracy, ~1e-5 relative); one wave owns 16 output rows with register accumulators.  Cout % 16 == 0.
+ */
 size_t v3d_sparse_conv_weight_image_bytes(int K, int Cin, int Cout);
 int v3d_sparse_conv_pack_weights(const float* weight, int K, int Cin, int Cout, void* image, v3d_stream_t stream);
+/* rows_hint: the caller's estimate of the LIVE row count (*n_out is device-side), used only to choose between the
+ * 16-row kernel and the 64-row LDS-shared-weights kernel (crossover ~32 k rows); <= 0 = unknown (16-row kernel). */
 int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
-                               float* out, v3d_stream_t stream);
+                               float* out, int rows_hint, v3d_stream_t stream);
 
 /* ---- T3 backward (spconv indice_conv backward; the reference trains through it at train.py:65).
  * Data gradient: dX[i] = sum_k dY[nbrT[k][i]] @ W[k]^T -- the forward entry points above on the TRANSPOSED
@@ -216,6 +219,9 @@ int v3d_backbone_forward(v3d_backbone* plan, const float* points, int n_points, 
  * layer >= 0 -> that layer's output rows.  *n_rows_dev is a device int32; cap = row capacity. */
 int v3d_backbone_layer_output(v3d_backbone* plan, int layer, float** features, int32_t** coords,
                               int32_t** n_rows_dev, int* cap, int* channels, int32_t* shape_host);
+/* Kernel-choice tuning from observed sparsity: reads the live row counts of the last forward (blocking, a few bytes)
+ * and uses them as size hints for the following forwards (capacities are upper bounds).  Not capturable. */
+int v3d_backbone_tune(v3d_backbone* plan);
 int32_t* v3d_backbone_occupancy(v3d_backbone* plan);       /* (cap0) i32, voxel occupancies of the last forward */
 int32_t* v3d_backbone_overflow_flags(v3d_backbone* plan);  /* (n_layers+1) i32 device flags, nonzero = capacity hit */
 

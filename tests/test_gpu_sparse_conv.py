@@ -77,6 +77,37 @@ def test_strided_conv_forward_ragged_tail(oracle, algo):
         assert_features_close(got, oracle.sparse_conv_fwd(feats, w, onbr, relu=True), f"strided {cin}->{cout} algo {algo}")
 
 
+@pytest.mark.parametrize("variant", [2, 4, 5], ids=["2tiles", "4tiles", "64rows_lds_weights"])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64)])
+def test_packed_kernel_variants(oracle, cin, cout, variant):
+    """The other row-tile variants of the packed (algo 4) kernel -- incl. the 64-row LDS-shared-weights kernel that is
+    selected automatically beyond ~24 k rows -- forced on a small problem: same result as the oracle, ragged tail,
+    fused affine + ReLU, submanifold and strided (3,1,1) tables."""
+    import ctypes
+    from vision3d_amd import _lib as L
+    from vision3d_amd.spconv.conv import build_sparse_rulebook, build_subm_rulebook, sparse_conv_forward
+    raw = ctypes.CDLL(L.LIB_PATH)
+    rng = np.random.default_rng(cin + cout + variant)
+    coords = kitti_coords(oracle, [5])[:5003]
+    shape = [41, 1600, 1408]
+    feats = rng.standard_normal((len(coords), cin)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32) * 0.1
+    x = make_tensor(coords, feats, shape, 1)
+    raw.v3d_debug_set_rows_mt(variant)
+    try:
+        w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(cin * 9)).astype(np.float32)
+        got = sparse_conv_forward(x.features, dev(w), build_subm_rulebook(x, [3, 3, 3]), dev(sc), dev(sh), True, 4).cpu().numpy()
+        ref = oracle.sparse_conv_fwd(feats, w, oracle.subm_rulebook(coords, shape, 3), sc, sh, True)
+        assert_features_close(got, ref, f"subm {cin}->{cout} variant {variant}")
+        w1 = (rng.standard_normal((3, 1, 1, cin, cout)) / np.sqrt(cin * 3)).astype(np.float32)
+        rb = build_sparse_rulebook(x, [3, 1, 1], [2, 1, 1], [0, 0, 0])
+        _, onbr, _ = oracle.sparse_rulebook(coords, shape, [3, 1, 1], [2, 1, 1], [0, 0, 0])
+        got = sparse_conv_forward(x.features, dev(w1), rb, None, None, False, 4).cpu().numpy()
+        assert_features_close(got, oracle.sparse_conv_fwd(feats, w1, onbr), f"strided {cin}->{cout} variant {variant}")
+    finally:
+        raw.v3d_debug_set_rows_mt(0)
+
+
 def test_tiny_and_empty_inputs(oracle):
     from vision3d_amd import spconv
     conv = spconv.SubMConv3d(4, 16, 3, indice_key="k", bias=False).cuda()

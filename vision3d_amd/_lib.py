@@ -36,7 +36,7 @@ _SIGNATURES = {
     "v3d_sparse_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "v3d_sparse_conv_weight_image_bytes": (_sz, [_i, _i, _i]),
     "v3d_sparse_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "v3d_sparse_conv_fwd_packed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "v3d_sparse_conv_fwd_packed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "v3d_debug_set_repeat": (None, [_i]),
     "v3d_debug_set_rows_mt": (None, [_i]),
     "v3d_debug_set_dense_variant": (None, [_i]),
@@ -52,6 +52,7 @@ _SIGNATURES = {
     "v3d_backbone_create": (_i, [_vp, _vp, _vp]),
     "v3d_backbone_destroy": (None, [_vp]),
     "v3d_backbone_arena_bytes": (_sz, [_vp]),
+    "v3d_backbone_tune": (_i, [_vp]),
     "v3d_backbone_num_layers": (_i, [_vp]),
     "v3d_backbone_set_layer": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "v3d_backbone_forward": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),

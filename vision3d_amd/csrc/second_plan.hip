@@ -26,6 +26,7 @@ struct PlanLayer {
   void* wimg;  // split + packed weights for the bf16x3 kernel
   int has_affine;
   int* chunk_counts;  // strided layers: published per-chunk counts -> offsets (inside the per-frame 0xFF region)
+  int rows_hint;      // expected live output rows (kernel choice): capacity-free estimate, refined by v3d_backbone_tune
 };
 
 struct PlanStage {
@@ -130,6 +131,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       L.builds_rulebook = true;
       p->nbr_cap.push_back(ns.cap);
     }
+    L.rows_hint = 0;  // unknown until tuned: the 16-row kernel (right for KITTI-size frames)
     cin = L.d.cout;
     p->layers.push_back(L);
   }
@@ -271,8 +273,9 @@ extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n
     rc = V3D_EUNSUPPORTED;
     // default (0): bf16x3 row-owner kernel where the reduction dim fills an MFMA (Cin >= 16), fp32 wave kernel else
     if (c.conv_algo == 4 || (c.conv_algo == 0 && L.d.cin >= 16))
-      rc = v3d_sparse_conv_fwd_packed(feat, L.wimg, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout,
-                                      L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr, L.d.relu, L.out, st);
+      rc = v3d_i_sparse_conv_fwd_packed(feat, L.wimg, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout,
+                                        L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr, L.d.relu, L.out,
+                                        L.rows_hint, st);
     if (rc == V3D_EUNSUPPORTED)
       rc = v3d_sparse_conv_fwd(feat, L.weight, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout,
                                L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr, L.d.relu, L.out,
@@ -317,6 +320,20 @@ extern "C" int v3d_backbone_layer_output(v3d_backbone* p, int layer, float** fea
   if (channels) *channels = L.d.cout;
   if (shape_host)
     for (int j = 0; j < 3; j++) shape_host[j] = so.shape[j];
+  return V3D_OK;
+}
+
+// Reads the live row counts of the LAST forward (one blocking 4-byte copy per stage) and stores them as the kernel-
+// choice hints of the following forwards: capacities are upper bounds (up to 30x the live count in later stages), and
+// the two sparse kernels cross over at ~32 k live rows.  Call after a representative forward, outside stream capture.
+extern "C" int v3d_backbone_tune(v3d_backbone* p) {
+  if (!p) return V3D_EINVAL;
+  std::vector<int> n_stage(p->stages.size(), 0);
+  for (size_t s = 0; s < p->stages.size(); s++) {
+    hipError_t e = hipMemcpy(&n_stage[s], p->stages[s].n_dev, sizeof(int), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+  }
+  for (auto& L : p->layers) L.rows_hint = n_stage[L.stage_out];
   return V3D_OK;
 }
 

@@ -20,7 +20,7 @@
 // Kernel `spconv_fwd_wave` (algo 3, the default) removes the per-offset barriers of algo 2: see its
 // header comment.  Kernel `spconv_fwd_scalar` (algo 1) is the simple VALU statement of the same sum, kept as the
 // on-device cross-check and for channel counts the MFMA tiling does not cover.
-#include "v3d_common.h"
+#include "v3d_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -782,6 +782,135 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_mt(const float* __r
   }
 }
 
+// Large-N variant: 64 output rows per workgroup, one 16-row tile per wave, every wave walks ALL K offsets (no
+// K-split, accumulators never leave registers) and the four waves share ONE copy of each W[k] image through LDS
+// (double buffered, fetched once per workgroup and offset).  Beyond ~30 k rows the 16-row kernel is bound by the
+// L2 -> CU weight stream (3 500 workgroups x 442 KB = 1.5 GB per launch at 56 k rows ~ the 34 TB/s of the L2s); here
+// that stream is 4x smaller and the kernel runs into the MFMA issue rate of the 4-term split instead.  Below that
+// size the 4x longer dependent chain per wave (27 instead of 7 offsets) loses: launch_rows picks by capacity.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __restrict__ in,
+                                                                 const unsigned short* __restrict__ wimg,
+                                                                 const int* __restrict__ nbr, const int* __restrict__ n_ptr,
+                                                                 int cap, int K, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, int relu,
+                                                                 float* __restrict__ out) {
+  constexpr int KI = (CIN + 31) / 32, NB = COUT / 16;
+  constexpr int NF = KI * NB * 2;          // 16-byte weight fragments per offset per lane
+  constexpr int WBYTES = NF * 64 * 16;     // one W[k] image
+  constexpr int WLOADS = WBYTES / (V3D_BLOCK * 16);  // 16-byte pieces per thread per offset
+  static_assert(WBYTES % (V3D_BLOCK * 16) == 0, "weight image must split evenly over the workgroup");
+  extern __shared__ __attribute__((aligned(16))) float smem_rows[];
+  unsigned char* wbuf = reinterpret_cast<unsigned char*>(smem_rows);      // [2][WBYTES]
+  int* nbr_s = reinterpret_cast<int*>(wbuf + 2 * WBYTES);                  // [K][64]
+  const int n = min(*n_ptr, cap);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * 64;
+  if (row0 >= n) return;
+  const int r = lane & 15, kg = lane >> 4;
+  for (int t = tid; t < K * 64; t += V3D_BLOCK) {
+    const int k = t >> 6, rr = t & 63;
+    nbr_s[t] = (row0 + rr < n) ? nbr[(size_t)k * cap + row0 + rr] : -1;
+  }
+  u32x4_t wreg[WLOADS];
+  auto load_w = [&](int k) {
+    const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(wimg) + (size_t)k * NF * 64 + tid;
+#pragma unroll
+    for (int i = 0; i < WLOADS; i++) wreg[i] = wp[(size_t)i * V3D_BLOCK];
+  };
+  auto store_w = [&](int buf) {
+    u32x4_t* dst = reinterpret_cast<u32x4_t*>(wbuf + buf * WBYTES) + tid;
+#pragma unroll
+    for (int i = 0; i < WLOADS; i++) dst[(size_t)i * V3D_BLOCK] = wreg[i];
+  };
+  float araw[2][KI][8];
+  auto load_a = [&](int k, float (&a)[KI][8]) {
+    const int src = nbr_s[k * 64 + wave * 16 + r];
+#pragma unroll
+    for (int ki = 0; ki < KI; ki++) {
+      const int c0 = ki * 32 + kg * 8;
+      if (src >= 0 && c0 < CIN) {
+        const float* p = in + (size_t)src * CIN + c0;
+        const float4 v0 = reinterpret_cast<const float4*>(p)[0], v1 = reinterpret_cast<const float4*>(p)[1];
+        a[ki][0] = v0.x; a[ki][1] = v0.y; a[ki][2] = v0.z; a[ki][3] = v0.w;
+        a[ki][4] = v1.x; a[ki][5] = v1.y; a[ki][6] = v1.z; a[ki][7] = v1.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) a[ki][e] = 0.f;
+      }
+    }
+  };
+  f32x4 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto multiply = [&](const float (&a)[KI][8], int buf) {
+    const bf16x8_t* bw = reinterpret_cast<const bf16x8_t*>(wbuf + buf * WBYTES) + lane;
+#pragma unroll
+    for (int ki = 0; ki < KI; ki++) {
+      bf16x8_t ah, am, al;
+      split8(a[ki], ah, am, al);
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        const bf16x8_t bh = bw[(size_t)((ki * NB + j) * 2) * 64], bl = bw[(size_t)((ki * NB + j) * 2 + 1) * 64];
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[j], 0, 0, 0);  // smallest terms first
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[j], 0, 0, 0);
+      }
+    }
+  };
+
+  load_w(0);
+  store_w(0);
+  __syncthreads();  // nbr_s and W[0] in place
+  load_a(0, araw[0]);
+  for (int k = 0; k < K; k += 2) {
+    if (k + 1 < K) {
+      load_w(k + 1);
+      load_a(k + 1, araw[1]);
+    }
+    multiply(araw[0], 0);
+    if (k + 1 < K) store_w(1);
+    __syncthreads();
+    if (k + 1 < K) {
+      if (k + 2 < K) {
+        load_w(k + 2);
+        load_a(k + 2, araw[0]);
+      }
+      multiply(araw[1], 1);
+      if (k + 2 < K) store_w(0);
+      __syncthreads();
+    }
+  }
+  // epilogue straight from the accumulators: D[row = kg*4 + rr][col = j*16 + r] of this wave's tile
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    const int col = j * 16 + r;
+    const float sc = scale ? scale[col] : 1.f, sh = scale ? shift[col] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int row = row0 + wave * 16 + kg * 4 + rr;
+      if (row < n) {
+        float v = acc[j][rr];
+        if (scale) v = v * sc + sh;
+        if (relu) v = fmaxf(v, 0.f);
+        out[(size_t)row * COUT + col] = v;
+      }
+    }
+  }
+}
+
+template <int CIN, int COUT>
+static void launch_rows_big(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
+                            const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
+  constexpr int NF = ((CIN + 31) / 32) * (COUT / 16) * 2;
+  const size_t lds = (size_t)2 * NF * 64 * 16 + (size_t)K * 64 * 4;
+  for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
+    hipLaunchKernelGGL((spconv_fwd_rows_big<CIN, COUT>), dim3(v3d_ceil_div(cap, 64)), dim3(V3D_BLOCK), lds, st, in,
+                       (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out);
+}
+
 int g_v3d_rows_mt = 0;  // 0 = pick from the capacity, 1 / 2 / 4 = force (microbenchmarks)
 extern "C" void v3d_debug_set_rows_mt(int mt) { g_v3d_rows_mt = mt; }
 
@@ -794,9 +923,21 @@ static void launch_rows_mt(const float* in, const void* wimg, const int* nbr, co
                        (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out);
 }
 
+// rows_hint = expected number of LIVE rows (the live count itself is device-side): the caller's best knowledge --
+// the capacity when it is exact (per-op Python path), the counts observed on earlier frames (v3d_backbone_tune).
+#define V3D_BIG_ROWS 32768
 template <int CIN, int COUT>
 static int launch_rows(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
-                       const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
+                       const float* scale, const float* shift, int relu, float* out, int rows_hint, hipStream_t st) {
+  if constexpr (CIN >= 32 && CIN <= 64 && COUT >= 32 && COUT <= 64) {
+    // 5 = the 64-row LDS-shared-weights kernel: from ~32 k live rows on the 16-row kernel is bound by the L2 -> CU
+    // weight stream (tools/mb_rows_mt.py: 64->64 at 36 k rows 54 vs 53 us, at 56 k 82 vs 66 us, at 81 k 110 vs 85 us)
+    if (g_v3d_rows_mt == 5 || (g_v3d_rows_mt == 0 && rows_hint >= V3D_BIG_ROWS)) {
+      launch_rows_big<CIN, COUT>(in, wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, st);
+      V3D_CHECK_LAUNCH();
+      return V3D_OK;
+    }
+  }
   if constexpr (CIN >= 32 && CIN <= 64 && COUT <= 64) {  // weight stream >= 27 x 4 KB per block: share it across more rows when there are enough of them
     int mt = g_v3d_rows_mt;
     if (mt == 0) mt = 1;  // measured (tools/mb_rows_mt.py, 8k..134k rows): the 16-row kernel wins everywhere -- see DESIGN.md
@@ -818,12 +959,19 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
 // Forward with PRE-PACKED split weights (v3d_sparse_conv_pack_weights): the bf16x3 row-owner kernel.
 extern "C" int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr,
                                           const int32_t* n_out, int cap_out, int K, int Cin, int Cout, const float* scale,
-                                          const float* shift, int relu, float* out, v3d_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
+                                          const float* shift, int relu, float* out, int rows_hint, v3d_stream_t stream) {
+  return v3d_i_sparse_conv_fwd_packed(in, weight_image, nbr, n_out, cap_out, K, Cin, Cout, scale, shift, relu, out, rows_hint,
+                                      (hipStream_t)stream);
+}
+
+int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
+                                 int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
+                                 float* out, int rows_hint, hipStream_t st) {
   if (!in || !weight_image || !nbr || !n_out || !out || cap_out < 1 || K < 1) return V3D_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return V3D_EINVAL;
 #define V3D_TRY(ci, co) \
-  if (Cin == ci && Cout == co) return launch_rows<ci, co>(in, weight_image, nbr, n_out, cap_out, K, scale, shift, relu, out, st);
+  if (Cin == ci && Cout == co)  \
+    return launch_rows<ci, co>(in, weight_image, nbr, n_out, cap_out, K, scale, shift, relu, out, rows_hint, st);
   V3D_TRY(4, 16)
   V3D_TRY(16, 16)
   V3D_TRY(16, 32)

@@ -16,7 +16,13 @@ class GraphedSecond(object):
         cap_pts = 1 << max(14, (self.offsets[-1] - 1).bit_length())
         self.plan = model.backbone_plan(len(self.frame_sizes), cap_pts)
         self.dense = model.dense_plan()
-        # warm-up on a side stream (uploads weights, fills allocator pools), then capture
+        self.graph = None  # captured on the first call, after a warm-up on THAT frame (see _capture)
+
+    def _capture(self):
+        """Warm-up on a side stream with the real first frame in the static buffer -- it uploads weights, fills the
+        allocator pools and lets the backbone plan pick its kernels from the observed sparsity (BackbonePlan.tune;
+        an all-zero buffer would tune for a one-voxel frame) -- then capture."""
+        dev = self.static_points.device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():
@@ -44,11 +50,15 @@ class GraphedSecond(object):
             self.static_points[a:b].copy_(c, non_blocking=True)
 
     def replay(self):
+        if self.graph is None:
+            self._capture()
         self.graph.replay()
         return self.outputs
 
     def __call__(self, clouds):
         self.load(clouds)
+        if self.graph is None:
+            self._capture()
         self.graph.replay()
         head = self.model.head
         return head.finalize_native(*self.outputs) if self.native else head.finalize(*self.outputs)

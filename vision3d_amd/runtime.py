@@ -131,7 +131,25 @@ class BackbonePlan(object):
         with torch.cuda.device(pts.device):
             L.check(L.lib().v3d_backbone_forward(self._handle, L.ptr(pts), pts.shape[0], L.host_i32(frame_offsets), b,
                                                  L.ptr(out), L.stream_ptr()), "backbone_forward")
+        if self._maybe_tune():
+            return self.forward(points, frame_offsets, out)
         return out
+
+    def tune(self):
+        """Refresh the kernel-choice size hints from the live row counts of the last forward (blocking; never during
+        stream capture).  Capacities are upper bounds -- up to 30x the live count in late stages -- and the sparse
+        kernels cross over at ~32 k live rows (csrc/spconv.hip)."""
+        torch.cuda.synchronize(self.device)
+        L.check(L.lib().v3d_backbone_tune(self._handle), "backbone_tune")
+        self._tuned = True
+
+    def _maybe_tune(self):
+        """True once, right after the first eager forward: the caller repeats that forward so that even the first
+        result it returns comes from the kernels every later frame will use (the variants differ in the last bits)."""
+        if not self.__dict__.get("_tuned") and not torch.cuda.is_current_stream_capturing():
+            self.tune()
+            return True
+        return False
 
     def forward_split(self, points, frame_offsets):
         """Same as forward() but the BEV map comes out as the dense head's input format: two bf16 NHWC
@@ -144,6 +162,8 @@ class BackbonePlan(object):
         with torch.cuda.device(pts.device):
             L.check(L.lib().v3d_backbone_forward2(self._handle, L.ptr(pts), pts.shape[0], L.host_i32(frame_offsets), b, 0,
                                                   L.ptr(hi), L.ptr(lo), L.stream_ptr()), "backbone_forward2")
+        if self._maybe_tune():  # once: kernels are now picked by the observed sparsity
+            return self.forward_split(points, frame_offsets)
         return hi, lo
 
     def layer_output(self, layer):

@@ -90,7 +90,7 @@ def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False
         with torch.cuda.device(feat.device):
             L.check(L.lib().v3d_sparse_conv_fwd_packed(L.ptr(feat), L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k,
                                                        cin, cout, L.ptr(sc), L.ptr(sh), int(bool(relu)), L.ptr(out),
-                                                       L.stream_ptr()), "sparse_conv_fwd_packed")
+                                                       int(rb.n), L.stream_ptr()), "sparse_conv_fwd_packed")
         return out
     with torch.cuda.device(feat.device):
         L.check(L.lib().v3d_sparse_conv_fwd(L.ptr(feat), L.ptr(w), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k, cin,
