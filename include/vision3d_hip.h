@@ -68,6 +68,21 @@ int v3d_proposals(const float* head_maps, const float* anchors, int B, int n_cls
                   int64_t* out_class_idx, float* out_scores, int32_t* n_out, void* workspace, size_t workspace_bytes,
                   v3d_stream_t stream);
 
+/* ---- Training-mode BatchNorm1d (+ ReLU) over sparse features (n, C), C a power of two in [4, 256].
+ * Replaces nn.BatchNorm1d(eps, momentum) + nn.ReLU on SparseConvTensor.features (detector/sparse_cnn.py:15-30) in
+ * training: forward = chunk statistics (two-pass per chunk) + Chan merge in double + fused normalise/affine/ReLU;
+ * backward = chunk sums + merge + fused input gradient.  save_mean / save_invstd (C) feed the backward; var_unbiased (C)
+ * is what the running_var update uses.  Deterministic. */
+size_t v3d_sparse_bn_workspace(int n, int C);
+int v3d_sparse_bn_relu_fwd(const float* x, int n, int C, const float* gamma, const float* beta, float eps, int relu, float* y,
+                           float* save_mean, float* save_invstd, float* var_unbiased, float* running_mean /*nullable pair:*/,
+                           float* running_var /*updated in place with `momentum`*/, float momentum,
+                           int64_t* num_batches_tracked /*nullable: += 1*/, void* workspace, size_t workspace_bytes,
+                           v3d_stream_t stream);
+int v3d_sparse_bn_relu_bwd(const float* x, const float* dy, int n, int C, const float* gamma, const float* beta,
+                           const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma, float* dbeta,
+                           void* workspace, size_t workspace_bytes, v3d_stream_t stream);
+
 /* ---- A13: anchor <-> ground-truth target assignment, fused around the rotated-IoU core.
  * Replaces ProposalTargetAssigner.forward (core/proposal_targets.py:10-88) + Matcher (ops/matcher.py:55-130) +
  * box_encode.encode (core/box_encode.py:26-36) without materialising the (n_gt x anchors) IoU matrix.

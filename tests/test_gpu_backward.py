@@ -109,3 +109,38 @@ def test_second_train_step_runs_and_is_deterministic():
     assert loss_a == loss_b
     for n in ("cnn.blocks.0.0.0.weight", "cnn.blocks.2.1.0.weight", "cnn.blocks.3.3.0.weight"):
         assert torch.equal(grads_a[n], grads_b[n]), n
+
+
+@pytest.mark.parametrize("n,c,relu", [(5000, 16, True), (70001, 64, True), (333, 32, False), (2, 64, True)])
+def test_sparse_batchnorm_relu_matches_torch(n, c, relu):
+    """csrc/sparse_bn.hip (training-mode BatchNorm1d + ReLU on sparse features) vs the torch modules: output, input /
+    weight / bias gradients and the running statistics after the step."""
+    from vision3d_amd.spconv.functional import sparse_batch_norm_relu
+    g = torch.Generator().manual_seed(n + c)
+    x0 = (torch.randn(n, c, generator=g) * 2.0 + torch.linspace(-3, 3, c)).cuda()
+    gy = torch.randn(n, c, generator=g).cuda()
+
+    def make():
+        bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+            bn.bias.copy_(torch.linspace(-0.2, 0.2, c))
+        return bn
+
+    bn_a, bn_b = make(), make()
+    xa = x0.clone().requires_grad_(True)
+    ya = sparse_batch_norm_relu(xa, bn_a, relu)
+    ya.backward(gy)
+    xb = x0.clone().requires_grad_(True)
+    yb = bn_b(xb)
+    if relu:
+        yb = torch.relu(yb)
+    yb.backward(gy)
+    tol = dict(rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(ya.detach().cpu().numpy(), yb.detach().cpu().numpy(), **tol)
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), xb.grad.cpu().numpy(), rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(bn_a.weight.grad.cpu().numpy(), bn_b.weight.grad.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(bn_a.bias.grad.cpu().numpy(), bn_b.bias.grad.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(bn_a.running_mean.cpu().numpy(), bn_b.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn_a.running_var.cpu().numpy(), bn_b.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 1

@@ -1,0 +1,267 @@
+// sparse_bn.hip -- training-mode BatchNorm1d (+ ReLU) over the (n_rows, C) feature matrix of a sparse tensor.
+//
+// Reference: nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU applied to SparseConvTensor.features by
+// spconv.SparseSequential (vision3d/detector/sparse_cnn.py:15-30).  In training torch runs it as 4-6 launches per
+// layer and direction (channels-last statistics, transform, ReLU, their backward twins; ~50 us each at 80 k rows);
+// here: forward = statistics + merge + fused normalise/affine/ReLU, backward = sums + merge + fused input gradient.
+//   statistics: each workgroup owns a contiguous row chunk, two passes over it (mean, then sum of squared deviations
+//   about THAT mean -- no E[x^2]-mean^2 cancellation; the second pass re-reads L2-resident rows); the chunk
+//   triples (count, mean, M2) are merged in double precision with Chan's formula in chunk order: deterministic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vision3d_hip.h"
+#include "v3d_common.h"
+
+#define SBN_MAX_CHUNKS 512
+#define SBN_MIN_ROWS 256  // rows per chunk at least
+
+static inline int sbn_chunks(int n) {
+  int g = (n + SBN_MIN_ROWS - 1) / SBN_MIN_ROWS;
+  return g < 1 ? 1 : (g > SBN_MAX_CHUNKS ? SBN_MAX_CHUNKS : g);
+}
+
+// thread = (row lane rl, channel c): rl = tid / C, c = tid % C; consecutive threads read consecutive channels
+__global__ __launch_bounds__(V3D_BLOCK) void sbn_stats_kernel(const float* __restrict__ x, int n, int C, int rows_per_chunk,
+                                                              float* __restrict__ part /*[G][3][C]: count, mean, M2*/) {
+  __shared__ float red[V3D_BLOCK];
+  __shared__ float mean_s[V3D_BLOCK];
+  const int tid = threadIdx.x, c = tid % C, rl = tid / C, RL = V3D_BLOCK / C;
+  const int r0 = blockIdx.x * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+  const int cnt = max(0, r1 - r0);
+  float s = 0.f;
+  for (int r = r0 + rl; r < r1; r += RL) s += x[(size_t)r * C + c];
+  red[tid] = s;
+  __syncthreads();
+  if (tid < C) {
+    float t = 0.f;
+    for (int q = 0; q < RL; q++) t += red[q * C + tid];
+    mean_s[tid] = cnt ? t / (float)cnt : 0.f;
+  }
+  __syncthreads();
+  const float m = mean_s[c];
+  float m2 = 0.f;
+  for (int r = r0 + rl; r < r1; r += RL) {
+    const float d = x[(size_t)r * C + c] - m;
+    m2 += d * d;
+  }
+  red[tid] = m2;
+  __syncthreads();
+  if (tid < C) {
+    float t = 0.f;
+    for (int q = 0; q < RL; q++) t += red[q * C + tid];
+    float* p = part + (size_t)blockIdx.x * 3 * C;
+    p[tid] = (float)cnt;
+    p[C + tid] = mean_s[tid];
+    p[2 * C + tid] = t;
+  }
+}
+
+// merge of the chunk triples by ONE 256-thread workgroup, thread = (group q, channel c), in double precision:
+//   mean = sum_b n_b * mean_b / n ;  M2 = sum_b [ M2_b + n_b * (mean_b - mean)^2 ]        (exact regrouping of the
+// deviations about the global mean).  Two sweeps over the partials with independent loads and no division inside the
+// loops (a serial Chan update over 512 chunks took 166 us, a grouped one 34 us: dependent loads + fp64 divisions).
+__global__ __launch_bounds__(V3D_BLOCK) void sbn_merge_kernel(const float* __restrict__ part, int G, int C, int n, float eps,
+                                                              float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                              float* __restrict__ var_unbiased, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, float momentum,
+                                                              long long* __restrict__ num_batches_tracked) {
+  __shared__ double s_a[V3D_BLOCK];
+  __shared__ double s_mean[V3D_BLOCK];
+  const int tid = threadIdx.x, c = tid % C, q = tid / C, Q = V3D_BLOCK / C;
+  double a = 0.0;
+#pragma unroll 8
+  for (int g = q; g < G; g += Q) {  // independent loads: keep 8 in flight
+    const float* p = part + (size_t)g * 3 * C;
+    a += (double)p[c] * (double)p[C + c];
+  }
+  s_a[tid] = a;
+  __syncthreads();
+  if (tid < C) {
+    double t = 0.0;
+    for (int j = 0; j < Q; j++) t += s_a[j * C + tid];
+    s_mean[tid] = n > 0 ? t / (double)n : 0.0;
+  }
+  __syncthreads();
+  const double mean = s_mean[c];
+  a = 0.0;
+#pragma unroll 8
+  for (int g = q; g < G; g += Q) {
+    const float* p = part + (size_t)g * 3 * C;
+    const double d = (double)p[C + c] - mean;
+    a += (double)p[2 * C + c] + (double)p[c] * d * d;
+  }
+  __syncthreads();
+  s_a[tid] = a;
+  __syncthreads();
+  if (tid < C) {
+    double m2 = 0.0;
+    for (int j = 0; j < Q; j++) m2 += s_a[j * C + tid];
+    const float var_b = n > 0 ? (float)(m2 / (double)n) : 0.f;
+    save_mean[tid] = (float)mean;
+    save_invstd[tid] = 1.f / sqrtf(var_b + eps);
+    const float var_u = n > 1 ? (float)(m2 / (double)(n - 1)) : var_b;
+    var_unbiased[tid] = var_u;
+    if (running_mean) {  // nn.BatchNorm1d's update: r = (1 - momentum) * r + momentum * batch statistic
+      running_mean[tid] = (1.f - momentum) * running_mean[tid] + momentum * (float)mean;
+      running_var[tid] = (1.f - momentum) * running_var[tid] + momentum * var_u;
+    }
+    if (tid == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  }
+}
+
+// elementwise passes: C is a power of two >= 4 here (host-checked), a thread handles 4 consecutive channels of one row
+__global__ __launch_bounds__(V3D_BLOCK) void sbn_apply_kernel(const float* __restrict__ x, long long total4, int C,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int relu, float* __restrict__ y) {
+  const int cmask = C - 1;
+  for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total4; t += (long long)gridDim.x * V3D_BLOCK) {
+    const int c = (int)((t << 2) & cmask);
+    const float4 xv = reinterpret_cast<const float4*>(x)[t];
+    const float4 m = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c), bt = *reinterpret_cast<const float4*>(beta + c);
+    float4 v;
+    v.x = (xv.x - m.x) * is.x * g.x + bt.x;
+    v.y = (xv.y - m.y) * is.y * g.y + bt.y;
+    v.z = (xv.z - m.z) * is.z * g.z + bt.z;
+    v.w = (xv.w - m.w) * is.w * g.w + bt.w;
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    reinterpret_cast<float4*>(y)[t] = v;
+  }
+}
+
+// backward sums per chunk: sum(dz) and sum(dz * xhat), dz = dy masked by the ReLU (y > 0)
+__global__ __launch_bounds__(V3D_BLOCK) void sbn_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy, int n,
+                                                                 int C, int rows_per_chunk, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int relu,
+                                                                 float* __restrict__ part /*[G][2][C]*/) {
+  __shared__ float red0[V3D_BLOCK], red1[V3D_BLOCK];
+  const int tid = threadIdx.x, c = tid % C, rl = tid / C, RL = V3D_BLOCK / C;
+  const int r0 = blockIdx.x * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+  const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+  for (int r = r0 + rl; r < r1; r += RL) {
+    const size_t i = (size_t)r * C + c;
+    const float xhat = (x[i] - m) * is;
+    // the ReLU mask is recomputed from x exactly as the forward computed y (one array less to read)
+    const float dz = (relu && !(xhat * ga + be > 0.f)) ? 0.f : dy[i];
+    s0 += dz;
+    s1 += dz * xhat;
+  }
+  red0[tid] = s0;
+  red1[tid] = s1;
+  __syncthreads();
+  if (tid < C) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int q = 0; q < RL; q++) {
+      t0 += red0[q * C + tid];
+      t1 += red1[q * C + tid];
+    }
+    part[(size_t)blockIdx.x * 2 * C + tid] = t0;
+    part[(size_t)blockIdx.x * 2 * C + C + tid] = t1;
+  }
+}
+
+__global__ __launch_bounds__(V3D_BLOCK) void sbn_bwd_merge_kernel(const float* __restrict__ part, int G, int C,
+                                                                  float* __restrict__ dbeta, float* __restrict__ dgamma) {
+  __shared__ double s_a[V3D_BLOCK], s_b[V3D_BLOCK];
+  const int tid = threadIdx.x, c = tid % C, q = tid / C, Q = V3D_BLOCK / C;
+  double a = 0.0, b = 0.0;
+#pragma unroll 8
+  for (int g = q; g < G; g += Q) {
+    a += part[(size_t)g * 2 * C + c];
+    b += part[(size_t)g * 2 * C + C + c];
+  }
+  s_a[tid] = a;
+  s_b[tid] = b;
+  __syncthreads();
+  if (tid < C) {
+    a = 0.0; b = 0.0;
+    for (int j = 0; j < Q; j++) {
+      a += s_a[j * C + tid];
+      b += s_b[j * C + tid];
+    }
+    dbeta[tid] = (float)a;
+    dgamma[tid] = (float)b;
+  }
+}
+
+__global__ __launch_bounds__(V3D_BLOCK) void sbn_bwd_apply_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ dy, long long total4, int C, int n,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const float* __restrict__ dbeta,
+                                                                  const float* __restrict__ dgamma, int relu,
+                                                                  float* __restrict__ dx) {
+  const float inv_n = 1.f / (float)n;
+  const int cmask = C - 1;
+  for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total4; t += (long long)gridDim.x * V3D_BLOCK) {
+    const int c = (int)((t << 2) & cmask);
+    const float4 xv = reinterpret_cast<const float4*>(x)[t];
+    const float4 gv = reinterpret_cast<const float4*>(dy)[t];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float is = invstd[c + e];
+      const float xhat = (xs[e] - mean[c + e]) * is;
+      const float dz = (relu && !(xhat * gamma[c + e] + beta[c + e] > 0.f)) ? 0.f : gs[e];
+      o[e] = gamma[c + e] * is * (dz - dbeta[c + e] * inv_n - xhat * dgamma[c + e] * inv_n);
+    }
+    reinterpret_cast<float4*>(dx)[t] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+extern "C" size_t v3d_sparse_bn_workspace(int n, int C) {
+  (void)n;
+  return (size_t)SBN_MAX_CHUNKS * 3 * (size_t)(C > 0 ? C : 1) * sizeof(float) + 256;
+}
+
+static bool sbn_shape_ok(int n, int C) { return n >= 1 && C >= 4 && C <= V3D_BLOCK && (C & (C - 1)) == 0; }  // power of two
+
+extern "C" int v3d_sparse_bn_relu_fwd(const float* x, int n, int C, const float* gamma, const float* beta, float eps, int relu,
+                                      float* y, float* save_mean, float* save_invstd, float* var_unbiased, float* running_mean,
+                                      float* running_var, float momentum, int64_t* num_batches_tracked, void* workspace,
+                                      size_t workspace_bytes, v3d_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !var_unbiased || !workspace) return V3D_EINVAL;
+  if (!sbn_shape_ok(n, C)) return V3D_EUNSUPPORTED;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return V3D_EINVAL;
+  if (workspace_bytes < v3d_sparse_bn_workspace(n, C)) return V3D_EWORKSPACE;
+  const int G = sbn_chunks(n), rows_per_chunk = (n + G - 1) / G;
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL(sbn_stats_kernel, dim3(G), dim3(V3D_BLOCK), 0, st, x, n, C, rows_per_chunk, part);
+  hipLaunchKernelGGL(sbn_merge_kernel, dim3(1), dim3(V3D_BLOCK), 0, st, part, G, C, n, eps, save_mean, save_invstd,
+                     var_unbiased, running_mean, running_var, momentum, (long long*)num_batches_tracked);
+  const long long total = (long long)n * C / 4;
+  const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
+  hipLaunchKernelGGL(sbn_apply_kernel, dim3(blocks > 8192 ? 8192 : blocks), dim3(V3D_BLOCK), 0, st, x, total, C, save_mean,
+                     save_invstd, gamma, beta, relu, y);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+extern "C" int v3d_sparse_bn_relu_bwd(const float* x, const float* dy, int n, int C, const float* gamma, const float* beta,
+                                      const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
+                                      float* dbeta, void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace) return V3D_EINVAL;
+  if (!sbn_shape_ok(n, C)) return V3D_EUNSUPPORTED;
+  if (workspace_bytes < v3d_sparse_bn_workspace(n, C)) return V3D_EWORKSPACE;
+  const int G = sbn_chunks(n), rows_per_chunk = (n + G - 1) / G;
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL(sbn_bwd_sums_kernel, dim3(G), dim3(V3D_BLOCK), 0, st, x, dy, n, C, rows_per_chunk, save_mean, save_invstd,
+                     gamma, beta, relu, part);
+  hipLaunchKernelGGL(sbn_bwd_merge_kernel, dim3(1), dim3(V3D_BLOCK), 0, st, part, G, C, dbeta, dgamma);
+  const long long total = (long long)n * C / 4;
+  const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
+  hipLaunchKernelGGL(sbn_bwd_apply_kernel, dim3(blocks > 8192 ? 8192 : blocks), dim3(V3D_BLOCK), 0, st, x, dy, total, C, n,
+                     save_mean, save_invstd, gamma, beta, dbeta, dgamma, relu, dx);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}

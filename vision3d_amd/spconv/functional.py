@@ -73,3 +73,74 @@ class SparseConvFunction(torch.autograd.Function):
 
 def sparse_conv_autograd(features, weight, rb, subm, algo=0):
     return SparseConvFunction.apply(features, weight, rb, subm, algo)
+
+
+_SBN_WS = {}
+
+
+def _sbn_workspace(dev):
+    """One scratch buffer per device, sized for the largest supported C (512 chunks x 3 x 256 floats): the ops run in
+    stream order, so consecutive layers can share it; no allocator traffic per call."""
+    ws = _SBN_WS.get(dev)
+    if ws is None:
+        ws = _SBN_WS[dev] = L.workspace(L.lib().v3d_sparse_bn_workspace(1, 256), dev)
+    return ws
+
+
+class SparseBatchNormReLUFunction(torch.autograd.Function):
+    """Training-mode BatchNorm1d (+ ReLU) on sparse features through csrc/sparse_bn.hip (3 launches each way, the
+    running statistics are updated by the merge kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, relu, running_mean, running_var, momentum, num_batches_tracked):
+        lib = L.lib()
+        xf = x if (x.dtype == torch.float32 and x.is_contiguous()) else L.as_f32("sparse_bn", x)
+        n, c = xf.shape
+        dev = xf.device
+        y = torch.empty_like(xf)
+        stats = torch.empty((3, c), dtype=torch.float32, device=dev)  # save_mean | save_invstd | unbiased variance
+        ws = _sbn_workspace(dev)
+        with torch.cuda.device(dev):
+            L.check(lib.v3d_sparse_bn_relu_fwd(xf.data_ptr(), n, c, weight.data_ptr(), bias.data_ptr(), float(eps), int(bool(relu)),
+                                               y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+                                               L.ptr(running_mean), L.ptr(running_var), float(momentum),
+                                               L.ptr(num_batches_tracked), ws.data_ptr(), ws.numel(), L.stream_ptr()),
+                    "sparse_bn_relu_fwd")
+        ctx.save_for_backward(xf, weight, bias, stats)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        x, weight, bias, stats = ctx.saved_tensors
+        n, c = x.shape
+        dev = x.device
+        g = dy if (dy.dtype == torch.float32 and dy.is_contiguous()) else L.as_f32("sparse_bn", dy)
+        dx = torch.empty_like(x)
+        dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
+        ws = _sbn_workspace(dev)
+        with torch.cuda.device(dev):
+            L.check(lib.v3d_sparse_bn_relu_bwd(x.data_ptr(), g.data_ptr(), n, c, weight.data_ptr(), bias.data_ptr(),
+                                               stats[0].data_ptr(), stats[1].data_ptr(), int(ctx.relu), dx.data_ptr(),
+                                               dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(), ws.numel(), L.stream_ptr()),
+                    "sparse_bn_relu_bwd")
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None
+
+
+def sparse_batch_norm_relu(features, bn, relu):
+    """nn.BatchNorm1d in TRAINING mode (+ optional ReLU) on (n, C) features; the running statistics are updated exactly
+    as the module would (momentum, unbiased variance, num_batches_tracked) -- inside the merge kernel."""
+    track = bn.track_running_stats and bn.running_mean is not None
+    if track and bn.momentum is None:  # cumulative moving average: 1 / (batches seen, including this one)
+        momentum = 1.0 / float(int(bn.num_batches_tracked) + 1)
+    else:
+        momentum = bn.momentum if bn.momentum is not None else 0.0
+    return SparseBatchNormReLUFunction.apply(features, bn.weight, bn.bias, bn.eps, relu,
+                                             bn.running_mean if track else None, bn.running_var if track else None, momentum,
+                                             bn.num_batches_tracked if track else None)
+
+
+def sparse_bn_supported(features, bn):
+    n, c = features.shape
+    return features.is_cuda and n > 1 and 4 <= c <= 256 and (c & (c - 1)) == 0 and features.dtype == torch.float32 and bn.affine

@@ -21,6 +21,12 @@ def fold_batchnorm(bn):
     return scale.contiguous(), shift.contiguous()
 
 
+import os
+
+# training-mode BatchNorm1d + ReLU on sparse features: csrc/sparse_bn.hip ("fused") or the torch modules ("torch")
+FUSED_TRAINING_BN = os.environ.get("V3D_SPARSE_BN", "fused") == "fused"
+
+
 class SparseSequential(nn.Sequential):
 
     def _folded(self, bn):
@@ -48,6 +54,17 @@ class SparseSequential(nn.Sequential):
                     relu = isinstance(nxt2, nn.ReLU)
                     x = m(x, scale, shift, relu)
                     i += 3 if relu else 2
+                    continue
+                if (FUSED_TRAINING_BN and isinstance(nxt, nn.BatchNorm1d) and nxt.training and torch.is_grad_enabled()):
+                    # training: conv (autograd through the HIP kernels) + fused batch-statistics BN (+ ReLU)
+                    from .functional import sparse_batch_norm_relu, sparse_bn_supported
+                    x = m(x)
+                    if x.features.shape[0] > 0 and sparse_bn_supported(x.features, nxt):
+                        relu = isinstance(nxt2, nn.ReLU)
+                        x = x.replace_feature(sparse_batch_norm_relu(x.features, nxt, relu))
+                        i += 3 if relu else 2
+                        continue
+                    i += 1
                     continue
                 x = m(x)
             elif isinstance(m, SparseSequential):
