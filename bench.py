@@ -5,7 +5,10 @@
 
 One step = one pass of the hot path over one batch (bs=1/GPU, configs[1]): device voxelizer + VFE ->
 14-layer sparse 3-D conv backbone -> .dense() BEV -> dense RPN (MFMA) -> proposal stage (top-k, decode, rotated
-NMS, score cut), all hand-written HIP, replayed as one HIP graph (~55 kernels) with a single 4-byte host read.  The cloud is resident in HBM before the timed region.  Frames are independent, so N GPUs run N
+NMS, score cut), all hand-written HIP, replayed as one HIP graph (~55 kernels) with a single 4-byte host read.  By default two frames are in flight per
+GPU (two graphs on two streams: the launch-latency-bound sparse half of one frame overlaps the MFMA-bound dense
+half of the other); every step submits one frame and the timed region completes exactly K of them.  The same
+graph run one frame at a time is reported as single_frame_ms / frames_per_s_one_at_a_time.  The cloud is resident in HBM before the timed region.  Frames are independent, so N GPUs run N
 replicas on different frames with no data-path collective (weak scaling); the only communication is the
 timing barrier / max-reduce.  Rank 0 prints ONE JSON line.
 
@@ -49,6 +52,11 @@ def parse():
                          "all-reduce over RCCL) -- a secondary line, same JSON contract")
     ap.add_argument("--no-channels-last", action="store_true", help="train mode: keep the dense RPN/head in NCHW")
     ap.add_argument("--no-amp", action="store_true", help="train mode: keep the dense RPN/head in fp32 (default bf16 autocast)")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="frames in flight per GPU (graph path).  2 (default): throughput mode -- two independent bs=1 frames "
+                         "overlap on two streams / HIP graphs / plan arenas, every step still submits ONE frame and the "
+                         "timed region completes exactly K frames; 1: one frame at a time (reported beside it as "
+                         "single_frame_ms / frames_per_s_one_at_a_time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch event timing pass (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=3)
@@ -234,12 +242,19 @@ def main():
     graphed = None
     if args.path == "graph":
         with torch.no_grad():
-            graphed = model.graphed_inference(anchors, [c.shape[0] for c in clouds])
+            if args.pipeline > 1:
+                graphed = model.pipelined_inference(anchors, [c.shape[0] for c in clouds], args.pipeline)
+            else:
+                graphed = model.graphed_inference(anchors, [c.shape[0] for c in clouds])
+    last_out = [None]
 
     def step():
         with torch.no_grad():
             if graphed is not None:
-                return graphed(clouds)
+                r = graphed(clouds)  # pipelined: the oldest finished frame (None while the pipeline fills)
+                if r is not None:
+                    last_out[0] = r
+                return r
             if args.path == "native":
                 return model.inference_points(clouds, anchors, dense="mfma")
             if args.path == "fused":
@@ -255,15 +270,34 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
+    if args.pipeline > 1 and args.path == "graph":
+        graphed.flush()  # the timed region starts with an empty pipeline
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    if args.pipeline > 1 and args.path == "graph":
+        # K steps submitted K frames; the ones still in flight are collected inside the timed region: steps == frames
+        rest = graphed.flush()
+        out = rest[-1] if rest else last_out[0]
     fence()
     elapsed = time.perf_counter() - t0
     elapsed = dist_util.max_over_ranks(elapsed, world, device="cuda")
     frames = world * args.steps * args.batch
     value = frames / elapsed
+    # one frame at a time through the same captured graph (latency view of the same work), not part of `value`
+    single_ms = None
+    if args.path == "graph":
+        g1 = graphed.slots[0] if args.pipeline > 1 else graphed
+        with torch.no_grad():
+            for _ in range(5):
+                g1(clouds)
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            for _ in range(50):
+                g1(clouds)
+            torch.cuda.synchronize()
+            single_ms = 1e3 * (time.perf_counter() - s0) / 50
 
     # ---- per-kernel timing of the sparse backbone with HIP events on the launch stream (rank 0)
     roofline, stages, roofline_dense = None, None, None
@@ -374,10 +408,13 @@ def main():
                     scaling="weak", vs_baseline=None, dtype="bf16x3 (fp32 operands split hi+lo, 3 bf16 MFMAs, fp32 accumulate: fp32-class, parity 1e-4)", data="synthetic",
                     config=dict(workload=wl,
                                 frames_per_gpu_per_step=args.batch, points_per_frame=args.points,
-                                parallelism=f"frame-parallel replicas x{world}",
-                                path={"graph": "native backbone plan + bf16x3 MFMA dense head, one HIP graph per frame",
+                                parallelism=f"frame-parallel replicas x{world}", pipeline_depth=args.pipeline,
+                                path={"graph": "native backbone plan + bf16x3 MFMA dense head + device proposal stage, one HIP graph per "
+                                               "frame" + (f", {args.pipeline} frames in flight" if args.pipeline > 1 else ""),
                                       "native": "native backbone plan + bf16x3 MFMA dense head", "fused": "native backbone plan + torch RPN",
                                       "eager": "eager python -> C ABI"}[args.path]),
+                    single_frame_ms=single_ms,
+                    frames_per_s_one_at_a_time=(world * args.batch * 1e3 / single_ms) if single_ms else None,
                     roofline=roofline, cpu_baseline=cpu_baseline, roofline_dense=roofline_dense, stages=stages,
                     n_proposals=int(out[0].shape[0]))
         print(json.dumps(line))

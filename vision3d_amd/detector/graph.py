@@ -4,7 +4,7 @@ import torch
 
 class GraphedSecond(object):
 
-    def __init__(self, model, anchors, frame_sizes):
+    def __init__(self, model, anchors, frame_sizes, slot=0):
         self.model, self.anchors = model, anchors
         self.frame_sizes = [int(n) for n in frame_sizes]
         self.offsets = [0]
@@ -14,7 +14,7 @@ class GraphedSecond(object):
         c_in = model.cfg.C_IN
         self.static_points = torch.zeros((self.offsets[-1], c_in), dtype=torch.float32, device=dev)
         cap_pts = 1 << max(14, (self.offsets[-1] - 1).bit_length())
-        self.plan = model.backbone_plan(len(self.frame_sizes), cap_pts)
+        self.plan = model.backbone_plan(len(self.frame_sizes), cap_pts, slot)
         self.dense = model.dense_plan()
         self.graph = None  # captured on the first call, after a warm-up on THAT frame (see _capture)
 
@@ -62,3 +62,56 @@ class GraphedSecond(object):
         self.graph.replay()
         head = self.model.head
         return head.finalize_native(*self.outputs) if self.native else head.finalize(*self.outputs)
+
+
+class PipelinedSecond(object):
+    """Throughput mode for independent frames: `depth` GraphedSecond instances (own plan arena, own static buffers, own
+    HIP graph) on `depth` streams.  The sparse half of a frame is a chain of small launches that fills a fraction of
+    the chip; with two frames in flight it overlaps the other frame's dense head.  Latency per frame is unchanged;
+    results come back in submission order.
+
+        run.submit(clouds)        # copy + graph launch on the next slot's stream, returns immediately
+        run.collect()             # oldest frame in flight: waits for ITS stream only, -> (boxes, batch, class, scores)
+    """
+
+    def __init__(self, model, anchors, frame_sizes, depth=2):
+        dev = next(model.parameters()).device
+        self.slots = [GraphedSecond(model, anchors, frame_sizes, slot=i) for i in range(depth)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        self.pending = []  # slot indices in submission order
+        self.next_slot = 0
+
+    def submit(self, clouds):
+        i = self.next_slot
+        assert i not in self.pending, "collect() the oldest frame before reusing its slot"
+        g, st = self.slots[i], self.streams[i]
+        st.wait_stream(torch.cuda.current_stream())  # the caller's cloud tensors are ready
+        with torch.cuda.stream(st), torch.no_grad():
+            g.load(clouds)
+            if g.graph is None:
+                g._capture()
+            g.graph.replay()
+        self.pending.append(i)
+        self.next_slot = (i + 1) % len(self.slots)
+
+    def collect(self):
+        i = self.pending.pop(0)
+        g = self.slots[i]
+        with torch.cuda.stream(self.streams[i]):
+            out = g.model.head.finalize_native(*g.outputs) if g.native else g.model.head.finalize(*g.outputs)
+        return [t.clone() for t in out]  # the slot's static buffers are overwritten by its next frame
+
+    def __call__(self, clouds):
+        """submit this frame, return the oldest finished one once the pipeline is full (None while it fills)."""
+        if len(self.pending) == len(self.slots):
+            out = self.collect()
+            self.submit(clouds)
+            return out
+        self.submit(clouds)
+        return None
+
+    def flush(self):
+        outs = []
+        while self.pending:
+            outs.append(self.collect())
+        return outs

@@ -119,11 +119,13 @@ class Second(nn.Module):
         return self.head.inference(self.feature_extract(item), item["anchors"])
 
     # ---- fused path: raw device points in, proposals out (voxelizer + sparse backbone in one native call)
-    def backbone_plan(self, max_batch, max_points):
+    def backbone_plan(self, max_batch, max_points, slot=0):
+        """Plans own their arena (hash tables, rulebooks, per-layer outputs): frames in flight at the same time need
+        one plan each -- `slot` keys them."""
         from ..runtime import BackbonePlan
         plans = self.__dict__.setdefault("_plans", {})
         dev = next(self.parameters()).device
-        key = (str(dev), int(max_batch), int(max_points))
+        key = (str(dev), int(max_batch), int(max_points)) + ((int(slot),) if slot else ())
         if key not in plans:
             plans[key] = BackbonePlan(self.cnn, self.cfg, max_batch=max_batch, max_points=max_points, device=dev)
         return plans[key]
@@ -170,6 +172,12 @@ class Second(nn.Module):
         variable-length selection.  Re-capture (call again) when the geometry changes."""
         from .graph import GraphedSecond
         return GraphedSecond(self, anchors, frame_sizes)
+
+    def pipelined_inference(self, anchors, frame_sizes, depth=2):
+        """Throughput mode: `depth` captured graphs on `depth` streams, frame i+1 is submitted before frame i's result
+        is collected (see detector/graph.py:PipelinedSecond).  `run.submit(clouds)`, `run.collect()`."""
+        from .graph import PipelinedSecond
+        return PipelinedSecond(self, anchors, frame_sizes, depth)
 
     def inference_points(self, clouds, anchors, dense="mfma", proposals="native"):
         """Same result as `inference(Preprocessor(cfg)(...))` without materialising the intermediate dict.
