@@ -21,6 +21,8 @@ class Middle(SpMiddleFHD):
 
     def forward(self, features, coordinates, batch_size):
         x = spconv.SparseConvTensor(features, coordinates.int(), self.grid_shape, batch_size)
+        if self.training and torch.is_grad_enabled():
+            spconv.prebuild_rulebooks(self.blocks, x)  # every host read of the step happens here, before any conv is enqueued
         return self.to_bev(self.blocks(x))
 
 

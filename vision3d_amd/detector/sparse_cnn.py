@@ -100,6 +100,8 @@ class SparseCNNBase(nn.Module):
 
     def forward(self, features, coordinates, batch_size):
         x0 = spconv.SparseConvTensor(features, coordinates.int(), self.grid_shape, batch_size)
+        if self.training and torch.is_grad_enabled():
+            spconv.prebuild_rulebooks(self.blocks, x0)  # all host reads of the step happen here, before any conv
         x1 = self.blocks[0](x0)
         x2 = self.blocks[1](x1)
         x3 = self.blocks[2](x2)

@@ -11,6 +11,6 @@ follows the published spconv-1.x semantics restated in oracle/v3d_oracle.c ("par
 from . import utils
 from .tensor import SparseConvTensor
 from .conv import SparseConv3d, SubMConv3d
-from .modules import SparseSequential
+from .modules import SparseSequential, prebuild_rulebooks
 
 __all__ = ["utils", "SparseConvTensor", "SparseConv3d", "SubMConv3d", "SparseSequential"]

@@ -148,6 +148,9 @@ class _SparseConvBase(nn.Module):
         return cache[1]
 
     def rulebook(self, x):
+        rb = x.indice_dict.get(("prebuilt", id(self)))  # training pre-pass (modules.prebuild_rulebooks)
+        if rb is not None:
+            return rb
         rb = x.find_indice_pair(self.indice_key)
         if rb is None:
             if self.subm:

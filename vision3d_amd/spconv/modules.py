@@ -27,6 +27,36 @@ import os
 FUSED_TRAINING_BN = os.environ.get("V3D_SPARSE_BN", "fused") == "fused"
 
 
+import os
+
+
+def prebuild_rulebooks(root, x):
+    """Coordinate-only pre-pass for training: build every rulebook of the module tree `root` for the sparse tensor `x`
+    BEFORE any convolution is enqueued, and hand them to the layers through `x.indice_dict` (keyed by module id).
+
+    Rulebooks depend on coordinates only, but a strided rulebook ends with one host read of its output count.  Built
+    lazily inside the layers, each of those reads waits for all the convolution / BatchNorm work enqueued before it and
+    the host then has to refill the queue: with five reads per step the train step was host-bound (13.4 ms of GPU work
+    in 17 ms).  In the pre-pass the reads only wait for the short rulebook kernels; afterwards the whole forward is
+    enqueued without a single synchronisation."""
+    from .conv import _SparseConvBase
+    if os.environ.get("V3D_PREBUILD_RULEBOOKS", "1") == "0":  # A/B switch (bench notes in DESIGN.md)
+        return x
+    cur = x
+    for m in root.modules():  # registration order == execution order for (nested) Sequential trees
+        if not isinstance(m, _SparseConvBase):
+            continue
+        rb = m.rulebook(cur)
+        x.indice_dict[("prebuilt", id(m))] = rb
+        if not m.subm:  # the next layers see the output sites; only coordinates matter here
+            nxt = SparseConvTensor.__new__(SparseConvTensor)
+            nxt.__dict__.update(dict(features=rb.out_indices.new_empty((rb.n, 0), dtype=torch.float32), indices=rb.out_indices,
+                                     spatial_shape=list(rb.out_shape), batch_size=x.batch_size, indice_dict=x.indice_dict,
+                                     _n_dev=rb.n_dev))
+            cur = nxt
+    return x
+
+
 class SparseSequential(nn.Sequential):
 
     def _folded(self, bn):
