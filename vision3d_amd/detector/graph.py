@@ -31,7 +31,9 @@ class GraphedSecond(object):
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        # thread_local: API calls of other host threads (e.g. the RCCL watchdog of a multi-GPU job polling its events)
+        # must not invalidate this capture
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.outputs = self._body()
 
     def _body(self):
