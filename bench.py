@@ -342,6 +342,19 @@ def main():
         dom_bytes = float(np.mean([l["bytes"] for l in dom]))
         dom_t = float(np.mean([l["t_avg_us"] for l in dom])) * 1e-6
         achieved = dom_bytes / dom_t / 1e9
+        # measured copy roofline of THIS box ("vendor peaks measured, not assumed"): 512 MiB device copy
+        src = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()
+        dst = torch.empty_like(src)
+        for _ in range(2):
+            dst.copy_(src)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src, dst
         # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed summary of the
         # two rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_h_pmc_traffic.txt) is
         # attached when the workload is the one it was collected on, else null
@@ -352,7 +365,8 @@ def main():
             traffic, traffic_src = pmc["spconv_fwd_rows<64,64>"]["traffic_bytes"], pmc["source"]
         roofline = dict(bound="hbm", kernel="spconv_fwd_rows<64,64>", launches_per_frame=len(dom),
                         bytes_per_launch=dom_bytes, avg_us=dom_t * 1e6, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src)
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                        peak_measured_copy=copy_gbs, frac_of_measured=achieved / copy_gbs)
         # the other large kernel of the frame: the 3x3 RPN convolution (MFMA-bound).  Algorithmic flops = 2*M*Cout*9*Cin;
         # the kernel issues 3 bf16 MFMA terms per product (split precision), so `issued` = 3x `achieved`.
         from vision3d_amd.runtime import conv2d_split, pack_conv_weight, to_split_nhwc
