@@ -1,63 +1,81 @@
-"""Small dense layers of the detector (interface of vision3d/detector/layers.py:7-73)."""
+"""Small dense building blocks of the detector.  Same classes, constructor arguments and state_dict keys as
+vision3d/detector/layers.py:7-73 (VoxelFeatureExtractor, BEVFeatureGatherer, MLP)."""
+from collections import OrderedDict
+
 import torch
+import torch.nn.functional as F
 from torch import nn
-from torch.nn import functional as F
 
 
 class VoxelFeatureExtractor(nn.Module):
-    """Mean of the occupied point slots of each voxel: (N, K, C), (N,) -> (N, C) (layers.py:10-17).
-    The device voxelizer already produces this mean (`item['voxel_mean']`); this module is the drop-in
-    form for callers that hold `features`/`occupancy`."""
+    """(M, K, C) zero-padded point slots + (M,) occupancy -> (M, C) mean over the occupied slots.
+
+    The device voxelizer emits this mean directly (`item['voxel_mean']`); the module exists for callers that hold
+    the reference's `features` / `occupancy` pair."""
 
     def forward(self, feature, occupancy):
-        return (feature.sum(1) / occupancy.to(feature.dtype).view(-1, 1)).contiguous()
+        count = occupancy.reshape(-1, 1).to(dtype=feature.dtype)
+        return torch.div(feature.sum(dim=1), count).contiguous()
 
 
 class BEVFeatureGatherer(nn.Module):
-    """Bilinear BEV feature lookup at keypoints (layers.py:20-50).  The index normalisation reproduces the
-    reference verbatim, including its (dims - 1) divisor on already-decremented dims and the H/W swap
-    (SURVEY.md H13)."""
+    """Bilinear lookup of BEV features at keypoint (x, y) positions.
+
+    grid_sample wants coordinates in [-1, 1]; the reference's conversion (layers.py:29-44) clamps the fractional
+    pixel index to [0, dim - 1] and then divides by (dim - 1) - 1, with W and H taken from the
+    swapped axes of the spconv layout.  `_to_grid` reproduces exactly that arithmetic."""
 
     def __init__(self, cfg, voxel_offset, base_voxel_size):
         super().__init__()
         self.cfg = cfg
-        # own buffers (not views of the CNN's): they must follow .cuda()/.to() with the module
+        # buffers of its own (the reference aliases the CNN's tensors, which then miss .cuda()/.to())
         self.register_buffer("pixel_offset", voxel_offset[:2].detach().clone(), persistent=False)
         self.register_buffer("base_pixel_size", base_voxel_size[:2].detach().clone(), persistent=False)
 
+    def _to_grid(self, xy, height, width):
+        pixel = self.base_pixel_size * self.cfg.STRIDES[-1]
+        frac = (xy - self.pixel_offset) / pixel
+        limit = frac.new_tensor([width - 1, height - 1])
+        frac = torch.min(frac.clamp(min=0), limit)
+        return (2 * (frac / (limit - 1)) - 1).flip(-1)
+
+    # reference method names, kept for callers that used them
     def normalize_indices(self, indices, H, W):
-        dims = indices.new_tensor([W - 1, H - 1])
-        clipped = torch.min(indices.clamp(min=0), dims)
-        return 2 * (clipped / (dims - 1)) - 1
+        limit = indices.new_tensor([W - 1, H - 1])
+        return 2 * (torch.min(indices.clamp(min=0), limit) / (limit - 1)) - 1
 
     def compute_bev_indices(self, keypoint_xyz, H, W):
-        pix = (keypoint_xyz[:, None, :, :2] - self.pixel_offset) / (self.base_pixel_size * self.cfg.STRIDES[-1])
-        return self.normalize_indices(pix, H, W).flip(3)
+        return self._to_grid(keypoint_xyz[:, None, :, :2], H, W)
 
     def forward(self, feature_map, keypoint_xyz):
-        _, _, H, W = feature_map.shape
-        grid = self.compute_bev_indices(keypoint_xyz, H, W)
+        height, width = feature_map.shape[-2:]
+        grid = self._to_grid(keypoint_xyz[:, None, :, :2], height, width)
         return F.grid_sample(feature_map, grid, align_corners=True).squeeze(2)
 
 
+def _per_layer(flag, n):
+    return list(flag) if isinstance(flag, (list, tuple)) else [flag] * n
+
+
 class MLP(nn.Sequential):
-    """Linear stack with optional per-layer bias / BatchNorm1d / ReLU; children are named
-    linear_i / batchnorm_i / relu_i (layers.py:53-73) so state_dict keys match."""
+    """Stack of nn.Linear with optional bias / BatchNorm1d / ReLU per layer.  Children are named
+    `linear_i`, `batchnorm_i`, `relu_i` -- the reference's state_dict keys (layers.py:53-73)."""
 
     def __init__(self, channels, bias=False, bn=False, relu=True):
-        super().__init__()
         n = len(channels) - 1
-        bias, bn, relu = (v if isinstance(v, (list, tuple)) else [v] * n for v in (bias, bn, relu))
-        for i in range(n):
-            lin = nn.Linear(channels[i], channels[i + 1], bias=bias[i])
-            nn.init.normal_(lin.weight, std=0.01)
-            if bias[i]:
-                nn.init.constant_(lin.bias, 0)
-            self.add_module(f"linear_{i}", lin)
-            if bn[i]:
-                norm = nn.BatchNorm1d(channels[i + 1])
-                nn.init.constant_(norm.weight, 1)
-                nn.init.constant_(norm.bias, 0)
-                self.add_module(f"batchnorm_{i}", norm)
-            if relu[i]:
-                self.add_module(f"relu_{i}", nn.ReLU(inplace=True))
+        layers = OrderedDict()
+        for i, (c_in, c_out, use_bias, use_bn, use_relu) in enumerate(
+                zip(channels[:-1], channels[1:], _per_layer(bias, n), _per_layer(bn, n), _per_layer(relu, n))):
+            linear = nn.Linear(c_in, c_out, bias=use_bias)
+            nn.init.normal_(linear.weight, std=0.01)
+            if use_bias:
+                nn.init.zeros_(linear.bias)
+            layers[f"linear_{i}"] = linear
+            if use_bn:
+                norm = nn.BatchNorm1d(c_out)
+                nn.init.ones_(norm.weight)
+                nn.init.zeros_(norm.bias)
+                layers[f"batchnorm_{i}"] = norm
+            if use_relu:
+                layers[f"relu_{i}"] = nn.ReLU(inplace=True)
+        super().__init__(layers)

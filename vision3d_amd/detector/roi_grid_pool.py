@@ -1,10 +1,11 @@
-"""RoI-grid pooling (interface of vision3d/detector/roi_grid_pool.py:10-72): sample grid points inside
-each proposal, set-abstract keypoint features around them, flatten, reduce.
+"""RoI-grid pooling: random points inside every proposal, multi-scale set abstraction of the keypoint features around
+them (ball query + group on the MI355X kernels), flatten per proposal, reduce with an MLP.  Interface of
+vision3d/detector/roi_grid_pool.py:10-72 (`RoiGridPool(cfg)(proposals, keypoint_xyz, keypoint_features)`).
 
-The reference draws the grid points with an unseeded torch.rand (roi_grid_pool.py:59);
-here `generator` / `samples` make that draw injectable so results are reproducible.
+The reference draws its points with an unseeded torch.rand (roi_grid_pool.py:59); here the draw can be
+injected (`samples`) or seeded (`self.generator`) so that results are reproducible.
 """
-from copy import deepcopy
+import copy
 
 import torch
 from torch import nn
@@ -13,39 +14,44 @@ from ..pointnet2.pointnet2_modules import PointnetSAModuleMSG
 from .layers import MLP
 
 
+def yaw_rotate(local, yaw):
+    """local (..., m, 3) offsets in the box frame, yaw (...) radians -> offsets in the world frame (rotation about z)."""
+    cos, sin = yaw.cos().unsqueeze(-1), yaw.sin().unsqueeze(-1)
+    lx, ly, lz = local[..., 0], local[..., 1], local[..., 2]
+    return torch.stack((cos * lx - sin * ly, sin * lx + cos * ly, lz), dim=-1)
+
+
 class RoiGridPool(nn.Module):
 
     def __init__(self, cfg):
         super().__init__()
         self.cfg = cfg
-        self.pnet = self.build_pointnet(cfg)
-        self.reduction = MLP(cfg.GRIDPOOL.MLPS_REDUCTION)
+        grid = cfg.GRIDPOOL
+        # the SA module appends 3 to the first channel count in place: give it a private copy of the spec
+        self.pnet = PointnetSAModuleMSG(npoint=-1, radii=grid.RADII_PN, nsamples=cfg.SAMPLES_PN,
+                                        mlps=copy.deepcopy(grid.MLPS_PN), use_xyz=True)
+        self.reduction = MLP(grid.MLPS_REDUCTION)
         self.generator = None
 
-    def build_pointnet(self, cfg):
+    def build_pointnet(self, cfg):  # reference entry point; the constructor builds the module inline
         return PointnetSAModuleMSG(npoint=-1, radii=cfg.GRIDPOOL.RADII_PN, nsamples=cfg.SAMPLES_PN,
-                                   mlps=deepcopy(cfg.GRIDPOOL.MLPS_PN), use_xyz=True)
+                                   mlps=copy.deepcopy(cfg.GRIDPOOL.MLPS_PN), use_xyz=True)
 
-    @staticmethod
-    def rotate_z(points, theta):
-        """points (b, n, m, 3) rotated by theta (b, n) about z."""
-        c, s = torch.cos(theta)[..., None], torch.sin(theta)[..., None]
-        x, y, z = points.unbind(-1)
-        return torch.stack((c * x - s * y, s * x + c * y, z), dim=-1)
+    rotate_z = staticmethod(yaw_rotate)
 
     def sample_gridpoints(self, boxes, samples=None):
-        """boxes (b, n, 7) -> (b, n, m, 3): uniform in the box frame, rotated by yaw, translated."""
-        b, n, _ = boxes.shape
-        m = self.cfg.GRIDPOOL.NUM_GRIDPOINTS
+        """boxes (b, n, 7) -> (b, n, m, 3) points uniform in each box: unit-cube draws scaled by (w, l, h), rotated
+        by the yaw, moved to the centre."""
+        b, n = boxes.shape[:2]
         if samples is None:
-            samples = torch.rand((b, n, m, 3), device=boxes.device, generator=self.generator)
-        local = boxes[:, :, None, 3:6] * (samples - 0.5)
-        return boxes[:, :, None, 0:3] + self.rotate_z(local, boxes[..., -1])
+            samples = torch.rand((b, n, self.cfg.GRIDPOOL.NUM_GRIDPOINTS, 3), device=boxes.device, generator=self.generator)
+        centre, size, yaw = boxes[..., None, 0:3], boxes[..., None, 3:6], boxes[..., 6]
+        return centre + yaw_rotate(size * (samples - 0.5), yaw)
 
     def forward(self, proposals, keypoint_xyz, keypoint_features, samples=None):
-        b, n, _ = proposals.shape
-        m = self.cfg.GRIDPOOL.NUM_GRIDPOINTS
-        grid = self.sample_gridpoints(proposals, samples).view(b, -1, 3).contiguous()
-        feats = self.pnet(keypoint_xyz, keypoint_features, grid)[1]            # (b, C, n*m)
-        feats = feats.view(b, -1, n, m).permute(0, 2, 1, 3).contiguous().view(b, n, -1)
-        return self.reduction(feats)
+        b, n = proposals.shape[:2]
+        points = self.sample_gridpoints(proposals, samples)
+        m = points.shape[2]
+        _, pooled = self.pnet(keypoint_xyz, keypoint_features, points.reshape(b, n * m, 3).contiguous())  # (b, C, n*m)
+        per_box = pooled.reshape(b, -1, n, m).permute(0, 2, 1, 3).reshape(b, n, -1)
+        return self.reduction(per_box)

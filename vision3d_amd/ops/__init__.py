@@ -1,5 +1,26 @@
-"""`vision3d.ops` surface (vision3d/ops/__init__.py:1-4), served by libvision3d_hip.so."""
-from .matcher import Matcher, subsample_labels
-from .focal_loss import sigmoid_focal_loss
-from .iou_nms import batched_nms, batched_nms_rotated, nms, nms_rotated, box_iou_rotated
-from .iou_nms import batched_nms_rotated_padded, nms_rotated_padded
+"""The `vision3d.ops` names (reference: vision3d/ops/__init__.py), served by libvision3d_hip.so, plus the two
+sync-free NMS forms used inside captured graphs.  Resolved on first access."""
+import importlib
+
+_EXPORTS = {
+    "Matcher": "matcher", "subsample_labels": "matcher",
+    "sigmoid_focal_loss": "focal_loss",
+    "box_iou_rotated": "iou_nms", "nms": "iou_nms", "nms_rotated": "iou_nms",
+    "batched_nms": "iou_nms", "batched_nms_rotated": "iou_nms",
+    "nms_rotated_padded": "iou_nms", "batched_nms_rotated_padded": "iou_nms",
+}
+__all__ = sorted(_EXPORTS)
+
+
+def __getattr__(name):
+    try:
+        module = importlib.import_module("." + _EXPORTS[name], __name__)
+    except KeyError:
+        raise AttributeError(f"module {__name__!r} has no attribute {name!r}") from None
+    value = getattr(module, name)
+    globals()[name] = value
+    return value
+
+
+def __dir__():
+    return sorted(list(globals()) + __all__)
