@@ -13,7 +13,7 @@ replicas on different frames with no data-path collective (weak scaling); the on
 timing barrier / max-reduce.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      the dominant kernel (spconv_fwd_rows<64,64>, 8 launches/frame): algorithmic bytes
+  roofline      the dominant kernel (spconv_fwd_rows_ring<64,64>, the 3x3x3 64->64 sparse conv: 7 launches/frame): algorithmic bytes
                 A_min = 4*(N_in*Cin + N_out*Cout + K*Cin*Cout) + 8*R per launch divided
                 by its average duration measured with HIP events on the launch stream, vs 8 TB/s.
   cpu_baseline  oracle/ (scalar C sparse path + torch CPU dense path, 1 thread) timed on the host on a
@@ -338,7 +338,7 @@ def main():
             st["bytes"] = layer_algorithmic_bytes(st)
             st["gbs"] = st["bytes"] / (st["t_avg_us"] * 1e-6) / 1e9
             layers.append(st)
-        dom = [l for l in layers if l["cin"] == 64 and l["cout"] == 64]
+        dom = [l for l in layers if l["cin"] == 64 and l["cout"] == 64 and l["K"] == 27]  # the launches of DOM_KERNEL
         dom_bytes = float(np.mean([l["bytes"] for l in dom]))
         dom_t = float(np.mean([l["t_avg_us"] for l in dom])) * 1e-6
         achieved = dom_bytes / dom_t / 1e9
@@ -358,12 +358,13 @@ def main():
         # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed summary of the
         # two rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_h_pmc_traffic.txt) is
         # attached when the workload is the one it was collected on, else null
+        DOM_KERNEL = "spconv_fwd_rows_ring<64,64>"  # 7 of the 8 64->64 launches (3x3x3); the (3,1,1) one runs spconv_fwd_rows<64,64>
         traffic, traffic_src = None, None
         pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path) and not waymo and args.batch == 1 and args.points == 16384:
             pmc = json.load(open(pmc_path))
-            traffic, traffic_src = pmc["spconv_fwd_rows<64,64>"]["traffic_bytes"], pmc["source"]
-        roofline = dict(bound="hbm", kernel="spconv_fwd_rows<64,64>", launches_per_frame=len(dom),
+            traffic, traffic_src = pmc[DOM_KERNEL]["traffic_bytes"] if DOM_KERNEL in pmc else None, pmc["source"]
+        roofline = dict(bound="hbm", kernel=DOM_KERNEL, launches_per_frame=len(dom),
                         bytes_per_launch=dom_bytes, avg_us=dom_t * 1e6, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                         peak_measured_copy=copy_gbs, frac_of_measured=achieved / copy_gbs)

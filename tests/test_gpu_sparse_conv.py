@@ -77,12 +77,14 @@ def test_strided_conv_forward_ragged_tail(oracle, algo):
         assert_features_close(got, oracle.sparse_conv_fwd(feats, w, onbr, relu=True), f"strided {cin}->{cout} algo {algo}")
 
 
-@pytest.mark.parametrize("variant", [2, 4, 5], ids=["2tiles", "4tiles", "64rows_lds_weights"])
-@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64)])
+@pytest.mark.parametrize("variant", [1, 2, 4, 5, 10], ids=["16rows", "2tiles", "4tiles", "64rows_lds_weights", "2tiles_lds_ring"])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 32), (64, 64)])
 def test_packed_kernel_variants(oracle, cin, cout, variant):
-    """The other row-tile variants of the packed (algo 4) kernel -- incl. the 64-row LDS-shared-weights kernel that is
-    selected automatically beyond ~24 k rows -- forced on a small problem: same result as the oracle, ragged tail,
-    fused affine + ReLU, submanifold and strided (3,1,1) tables."""
+    """Every row-tile variant of the packed (algo 4) kernel -- the 16-row kernel, the two-tile LDS-ring kernel (3x3x3,
+    the default below 32 k rows: wave-specialised weight movers, three LDS round buffers), the 64-row LDS-shared-weights
+    kernel (the default beyond) and the debug-only register-tile variants -- forced on a small problem: same result
+    as the oracle, ragged tail (5003 rows: a half-empty last workgroup), fused affine + ReLU, submanifold and
+    strided (3,1,1) tables."""
     import ctypes
     from vision3d_amd import _lib as L
     from vision3d_amd.spconv.conv import build_sparse_rulebook, build_subm_rulebook, sparse_conv_forward

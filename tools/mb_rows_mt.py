@@ -39,7 +39,7 @@ for (a, k) in cap:
     if cin < 32: continue
     row = f"{cin:3d}->{cout:3d} K={rb.nbr.shape[0]:2d} n={rb.n:6d} cap={rb.cap:6d} "
     ref = None
-    for mt in (1, 2, 4, 5):
+    for mt in (1, 10, 5):
         raw.v3d_debug_set_rows_mt(mt)
         ts = []
         for trial in range(4):
@@ -49,6 +49,7 @@ for (a, k) in cap:
             raw.v3d_debug_set_repeat(1); torch.cuda.synchronize()
             if trial: ts.append(e0.elapsed_time(e1) * 1e3 / REP)
         if ref is None: ref = o.clone()
+        elif os.environ.get("MB_NOCHECK"): pass
         else: assert torch.equal(ref, o) or (ref - o).abs().max() < 1e-3 * ref.abs().max(), "mt variants disagree"
         row += f" mt{mt}={np.mean(ts):7.1f}us"
     raw.v3d_debug_set_rows_mt(0)

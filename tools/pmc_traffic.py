@@ -1,0 +1,33 @@
+"""Fold the two --pmc passes of tools/pmc_traffic.sh into traffic per launch (2 * FETCH_SIZE + WRITE_SIZE, KB per dispatch;
+the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md) and write pmc_traffic.json next to the text."""
+import collections, csv, glob, json, os, sys
+
+out_dir = sys.argv[1]
+KERNELS = {"spconv_fwd_rows_ring<64,64>": "spconv_fwd_rows_ring<64, 64>", "conv2d_bf16x3_large_kernel<3>": "conv2d_bf16x3_large_kernel<3>"}
+mean = collections.defaultdict(dict)
+print("== rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, each with --kernel-trace only) -- "
+      "python bench.py --steps 3 --warmup 2 --no-cpu-baseline")
+print("== counter unit: KB per dispatch; gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide coalesced "
+      "reads at half their bytes -> x2")
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(os.path.join(out_dir, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        sys.exit(f"no counter_collection.csv for {counter}")
+    vals = collections.defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        if r["Counter_Name"] != counter:
+            continue
+        for key, pat in KERNELS.items():
+            if pat in r["Kernel_Name"]:
+                vals[key].append(float(r["Counter_Value"]))
+    for key, v in vals.items():
+        mean[key][counter] = sum(v) / len(v)
+        print(f"{key:36s} {counter:11s} mean {mean[key][counter]:12.1f} KB  (n={len(v)})")
+res = {"source": "profiles/r01_j_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes; FETCH_SIZE x2 gfx950 correction)"}
+print("\ntraffic per launch = 2*FETCH_SIZE + WRITE_SIZE:")
+for key, m in mean.items():
+    if len(m) == 2:
+        kb = 2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]
+        res[key] = dict(fetch_kb=m["FETCH_SIZE"], write_kb=m["WRITE_SIZE"], traffic_bytes=kb * 1024)
+        print(f"  {key}: 2*{m['FETCH_SIZE']:.1f} + {m['WRITE_SIZE']:.1f} = {kb:.1f} KB = {kb * 1024 / 1e6:.2f} MB")
+json.dump(res, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)

@@ -484,6 +484,13 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float f) {
 // slot limiter of this kernel).  The two bf16 halves of a dword are merged with one v_perm_b32.
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
   u32x4_t h, m, l;
+#ifdef SPR_NOSPLIT  // experiment only (wrong results): what the kernels cost without the split's VALU work
+  h = u32x4_t{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+  m = u32x4_t{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
+  l = h ^ m;
+  hi = __builtin_bit_cast(bf16x8_t, h); mid = __builtin_bit_cast(bf16x8_t, m); lo = __builtin_bit_cast(bf16x8_t, l);
+  return;
+#endif
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const unsigned u0 = __float_as_uint(x[2 * i]), u1 = __float_as_uint(x[2 * i + 1]);
@@ -534,6 +541,19 @@ extern "C" int v3d_sparse_conv_pack_weights(const float* weight, int K, int Cin,
   return V3D_OK;
 }
 
+#ifndef SPR_TIMELINE
+#define SPR_TIMELINE 0  // 1: cycle-counter stamps of 4 workgroups x 4 waves (tools/mb_rows_timeline.py prints them)
+#endif
+#if SPR_TIMELINE
+__device__ unsigned long long spr_tl[4][4][16];
+extern "C" int v3d_debug_rows_timeline(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(spr_tl), sizeof(spr_tl));
+}
+#define SPR_STAMP(idx) do { if (lane == 0 && wave < 4 && (blockIdx.x & 127) == 5 && blockIdx.x < 512) spr_tl[blockIdx.x >> 7][wave][idx] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SPR_STAMP(idx)
+#endif
+
 template <int CIN, int COUT>
 __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __restrict__ in,
                                                              const unsigned short* __restrict__ wimg,
@@ -554,12 +574,24 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
   const int n = min(*n_ptr, cap);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int row0 = blockIdx.x * 16;
-  if (row0 >= n) return;
+  int wg = blockIdx.x;
+  {
+    // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (private L2s);
+    // remap the LIVE tiles so that each XCD walks one contiguous run of rows -- the rows a tile gathers are mostly
+    // its neighbours', which then sit in that XCD's L2 instead of being fetched by all eight (64->64 at 36 k rows:
+    // 53 -> 48 us; neutral at 8 k).
+    const int nwg = (n + 15) / 16;
+    if (wg >= nwg) return;
+    const int q = nwg / 8, rmd = nwg % 8, xcd = wg % 8, idx = wg / 8;
+    wg = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;  // bijective on [0, nwg)
+  }
+  const int row0 = wg * 16;
   const int r = lane & 15, kg = lane >> 4;
+  SPR_STAMP(0);
   for (int k = tid >> 4; k < K; k += V3D_BLOCK / 16)
     nbr_s[k * 16 + r] = (row0 + r < n) ? nbr[(size_t)k * cap + row0 + r] : -1;
   __syncthreads();
+  SPR_STAMP(1);
 
   float araw[2][KI][8];
   u32x4_t braw[2][NF];
@@ -612,20 +644,32 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
   };
 
   // this wave's offsets: wave, wave + NW, ...   (two register sets: operands of the next offset in flight)
+  SPR_STAMP(2);
   if (wave < K) load_ops(wave, araw[0], braw[0]);
+  SPR_STAMP(3);
   for (int k = wave; k < K; k += 2 * NW) {
     if (k + NW < K) load_ops(k + NW, araw[1], braw[1]);
     multiply(araw[0], braw[0]);
+#if SPR_TIMELINE
+    __builtin_amdgcn_sched_barrier(0);
+    SPR_STAMP(4 + 2 * ((k - wave) / (2 * NW)));
+#endif
     if (k + NW < K) {
       if (k + 2 * NW < K) load_ops(k + 2 * NW, araw[0], braw[0]);
       multiply(araw[1], braw[1]);
+#if SPR_TIMELINE
+      __builtin_amdgcn_sched_barrier(0);
+      SPR_STAMP(5 + 2 * ((k - wave) / (2 * NW)));
+#endif
     }
   }
 #pragma unroll
   for (int j = 0; j < NB; j++)
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) part[((wave * NB + j) * 4 + rr) * 64 + lane] = acc[j][rr];
+  SPR_STAMP(12);
   __syncthreads();
+  SPR_STAMP(13);
 
   // epilogue: wave w finishes column blocks j = w, w + NW, ...;  D[row = kg*4 + rr][col = r]
   for (int j = wave; j < NB; j += NW) {
@@ -644,6 +688,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
       }
     }
   }
+  SPR_STAMP(14);
 }
 
 // Same algorithm with MT (2 or 4) row tiles per workgroup: every wave still owns the offsets k = w, w+4, ... but
@@ -901,6 +946,191 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __
   }
 }
 
+// Mid-size variant for K = 27 (3x3x3), the KITTI bs = 1 operating point.  The cycle-counter timeline of the 16-row
+// kernel (tools/mb_rows_timeline.py, -DSPR_TIMELINE=1) shows it bound by the CU's 64 B/clk vector-memory path:
+// every wave pulls its own 16 KB W[k] image plus 4 KB of gathered rows per offset -- 1.08 MB per CU per launch at
+// 64->64 -- and spends 2 500-4 000 clocks just ISSUING one offset's 20 loads, whether one or two workgroups share
+// the CU.  Here a workgroup owns TWO 16-row tiles and walks the offsets in 9 rounds of THREE: the three W[k] images
+// of a round cross the vector path ONCE per workgroup, by LDS-DMA (global_load_lds_dwordx4) into one of THREE
+// statically separate LDS round buffers, and every multiplying wave takes its operand fragments from LDS (a separate
+// 128 B/clk path).  WAVE SPECIALISATION: waves 0-5 multiply (tile t, offset group g), waves 6-7 only move weights.
+// Why: global_load_lds is a FLAT-encoded instruction that writes LDS; once one is pending in a wave, the compiler's
+// waitcnt pass treats that wave's vector-memory counter as out of order and emits s_waitcnt vmcnt(0) for EVERY
+// later register or LDS dependency (a first version with DMA and multiply in the same waves ran them back to back:
+// 3 150 clocks per 4-offset round).  A wave that never issues a DMA keeps exact vmcnt bookkeeping (its gathers stay a
+// round ahead), and a wave that only issues DMAs needs no compiler-placed waits at all -- it counts its own
+// (s_waitcnt vmcnt(24) = "everything but the newest round has landed").  64->64 at 8 160 rows: 14.4 -> 12.3 us.
+// Round r: [barrier: round r's weights are in LDS, multiply(r-1) is finished everywhere]
+//          movers: DMA(r+2) into the buffer multiply(r-1) just released, wait for DMA(r+1)
+//          multipliers: gather(r+2), multiply(r) from buffer r%3.
+// Two rounds of weights are in flight while one multiplies.  Absent neighbours gather a row of zeros (branch-free:
+// the vmcnt bookkeeping needs a fixed number of loads per round).
+__device__ __attribute__((aligned(256))) const float spr_zero_row[128] = {};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512) void spconv_fwd_rows_ring(const float* __restrict__ in,
+                                                            const unsigned short* __restrict__ wimg,
+                                                            const int* __restrict__ nbr, const int* __restrict__ n_ptr,
+                                                            int cap, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int relu,
+                                                            float* __restrict__ out) {
+  constexpr int K = 27, OG = 3, TILES = 2, ROUNDS = K / OG, NCW = TILES * OG, NMV = 2;
+  constexpr int KI = CIN / 32, NB = COUT / 16;
+  constexpr int NF = KI * NB * 2;          // 1 KB weight fragments per offset
+  constexpr int WBYTES = NF * 1024;        // one W[k] image
+  constexpr int RB = OG * WBYTES;          // one round
+  constexpr int FPM = OG * NF / NMV;       // fragments each mover wave moves per round
+  static_assert(CIN % 32 == 0 && CIN <= 128 && (OG * NF) % NMV == 0 && FPM < 64, "shape not covered by the ring kernel");
+  static_assert(RB >= TILES * OG * NB * 4 * 64 * 4, "partials must fit one round buffer");
+  __shared__ __attribute__((aligned(16))) unsigned char wb0[RB];
+  __shared__ __attribute__((aligned(16))) unsigned char wb1[RB];
+  __shared__ __attribute__((aligned(16))) unsigned char wb2[RB];
+  __shared__ int nbr_all[TILES * K * 16];
+#define SPR_RING(i) ((i) % 3 == 0 ? wb0 : ((i) % 3 == 1 ? wb1 : wb2))
+  const int n = min(*n_ptr, cap);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wg = blockIdx.x;
+  {
+    const int nwg = (n + 16 * TILES - 1) / (16 * TILES);  // live workgroups; each XCD (private L2) walks one contiguous run
+    if (wg >= nwg) return;
+    const int qd = nwg / 8, rmd = nwg % 8, xcd = wg % 8, idx = wg / 8;
+    wg = (xcd < rmd ? xcd * (qd + 1) : rmd * (qd + 1) + (xcd - rmd) * qd) + idx;  // bijective on [0, nwg)
+  }
+
+  [[maybe_unused]] const int wave = wv == NCW ? 3 : (wv < 3 ? wv : 99);  // SPR_STAMP slot: multipliers 0-2, first mover
+  SPR_STAMP(0);
+  if (wv >= NCW) {
+    // ---------------------------------------------------------------- movers: weights, global -> LDS, nothing else
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int mv = wv - NCW;
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(wimg) + (size_t)mv * FPM * 1024 + (size_t)lane * 16;
+#define SPR_DMA(R)                                                                                                  \
+  {                                                                                                                 \
+    const unsigned char* gsrc = wsrc + (size_t)(R) * RB;                                                            \
+    _Pragma("unroll") for (int i = 0; i < FPM; i++)                                                                 \
+        __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + i * 1024), (lptr_t)(SPR_RING(R) + (mv * FPM + i) * 1024), 16, 0, 0); \
+  }
+    SPR_DMA(0)
+    SPR_DMA(1)
+    SPR_STAMP(1);
+#pragma unroll
+    for (int R = 0; R < ROUNDS; R++) {
+      // round R has landed once at most the FPM DMAs of round R+1 are outstanding
+      if (R + 1 < ROUNDS) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(FPM) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (R + 2 < ROUNDS) SPR_DMA(R + 2)
+      SPR_STAMP(3 + R);
+    }
+#undef SPR_DMA
+    __syncthreads();  // the multipliers' partial-sum barrier
+    return;
+  }
+
+  // -------------------------------------------------------------------- multipliers: tile t, offset group g
+  const int t = wv / OG, g = wv % OG;
+  int* nbr_s = nbr_all + t * K * 16;
+  const int row0 = (wg * TILES + t) * 16;
+  const int r = lane & 15, kg = lane >> 4;
+  typedef const __attribute__((address_space(1))) f32x4* gf4_t;  // keeps the gathers global_load (a generic select would be flat_load)
+  float araw[3][KI][8];
+  f32x4 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define SPR_GATHER(R, SRC)                                                                                       \
+  {                                                                                                              \
+    const int src = (SRC);                                                                                       \
+    const gf4_t prow = (src >= 0 ? (gf4_t)(in + (size_t)src * CIN) : (gf4_t)spr_zero_row) + kg * 2;              \
+    _Pragma("unroll") for (int ki = 0; ki < KI; ki++) {                                                          \
+      const f32x4 v0 = prow[ki * 8], v1 = prow[ki * 8 + 1];                                                      \
+      float* a = araw[(R) % 3][ki];                                                                              \
+      a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;    \
+    }                                                                                                            \
+  }
+  {
+    // entries of rounds 0 and 1 straight from global (the first gathers do not wait for the staging barrier), then
+    // this wave's share of the tile's table for the later rounds: 9 offsets (k = g, g+3, ...) x 16 rows, quarter by lane
+    const bool live = row0 + r < n;
+    const int src0 = live ? nbr[(size_t)g * cap + row0 + r] : -1, src1 = live ? nbr[(size_t)(OG + g) * cap + row0 + r] : -1;
+    int stage[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int kk = (kg + 4 * i) * OG + g;  // kg + 4 i < 9
+      stage[i] = (live && kg + 4 * i < ROUNDS) ? nbr[(size_t)kk * cap + row0 + r] : -1;
+    }
+    SPR_GATHER(0, src0)
+    SPR_GATHER(1, src1)
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      if (kg + 4 * i < ROUNDS) nbr_s[((kg + 4 * i) * OG + g) * 16 + r] = stage[i];
+  }
+  SPR_STAMP(1);
+#pragma unroll
+  for (int R = 0; R < ROUNDS; R++) {
+    // (round 0: also "the tile's neighbour table is staged" -- hence the lgkmcnt; no vmcnt: the gathers stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (R + 2 < ROUNDS) SPR_GATHER(R + 2, nbr_s[((R + 2) * OG + g) * 16 + r])
+    const bf16x8_t* bw = reinterpret_cast<const bf16x8_t*>(SPR_RING(R) + g * WBYTES) + lane;
+#pragma unroll
+    for (int ki = 0; ki < KI; ki++) {
+      bf16x8_t ah, am, al, bh[NB], bl[NB];
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        bh[j] = bw[(size_t)((ki * NB + j) * 2) * 64];
+        bl[j] = bw[(size_t)((ki * NB + j) * 2 + 1) * 64];
+      }
+      split8(araw[R % 3][ki], ah, am, al);
+#pragma unroll
+      for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[j], 0, 0, 0);  // smallest terms first
+#pragma unroll
+      for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[j], 0, 0, 0);
+    }
+#if SPR_TIMELINE
+    __builtin_amdgcn_sched_barrier(0);
+    SPR_STAMP(3 + R);
+#endif
+  }
+#undef SPR_GATHER
+  // partial tiles of the 3 offset groups meet in round buffer 0 (last read in round 6: every wave is past round 7's barrier)
+  float* part = reinterpret_cast<float*>(wb0) + t * (OG * NB * 4 * 64);  // [TILES][OG][NB][4][64]
+#pragma unroll
+  for (int j = 0; j < NB; j++)
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) part[((g * NB + j) * 4 + rr) * 64 + lane] = acc[j][rr];
+  SPR_STAMP(12);
+  __syncthreads();
+  SPR_STAMP(13);
+  for (int it = g; it < NB * 4; it += OG) {  // D[row = kg*4 + rr][col = j*16 + r]: 4 NB (j, rr) slices dealt to the tile's 3 waves
+    const int j = it >> 2, rr = it & 3;
+    const int col = j * 16 + r, row = row0 + kg * 4 + rr;
+    float v = part[((0 * NB + j) * 4 + rr) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < OG; w++) v += part[((w * NB + j) * 4 + rr) * 64 + lane];
+    if (row < n) {
+      if (scale) v = v * scale[col] + shift[col];
+      if (relu) v = fmaxf(v, 0.f);
+      out[(size_t)row * COUT + col] = v;
+    }
+  }
+  SPR_STAMP(14);
+#undef SPR_RING
+}
+
+template <int CIN, int COUT>
+static int launch_rows_ring(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
+                            const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
+  for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
+    hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT>), dim3(v3d_ceil_div(cap, 32)), dim3(512), 0, st, in,
+                       (const unsigned short*)wimg, nbr, n_ptr, cap, scale, shift, relu, out);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 template <int CIN, int COUT>
 static void launch_rows_big(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
                             const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
@@ -926,6 +1156,7 @@ static void launch_rows_mt(const float* in, const void* wimg, const int* nbr, co
 // rows_hint = expected number of LIVE rows (the live count itself is device-side): the caller's best knowledge --
 // the capacity when it is exact (per-op Python path), the counts observed on earlier frames (v3d_backbone_tune).
 #define V3D_BIG_ROWS 32768
+#define V3D_RING_ROWS 16384  // two full rounds of 32-row workgroups on 256 CUs; beyond, the 16-row kernel wins again (36 k rows: 47 vs 53 us)
 template <int CIN, int COUT>
 static int launch_rows(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
                        const float* scale, const float* shift, int relu, float* out, int rows_hint, hipStream_t st) {
@@ -937,6 +1168,9 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
       V3D_CHECK_LAUNCH();
       return V3D_OK;
     }
+    // 10 = the two-tile LDS-ring kernel (3x3x3 only): 64->64 at 8 160 rows 14.4 -> 12.3 us, 32->32 at 13 731 rows 10.9 -> 9.6 us
+    if (K == 27 && (g_v3d_rows_mt == 10 || (g_v3d_rows_mt == 0 && rows_hint <= V3D_RING_ROWS)))
+      return launch_rows_ring<CIN, COUT>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
   }
   if constexpr (CIN >= 32 && CIN <= 64 && COUT <= 64) {  // weight stream >= 27 x 4 KB per block: share it across more rows when there are enough of them
     int mt = g_v3d_rows_mt;
