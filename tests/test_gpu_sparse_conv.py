@@ -77,7 +77,7 @@ def test_strided_conv_forward_ragged_tail(oracle, algo):
         assert_features_close(got, oracle.sparse_conv_fwd(feats, w, onbr, relu=True), f"strided {cin}->{cout} algo {algo}")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 5, 10], ids=["16rows", "2tiles", "4tiles", "64rows_lds_weights", "2tiles_lds_ring"])
+@pytest.mark.parametrize("variant", [1, 2, 4, 5, 10, 11], ids=["16rows", "2tiles", "4tiles", "64rows_lds_weights", "lds_ring_3", "lds_ring_2"])
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 32), (64, 64)])
 def test_packed_kernel_variants(oracle, cin, cout, variant):
     """Every row-tile variant of the packed (algo 4) kernel -- the 16-row kernel, the two-tile LDS-ring kernel (3x3x3,

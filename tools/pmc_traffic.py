@@ -3,7 +3,7 @@ the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md) and write pmc
 import collections, csv, glob, json, os, sys
 
 out_dir = sys.argv[1]
-KERNELS = {"spconv_fwd_rows_ring<64,64>": "spconv_fwd_rows_ring<64, 64>", "conv2d_bf16x3_large_kernel<3>": "conv2d_bf16x3_large_kernel<3>"}
+KERNELS = {"spconv_fwd_rows_ring<64,64>": "spconv_fwd_rows_ring<64, 64, 3>", "conv2d_bf16x3_large_kernel<3>": "conv2d_bf16x3_large_kernel<3>"}
 mean = collections.defaultdict(dict)
 print("== rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, each with --kernel-trace only) -- "
       "python bench.py --steps 3 --warmup 2 --no-cpu-baseline")

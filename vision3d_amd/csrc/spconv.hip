@@ -967,26 +967,36 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __
 // the vmcnt bookkeeping needs a fixed number of loads per round).
 __device__ __attribute__((aligned(256))) const float spr_zero_row[128] = {};
 
-template <int CIN, int COUT>
-__global__ __launch_bounds__(512) void spconv_fwd_rows_ring(const float* __restrict__ in,
-                                                            const unsigned short* __restrict__ wimg,
-                                                            const int* __restrict__ nbr, const int* __restrict__ n_ptr,
-                                                            int cap, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, int relu,
-                                                            float* __restrict__ out) {
-  constexpr int K = 27, OG = 3, TILES = 2, ROUNDS = K / OG, NCW = TILES * OG, NMV = 2;
+template <int CIN, int COUT, int OG>
+__global__ __launch_bounds__((2 * OG + 2) * 64) void spconv_fwd_rows_ring(const float* __restrict__ in,
+                                                                          const unsigned short* __restrict__ wimg,
+                                                                          const int* __restrict__ nbr,
+                                                                          const int* __restrict__ n_ptr, int cap,
+                                                                          const float* __restrict__ scale,
+                                                                          const float* __restrict__ shift, int relu,
+                                                                          float* __restrict__ out) {
+  // OG = offsets per round = multiplying waves per tile.  OG = 3: 9 rounds, 3 round buffers, 6 + 2 waves.
+  // OG = 2: 14 rounds (the 28th offset is a zero row), 4 round buffers (three rounds of weights in flight), 4 + 2
+  // waves -- one multiplying wave per SIMD.  Measured slower (64->64 at 8 160 rows: 12.3 vs 13.0 us): the cost of a round
+  // is mostly its barrier and the LDS read burst behind it, not the matrix pipe, so fewer, longer rounds win.  Also
+  // tried and dropped: splitting (R, ki+1) while the MFMAs of (R, ki) run, with and without sched_group_barrier
+  // interleave (12.9 / 13.2 us).  OG = 2 stays reachable as debug variant 11.
+  constexpr int K = 27, TILES = 2, ROUNDS = (K + OG - 1) / OG, NCW = TILES * OG, NMV = 2;
+  constexpr int NBUF = OG == 2 ? 4 : 3, LOOK = NBUF - 1;  // rounds of weights / gathered rows in flight ahead of the multiply
   constexpr int KI = CIN / 32, NB = COUT / 16;
   constexpr int NF = KI * NB * 2;          // 1 KB weight fragments per offset
   constexpr int WBYTES = NF * 1024;        // one W[k] image
   constexpr int RB = OG * WBYTES;          // one round
   constexpr int FPM = OG * NF / NMV;       // fragments each mover wave moves per round
-  static_assert(CIN % 32 == 0 && CIN <= 128 && (OG * NF) % NMV == 0 && FPM < 64, "shape not covered by the ring kernel");
+  constexpr int NSTG = (ROUNDS + 3) / 4;   // neighbour-table entries a multiplier lane stages
+  static_assert(CIN % 32 == 0 && CIN <= 128 && (OG * NF) % NMV == 0 && (LOOK - 1) * FPM < 64, "shape not covered by the ring kernel");
   static_assert(RB >= TILES * OG * NB * 4 * 64 * 4, "partials must fit one round buffer");
   __shared__ __attribute__((aligned(16))) unsigned char wb0[RB];
   __shared__ __attribute__((aligned(16))) unsigned char wb1[RB];
   __shared__ __attribute__((aligned(16))) unsigned char wb2[RB];
+  __shared__ __attribute__((aligned(16))) unsigned char wb3[NBUF == 4 ? RB : 16];
   __shared__ int nbr_all[TILES * K * 16];
-#define SPR_RING(i) ((i) % 3 == 0 ? wb0 : ((i) % 3 == 1 ? wb1 : wb2))
+#define SPR_RING(i) ((i) % NBUF == 0 ? wb0 : ((i) % NBUF == 1 ? wb1 : ((i) % NBUF == 2 ? wb2 : wb3)))
   const int n = min(*n_ptr, cap);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1006,22 +1016,28 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_ring(const float* __restr
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int mv = wv - NCW;
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(wimg) + (size_t)mv * FPM * 1024 + (size_t)lane * 16;
+    // (an offset slot beyond K -- OG = 2, last round -- re-reads the previous image: its rows are all zero)
 #define SPR_DMA(R)                                                                                                  \
   {                                                                                                                 \
     const unsigned char* gsrc = wsrc + (size_t)(R) * RB;                                                            \
-    _Pragma("unroll") for (int i = 0; i < FPM; i++)                                                                 \
-        __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + i * 1024), (lptr_t)(SPR_RING(R) + (mv * FPM + i) * 1024), 16, 0, 0); \
+    _Pragma("unroll") for (int i = 0; i < FPM; i++) {                                                               \
+      const bool ok = (R) * OG + (mv * FPM + i) / NF < K;                                                           \
+      __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + i * 1024 - (ok ? 0 : WBYTES)),                               \
+                                       (lptr_t)(SPR_RING(R) + (mv * FPM + i) * 1024), 16, 0, 0);                    \
+    }                                                                                                               \
   }
-    SPR_DMA(0)
-    SPR_DMA(1)
+#pragma unroll
+    for (int R = 0; R < LOOK; R++) SPR_DMA(R)
     SPR_STAMP(1);
 #pragma unroll
     for (int R = 0; R < ROUNDS; R++) {
-      // round R has landed once at most the FPM DMAs of round R+1 are outstanding
-      if (R + 1 < ROUNDS) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(FPM) : "memory");
+      // round R has landed once only the DMAs of the (up to LOOK - 1) younger rounds are outstanding
+      const int younger = (ROUNDS - 1 - R) < (LOOK - 1) ? (ROUNDS - 1 - R) : (LOOK - 1);
+      if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * FPM < 64 ? 2 * FPM : 63) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(FPM) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      if (R + 2 < ROUNDS) SPR_DMA(R + 2)
-      SPR_STAMP(3 + R);
+      if (R + LOOK < ROUNDS) SPR_DMA(R + LOOK)
+      SPR_STAMP(3 + (R < 9 ? R : 8));
     }
 #undef SPR_DMA
     __syncthreads();  // the multipliers' partial-sum barrier
@@ -1034,7 +1050,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_ring(const float* __restr
   const int row0 = (wg * TILES + t) * 16;
   const int r = lane & 15, kg = lane >> 4;
   typedef const __attribute__((address_space(1))) f32x4* gf4_t;  // keeps the gathers global_load (a generic select would be flat_load)
-  float araw[3][KI][8];
+  float araw[NBUF][KI][8];
   f32x4 acc[NB];
 #pragma unroll
   for (int j = 0; j < NB; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1044,33 +1060,35 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_ring(const float* __restr
     const gf4_t prow = (src >= 0 ? (gf4_t)(in + (size_t)src * CIN) : (gf4_t)spr_zero_row) + kg * 2;              \
     _Pragma("unroll") for (int ki = 0; ki < KI; ki++) {                                                          \
       const f32x4 v0 = prow[ki * 8], v1 = prow[ki * 8 + 1];                                                      \
-      float* a = araw[(R) % 3][ki];                                                                              \
+      float* a = araw[(R) % NBUF][ki];                                                                           \
       a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;    \
     }                                                                                                            \
   }
   {
-    // entries of rounds 0 and 1 straight from global (the first gathers do not wait for the staging barrier), then
-    // this wave's share of the tile's table for the later rounds: 9 offsets (k = g, g+3, ...) x 16 rows, quarter by lane
+    // entries of the first LOOK rounds straight from global (the first gathers do not wait for the staging barrier),
+    // then this wave's share of the tile's table for the later rounds: offsets k = g, g + OG, ... x 16 rows, a quarter
+    // of the rounds per 16-lane group
     const bool live = row0 + r < n;
-    const int src0 = live ? nbr[(size_t)g * cap + row0 + r] : -1, src1 = live ? nbr[(size_t)(OG + g) * cap + row0 + r] : -1;
-    int stage[3];
+    int first[LOOK], stage[NSTG];
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const int kk = (kg + 4 * i) * OG + g;  // kg + 4 i < 9
-      stage[i] = (live && kg + 4 * i < ROUNDS) ? nbr[(size_t)kk * cap + row0 + r] : -1;
+    for (int i = 0; i < LOOK; i++) first[i] = (live && i * OG + g < K) ? nbr[(size_t)(i * OG + g) * cap + row0 + r] : -1;
+#pragma unroll
+    for (int i = 0; i < NSTG; i++) {
+      const int kk = (kg + 4 * i) * OG + g;
+      stage[i] = (live && kk < K) ? nbr[(size_t)kk * cap + row0 + r] : -1;
     }
-    SPR_GATHER(0, src0)
-    SPR_GATHER(1, src1)
 #pragma unroll
-    for (int i = 0; i < 3; i++)
-      if (kg + 4 * i < ROUNDS) nbr_s[((kg + 4 * i) * OG + g) * 16 + r] = stage[i];
+    for (int i = 0; i < LOOK; i++) SPR_GATHER(i, first[i])
+#pragma unroll
+    for (int i = 0; i < NSTG; i++)
+      if ((kg + 4 * i) * OG + g < K) nbr_s[((kg + 4 * i) * OG + g) * 16 + r] = stage[i];
   }
   SPR_STAMP(1);
 #pragma unroll
   for (int R = 0; R < ROUNDS; R++) {
     // (round 0: also "the tile's neighbour table is staged" -- hence the lgkmcnt; no vmcnt: the gathers stay in flight)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (R + 2 < ROUNDS) SPR_GATHER(R + 2, nbr_s[((R + 2) * OG + g) * 16 + r])
+    if (R + LOOK < ROUNDS) SPR_GATHER(R + LOOK, ((R + LOOK) * OG + g < K) ? nbr_s[((R + LOOK) * OG + g) * 16 + r] : -1)
     const bf16x8_t* bw = reinterpret_cast<const bf16x8_t*>(SPR_RING(R) + g * WBYTES) + lane;
 #pragma unroll
     for (int ki = 0; ki < KI; ki++) {
@@ -1080,7 +1098,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_ring(const float* __restr
         bh[j] = bw[(size_t)((ki * NB + j) * 2) * 64];
         bl[j] = bw[(size_t)((ki * NB + j) * 2 + 1) * 64];
       }
-      split8(araw[R % 3][ki], ah, am, al);
+      split8(araw[R % NBUF][ki], ah, am, al);
 #pragma unroll
       for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[j], 0, 0, 0);  // smallest terms first
 #pragma unroll
@@ -1092,11 +1110,13 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_ring(const float* __restr
     }
 #if SPR_TIMELINE
     __builtin_amdgcn_sched_barrier(0);
-    SPR_STAMP(3 + R);
+    SPR_STAMP(3 + (R < 9 ? R : 8));
 #endif
   }
 #undef SPR_GATHER
-  // partial tiles of the 3 offset groups meet in round buffer 0 (last read in round 6: every wave is past round 7's barrier)
+  // partial tiles of the OG offset groups meet in round buffer 0 (its last reader round is followed by at least one
+  // more round barrier: every wave is past it)
+  static_assert((ROUNDS - 1) % NBUF != 0, "round buffer 0 must not be the last one read");
   float* part = reinterpret_cast<float*>(wb0) + t * (OG * NB * 4 * 64);  // [TILES][OG][NB][4][64]
 #pragma unroll
   for (int j = 0; j < NB; j++)
@@ -1105,7 +1125,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_ring(const float* __restr
   SPR_STAMP(12);
   __syncthreads();
   SPR_STAMP(13);
-  for (int it = g; it < NB * 4; it += OG) {  // D[row = kg*4 + rr][col = j*16 + r]: 4 NB (j, rr) slices dealt to the tile's 3 waves
+  for (int it = g; it < NB * 4; it += OG) {  // D[row = kg*4 + rr][col = j*16 + r]: 4 NB (j, rr) slices dealt to the tile's waves
     const int j = it >> 2, rr = it & 3;
     const int col = j * 16 + r, row = row0 + kg * 4 + rr;
     float v = part[((0 * NB + j) * 4 + rr) * 64 + lane];
@@ -1121,11 +1141,11 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_ring(const float* __restr
 #undef SPR_RING
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int OG>
 static int launch_rows_ring(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
                             const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
   for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
-    hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT>), dim3(v3d_ceil_div(cap, 32)), dim3(512), 0, st, in,
+    hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG>), dim3(v3d_ceil_div(cap, 32)), dim3((2 * OG + 2) * 64), 0, st, in,
                        (const unsigned short*)wimg, nbr, n_ptr, cap, scale, shift, relu, out);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
@@ -1169,8 +1189,9 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
       return V3D_OK;
     }
     // 10 = the two-tile LDS-ring kernel (3x3x3 only): 64->64 at 8 160 rows 14.4 -> 12.3 us, 32->32 at 13 731 rows 10.9 -> 9.6 us
+    if (K == 27 && g_v3d_rows_mt == 11) return launch_rows_ring<CIN, COUT, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
     if (K == 27 && (g_v3d_rows_mt == 10 || (g_v3d_rows_mt == 0 && rows_hint <= V3D_RING_ROWS)))
-      return launch_rows_ring<CIN, COUT>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+      return launch_rows_ring<CIN, COUT, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
   }
   if constexpr (CIN >= 32 && CIN <= 64 && COUT <= 64) {  // weight stream >= 27 x 4 KB per block: share it across more rows when there are enough of them
     int mt = g_v3d_rows_mt;
