@@ -34,6 +34,12 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+# RCCL ("nccl") over xGMI is the launch contract.  V3D_BENCH_BACKEND=gloo exists only to exercise the multi-rank control flow
+# (env parsing, barrier, max-over-ranks, rank-0 JSON) where there are fewer GPUs than ranks: ranks then share devices.
+BACKEND = os.environ.get("V3D_BENCH_BACKEND", "nccl")
+REDUCE_DEVICE = "cuda" if BACKEND == "nccl" else "cpu"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,8 +86,8 @@ def train_main(args):
     from vision3d_amd.detector import ProposalLoss, Second
     import torch.distributed as dist
     rank, local, world = dist_util.env_world()
-    torch.cuda.set_device(local)
-    dist_util.init_from_env("nccl")
+    torch.cuda.set_device(local % torch.cuda.device_count())
+    dist_util.init_from_env(BACKEND)
     cfg = second_car_cfg()
     if args.points is None:
         args.points = 16384
@@ -131,7 +137,7 @@ def train_main(args):
     for _ in range(args.steps):
         loss = step()
     fence()
-    elapsed = dist_util.max_over_ranks(time.perf_counter() - t0, world, device="cuda")
+    elapsed = dist_util.max_over_ranks(time.perf_counter() - t0, world, device=REDUCE_DEVICE)
     if rank == 0:
         print(json.dumps(dict(
             metric="frames/sec SECOND train step, 16k-pt KITTI cloud", value=world * bs * args.steps / elapsed, unit="frames/s",
@@ -156,8 +162,8 @@ def pvrcnn_main(args):
     from vision3d_amd.detector import PV_RCNN
     import torch.distributed as dist
     rank, local, world = dist_util.env_world()
-    torch.cuda.set_device(local)
-    dist_util.init_from_env("nccl")
+    torch.cuda.set_device(local % torch.cuda.device_count())
+    dist_util.init_from_env(BACKEND)
     cfg = second_car_cfg()
     torch.manual_seed(0)
     model = PV_RCNN(cfg).cuda().eval()
@@ -188,7 +194,7 @@ def pvrcnn_main(args):
         for _ in range(args.steps):
             out = step()
         fence()
-    elapsed = dist_util.max_over_ranks(time.perf_counter() - t0, world, device="cuda")
+    elapsed = dist_util.max_over_ranks(time.perf_counter() - t0, world, device=REDUCE_DEVICE)
     if rank == 0:
         print(json.dumps(dict(
             metric="frames/sec PV-RCNN stage 2, 16k-pt KITTI cloud", value=world * bs * args.steps / elapsed, unit="frames/s",
@@ -211,8 +217,8 @@ def main():
     from vision3d_amd import dist_util
     rank, local, world = dist_util.env_world()
     assert torch.cuda.is_available(), "bench.py needs a GPU (vision3d_amd has no CPU path)"
-    torch.cuda.set_device(local)
-    dist_util.init_from_env("nccl")  # RCCL; used for the barrier and the max-reduce only (frames are independent)
+    torch.cuda.set_device(local % torch.cuda.device_count())
+    dist_util.init_from_env(BACKEND)  # RCCL; used for the barrier and the max-reduce only (frames are independent)
     import torch.distributed as dist
 
     from vision3d_amd import synth
@@ -282,7 +288,7 @@ def main():
         out = rest[-1] if rest else last_out[0]
     fence()
     elapsed = time.perf_counter() - t0
-    elapsed = dist_util.max_over_ranks(elapsed, world, device="cuda")
+    elapsed = dist_util.max_over_ranks(elapsed, world, device=REDUCE_DEVICE)
     frames = world * args.steps * args.batch
     value = frames / elapsed
     # one frame at a time through the same captured graph (latency view of the same work), not part of `value`
