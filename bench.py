@@ -5,9 +5,10 @@
 
 One step = one pass of the hot path over one batch (bs=1/GPU, configs[1]): device voxelizer + VFE ->
 14-layer sparse 3-D conv backbone -> .dense() BEV -> dense RPN (MFMA) -> proposal stage (top-k, decode, rotated
-NMS, score cut), all hand-written HIP, replayed as one HIP graph (~55 kernels) with a single 4-byte host read.  By default two frames are in flight per
-GPU (two graphs on two streams: the launch-latency-bound sparse half of one frame overlaps the MFMA-bound dense
-half of the other); every step submits one frame and the timed region completes exactly K of them.  The same
+NMS, score cut), all hand-written HIP, replayed as one HIP graph (~55 kernels) with a single 4-byte host read.  By default several frames are in flight per
+GPU (one graph, stream and plan arena each: the launch-latency-bound sparse half of one frame overlaps the MFMA-bound dense
+half of the others; up to 4, streams and depth picked by measurement before the warm-up -- config.pipeline_tuning); every step
+submits one frame and the timed region completes exactly K of them.  The same
 graph run one frame at a time is reported as single_frame_ms / frames_per_s_one_at_a_time.  The cloud is resident in HBM before the timed region.  Frames are independent, so N GPUs run N
 replicas on different frames with no data-path collective (weak scaling); the only communication is the
 timing barrier / max-reduce.  Rank 0 prints ONE JSON line.
@@ -25,6 +26,10 @@ import os
 import sys
 import time
 
+# more hardware queues for the runtime to spread streams over (the pipeline picks its streams by measurement, see
+# vision3d_amd/detector/graph.py:PipelinedSecond.tune); must be set before the HIP runtime starts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -38,6 +43,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # (env parsing, barrier, max-over-ranks, rank-0 JSON) where there are fewer GPUs than ranks: ranks then share devices.
 BACKEND = os.environ.get("V3D_BENCH_BACKEND", "nccl")
 REDUCE_DEVICE = "cuda" if BACKEND == "nccl" else "cpu"
+MAX_PIPELINE = int(os.environ.get("V3D_BENCH_MAX_PIPELINE", "4"))  # slots the autotuned pipeline may use
 
 
 def parse():
@@ -58,11 +64,12 @@ def parse():
                          "all-reduce over RCCL) -- a secondary line, same JSON contract")
     ap.add_argument("--no-channels-last", action="store_true", help="train mode: keep the dense RPN/head in NCHW")
     ap.add_argument("--no-amp", action="store_true", help="train mode: keep the dense RPN/head in fp32 (default bf16 autocast)")
-    ap.add_argument("--pipeline", type=int, default=2,
-                    help="frames in flight per GPU (graph path).  2 (default): throughput mode -- two independent bs=1 frames "
-                         "overlap on two streams / HIP graphs / plan arenas, every step still submits ONE frame and the "
-                         "timed region completes exactly K frames; 1: one frame at a time (reported beside it as "
-                         "single_frame_ms / frames_per_s_one_at_a_time)")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="frames in flight per GPU (graph path).  Throughput mode: independent bs=1 frames overlap on separate "
+                         "streams / HIP graphs / plan arenas; every step still submits ONE frame and the timed region completes "
+                         "exactly K frames.  0 (default): up to 4 in flight, streams and depth picked by measurement before the "
+                         "warm-up (PipelinedSecond.tune); N >= 2: exactly N on streams in creation order; 1: one frame at a time "
+                         "(always reported beside it as single_frame_ms / frames_per_s_one_at_a_time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch event timing pass (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=3)
@@ -248,8 +255,11 @@ def main():
     graphed = None
     if args.path == "graph":
         with torch.no_grad():
-            if args.pipeline > 1:
-                graphed = model.pipelined_inference(anchors, [c.shape[0] for c in clouds], args.pipeline)
+            if args.pipeline != 1:
+                graphed = model.pipelined_inference(anchors, [c.shape[0] for c in clouds], args.pipeline or MAX_PIPELINE,
+                                                    autotune=args.pipeline == 0)
+                if args.pipeline == 0:
+                    graphed.tune(clouds)  # outside warm-up and timed region
             else:
                 graphed = model.graphed_inference(anchors, [c.shape[0] for c in clouds])
     last_out = [None]
@@ -276,13 +286,14 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
-    if args.pipeline > 1 and args.path == "graph":
+    pipelined = args.pipeline != 1 and args.path == "graph"
+    if pipelined:
         graphed.flush()  # the timed region starts with an empty pipeline
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    if args.pipeline > 1 and args.path == "graph":
+    if pipelined:
         # K steps submitted K frames; the ones still in flight are collected inside the timed region: steps == frames
         rest = graphed.flush()
         out = rest[-1] if rest else last_out[0]
@@ -294,7 +305,7 @@ def main():
     # one frame at a time through the same captured graph (latency view of the same work), not part of `value`
     single_ms = None
     if args.path == "graph":
-        g1 = graphed.slots[0] if args.pipeline > 1 else graphed
+        g1 = graphed.slots[0] if pipelined else graphed
         with torch.no_grad():
             for _ in range(5):
                 g1(clouds)
@@ -429,9 +440,10 @@ def main():
                     scaling="weak", vs_baseline=None, dtype="bf16x3 (fp32 operands split hi+lo, 3 bf16 MFMAs, fp32 accumulate: fp32-class, parity 1e-4)", data="synthetic",
                     config=dict(workload=wl,
                                 frames_per_gpu_per_step=args.batch, points_per_frame=args.points,
-                                parallelism=f"frame-parallel replicas x{world}", pipeline_depth=args.pipeline,
+                                parallelism=f"frame-parallel replicas x{world}", pipeline_depth=(graphed.depth if pipelined else 1),
+                                pipeline_tuning=(graphed.tuned if pipelined else None),
                                 path={"graph": "native backbone plan + bf16x3 MFMA dense head + device proposal stage, one HIP graph per "
-                                               "frame" + (f", {args.pipeline} frames in flight" if args.pipeline > 1 else ""),
+                                               "frame" + (f", {graphed.depth} frames in flight" if pipelined else ""),
                                       "native": "native backbone plan + bf16x3 MFMA dense head", "fused": "native backbone plan + torch RPN",
                                       "eager": "eager python -> C ABI"}[args.path]),
                     single_frame_ms=single_ms,

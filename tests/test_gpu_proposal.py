@@ -124,19 +124,21 @@ def test_graph_and_eager_native_paths_agree():
         assert torch.equal(a, b)
 
 
-def test_pipelined_frames_match_single_frame_graph():
-    """Throughput mode (two frames in flight on two streams / graphs / plan arenas): every frame's result equals the
-    one-frame-at-a-time graph result, in submission order, for a stream of DIFFERENT clouds of the same size."""
+@pytest.mark.parametrize("autotune", [False, True], ids=["two_streams", "autotuned_streams"])
+def test_pipelined_frames_match_single_frame_graph(autotune):
+    """Throughput mode (frames in flight on separate streams / graphs / plan arenas; fixed depth 2, or depth and streams
+    picked by measurement on the first frame): every frame's result equals the one-frame-at-a-time graph result, in
+    submission order, for a stream of DIFFERENT clouds of the same size."""
     from test_gpu_dense_conv import build_model  # randomised BatchNorm + larger head weights: outputs depend on the cloud
     from vision3d_amd import synth
     cfg = second_car_cfg()
     model = build_model(3)
     anchors = AnchorGenerator(cfg).anchors.cuda()
-    frames = [[torch.from_numpy(synth.make_cloud(s)).cuda()] for s in (1, 2, 3, 4, 5)]
+    frames = [[torch.from_numpy(synth.make_cloud(s)).cuda()] for s in (1, 2, 3, 4, 5, 6, 7)]
     with torch.no_grad():
         single = model.graphed_inference(anchors, [frames[0][0].shape[0]])
         want = [[t.clone() for t in single(f)] for f in frames]
-        pipe = model.pipelined_inference(anchors, [frames[0][0].shape[0]], depth=2)
+        pipe = model.pipelined_inference(anchors, [frames[0][0].shape[0]], depth=3 if autotune else 2, autotune=autotune)
         got = []
         for f in frames:
             r = pipe(f)
@@ -144,6 +146,8 @@ def test_pipelined_frames_match_single_frame_graph():
                 got.append(r)
         got += pipe.flush()
     assert len(got) == len(want)
+    if autotune:
+        assert pipe.tuned is not None and 2 <= pipe.depth <= 3 and pipe.tuned["depth"] == pipe.depth
     distinct = {tuple(w[0].cpu().numpy().round(4).ravel()[:70]) for w in want}
     assert len(distinct) > 1, "test frames must give different proposals"
     for g, w in zip(got, want):

@@ -8,7 +8,7 @@ cfg = second_car_cfg(); torch.manual_seed(0)
 model = Second(cfg).cuda().eval()
 anchors = AnchorGenerator(cfg).anchors.cuda()
 clouds = [torch.from_numpy(synth.make_cloud(0, 16384)).cuda()]
-for depth in (2, 3):
+for depth in (2, 3, 4):
     with torch.no_grad():
         pipe = model.pipelined_inference(anchors, [16384], depth)
         for _ in range(10): pipe(clouds)

@@ -69,43 +69,123 @@ class GraphedSecond(object):
 class PipelinedSecond(object):
     """Throughput mode for independent frames: `depth` GraphedSecond instances (own plan arena, own static buffers, own
     HIP graph) on `depth` streams.  The sparse half of a frame is a chain of small launches that fills a fraction of
-    the chip; with two frames in flight it overlaps the other frame's dense head.  Latency per frame is unchanged;
+    the chip; with several frames in flight it overlaps the other frames' dense heads.  Latency per frame is unchanged;
     results come back in submission order.
 
         run.submit(clouds)        # copy + graph launch on the next slot's stream, returns immediately
         run.collect()             # oldest frame in flight: waits for ITS stream only, -> (boxes, batch, class, scores)
+
+    Which streams: two HIP streams only overlap if their hardware queues sit on different command-processor pipes,
+    and the runtime gives no handle on that (measured on one MI355X with 2 / 3 / 4 streams taken in creation order
+    and GPU_MAX_HW_QUEUES = 4, 8, 16: 434 / 530 / 445, 468 / 347 / 523, 483 / 644 / 369 us per frame -- luck of the
+    mapping, not depth).  With `autotune=True` (depth = the maximum) the first submitted frame is used to MEASURE: the
+    slots are captured, every pair out of 8 candidate streams runs a few frames, the best pair is extended greedily
+    while a deeper pipeline still pays, and that stream set is kept.
     """
 
-    def __init__(self, model, anchors, frame_sizes, depth=2):
+    CANDIDATE_STREAMS = 8
+    TUNE_FRAMES = 8
+
+    def __init__(self, model, anchors, frame_sizes, depth=2, autotune=False):
         dev = next(model.parameters()).device
         self.slots = [GraphedSecond(model, anchors, frame_sizes, slot=i) for i in range(depth)]
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        self.autotune, self.tuned = bool(autotune), None
         self.pending = []  # slot indices in submission order
         self.next_slot = 0
 
-    def submit(self, clouds):
-        i = self.next_slot
-        assert i not in self.pending, "collect() the oldest frame before reusing its slot"
-        g, st = self.slots[i], self.streams[i]
-        st.wait_stream(torch.cuda.current_stream())  # the caller's cloud tensors are ready
-        with torch.cuda.stream(st), torch.no_grad():
+    @property
+    def depth(self):
+        return len(self.streams)
+
+    # ---- one frame on one slot -------------------------------------------------------------------------------
+    def _launch(self, i, stream, clouds):
+        g = self.slots[i]
+        stream.wait_stream(torch.cuda.current_stream())  # the caller's cloud tensors are ready
+        with torch.cuda.stream(stream), torch.no_grad():
             g.load(clouds)
             if g.graph is None:
                 g._capture()
             g.graph.replay()
+
+    def _finish(self, i, stream):
+        g = self.slots[i]
+        with torch.cuda.stream(stream):
+            return g.model.head.finalize_native(*g.outputs) if g.native else g.model.head.finalize(*g.outputs)
+
+    # ---- stream selection by measurement ---------------------------------------------------------------------
+    def _time_streams(self, streams, clouds, frames):
+        import time
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0, inflight = time.perf_counter(), []
+            for f in range(frames):
+                i = f % len(streams)
+                if len(inflight) == len(streams):
+                    j = inflight.pop(0)
+                    self._finish(j, streams[j])
+                self._launch(i, streams[i], clouds)
+                inflight.append(i)
+            for j in inflight:
+                self._finish(j, streams[j])
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / frames
+            best = t if best is None else min(best, t)
+        return best
+
+    def tune(self, clouds):
+        """Pick the stream set (and depth <= len(slots)) that gives the shortest time per frame on THIS frame."""
+        dev = self.slots[0].static_points.device
+        cands = [torch.cuda.Stream(device=dev) for _ in range(self.CANDIDATE_STREAMS)]
+        for i in range(len(self.slots)):  # capture every slot (tunes the plans on the real frame), one at a time
+            self._launch(i, cands[0], clouds)
+            self._finish(i, cands[0])
+        n = self.TUNE_FRAMES
+        log = {}
+        if len(self.slots) == 1:
+            chosen, t_best = [cands[0]], None
+        else:
+            pairs = [(a, b) for a in range(len(cands)) for b in range(a + 1, len(cands))]
+            times = {ab: self._time_streams([cands[ab[0]], cands[ab[1]]], clouds, n) for ab in pairs}
+            ab = min(times, key=times.get)
+            chosen, t_best = list(ab), times[ab]
+            log[2] = t_best
+            while len(chosen) < len(self.slots):
+                rest = [c for c in range(len(cands)) if c not in chosen]
+                trial = {c: self._time_streams([cands[x] for x in chosen + [c]], clouds, n + len(chosen)) for c in rest}
+                c = min(trial, key=trial.get)
+                log[len(chosen) + 1] = trial[c]
+                if trial[c] > 0.97 * t_best:  # a deeper pipeline has to pay for its arena
+                    break
+                chosen, t_best = chosen + [c], trial[c]
+            chosen = [cands[x] for x in chosen]
+        self.streams = chosen
+        self.tuned = dict(depth=len(chosen), us_per_frame={k: round(v * 1e6, 1) for k, v in log.items()})
+        self.pending, self.next_slot = [], 0
+        return self.tuned
+
+    # ---- the pipeline ----------------------------------------------------------------------------------------
+    def submit(self, clouds):
+        if self.autotune and self.tuned is None:
+            self.tune(clouds)
+        i = self.next_slot
+        assert i not in self.pending, "collect() the oldest frame before reusing its slot"
+        self._launch(i, self.streams[i], clouds)
         self.pending.append(i)
-        self.next_slot = (i + 1) % len(self.slots)
+        self.next_slot = (i + 1) % self.depth
 
     def collect(self):
         i = self.pending.pop(0)
-        g = self.slots[i]
+        out = self._finish(i, self.streams[i])
         with torch.cuda.stream(self.streams[i]):
-            out = g.model.head.finalize_native(*g.outputs) if g.native else g.model.head.finalize(*g.outputs)
-        return [t.clone() for t in out]  # the slot's static buffers are overwritten by its next frame
+            return [t.clone() for t in out]  # the slot's static buffers are overwritten by its next frame
 
     def __call__(self, clouds):
         """submit this frame, return the oldest finished one once the pipeline is full (None while it fills)."""
-        if len(self.pending) == len(self.slots):
+        if self.autotune and self.tuned is None:
+            self.tune(clouds)
+        if len(self.pending) == self.depth:
             out = self.collect()
             self.submit(clouds)
             return out

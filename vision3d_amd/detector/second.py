@@ -175,11 +175,12 @@ class Second(nn.Module):
         from .graph import GraphedSecond
         return GraphedSecond(self, anchors, frame_sizes)
 
-    def pipelined_inference(self, anchors, frame_sizes, depth=2):
+    def pipelined_inference(self, anchors, frame_sizes, depth=2, autotune=False):
         """Throughput mode: `depth` captured graphs on `depth` streams, frame i+1 is submitted before frame i's result
-        is collected (see detector/graph.py:PipelinedSecond).  `run.submit(clouds)`, `run.collect()`."""
+        is collected (see detector/graph.py:PipelinedSecond).  `run.submit(clouds)`, `run.collect()`.
+        autotune: `depth` is the maximum; streams and depth are picked by measurement on the first frame."""
         from .graph import PipelinedSecond
-        return PipelinedSecond(self, anchors, frame_sizes, depth)
+        return PipelinedSecond(self, anchors, frame_sizes, depth, autotune)
 
     def inference_points(self, clouds, anchors, dense="mfma", proposals="native"):
         """Same result as `inference(Preprocessor(cfg)(...))` without materialising the intermediate dict.
