@@ -39,7 +39,7 @@ for (a, k) in cap:
     if cin < 32: continue
     row = f"{cin:3d}->{cout:3d} K={rb.nbr.shape[0]:2d} n={rb.n:6d} cap={rb.cap:6d} "
     ref = None
-    for mt in (1, 10, 11):
+    for mt in (1, 10, 11, 5):
         raw.v3d_debug_set_rows_mt(mt)
         ts = []
         for trial in range(4):
