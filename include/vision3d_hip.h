@@ -172,7 +172,9 @@ int v3d_sparse_conv_bwd_weight(const float* X, const float* dY, const int32_t* n
 
 /* Timing harness (bench.py, tools/): every subsequent sparse-conv launch is issued n times back to back. */
 void v3d_debug_set_repeat(int n);
-/* Debug/benchmark aid: force the row-tile count of the packed sparse kernel (0 = automatic, 1, 2, 4). */
+/* Debug/benchmark aid: force the variant of the packed sparse kernel.  0 = automatic (3x3x3, Cin/Cout in {32, 64}: LDS-ring
+ * kernel up to 16 384 live rows, 64-row kernel from 32 768, 16-row kernel otherwise); 1 = 16-row kernel; 2 / 4 = register
+ * tiles (measured slower); 5 = 64-row LDS-shared-weights kernel; 10 / 11 = LDS-ring kernel with 3 / 2 offsets per round. */
 void v3d_debug_set_rows_mt(int mt);
 /* Debug/benchmark aid: dense convolution kernel choice (0 = automatic, 1 = 64-pixel tile, 2 = 144-pixel tile). */
 void v3d_debug_set_dense_variant(int v);

@@ -1161,7 +1161,7 @@ static void launch_rows_big(const float* in, const void* wimg, const int* nbr, c
                        (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out);
 }
 
-int g_v3d_rows_mt = 0;  // 0 = pick from the capacity, 1 / 2 / 4 = force (microbenchmarks)
+int g_v3d_rows_mt = 0;  // 0 = pick from rows_hint; 1 / 2 / 4 / 5 / 10 / 11 = force a variant (include/vision3d_hip.h, microbenchmarks)
 extern "C" void v3d_debug_set_rows_mt(int mt) { g_v3d_rows_mt = mt; }
 
 template <int CIN, int COUT, int MT>
