@@ -124,6 +124,24 @@ def test_tiny_and_empty_inputs(oracle):
     assert out.dense().shape == (1, 16, 8, 80, 160)
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64)])
+def test_ring_kernel_edge_sizes(oracle, cin, cout):
+    """The default 3x3x3 kernel for 32/64-channel layers (two 16-row tiles per workgroup) at the sizes where its tiling has
+    edges: one row, one tile, one workgroup +- 1 row, a dead second tile, an odd number of workgroups; capacity larger than
+    the live count (the kernel reads the count from device memory and most workgroups must exit)."""
+    from vision3d_amd import spconv
+    conv = spconv.SubMConv3d(cin, cout, 3, indice_key="k", bias=False).cuda()
+    w = conv.weight.detach().cpu().numpy()
+    for n in (1, 15, 16, 17, 31, 32, 33, 48, 95, 161):
+        coords = np.stack([np.zeros(n), np.arange(n) % 5, (np.arange(n) // 5) % 40, np.arange(n) // 200 + (np.arange(n) % 3)], 1).astype(np.int32)
+        coords = np.unique(coords, axis=0)
+        m = len(coords)
+        feats = np.random.default_rng(n).standard_normal((m, cin)).astype(np.float32)
+        out = conv(make_tensor(coords, feats, [8, 80, 160], 1))
+        ref = oracle.sparse_conv_fwd(feats, w, oracle.subm_rulebook(coords, [8, 80, 160], 3))
+        assert_features_close(out.features.detach().cpu().numpy(), ref, f"ring n={m}")
+
+
 def test_densify_exact(oracle):
     rng = np.random.default_rng(3)
     coords = kitti_coords(oracle, [5, 6])
