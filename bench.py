@@ -72,7 +72,7 @@ def parse():
                          "(always reported beside it as single_frame_ms / frames_per_s_one_at_a_time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch event timing pass (profiling runs)")
-    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (about 1.4 s each on one core: ~11 s)")
     return ap.parse_args()
 
 
