@@ -176,6 +176,9 @@ void v3d_debug_set_repeat(int n);
  * kernel up to 16 384 live rows, 64-row kernel from 32 768, 16-row kernel otherwise); 1 = 16-row kernel; 2 / 4 = register
  * tiles (measured slower); 5 = 64-row LDS-shared-weights kernel; 10 / 11 = LDS-ring kernel with 3 / 2 offsets per round. */
 void v3d_debug_set_rows_mt(int mt);
+/* Debug/benchmark aid: 0 = build the NMS suppression mask with one wave per (row, 64-column block) at every size; 1 (default) =
+ * one wave per row with near-pair compaction beyond 128 boxes. */
+void v3d_debug_set_nms_rows(int on);
 /* Debug/benchmark aid: dense convolution kernel choice (0 = automatic, 1 = 64-pixel tile, 2 = 144-pixel tile). */
 void v3d_debug_set_dense_variant(int v);
 

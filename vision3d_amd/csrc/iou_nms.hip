@@ -133,6 +133,67 @@ __global__ __launch_bounds__(V3D_WAVE) void nms_mask_kernel(const BoxPrep* __res
   if (lane == 0) mask[(size_t)row * nwords + cb] = word;
 }
 
+// The same mask for N > 128, one WAVE PER ROW.  In the kernel above a wave runs the polygon clipper as soon as ONE of its
+// 64 column boxes is near the row box -- in score order that is almost every wave, although only a few per cent of the
+// pairs are near (proposal stage, 1 000 boxes: 8 000 waves, all on the slow path, 19 us).  Here the wave walks the row's
+// column blocks with the exact disjointness test only (iou_needs_clip: the pairs it rejects have IoU = +0.0f in the
+// reference too), compacts the surviving columns into an LDS queue and runs the clipper on 64 QUEUED pairs at a time --
+// typically once per row.  Bit-identical mask; words are assembled in LDS (queued hits arrive out of order) and written
+// once.
+__global__ __launch_bounds__(V3D_BLOCK) void nms_mask_rows_kernel(const BoxPrep* __restrict__ prep, int N, int nwords,
+                                                                  float thr, unsigned long long* __restrict__ mask) {
+  extern __shared__ unsigned long long nms_rows_sm[];  // per wave: words[nwords], queue[128] (ints)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * (V3D_BLOCK / V3D_WAVE) + wave;
+  if (row >= N) return;  // (no workgroup barrier below)
+  unsigned long long* words = nms_rows_sm + (size_t)wave * (nwords + 64);
+  int* queue = reinterpret_cast<int*>(words + nwords);
+  const BoxPrep br = prep[row];
+  const bool zero_hits = 0.f >= thr;  // thr <= 0: disjoint pairs "overlap" too
+  const int cb0 = row >> 6;           // words left of the diagonal block are never read
+  int cnt = 0;                        // queued columns (wave-uniform)
+  auto clip = [&](int m) {
+    if (lane < m) {
+      const int col = queue[lane];
+      if (v3d::iou_prepped(br, prep[col]) >= thr) atomicOr(&words[col >> 6], 1ull << (col & 63));
+    }
+  };
+  for (int cb = cb0; cb < nwords; cb++) {
+    const int col = cb * 64 + lane;
+    bool near = false, far_hit = false;
+    if (col < N && col > row) {
+      near = v3d::iou_needs_clip(br, prep[col]);
+      far_hit = !near && zero_hits;
+    }
+    const unsigned long long nm = __ballot(near), fm = __ballot(far_hit);
+    if (lane == 0) words[cb] = fm;
+    if (near) queue[cnt + __popcll(nm & ((1ull << lane) - 1ull))] = col;
+    cnt += __popcll(nm);
+    if (cnt >= 64) {
+      clip(64);
+      const int rem = cnt - 64;
+      const int v = lane < rem ? queue[64 + lane] : 0;
+      if (lane < rem) queue[lane] = v;
+      cnt = rem;
+    }
+  }
+  clip(cnt);
+  for (int w = cb0 + lane; w < nwords; w += 64) mask[(size_t)row * nwords + w] = words[w];
+}
+
+static int g_v3d_nms_rows = 1;  // 0: one wave per (row, column block) at every size (microbenchmarks)
+extern "C" void v3d_debug_set_nms_rows(int on) { g_v3d_nms_rows = on; }
+
+static void launch_nms_mask(const BoxPrep* prep, int N, int nwords, float thr, unsigned long long* mask, hipStream_t st) {
+  if (nwords <= 2 || !g_v3d_nms_rows) {  // inference shape (N ~ 100): one evaluation per lane is already the whole latency
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, N), dim3(V3D_WAVE), 0, st, prep, N, nwords, thr, mask);
+  } else {
+    constexpr int RPB = V3D_BLOCK / V3D_WAVE;
+    hipLaunchKernelGGL(nms_mask_rows_kernel, dim3(v3d_ceil_div(N, RPB)), dim3(V3D_BLOCK), (size_t)RPB * (nwords + 64) * 8, st, prep, N,
+                       nwords, thr, mask);
+  }
+}
+
 // NMS step 4: greedy reduction on the device.
 __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
@@ -195,8 +256,7 @@ int v3d_i_nms_sorted(const void* prep_sorted, const int* order, int N, float iou
                      unsigned long long* mask, unsigned long long* remv, hipStream_t st) {
   if (N < 1 || N > 65535) return V3D_EUNSUPPORTED;
   const int nwords = (N + 63) / 64;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, N), dim3(V3D_WAVE), 0, st, (const BoxPrep*)prep_sorted, N, nwords,
-                     iou_threshold, mask);
+  launch_nms_mask((const BoxPrep*)prep_sorted, N, nwords, iou_threshold, mask, st);
   hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(V3D_BLOCK), 0, st, mask, order, N, nwords, remv, (long long*)keep,
                      n_keep);
   V3D_CHECK_LAUNCH();
@@ -238,7 +298,7 @@ extern "C" int v3d_nms_rotated(const float* boxes, const float* scores, int N, f
   }
   hipLaunchKernelGGL(nms_gather_kernel, dim3(v3d_ceil_div(N, 256)), dim3(256), 0, st, keys, boxes, N, order, prep);
   if (N > 65535) return V3D_EUNSUPPORTED;  // grid.y limit
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, N), dim3(V3D_WAVE), 0, st, prep, N, nwords, iou_threshold, mask);
+  launch_nms_mask(prep, N, nwords, iou_threshold, mask, st);
   hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(V3D_BLOCK), 0, st, mask, order, N, nwords, remv,
                      (long long*)keep, n_keep);
   V3D_CHECK_LAUNCH();

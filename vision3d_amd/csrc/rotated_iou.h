@@ -227,14 +227,17 @@ V3D_HD BoxPrep prep_box(const float* b) {
 // utils.h:313-340.  Early exit: when the centre distance exceeds the sum of the circumradii (with a
 // 1% + 1e-3 margin) the rectangles are disjoint, the reference finds no intersection point and
 // returns inter = 0, i.e. exactly 0/(a1+a2) = +0.0f -- the same value without running the clipper.
+V3D_HD bool iou_needs_clip(const BoxPrep& a, const BoxPrep& b) {  // false <=> iou_prepped returns +0.0f without the clipper
+  if (a.area < 1e-14 || b.area < 1e-14) return false;
+  const float dx = a.x - b.x, dy = a.y - b.y;
+  const float ra = 0.5f * sqrtf(a.w * a.w + a.h * a.h), rb = 0.5f * sqrtf(b.w * b.w + b.h * b.h);
+  const float reach = (ra + rb) * 1.01f + 1e-3f;
+  if (dx * dx + dy * dy > reach * reach && (a.area + b.area) > 0.f && (a.area + b.area) < 3.0e38f) return false;
+  return true;
+}
+
 V3D_HD float iou_prepped(const BoxPrep& a, const BoxPrep& b) {
-  if (a.area < 1e-14 || b.area < 1e-14) return 0.f;
-  {
-    const float dx = a.x - b.x, dy = a.y - b.y;
-    const float ra = 0.5f * sqrtf(a.w * a.w + a.h * a.h), rb = 0.5f * sqrtf(b.w * b.w + b.h * b.h);
-    const float reach = (ra + rb) * 1.01f + 1e-3f;
-    if (dx * dx + dy * dy > reach * reach && (a.area + b.area) > 0.f && (a.area + b.area) < 3.0e38f) return 0.f;
-  }
+  if (!iou_needs_clip(a, b)) return 0.f;
   const double csx = (a.x + b.x) / 2.0;
   const double csy = (a.y + b.y) / 2.0;
   P2 p1[4], p2[4];
