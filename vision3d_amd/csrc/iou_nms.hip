@@ -25,6 +25,8 @@ __global__ __launch_bounds__(V3D_BLOCK) void box_iou_rotated_kernel(const float*
                                                                     const float* __restrict__ b2, int N,
                                                                     float* __restrict__ out) {
   __shared__ BoxPrep rows[IOU_ROWS];
+  __shared__ v3d::P2 clip_pts[V3D_BLOCK / V3D_WAVE][24 * 64];  // the clipper's work arrays: LDS, not scratch (rotated_iou.h)
+  __shared__ float clip_dist[V3D_BLOCK / V3D_WAVE][24 * 64];
   const int row0 = blockIdx.y * IOU_ROWS;
   const int nrows = min(IOU_ROWS, M - row0);
   if ((int)threadIdx.x < nrows) rows[threadIdx.x] = v3d::prep_box(b1 + 5 * (size_t)(row0 + threadIdx.x));
@@ -32,7 +34,9 @@ __global__ __launch_bounds__(V3D_BLOCK) void box_iou_rotated_kernel(const float*
   const int j = blockIdx.x * V3D_BLOCK + threadIdx.x;
   if (j >= N) return;
   const BoxPrep bj = v3d::prep_box(b2 + 5 * (size_t)j);
-  for (int r = 0; r < nrows; r++) out[(size_t)(row0 + r) * N + j] = v3d::iou_prepped(rows[r], bj);
+  v3d::P2* pts = clip_pts[threadIdx.x >> 6] + (threadIdx.x & 63);
+  float* dist = clip_dist[threadIdx.x >> 6] + (threadIdx.x & 63);
+  for (int r = 0; r < nrows; r++) out[(size_t)(row0 + r) * N + j] = v3d::iou_prepped_lds(rows[r], bj, pts, dist);
 }
 
 extern "C" int v3d_box_iou_rotated(const float* boxes1, int M, const float* boxes2, int N, float* ious,
@@ -121,13 +125,15 @@ __global__ __launch_bounds__(V3D_WAVE) void nms_mask_kernel(const BoxPrep* __res
                                                             float thr, unsigned long long* __restrict__ mask) {
   const int cb = blockIdx.x, row = blockIdx.y;
   if (cb < (row >> 6)) return;  // words left of the diagonal block are never read
+  __shared__ v3d::P2 clip_pts[24 * 64];  // the clipper's work arrays, lane-interleaved (rotated_iou.h: LDS instead of scratch)
+  __shared__ float clip_dist[24 * 64];
   const int lane = threadIdx.x;
   const int col = cb * 64 + lane;
   bool hit = false;
   if (col < N && col > row) {
     const BoxPrep br = prep[row];  // same address in every lane: one broadcast load
     const BoxPrep bc = prep[col];
-    hit = v3d::iou_prepped(br, bc) >= thr;
+    hit = v3d::iou_prepped_lds(br, bc, clip_pts + lane, clip_dist + lane) >= thr;
   }
   const unsigned long long word = __ballot(hit);
   if (lane == 0) mask[(size_t)row * nwords + cb] = word;
@@ -143,6 +149,8 @@ __global__ __launch_bounds__(V3D_WAVE) void nms_mask_kernel(const BoxPrep* __res
 __global__ __launch_bounds__(V3D_BLOCK) void nms_mask_rows_kernel(const BoxPrep* __restrict__ prep, int N, int nwords,
                                                                   float thr, unsigned long long* __restrict__ mask) {
   extern __shared__ unsigned long long nms_rows_sm[];  // per wave: words[nwords], queue[128] (ints)
+  __shared__ v3d::P2 clip_pts[V3D_BLOCK / V3D_WAVE][24 * 64];  // the clipper's work arrays, one lane-interleaved slab per wave
+  __shared__ float clip_dist[V3D_BLOCK / V3D_WAVE][24 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * (V3D_BLOCK / V3D_WAVE) + wave;
   if (row >= N) return;  // (no workgroup barrier below)
@@ -155,7 +163,8 @@ __global__ __launch_bounds__(V3D_BLOCK) void nms_mask_rows_kernel(const BoxPrep*
   auto clip = [&](int m) {
     if (lane < m) {
       const int col = queue[lane];
-      if (v3d::iou_prepped(br, prep[col]) >= thr) atomicOr(&words[col >> 6], 1ull << (col & 63));
+      if (v3d::iou_prepped_lds(br, prep[col], clip_pts[wave] + lane, clip_dist[wave] + lane) >= thr)
+        atomicOr(&words[col >> 6], 1ull << (col & 63));
     }
   };
   for (int cb = cb0; cb < nwords; cb++) {

@@ -58,8 +58,25 @@ V3D_HD bool hull_less(const P2 A, const P2 B) {
   return t > 0;
 }
 
+// ---- point / distance work arrays --------------------------------------------------------------
+// The clipper indexes its <= 24-point arrays dynamically, so as plain locals they live in SCRATCH (400 bytes per
+// lane: every access is a global-memory round trip -- the 19 us of one NMS mask evaluation were mostly that).  The
+// algorithms below are written against a strided view instead: stride 1 over locals (host, and kernels that keep the
+// scratch form), stride 64 over a per-wave LDS slab in which element e of lane L sits at [e * 64 + L] (conflict-free).
+template <int S>
+struct P2View {
+  P2* p;
+  V3D_HD P2& operator[](int i) const { return p[i * S]; }
+};
+template <int S>
+struct F1View {
+  float* p;
+  V3D_HD float& operator[](int i) const { return p[i * S]; }
+};
+
 // ---- std::sort (libstdc++ introsort) visiting order, for n <= 23 elements -------------------------
-V3D_HD void ins_unguarded(P2* a, int last) {
+template <class A>
+V3D_HD void ins_unguarded(A a, int last) {
   const P2 val = a[last];
   int next = last - 1;
   while (hull_less(val, a[next])) {
@@ -69,7 +86,8 @@ V3D_HD void ins_unguarded(P2* a, int last) {
   }
   a[last] = val;
 }
-V3D_HD void ins_sort(P2* a, int first, int last) {  // [first, last)
+template <class A>
+V3D_HD void ins_sort(A a, int first, int last) {  // [first, last)
   for (int i = first + 1; i < last; ++i) {
     if (hull_less(a[i], a[first])) {
       const P2 val = a[i];
@@ -80,12 +98,14 @@ V3D_HD void ins_sort(P2* a, int first, int last) {  // [first, last)
     }
   }
 }
-V3D_HD void swap2(P2* a, int i, int j) {
+template <class A>
+V3D_HD void swap2(A a, int i, int j) {
   const P2 t = a[i];
   a[i] = a[j];
   a[j] = t;
 }
-V3D_HD void median_to_first(P2* q, int result, int a, int b, int c) {
+template <class A>
+V3D_HD void median_to_first(A q, int result, int a, int b, int c) {
   if (hull_less(q[a], q[b])) {
     if (hull_less(q[b], q[c])) swap2(q, result, b);
     else if (hull_less(q[a], q[c])) swap2(q, result, c);
@@ -94,7 +114,8 @@ V3D_HD void median_to_first(P2* q, int result, int a, int b, int c) {
   else if (hull_less(q[b], q[c])) swap2(q, result, c);
   else swap2(q, result, b);
 }
-V3D_HD int unguarded_partition(P2* q, int first, int last, int pivot) {
+template <class A>
+V3D_HD int unguarded_partition(A q, int first, int last, int pivot) {
   for (;;) {
     while (hull_less(q[first], q[pivot])) ++first;
     --last;
@@ -105,7 +126,8 @@ V3D_HD int unguarded_partition(P2* q, int first, int last, int pivot) {
   }
 }
 // sort q[first, last) exactly as std::sort would (depth limit is never reached for n <= 23)
-V3D_HD void std_sort(P2* q, int first, int last) {
+template <class A>
+V3D_HD void std_sort(A q, int first, int last) {
   if (last - first <= 1) return;
   // introsort loop, recursion on the right part unrolled into a small explicit stack
   int stack_first[6], stack_last[6], sp = 0;
@@ -135,9 +157,11 @@ V3D_HD void std_sort(P2* q, int first, int last) {
   }
 }
 
-// Intersection area of two rectangles given their vertices (utils.h:76-309).
-V3D_HD float intersection_area(const P2 (&p1)[4], const P2 (&p2)[4]) {
-  P2 ip[24];
+// Intersection area of two rectangles given their vertices (utils.h:76-309).  q: 24 points, dist: 24 floats of work
+// space (the intersection points are shifted in place: the reference's separate `ip` and `q` hold ip[i] and
+// ip[i] - start, and ip is dead once q is built).
+template <class A, class F>
+V3D_HD float intersection_area_ws(const P2 (&p1)[4], const P2 (&p2)[4], A q, F dist) {
   int num = 0;
   P2 v1[4], v2[4];
 #pragma unroll
@@ -153,8 +177,7 @@ V3D_HD float intersection_area(const P2 (&p1)[4], const P2 (&p2)[4]) {
       const float t1 = cross2(v2[j], v12) / det;
       const float t2 = cross2(v1[i], v12) / det;
       if (t1 >= 0.0f && t1 <= 1.0f && t2 >= 0.0f && t2 <= 1.0f) {
-        ip[num].x = p1[i].x + v1[i].x * t1;
-        ip[num].y = p1[i].y + v1[i].y * t1;
+        q[num] = P2{p1[i].x + v1[i].x * t1, p1[i].y + v1[i].y * t1};
         num++;
       }
     }
@@ -166,7 +189,7 @@ V3D_HD float intersection_area(const P2 (&p1)[4], const P2 (&p2)[4]) {
       const P2 AP = sub2(p1[i], p2[0]);
       const float APdotAB = dot2(AP, AB);
       const float APdotAD = -dot2(AP, DA);
-      if (APdotAB >= 0 && APdotAD >= 0 && APdotAB <= ABdotAB && APdotAD <= ADdotAD) ip[num++] = p1[i];
+      if (APdotAB >= 0 && APdotAD >= 0 && APdotAB <= ABdotAB && APdotAD <= ADdotAD) q[num++] = p1[i];
     }
   }
   {
@@ -176,21 +199,24 @@ V3D_HD float intersection_area(const P2 (&p1)[4], const P2 (&p2)[4]) {
       const P2 AP = sub2(p2[i], p1[0]);
       const float APdotAB = dot2(AP, AB);
       const float APdotAD = -dot2(AP, DA);
-      if (APdotAB >= 0 && APdotAD >= 0 && APdotAB <= ABdotAB && APdotAD <= ADdotAD) ip[num++] = p2[i];
+      if (APdotAB >= 0 && APdotAD >= 0 && APdotAB <= ABdotAB && APdotAD <= ADdotAD) q[num++] = p2[i];
     }
   }
   if (num <= 2) return 0.0f;
 
   // Graham scan (utils.h:157-270, shift_to_zero = true)
   int t = 0;
-  for (int i = 1; i < num; i++)
-    if (ip[i].y < ip[t].y || (ip[i].y == ip[t].y && ip[i].x < ip[t].x)) t = i;
-  const P2 start = ip[t];
-  P2 q[24];
-  float dist[24];
-  for (int i = 0; i < num; i++) q[i] = sub2(ip[i], start);
+  for (int i = 1; i < num; i++) {
+    const P2 pi = q[i], pt = q[t];
+    if (pi.y < pt.y || (pi.y == pt.y && pi.x < pt.x)) t = i;
+  }
+  const P2 start = q[t];
+  for (int i = 0; i < num; i++) q[i] = sub2(q[i], start);
   swap2(q, 0, t);
-  for (int i = 0; i < num; i++) dist[i] = dot2(q[i], q[i]);
+  for (int i = 0; i < num; i++) {
+    const P2 qi = q[i];
+    dist[i] = dot2(qi, qi);
+  }
   std_sort(q, 1, num);  // dist[] deliberately NOT permuted (reference host-branch quirk)
   int k;
   for (k = 1; k < num; k++)
@@ -199,13 +225,21 @@ V3D_HD float intersection_area(const P2 (&p1)[4], const P2 (&p2)[4]) {
   q[1] = q[k];
   int m = 2;
   for (int i = k + 1; i < num; i++) {
-    while (m > 1 && cross2(sub2(q[i], q[m - 2]), sub2(q[m - 1], q[m - 2])) >= 0) m--;
-    q[m++] = q[i];
+    const P2 qi = q[i];
+    while (m > 1 && cross2(sub2(qi, q[m - 2]), sub2(q[m - 1], q[m - 2])) >= 0) m--;
+    q[m++] = qi;
   }
   if (m <= 2) return 0.0f;
   float area = 0;
-  for (int i = 1; i < m - 1; i++) area += (float)fabs((double)cross2(sub2(q[i], q[0]), sub2(q[i + 1], q[0])));
+  const P2 q0 = q[0];
+  for (int i = 1; i < m - 1; i++) area += (float)fabs((double)cross2(sub2(q[i], q0), sub2(q[i + 1], q0)));
   return (float)(area / 2.0);
+}
+
+V3D_HD float intersection_area(const P2 (&p1)[4], const P2 (&p2)[4]) {
+  P2 q[24];
+  float dist[24];
+  return intersection_area_ws(p1, p2, P2View<1>{q}, F1View<1>{dist});
 }
 
 // A box prepared once: raw centre, size, half-trig, area.
@@ -244,6 +278,19 @@ V3D_HD float iou_prepped(const BoxPrep& a, const BoxPrep& b) {
   vertices((float)(a.x - csx), (float)(a.y - csy), a.w, a.h, a.c2, a.s2, p1);
   vertices((float)(b.x - csx), (float)(b.y - csy), b.w, b.h, b.c2, b.s2, p2);
   const float inter = intersection_area(p1, p2);
+  return inter / (a.area + b.area - inter);
+}
+
+// iou_prepped with the clipper's work arrays in a per-wave LDS slab: pts = slab of 24 * 64 P2 + this lane's index,
+// dist = slab of 24 * 64 floats + this lane's index.  Same value, bit for bit.
+V3D_HD float iou_prepped_lds(const BoxPrep& a, const BoxPrep& b, P2* pts, float* dist) {
+  if (!iou_needs_clip(a, b)) return 0.f;
+  const double csx = (a.x + b.x) / 2.0;
+  const double csy = (a.y + b.y) / 2.0;
+  P2 p1[4], p2[4];
+  vertices((float)(a.x - csx), (float)(a.y - csy), a.w, a.h, a.c2, a.s2, p1);
+  vertices((float)(b.x - csx), (float)(b.y - csy), b.w, b.h, b.c2, b.s2, p2);
+  const float inter = intersection_area_ws(p1, p2, P2View<64>{pts}, F1View<64>{dist});
   return inter / (a.area + b.area - inter);
 }
 

@@ -54,15 +54,19 @@ __global__ __launch_bounds__(V3D_BLOCK) void ta_match_kernel(const float* __rest
   __shared__ v3d::BoxPrep sp[TA_MAX_GT];
   __shared__ int sidx[TA_MAX_GT];
   __shared__ int s_count;
+  __shared__ v3d::P2 clip_pts[V3D_BLOCK / V3D_WAVE][24 * 64];  // the clipper's work arrays: LDS, not scratch (rotated_iou.h)
+  __shared__ float clip_dist[V3D_BLOCK / V3D_WAVE][24 * 64];
   const int c = blockIdx.y;
   const int m = ta_stage(gt, gt_class, p.n_gt, c, sp, sidx, &s_count);
   const int a = blockIdx.x * V3D_BLOCK + threadIdx.x;
   if (a >= p.A) return;
+  v3d::P2* pts = clip_pts[threadIdx.x >> 6] + (threadIdx.x & 63);
+  float* dist = clip_dist[threadIdx.x >> 6] + (threadIdx.x & 63);
   const v3d::BoxPrep ba = ta_prep7(anchors + 7 * ((size_t)c * p.A + a));
   float best = -1.f;
   int arg = 0;
   for (int i = 0; i < m; i++) {
-    const float q = v3d::iou_prepped(sp[i], ba);  // box_iou_rotated(gt, anchors)[i][a]
+    const float q = v3d::iou_prepped_lds(sp[i], ba, pts, dist);  // box_iou_rotated(gt, anchors)[i][a]
     if (q > best) {  // strict: the FIRST maximal ground truth, as torch.max(dim=0) returns
       best = q;
       arg = i;
@@ -88,10 +92,14 @@ __global__ __launch_bounds__(V3D_BLOCK) void ta_label_kernel(const float* __rest
   __shared__ v3d::BoxPrep sp[TA_MAX_GT];
   __shared__ int sidx[TA_MAX_GT];
   __shared__ int s_count;
+  __shared__ v3d::P2 clip_pts[V3D_BLOCK / V3D_WAVE][24 * 64];  // the clipper's work arrays: LDS, not scratch (rotated_iou.h)
+  __shared__ float clip_dist[V3D_BLOCK / V3D_WAVE][24 * 64];
   const int c = blockIdx.y;
   const int m = ta_stage(gt, gt_class, p.n_gt, c, sp, sidx, &s_count);
   const int a = blockIdx.x * V3D_BLOCK + threadIdx.x;
   if (a >= p.A) return;
+  v3d::P2* pts = clip_pts[threadIdx.x >> 6] + (threadIdx.x & 63);
+  float* dist = clip_dist[threadIdx.x >> 6] + (threadIdx.x & 63);
   const size_t ia = (size_t)c * p.A + a;
   const float* an = anchors + 7 * ia;
   int label = 0;  // no ground truth of this class: the lowest band (matcher.py:69-79)
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void ta_label_kernel(const float* __rest
     if (p.allow_low_quality) {
       const v3d::BoxPrep ba = ta_prep7(an);
       for (int i = 0; i < m; i++)
-        if (__float_as_uint(v3d::iou_prepped(sp[i], ba)) == gt_max[sidx[i]]) label = 1;  // ties included (matcher.py:98-130)
+        if (__float_as_uint(v3d::iou_prepped_lds(sp[i], ba, pts, dist)) == gt_max[sidx[i]]) label = 1;  // ties included (matcher.py:98-130)
     }
   }
   const int g = best_gt[ia];
