@@ -23,7 +23,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     for key, v in vals.items():
         mean[key][counter] = sum(v) / len(v)
         print(f"{key:36s} {counter:11s} mean {mean[key][counter]:12.1f} KB  (n={len(v)})")
-res = {"source": "profiles/r01_j_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes; FETCH_SIZE x2 gfx950 correction)"}
+res = {"source": "profiles/r01_l_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes; FETCH_SIZE x2 gfx950 correction)"}
 print("\ntraffic per launch = 2*FETCH_SIZE + WRITE_SIZE:")
 for key, m in mean.items():
     if len(m) == 2:
