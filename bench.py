@@ -382,13 +382,13 @@ def main():
             pmc = json.load(open(pmc_path))
             traffic, traffic_src = pmc[DOM_KERNEL]["traffic_bytes"] if DOM_KERNEL in pmc else None, pmc["source"]
         # the same kernel against the matrix pipe: MFMAs it ISSUES (16-row tiles incl. the padded one of the last workgroup x
-        # 27 offsets x Cin/32 x Cout/16 x 4 split terms, 16 384 flop each) and the useful flops (2 Cin Cout per rulebook pair)
+        # 27 offsets x Cin/32 x Cout/16 x 3 split terms, 16 384 flop each) and the useful flops (2 Cin Cout per rulebook pair)
         dom_tiles = float(np.mean([2 * ((l["n_out"] + 31) // 32) for l in dom]))
-        mfma_issued = dom_tiles * 27 * 2 * 4 * 4 * 16384
+        mfma_issued = dom_tiles * 27 * 2 * 4 * 3 * 16384  # Cin/32 = 2, Cout/16 = 4, 3 split terms (csrc/spconv.hip SPC_TERMS)
         mfma_useful = float(np.mean([l["pairs"] for l in dom])) * 2 * 64 * 64
         mfma_view = dict(issued_tflops=mfma_issued / dom_t / 1e12, frac_issued=mfma_issued / dom_t / 1e12 / 2500.0,
                          useful_tflops=mfma_useful / dom_t / 1e12, peak_tflops=2500.0,
-                         note="bf16 dense MFMA peak; 4 bf16 terms per fp32-class product, zero rows of absent neighbours included in 'issued'")
+                         note="bf16 dense MFMA peak; 3 bf16 terms per product (hi*Wh + hi*Wl + lo*Wh), zero rows of absent neighbours included in 'issued'")
         roofline = dict(bound="hbm", kernel=DOM_KERNEL, launches_per_frame=len(dom), mfma_view=mfma_view,
                         bytes_per_launch=dom_bytes, avg_us=dom_t * 1e6, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,

@@ -51,6 +51,6 @@ for (a, k) in cap:
         if ref is None: ref = o.clone()
         elif os.environ.get("MB_NOCHECK"): pass
         else: assert torch.equal(ref, o) or (ref - o).abs().max() < 1e-3 * ref.abs().max(), "mt variants disagree"
-        row += f" mt{mt}={np.mean(ts):7.1f}us"
+        row += f" mt{mt}={np.mean(ts):7.1f}us" + (f" (maxdiff/max {float((ref - o).abs().max() / ref.abs().max()):.1e})" if mt != 1 else "")
     raw.v3d_debug_set_rows_mt(0)
     print(row)

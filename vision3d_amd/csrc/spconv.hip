@@ -507,6 +507,41 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8_t& hi, bf16x8
   lo = __builtin_bit_cast(bf16x8_t, l);
 }
 
+// two-way split (hi = RNE(x), lo = RNE(x - hi)) on the hardware converter: 16 significant bits, for the 3-term product
+// hi*Whi + hi*Wlo + lo*Whi (the scheme of csrc/dense_conv.hip)
+typedef __bf16 spr_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float spr_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8_2(const float (&x)[8], bf16x8_t& hi, bf16x8_t& lo) {
+  u32x4_t h, l;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const spr_bf16x2_t hh = __builtin_convertvector(spr_f32x2_t{x[2 * i], x[2 * i + 1]}, spr_bf16x2_t);
+    const unsigned hb = __builtin_bit_cast(unsigned, hh);
+    const float r0 = x[2 * i] - __uint_as_float(hb << 16), r1 = x[2 * i + 1] - __uint_as_float(hb & 0xFFFF0000u);
+    h[i] = hb;
+    l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(spr_f32x2_t{r0, r1}, spr_bf16x2_t));
+  }
+  hi = __builtin_bit_cast(bf16x8_t, h);
+  lo = __builtin_bit_cast(bf16x8_t, l);
+}
+
+// Terms of the split-precision product in the packed kernels.  4: activations hi+mid+lo (24 bits) x weights hi+lo: al*Wh +
+// am*Wh + ah*Wl + ah*Wh, fp32-class (2^-18 from the weights' residual).  3 (default since the ring kernel made the matrix
+// pipe count again): activations hi+lo (16 bits, both RNE on the hardware converter): al*Wh + ah*Wl + ah*Wh, 2^-17 -- the
+// scheme of the dense kernels, 25 % fewer MFMAs and a third of the split's VALU work.  Measured against the 4-term result
+// per layer: max |diff| / max |out| = 2-4e-6 (4-term vs oracle: 4e-7), bar 1e-4; ring 64->64 13.1 -> 12.2 us.
+#ifndef SPC_TERMS
+#define SPC_TERMS 3
+#endif
+__device__ __forceinline__ void split_act(const float (&x)[8], bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
+  if constexpr (SPC_TERMS == 4) {
+    split8(x, hi, mid, lo);
+  } else {
+    split8_2(x, hi, lo);
+    mid = lo;  // unused
+  }
+}
+
 // packed weights: img[k][ki][nb][plane][lane][8]: lane (j = lane&15, kg = lane>>4) holds
 // W[k][cin = ki*32 + kg*8 + e][cout = nb*16 + j], e < 8 (zero beyond Cin)
 __global__ void spconv_pack_weights_kernel(const float* __restrict__ W, int K, int Cin, int Cout, unsigned short* __restrict__ img) {
@@ -627,13 +662,15 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
 #pragma unroll
     for (int ki = 0; ki < KI; ki++) {
       bf16x8_t ah, am, al;
-      split8(a[ki], ah, am, al);
+      split_act(a[ki], ah, am, al);
 #pragma unroll
       for (int j = 0; j < NB; j++)  // smallest terms first
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), acc[j], 0, 0, 0);
+      if constexpr (SPC_TERMS == 4) {
 #pragma unroll
-      for (int j = 0; j < NB; j++)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), acc[j], 0, 0, 0);
+        for (int j = 0; j < NB; j++)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), acc[j], 0, 0, 0);
+      }
 #pragma unroll
       for (int j = 0; j < NB; j++)
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2 + 1]), acc[j], 0, 0, 0);
@@ -760,13 +797,15 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_mt(const float* __r
 #pragma unroll
     for (int ki = 0; ki < KI; ki++) {
       bf16x8_t ah, am, al;
-      split8(a[ki], ah, am, al);
+      split_act(a[ki], ah, am, al);
 #pragma unroll
       for (int j = 0; j < NB; j++)  // smallest terms first
         c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), c[j], 0, 0, 0);
+      if constexpr (SPC_TERMS == 4) {
 #pragma unroll
-      for (int j = 0; j < NB; j++)
-        c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), c[j], 0, 0, 0);
+        for (int j = 0; j < NB; j++)
+          c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), c[j], 0, 0, 0);
+      }
 #pragma unroll
       for (int j = 0; j < NB; j++)
         c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2 + 1]), c[j], 0, 0, 0);
@@ -894,12 +933,12 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __
 #pragma unroll
     for (int ki = 0; ki < KI; ki++) {
       bf16x8_t ah, am, al;
-      split8(a[ki], ah, am, al);
+      split_act(a[ki], ah, am, al);
 #pragma unroll
       for (int j = 0; j < NB; j++) {
         const bf16x8_t bh = bw[(size_t)((ki * NB + j) * 2) * 64], bl = bw[(size_t)((ki * NB + j) * 2 + 1) * 64];
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[j], 0, 0, 0);  // smallest terms first
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[j], 0, 0, 0);
+        if constexpr (SPC_TERMS == 4) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[j], 0, 0, 0);
       }
@@ -1098,11 +1137,13 @@ __global__ __launch_bounds__((2 * OG + 2) * 64) void spconv_fwd_rows_ring(const 
         bh[j] = bw[(size_t)((ki * NB + j) * 2) * 64];
         bl[j] = bw[(size_t)((ki * NB + j) * 2 + 1) * 64];
       }
-      split8(araw[R % NBUF][ki], ah, am, al);
+      split_act(araw[R % NBUF][ki], ah, am, al);
 #pragma unroll
       for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[j], 0, 0, 0);  // smallest terms first
+      if constexpr (SPC_TERMS == 4) {
 #pragma unroll
-      for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[j], acc[j], 0, 0, 0);
+      }
 #pragma unroll
       for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[j], 0, 0, 0);
 #pragma unroll
