@@ -20,10 +20,14 @@ def host_iou():
     lib = C.CDLL(so)
 
     def run(b1, b2):
+        """Both forms of the core -- work arrays as plain locals, and lane-interleaved in a 64-lane slab as the kernels keep
+        them in LDS -- which must agree bit for bit; returns the plain one."""
         b1, b2 = np.ascontiguousarray(b1, np.float32), np.ascontiguousarray(b2, np.float32)
         out = np.empty((len(b1), len(b2)), np.float32)
-        lib.host_box_iou_rotated(b1.ctypes.data_as(C.c_void_p), len(b1), b2.ctypes.data_as(C.c_void_p), len(b2),
-                                 out.ctypes.data_as(C.c_void_p))
+        strided = np.empty_like(out)
+        for fn, dst in ((lib.host_box_iou_rotated, out), (lib.host_box_iou_rotated_strided, strided)):
+            fn(b1.ctypes.data_as(C.c_void_p), len(b1), b2.ctypes.data_as(C.c_void_p), len(b2), dst.ctypes.data_as(C.c_void_p))
+        np.testing.assert_array_equal(out.view(np.uint32), strided.view(np.uint32))
         return out
     return run
 
