@@ -1,0 +1,81 @@
+"""GPU: GT-sampling + global augmentation on the device against vectors captured from the reference's
+own vision3d/dataset/augmentation.py (tests/golden/make_golden_aug.py).  The device implementation makes the reference's
+numpy draws in the reference's order, so a seeded run must reproduce it: same pasted objects in the same order, same
+survivors of the collision filter, same scene points removed, coordinates within float32 rounding of the reference's
+float64 results (exact for the flip, the dtype promotions are reproduced)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from vision3d_amd.core.config import _defaults, second_car_cfg
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def golden_aug():
+    return np.load(os.path.join(HERE, "golden", "augmentation.npz"))
+
+
+def case_cfg(g, tag):
+    cfg = (_defaults() if tag == "three" else second_car_cfg()).clone()
+    meta = g[f"{tag}_cfg"]
+    assert cfg.NUM_CLASSES == int(meta[0]) and list(cfg.AUG.NUM_SAMPLE_OBJECTS) == [int(v) for v in meta[2:]]
+    cfg.AUG.DATABASE_SAMPLE = bool(meta[1])
+    return cfg
+
+
+def case_database(g, tag, num_classes):
+    db = {}
+    for c in range(num_classes):
+        sizes = g[f"{tag}_db{c}_sizes"]
+        pts = np.split(g[f"{tag}_db{c}_points"], np.cumsum(sizes)[:-1]) if len(sizes) else []
+        db[c] = [dict(points=p, box=b) for p, b in zip(pts, g[f"{tag}_db{c}_boxes"])]
+    return db
+
+
+@pytest.mark.parametrize("tag", ["car", "car_b", "three", "nosample"])
+def test_matches_reference_draw_for_draw(golden_aug, tag):
+    from vision3d_amd.dataset import ChainedAugmentation
+    g = golden_aug
+    cfg = case_cfg(g, tag)
+    db = case_database(g, tag, 3)
+    aug = ChainedAugmentation(cfg, database=db)
+    np.random.seed(int(g[f"{tag}_seed"]))
+    points, boxes, cls = aug(g[f"{tag}_points"].copy(), g[f"{tag}_boxes"].copy(), g[f"{tag}_class_idx"].copy())
+    ref_p, ref_b, ref_c = g[f"{tag}_out_points"], g[f"{tag}_out_boxes"], g[f"{tag}_out_class_idx"]
+    assert points.dtype == np.float32 and boxes.dtype == np.float32
+    assert points.shape == ref_p.shape and boxes.shape == ref_b.shape, (points.shape, ref_p.shape, boxes.shape, ref_b.shape)
+    np.testing.assert_array_equal(cls, ref_c)
+    np.testing.assert_allclose(boxes, ref_b.astype(np.float32), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(points, ref_p.astype(np.float32), rtol=1e-6, atol=2e-6)
+    if tag != "nosample":
+        assert boxes.shape[0] > g[f"{tag}_boxes"].shape[0], "the case must paste at least one object"
+        frac_exact = float((points == ref_p.astype(np.float32)).mean())
+        assert frac_exact > 0.999, frac_exact  # float64 arithmetic like the reference's: only rounding ties of the last cast may differ
+
+
+def test_device_tensors_in_and_out_and_no_collisions(golden_aug):
+    """cuda tensors in -> cuda tensors out, equal to the numpy entry; no pasted box overlaps another box afterwards."""
+    from vision3d_amd.dataset import ChainedAugmentation, SampleDatabase
+    from vision3d_amd.ops import box_iou_rotated
+    g, tag = golden_aug, "three"
+    cfg = case_cfg(g, tag)
+    db = SampleDatabase(case_database(g, tag, 3), cfg.NUM_CLASSES)
+    aug = ChainedAugmentation(cfg, database=db)
+    np.random.seed(7)
+    a = aug(g[f"{tag}_points"].copy(), g[f"{tag}_boxes"].copy(), g[f"{tag}_class_idx"].copy())
+    np.random.seed(7)
+    b = aug(torch.from_numpy(g[f"{tag}_points"]).cuda(), torch.from_numpy(g[f"{tag}_boxes"]).cuda(),
+            torch.from_numpy(g[f"{tag}_class_idx"]).cuda())
+    for x, y in zip(a, b):
+        assert y.is_cuda
+        np.testing.assert_array_equal(x, y.cpu().numpy())
+    n0 = g[f"{tag}_boxes"].shape[0]
+    bev = b[1][:, [0, 1, 3, 4, 6]].contiguous()
+    iou = box_iou_rotated(bev, bev).cpu().numpy()
+    np.fill_diagonal(iou, 0)
+    assert iou[n0:].max() <= 1e-2
