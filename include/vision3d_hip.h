@@ -46,6 +46,12 @@ const char* v3d_error_string(int code);
  * Arithmetic follows the HOST branch of box_iou_rotated_utils.h (the CPU path is the parity target). */
 int v3d_box_iou_rotated(const float* boxes1, int M, const float* boxes2, int N, float* ious, v3d_stream_t stream);
 
+/* 3-D IoU of (x, y, z, w, l, h, yaw) boxes, z = centre: (M,7) x (N,7) -> (M,N).  BEV intersection area through the operator of
+ * v3d_box_iou_rotated on columns (0,1,3,4,6) -- the yaw is read the way that operator reads it -- times the overlap of the z
+ * extents, over the union of the volumes.  Replaces the stub vision3d/ops/iou_nms.py:12-13 (`box_iou_rotated_3d` raises
+ * NotImplementedError upstream): defined by oracle/v3d_oracle.c:orc_box_iou_rotated_3d. */
+int v3d_box_iou_rotated_3d(const float* boxes1, int M, const float* boxes2, int N, float* ious, v3d_stream_t stream);
+
 /* ---- A3: greedy rotated NMS.
  * Replaces detectron2::nms_rotated (ops/csrc/nms_rotated/nms_rotated.h:22-36; CPU semantics
  * nms_rotated_cpu.cpp:7-59: suppress when IoU >= thr).  keep (N) i64 receives indices into the

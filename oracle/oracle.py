@@ -88,6 +88,14 @@ def box_iou_rotated(b1, b2, use_ref=False):
     return out
 
 
+def box_iou_rotated_3d(b1, b2):
+    """(M, 7) x (N, 7) -> (M, N): BEV intersection (box_iou_rotated's operator on columns 0,1,3,4,6) x z overlap / union volume."""
+    b1, b2 = _f32(b1).reshape(-1, 7), _f32(b2).reshape(-1, 7)
+    out = np.empty((b1.shape[0], b2.shape[0]), np.float32)
+    lib().orc_box_iou_rotated_3d(_fp(b1), b1.shape[0], _fp(b2), b2.shape[0], _fp(out))
+    return out
+
+
 def score_order(scores):
     """Descending-score permutation; ties -> lower index first (stable)."""
     return np.argsort(-_f32(scores), kind="stable").astype(np.int64)

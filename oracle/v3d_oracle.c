@@ -228,6 +228,44 @@ float orc_single_box_iou_rotated(const float* b1, const float* b2) {
   return inter / (area1 + area2 - inter);
 }
 
+/* BEV intersection AREA of two (xc, yc, w, h, angle) boxes: orc_single_box_iou_rotated without the final division. */
+float orc_single_box_inter_rotated(const float* b1, const float* b2) {
+  double csx = (b1[0] + b2[0]) / 2.0;
+  double csy = (b1[1] + b2[1]) / 2.0;
+  float x1 = (float)(b1[0] - csx), y1 = (float)(b1[1] - csy);
+  float x2 = (float)(b2[0] - csx), y2 = (float)(b2[1] - csy);
+  float area1 = b1[2] * b1[3];
+  float area2 = b2[2] * b2[3];
+  if (area1 < 1e-14 || area2 < 1e-14) return 0.f;
+  pt_t p1[4], p2[4], ip[24], op[24];
+  rotated_vertices(x1, y1, b1[2], b1[3], b1[4], p1);
+  rotated_vertices(x2, y2, b2[2], b2[3], b2[4], p2);
+  int num = intersection_points(p1, p2, ip);
+  if (num <= 2) return 0.0f;
+  int nh = convex_hull_graham(ip, num, op);
+  return polygon_area(op, nh);
+}
+
+/* 3-D IoU of (x, y, z, w, l, h, yaw) boxes, z = centre: BEV intersection area (columns 0, 1, 3, 4, 6 through the SAME
+ * operator as box_iou_rotated, so the yaw is read the way that operator reads it -- SURVEY.md H1) times the overlap of the
+ * z extents, over the union of the volumes.  The reference declares this function and raises (ops/iou_nms.py:12-13): this
+ * is the repository's definition of it, not a parity claim.  float32, fixed operation order. */
+float orc_single_box_iou_rotated_3d(const float* b1, const float* b2) {
+  const float bev1[5] = {b1[0], b1[1], b1[3], b1[4], b1[6]}, bev2[5] = {b2[0], b2[1], b2[3], b2[4], b2[6]};
+  const float inter_bev = orc_single_box_inter_rotated(bev1, bev2);
+  const float lo = fmaxf(b1[2] - b1[5] / 2.f, b2[2] - b2[5] / 2.f), hi = fminf(b1[2] + b1[5] / 2.f, b2[2] + b2[5] / 2.f);
+  const float oh = fmaxf(hi - lo, 0.f);
+  const float inter = inter_bev * oh;
+  const float v1 = b1[3] * b1[4] * b1[5], v2 = b2[3] * b2[4] * b2[5];
+  const float den = v1 + v2 - inter;
+  return den > 0.f ? inter / den : 0.f;
+}
+
+void orc_box_iou_rotated_3d(const float* b1, int M, const float* b2, int N, float* out) {
+  for (int i = 0; i < M; i++)
+    for (int j = 0; j < N; j++) out[(size_t)i * N + j] = orc_single_box_iou_rotated_3d(b1 + 7 * i, b2 + 7 * j);
+}
+
 /* box_iou_rotated_cpu.cpp:7-44 */
 void orc_box_iou_rotated(const float* b1, int M, const float* b2, int N, float* out) {
   for (int i = 0; i < M; i++)

@@ -60,6 +60,39 @@ def test_iou_vs_oracle_random_and_edges(oracle):
     assert gpu_iou(boxes(7, 1, 1), np.zeros((0, 5), np.float32)).shape == (7, 0)
 
 
+def test_iou_3d_vs_oracle(oracle):
+    """box_iou_rotated_3d (a stub upstream): BEV intersection of the 2-D operator x z overlap / union of the
+    volumes, bit-exact against oracle/ (same float32 operation order) on KITTI-like boxes, dense clusters, stacked and
+    degenerate boxes; ragged shapes; consistency with the 2-D operator when the z extents coincide."""
+    from vision3d_amd.ops import box_iou_rotated, box_iou_rotated_3d
+    rng = np.random.default_rng(33)
+
+    def boxes(n, spread, ang):
+        return np.concatenate([rng.uniform(-spread, spread, (n, 2)), rng.uniform(-2, 1, (n, 1)), rng.uniform(0.3, 4.5, (n, 3)),
+                               rng.uniform(-1, 1, (n, 1)) * ang], 1).astype(np.float32)
+    for spread, ang, m, n in ((30, 3.2, 300, 517), (4, 180, 65, 1000), (2, 90, 33, 257), (1, 1, 1, 1)):
+        b1, b2 = boxes(m, spread, ang), boxes(n, spread, ang)
+        got = box_iou_rotated_3d(dev(b1, torch.float32), dev(b2, torch.float32)).cpu().numpy()
+        ref = oracle.box_iou_rotated_3d(b1, b2)
+        np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32), err_msg=f"{m}x{n}")
+        assert (got >= 0).all() and (got <= 1 + 1e-6).all() and (m * n < 100 or (got > 0).any())
+    deg = boxes(12, 1, 30)
+    deg[0, 5] = 0.0            # zero height
+    deg[1, 3] = 0.0            # zero width
+    deg[2] = deg[3]            # identical boxes
+    deg[4, :2] = deg[5, :2]
+    deg[4, 2] = deg[5, 2] + deg[5, 5] / 2 + deg[4, 5] / 2  # stacked: z extents touch
+    got = box_iou_rotated_3d(dev(deg, torch.float32), dev(deg, torch.float32)).cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint32), oracle.box_iou_rotated_3d(deg, deg).view(np.uint32))
+    assert got[0].max() == 0 and got[1].max() == 0 and abs(got[2, 3] - 1) < 1e-6 and got[4, 5] == 0
+    same_z = boxes(40, 3, 90)
+    same_z[:, 2], same_z[:, 5] = -1.0, 1.5
+    g3 = box_iou_rotated_3d(dev(same_z, torch.float32), dev(same_z, torch.float32)).cpu().numpy()
+    g2 = box_iou_rotated(dev(same_z[:, [0, 1, 3, 4, 6]].copy(), torch.float32), dev(same_z[:, [0, 1, 3, 4, 6]].copy(), torch.float32)).cpu().numpy()
+    np.testing.assert_allclose(g3, g2, rtol=2e-6, atol=1e-7)  # equal heights: the 3-D ratio reduces to the BEV one
+    assert box_iou_rotated_3d(dev(np.zeros((0, 7), np.float32), torch.float32), dev(deg, torch.float32)).shape == (0, 12)
+
+
 def gpu_nms(boxes, scores, thr):
     from vision3d_amd.ops import nms_rotated
     return nms_rotated(dev(boxes, torch.float32), dev(scores, torch.float32), thr).cpu().numpy()

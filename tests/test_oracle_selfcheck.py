@@ -131,3 +131,16 @@ def test_fps_and_ball_query_vs_numpy(oracle):
     feat = rng.standard_normal((2, 6, 500)).astype(np.float32)
     np.testing.assert_array_equal(oracle.group(feat, bq), np.stack([feat[b][:, bq[b]] for b in range(2)]))
     np.testing.assert_array_equal(oracle.gather(feat, idx), np.stack([feat[b][:, idx[b]] for b in range(2)]))
+
+
+def test_iou_3d_known_answers(oracle):
+    """The repository's definition of box_iou_rotated_3d (a stub upstream): analytic cases."""
+    b = np.array([[0, 0, 0, 2, 4, 2, 0], [0, 0, 1, 2, 4, 2, 0], [1, 0, 0, 2, 4, 2, 0], [0, 0, 0, 2, 4, 2, 90], [10, 10, 0, 2, 4, 2, 0],
+                  [0, 0, 2, 2, 4, 2, 0]], np.float32)
+    iou = oracle.box_iou_rotated_3d(b, b)
+    np.testing.assert_allclose(np.diag(iou), 1.0, rtol=1e-6)
+    np.testing.assert_allclose(iou[0, 1], 1 / 3, rtol=1e-6)   # half the height shared
+    np.testing.assert_allclose(iou[0, 2], 1 / 3, rtol=1e-6)   # half the width shared
+    np.testing.assert_allclose(iou[0, 3], 1 / 3, rtol=1e-6)   # crossed at 90 degrees: 2 x 2 x 2 shared of 16 + 16 - 8
+    assert iou[0, 4] == 0 and iou[0, 5] == 0                    # disjoint in BEV; z extents only touch
+    np.testing.assert_array_equal(iou, iou.T)

@@ -21,6 +21,7 @@ _SIGNATURES = {
     "v3d_compiler_version": (C.c_char_p, []),
     "v3d_error_string": (C.c_char_p, [_i]),
     "v3d_box_iou_rotated": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "v3d_box_iou_rotated_3d": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "v3d_nms_rotated_workspace": (_sz, [_i]),
     "v3d_nms_rotated": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "v3d_proposals_workspace": (_sz, [_i, _i, _i]),

@@ -52,6 +52,61 @@ extern "C" int v3d_box_iou_rotated(const float* boxes1, int M, const float* boxe
   return V3D_OK;
 }
 
+// 3-D IoU of (x, y, z, w, l, h, yaw) boxes (z = centre): BEV intersection area through the SAME operator as above on columns
+// (0, 1, 3, 4, 6) x overlap of the z extents / union of the volumes.  The reference declares box_iou_rotated_3d and raises
+// (ops/iou_nms.py:12-13); this is the definition SURVEY.md 8(f) rank 3 asks for, checked against oracle/ (same float32
+// operation order: bit-exact), not a parity claim against the reference.
+struct Box3Prep {
+  BoxPrep bev;
+  float zlo, zhi, vol;
+};
+__device__ __forceinline__ Box3Prep prep_box3(const float* b) {
+  const float bev[5] = {b[0], b[1], b[3], b[4], b[6]};
+  Box3Prep r;
+  r.bev = v3d::prep_box(bev);
+  r.zlo = b[2] - b[5] / 2.f;
+  r.zhi = b[2] + b[5] / 2.f;
+  r.vol = b[3] * b[4] * b[5];
+  return r;
+}
+
+__global__ __launch_bounds__(V3D_BLOCK) void box_iou_rotated_3d_kernel(const float* __restrict__ b1, int M,
+                                                                       const float* __restrict__ b2, int N,
+                                                                       float* __restrict__ out) {
+  __shared__ Box3Prep rows[IOU_ROWS];
+  __shared__ v3d::P2 clip_pts[V3D_BLOCK / V3D_WAVE][24 * 64];
+  __shared__ float clip_dist[V3D_BLOCK / V3D_WAVE][24 * 64];
+  const int row0 = blockIdx.y * IOU_ROWS;
+  const int nrows = min(IOU_ROWS, M - row0);
+  if ((int)threadIdx.x < nrows) rows[threadIdx.x] = prep_box3(b1 + 7 * (size_t)(row0 + threadIdx.x));
+  __syncthreads();
+  const int j = blockIdx.x * V3D_BLOCK + threadIdx.x;
+  if (j >= N) return;
+  const Box3Prep bj = prep_box3(b2 + 7 * (size_t)j);
+  v3d::P2* pts = clip_pts[threadIdx.x >> 6] + (threadIdx.x & 63);
+  float* dist = clip_dist[threadIdx.x >> 6] + (threadIdx.x & 63);
+  for (int r = 0; r < nrows; r++) {
+    const Box3Prep& bi = rows[r];
+    const float inter_bev = v3d::inter_prepped_lds(bi.bev, bj.bev, pts, dist);
+    const float oh = fmaxf(fminf(bi.zhi, bj.zhi) - fmaxf(bi.zlo, bj.zlo), 0.f);
+    const float inter = inter_bev * oh;
+    const float den = bi.vol + bj.vol - inter;
+    out[(size_t)(row0 + r) * N + j] = den > 0.f ? inter / den : 0.f;
+  }
+}
+
+extern "C" int v3d_box_iou_rotated_3d(const float* boxes1, int M, const float* boxes2, int N, float* ious,
+                                      v3d_stream_t stream) {
+  if (M < 0 || N < 0) return V3D_EINVAL;
+  if (M == 0 || N == 0) return V3D_OK;
+  if (!boxes1 || !boxes2 || !ious) return V3D_EINVAL;
+  dim3 grid(v3d_ceil_div(N, V3D_BLOCK), v3d_ceil_div(M, IOU_ROWS));
+  if (grid.y > 65535) return V3D_EUNSUPPORTED;
+  hipLaunchKernelGGL(box_iou_rotated_3d_kernel, grid, dim3(V3D_BLOCK), 0, (hipStream_t)stream, boxes1, M, boxes2, N, ious);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // NMS step 1: sort keys.  key = (~orderable(score) << 32) | index, ascending u64 order ==
 // descending score, ties by ascending index.  Padding keys are all ones (sort last).

@@ -283,14 +283,19 @@ V3D_HD float iou_prepped(const BoxPrep& a, const BoxPrep& b) {
 
 // iou_prepped with the clipper's work arrays in a per-wave LDS slab: pts = slab of 24 * 64 P2 + this lane's index,
 // dist = slab of 24 * 64 floats + this lane's index.  Same value, bit for bit.
-V3D_HD float iou_prepped_lds(const BoxPrep& a, const BoxPrep& b, P2* pts, float* dist) {
+V3D_HD float inter_prepped_lds(const BoxPrep& a, const BoxPrep& b, P2* pts, float* dist) {  // intersection AREA
   if (!iou_needs_clip(a, b)) return 0.f;
   const double csx = (a.x + b.x) / 2.0;
   const double csy = (a.y + b.y) / 2.0;
   P2 p1[4], p2[4];
   vertices((float)(a.x - csx), (float)(a.y - csy), a.w, a.h, a.c2, a.s2, p1);
   vertices((float)(b.x - csx), (float)(b.y - csy), b.w, b.h, b.c2, b.s2, p2);
-  const float inter = intersection_area_ws(p1, p2, P2View<64>{pts}, F1View<64>{dist});
+  return intersection_area_ws(p1, p2, P2View<64>{pts}, F1View<64>{dist});
+}
+
+V3D_HD float iou_prepped_lds(const BoxPrep& a, const BoxPrep& b, P2* pts, float* dist) {
+  if (!iou_needs_clip(a, b)) return 0.f;
+  const float inter = inter_prepped_lds(a, b, pts, dist);
   return inter / (a.area + b.area - inter);
 }
 

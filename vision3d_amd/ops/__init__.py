@@ -5,7 +5,7 @@ import importlib
 _EXPORTS = {
     "Matcher": "matcher", "subsample_labels": "matcher",
     "sigmoid_focal_loss": "focal_loss",
-    "box_iou_rotated": "iou_nms", "nms": "iou_nms", "nms_rotated": "iou_nms",
+    "box_iou_rotated": "iou_nms", "box_iou_rotated_3d": "iou_nms", "nms": "iou_nms", "nms_rotated": "iou_nms",
     "batched_nms": "iou_nms", "batched_nms_rotated": "iou_nms",
     "nms_rotated_padded": "iou_nms", "batched_nms_rotated_padded": "iou_nms",
 }

@@ -24,7 +24,19 @@ def box_iou_rotated(boxes1, boxes2):
 
 
 def box_iou_rotated_3d(boxes1, boxes2):
-    raise NotImplementedError  # vision3d/ops/iou_nms.py:12-13
+    """3-D IoU matrix (M, N) float32 of (x, y, z, w, l, h, yaw) boxes, z = centre: BEV intersection area -- the operator of
+    `box_iou_rotated` on columns (0, 1, 3, 4, 6), so the yaw is read the way that operator reads it -- times the
+    overlap of the z extents, over the union of the volumes.  Upstream declares the name and raises
+    (vision3d/ops/iou_nms.py:12-13); this is the repository's definition (oracle/v3d_oracle.c:orc_box_iou_rotated_3d)."""
+    L.require_gpu("box_iou_rotated_3d", boxes1, boxes2)
+    b1, b2 = L.as_f32("box_iou_rotated_3d", boxes1), L.as_f32("box_iou_rotated_3d", boxes2)
+    if b1.dim() != 2 or b2.dim() != 2 or b1.shape[-1] != 7 or b2.shape[-1] != 7:
+        raise RuntimeError("box_iou_rotated_3d: expected (M,7) and (N,7)")
+    m, n = b1.shape[0], b2.shape[0]
+    out = torch.empty((m, n), dtype=torch.float32, device=b1.device)
+    with torch.cuda.device(b1.device):
+        L.check(L.lib().v3d_box_iou_rotated_3d(L.ptr(b1), m, L.ptr(b2), n, L.ptr(out), L.stream_ptr()), "box_iou_rotated_3d")
+    return out
 
 
 def nms_rotated_padded(boxes, scores, iou_threshold):
