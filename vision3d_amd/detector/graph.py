@@ -66,6 +66,27 @@ class GraphedSecond(object):
         return head.finalize_native(*self.outputs) if self.native else head.finalize(*self.outputs)
 
 
+def choose_streams(time_of, n_candidates, max_depth, min_gain=0.03):
+    """The selection rule of PipelinedSecond.tune, free of any device: `time_of(ids)` -> seconds per frame with the
+    candidate streams `ids` (one slot each).  Every pair is timed and the best kept; a further stream is added
+    greedily -- the one that gives the shortest time -- as long as that beats the current set by `min_gain`.
+    Returns (chosen ids, {depth: best time seen at that depth})."""
+    if max_depth < 2 or n_candidates < 2:
+        return [0], {}
+    pairs = {(a, b): time_of([a, b]) for a in range(n_candidates) for b in range(a + 1, n_candidates)}
+    best = min(pairs, key=pairs.get)
+    chosen, t_best = list(best), pairs[best]
+    log = {2: t_best}
+    while len(chosen) < min(max_depth, n_candidates):
+        trial = {c: time_of(chosen + [c]) for c in range(n_candidates) if c not in chosen}
+        c = min(trial, key=trial.get)
+        log[len(chosen) + 1] = trial[c]
+        if trial[c] > (1.0 - min_gain) * t_best:  # a deeper pipeline has to pay for its arena
+            break
+        chosen, t_best = chosen + [c], trial[c]
+    return chosen, log
+
+
 class PipelinedSecond(object):
     """Throughput mode for independent frames: `depth` GraphedSecond instances (own plan arena, own static buffers, own
     HIP graph) on `depth` streams.  The sparse half of a frame is a chain of small launches that fills a fraction of
@@ -141,26 +162,9 @@ class PipelinedSecond(object):
         for i in range(len(self.slots)):  # capture every slot (tunes the plans on the real frame), one at a time
             self._launch(i, cands[0], clouds)
             self._finish(i, cands[0])
-        n = self.TUNE_FRAMES
-        log = {}
-        if len(self.slots) == 1:
-            chosen, t_best = [cands[0]], None
-        else:
-            pairs = [(a, b) for a in range(len(cands)) for b in range(a + 1, len(cands))]
-            times = {ab: self._time_streams([cands[ab[0]], cands[ab[1]]], clouds, n) for ab in pairs}
-            ab = min(times, key=times.get)
-            chosen, t_best = list(ab), times[ab]
-            log[2] = t_best
-            while len(chosen) < len(self.slots):
-                rest = [c for c in range(len(cands)) if c not in chosen]
-                trial = {c: self._time_streams([cands[x] for x in chosen + [c]], clouds, n + len(chosen)) for c in rest}
-                c = min(trial, key=trial.get)
-                log[len(chosen) + 1] = trial[c]
-                if trial[c] > 0.97 * t_best:  # a deeper pipeline has to pay for its arena
-                    break
-                chosen, t_best = chosen + [c], trial[c]
-            chosen = [cands[x] for x in chosen]
-        self.streams = chosen
+        chosen, log = choose_streams(lambda ids: self._time_streams([cands[x] for x in ids], clouds, self.TUNE_FRAMES + len(ids) - 2),
+                                     len(cands), len(self.slots))
+        self.streams = [cands[x] for x in chosen]
         self.tuned = dict(depth=len(chosen), us_per_frame={k: round(v * 1e6, 1) for k, v in log.items()})
         self.pending, self.next_slot = [], 0
         return self.tuned
