@@ -56,6 +56,8 @@ int v3d_box_iou_rotated_3d(const float* boxes1, int M, const float* boxes2, int 
  * Replaces detectron2::nms_rotated (ops/csrc/nms_rotated/nms_rotated.h:22-36; CPU semantics
  * nms_rotated_cpu.cpp:7-59: suppress when IoU >= thr).  keep (N) i64 receives indices into the
  * ORIGINAL arrays in decreasing-score order (ties: lower index first); *n_keep (device i32) the count.
+ * The reference's CUDA build suppresses on IoU > thr (nms_rotated_cuda.cu:62-63): pass nextafterf(thr, INFINITY) for that rule
+ * (the two differ only at IoU == thr exactly; vision3d_amd.ops.nms_rotated(..., rule="cuda") does so).
  * The score sort, the IoU bitmask and the sequential reduction all run on the device. */
 size_t v3d_nms_rotated_workspace(int N);
 int v3d_nms_rotated(const float* boxes, const float* scores, int N, float iou_threshold, int64_t* keep,
@@ -205,6 +207,18 @@ int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M, 
 int v3d_group_points(const float* feat, const int32_t* idx, int B, int C, int N, int M, int nsample, float* out,
                      v3d_stream_t stream);
 
+/* ---- T5: one layer of a set-abstraction shared MLP on gathered rows, exact fp32 on the matrix cores (csrc/sa_mlp.hip).
+ * Replaces, per scale of pointnet2_modules.PointnetSAModuleMSG (call sites detector/model.py:58-66, detector/roi_grid_pool.py:
+ * 64-72), grouping_operation + SharedMLP (Conv2d 1x1, no bias + BatchNorm2d + ReLU per layer) + max over the samples, without the
+ * grouped (B, C+3, M, ns) tensor.  Rows are (b, m, s) in that order, rows = B*M*ns.
+ *   first layer  (idx != NULL): feat (B, N, Kf) POINT-major, xyz (B, N, 3), new_xyz (B, M, 3), idx (B, M, ns) i32 into N;
+ *                row = [xyz[i] - new_xyz[m], 0 | feat[i, :]], W (4 + Kf, Nout) row-major (row 3 multiplies the zero);
+ *   later layers (idx == NULL, xyz == new_xyz == NULL): feat (rows, Kf) = the previous layer's output, N must equal M*ns, W (Kf, Nout).
+ * out[row, :] = act(row @ W + bias); pool != 0: out (B*M, Nout) = max over the ns rows of each (b, m) (ns = 16 or 32).
+ * Kf % 4 == 0, Nout in {16, 32, 64, 96, 128, 192, 256}; BatchNorm(eval) is folded into W / bias by the caller. */
+int v3d_sa_mlp_layer(const float* feat, const float* xyz, const float* new_xyz, const int32_t* idx, int B, int N, int M, int ns,
+                     int Kf, const float* W, const float* bias, int Nout, int relu, int pool, float* out, v3d_stream_t stream);
+
 /* ---- Fused sparse-backbone plan: voxelizer -> [rulebooks + sparse conv layers] -> .dense().
  * The native form of the sparse half of Second.feature_extract (detector/second.py:20-24,41-46 over
  * detector/sparse_cnn.py:151-175): created once per model, every forward only ENQUEUES kernels on
@@ -249,7 +263,8 @@ int v3d_backbone_layer_output(v3d_backbone* plan, int layer, float** features, i
  * and uses them as size hints for the following forwards (capacities are upper bounds).  Not capturable. */
 int v3d_backbone_tune(v3d_backbone* plan);
 int32_t* v3d_backbone_occupancy(v3d_backbone* plan);       /* (cap0) i32, voxel occupancies of the last forward */
-int32_t* v3d_backbone_overflow_flags(v3d_backbone* plan);  /* (n_layers+1) i32 device flags, nonzero = capacity hit */
+int32_t* v3d_backbone_overflow_flags(v3d_backbone* plan);  /* (n_layers+1) i32 device flags of the last forward: [l] > 0 = layer l
+                                                              hit its active-site capacity (rows were dropped), [n_layers] > 0 = any */
 
 /* ---- A8/A9: dense 2-D convolutions of the BEV head on the matrix cores (csrc/dense_conv.hip).
  * Replaces nn.Conv2d + BatchNorm2d(eval) + ReLU (detector/second.py:58-94) and the 1x1 heads

@@ -145,3 +145,19 @@ def test_version_probes():
     from vision3d_amd import _C
     assert _C.get_cuda_version().startswith("HIP")
     assert "clang" in _C.get_compiler_version()
+
+
+def test_nms_tie_at_threshold_follows_the_chosen_rule():
+    """IoU == threshold exactly: the CPU rule (>=, the parity target) suppresses, the CUDA rule (>) keeps."""
+    from vision3d_amd.ops import box_iou_rotated, nms_rotated
+    boxes = torch.tensor([[0.0, 0.0, 2.0, 2.0, 0.0], [1.0, 0.0, 2.0, 2.0, 0.0], [10.0, 10.0, 2.0, 2.0, 0.0]]).cuda()
+    scores = torch.tensor([0.9, 0.8, 0.7]).cuda()
+    thr = float(box_iou_rotated(boxes[:1], boxes[1:2]).item())  # the exact float the kernels compare
+    assert abs(thr - 1.0 / 3.0) < 1e-6
+    assert nms_rotated(boxes, scores, thr).tolist() == [0, 2]
+    assert nms_rotated(boxes, scores, thr, rule="cuda").tolist() == [0, 1, 2]
+    lower = float(np.nextafter(np.float32(thr), np.float32(0)))
+    assert nms_rotated(boxes, scores, lower, rule="cuda").tolist() == [0, 2]
+    # thr = 0: ">=" suppresses even disjoint boxes (0 >= 0), ">" does not
+    assert nms_rotated(boxes, scores, 0.0).tolist() == [0]
+    assert nms_rotated(boxes, scores, 0.0, rule="cuda").tolist() == [0, 2]

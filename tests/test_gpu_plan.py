@@ -87,10 +87,39 @@ def test_plan_capacity_overflow_is_flagged():
     cfg = second_car_cfg()
     model = build_model(4)
     plan = BackbonePlan(model.cnn, cfg, max_batch=1, max_points=16384, growth=0.25)
+    plan.allow_overflow = True  # look at the flags instead of raising
     with torch.no_grad():
         out = plan.forward(torch.from_numpy(synth.make_cloud(0)).cuda(), [0, 16384])
     torch.cuda.synchronize()
-    assert int(plan.overflow().sum().item()) > 0 and torch.isfinite(out).all()
+    flags = plan.overflow()
+    assert int(flags[:-1].sum().item()) > 0 and int(flags[-1].item()) == 1 and torch.isfinite(out).all()
+    assert int(plan.overflow_any().item()) > 0
+    with pytest.raises(RuntimeError, match="capacity"):
+        plan.check_overflow()
+
+
+def test_inference_paths_refuse_a_frame_that_overflowed():
+    """Product paths read the plan's summary flag with the proposal count: a frame whose stages dropped rows raises instead
+    of returning detections from a wrong BEV map (eager native path, first-forward check, HIP-graph path)."""
+    from vision3d_amd.core import AnchorGenerator
+    from vision3d_amd.runtime import BackbonePlan
+    cfg = second_car_cfg()
+    anchors = AnchorGenerator(cfg).anchors.cuda()
+    cloud = [torch.from_numpy(synth.make_cloud(0)).cuda()]
+    with torch.no_grad():
+        plan = BackbonePlan(build_model(4).cnn, cfg, max_batch=1, max_points=16384, growth=0.25)
+        with pytest.raises(RuntimeError, match="capacity"):
+            plan.forward(cloud[0], [0, 16384])  # the synchronised first forward checks
+        model = build_model(4)
+        model.plan_growth = 0.25
+        with pytest.raises(RuntimeError, match="capacity"):
+            model.inference_points(cloud, anchors)
+        model = build_model(4)
+        model.plan_growth = 0.25
+        with pytest.raises(RuntimeError, match="capacity"):
+            model.graphed_inference(anchors, [16384])(cloud)
+        ok = build_model(4)
+        assert len(ok.graphed_inference(anchors, [16384])(cloud)) == 4
 
 
 def test_graphed_inference_equals_stepwise():

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "v3d_gather_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "v3d_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "v3d_group_points": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "v3d_sa_mlp_layer": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "v3d_backbone_create": (_i, [_vp, _vp, _vp]),
     "v3d_backbone_destroy": (None, [_vp]),
     "v3d_backbone_arena_bytes": (_sz, [_vp]),

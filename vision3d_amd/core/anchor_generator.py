@@ -3,6 +3,12 @@
 Interface of `vision3d/core/anchor_generator.py:28-74` (`AnchorGenerator(cfg).anchors`); the tensor is
 assembled directly in its final layout instead of cat+permute.  Cell centres sit at bin midpoints of
 the BEV grid whose pixel is VOXEL_SIZE[:2] * STRIDES[-1] (anchor_generator.py:41-45).
+
+Reference quirk reproduced on purpose: the reference writes the per-class centre z through an EXPANDED view
+(`centers.expand(...)`, then `centers[:, :, :, arange(NUM_CLASSES), 2] = anchor_z`, anchor_generator.py:56-58) -- the class
+dimension shares memory, so every class ends up with the LAST class's `center_z` (default 3-class configuration: -0.6 for
+Car as well, not -1.0).  A reference-trained multi-class checkpoint was trained against that grid, so it is what this
+generator returns; tests/golden/anchors.npz holds the reference's own output for 1 and 3 classes.
 """
 import torch
 from torch import nn
@@ -10,7 +16,7 @@ from torch import nn
 
 def bin_midpoints(lo, hi, n):
     """n samples at the centres of n equal bins on [lo, hi) -- float32 arithmetic on 0-dim tensors,
-    matching anchor_generator.py:5-12 so the grid is bit-identical."""
+    matching anchor_generator.py:5-12 (the grid is compared with the reference's in tests/test_host_golden.py)."""
     lo = torch.as_tensor(lo, dtype=torch.float32)
     hi = torch.as_tensor(hi, dtype=torch.float32)
     width = (hi - lo) / n
@@ -42,8 +48,9 @@ class AnchorGenerator(nn.Module):
         out = torch.empty(n_cls, n_yaw, ny, nx, 7, dtype=torch.float32)
         out[..., 0] = xs.view(1, 1, 1, nx)
         out[..., 1] = ys.view(1, 1, ny, 1)
+        z_all = float(cfg.ANCHORS[n_cls - 1]["center_z"])  # the reference's expanded-view write: last class wins
         for c, spec in enumerate(cfg.ANCHORS[:n_cls]):
-            out[c, ..., 2] = float(spec["center_z"])
+            out[c, ..., 2] = z_all
             out[c, ..., 3:6] = torch.tensor(spec["wlh"], dtype=torch.float32)
             out[c, ..., 6] = torch.tensor(spec["yaw"], dtype=torch.float32).view(n_yaw, 1, 1)
         return out.contiguous()

@@ -99,6 +99,193 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
   }
 }
 
+// ---- slab-skipping variant for 1 024 < N <= 16 384 (the PV-RCNN keypoint size) ---------------------------------
+// The K steps are a dependent chain on ONE CU (an exchange between CUs costs more per step than the step itself), and the
+// kernel above is bound by VALU ISSUE: 4 waves per SIMD x ~200 instructions x 4 clocks = the 3 300 clocks a step takes
+// (a 256- or 512-thread launch of the same code is not faster).  So this variant cuts the instructions per step:
+//   * 256 threads = one wave per SIMD, 16-64 points per lane in registers;
+//   * points are binned by x inside the kernel (counting sort, 1 024 bins, LDS) and register slot j of every lane holds one
+//     point of the j-th run of 256 sorted points -- an x-slab [xlo_j, xhi_j], whose bounds live in lane j;
+//   * a step only touches slab j if the new sample can lower a running distance there: every running distance is <= D* (the
+//     distance of the sample just chosen = the current maximum) and a point of slab j is at least gap_j = (x distance to the
+//     slab) away, so  gap_j^2 >= D*  =>  min(td, d) == td in the whole slab  =>  skip.  One ballot per step gives the touched
+//     set (the same in every wave); on the KITTI-shaped sweep 3.8 of 64 slabs are touched (profiles/r02_b_fps_slab_skip.txt);
+//   * per lane the maximum is kept per group of 8 slots, so a touched slab costs 10 + 3 instructions, not a 64-slot rescan;
+//   * the block maximum of the DISTANCE is found first (one DPP reduction per wave, one barrier); only the wave(s) holding it
+//     recover the lowest original index and the point's coordinates, which travel through LDS (no global load in the loop).
+// The result is the plain algorithm's bit for bit: the bound is exact in floating point (x - c is monotone, squares and sums
+// of non-negative terms are monotone), ties still resolve to the lowest ORIGINAL index whatever order the bins have inside.
+#define FPS_SLAB_THREADS 256
+template <int PPT>
+__global__ __launch_bounds__(FPS_SLAB_THREADS) void fps_slab_kernel(const float* __restrict__ xyz, int N, int K,
+                                                                    int* __restrict__ idx) {
+  constexpr int T = FPS_SLAB_THREADS, NW = T / V3D_WAVE, NBINS = 1024, BPT = NBINS / T, NG = PPT / 8;
+  static_assert(PPT % 8 == 0 && PPT <= 64, "one slab per lane, groups of 8 slots");
+  __shared__ float red_f[2][NW];
+  __shared__ int bin_cnt[NBINS];
+  __shared__ int wsum[NW];
+  __shared__ int slab_bin[2 * PPT];
+  __shared__ int perm[PPT * T];
+  __shared__ float wave_d[2][NW];
+  __shared__ int win_n[2][NW];
+  __shared__ float win_xyz[2][NW][3];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* p = xyz + (size_t)b * N * 3;
+  int* out = idx + (size_t)b * K;
+  // ---- x range
+  float mn = 3.4e38f, mx = -3.4e38f;
+  for (int n = tid; n < N; n += T) {
+    const float x = p[3 * n];
+    mn = fminf(mn, x);
+    mx = fmaxf(mx, x);
+  }
+  mx = v3d_dpp_max_f32<true>(mx);
+  mn = -v3d_dpp_max_f32<true>(-mn);
+  if (lane == 0) { red_f[0][wave] = mn; red_f[1][wave] = mx; }
+  for (int i = tid; i < NBINS; i += T) bin_cnt[i] = 0;
+  for (int i = tid; i < 2 * PPT; i += T) slab_bin[i] = 0;
+  __syncthreads();
+  mn = red_f[0][0];
+  mx = red_f[1][0];
+#pragma unroll
+  for (int w = 1; w < NW; w++) { mn = fminf(mn, red_f[0][w]); mx = fmaxf(mx, red_f[1][w]); }
+  const float span = fmaxf(mx - mn, 1e-20f);
+  const float inv = (float)NBINS / span, width = span / (float)NBINS;
+  auto bin_of = [&](float x) { return min(NBINS - 1, max(0, (int)((x - mn) * inv))); };
+  // ---- counting sort of the point indices by bin: histogram, exclusive scan (thread t owns bins BPT t ..), scatter
+  for (int n = tid; n < N; n += T) atomicAdd(&bin_cnt[bin_of(p[3 * n])], 1);
+  __syncthreads();
+  int cnt[BPT], mine = 0;
+#pragma unroll
+  for (int i = 0; i < BPT; i++) { cnt[i] = bin_cnt[tid * BPT + i]; mine += cnt[i]; }
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = incl - mine;
+  for (int w = 0; w < wave; w++) base += wsum[w];
+#pragma unroll
+  for (int i = 0; i < BPT; i++) {
+    // slab boundaries: sorted positions 256 j (first) and 256 j + 255 (last) lie in the bins whose runs cover them
+    if (cnt[i] > 0) {
+      const int j0 = (base + T - 1) / T, j1 = (base + cnt[i] - 1) / T;  // slabs whose FIRST position falls in this bin's run
+      for (int j = j0; j <= j1 && j < PPT; j++)
+        if (j * T >= base && j * T < base + cnt[i]) slab_bin[2 * j] = tid * BPT + i;
+      for (int j = base / T; j <= (base + cnt[i] - 1) / T && j < PPT; j++) {
+        const int last_pos = min(N, (j + 1) * T) - 1;
+        if (last_pos >= base && last_pos < base + cnt[i]) slab_bin[2 * j + 1] = tid * BPT + i;
+      }
+    }
+    bin_cnt[tid * BPT + i] = base;  // becomes the scatter cursor (every thread rewrites only its own bins)
+    base += cnt[i];
+  }
+  __syncthreads();
+  for (int n = tid; n < N; n += T) perm[atomicAdd(&bin_cnt[bin_of(p[3 * n])], 1)] = n;
+  __syncthreads();
+  // ---- slots: sorted position j * 256 + tid.  Slab j's bounds (lane j of every wave), widened by two bins: bin edges are
+  //      computed in floating point, the widening keeps them true bounds
+  float px[PPT], py[PPT], pz[PPT], td[PPT];
+  int orig[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; j++) {
+    const int pos = j * T + tid;
+    const bool ok = pos < N;
+    const int n = ok ? perm[pos] : 0;
+    orig[j] = ok ? n : 0x7FFFFFFF;
+    px[j] = ok ? p[3 * n] : 0.f;
+    py[j] = ok ? p[3 * n + 1] : 0.f;
+    pz[j] = ok ? p[3 * n + 2] : 0.f;
+    td[j] = ok ? 1e10f : -1.f;  // fminf keeps -1 forever: a slot without a point can never win (distances are >= 0)
+  }
+  const bool live_slab = lane < PPT && lane * T < N;
+  const float xlo = live_slab ? mn + (float)(slab_bin[2 * (lane % PPT)] - 2) * width : 3.4e38f;  // an empty slab is never touched
+  const float xhi = live_slab ? mn + (float)(slab_bin[2 * (lane % PPT) + 1] + 3) * width : -3.4e38f;
+  float gmax[NG];  // per lane: maximum of each group of 8 slots
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    gmax[g] = td[8 * g];
+#pragma unroll
+    for (int e = 1; e < 8; e++) gmax[g] = fmaxf(gmax[g], td[8 * g + e]);
+  }
+  if (tid == 0) out[0] = 0;
+  float cx = p[0], cy = p[1], cz = p[2];  // sample 0 = point 0
+  float dstar = 1e10f;
+  for (int s = 1; s < K; s++) {
+    const float gap = fmaxf(fmaxf(xlo - cx, cx - xhi), 0.f);
+    const unsigned long long touch = __ballot(gap * gap < dstar);  // bit j: slab j can change (same in every wave)
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      if ((touch >> (8 * g)) & 0xFFull) {  // scalar branches
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int j = 8 * g + e;
+          if ((touch >> j) & 1ull) {
+            const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+            const float d = dx * dx + dy * dy + dz * dz;  // (dx*dx + dy*dy) + dz*dz, no contraction: the oracle's bits
+            td[j] = fminf(d, td[j]);
+          }
+        }
+        gmax[g] = fmaxf(fmaxf(fmaxf(td[8 * g], td[8 * g + 1]), fmaxf(td[8 * g + 2], td[8 * g + 3])),
+                        fmaxf(fmaxf(td[8 * g + 4], td[8 * g + 5]), fmaxf(td[8 * g + 6], td[8 * g + 7])));
+      }
+    }
+    float bd = gmax[0];
+#pragma unroll
+    for (int g = 1; g < NG; g++) bd = fmaxf(bd, gmax[g]);
+    const float wd = v3d_dpp_max_f32<true>(bd);
+    if (lane == 0) wave_d[s & 1][wave] = wd;
+    __syncthreads();
+    float bm = wave_d[s & 1][0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) bm = fmaxf(bm, wave_d[s & 1][w]);
+    dstar = bm;
+    // only the wave(s) that hold the maximum look for its lowest original index and the point behind it (a version in
+    // which every wave published a full candidate before ONE barrier was slower: 2.84 vs 2.48 ms)
+    int wn = 0x7FFFFFFF;
+    if (wd == dstar) {
+      int bn = 0x7FFFFFFF;
+      float ox = 0.f, oy = 0.f, oz = 0.f;
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        if (__ballot(gmax[g] == dstar)) {  // scalar branch: usually one group of one wave
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const int j = 8 * g + e;
+            const bool hit = td[j] == dstar && orig[j] < bn;
+            bn = hit ? orig[j] : bn;
+            ox = hit ? px[j] : ox;
+            oy = hit ? py[j] : oy;
+            oz = hit ? pz[j] : oz;
+          }
+        }
+      }
+      wn = v3d_dpp_min_i32<true>(bn);
+      if (bn == wn && wn != 0x7FFFFFFF) {  // the owning lane publishes the point
+        win_xyz[s & 1][wave][0] = ox;
+        win_xyz[s & 1][wave][1] = oy;
+        win_xyz[s & 1][wave][2] = oz;
+      }
+    }
+    if (lane == 0) win_n[s & 1][wave] = wn;
+    __syncthreads();
+    int last = win_n[s & 1][0], ww = 0;
+#pragma unroll
+    for (int w = 1; w < NW; w++) {
+      const int c = win_n[s & 1][w];
+      ww = c < last ? w : ww;
+      last = min(last, c);
+    }
+    cx = win_xyz[s & 1][ww][0];
+    cy = win_xyz[s & 1][ww][1];
+    cz = win_xyz[s & 1][ww][2];
+    if (tid == 0) out[s] = last;
+  }
+}
+
 extern "C" size_t v3d_fps_workspace(int B, int N) {
   (void)B;
   (void)N;
@@ -113,6 +300,14 @@ extern "C" int v3d_furthest_point_sample(const float* xyz, int B, int N, int K, 
   if (B < 0 || N < 1 || K < 1 || K > N) return V3D_EINVAL;
   if (B == 0) return V3D_OK;
   if (!xyz || !idx) return V3D_EINVAL;
+  if (N > 1024 && N <= 64 * FPS_SLAB_THREADS) {  // the PV-RCNN keypoint sizes: slab-skipping kernel
+    const int slots = v3d_ceil_div(N, FPS_SLAB_THREADS);
+    if (slots <= 16) hipLaunchKernelGGL(fps_slab_kernel<16>, dim3(B), dim3(FPS_SLAB_THREADS), 0, st, xyz, N, K, idx);
+    else if (slots <= 32) hipLaunchKernelGGL(fps_slab_kernel<32>, dim3(B), dim3(FPS_SLAB_THREADS), 0, st, xyz, N, K, idx);
+    else hipLaunchKernelGGL(fps_slab_kernel<64>, dim3(B), dim3(FPS_SLAB_THREADS), 0, st, xyz, N, K, idx);
+    V3D_CHECK_LAUNCH();
+    return V3D_OK;
+  }
   const int ppt = v3d_ceil_div(N, FPS_THREADS);
 #define V3D_FPS(P)                                                                                   \
   if (ppt <= P) {                                                                                    \

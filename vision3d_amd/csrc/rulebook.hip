@@ -78,7 +78,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_candidates_kernel(const int4* __
                                                                   const RbGeom g, const V3dHash h,
                                                                   unsigned* __restrict__ first_ticket,
                                                                   int* __restrict__ cand_slot,
-                                                                  int* __restrict__ overflow) {
+                                                                  int* __restrict__ overflow, int* __restrict__ overflow_any) {
   const long long nt = (long long)min(*n_ptr, cap_in) * g.K;
   for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < nt; t += (long long)gridDim.x * V3D_BLOCK) {
     const int i = (int)(t / g.K), k = (int)(t % g.K);
@@ -87,7 +87,10 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_candidates_kernel(const int4* __
     if (rb_candidate(c, k, g, oz, oy, ox)) {
       s = v3d_hash_insert(h, rb_key(c.x, oz, oy, ox, g.out_shape));
       if (s >= 0) atomicMin(&first_ticket[s], (unsigned)t);
-      else atomicExch(overflow, 1);
+      else {
+        atomicExch(overflow, 1);
+        if (overflow_any) atomicExch(overflow_any, 1);
+      }
     }
     cand_slot[t] = s;
   }
@@ -122,7 +125,8 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_count_scan_kernel(const int* __r
                                                                   const unsigned* __restrict__ first_ticket,
                                                                   const int* __restrict__ n_ptr, int cap_in, int K,
                                                                   int* __restrict__ chunk_counts, int n_chunks, int cap_out,
-                                                                  int* __restrict__ n_out, int* __restrict__ overflow) {
+                                                                  int* __restrict__ n_out, int* __restrict__ overflow,
+                                                                  int* __restrict__ overflow_any) {
   __shared__ int lds[8];
   const long long nt = (long long)min(*n_ptr, cap_in) * K;
   const long long base = (long long)blockIdx.x * V3D_SCAN_CHUNK;
@@ -139,7 +143,10 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_count_scan_kernel(const int* __r
   if (blockIdx.x != gridDim.x - 1) return;
   const int total = v3d_block_exclusive_scan_global(chunk_counts, n_chunks, lds);
   if (threadIdx.x == 0) {
-    if (total > cap_out) atomicExch(overflow, 1);
+    if (total > cap_out) {
+      atomicExch(overflow, 1);
+      if (overflow_any) atomicExch(overflow_any, 1);
+    }
     *n_out = min(total, cap_out);
   }
 }
@@ -281,7 +288,7 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
                           const int32_t* ksize, const int32_t* stride, const int32_t* padding, int32_t* coords_out,
                           int32_t* n_out, int cap_out, int32_t* nbr, int32_t* overflow, V3dRbHash out,
                           unsigned* first_ticket, int* cand_slot, int* chunk_counts, int32_t* out_shape, int clear,
-                          const int32_t* next_subm_ksize, int32_t* next_subm_nbr, hipStream_t st) {
+                          const int32_t* next_subm_ksize, int32_t* next_subm_nbr, hipStream_t st, int32_t* overflow_any) {
   RbGeom g;
   int rc = fill_geom(g, shape, ksize, stride, padding);
   if (rc) return rc;
@@ -301,9 +308,9 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
   V3dHash h = v3d_make_hash(out.keys, out.hcap);
   const int tblocks = min(v3d_ceil_div(tickets, V3D_BLOCK), 4096);
   hipLaunchKernelGGL(rb_candidates_kernel, dim3(tblocks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in,
-                     g, h, first_ticket, cand_slot, overflow);
+                     g, h, first_ticket, cand_slot, overflow, overflow_any);
   hipLaunchKernelGGL(rb_count_scan_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, cand_slot, first_ticket, n_in, cap_in, g.K,
-                     chunk_counts, chunks, cap_out, n_out, overflow);
+                     chunk_counts, chunks, cap_out, n_out, overflow, overflow_any);
   hipLaunchKernelGGL(rb_emit_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in, g,
                      cand_slot, first_ticket, chunk_counts, cap_out, (int4*)coords_out, out.vals);
   RbGeom sg = g;

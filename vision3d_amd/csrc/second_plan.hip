@@ -265,7 +265,8 @@ extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n
                                    so.n_dev, so.cap, p->nbr[L.rulebook], p->overflow + l, so.hash, so.first_ticket,
                                    p->cand_slot, L.chunk_counts, nullptr, 0,
                                    fuse ? p->layers[l + 1].d.ksize : nullptr,
-                                   fuse ? p->nbr[p->layers[l + 1].rulebook] : nullptr, st);
+                                   fuse ? p->nbr[p->layers[l + 1].rulebook] : nullptr, st,
+                                   p->overflow + p->layers.size() /*summary flag: any layer*/);
         if (fuse) rb_done[l + 1] = 1;
       }
       if (rc) return rc;
@@ -338,5 +339,6 @@ extern "C" int v3d_backbone_tune(v3d_backbone* p) {
 }
 
 extern "C" int32_t* v3d_backbone_occupancy(v3d_backbone* p) { return p ? p->occupancy : nullptr; }
+// flags[l] = layer l hit its active-site capacity; flags[n_layers] = any of them (one word for the caller's per-frame read)
 extern "C" int32_t* v3d_backbone_overflow_flags(v3d_backbone* p) { return p ? p->overflow : nullptr; }
 extern "C" int v3d_backbone_num_layers(const v3d_backbone* p) { return p ? (int)p->layers.size() : 0; }

@@ -25,7 +25,8 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
                           unsigned* first_ticket, int* cand_slot, int* chunk_counts /*reads -1 at launch unless clear*/,
                           int32_t* out_shape, int clear,
                           const int32_t* next_subm_ksize /*nullable: also build the submanifold table of the OUTPUT sites*/,
-                          int32_t* next_subm_nbr, hipStream_t st);
+                          int32_t* next_subm_nbr, hipStream_t st,
+                          int32_t* overflow_any = nullptr /*nullable: a second flag raised together with *overflow (the plan's summary)*/);
 
 // iou_nms.hip: mask + greedy reduction on boxes already sorted by (score desc, index asc) and prepped (BoxPrep rows)
 int v3d_i_nms_sorted(const void* prep_sorted, const int* order, int N, float iou_threshold, int64_t* keep, int32_t* n_keep,

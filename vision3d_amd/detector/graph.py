@@ -63,7 +63,9 @@ class GraphedSecond(object):
             self._capture()
         self.graph.replay()
         head = self.model.head
-        return head.finalize_native(*self.outputs) if self.native else head.finalize(*self.outputs)
+        if self.native:
+            return head.finalize_native(*self.outputs, overflow_flag=self.plan.overflow_any())
+        return head.finalize(*self.outputs)
 
 
 def choose_streams(time_of, n_candidates, max_depth, min_gain=0.03):
@@ -132,7 +134,9 @@ class PipelinedSecond(object):
     def _finish(self, i, stream):
         g = self.slots[i]
         with torch.cuda.stream(stream):
-            return g.model.head.finalize_native(*g.outputs) if g.native else g.model.head.finalize(*g.outputs)
+            if g.native:
+                return g.model.head.finalize_native(*g.outputs, overflow_flag=g.plan.overflow_any())
+            return g.model.head.finalize(*g.outputs)
 
     # ---- stream selection by measurement ---------------------------------------------------------------------
     def _time_streams(self, streams, clouds, frames):
@@ -182,8 +186,15 @@ class PipelinedSecond(object):
     def collect(self):
         i = self.pending.pop(0)
         out = self._finish(i, self.streams[i])
+        consumer = torch.cuda.current_stream()
         with torch.cuda.stream(self.streams[i]):
-            return [t.clone() for t in out]  # the slot's static buffers are overwritten by its next frame
+            res = [t.clone() for t in out]  # the slot's static buffers are overwritten by its next frame
+        # the clones were produced on the slot's stream: order the caller's stream behind them and tell the caching allocator
+        # that the blocks are in use there (they were allocated on the slot's stream)
+        consumer.wait_stream(self.streams[i])
+        for t in res:
+            t.record_stream(consumer)
+        return res
 
     def __call__(self, clouds):
         """submit this frame, return the oldest finished one once the pipeline is full (None while it fills)."""

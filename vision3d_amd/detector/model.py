@@ -1,6 +1,7 @@
 """PV-RCNN (interface of vision3d/detector/model.py:16-85).
 
-Data flow of the pieces that exist upstream (its `forward` raises: stage 2 was never wired, model.py:84-85):
+Data flow of the pieces that exist upstream (its `forward` raises: stage 2 was never wired, model.py:84-85; here `forward` /
+`inference` wire them the evident way -- SURVEY.md 8(f) rank 3 -- and say so, this is the repository's definition):
 
     points --FPS--> keypoints --------------------------------------------+
     voxels --sparse CNN--> 4 levels of (xyz, features) + BEV map          |
@@ -55,7 +56,7 @@ class PV_RCNN(nn.Module):
         """sources: [(xyz (B, N, 3), features (B, N, C))] -> [(B, C_out, K)], one per source."""
         pooled = []
         for pnet, (xyz, features) in zip(self.pnets, sources):
-            _, out = pnet(xyz.contiguous(), features.transpose(1, 2).contiguous(), keypoint_xyz)
+            _, out = pnet(xyz.contiguous(), None, keypoint_xyz, features_pm=features)  # point-major in: no (B, C, N) round trip
             pooled.append(out)
         return pooled
 
@@ -79,5 +80,51 @@ class PV_RCNN(nn.Module):
         item["_cnn_features"], item["_bev_map"] = cnn_features, bev_map
         return item
 
-    def forward(self, item):
-        raise NotImplementedError("upstream never wired stage 2 into forward (vision3d/detector/model.py:84-85)")
+    # ---- stage 2 (upstream: `forward` raises, model.py:84-85).  Definition of this repository:
+    #   proposals   = per (frame, class) the TOPK highest-scoring anchors of stage 1, decoded (ProposalLayer's own top-k + decode,
+    #                 proposal.py:61-77), BEFORE NMS: a fixed (B, n_cls * TOPK, 7) block, which is what RoiGridPool takes;
+    #   refinement  = RefinementLayer on the RoI-grid-pooled keypoint features -> 7 residuals + 1 confidence logit per proposal;
+    #   refined box = box_encode.decode(residuals, proposal)  (RefinementLayer.apply_refinements);
+    #   inference   = refined boxes scored by sigmoid(confidence), rotated NMS per (frame, class) at the stage-1 IoU threshold,
+    #                 the per-class score threshold of the config.
+    def stage1_proposals(self, item):
+        """-> boxes (B, n_cls * TOPK, 7), scores (B, n_cls * TOPK), class_idx (n_cls * TOPK,) from P_cls / P_reg / anchors."""
+        head = self.proposal_layer
+        score_map = item["P_cls"].sigmoid()
+        b, n_cls = score_map.shape[:2]
+        scores, anchor_idx = score_map.reshape(b, n_cls, -1).topk(head.TOPK, -1)
+        boxes = head._decode(item["P_reg"], item["anchors"], anchor_idx)  # (B, n_cls, TOPK, 7)
+        class_idx = torch.arange(n_cls, device=scores.device).repeat_interleave(head.TOPK)
+        return boxes.reshape(b, -1, head.DOF), scores.reshape(b, -1), class_idx
+
+    def forward(self, item, samples=None):
+        """Stage 1 + stage 2.  Adds to `item`: keypoints, P_cls, P_reg, keypoint_features (B, 512, K), proposals (B, n, 7),
+        proposal_scores (B, n), proposal_class (n,), pooled_features (B, n, 256), R_reg (B, n, 7), R_cls (B, n, 1) and
+        boxes_refined (B, n, 7).  `samples` (B, n, NUM_GRIDPOINTS, 3) in [0, 1) fixes the RoI grid points (the reference draws
+        them with an unseeded torch.rand, roi_grid_pool.py:59)."""
+        item = self.proposal(item)
+        features = self.point_feature_extract(item, item["_cnn_features"], item["_bev_map"])
+        boxes, scores, class_idx = self.stage1_proposals(item)
+        pooled = self.roi_grid_pool(boxes, item["keypoints"], features, samples)
+        deltas, conf = self.refinement_layer(item["points"], pooled, boxes)
+        item.update(keypoint_features=features, proposals=boxes, proposal_scores=scores, proposal_class=class_idx,
+                    pooled_features=pooled, R_reg=deltas, R_cls=conf,
+                    boxes_refined=self.refinement_layer.apply_refinements(deltas, boxes))
+        return item
+
+    def inference(self, item, samples=None):
+        """-> (boxes (K, 7), batch_idx (K,), class_idx (K,), scores (K,)) by decreasing score, the return contract of
+        Second.inference / ProposalLayer.inference."""
+        from ..ops import batched_nms_rotated
+        item = self.forward(item, samples)
+        boxes = item["boxes_refined"]
+        b, n = boxes.shape[:2]
+        scores = item["R_cls"].sigmoid().reshape(-1)
+        boxes = boxes.reshape(-1, boxes.shape[-1])
+        batch_idx = torch.arange(b, device=boxes.device).repeat_interleave(n)
+        class_idx = item["proposal_class"].repeat(b)
+        n_cls = self.cfg.NUM_CLASSES
+        keep = batched_nms_rotated(boxes[:, [0, 1, 3, 4, 6]].contiguous(), scores, class_idx + n_cls * batch_idx, 0.01)
+        boxes, batch_idx, class_idx, scores = (x[keep] for x in (boxes, batch_idx, class_idx, scores))
+        mask = self.proposal_layer._above_score_thresh(scores, class_idx)
+        return [x[mask] for x in (boxes, batch_idx, class_idx, scores)]

@@ -16,6 +16,17 @@ from ..core.box_encode import decode
 from ..ops import batched_nms_rotated, batched_nms_rotated_padded, sigmoid_focal_loss
 
 
+_PINNED = {}
+
+
+def _pinned_pair(device):
+    """Two pinned int32 words per device for the per-frame count / overflow read (host code is sequential: copy, sync, read)."""
+    key = str(device)
+    if key not in _PINNED:
+        _PINNED[key] = torch.empty(2, dtype=torch.int32).pin_memory()
+    return _PINNED[key]
+
+
 class ProposalLayer(nn.Module):
 
     def __init__(self, cfg):
@@ -123,15 +134,31 @@ class ProposalLayer(nn.Module):
         return boxes, batch_idx, class_idx, scores, n_out
 
     @staticmethod
-    def finalize_native(boxes, batch_idx, class_idx, scores, n_out):
-        n = int(n_out.item())  # the one host read of the frame (the reference synchronises inside its NMS)
+    def finalize_native(boxes, batch_idx, class_idx, scores, n_out, overflow_flag=None):
+        """The one host read of the frame (the reference synchronises inside its NMS): the number of proposals and, when
+        the frame came through a BackbonePlan, that plan's capacity-overflow word in the same synchronisation -- a stage
+        that hit its active-site capacity has dropped rows, so the BEV map is wrong and the frame must not be returned."""
+        if overflow_flag is None:
+            n = int(n_out.item())
+        else:
+            host = _pinned_pair(n_out.device)
+            host[0:1].copy_(n_out, non_blocking=True)
+            host[1:2].copy_(overflow_flag, non_blocking=True)
+            torch.cuda.current_stream(n_out.device).synchronize()
+            n, ovf = int(host[0]), int(host[1])
+            if ovf > 0:
+                raise RuntimeError("sparse backbone: a stage exceeded its active-site capacity (rows were dropped); build the "
+                                   "plan with a larger `growth` (Second.plan_growth / BackbonePlan(growth=...))")
         return [boxes[:n], batch_idx[:n], class_idx[:n], scores[:n]]
 
-    def inference_native(self, head_maps, anchors):
+    def inference_native(self, head_maps, anchors, overflow_flag=None):
         if not self.native_supported(head_maps.shape[0], anchors.numel() // (7 * self.cfg.NUM_CLASSES)):  # too large: op-by-op
             cls_map, reg_map = self.maps_from_fused(head_maps)
-            return self.inference_from_maps(cls_map, reg_map, anchors)
-        return self.finalize_native(*self.native_proposals(head_maps, anchors))
+            out = self.inference_from_maps(cls_map, reg_map, anchors)
+            if overflow_flag is not None and int(overflow_flag.item()) > 0:
+                raise RuntimeError("sparse backbone: a stage exceeded its active-site capacity (rows were dropped)")
+            return out
+        return self.finalize_native(*self.native_proposals(head_maps, anchors), overflow_flag=overflow_flag)
 
     def finalize(self, boxes, batch_idx, class_idx, scores, keep, n_keep):
         keep = keep[: int(n_keep.item())]

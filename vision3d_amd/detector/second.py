@@ -129,7 +129,8 @@ class Second(nn.Module):
         dev = next(self.parameters()).device
         key = (str(dev), int(max_batch), int(max_points)) + ((int(slot),) if slot else ())
         if key not in plans:
-            plans[key] = BackbonePlan(self.cnn, self.cfg, max_batch=max_batch, max_points=max_points, device=dev)
+            plans[key] = BackbonePlan(self.cnn, self.cfg, max_batch=max_batch, max_points=max_points, device=dev,
+                                      growth=self.__dict__.get("plan_growth", 2.0))
         return plans[key]
 
     def bev_from_points(self, clouds):
@@ -191,6 +192,8 @@ class Second(nn.Module):
         if dense == "torch":
             return self.head.inference(self.rpn(self.bev_from_points(clouds)), anchors)
         if proposals == "native":
-            return self.head.inference_native(self.fused_head_from_points(clouds), anchors)
+            plan, flat, offsets = self._plan_for(clouds)
+            hi, lo = plan.forward_split(flat, offsets)
+            return self.head.inference_native(self.dense_plan().forward(hi, lo), anchors, overflow_flag=plan.overflow_any())
         cls_map, reg_map = self.head_maps_from_points(clouds)
         return self.head.inference_from_maps(cls_map, reg_map, anchors)

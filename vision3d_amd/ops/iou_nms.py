@@ -4,6 +4,7 @@ Boxes are (x_ctr, y_ctr, width, height, angle_degrees) float32.  The detector fe
 these degree-based ops; that behaviour is part of the reference and is preserved.
 All arithmetic runs in libvision3d_hip.so (csrc/iou_nms.hip); there is no CPU path.
 """
+import numpy as np
 import torch
 
 from .. import _lib as L
@@ -39,8 +40,22 @@ def box_iou_rotated_3d(boxes1, boxes2):
     return out
 
 
-def nms_rotated_padded(boxes, scores, iou_threshold):
+def _rule_threshold(iou_threshold, rule):
+    """The kernels suppress on IoU >= t (the reference CPU path, nms_rotated_cpu.cpp:53 -- the parity target named by
+    BASELINE.json: "match the reference CPU/PyTorch path").  The reference CUDA path suppresses on IoU > t
+    (nms_rotated_cuda.cu:62-63); for float32 that is IoU >= nextafter(t, +inf), so rule="cuda" needs no second kernel.
+    The two differ only when an IoU equals the threshold exactly."""
+    t = np.float32(iou_threshold)
+    if rule == "cpu":
+        return float(t)
+    if rule == "cuda":
+        return float(np.nextafter(t, np.float32(np.inf)))
+    raise ValueError("rule must be 'cpu' (IoU >= thr) or 'cuda' (IoU > thr)")
+
+
+def nms_rotated_padded(boxes, scores, iou_threshold, rule="cpu"):
     """Device-resident result: (keep (N,) int64 padded, n_keep (1,) int32) -- no host synchronisation."""
+    iou_threshold = _rule_threshold(iou_threshold, rule)
     L.require_gpu("nms_rotated", boxes, scores)
     b, s = L.as_f32("nms_rotated", boxes), L.as_f32("nms_rotated", scores)
     if b.dim() != 2 or b.shape[-1] != 5 or s.shape != (b.shape[0],):
@@ -57,14 +72,15 @@ def nms_rotated_padded(boxes, scores, iou_threshold):
     return keep, n_keep
 
 
-def nms_rotated(boxes, scores, iou_threshold):
+def nms_rotated(boxes, scores, iou_threshold, rule="cpu"):
     """Indices kept by greedy rotated NMS, by decreasing score (vision3d/ops/iou_nms.py:38-85).
-    Suppression rule of the reference CPU path: IoU >= threshold (nms_rotated_cpu.cpp:53)."""
-    keep, n_keep = nms_rotated_padded(boxes, scores, iou_threshold)
+    rule="cpu" (default): suppress on IoU >= threshold, the reference CPU path (nms_rotated_cpu.cpp:53) and this
+    repository's parity target; rule="cuda": IoU > threshold, what the reference's CUDA build does (nms_rotated_cuda.cu:62)."""
+    keep, n_keep = nms_rotated_padded(boxes, scores, iou_threshold, rule)
     return keep[: int(n_keep.item())]
 
 
-def batched_nms_rotated(boxes, scores, idxs, iou_threshold):
+def batched_nms_rotated(boxes, scores, idxs, iou_threshold, rule="cpu"):
     """Per-category NMS through the coordinate-offset trick (vision3d/ops/iou_nms.py:90-134): every
     category is shifted by idx * (max_coord - min_coord + 1) so categories never overlap."""
     assert boxes.shape[-1] == 5
@@ -74,7 +90,7 @@ def batched_nms_rotated(boxes, scores, idxs, iou_threshold):
     lo = (torch.min(boxes[:, 0], boxes[:, 1]) - torch.min(boxes[:, 2], boxes[:, 3]) / 2).min()
     shifted = boxes.clone()
     shifted[:, :2] += (idxs.to(boxes) * (hi - lo + 1))[:, None]
-    return nms_rotated(shifted, scores, iou_threshold)
+    return nms_rotated(shifted, scores, iou_threshold, rule)
 
 
 def batched_nms_rotated_padded(boxes, scores, idxs, iou_threshold):

@@ -31,11 +31,88 @@ class PointnetSAModuleMSG(nn.Module):
                 spec[0] += 3
             self.mlps.append(shared_mlp(spec, bn=bn))
 
-    def forward(self, xyz, features=None, new_xyz=None):
-        """xyz (B,N,3), features (B,C,N), new_xyz (B,M,3) -> (new_xyz, (B, sum(mlps[k][-1]), M))."""
+    # ---- inference: the whole scale on csrc/sa_mlp.hip (no grouped tensor, no MIOpen 1x1 convolution)
+    def _fusable(self, features):
+        if self.training or torch.is_grad_enabled() or features is None or not features.is_cuda or self.pool_method != "max_pool":
+            return False
+        for g, mlp in zip(self.groupers, self.mlps):
+            if not g.use_xyz or g.nsample not in (16, 32):
+                return False
+            mods = list(mlp)
+            if not mods or any(not isinstance(m, (nn.Conv2d, nn.BatchNorm2d, nn.ReLU)) for m in mods):
+                return False
+        return True
+
+    def _packed_layers(self, k):
+        """[(W (K_in, Nout_pad), bias (Nout_pad))] of scale k: eval BatchNorm folded in, rows laid out for sa_mlp_layer (first
+        layer: xyz rows 0-2, a zero row, then the feature rows; channel counts padded with zeros to multiples of 4 / 16),
+        cached until a parameter or running statistic changes."""
+        mods = list(self.mlps[k])
+        convs = [m for m in mods if isinstance(m, nn.Conv2d)]
+        bns = [m for m in mods if isinstance(m, nn.BatchNorm2d)]
+        tensors = [t for c in convs for t in (c.weight, c.bias) if t is not None]
+        tensors += [t for b in bns for t in (b.weight, b.bias, b.running_mean, b.running_var)]
+        stamp = tuple((t.data_ptr(), t._version) for t in tensors)
+        cache = self.__dict__.setdefault("_pack_cache", {})
+        if k in cache and cache[k][0] == stamp:
+            return cache[k][1]
+        packed, k_prev_pad = [], None
+        with torch.no_grad():
+            for li, conv in enumerate(convs):
+                w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels).float()
+                bias = conv.bias.detach().float() if conv.bias is not None else w.new_zeros(conv.out_channels)
+                if bns:
+                    bn = bns[li]
+                    scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+                    w, bias = w * scale[:, None], (bias - bn.running_mean.float()) * scale + bn.bias.float()
+                wt = w.t().contiguous()  # (cin, cout)
+                nout_pad = -(-conv.out_channels // 16) * 16
+                if li == 0:
+                    c = conv.in_channels - 3
+                    kf = -(-c // 4) * 4
+                    full = wt.new_zeros((4 + kf, nout_pad))
+                    full[0:3, :conv.out_channels] = wt[0:3]
+                    full[4:4 + c, :conv.out_channels] = wt[3:]
+                else:
+                    full = wt.new_zeros((k_prev_pad, nout_pad))
+                    full[:conv.in_channels, :conv.out_channels] = wt
+                bpad = bias.new_zeros(nout_pad)
+                bpad[:conv.out_channels] = bias
+                packed.append((full.contiguous(), bpad.contiguous()))
+                k_prev_pad = nout_pad
+        cache[k] = (stamp, packed)
+        return packed
+
+    def fused_forward(self, xyz, features_pm, new_xyz):
+        """features_pm (B, N, C) POINT-major -> (B, sum(mlps[k][-1]), M)."""
+        b, n, c = features_pm.shape
+        m = new_xyz.shape[1]
+        kf = -(-c // 4) * 4
+        feat = features_pm.contiguous() if kf == c else torch.nn.functional.pad(features_pm, (0, kf - c)).contiguous()
+        xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
+        outs = []
+        for k, grouper in enumerate(self.groupers):
+            layers = self._packed_layers(k)
+            ns = grouper.nsample
+            idx = PU.ball_query(grouper.radius, ns, xyz, new_xyz)
+            x = PU.sa_mlp_layer(feat, layers[0][0], layers[0][1], True, len(layers) == 1, xyz=xyz, new_xyz=new_xyz, idx=idx)
+            for li in range(1, len(layers)):
+                x = PU.sa_mlp_layer(x, layers[li][0], layers[li][1], True, li == len(layers) - 1, groups=(b, m, ns))
+            cout = [mod for mod in self.mlps[k] if isinstance(mod, nn.Conv2d)][-1].out_channels
+            outs.append(x.view(b, m, -1)[:, :, :cout])
+        return torch.cat(outs, dim=2).transpose(1, 2).contiguous()
+
+    def forward(self, xyz, features=None, new_xyz=None, features_pm=None):
+        """xyz (B,N,3), features (B,C,N), new_xyz (B,M,3) -> (new_xyz, (B, sum(mlps[k][-1]), M)).  `features_pm` (B,N,C) may
+        be given instead of `features` by callers that hold point-major features (saves two transposes)."""
         if new_xyz is None:
             idx = PU.furthest_point_sample(xyz, self.npoint)
             new_xyz = PU.gather_operation(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+        if features is None and features_pm is not None and not self._fusable(features_pm):
+            features = features_pm.transpose(1, 2).contiguous()
+        if self._fusable(features if features is not None else features_pm):
+            pm = features_pm if features_pm is not None else features.transpose(1, 2)
+            return new_xyz, self.fused_forward(xyz, pm, new_xyz)
         outs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             g = mlp(grouper(xyz, new_xyz, features))  # (B, C', M, ns)

@@ -1,5 +1,6 @@
 """furthest_point_sample / gather_operation / ball_query / grouping_operation / QueryAndGroup
-(csrc/pointops.hip).  Forward only in this round."""
+(csrc/pointops.hip, csrc/sa_mlp.hip).  gather_operation and grouping_operation are differentiable in `features`
+(upstream pointnet2 implements both backward passes: a scatter-add of the output gradient)."""
 import torch
 from torch import nn
 
@@ -18,10 +19,52 @@ def furthest_point_sample(xyz, npoint):
     return idx
 
 
+def _scatter_add_backward(grad_out, idx_flat, n):
+    """grad_out (B, C, J), idx_flat (B, J) -> (B, C, N): gradient of a gather along the last axis."""
+    b, c, _ = grad_out.shape
+    grad = grad_out.new_zeros((b, c, n))
+    return grad.scatter_add_(2, idx_flat.long().unsqueeze(1).expand(-1, c, -1), grad_out)
+
+
+class _GatherFunction(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = features.shape[2]
+        return _gather_forward(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return _scatter_add_backward(grad_out.contiguous(), idx, ctx.n), None
+
+
+class _GroupFunction(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = features.shape[2]
+        return _group_forward(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        b, c, m, ns = grad_out.shape
+        return _scatter_add_backward(grad_out.reshape(b, c, m * ns), idx.reshape(b, m * ns), ctx.n), None
+
+
 def gather_operation(features, idx):
-    """features (B, C, N), idx (B, K) int32 -> (B, C, K)."""
+    """features (B, C, N), idx (B, K) int32 -> (B, C, K); differentiable in `features`."""
+    if torch.is_grad_enabled() and features.requires_grad:
+        return _GatherFunction.apply(features, idx)
+    return _gather_forward(features, idx)
+
+
+def _gather_forward(features, idx):
     L.require_gpu("gather_operation", features, idx)
-    f, i = L.as_f32("gather_operation", features), L.as_i32("gather_operation", idx)
+    f, i = L.as_f32("gather_operation", features.detach()), L.as_i32("gather_operation", idx)
     b, c, n = f.shape
     k = i.shape[1]
     out = torch.empty((b, c, k), dtype=torch.float32, device=f.device)
@@ -45,9 +88,15 @@ def ball_query(radius, nsample, xyz, new_xyz):
 
 
 def grouping_operation(features, idx):
-    """features (B, C, N), idx (B, M, ns) int32 -> (B, C, M, ns)."""
+    """features (B, C, N), idx (B, M, ns) int32 -> (B, C, M, ns); differentiable in `features`."""
+    if torch.is_grad_enabled() and features.requires_grad:
+        return _GroupFunction.apply(features, idx)
+    return _group_forward(features, idx)
+
+
+def _group_forward(features, idx):
     L.require_gpu("grouping_operation", features, idx)
-    f, i = L.as_f32("grouping_operation", features), L.as_i32("grouping_operation", idx)
+    f, i = L.as_f32("grouping_operation", features.detach()), L.as_i32("grouping_operation", idx)
     b, c, n = f.shape
     _, m, ns = i.shape
     out = torch.empty((b, c, m, ns), dtype=torch.float32, device=f.device)
@@ -73,3 +122,33 @@ class QueryAndGroup(nn.Module):
             return grouped_xyz
         grouped = grouping_operation(features, idx)
         return torch.cat([grouped_xyz, grouped], dim=1) if self.use_xyz else grouped
+
+
+def sa_mlp_layer(feat, w, bias, relu=True, pool=False, xyz=None, new_xyz=None, idx=None, groups=None):
+    """One layer of a set-abstraction shared MLP on the matrix cores (csrc/sa_mlp.hip, exact fp32 MFMA).
+
+    first layer:  feat (B, N, Kf) point-major, xyz (B, N, 3), new_xyz (B, M, 3), idx (B, M, ns) int32;
+                  row (b, m, s) = [xyz[i] - new_xyz[m], 0 | feat[i]] with i = idx[b, m, s], w is (4 + Kf, Nout)
+    later layers: feat (B*M*ns, Kf) (the previous layer's output), groups = (B, M, ns), w is (Kf, Nout)
+    Kf % 4 == 0, Nout % 16 == 0.  Returns (B*M*ns, Nout), or (B*M, Nout) = max over the ns rows of a group with pool=True."""
+    L.require_gpu("sa_mlp_layer", feat, w)
+    f, wf = L.as_f32("sa_mlp_layer", feat), L.as_f32("sa_mlp_layer", w)
+    bf = None if bias is None else L.as_f32("sa_mlp_layer", bias)
+    if idx is not None:
+        b, n, kf = f.shape
+        _, m, ns = idx.shape
+        x, q, ii = L.as_f32("sa_mlp_layer", xyz), L.as_f32("sa_mlp_layer", new_xyz), L.as_i32("sa_mlp_layer", idx)
+    else:
+        b, m, ns = groups
+        n, kf = m * ns, f.shape[1]
+        x = q = ii = None
+        if f.shape[0] != b * m * ns:
+            raise RuntimeError("sa_mlp_layer: rows do not match (B, M, ns)")
+    nout = wf.shape[1]
+    if wf.shape[0] != kf + (4 if idx is not None else 0):
+        raise RuntimeError("sa_mlp_layer: weight rows do not match the input width")
+    out = torch.empty((b * m if pool else b * m * ns, nout), dtype=torch.float32, device=f.device)
+    with torch.cuda.device(f.device):
+        L.check(L.lib().v3d_sa_mlp_layer(L.ptr(f), L.ptr(x), L.ptr(q), L.ptr(ii), b, n, m, ns, kf, L.ptr(wf), L.ptr(bf), nout,
+                                         int(bool(relu)), int(bool(pool)), L.ptr(out), L.stream_ptr()), "sa_mlp_layer")
+    return out

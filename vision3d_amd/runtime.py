@@ -145,9 +145,12 @@ class BackbonePlan(object):
 
     def _maybe_tune(self):
         """True once, right after the first eager forward: the caller repeats that forward so that even the first
-        result it returns comes from the kernels every later frame will use (the variants differ in the last bits)."""
+        result it returns comes from the kernels every later frame will use (the variants differ in the last bits).
+        That first forward is synchronised anyway, so it also checks the capacities against the observed frame."""
         if not self.__dict__.get("_tuned") and not torch.cuda.is_current_stream_capturing():
             self.tune()
+            if not self.__dict__.get("allow_overflow"):
+                self.check_overflow()
             return True
         return False
 
@@ -178,9 +181,23 @@ class BackbonePlan(object):
             _view(c.value, (cap.value, 4), torch.int32, self.device), _view(n.value, (1,), torch.int32, self.device), list(shape)
 
     def overflow(self):
-        """(n_layers + 1,) int32 device flags of the last forward: 1 where a capacity was hit."""
+        """(n_layers + 1,) int32 device flags of the last forward: [l] = 1 where layer l hit its active-site capacity
+        (rows were dropped), [n_layers] = 1 if any did."""
         ptr = L.lib().v3d_backbone_overflow_flags(self._handle)
         return (_view(ptr, (len(self.layers) + 1,), torch.int32, self.device) > 0).to(torch.int32)
+
+    def overflow_any(self):
+        """(1,) int32 device view of the summary word (> 0 = some stage dropped rows in the last forward): what the
+        inference paths read together with the proposal count (ProposalLayer.finalize_native)."""
+        ptr = L.lib().v3d_backbone_overflow_flags(self._handle)
+        return _view(ptr + 4 * len(self.layers), (1,), torch.int32, self.device)
+
+    def check_overflow(self):
+        """Blocking check for callers that only take the BEV map (no per-frame host read of their own)."""
+        if int(self.overflow_any().item()) > 0:
+            hit = [i for i, f in enumerate(self.overflow()[:-1].tolist()) if f]
+            raise RuntimeError(f"sparse backbone: layers {hit} exceeded their active-site capacity (rows were dropped); "
+                               "build the plan with a larger `growth`")
 
 
 class _DevMem(object):
