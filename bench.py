@@ -70,6 +70,7 @@ def parse():
                          "exactly K frames.  0 (default): up to 4 in flight, streams and depth picked by measurement before the "
                          "warm-up (PipelinedSecond.tune); N >= 2: exactly N on streams in creation order; 1: one frame at a time "
                          "(always reported beside it as single_frame_ms / frames_per_s_one_at_a_time)")
+    ap.add_argument("--stream", type=int, default=8, help="different synthetic frames per rank the timed loop cycles through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch event timing pass (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (about 1.4 s each on one core: ~11 s)")
@@ -215,6 +216,60 @@ def pvrcnn_main(args):
         dist.destroy_process_group()
 
 
+def _cpu_frame(job):
+    """One frame of the CPU restatement (oracle/: scalar C sparse path + torch CPU dense path) on ONE thread; returns seconds."""
+    sd, seed, points, cfgd, anchors, workload = job
+    import torch as _t
+    _t.set_num_threads(1)
+    from oracle import second_cpu
+    from vision3d_amd import synth as _s
+    cloud = _s.make_waymo_cloud(seed, points) if workload == "waymo" else _s.make_cloud(seed, points)
+    c0 = time.perf_counter()
+    ref = second_cpu.second_forward(sd, [cloud], cfgd["VOXEL_SIZE"], cfgd["GRID_BOUNDS"], cfgd["MAX_OCCUPANCY"], cfgd["MAX_VOXELS"])
+    second_cpu.proposals(ref["cls"], ref["reg"], anchors, 1, 2, 7, cfgd["TOPK"], cfgd["THRESH"])
+    return time.perf_counter() - c0
+
+
+def run_cpu_baseline(model, cfg, anchors, make, args):
+    """cpu_baseline object: the CPU restatement timed on the host of THIS box -- one thread (value) and all cores (one frame
+    per worker process, one thread each: frames are independent, so that is how a CPU deployment would use its cores)."""
+    import multiprocessing as mp
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    n_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    cfgd = dict(VOXEL_SIZE=list(cfg.VOXEL_SIZE), GRID_BOUNDS=list(cfg.GRID_BOUNDS), MAX_OCCUPANCY=cfg.MAX_OCCUPANCY,
+                MAX_VOXELS=cfg.MAX_VOXELS, TOPK=cfg.PROPOSAL.TOPK, THRESH=[a["score_thresh"] for a in cfg.ANCHORS])
+    anc = anchors.cpu().numpy()
+    n_frames, t_cpu = 0, 0.0
+    while n_frames < args.cpu_frames and t_cpu < 30.0:
+        t_cpu += _cpu_frame((sd, 100 + n_frames, args.points, cfgd, anc, "kitti"))
+        n_frames += 1
+    out = dict(value=n_frames / t_cpu, unit="frames/s", cores=1, kind="port", cpu_model=cpu_model, host_cores=n_cores,
+               sample=f"{n_frames} frame(s) of the same 16k-pt workload, oracle/ (scalar C sparse path + torch CPU dense path, "
+                      f"1 thread), {t_cpu:.1f} s")
+    workers = max(1, min(n_cores, 32))
+    try:
+        ctx = mp.get_context("spawn")
+        jobs = [(sd, 200 + i, args.points, cfgd, anc, "kitti") for i in range(workers)]
+        w0 = time.perf_counter()
+        with ctx.Pool(workers) as pool:
+            per = pool.map(_cpu_frame, jobs)
+        wall = time.perf_counter() - w0
+        out["all_cores"] = dict(value=workers / max(per), unit="frames/s", cores=workers,
+                                sample=f"{workers} frames in {workers} single-thread worker processes, slowest frame {max(per):.2f} s "
+                                       f"(wall incl. process start {wall:.1f} s)")
+    except Exception as e:  # the 1-thread figure stands on its own
+        out["all_cores"] = dict(value=None, error=str(e)[:200])
+    return out
+
+
 def main():
     args = parse()
     if args.mode == "train":
@@ -248,9 +303,13 @@ def main():
     anchors = AnchorGenerator(acfg).anchors.cuda()
     # frame-parallel sharding: rank r owns frames r*B .. r*B+B-1 of the synthetic stream
     make = (lambda seed, n: synth.make_waymo_cloud(seed, n)) if waymo else (lambda seed, n: synth.make_cloud(seed, n))
-    clouds_np = [make(fid, args.points) for fid in
-                 [rank * args.batch + i for i in range(args.batch)]]  # = dist_util.shard_frames(world*B, rank, world)
-    clouds = [torch.from_numpy(c).cuda() for c in clouds_np]
+    # A stream of N_STREAM different frames per rank (seeds differ per rank and per step), resident in HBM before the timed
+    # region; step i runs frames stream[i % N_STREAM]: the timed loop is not a replay of one cache-resident cloud.
+    N_STREAM = max(1, args.stream)
+    stream_np = [[make((j * world + rank) * args.batch + i, args.points) for i in range(args.batch)] for j in range(N_STREAM)]
+    stream = [[torch.from_numpy(c).cuda() for c in frame] for frame in stream_np]
+    clouds_np, clouds = stream_np[0], stream[0]
+    step_no = [0]
 
     graphed = None
     if args.path == "graph":
@@ -265,6 +324,8 @@ def main():
     last_out = [None]
 
     def step():
+        clouds = stream[step_no[0] % N_STREAM]
+        step_no[0] += 1
         with torch.no_grad():
             if graphed is not None:
                 r = graphed(clouds)  # pipelined: the oldest finished frame (None while the pipeline fills)
@@ -307,12 +368,12 @@ def main():
     if args.path == "graph":
         g1 = graphed.slots[0] if pipelined else graphed
         with torch.no_grad():
-            for _ in range(5):
-                g1(clouds)
+            for i in range(5):
+                g1(stream[i % N_STREAM])
             torch.cuda.synchronize()
             s0 = time.perf_counter()
-            for _ in range(50):
-                g1(clouds)
+            for i in range(50):
+                g1(stream[i % N_STREAM])
             torch.cuda.synchronize()
             single_ms = 1e3 * (time.perf_counter() - s0) / 50
 
@@ -333,8 +394,9 @@ def main():
             captured.append((features, weight, rb, scale, shift, relu, algo, packed))
             return orig(features, weight, rb, scale, shift, relu, algo, packed)
         convmod.sparse_conv_forward = capture
-        with torch.no_grad():
-            model.inference(pre(dict(points=clouds, anchors=anchors)))
+        with torch.no_grad():  # the per-op sparse backbone (Second.inference(item) itself runs the fused plan: nothing to capture there)
+            it = pre(dict(points=clouds, anchors=anchors))
+            model.cnn(it["voxel_mean"], it["coordinates"], it["batch_size"])
         convmod.sparse_conv_forward = orig
         REP, layers = 25, []
         for (features, weight, rb, scale, shift, relu, algo, packed) in captured:
@@ -355,7 +417,12 @@ def main():
             st["bytes"] = layer_algorithmic_bytes(st)
             st["gbs"] = st["bytes"] / (st["t_avg_us"] * 1e-6) / 1e9
             layers.append(st)
-        dom = [l for l in layers if l["cin"] == 64 and l["cout"] == 64 and l["K"] == 27]  # the launches of DOM_KERNEL
+        # the launches of the dominant kernel: KITTI bs = 1 -> the 7 3x3x3 64->64 layers (all <= 16 384 rows: LDS-ring kernel);
+        # Waymo range -> the 3x3x3 64->64 layers with >= 32 768 live rows (64-row LDS-shared-weights kernel)
+        big = waymo or args.batch > 1
+        dom = [l for l in layers if l["cin"] == 64 and l["cout"] == 64 and l["K"] == 27 and (l["n_out"] >= 32768 if big else l["n_out"] <= 16384)]
+        if not dom:
+            dom = [l for l in layers if l["cin"] == 64 and l["cout"] == 64 and l["K"] == 27]
         dom_bytes = float(np.mean([l["bytes"] for l in dom]))
         dom_t = float(np.mean([l["t_avg_us"] for l in dom])) * 1e-6
         achieved = dom_bytes / dom_t / 1e9
@@ -375,15 +442,16 @@ def main():
         # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed summary of the
         # two rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_h_pmc_traffic.txt) is
         # attached when the workload is the one it was collected on, else null
-        DOM_KERNEL = "spconv_fwd_rows_ring<64,64>"  # 7 of the 8 64->64 launches (3x3x3); the (3,1,1) one runs spconv_fwd_rows<64,64>
+        DOM_KERNEL = "spconv_fwd_rows_big<64,64>" if (big and dom[0]["n_out"] >= 32768) else "spconv_fwd_rows_ring<64,64>"
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path) and not waymo and args.batch == 1 and args.points == 16384:
+        pmc_path = os.path.join(REPO, "profiles", "pmc_traffic_waymo.json" if waymo else "pmc_traffic.json")
+        if os.path.exists(pmc_path) and args.batch == 1 and args.points == (180000 if waymo else 16384):
             pmc = json.load(open(pmc_path))
             traffic, traffic_src = pmc[DOM_KERNEL]["traffic_bytes"] if DOM_KERNEL in pmc else None, pmc["source"]
         # the same kernel against the matrix pipe: MFMAs it ISSUES (16-row tiles incl. the padded one of the last workgroup x
         # 27 offsets x Cin/32 x Cout/16 x 3 split terms, 16 384 flop each) and the useful flops (2 Cin Cout per rulebook pair)
-        dom_tiles = float(np.mean([2 * ((l["n_out"] + 31) // 32) for l in dom]))
+        dom_tiles = float(np.mean([(l["n_out"] + 15) // 16 for l in dom])) if DOM_KERNEL.startswith("spconv_fwd_rows_big") else \
+            float(np.mean([2 * ((l["n_out"] + 31) // 32) for l in dom]))
         mfma_issued = dom_tiles * 27 * 2 * 4 * 3 * 16384  # Cin/32 = 2, Cout/16 = 4, 3 split terms (csrc/spconv.hip SPC_TERMS)
         mfma_useful = float(np.mean([l["pairs"] for l in dom])) * 2 * 64 * 64
         mfma_view = dict(issued_tflops=mfma_issued / dom_t / 1e12, frac_issued=mfma_issued / dom_t / 1e12 / 2500.0,
@@ -423,21 +491,7 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not waymo:
-        from oracle import second_cpu
-        torch.set_num_threads(1)
-        sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-        n_frames, t_cpu = 0, 0.0
-        while n_frames < args.cpu_frames and t_cpu < 30.0:
-            cloud = make(100 + n_frames, args.points)
-            c0 = time.perf_counter()
-            ref = second_cpu.second_forward(sd, [cloud], cfg.VOXEL_SIZE, cfg.GRID_BOUNDS, cfg.MAX_OCCUPANCY, cfg.MAX_VOXELS)
-            second_cpu.proposals(ref["cls"], ref["reg"], anchors.cpu().numpy(), 1, 2, 7, cfg.PROPOSAL.TOPK,
-                                 [a["score_thresh"] for a in cfg.ANCHORS])
-            t_cpu += time.perf_counter() - c0
-            n_frames += 1
-        cpu_baseline = dict(value=n_frames / t_cpu, unit="frames/s", cores=1, kind="port",
-                            sample=f"{n_frames} frame(s) of the same 16k-pt workload, oracle/ (scalar C sparse path + torch CPU "
-                                   f"dense path, 1 thread), {t_cpu:.1f} s")
+        cpu_baseline = run_cpu_baseline(model, cfg, anchors, make, args)
 
     if rank == 0:
         wl = ("SECOND forward, bs=1, 180000-pt synthetic Waymo-range sweep per GPU, 0.05 m voxels over +-75.2 m "
@@ -448,6 +502,7 @@ def main():
                     scaling="weak", vs_baseline=None, dtype="bf16x3 (fp32 operands split hi+lo, 3 bf16 MFMAs, fp32 accumulate: fp32-class, parity 1e-4)", data="synthetic",
                     config=dict(workload=wl,
                                 frames_per_gpu_per_step=args.batch, points_per_frame=args.points,
+                                distinct_frames_in_timed_loop=N_STREAM,
                                 parallelism=f"frame-parallel replicas x{world}", pipeline_depth=(graphed.depth if pipelined else 1),
                                 pipeline_tuning=(graphed.tuned if pipelined else None),
                                 path={"graph": "native backbone plan + bf16x3 MFMA dense head + device proposal stage, one HIP graph per "

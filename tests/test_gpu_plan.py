@@ -75,7 +75,7 @@ def test_inference_points_equals_item_path():
     anchors = AnchorGenerator(cfg).anchors.cuda()
     clouds = [torch.from_numpy(synth.make_cloud(s)).cuda() for s in (1, 2)]
     with torch.no_grad():
-        a = model.inference_points(clouds, anchors, dense="torch")   # same dense kernels as the item path
+        a = model.inference_points(clouds, anchors)   # the item path runs the same native kernels on the item's voxels
         b = model.inference(Preprocessor(cfg)(dict(points=[c.clone() for c in clouds], anchors=anchors)))
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
@@ -137,3 +137,23 @@ def test_graphed_inference_equals_stepwise():
             assert len(got[0]) == len(ref[0]) > 0
             for x, y in zip(got, ref):
                 np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
+
+
+def test_graph_capacity_accepts_shorter_frames():
+    """A graph captured for a point CAPACITY serves frames of any smaller size (padding far outside the grid is dropped by the
+    voxelizer): same detections as the eager native path on the unpadded frame; a larger frame is refused."""
+    from vision3d_amd.core import AnchorGenerator
+    from vision3d_amd.detector.graph import bucket_points
+    model = build_model(6)
+    anchors = AnchorGenerator(second_car_cfg()).anchors.cuda()
+    assert bucket_points(15000) == 16384 and bucket_points(16384) == 16384 and bucket_points(16385) == 18432
+    with torch.no_grad():
+        run = model.graphed_inference(anchors, [bucket_points(15000), bucket_points(9000)])
+        for sizes in ((16384, 10240), (15000, 9000), (12345, 1), (16384, 10240)):
+            clouds = [torch.from_numpy(synth.make_cloud(20 + i)[:n]).cuda() for i, n in enumerate(sizes)]
+            got = run(clouds)
+            ref = model.inference_points(clouds, anchors, dense="mfma")
+            for x, y in zip(got, ref):
+                np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
+        with pytest.raises(RuntimeError, match="capacity"):
+            run([torch.from_numpy(synth.make_cloud(1)).cuda(), torch.from_numpy(synth.make_cloud(2)[:10241]).cuda()])

@@ -3,10 +3,13 @@ the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md) and write pmc
 import collections, csv, glob, json, os, sys
 
 out_dir = sys.argv[1]
-KERNELS = {"spconv_fwd_rows_ring<64,64>": "spconv_fwd_rows_ring<64, 64, 3>", "conv2d_bf16x3_large_kernel<3>": "conv2d_bf16x3_large_kernel<3>"}
+workload = sys.argv[2] if len(sys.argv) > 2 else "kitti"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
+KERNELS = {"spconv_fwd_rows_ring<64,64>": "spconv_fwd_rows_ring<64, 64, 3>", "conv2d_bf16x3_large_kernel<3>": "conv2d_bf16x3_large_kernel<3>",
+           "spconv_fwd_rows_big<64,64>": "spconv_fwd_rows_big<64, 64>"}
 mean = collections.defaultdict(dict)
 print("== rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, each with --kernel-trace only) -- "
-      "python bench.py --steps 3 --warmup 2 --no-cpu-baseline")
+      f"python bench.py --steps 3 --warmup 2 --no-cpu-baseline{' --workload waymo' if workload == 'waymo' else ''}")
 print("== counter unit: KB per dispatch; gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide coalesced "
       "reads at half their bytes -> x2")
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -23,11 +26,12 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     for key, v in vals.items():
         mean[key][counter] = sum(v) / len(v)
         print(f"{key:36s} {counter:11s} mean {mean[key][counter]:12.1f} KB  (n={len(v)})")
-res = {"source": "profiles/r01_l_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes; FETCH_SIZE x2 gfx950 correction)"}
+suffix = "_waymo" if workload == "waymo" else ""
+res = {"source": f"profiles/{tag}_pmc_traffic{suffix}.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes; FETCH_SIZE x2 gfx950 correction)"}
 print("\ntraffic per launch = 2*FETCH_SIZE + WRITE_SIZE:")
 for key, m in mean.items():
     if len(m) == 2:
         kb = 2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]
         res[key] = dict(fetch_kb=m["FETCH_SIZE"], write_kb=m["WRITE_SIZE"], traffic_bytes=kb * 1024)
         print(f"  {key}: 2*{m['FETCH_SIZE']:.1f} + {m['WRITE_SIZE']:.1f} = {kb:.1f} KB = {kb * 1024 / 1e6:.2f} MB")
-json.dump(res, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(out_dir, f"pmc_traffic{suffix}.json"), "w"), indent=1)

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "v3d_backbone_occupancy": (_vp, [_vp]),
     "v3d_backbone_overflow_flags": (_vp, [_vp]),
     "v3d_backbone_forward2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "v3d_backbone_forward_voxels": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "v3d_conv2d_weight_image_bytes": (_sz, [_i, _i, _i]),
     "v3d_conv2d_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "v3d_conv2d_nhwc_bf16x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -227,6 +227,9 @@ extern "C" int v3d_backbone_forward(v3d_backbone* p, const float* points, int n_
   return v3d_backbone_forward2(p, points, n_points, frame_offsets_host, B, dense_out, nullptr, nullptr, stream);
 }
 
+static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense_out, void* dense_hi, void* dense_lo,
+                           hipStream_t st);
+
 extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n_points,
                                      const int32_t* frame_offsets_host, int B, float* dense_out, void* dense_hi,
                                      void* dense_lo, v3d_stream_t stream) {
@@ -242,7 +245,33 @@ extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n
                           c.max_voxels, nullptr, s0.coords, p->occupancy, p->mean, s0.n_dev, p->vox_ws, p->vox_ws_bytes, 0,
                           vox_hash ? &s0.hash : nullptr, s0.shape, st);
   if (rc) return rc;
-  bool hash0_done = vox_hash;
+  return plan_run_layers(p, B, vox_hash, dense_out, dense_hi, dense_lo, st);
+}
+
+// Same plan fed with voxels that already exist (the `item` of the reference's Preprocessor: voxel_mean + coordinates,
+// core/preprocess.py:26-33 + detector/layers.py:10-17): two device copies into the plan's stage-0 arrays instead of the
+// voxelizer, then the identical layer sequence.  Lets Second.forward(item) / Second.inference(item) -- the entry points
+// train.py:63 and inference.py:38 call -- run the native path without voxelizing twice.
+extern "C" int v3d_backbone_forward_voxels(v3d_backbone* p, const float* voxel_mean, const int32_t* coords, int n_voxels, int B,
+                                           float* dense_out, void* dense_hi, void* dense_lo, v3d_stream_t stream) {
+  if (!p || !voxel_mean || !coords || B < 1 || B > p->cfg.max_batch || n_voxels < 0 || n_voxels > p->stages[0].cap)
+    return V3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  PlanStage& s0 = p->stages[0];
+  V3D_CHECK_HIP(v3d_fill_async(p->ff_begin, 0xFF, p->ff_bytes, st));
+  if (n_voxels > 0) {
+    V3D_CHECK_HIP(hipMemcpyAsync(s0.coords, coords, (size_t)n_voxels * 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    V3D_CHECK_HIP(hipMemcpyAsync(p->mean, voxel_mean, (size_t)n_voxels * p->cfg.point_channels * sizeof(float),
+                                 hipMemcpyDeviceToDevice, st));
+  }
+  V3D_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)s0.n_dev, n_voxels, 1, st));
+  return plan_run_layers(p, B, false, dense_out, dense_hi, dense_lo, st);
+}
+
+static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense_out, void* dense_hi, void* dense_lo,
+                           hipStream_t st) {
+  const v3d_backbone_config& c = p->cfg;
+  int rc = V3D_OK;
   std::vector<char> rb_done(p->layers.size(), 0);
   const float* feat = p->mean;
   for (size_t l = 0; l < p->layers.size(); l++) {

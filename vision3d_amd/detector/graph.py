@@ -1,5 +1,18 @@
-"""HIP-graph capture of the SECOND inference path (one replay instead of ~150 launches per frame)."""
+"""HIP-graph capture of the SECOND inference path (one replay instead of ~150 launches per frame).
+
+A captured graph has its frame geometry baked in (point capacities are kernel arguments).  Real sweeps vary in size, so a
+graph is captured for a CAPACITY per frame and a shorter frame is padded with points far outside every grid: the voxelizer
+drops them before they can touch a voxel, a count or an order, so the result is the unpadded frame's bit for bit
+(`bucket_points` rounds a size up to the capture quantum; a frame above the capacity needs a graph captured for a larger bucket).
+"""
 import torch
+
+PAD_COORDINATE = 1.0e30  # outside any GRID_BOUNDS: dropped by the voxelizer's range test (csrc/voxelize.hip)
+
+
+def bucket_points(n, quantum=2048):
+    """Point capacity to capture for frames of about n points: the next multiple of `quantum`."""
+    return max(quantum, -(-int(n) // quantum) * quantum)
 
 
 class GraphedSecond(object):
@@ -46,10 +59,16 @@ class GraphedSecond(object):
         return head.proposals_padded(*head.maps_from_fused(maps), self.anchors)
 
     def load(self, clouds):
-        assert len(clouds) == len(self.frame_sizes)
+        if len(clouds) != len(self.frame_sizes):
+            raise RuntimeError(f"graph captured for {len(self.frame_sizes)} frame(s), got {len(clouds)}")
         for c, a, b in zip(clouds, self.offsets[:-1], self.offsets[1:]):
-            assert c.shape[0] == b - a, "frame size differs from the captured geometry: re-capture"
-            self.static_points[a:b].copy_(c, non_blocking=True)
+            n = c.shape[0]
+            if n > b - a:
+                raise RuntimeError(f"frame of {n} points exceeds the captured capacity {b - a}: capture a graph for a larger "
+                                   "bucket (detector/graph.py:bucket_points)")
+            self.static_points[a:a + n].copy_(c, non_blocking=True)
+            if n < b - a:
+                self.static_points[a + n:b].fill_(PAD_COORDINATE)
 
     def replay(self):
         if self.graph is None:

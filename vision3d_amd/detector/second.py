@@ -112,12 +112,38 @@ class Second(nn.Module):
         features = self.cnn(features, item["coordinates"], item["batch_size"])
         return self.rpn(features)
 
+    # ---- the reference's entry points (train.py:63 calls forward(item), inference.py:38 calls inference(item)).  In eval mode
+    #      without autograd an item of the device Preprocessor runs the native path: backbone plan fed with the item's voxels
+    #      (csrc/second_plan.hip) -> bf16x3 MFMA RPN + heads (csrc/dense_conv.hip) -> device proposal stage (csrc/proposal.hip).
+    #      Training (autograd) keeps the module-by-module path.
+    def _native_item(self, item):
+        if self.training or torch.is_grad_enabled() or "voxel_mean" not in item:
+            return False
+        vm, co = item["voxel_mean"], item["coordinates"]
+        return vm.is_cuda and co.is_cuda and co.dtype == torch.int32 and vm.dtype == torch.float32 and vm.shape[0] > 0
+
+    def _head_maps_from_item(self, item):
+        """-> (fused [cls | reg] head maps (B, n_anchor * (1 + DOF), H, W) fp32, the plan that produced them)."""
+        m, b = item["voxel_mean"].shape[0], int(item["batch_size"])
+        cap_pts = 1 << max(14, (max(m, 1) - 1).bit_length())  # the plan's voxel capacity is min(points, B * MAX_VOXELS) >= M
+        plan = self.backbone_plan(b, max(cap_pts, b * 16384))
+        hi, lo = plan.forward_voxels_split(item["voxel_mean"], item["coordinates"], b)
+        return self.dense_plan().forward(hi, lo), plan
+
     def forward(self, item):
-        scores, boxes = self.head(self.feature_extract(item))
+        if self._native_item(item):
+            maps, plan = self._head_maps_from_item(item)
+            plan.check_overflow()  # no count is read on this path: one blocking word
+            scores, boxes = self.head.maps_from_fused(maps)
+        else:
+            scores, boxes = self.head(self.feature_extract(item))
         item.update(dict(P_cls=scores, P_reg=boxes))
         return item
 
     def inference(self, item):
+        if self._native_item(item):
+            maps, plan = self._head_maps_from_item(item)
+            return self.head.inference_native(maps, item["anchors"], overflow_flag=plan.overflow_any())
         return self.head.inference(self.feature_extract(item), item["anchors"])
 
     # ---- fused path: raw device points in, proposals out (voxelizer + sparse backbone in one native call)

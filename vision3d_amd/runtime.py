@@ -169,6 +169,24 @@ class BackbonePlan(object):
             return self.forward_split(points, frame_offsets)
         return hi, lo
 
+    def forward_voxels_split(self, voxel_mean, coordinates, batch_size):
+        """The plan fed with EXISTING voxels (`item['voxel_mean']` (M, C), `item['coordinates']` (M, 4) int32 of the
+        Preprocessor) instead of raw points: split bf16 NHWC planes of the BEV map, as forward_split."""
+        self.sync_weights()
+        mean = L.as_f32("backbone", voxel_mean)
+        coords = L.as_i32("backbone", coordinates)
+        m = mean.shape[0]
+        if coords.shape != (m, 4) or mean.shape[1] != self.cfg.C_IN:
+            raise RuntimeError("backbone: voxel_mean (M, C_IN) / coordinates (M, 4) expected")
+        d, h, w = self.out_shape
+        hi, lo = split_planes_like(int(batch_size), h, w, self.out_channels * d, mean.device)
+        with torch.cuda.device(mean.device):
+            L.check(L.lib().v3d_backbone_forward_voxels(self._handle, L.ptr(mean), L.ptr(coords), m, int(batch_size), 0,
+                                                        L.ptr(hi), L.ptr(lo), L.stream_ptr()), "backbone_forward_voxels")
+        if self._maybe_tune():
+            return self.forward_voxels_split(voxel_mean, coordinates, batch_size)
+        return hi, lo
+
     def layer_output(self, layer):
         """(features (cap, C) view, coords (cap, 4) view, n_rows device int32 (1,), shape) of the last forward;
         layer = -1 is the voxelizer output.  Views alias the plan's arena: valid until the next forward."""
