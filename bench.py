@@ -380,34 +380,42 @@ def main():
     # ---- per-kernel timing of the sparse backbone with HIP events on the launch stream (rank 0)
     roofline, stages, roofline_dense = None, None, None
     if rank == 0 and not args.no_roofline:
-        # One eager pass captures the exact operands of the 14 sparse-conv launches of this frame; every launch
-        # is then re-issued REP times back to back on the launch stream inside one HIP-event bracket
-        # (v3d_debug_set_repeat), so the average is the kernel's own duration, not interpreter time.
-        import ctypes
+        # One eager pass captures the exact operands of the 14 sparse-conv launches of this frame; every launch is then
+        # re-issued REP times back to back on the launch stream inside one HIP-event bracket -- the REP calls are captured
+        # in a HIP graph, so there is no interpreter time between them and the average is the kernel's own duration.
         import vision3d_amd.spconv.conv as convmod
-        from vision3d_amd import _lib as L
-        raw = ctypes.CDLL(L.LIB_PATH)
         orig = convmod.sparse_conv_forward
         captured = []
 
-        def capture(features, weight, rb, scale=None, shift=None, relu=False, algo=0, packed=None):
+        def capture(features, weight, rb, scale=None, shift=None, relu=False, algo=0, packed=None, variant=0):
             captured.append((features, weight, rb, scale, shift, relu, algo, packed))
-            return orig(features, weight, rb, scale, shift, relu, algo, packed)
+            return orig(features, weight, rb, scale, shift, relu, algo, packed, variant)
         convmod.sparse_conv_forward = capture
         with torch.no_grad():  # the per-op sparse backbone (Second.inference(item) itself runs the fused plan: nothing to capture there)
             it = pre(dict(points=clouds, anchors=anchors))
             model.cnn(it["voxel_mean"], it["coordinates"], it["batch_size"])
         convmod.sparse_conv_forward = orig
         REP, layers = 25, []
+        side = torch.cuda.Stream()
         for (features, weight, rb, scale, shift, relu, algo, packed) in captured:
+            if packed is None and features.shape[1] >= 16 and weight.shape[-1] % 16 == 0:
+                packed = convmod.pack_sparse_weight(weight.reshape(-1, weight.shape[-2], weight.shape[-1]).contiguous(),
+                                                    rb.nbr.shape[0], weight.shape[-2], weight.shape[-1])
+            graph = torch.cuda.CUDAGraph()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                orig(features, weight, rb, scale, shift, relu, algo, packed)  # warm-up outside the capture
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            with torch.no_grad(), torch.cuda.graph(graph):
+                for _ in range(REP):
+                    orig(features, weight, rb, scale, shift, relu, algo, packed)
             ts = []
             for trial in range(4):
-                raw.v3d_debug_set_repeat(REP)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                orig(features, weight, rb, scale, shift, relu, algo, packed)
+                graph.replay()
                 e1.record()
-                raw.v3d_debug_set_repeat(1)
                 torch.cuda.synchronize()
                 if trial:
                     ts.append(e0.elapsed_time(e1) * 1e-3 / REP)

@@ -149,8 +149,8 @@ int v3d_rulebook_sparse(const int32_t* coords_in, const int32_t* n_in, int cap_i
  * (BatchNorm1d in eval mode folded to scale/shift, sparse_cnn.py:18,27) and ReLU.
  * in (>=n_in,Cin) f32, weight (K,Cin,Cout) f32 [= spconv's (k0,k1,k2,Cin,Cout)], out (cap_out,Cout).
  * out[o,:] = act( (sum_k in[nbr[k,o],:] @ weight[k]) * scale + shift ).  Deterministic (no atomics).
- * algo: 0 = auto, 1 = scalar reference kernel, 2 = LDS-staged MFMA kernel, 3 = wave-autonomous MFMA kernel
- * (2 and 3 need Cin%4==0, Cout%16==0 and a compiled (Cin,Cout) instance). */
+ * algo: 0 = auto, 1 = scalar reference kernel, 3 = wave-autonomous exact-fp32 MFMA kernel (needs Cin%4==0, Cout%16==0 and a
+ * compiled (Cin,Cout) instance). */
 int v3d_sparse_conv_fwd(const float* in, const float* weight, const int32_t* nbr, const int32_t* n_out, int cap_out,
                         int K, int Cin, int Cout, const float* scale, const float* shift, int relu, float* out,
                         int algo, v3d_stream_t stream);
@@ -161,8 +161,10 @@ int v3d_sparse_conv_fwd(const float* in, const float* weight, const int32_t* nbr
  */
 size_t v3d_sparse_conv_weight_image_bytes(int K, int Cin, int Cout);
 int v3d_sparse_conv_pack_weights(const float* weight, int K, int Cin, int Cout, void* image, v3d_stream_t stream);
-/* rows_hint: the caller's estimate of the LIVE row count (*n_out is device-side), used only to choose between the
- * 16-row kernel and the 64-row LDS-shared-weights kernel (crossover ~32 k rows); <= 0 = unknown (16-row kernel). */
+/* rows_hint > 0: the caller's estimate of the LIVE row count (*n_out is device-side), used only to choose the kernel: 3x3x3 with
+ * Cin, Cout in {32, 64}: LDS-ring kernel up to 16 384 rows, 64-row LDS-shared-weights kernel from 32 768, else the 16-row kernel;
+ * 0 = unknown (ring / 16-row).  rows_hint < 0 FORCES a kernel (tests, benchmarks): -1 = 16-row, -5 = 64-row, -10 = LDS ring.
+ * There is no process-global switch. */
 int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
                                float* out, int rows_hint, v3d_stream_t stream);
@@ -177,18 +179,6 @@ size_t v3d_sparse_conv_bwd_weight_workspace(int K, int Cin, int Cout);
 int v3d_sparse_conv_bwd_weight(const float* X, const float* dY, const int32_t* nbr, const int32_t* n_out, int cap_out,
                                int K, int Cin, int Cout, float* dW, void* workspace, size_t workspace_bytes,
                                v3d_stream_t stream);
-
-/* Timing harness (bench.py, tools/): every subsequent sparse-conv launch is issued n times back to back. */
-void v3d_debug_set_repeat(int n);
-/* Debug/benchmark aid: force the variant of the packed sparse kernel.  0 = automatic (3x3x3, Cin/Cout in {32, 64}: LDS-ring
- * kernel up to 16 384 live rows, 64-row kernel from 32 768, 16-row kernel otherwise); 1 = 16-row kernel; 2 / 4 = register
- * tiles (measured slower); 5 = 64-row LDS-shared-weights kernel; 10 / 11 = LDS-ring kernel with 3 / 2 offsets per round. */
-void v3d_debug_set_rows_mt(int mt);
-/* Debug/benchmark aid: 0 = build the NMS suppression mask with one wave per (row, 64-column block) at every size; 1 (default) =
- * one wave per row with near-pair compaction beyond 128 boxes. */
-void v3d_debug_set_nms_rows(int on);
-/* Debug/benchmark aid: dense convolution kernel choice (0 = automatic, 1 = 64-pixel tile, 2 = 144-pixel tile). */
-void v3d_debug_set_dense_variant(int v);
 
 /* ---- T2: SparseConvTensor.dense() (detector/sparse_cnn.py:128-133): zero-fill + scatter.
  * feat (cap,C), coords (cap,4), *n rows -> dense (B,C,D,H,W) f32. */

@@ -12,21 +12,13 @@ from vision3d_amd.core.config import second_car_cfg
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 2], ids=["tile64", "tile144"])
-def dense_variant(request):
-    """Both kernels of csrc/dense_conv.hip (the 144-pixel one needs Cin % 64 == 0, else the call falls back)."""
-    import ctypes
-    from vision3d_amd import _lib as L
-    raw = ctypes.CDLL(L.LIB_PATH)
-    raw.v3d_debug_set_dense_variant(request.param)
-    yield request.param
-    raw.v3d_debug_set_dense_variant(0)
-
-
 @pytest.mark.parametrize("b,h,w,cin,cout,k", [(2, 37, 29, 64, 128, 3), (1, 20, 16, 128, 128, 3), (1, 33, 50, 128, 128, 1),
                                              (3, 9, 7, 32, 256, 3), (1, 40, 31, 128, 16, 1), (1, 61, 53, 256, 128, 1),
                                              (2, 24, 12, 128, 256, 3), (1, 30, 44, 192, 128, 3), (1, 19, 23, 64, 64, 3), (1, 25, 17, 96, 128, 1)])
-def test_conv_matches_torch_fp32(b, h, w, cin, cout, k, dense_variant):
+def test_conv_matches_torch_fp32(b, h, w, cin, cout, k):
+    """The shape list reaches all three kernels through the dispatch of v3d_conv2d_nhwc_bf16x3: the 144-pixel kernel (Cin >= 64,
+    Cout > 32, W >= 16), the 64-pixel kernel (Cin = 32, Cout <= 32, or W < 16: the (2, 24, 12, 128, 256) and (3, 9, 7, 32, 256)
+    rows) and the streaming 1x1 head kernel (128 -> 16)."""
     from vision3d_amd.runtime import conv2d_split, pack_conv_weight, to_split_nhwc
     g = torch.Generator().manual_seed(cin * 7 + cout + k)
     x = torch.randn(b, cin, h, w, generator=g).cuda()

@@ -22,10 +22,9 @@ L.check(L.lib().v3d_sparse_conv_pack_weights(L.ptr(w), K, C, C, L.ptr(img), L.st
 n_dev = torch.tensor([n], dtype=torch.int32, device="cuda")
 out = torch.empty(n, C, device="cuda")
 for variant in (10,):
-    raw.v3d_debug_set_rows_mt(variant)
     for _ in range(5):
         L.check(L.lib().v3d_sparse_conv_fwd_packed(L.ptr(x), L.ptr(img), L.ptr(nbr), L.ptr(n_dev), n, K, C, C, None, None, 0,
-                                                   L.ptr(out), n, L.stream_ptr()), "fwd")
+                                                   L.ptr(out), -variant, L.stream_ptr()), "fwd")  # negative rows_hint = forced kernel
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 256)()
     raw.v3d_debug_rows_timeline(buf)

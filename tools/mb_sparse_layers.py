@@ -1,0 +1,59 @@
+"""Per-layer timing of the packed sparse product (algo 4) on the layers of one real frame: the automatic kernel choice and
+each forced kernel (1 = 16-row, 10 = LDS ring, 5 = 64-row LDS-shared weights; a negative rows_hint at the C ABI).  Every
+launch is repeated REP times inside a captured HIP graph between two HIP events: the kernel's own duration, no interpreter time.
+usage: python tools/mb_sparse_layers.py [kitti|waymo] [batch]"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vision3d_amd import synth
+from vision3d_amd.core import Preprocessor
+from vision3d_amd.core.config import second_car_cfg, waymo_range_cfg
+from vision3d_amd.detector import Second
+import vision3d_amd.spconv.conv as convmod
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "kitti"
+bs = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+cfg = waymo_range_cfg() if wl == "waymo" else second_car_cfg()
+torch.manual_seed(0)
+model = Second(cfg).cuda().eval()
+mk = (lambda s: synth.make_waymo_cloud(s, 180000)) if wl == "waymo" else (lambda s: synth.make_cloud(s, 16384))
+clouds = [torch.from_numpy(mk(i)).cuda() for i in range(bs)]
+orig = convmod.sparse_conv_forward
+cap = []
+convmod.sparse_conv_forward = lambda *a, **k: (cap.append(a), orig(*a, **k))[1]
+with torch.no_grad():
+    it = Preprocessor(cfg, seed=0)(dict(points=clouds))
+    model.cnn(it["voxel_mean"], it["coordinates"], it["batch_size"])
+convmod.sparse_conv_forward = orig
+REP = 25
+
+
+def timed(a, variant):
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad():
+        orig(a[0], a[1], a[2], a[3], a[4], a[5], 4, a[7], variant)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            for _ in range(REP):
+                o = orig(a[0], a[1], a[2], a[3], a[4], a[5], 4, a[7], variant)
+    ts = []
+    for trial in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        if trial: ts.append(e0.elapsed_time(e1) * 1e3 / REP)
+    return float(np.mean(ts)), o
+
+
+print(f"{wl} bs={bs}")
+for a in cap:
+    cin, cout = a[1].shape[-2], a[1].shape[-1]
+    if cin < 16: continue
+    rb = a[2]
+    row = f"{cin:3d}->{cout:3d} K={rb.nbr.shape[0]:2d} n={rb.n:6d}"
+    ref = None
+    for v in (0, 1, 10, 5):
+        t, o = timed(a, v)
+        ref = o.clone() if ref is None else ref
+        assert (ref - o).abs().max() <= 1e-4 * ref.abs().max()
+        row += f"  {'auto' if v == 0 else 'v' + str(v)}={t:7.1f}us"
+    print(row)

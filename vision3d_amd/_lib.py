@@ -41,10 +41,6 @@ _SIGNATURES = {
     "v3d_sparse_conv_weight_image_bytes": (_sz, [_i, _i, _i]),
     "v3d_sparse_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "v3d_sparse_conv_fwd_packed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
-    "v3d_debug_set_repeat": (None, [_i]),
-    "v3d_debug_set_rows_mt": (None, [_i]),
-    "v3d_debug_set_nms_rows": (None, [_i]),
-    "v3d_debug_set_dense_variant": (None, [_i]),
     "v3d_rulebook_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "v3d_sparse_conv_bwd_weight_workspace": (_sz, [_i, _i, _i]),
     "v3d_sparse_conv_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

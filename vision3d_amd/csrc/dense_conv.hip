@@ -756,9 +756,6 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_small_cout_kernel(const bf
   }
 }
 
-int g_v3d_dense_variant = 0;  // 0 = automatic, 1 = 64-pixel kernel, 2 = 144-pixel kernel (microbenchmarks / tests)
-extern "C" void v3d_debug_set_dense_variant(int v) { g_v3d_dense_variant = v; }
-
 extern "C" int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
                                       int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
                                       float* y_nchw, v3d_stream_t stream) {
@@ -772,7 +769,7 @@ extern "C" int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const 
   p.M = B * H * W;
   p.cout_store = Cout;
   hipStream_t st = (hipStream_t)stream;
-  if (ksize == 1 && !y_hi && Cout <= 16 && (Cin == 128 || Cin == 256) && g_v3d_dense_variant == 0) {  // the head: stream kernel
+  if (ksize == 1 && !y_hi && Cout <= 16 && (Cin == 128 || Cin == 256)) {  // the head: stream kernel
     const dim3 sgrid(v3d_ceil_div(v3d_ceil_div(p.M, 16), 4));
     if (Cin == 128)
       hipLaunchKernelGGL(conv1x1_bf16x3_small_cout_kernel<4>, sgrid, dim3(256), 0, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
@@ -784,7 +781,7 @@ extern "C" int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const 
     return V3D_OK;
   }
   const bool large_ok = Cin >= 64 && H < 32768 && W < 65536 && W >= 16;  // (Cin % 32 == 0 checked above) else: the 64-pixel kernel
-  if (large_ok && (g_v3d_dense_variant == 2 || (g_v3d_dense_variant == 0 && Cout > 32))) {
+  if (large_ok && Cout > 32) {
     dim3 lgrid(v3d_ceil_div(p.M, DL_BM), p.CoutPad / DC_BN);
     auto kern = ksize == 3 ? conv2d_bf16x3_large_kernel<3> : conv2d_bf16x3_large_kernel<1>;
     V3D_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, DL_SMEM));

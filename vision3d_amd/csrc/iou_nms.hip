@@ -245,11 +245,8 @@ __global__ __launch_bounds__(V3D_BLOCK) void nms_mask_rows_kernel(const BoxPrep*
   for (int w = cb0 + lane; w < nwords; w += 64) mask[(size_t)row * nwords + w] = words[w];
 }
 
-static int g_v3d_nms_rows = 1;  // 0: one wave per (row, column block) at every size (microbenchmarks)
-extern "C" void v3d_debug_set_nms_rows(int on) { g_v3d_nms_rows = on; }
-
 static void launch_nms_mask(const BoxPrep* prep, int N, int nwords, float thr, unsigned long long* mask, hipStream_t st) {
-  if (nwords <= 2 || !g_v3d_nms_rows) {  // inference shape (N ~ 100): one evaluation per lane is already the whole latency
+  if (nwords <= 2) {  // inference shape (N ~ 100): one evaluation per lane is already the whole latency
     hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, N), dim3(V3D_WAVE), 0, st, prep, N, nwords, thr, mask);
   } else {
     constexpr int RPB = V3D_BLOCK / V3D_WAVE;

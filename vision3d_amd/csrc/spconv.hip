@@ -6,29 +6,17 @@
 // output-stationary: every output row is produced by exactly one workgroup, written once, in a fixed
 // summation order (deterministic, no atomics); BatchNorm(eval)+ReLU are fused into the epilogue.
 //
-// Kernel `spconv_fwd_mfma` (algo 2), per workgroup = 64 output rows (one wave64 ballot wide):
-//   prologue  the tile's K x 64 neighbour indices are loaded once (coalesced, k-major) and, per kernel
-//             offset, compacted with a wave ballot + popcount into a dense list of (row, input) pairs
-//             padded to a multiple of 16 -- so the matrix cores only see rows that really have a
-//             neighbour under that offset (mean fan-in is 3-10 of 27);
-//   loop k    gathered input rows (A, cnt x Cin) and W[k] (B, Cin x Cout) are staged through LDS
-//             (register-staged double buffer: the global gather of offset k+1 is in flight while the
-//             MFMAs of offset k run), multiplied with v_mfma_f32_16x16x4_f32 (exact fp32) and the
-//             16x16 results added into the tile's fp32 accumulator in LDS (each (row, col) has one
-//             owner per offset -> plain read-modify-write);
-//   epilogue  scale/shift/ReLU, coalesced float4 stores.
-// Kernel `spconv_fwd_wave` (algo 3, the default) removes the per-offset barriers of algo 2: see its
-// header comment.  Kernel `spconv_fwd_scalar` (algo 1) is the simple VALU statement of the same sum, kept as the
-// on-device cross-check and for channel counts the MFMA tiling does not cover.
+// Kernels: `spconv_fwd_rows*` (algo 4: packed bf16x3 product, the default for Cin >= 16), `spconv_fwd_wave` (algo 3: exact
+// fp32 MFMA, the 4-channel input layer), `spconv_fwd_scalar` (algo 1: the plain VALU statement of the same sum, the
+// on-device cross-check and the fallback for channel counts the MFMA tilings do not cover).  Earlier variants that lost
+// their measurements (an LDS-staged fp32 kernel "algo 2", register-tile variants of algo 4, a two-offsets-per-round ring)
+// live in the history of this file, not in the library.
 #include "v3d_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// development-only ablation switches for spconv_fwd_wave (0 in production); see tools/microbench.py
-static int g_v3d_debug_flags = 0;
-static int g_v3d_debug_repeat = 1;  // launch each conv kernel this many times (timing harness only)
-extern "C" void v3d_debug_set_flags(int flags) { g_v3d_debug_flags = flags; }
-extern "C" void v3d_debug_set_repeat(int n) { g_v3d_debug_repeat = n < 1 ? 1 : n; }
+// The library has no process-global state: kernel variants are chosen from the arguments of each call (rows_hint; a
+// NEGATIVE rows_hint forces a variant, for tests and benchmarks -- see v3d_sparse_conv_fwd_packed in the header).
 
 // ---------------------------------------------------------------------------------- algo 1: scalar
 __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_scalar(const float* __restrict__ in,
@@ -58,183 +46,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_scalar(const float* __re
   }
 }
 
-// ---------------------------------------------------------------------------------- algo 2: MFMA
-#define SPC_TM 64  // output rows per workgroup == wave width (ballot compaction)
-
-template <int CIN, int COUT>
-struct SpcLayout {
-  static constexpr int AS = CIN + 2;    // A row stride (floats): conflict-free column reads
-  static constexpr int BS = COUT + 16;  // B row stride (floats): the two k-rows of a half-wave hit disjoint banks
-  static constexpr int ACC = SPC_TM * COUT;
-  static constexpr int ABUF = SPC_TM * AS;
-  static constexpr int BBUF = CIN * BS;
-  // floats: acc | A0 | A1 | B0 | B1 ; ints: lists
-  static constexpr int FLOATS = ACC + 2 * ABUF + 2 * BBUF;
-  static constexpr size_t bytes(int K) {
-    return (size_t)FLOATS * 4 + (size_t)K * SPC_TM * 4 /*list_in*/ + (size_t)K * SPC_TM /*list_row u8*/ +
-           (size_t)K * 4 /*cnt*/ + 64;
-  }
-};
-
-template <int CIN, int COUT>
-__global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_mfma(const float* __restrict__ in,
-                                                             const float* __restrict__ W,
-                                                             const int* __restrict__ nbr,
-                                                             const int* __restrict__ n_ptr, int cap, int K,
-                                                             const float* __restrict__ scale,
-                                                             const float* __restrict__ shift, int relu,
-                                                             float* __restrict__ out) {
-  using L = SpcLayout<CIN, COUT>;
-  constexpr int AS = L::AS, BS = L::BS;
-  constexpr int A4 = CIN / 4;                            // float4 per gathered row
-  constexpr int A_ITERS = (SPC_TM * A4 + V3D_BLOCK - 1) / V3D_BLOCK;
-  constexpr int B4 = CIN * COUT / 4;                     // float4 in one W[k]
-  constexpr int B_ITERS = (B4 + V3D_BLOCK - 1) / V3D_BLOCK;
-  constexpr int NB = COUT / 16;                          // 16-wide column blocks
-
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* acc = smem;
-  float* Abuf = acc + L::ACC;
-  float* Bbuf = Abuf + 2 * L::ABUF;
-  int* list_in = (int*)(Bbuf + 2 * L::BBUF);             // [K][64] input row per compacted slot (-1 = zero row)
-  int* cnt_pad = list_in + K * SPC_TM;                   // [K] compacted count rounded up to 16
-  unsigned char* list_row = (unsigned char*)(cnt_pad + K);  // [K][64] tile row per slot (255 = padding)
-
-  const int n = min(*n_ptr, cap);
-  const int row0 = blockIdx.x * SPC_TM;
-  if (row0 >= n) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-  // ---- prologue: zero accumulator; per-offset ballot compaction of the tile's neighbour table
-  for (int i = tid; i < L::ACC; i += V3D_BLOCK) acc[i] = 0.f;
-  for (int k = wave; k < K; k += V3D_BLOCK / V3D_WAVE) {
-    const int row = row0 + lane;
-    const int v = row < n ? nbr[(size_t)k * cap + row] : -1;
-    const unsigned long long m = __ballot(v >= 0);
-    const int c = __popcll(m);
-    const int cp = (c + 15) & ~15;
-    const int pos = __popcll(m & ((1ull << lane) - 1ull));
-    if (v >= 0) {
-      list_in[k * SPC_TM + pos] = v;
-      list_row[k * SPC_TM + pos] = (unsigned char)lane;
-    }
-    if (lane >= c && lane < cp) {  // padding slots
-      list_in[k * SPC_TM + lane] = -1;
-      list_row[k * SPC_TM + lane] = 255;
-    }
-    if (lane == 0) cnt_pad[k] = cp;
-  }
-  __syncthreads();
-
-  float4 ra[A_ITERS], rb[B_ITERS];
-  // issue the global loads of offset k into registers
-  auto stage_load = [&](int k) {
-    const int cp = cnt_pad[k];
-#pragma unroll
-    for (int it = 0; it < A_ITERS; it++) {
-      const int idx = tid + it * V3D_BLOCK;
-      const int p = idx / A4, q = idx % A4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < cp) {
-        const int src = list_in[k * SPC_TM + p];
-        if (src >= 0) v = *reinterpret_cast<const float4*>(in + (size_t)src * CIN + q * 4);
-      }
-      ra[it] = v;
-    }
-    const float4* wk = reinterpret_cast<const float4*>(W + (size_t)k * CIN * COUT);
-#pragma unroll
-    for (int it = 0; it < B_ITERS; it++) {
-      const int idx = tid + it * V3D_BLOCK;
-      rb[it] = idx < B4 ? wk[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  // registers -> LDS buffer `buf`
-  auto stage_store = [&](int buf) {
-    float* As = Abuf + buf * L::ABUF;
-    float* Bs = Bbuf + buf * L::BBUF;
-#pragma unroll
-    for (int it = 0; it < A_ITERS; it++) {
-      const int idx = tid + it * V3D_BLOCK;
-      const int p = idx / A4, q = idx % A4;
-      if (p < SPC_TM) {
-        float2* d = reinterpret_cast<float2*>(As + p * AS + q * 4);  // AS is even -> 8-byte aligned
-        d[0] = make_float2(ra[it].x, ra[it].y);
-        d[1] = make_float2(ra[it].z, ra[it].w);
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < B_ITERS; it++) {
-      const int idx = tid + it * V3D_BLOCK;
-      if (idx < B4) {
-        const int ci = idx / (COUT / 4), c4 = idx % (COUT / 4);
-        *reinterpret_cast<float4*>(Bs + ci * BS + c4 * 4) = rb[it];
-      }
-    }
-  };
-
-  // first active offset
-  int k = 0;
-  while (k < K && cnt_pad[k] == 0) k++;
-  int buf = 0;
-  if (k < K) {
-    stage_load(k);
-    stage_store(0);
-  }
-  __syncthreads();
-  while (k < K) {
-    int kn = k + 1;
-    while (kn < K && cnt_pad[kn] == 0) kn++;
-    if (kn < K) stage_load(kn);  // global gather of the next offset in flight during the MFMAs
-
-    const float* As = Abuf + buf * L::ABUF;
-    const float* Bs = Bbuf + buf * L::BBUF;
-    const int units = (cnt_pad[k] >> 4) * NB;
-    for (int u = wave; u < units; u += V3D_BLOCK / V3D_WAVE) {
-      const int rblk = u / NB, nb = u % NB;
-      f32x4 d = {0.f, 0.f, 0.f, 0.f};
-      const float* ap = As + (rblk * 16 + (lane & 15)) * AS + (lane >> 4);
-      const float* bp = Bs + (lane >> 4) * BS + nb * 16 + (lane & 15);
-#pragma unroll
-      for (int kk = 0; kk < CIN / 4; kk++) {
-        // A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4], bp[kk * 4 * BS], d, 0, 0, 0);
-      }
-      // D[row = (lane>>4)*4 + r][col = lane&15]
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int slot = rblk * 16 + (lane >> 4) * 4 + r;
-        const int trow = list_row[k * SPC_TM + slot];
-        if (trow != 255) acc[trow * COUT + nb * 16 + (lane & 15)] += d[r];
-      }
-    }
-    if (kn < K) stage_store(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-    k = kn;
-  }
-
-  // ---- epilogue
-  for (int idx = tid; idx < SPC_TM * (COUT / 4); idx += V3D_BLOCK) {
-    const int r = idx / (COUT / 4), c4 = idx % (COUT / 4);
-    if (row0 + r >= n) continue;
-    float4 v = *reinterpret_cast<const float4*>(acc + r * COUT + c4 * 4);
-    if (scale) {
-      const float4 s = *reinterpret_cast<const float4*>(scale + c4 * 4);
-      const float4 b = *reinterpret_cast<const float4*>(shift + c4 * 4);
-      v.x = v.x * s.x + b.x;
-      v.y = v.y * s.y + b.y;
-      v.z = v.z * s.z + b.z;
-      v.w = v.w * s.w + b.w;
-    }
-    if (relu) {
-      v.x = fmaxf(v.x, 0.f);
-      v.y = fmaxf(v.y, 0.f);
-      v.z = fmaxf(v.z, 0.f);
-      v.w = fmaxf(v.w, 0.f);
-    }
-    *reinterpret_cast<float4*>(out + (size_t)(row0 + r) * COUT + c4 * 4) = v;
-  }
-}
+#define SPC_TM 64  // output rows per workgroup of spconv_fwd_wave == wave width (ballot compaction)
 
 // ---------------------------------------------------------------------------------- algo 3: wave-autonomous MFMA
 // One workgroup = one 64-row output tile, 8 waves.  Wave (g, nb) owns the 16 output columns
@@ -259,7 +71,7 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
                                                                        const int* __restrict__ n_ptr, int cap, int K,
                                                                        const float* __restrict__ scale,
                                                                        const float* __restrict__ shift, int relu,
-                                                                       float* __restrict__ out, int dbg) {
+                                                                       float* __restrict__ out) {
   constexpr int NB = COUT / 16;
   constexpr int G = SPW_WAVES / NB;
   constexpr int T = CIN / 4;  // MFMA steps; also floats of one row held per lane
@@ -309,7 +121,7 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
 
   float a0[T], a1[T], b0[T], b1[T];
   auto load_a = [&](int k, int rblk, float (&a)[T]) {
-    const int src = (dbg & 1) ? -1 : list_in[k * SPC_TM + rblk * 16 + r];
+    const int src = list_in[k * SPC_TM + rblk * 16 + r];
     if (src >= 0) {
       const float* p = in + (size_t)src * CIN + q * T;
       if constexpr (T % 4 == 0) {
@@ -331,12 +143,7 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
     }
   };
   auto load_b = [&](int k, float (&b)[T]) {
-    const float* p = W + ((size_t)((dbg & 2) ? 0 : k) * CIN + q * T) * COUT + nb * 16 + r;
-    if (dbg & 16) {
-#pragma unroll
-      for (int t = 0; t < T; t++) b[t] = 1.0f;
-      return;
-    }
+    const float* p = W + ((size_t)k * CIN + q * T) * COUT + nb * 16 + r;
 #pragma unroll
     for (int t = 0; t < T; t++) b[t] = p[(size_t)t * COUT];
   };
@@ -352,7 +159,6 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
 
   int k = k_lo, rblk = 0;
   while (k < k_hi && count_of(k) == 0) k++;
-  if (dbg & 64) k = k_hi;
   if (k < k_hi) {
     load_a(k, rblk, a0);
     load_b(k, b0);
@@ -368,12 +174,7 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
       if (newk) load_b(kn, b1);
     }
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-    if (dbg & 4) {
-      float sacc = 0.f;
-#pragma unroll
-      for (int t = 0; t < T; t++) sacc += a0[t] * b0[t];
-      d0[0] = sacc;
-    } else if constexpr (T >= 2) {
+    if constexpr (T >= 2) {
 #pragma unroll
       for (int t = 0; t < T; t += 2) {  // two independent accumulator chains hide the MFMA latency
         d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b0[t], d0, 0, 0, 0);
@@ -385,7 +186,7 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
     }
     // accumulate: this wave is the only owner of acc[g][:, 16 nb .. 16 nb + 16) and a tile row occurs
     // at most once per offset -> plain read-modify-write (LDS float atomics are ~0.4 us each here)
-    if (!(dbg & 32)) {
+    {
       float old[4];
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
@@ -447,9 +248,8 @@ static int launch_wave(const float* in, const float* W, const int* nbr, const in
   constexpr int G = SPW_WAVES / (COUT / 16);
   const size_t lds = (size_t)G * SPC_TM * COUT * 4 + (size_t)K * SPC_TM * 4 + (size_t)K * 4 + (size_t)K * SPC_TM + 64;
   if (lds > 64 * 1024) return V3D_EUNSUPPORTED;
-  for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
-    hipLaunchKernelGGL((spconv_fwd_wave<CIN, COUT>), dim3(v3d_ceil_div(cap, SPC_TM)), dim3(SPW_WAVES * V3D_WAVE), lds, st,
-                       in, W, nbr, n_ptr, cap, K, scale, shift, relu, out, g_v3d_debug_flags);
+  hipLaunchKernelGGL((spconv_fwd_wave<CIN, COUT>), dim3(v3d_ceil_div(cap, SPC_TM)), dim3(SPW_WAVES * V3D_WAVE), lds, st,
+                     in, W, nbr, n_ptr, cap, K, scale, shift, relu, out);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -728,144 +528,6 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
   SPR_STAMP(14);
 }
 
-// Same algorithm with MT (2 or 4) row tiles per workgroup: every wave still owns the offsets k = w, w+4, ... but
-// multiplies each W[k] fragment set, once in registers, against MT gathered 16-row tiles -- the L2->CU weight
-// stream (the measured limiter of the 16-row kernel: 442 KB per block at 64->64) shrinks MT-fold.  A operands
-// are double-buffered per tile, B per offset; the 4 wave partials are summed through LDS in wave order.
-template <int CIN, int COUT, int MT>
-__global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_mt(const float* __restrict__ in,
-                                                                const unsigned short* __restrict__ wimg,
-                                                                const int* __restrict__ nbr, const int* __restrict__ n_ptr,
-                                                                int cap, int K, const float* __restrict__ scale,
-                                                                const float* __restrict__ shift, int relu,
-                                                                float* __restrict__ out) {
-  static_assert(MT == 2 || MT == 4, "even tile counts only (static A-buffer parity)");
-  constexpr int KI = (CIN + 31) / 32, NB = COUT / 16;
-  constexpr int NF = KI * NB * 2;
-  constexpr int NW = V3D_BLOCK / V3D_WAVE;
-  constexpr int RB = 16 * MT;
-  extern __shared__ __attribute__((aligned(16))) float smem_rows[];
-  float* red = smem_rows;                          // [MT][NB][4][64] running sum over waves
-  int* nbr_s = (int*)(red + MT * NB * 4 * 64);     // [K][RB]
-  const int n = min(*n_ptr, cap);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int row0 = blockIdx.x * RB;
-  if (row0 >= n) return;
-  const int r = lane & 15, kg = lane >> 4;
-  for (int t = tid; t < K * RB; t += V3D_BLOCK) {
-    const int k = t / RB, rr = t % RB;
-    nbr_s[t] = (row0 + rr < n) ? nbr[(size_t)k * cap + row0 + rr] : -1;
-  }
-  __syncthreads();
-
-  float araw[2][KI][8];
-  u32x4_t braw[2][NF];
-  auto load_a = [&](int k, int m, float (&a)[KI][8]) {
-    const int src = nbr_s[k * RB + m * 16 + r];
-#pragma unroll
-    for (int ki = 0; ki < KI; ki++) {
-      const int c0 = ki * 32 + kg * 8;
-      if (src >= 0 && c0 < CIN) {
-        const float* p = in + (size_t)src * CIN + c0;
-        if constexpr (CIN % 8 == 0) {
-          const float4 v0 = reinterpret_cast<const float4*>(p)[0], v1 = reinterpret_cast<const float4*>(p)[1];
-          a[ki][0] = v0.x; a[ki][1] = v0.y; a[ki][2] = v0.z; a[ki][3] = v0.w;
-          a[ki][4] = v1.x; a[ki][5] = v1.y; a[ki][6] = v1.z; a[ki][7] = v1.w;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; e++) a[ki][e] = (c0 + e < CIN) ? p[e] : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; e++) a[ki][e] = 0.f;
-      }
-    }
-  };
-  auto load_b = [&](int k, u32x4_t (&b)[NF]) {
-    const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(wimg) + (size_t)k * NF * 64 + lane;
-#pragma unroll
-    for (int f = 0; f < NF; f++) b[f] = wp[(size_t)f * 64];
-  };
-
-  f32x4 acc[MT][NB];
-#pragma unroll
-  for (int m = 0; m < MT; m++)
-#pragma unroll
-    for (int j = 0; j < NB; j++) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto multiply = [&](const float (&a)[KI][8], const u32x4_t (&b)[NF], f32x4 (&c)[NB]) {
-#pragma unroll
-    for (int ki = 0; ki < KI; ki++) {
-      bf16x8_t ah, am, al;
-      split_act(a[ki], ah, am, al);
-#pragma unroll
-      for (int j = 0; j < NB; j++)  // smallest terms first
-        c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), c[j], 0, 0, 0);
-      if constexpr (SPC_TERMS == 4) {
-#pragma unroll
-        for (int j = 0; j < NB; j++)
-          c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), c[j], 0, 0, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < NB; j++)
-        c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2 + 1]), c[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < NB; j++)
-        c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), c[j], 0, 0, 0);
-    }
-  };
-  // one offset: MT tiles against bcur; the next offset's B and first A tile are fetched while it runs
-  auto offset_step = [&](int k, const u32x4_t (&bcur)[NF], u32x4_t (&bnext)[NF]) {
-    const bool more = k + NW < K;
-#pragma unroll
-    for (int m = 0; m < MT; m++) {
-      if (m + 1 < MT) load_a(k, m + 1, araw[(m + 1) & 1]);
-      else if (more) load_a(k + NW, 0, araw[0]);
-      if (m == 0 && more) load_b(k + NW, bnext);
-      multiply(araw[m & 1], bcur, acc[m]);
-    }
-  };
-  if (wave < K) {
-    load_b(wave, braw[0]);
-    load_a(wave, 0, araw[0]);
-  }
-  for (int k = wave; k < K; k += 2 * NW) {
-    offset_step(k, braw[0], braw[1]);
-    if (k + NW < K) offset_step(k + NW, braw[1], braw[0]);
-  }
-
-  for (int w = 0; w < NW; w++) {
-    if (wave == w) {
-#pragma unroll
-      for (int m = 0; m < MT; m++)
-#pragma unroll
-        for (int j = 0; j < NB; j++)
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) {
-            const int idx = (((m * NB + j) * 4 + rr) << 6) + lane;
-            red[idx] = w == 0 ? acc[m][j][rr] : red[idx] + acc[m][j][rr];
-          }
-    }
-    __syncthreads();
-  }
-  // epilogue: D[row = kg*4 + rr][col = r] of tile m, column block j
-  for (int t = wave; t < MT * NB; t += NW) {
-    const int m = t / NB, j = t % NB;
-    const int col = j * 16 + r;
-    const float sc = scale ? scale[col] : 1.f, sh = scale ? shift[col] : 0.f;
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-      float v = red[((t * 4 + rr) << 6) + lane];
-      const int row = row0 + m * 16 + kg * 4 + rr;
-      if (row < n) {
-        if (scale) v = v * sc + sh;
-        if (relu) v = fmaxf(v, 0.f);
-        out[(size_t)row * COUT + col] = v;
-      }
-    }
-  }
-}
-
 // Large-N variant: 64 output rows per workgroup, one 16-row tile per wave, every wave walks ALL K offsets (no
 // K-split, accumulators never leave registers) and the four waves share ONE copy of each W[k] image through LDS
 // (double buffered, fetched once per workgroup and offset).  Beyond ~30 k rows the 16-row kernel is bound by the
@@ -1019,7 +681,7 @@ __global__ __launch_bounds__((2 * OG + 2) * 64) void spconv_fwd_rows_ring(const 
   // waves -- one multiplying wave per SIMD.  Measured slower (64->64 at 8 160 rows: 12.3 vs 13.0 us): the cost of a round
   // is mostly its barrier and the LDS read burst behind it, not the matrix pipe, so fewer, longer rounds win.  Also
   // tried and dropped: splitting (R, ki+1) while the MFMAs of (R, ki) run, with and without sched_group_barrier
-  // interleave (12.9 / 13.2 us).  OG = 2 stays reachable as debug variant 11.
+  // interleave (12.9 / 13.2 us).  Only OG = 3 is instantiated.
   constexpr int K = 27, TILES = 2, ROUNDS = (K + OG - 1) / OG, NCW = TILES * OG, NMV = 2;
   constexpr int NBUF = OG == 2 ? 4 : 3, LOOK = NBUF - 1;  // rounds of weights / gathered rows in flight ahead of the multiply
   constexpr int KI = CIN / 32, NB = COUT / 16;
@@ -1185,8 +847,7 @@ __global__ __launch_bounds__((2 * OG + 2) * 64) void spconv_fwd_rows_ring(const 
 template <int CIN, int COUT, int OG>
 static int launch_rows_ring(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
                             const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
-  for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
-    hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG>), dim3(v3d_ceil_div(cap, 32)), dim3((2 * OG + 2) * 64), 0, st, in,
+  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG>), dim3(v3d_ceil_div(cap, 32)), dim3((2 * OG + 2) * 64), 0, st, in,
                        (const unsigned short*)wimg, nbr, n_ptr, cap, scale, shift, relu, out);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
@@ -1197,57 +858,35 @@ static void launch_rows_big(const float* in, const void* wimg, const int* nbr, c
                             const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
   constexpr int NF = ((CIN + 31) / 32) * (COUT / 16) * 2;
   const size_t lds = (size_t)2 * NF * 64 * 16 + (size_t)K * 64 * 4;
-  for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
-    hipLaunchKernelGGL((spconv_fwd_rows_big<CIN, COUT>), dim3(v3d_ceil_div(cap, 64)), dim3(V3D_BLOCK), lds, st, in,
+  hipLaunchKernelGGL((spconv_fwd_rows_big<CIN, COUT>), dim3(v3d_ceil_div(cap, 64)), dim3(V3D_BLOCK), lds, st, in,
                        (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out);
 }
 
-int g_v3d_rows_mt = 0;  // 0 = pick from rows_hint; 1 / 2 / 4 / 5 / 10 / 11 = force a variant (include/vision3d_hip.h, microbenchmarks)
-extern "C" void v3d_debug_set_rows_mt(int mt) { g_v3d_rows_mt = mt; }
-
-template <int CIN, int COUT, int MT>
-static void launch_rows_mt(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
-                           const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
-  const size_t lds = (size_t)MT * (COUT / 16) * 4 * 64 * 4 + (size_t)K * 16 * MT * 4;
-  for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
-    hipLaunchKernelGGL((spconv_fwd_rows_mt<CIN, COUT, MT>), dim3(v3d_ceil_div(cap, 16 * MT)), dim3(V3D_BLOCK), lds, st, in,
-                       (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out);
-}
-
-// rows_hint = expected number of LIVE rows (the live count itself is device-side): the caller's best knowledge --
-// the capacity when it is exact (per-op Python path), the counts observed on earlier frames (v3d_backbone_tune).
+// rows_hint > 0: expected number of LIVE rows (the live count itself is device-side): the caller's best knowledge -- the
+// capacity when it is exact (per-op Python path), the counts observed on earlier frames (v3d_backbone_tune); 0 = unknown.
+// rows_hint < 0 forces a kernel (tests, benchmarks): -1 the 16-row kernel, -5 the 64-row LDS-shared-weights kernel, -10 the
+// LDS-ring kernel (the last two where the shape has them, else the 16-row kernel).
 #define V3D_BIG_ROWS 32768
 #define V3D_RING_ROWS 16384  // two full rounds of 32-row workgroups on 256 CUs; beyond, the 16-row kernel wins again (36 k rows: 47 vs 53 us)
 template <int CIN, int COUT>
 static int launch_rows(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
                        const float* scale, const float* shift, int relu, float* out, int rows_hint, hipStream_t st) {
+  const int force = rows_hint < 0 ? -rows_hint : 0;
   if constexpr (CIN >= 32 && CIN <= 64 && COUT >= 32 && COUT <= 64) {
-    // 5 = the 64-row LDS-shared-weights kernel: from ~32 k live rows on the 16-row kernel is bound by the L2 -> CU
-    // weight stream (tools/mb_rows_mt.py: 64->64 at 36 k rows 54 vs 53 us, at 56 k 82 vs 66 us, at 81 k 110 vs 85 us)
-    if (g_v3d_rows_mt == 5 || (g_v3d_rows_mt == 0 && rows_hint >= V3D_BIG_ROWS)) {
+    // the 64-row LDS-shared-weights kernel: from ~32 k live rows on the 16-row kernel is bound by the L2 -> CU weight
+    // stream (64->64 at 36 k rows 54 vs 53 us, at 56 k 82 vs 66 us, at 81 k 110 vs 85 us)
+    if (force == 5 || (force == 0 && rows_hint >= V3D_BIG_ROWS)) {
       launch_rows_big<CIN, COUT>(in, wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, st);
       V3D_CHECK_LAUNCH();
       return V3D_OK;
     }
-    // 10 = the two-tile LDS-ring kernel (3x3x3 only): 64->64 at 8 160 rows 14.4 -> 12.3 us, 32->32 at 13 731 rows 10.9 -> 9.6 us
-    if (K == 27 && g_v3d_rows_mt == 11) return launch_rows_ring<CIN, COUT, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
-    if (K == 27 && (g_v3d_rows_mt == 10 || (g_v3d_rows_mt == 0 && rows_hint <= V3D_RING_ROWS)))
+    // the two-tile LDS-ring kernel (3x3x3 only): 64->64 at 8 160 rows 14.4 -> 12.3 us, 32->32 at 13 731 rows 10.9 -> 9.6 us
+    if (K == 27 && (force == 10 || (force == 0 && rows_hint <= V3D_RING_ROWS)))
       return launch_rows_ring<CIN, COUT, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
   }
-  if constexpr (CIN >= 32 && CIN <= 64 && COUT <= 64) {  // weight stream >= 27 x 4 KB per block: share it across more rows when there are enough of them
-    int mt = g_v3d_rows_mt;
-    if (mt == 0) mt = 1;  // measured (tools/mb_rows_mt.py, 8k..134k rows): the 16-row kernel wins everywhere -- see DESIGN.md
-    if (mt == 2 || mt == 4) {
-      if (mt == 2) launch_rows_mt<CIN, COUT, 2>(in, wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, st);
-      else launch_rows_mt<CIN, COUT, 4>(in, wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, st);
-      V3D_CHECK_LAUNCH();
-      return V3D_OK;
-    }
-  }
   const size_t lds = (size_t)4 * (COUT / 16) * 4 * 64 * 4 + (size_t)K * 16 * 4;
-  for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
-    hipLaunchKernelGGL((spconv_fwd_rows<CIN, COUT>), dim3(v3d_ceil_div(cap, 16)), dim3(V3D_BLOCK), lds, st, in,
-                       (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out);
+  hipLaunchKernelGGL((spconv_fwd_rows<CIN, COUT>), dim3(v3d_ceil_div(cap, 16)), dim3(V3D_BLOCK), lds, st, in,
+                     (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -1283,29 +922,13 @@ int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, cons
   return V3D_EUNSUPPORTED;
 }
 
-template <int CIN, int COUT>
-static int launch_mfma(const float* in, const float* W, const int* nbr, const int* n_ptr, int cap, int K,
-                       const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
-  const size_t lds = SpcLayout<CIN, COUT>::bytes(K);
-  if (lds > 160 * 1024) return V3D_EUNSUPPORTED;
-  auto kern = spconv_fwd_mfma<CIN, COUT>;
-  if (lds > 64 * 1024) {
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-  for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
-    hipLaunchKernelGGL(kern, dim3(v3d_ceil_div(cap, SPC_TM)), dim3(V3D_BLOCK), lds, st, in, W, nbr, n_ptr, cap, K, scale,
-                       shift, relu, out);
-  V3D_CHECK_LAUNCH();
-  return V3D_OK;
-}
-
 extern "C" int v3d_sparse_conv_fwd(const float* in, const float* weight, const int32_t* nbr, const int32_t* n_out,
                                    int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift,
                                    int relu, float* out, int algo, v3d_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!in || !weight || !nbr || !n_out || !out || cap_out < 1 || K < 1 || Cin < 1 || Cout < 1) return V3D_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return V3D_EINVAL;
-  if (algo < 0 || algo > 3) return V3D_EINVAL;
+  if (algo != 0 && algo != 1 && algo != 3) return V3D_EINVAL;  // (2 was an LDS-staged fp32 kernel: removed)
   if (algo == 0 || algo == 3) {
     int rc = V3D_EUNSUPPORTED;
 #define V3D_TRY(ci, co) \
@@ -1322,27 +945,11 @@ extern "C" int v3d_sparse_conv_fwd(const float* in, const float* weight, const i
     V3D_TRY(64, 128)
     V3D_TRY(128, 128)
 #undef V3D_TRY
-    if (rc != V3D_EUNSUPPORTED || algo == 3) return rc;
-  }
-  if (algo == 0 || algo == 2) {
-    int rc = V3D_EUNSUPPORTED;
-#define V3D_TRY(ci, co) \
-  if (Cin == ci && Cout == co) rc = launch_mfma<ci, co>(in, weight, nbr, n_out, cap_out, K, scale, shift, relu, out, st);
-    V3D_TRY(4, 16)
-    V3D_TRY(16, 16)
-    V3D_TRY(16, 32)
-    V3D_TRY(32, 32)
-    V3D_TRY(32, 64)
-    V3D_TRY(64, 64)
-    V3D_TRY(4, 32)
-    V3D_TRY(64, 128)
-#undef V3D_TRY
-    if (rc != V3D_EUNSUPPORTED || algo == 2) return rc;  // algo 0 falls through to the scalar kernel
+    if (rc != V3D_EUNSUPPORTED || algo == 3) return rc;  // algo 0 falls through to the scalar kernel
   }
   const long long total = (long long)cap_out * Cout;
   const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
-  for (int rep = 0; rep < g_v3d_debug_repeat; rep++)
-    hipLaunchKernelGGL(spconv_fwd_scalar, dim3(blocks > 8192 ? 8192 : blocks), dim3(V3D_BLOCK), 0, st, in, weight, nbr,
+  hipLaunchKernelGGL(spconv_fwd_scalar, dim3(blocks > 8192 ? 8192 : blocks), dim3(V3D_BLOCK), 0, st, in, weight, nbr,
                        n_out, cap_out, K, Cin, Cout, scale, shift, relu, out);
   V3D_CHECK_LAUNCH();
   return V3D_OK;

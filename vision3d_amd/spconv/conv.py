@@ -70,8 +70,10 @@ def build_sparse_rulebook(x, ksize, stride, padding):
     return Rulebook(nbr, cap_out, n_host, n_out, coords_out[:n_host], out_shape)
 
 
-def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False, algo=0, packed=None):
-    """out (rb.n, Cout) = act((sum_k features[nbr[k]] @ weight[k]) * scale + shift)."""
+def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False, algo=0, packed=None, variant=0):
+    """out (rb.n, Cout) = act((sum_k features[nbr[k]] @ weight[k]) * scale + shift).
+    variant (algo 4 only; tests and benchmarks): 0 = the kernel is picked from the live row count; 1 / 5 / 10 force the 16-row,
+    the 64-row LDS-shared-weights or the LDS-ring kernel (passed to the C ABI as a negative rows_hint)."""
     feat = L.as_f32("sparse_conv", features)
     cin, cout = weight.shape[-2], weight.shape[-1]
     w = L.as_f32("sparse_conv", weight).reshape(-1, cin, cout)
@@ -90,7 +92,8 @@ def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False
         with torch.cuda.device(feat.device):
             L.check(L.lib().v3d_sparse_conv_fwd_packed(L.ptr(feat), L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k,
                                                        cin, cout, L.ptr(sc), L.ptr(sh), int(bool(relu)), L.ptr(out),
-                                                       int(rb.n), L.stream_ptr()), "sparse_conv_fwd_packed")
+                                                       -int(variant) if variant else int(rb.n), L.stream_ptr()),
+                    "sparse_conv_fwd_packed")
         return out
     with torch.cuda.device(feat.device):
         L.check(L.lib().v3d_sparse_conv_fwd(L.ptr(feat), L.ptr(w), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k, cin,
@@ -123,6 +126,7 @@ class _SparseConvBase(nn.Module):
         self.padding = [k // 2 for k in self.kernel_size] if self.subm else _triple(padding)
         self.indice_key = indice_key
         self.algo = 0
+        self.variant = 0  # tests / benchmarks: force a packed-kernel variant (see sparse_conv_forward)
         self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self.reset_parameters()
@@ -186,7 +190,7 @@ class _SparseConvBase(nn.Module):
         packed = None
         if self.algo in (0, 4) and self.in_channels >= 16 and self.out_channels % 16 == 0:
             packed = self._packed_weight()
-        feats = sparse_conv_forward(x.features.detach(), self.weight.detach(), rb, scale, shift, relu, self.algo, packed)
+        feats = sparse_conv_forward(x.features.detach(), self.weight.detach(), rb, scale, shift, relu, self.algo, packed, self.variant)
         out = SparseConvTensor(feats, rb.out_indices, rb.out_shape, x.batch_size)
         out.indice_dict = x.indice_dict
         out._n_dev = rb.n_dev
