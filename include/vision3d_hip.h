@@ -285,6 +285,39 @@ int v3d_backbone_forward2(v3d_backbone* plan, const float* points, int n_points,
 int v3d_backbone_forward_voxels(v3d_backbone* plan, const float* voxel_mean, const int32_t* coords, int n_voxels, int B,
                                 float* dense_nchw, void* dense_hi, void* dense_lo, v3d_stream_t stream);
 
+/* ---- Training plan: the sparse half of a train step (train.py:63-67 through detector/second.py:41-46 and
+ * detector/sparse_cnn.py:15-30,151-175) as ONE call forwards and ONE call backwards, no host synchronisation.
+ * Every layer must be conv + BatchNorm1d (training mode: batch statistics) [+ ReLU] with a power-of-two Cout in [4, 256].
+ * Parameters are read from the caller's device pointers on every call (they change every optimiser step); the running
+ * statistics are updated in place exactly as nn.BatchNorm1d would (momentum, unbiased variance, num_batches_tracked += 1).
+ * forward:  voxel_mean (n_voxels, C) f32, coords (n_voxels, 4) i32 [b, z, y, x] (the Preprocessor's item) -> dense_out
+ *           (B, Cout, D, H, W) f32; activations needed by the backward stay in the plan's training arena (allocated by the
+ *           first call: v3d_backbone_train_arena_bytes).
+ * backward: grad_dense (B, Cout, D, H, W) f32 -> grad_weight (K, Cin, Cout), grad_gamma (Cout), grad_beta (Cout) of every
+ *           layer.  Must follow a train_forward of the same plan; the layer array is the same (host) array of device pointers.
+ * Deterministic: no atomics in any reduction. */
+typedef struct {
+  const float* weight;          /* (K, Cin, Cout) f32 */
+  const float* gamma;           /* BatchNorm weight (Cout) */
+  const float* beta;            /* BatchNorm bias (Cout) */
+  float* running_mean;          /* nullable pair */
+  float* running_var;
+  int64_t* num_batches_tracked; /* nullable */
+  float eps, momentum;
+  float* grad_weight;           /* backward outputs (ignored by the forward) */
+  float* grad_gamma;
+  float* grad_beta;
+} v3d_train_layer;
+int v3d_backbone_train_forward(v3d_backbone* plan, const float* voxel_mean, const int32_t* coords, int n_voxels, int B,
+                               const v3d_train_layer* layers_host, float* dense_out, v3d_stream_t stream);
+int v3d_backbone_train_backward(v3d_backbone* plan, const float* grad_dense, int B, const v3d_train_layer* layers_host,
+                                v3d_stream_t stream);
+size_t v3d_backbone_train_arena_bytes(const v3d_backbone* plan);
+/* Coordinate-only pass + v3d_backbone_tune: builds the rulebooks for these voxels (no convolution), waits for `stream` and takes
+ * the kernel-choice hints from the row counts.  Lets the FIRST training step run the kernels of all later steps (a training
+ * forward cannot be repeated after tuning: it updates the running statistics).  Blocking; never during stream capture. */
+int v3d_backbone_tune_from_voxels(v3d_backbone* plan, const int32_t* coords, int n_voxels, int B, v3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,115 @@
+"""Training plan (csrc/second_plan.hip "Training plan", runtime.PlanTrainFunction): the sparse half of a train step as one
+native call each way must agree with the module-by-module autograd path (spconv.SparseSequential: SparseConvFunction +
+SparseBatchNormReLUFunction + .dense()), which test_gpu_spconv.py / test_gpu_configs.py pin against torch and fp64."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from vision3d_amd import synth
+from vision3d_amd.core import Preprocessor
+from vision3d_amd.core.config import second_car_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _model_and_item(bs, seed=0):
+    from vision3d_amd.detector import Second
+    cfg = second_car_cfg()
+    torch.manual_seed(seed)
+    model = Second(cfg).cuda().train()
+    with torch.no_grad():  # non-trivial BatchNorm parameters and statistics
+        for m in model.cnn.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+                m.running_mean.uniform_(-0.1, 0.1)
+                m.running_var.uniform_(0.5, 2.0)
+    clouds = [torch.from_numpy(synth.make_cloud(s)).cuda() for s in range(bs)]
+    item = Preprocessor(cfg, seed=0)(dict(points=clouds))
+    return cfg, model, item
+
+
+def _run(cnn, item, g_bev, native):
+    cnn.native_train = native
+    for p in cnn.parameters():
+        p.grad = None
+    bev = cnn(item["voxel_mean"], item["coordinates"], item["batch_size"])
+    (bev * g_bev).sum().backward()
+    grads = {n: p.grad.detach().clone() for n, p in cnn.named_parameters()}
+    stats = {n: b.detach().clone() for n, b in cnn.named_buffers() if "running" in n or "num_batches" in n}
+    return bev.detach().clone(), grads, stats
+
+
+@pytest.mark.parametrize("bs", [1, 2])
+def test_train_plan_matches_module_path(bs):
+    cfg, model, item = _model_and_item(bs)
+    cnn_a, cnn_b = model.cnn, copy.deepcopy(model.cnn)
+    torch.manual_seed(1)
+    g_bev = torch.randn(bs, 128, 200, 176, device="cuda")
+    bev_a, grads_a, stats_a = _run(cnn_a, item, g_bev, native=True)
+    bev_b, grads_b, stats_b = _run(cnn_b, item, g_bev, native=False)
+    assert "_train_plans" in cnn_a.__dict__ and "_train_plans" not in cnn_b.__dict__  # the two paths really differ
+    scale = float(bev_b.abs().max())
+    assert scale > 0
+    assert float((bev_a - bev_b).abs().max()) <= 1e-5 * scale
+    assert abs(int((bev_a != 0).sum()) - int((bev_b != 0).sum())) <= 8  # values at the ReLU boundary may fall either side
+    assert set(grads_a) == set(grads_b) and len(grads_a) == 14 * 3
+    for n in grads_b:  # same kernels on both paths (the plan tunes from a coordinate-only pass before its first step)
+        ref = grads_b[n]
+        err = float((grads_a[n] - ref).abs().max())
+        assert err <= 1e-5 * float(ref.abs().max()) + 1e-12, (n, err, float(ref.abs().max()))
+    for n in stats_b:  # running statistics: momentum update with the unbiased variance, num_batches_tracked += 1
+        if "num_batches" in n:
+            assert int(stats_a[n]) == int(stats_b[n]) == 1, n
+        else:
+            torch.testing.assert_close(stats_a[n], stats_b[n], rtol=1e-5, atol=1e-6, msg=n)
+
+
+def test_train_plan_repeats_bit_for_bit_and_tracks_parameter_updates():
+    cfg, model, item = _model_and_item(2)
+    cnn = model.cnn
+    torch.manual_seed(1)
+    g_bev = torch.randn(2, 128, 200, 176, device="cuda")
+    snapshot = copy.deepcopy(cnn.state_dict())
+    bev_1, grads_1, _ = _run(cnn, item, g_bev, native=True)  # first call: tunes the kernel choice from a coordinate-only pass
+    cnn.load_state_dict(snapshot)
+    bev_2, grads_2, _ = _run(cnn, item, g_bev, native=True)
+    cnn.load_state_dict(snapshot)
+    bev_3, grads_3, _ = _run(cnn, item, g_bev, native=True)
+    assert torch.equal(bev_2, bev_3)  # deterministic: no atomics in any reduction
+    for n in grads_2:
+        assert torch.equal(grads_2[n], grads_3[n]), n
+    assert torch.equal(bev_1, bev_2)  # ... so even the first step runs the kernels of every later step
+    with torch.no_grad():  # an optimiser step: the plan reads the parameters on every call
+        for p in cnn.parameters():
+            p.mul_(0.5)
+    bev_4, _, _ = _run(cnn, item, g_bev, native=True)
+    assert not torch.equal(bev_4, bev_3)
+    ref = copy.deepcopy(cnn)
+    ref.load_state_dict(cnn.state_dict())
+    # (same parameters, module path, running statistics irrelevant for training-mode outputs)
+    bev_5, _, _ = _run(ref, item, g_bev, native=False)
+    assert float((bev_4 - bev_5).abs().max()) <= 1e-5 * float(bev_5.abs().max())
+
+
+def test_train_plan_step_is_capturable_in_a_hip_graph():
+    """No host read anywhere in the plan's forward / backward: one train step of the sparse half replays from a graph."""
+    cfg, model, item = _model_and_item(1)
+    cnn = model.cnn
+    torch.manual_seed(1)
+    g_bev = torch.randn(1, 128, 200, 176, device="cuda")
+    plan = cnn._train_plan(item["voxel_mean"].shape[0], 1, item["voxel_mean"].device)
+    bev_eager = plan.train_forward(item["voxel_mean"], item["coordinates"], 1)
+    grads_eager = [g.clone() for g in plan.train_backward(g_bev, 1)]
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        bev = plan.train_forward(item["voxel_mean"], item["coordinates"], 1)
+        grads = plan.train_backward(g_bev, 1)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(bev, bev_eager)
+    for a, b in zip(grads, grads_eager):
+        assert torch.equal(a, b)

@@ -63,6 +63,10 @@ _SIGNATURES = {
     "v3d_backbone_overflow_flags": (_vp, [_vp]),
     "v3d_backbone_forward2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "v3d_backbone_forward_voxels": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "v3d_backbone_train_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "v3d_backbone_train_backward": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "v3d_backbone_train_arena_bytes": (_sz, [_vp]),
+    "v3d_backbone_tune_from_voxels": (_i, [_vp, _vp, _i, _i, _vp]),
     "v3d_conv2d_weight_image_bytes": (_sz, [_i, _i, _i]),
     "v3d_conv2d_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "v3d_conv2d_nhwc_bf16x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -81,6 +85,15 @@ class BackboneConfig(C.Structure):
                 ("max_voxels", C.c_int32), ("point_channels", C.c_int32), ("grid_shape", C.c_int32 * 3),
                 ("max_batch", C.c_int32), ("max_points", C.c_int32), ("n_layers", C.c_int32), ("growth", C.c_float),
                 ("conv_algo", C.c_int32)]
+
+
+
+class TrainLayer(C.Structure):
+    """v3d_train_layer: device pointers of one conv + BatchNorm group (parameters in, gradients out)."""
+    _fields_ = [("weight", _vp), ("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp),
+                ("num_batches_tracked", _vp), ("eps", C.c_float), ("momentum", C.c_float), ("grad_weight", _vp),
+                ("grad_gamma", _vp), ("grad_beta", _vp)]
+
 
 _lib = None
 

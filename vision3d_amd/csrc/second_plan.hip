@@ -11,6 +11,7 @@
 //   * one coordinate hash per stage: the strided rulebook leaves the hash of its OUTPUT sites behind and
 //     the next stage's submanifold rulebook reuses it (spconv rebuilds a dense index grid per call);
 //   * submanifold layers that share an indice_key share one neighbour table.
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -27,7 +28,10 @@ struct PlanLayer {
   int has_affine;
   int* chunk_counts;  // strided layers: published per-chunk counts -> offsets (inside the per-frame 0xFF region)
   int rows_hint;      // expected live output rows (kernel choice): capacity-free estimate, refined by v3d_backbone_tune
+  int rows_hint_in;   // same for the input stage (the data-gradient pass of the training plan gathers over input rows)
 };
+
+struct PlanTrain;
 
 struct PlanStage {
   int cap;
@@ -58,6 +62,7 @@ struct v3d_backbone {
   char* ff_begin = nullptr;     // arena region reset to 0xFF by one memset per forward
   size_t ff_bytes = 0;
   int out_channels = 0;
+  struct PlanTrain* train = nullptr;  // training buffers, allocated by the first v3d_backbone_train_forward
 };
 
 static int conv_fan(const v3d_layer_desc& d) {
@@ -131,7 +136,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       L.builds_rulebook = true;
       p->nbr_cap.push_back(ns.cap);
     }
-    L.rows_hint = 0;  // unknown until tuned: the 16-row kernel (right for KITTI-size frames)
+    L.rows_hint = L.rows_hint_in = 0;  // unknown until tuned: the 16-row kernel (right for KITTI-size frames)
     cin = L.d.cout;
     p->layers.push_back(L);
   }
@@ -195,8 +200,11 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
   return V3D_OK;
 }
 
+static void plan_train_free(v3d_backbone* p);
+
 extern "C" void v3d_backbone_destroy(v3d_backbone* p) {
   if (!p) return;
+  plan_train_free(p);
   if (p->arena) (void)hipFree(p->arena);
   delete p;
 }
@@ -268,48 +276,59 @@ extern "C" int v3d_backbone_forward_voxels(v3d_backbone* p, const float* voxel_m
   return plan_run_layers(p, B, false, dense_out, dense_hi, dense_lo, st);
 }
 
+// rulebook of layer l (and, riding in the strided builder's last launch, the submanifold table of the layer after it)
+static int plan_layer_rulebook(v3d_backbone* p, size_t l, std::vector<char>& rb_done, bool& hash0_done, hipStream_t st) {
+  PlanLayer& L = p->layers[l];
+  if (!L.builds_rulebook || rb_done[l]) return V3D_OK;
+  PlanStage& si = p->stages[L.stage_in];
+  PlanStage& so = p->stages[L.stage_out];
+  int rc;
+  if (L.d.subm) {
+    if (!si.hash_ready_by_sparse && !(L.stage_in == 0 && hash0_done)) {
+      rc = v3d_i_hash_build(si.coords, si.n_dev, si.cap, si.shape, si.hash, 0, st);
+      if (rc) return rc;
+      if (L.stage_in == 0) hash0_done = true;
+    }
+    return v3d_i_subm_nbr(si.coords, si.n_dev, si.cap, si.shape, L.d.ksize, si.hash, p->nbr[L.rulebook], st);
+  }
+  const bool fuse = l + 1 < p->layers.size() && p->layers[l + 1].d.subm && p->layers[l + 1].builds_rulebook &&
+                    p->layers[l + 1].stage_in == L.stage_out;
+  rc = v3d_i_sparse_rulebook(si.coords, si.n_dev, si.cap, si.shape, L.d.ksize, L.d.stride, L.d.padding, so.coords, so.n_dev,
+                             so.cap, p->nbr[L.rulebook], p->overflow + l, so.hash, so.first_ticket, p->cand_slot, L.chunk_counts,
+                             nullptr, 0, fuse ? p->layers[l + 1].d.ksize : nullptr,
+                             fuse ? p->nbr[p->layers[l + 1].rulebook] : nullptr, st,
+                             p->overflow + p->layers.size() /*summary flag: any layer*/);
+  if (fuse) rb_done[l + 1] = 1;
+  return rc;
+}
+
+// out = act((sum_k feat[nbr[k]] @ W[k]) * scale + shift) of layer l: the packed bf16x3 kernels where the reduction dim fills
+// an MFMA (Cin >= 16), the exact-fp32 wave kernel else
+static int plan_layer_conv(v3d_backbone* p, PlanLayer& L, const float* feat, const void* wimg, const float* weight,
+                           const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
+  const v3d_backbone_config& c = p->cfg;
+  PlanStage& so = p->stages[L.stage_out];
+  int rc = V3D_EUNSUPPORTED;
+  if (c.conv_algo == 4 || (c.conv_algo == 0 && L.d.cin >= 16))
+    rc = v3d_i_sparse_conv_fwd_packed(feat, wimg, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout, scale, shift,
+                                      relu, out, L.rows_hint, st);
+  if (rc == V3D_EUNSUPPORTED)
+    rc = v3d_sparse_conv_fwd(feat, weight, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout, scale, shift, relu,
+                             out, (c.conv_algo == 4 || c.conv_algo == 0) ? 3 : c.conv_algo, st);
+  return rc;
+}
+
 static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense_out, void* dense_hi, void* dense_lo,
                            hipStream_t st) {
-  const v3d_backbone_config& c = p->cfg;
   int rc = V3D_OK;
   std::vector<char> rb_done(p->layers.size(), 0);
   const float* feat = p->mean;
   for (size_t l = 0; l < p->layers.size(); l++) {
     PlanLayer& L = p->layers[l];
-    PlanStage& si = p->stages[L.stage_in];
-    PlanStage& so = p->stages[L.stage_out];
-    if (L.builds_rulebook && !rb_done[l]) {
-      if (L.d.subm) {
-        if (!si.hash_ready_by_sparse && !(L.stage_in == 0 && hash0_done)) {
-          rc = v3d_i_hash_build(si.coords, si.n_dev, si.cap, si.shape, si.hash, 0, st);
-          if (rc) return rc;
-          if (L.stage_in == 0) hash0_done = true;
-        }
-        rc = v3d_i_subm_nbr(si.coords, si.n_dev, si.cap, si.shape, L.d.ksize, si.hash, p->nbr[L.rulebook], st);
-      } else {
-        // the next layer's submanifold table (over THIS layer's output sites) rides in the same last launch
-        const bool fuse = l + 1 < p->layers.size() && p->layers[l + 1].d.subm && p->layers[l + 1].builds_rulebook &&
-                          p->layers[l + 1].stage_in == L.stage_out;
-        rc = v3d_i_sparse_rulebook(si.coords, si.n_dev, si.cap, si.shape, L.d.ksize, L.d.stride, L.d.padding, so.coords,
-                                   so.n_dev, so.cap, p->nbr[L.rulebook], p->overflow + l, so.hash, so.first_ticket,
-                                   p->cand_slot, L.chunk_counts, nullptr, 0,
-                                   fuse ? p->layers[l + 1].d.ksize : nullptr,
-                                   fuse ? p->nbr[p->layers[l + 1].rulebook] : nullptr, st,
-                                   p->overflow + p->layers.size() /*summary flag: any layer*/);
-        if (fuse) rb_done[l + 1] = 1;
-      }
-      if (rc) return rc;
-    }
-    rc = V3D_EUNSUPPORTED;
-    // default (0): bf16x3 row-owner kernel where the reduction dim fills an MFMA (Cin >= 16), fp32 wave kernel else
-    if (c.conv_algo == 4 || (c.conv_algo == 0 && L.d.cin >= 16))
-      rc = v3d_i_sparse_conv_fwd_packed(feat, L.wimg, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout,
-                                        L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr, L.d.relu, L.out,
-                                        L.rows_hint, st);
-    if (rc == V3D_EUNSUPPORTED)
-      rc = v3d_sparse_conv_fwd(feat, L.weight, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout,
-                               L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr, L.d.relu, L.out,
-                               (c.conv_algo == 4 || c.conv_algo == 0) ? 3 : c.conv_algo, st);
+    rc = plan_layer_rulebook(p, l, rb_done, hash0_done, st);
+    if (rc) return rc;
+    rc = plan_layer_conv(p, L, feat, L.wimg, L.weight, L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr,
+                         L.d.relu, L.out, st);
     if (rc) return rc;
     feat = L.out;
   }
@@ -363,11 +382,258 @@ extern "C" int v3d_backbone_tune(v3d_backbone* p) {
     hipError_t e = hipMemcpy(&n_stage[s], p->stages[s].n_dev, sizeof(int), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return (int)e;
   }
-  for (auto& L : p->layers) L.rows_hint = n_stage[L.stage_out];
+  for (auto& L : p->layers) {
+    L.rows_hint = n_stage[L.stage_out];
+    L.rows_hint_in = n_stage[L.stage_in];
+  }
   return V3D_OK;
+}
+
+// Coordinate-only pass: builds every rulebook for the given voxel coordinates (no features, no convolutions), waits for the
+// stream and takes the kernel-choice hints from the row counts -- v3d_backbone_tune without a forward.  The training plan
+// calls it before its FIRST step, so that step already runs the kernels every later step will use (a training forward
+// cannot simply be repeated after tuning: it updates the BatchNorm running statistics).
+extern "C" int v3d_backbone_tune_from_voxels(v3d_backbone* p, const int32_t* coords, int n_voxels, int B, v3d_stream_t stream) {
+  if (!p || !coords || B < 1 || B > p->cfg.max_batch || n_voxels < 1 || n_voxels > p->stages[0].cap) return V3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  PlanStage& s0 = p->stages[0];
+  V3D_CHECK_HIP(v3d_fill_async(p->ff_begin, 0xFF, p->ff_bytes, st));
+  V3D_CHECK_HIP(hipMemcpyAsync(s0.coords, coords, (size_t)n_voxels * 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  V3D_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)s0.n_dev, n_voxels, 1, st));
+  std::vector<char> rb_done(p->layers.size(), 0);
+  bool hash0_done = false;
+  for (size_t l = 0; l < p->layers.size(); l++) {
+    int rc = plan_layer_rulebook(p, l, rb_done, hash0_done, st);
+    if (rc) return rc;
+  }
+  V3D_CHECK_HIP(hipStreamSynchronize(st));
+  return v3d_backbone_tune(p);
 }
 
 extern "C" int32_t* v3d_backbone_occupancy(v3d_backbone* p) { return p ? p->occupancy : nullptr; }
 // flags[l] = layer l hit its active-site capacity; flags[n_layers] = any of them (one word for the caller's per-frame read)
 extern "C" int32_t* v3d_backbone_overflow_flags(v3d_backbone* p) { return p ? p->overflow : nullptr; }
 extern "C" int v3d_backbone_num_layers(const v3d_backbone* p) { return p ? (int)p->layers.size() : 0; }
+
+// =================================================================================================
+// Training plan: the same stage / rulebook machinery driven forwards AND backwards by one C call each way.
+//
+// Replaces, for the sparse half of a train step (train.py:63-67 through detector/second.py:41-46 and
+// detector/sparse_cnn.py:15-30,151-175), the ~400 Python-level operator calls of the module-by-module autograd path
+// (rulebook builders, SparseConvFunction, SparseBatchNormReLUFunction, .dense() and their backward twins):
+//   forward   per layer: pack the CURRENT weights -> conv (no affine) -> batch-statistics BatchNorm (+ ReLU) with the
+//             running statistics updated in the merge kernel; the pre-BN rows and the saved mean / invstd stay in the
+//             training arena for the backward;
+//   backward  d(BEV) gathered back onto the last stage's rows, then per layer in reverse: BatchNorm(+ReLU) backward ->
+//             weight gradient (exact-fp32 MFMA reduction) -> data gradient = the forward kernel on the transposed
+//             rulebook (a submanifold table is its own transpose with the offsets reversed) and transposed weights.
+// Row counts never leave the device (BatchNorm included: v3d_i_sparse_bn_*), so a whole train step can be captured in a
+// HIP graph.  Parameters are read from / gradients written to the caller's device pointers (v3d_train_layer).
+// =================================================================================================
+struct PlanTrainLayer {
+  float* conv_out = nullptr;  // (cap_out, cout) pre-BatchNorm rows
+  float* stats = nullptr;     // save_mean | save_invstd | unbiased variance, 3 x cout
+  void* wimg_t = nullptr;     // packed image of the transposed weights (Cin >= 16 layers)
+  int32_t* nbr_t = nullptr;   // strided layers: (K, cap_in) transposed rulebook
+};
+
+struct PlanTrain {
+  void* arena = nullptr;
+  size_t arena_bytes = 0;
+  std::vector<PlanTrainLayer> tl;
+  float* g[2] = {nullptr, nullptr};  // gradient wrt a layer's output / input rows (ping-pong)
+  float* g_conv = nullptr;           // gradient wrt the pre-BatchNorm rows
+  float* w_t = nullptr;              // fp32 transposed weights of the layer in flight
+  void* dw_ws = nullptr;
+  size_t dw_ws_bytes = 0;
+  void* bn_ws = nullptr;
+  size_t bn_ws_bytes = 0;
+  bool forward_done = false;
+};
+
+static void plan_train_free(v3d_backbone* p) {
+  if (!p->train) return;
+  if (p->train->arena) (void)hipFree(p->train->arena);
+  delete p->train;
+  p->train = nullptr;
+}
+
+static int plan_train_alloc(v3d_backbone* p) {
+  if (p->train) return V3D_OK;
+  for (auto& L : p->layers) {
+    const int c = L.d.cout;
+    if (c < 4 || c > V3D_BLOCK || (c & (c - 1))) return V3D_EUNSUPPORTED;  // sparse_bn.hip: power-of-two channel counts
+  }
+  PlanTrain* t = new (std::nothrow) PlanTrain();
+  if (!t) return V3D_EINVAL;
+  t->tl.resize(p->layers.size());
+  auto carve = [&](V3dArena& ar) {
+    size_t max_rows = 1, max_w = 1, max_dw = 1;
+    int max_c = 4;
+    for (size_t l = 0; l < p->layers.size(); l++) {
+      PlanLayer& L = p->layers[l];
+      PlanTrainLayer& T = t->tl[l];
+      const PlanStage &si = p->stages[L.stage_in], &so = p->stages[L.stage_out];
+      T.conv_out = ar.take<float>((size_t)so.cap * L.d.cout);
+      T.stats = ar.take<float>((size_t)3 * L.d.cout);
+      if (L.d.cin >= 16 && L.d.cin % 16 == 0)
+        T.wimg_t = ar.take<char>(v3d_sparse_conv_weight_image_bytes(L.K, L.d.cout, L.d.cin));
+      if (!L.d.subm && l > 0) T.nbr_t = ar.take<int32_t>((size_t)L.K * si.cap);
+      max_rows = std::max(max_rows, std::max((size_t)so.cap * L.d.cout, (size_t)si.cap * L.d.cin));
+      max_w = std::max(max_w, (size_t)L.K * L.d.cin * L.d.cout);
+      max_dw = std::max(max_dw, v3d_sparse_conv_bwd_weight_workspace(L.K, L.d.cin, L.d.cout));
+      max_c = std::max(max_c, (int)L.d.cout);
+    }
+    t->g[0] = ar.take<float>(max_rows);
+    t->g[1] = ar.take<float>(max_rows);
+    t->g_conv = ar.take<float>(max_rows);
+    t->w_t = ar.take<float>(max_w);
+    t->dw_ws_bytes = max_dw;
+    t->dw_ws = ar.take<char>(max_dw);
+    t->bn_ws_bytes = v3d_sparse_bn_workspace(1, max_c);
+    t->bn_ws = ar.take<char>(t->bn_ws_bytes);
+  };
+  {
+    V3dArena probe((void*)256, (size_t)1 << 60);
+    carve(probe);
+    t->arena_bytes = probe.off + 4096;
+  }
+  hipError_t e = hipMalloc(&t->arena, t->arena_bytes);
+  if (e != hipSuccess) { delete t; return (int)e; }
+  V3dArena ar(t->arena, t->arena_bytes);
+  carve(ar);
+  if (!ar.ok()) { (void)hipFree(t->arena); delete t; return V3D_EWORKSPACE; }
+  p->train = t;
+  return V3D_OK;
+}
+
+extern "C" size_t v3d_backbone_train_arena_bytes(const v3d_backbone* p) { return (p && p->train) ? p->train->arena_bytes : 0; }
+
+// Wt[k'][co][ci] = W[k][ci][co], k' = K-1-k when `flip` (submanifold layers: offset k of the transposed table is offset
+// K-1-k of the forward table)
+__global__ __launch_bounds__(V3D_BLOCK) void plan_transpose_weights_kernel(const float* __restrict__ w, int K, int cin, int cout,
+                                                                           int flip, float* __restrict__ wt) {
+  const int total = K * cin * cout;
+  for (int t = blockIdx.x * V3D_BLOCK + threadIdx.x; t < total; t += gridDim.x * V3D_BLOCK) {
+    const int k = t / (cin * cout), rem = t - k * cin * cout, co = rem / cin, ci = rem - co * cin;  // t indexes wt
+    const int ks = flip ? K - 1 - k : k;
+    wt[t] = w[((size_t)ks * cin + ci) * cout + co];
+  }
+}
+
+// rows[i, c] = grad_dense[b, c, z, y, x]   ((B, C, D, H, W): the backward of densify_kernel)
+__global__ __launch_bounds__(V3D_BLOCK) void plan_densify_bwd_kernel(const float* __restrict__ gdense, const int4* __restrict__ coords,
+                                                                     const int* __restrict__ n_ptr, int cap, int C, int D, int H,
+                                                                     int Wd, float* __restrict__ rows) {
+  const int n = min(*n_ptr, cap);
+  const long long total = (long long)n * C;
+  const size_t vol = (size_t)D * H * Wd;
+  for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * V3D_BLOCK) {
+    const int i = (int)(t / C), ch = (int)(t % C);
+    const int4 c = coords[i];
+    rows[t] = gdense[((size_t)c.x * C + ch) * vol + ((size_t)c.y * H + c.z) * Wd + c.w];
+  }
+}
+
+extern "C" int v3d_backbone_train_forward(v3d_backbone* p, const float* voxel_mean, const int32_t* coords, int n_voxels, int B,
+                                          const v3d_train_layer* io, float* dense_out, v3d_stream_t stream) {
+  if (!p || !voxel_mean || !coords || !io || !dense_out || B < 1 || B > p->cfg.max_batch || n_voxels < 1 ||
+      n_voxels > p->stages[0].cap)
+    return V3D_EINVAL;
+  for (size_t l = 0; l < p->layers.size(); l++)
+    if (!io[l].weight || !io[l].gamma || !io[l].beta || (io[l].running_mean == nullptr) != (io[l].running_var == nullptr))
+      return V3D_EINVAL;
+  int rc = plan_train_alloc(p);
+  if (rc) return rc;
+  PlanTrain* t = p->train;
+  hipStream_t st = (hipStream_t)stream;
+  PlanStage& s0 = p->stages[0];
+  V3D_CHECK_HIP(v3d_fill_async(p->ff_begin, 0xFF, p->ff_bytes, st));
+  V3D_CHECK_HIP(hipMemcpyAsync(s0.coords, coords, (size_t)n_voxels * 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  V3D_CHECK_HIP(hipMemcpyAsync(p->mean, voxel_mean, (size_t)n_voxels * p->cfg.point_channels * sizeof(float),
+                               hipMemcpyDeviceToDevice, st));
+  V3D_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)s0.n_dev, n_voxels, 1, st));
+  std::vector<char> rb_done(p->layers.size(), 0);
+  bool hash0_done = false;
+  const float* feat = p->mean;
+  for (size_t l = 0; l < p->layers.size(); l++) {
+    PlanLayer& L = p->layers[l];
+    PlanTrainLayer& T = t->tl[l];
+    PlanStage& so = p->stages[L.stage_out];
+    rc = plan_layer_rulebook(p, l, rb_done, hash0_done, st);
+    if (rc) return rc;
+    if (L.d.cin >= 16 && L.d.cout % 16 == 0) {
+      rc = v3d_sparse_conv_pack_weights(io[l].weight, L.K, L.d.cin, L.d.cout, L.wimg, stream);
+      if (rc) return rc;
+    }
+    rc = plan_layer_conv(p, L, feat, L.wimg, io[l].weight, nullptr, nullptr, 0, T.conv_out, st);
+    if (rc) return rc;
+    rc = v3d_i_sparse_bn_relu_fwd(T.conv_out, so.cap, so.n_dev, L.d.cout, io[l].gamma, io[l].beta, io[l].eps, L.d.relu, L.out,
+                                  T.stats, T.stats + L.d.cout, T.stats + 2 * L.d.cout, io[l].running_mean, io[l].running_var,
+                                  io[l].momentum, io[l].num_batches_tracked, t->bn_ws, t->bn_ws_bytes, st);
+    if (rc) return rc;
+    feat = L.out;
+  }
+  PlanStage& sl = p->stages.back();
+  rc = v3d_densify(feat, sl.coords, sl.n_dev, sl.cap, B, p->out_channels, sl.shape, dense_out, st);
+  if (rc) return rc;
+  t->forward_done = true;
+  return V3D_OK;
+}
+
+extern "C" int v3d_backbone_train_backward(v3d_backbone* p, const float* grad_dense, int B, const v3d_train_layer* io,
+                                           v3d_stream_t stream) {
+  if (!p || !grad_dense || !io || B < 1 || B > p->cfg.max_batch) return V3D_EINVAL;
+  if (!p->train || !p->train->forward_done) return V3D_EINVAL;  // backward of what?
+  for (size_t l = 0; l < p->layers.size(); l++)
+    if (!io[l].weight || !io[l].gamma || !io[l].beta || !io[l].grad_weight || !io[l].grad_gamma || !io[l].grad_beta)
+      return V3D_EINVAL;
+  PlanTrain* t = p->train;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  {
+    PlanStage& sl = p->stages.back();
+    const long long total = (long long)sl.cap * p->out_channels;
+    hipLaunchKernelGGL(plan_densify_bwd_kernel, dim3((int)std::min<long long>(v3d_ceil_div(total, V3D_BLOCK), 4096)),
+                       dim3(V3D_BLOCK), 0, st, grad_dense, (const int4*)sl.coords, sl.n_dev, sl.cap, p->out_channels, sl.shape[0],
+                       sl.shape[1], sl.shape[2], t->g[0]);
+  }
+  int cur = 0;
+  for (int l = (int)p->layers.size() - 1; l >= 0; l--) {
+    PlanLayer& L = p->layers[l];
+    PlanTrainLayer& T = t->tl[l];
+    PlanStage &si = p->stages[L.stage_in], &so = p->stages[L.stage_out];
+    const float* x_in = l > 0 ? p->layers[l - 1].out : p->mean;
+    rc = v3d_i_sparse_bn_relu_bwd(T.conv_out, t->g[cur], so.cap, so.n_dev, L.d.cout, io[l].gamma, io[l].beta, T.stats,
+                                  T.stats + L.d.cout, L.d.relu, t->g_conv, io[l].grad_gamma, io[l].grad_beta, t->bn_ws,
+                                  t->bn_ws_bytes, st);
+    if (rc) return rc;
+    rc = v3d_sparse_conv_bwd_weight(x_in, t->g_conv, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout,
+                                    io[l].grad_weight, t->dw_ws, t->dw_ws_bytes, stream);
+    if (rc) return rc;
+    if (l == 0) break;  // the voxel features need no gradient
+    const int total = L.K * L.d.cin * L.d.cout;
+    hipLaunchKernelGGL(plan_transpose_weights_kernel, dim3(std::min(v3d_ceil_div(total, V3D_BLOCK), 1024)), dim3(V3D_BLOCK), 0,
+                       st, io[l].weight, L.K, L.d.cin, L.d.cout, L.d.subm ? 1 : 0, t->w_t);
+    const int32_t* nbr_t = p->nbr[L.rulebook];
+    if (!L.d.subm) {
+      rc = v3d_rulebook_transpose(p->nbr[L.rulebook], so.n_dev, so.cap, L.K, si.cap, T.nbr_t, stream);
+      if (rc) return rc;
+      nbr_t = T.nbr_t;
+    }
+    rc = V3D_EUNSUPPORTED;
+    if (T.wimg_t && L.d.cout >= 16) {  // transposed layer: Cin' = cout, Cout' = cin
+      rc = v3d_sparse_conv_pack_weights(t->w_t, L.K, L.d.cout, L.d.cin, T.wimg_t, stream);
+      if (rc) return rc;
+      rc = v3d_i_sparse_conv_fwd_packed(t->g_conv, T.wimg_t, nbr_t, si.n_dev, si.cap, L.K, L.d.cout, L.d.cin, nullptr, nullptr,
+                                        0, t->g[cur ^ 1], L.rows_hint_in, st);
+    }
+    if (rc == V3D_EUNSUPPORTED)
+      rc = v3d_sparse_conv_fwd(t->g_conv, t->w_t, nbr_t, si.n_dev, si.cap, L.K, L.d.cout, L.d.cin, nullptr, nullptr, 0,
+                               t->g[cur ^ 1], 0, stream);
+    if (rc) return rc;
+    cur ^= 1;
+  }
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}

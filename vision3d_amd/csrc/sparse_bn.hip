@@ -11,21 +11,33 @@
 #include <stdint.h>
 
 #include "../../include/vision3d_hip.h"
-#include "v3d_common.h"
+#include "v3d_internal.h"
 
 #define SBN_MAX_CHUNKS 512
 #define SBN_MIN_ROWS 256  // rows per chunk at least
 
-static inline int sbn_chunks(int n) {
+__host__ __device__ static inline int sbn_chunks(int n) {
   int g = (n + SBN_MIN_ROWS - 1) / SBN_MIN_ROWS;
   return g < 1 ? 1 : (g > SBN_MAX_CHUNKS ? SBN_MAX_CHUNKS : g);
 }
 
+// The row count is either a host value (n_dev == nullptr) or lives in device memory (the plan's training path: no host
+// read anywhere).  Every kernel derives the SAME chunking from it -- G = sbn_chunks(n), rows_per_chunk = ceil(n / G) -- so
+// both forms give bit-identical results; with a device count the grids are sized from the capacity and surplus
+// workgroups leave at once.
+struct SbnRows {
+  const int* n_dev;
+  int n_host;  // the count itself, or the capacity when n_dev is set
+  __device__ int n() const { return n_dev ? min(*n_dev, n_host) : n_host; }
+};
+
 // thread = (row lane rl, channel c): rl = tid / C, c = tid % C; consecutive threads read consecutive channels
-__global__ __launch_bounds__(V3D_BLOCK) void sbn_stats_kernel(const float* __restrict__ x, int n, int C, int rows_per_chunk,
+__global__ __launch_bounds__(V3D_BLOCK) void sbn_stats_kernel(const float* __restrict__ x, SbnRows rows, int C,
                                                               float* __restrict__ part /*[G][3][C]: count, mean, M2*/) {
   __shared__ float red[V3D_BLOCK];
   __shared__ float mean_s[V3D_BLOCK];
+  const int n = rows.n(), G = sbn_chunks(n), rows_per_chunk = (n + G - 1) / G;
+  if ((int)blockIdx.x >= G) return;
   const int tid = threadIdx.x, c = tid % C, rl = tid / C, RL = V3D_BLOCK / C;
   const int r0 = blockIdx.x * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
   const int cnt = max(0, r1 - r0);
@@ -61,13 +73,14 @@ __global__ __launch_bounds__(V3D_BLOCK) void sbn_stats_kernel(const float* __res
 //   mean = sum_b n_b * mean_b / n ;  M2 = sum_b [ M2_b + n_b * (mean_b - mean)^2 ]        (exact regrouping of the
 // deviations about the global mean).  Two sweeps over the partials with independent loads and no division inside the
 // loops (a serial Chan update over 512 chunks took 166 us, a grouped one 34 us: dependent loads + fp64 divisions).
-__global__ __launch_bounds__(V3D_BLOCK) void sbn_merge_kernel(const float* __restrict__ part, int G, int C, int n, float eps,
+__global__ __launch_bounds__(V3D_BLOCK) void sbn_merge_kernel(const float* __restrict__ part, SbnRows rows, int C, float eps,
                                                               float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                               float* __restrict__ var_unbiased, float* __restrict__ running_mean,
                                                               float* __restrict__ running_var, float momentum,
                                                               long long* __restrict__ num_batches_tracked) {
   __shared__ double s_a[V3D_BLOCK];
   __shared__ double s_mean[V3D_BLOCK];
+  const int n = rows.n(), G = sbn_chunks(n);
   const int tid = threadIdx.x, c = tid % C, q = tid / C, Q = V3D_BLOCK / C;
   double a = 0.0;
 #pragma unroll 8
@@ -111,10 +124,11 @@ __global__ __launch_bounds__(V3D_BLOCK) void sbn_merge_kernel(const float* __res
 }
 
 // elementwise passes: C is a power of two >= 4 here (host-checked), a thread handles 4 consecutive channels of one row
-__global__ __launch_bounds__(V3D_BLOCK) void sbn_apply_kernel(const float* __restrict__ x, long long total4, int C,
+__global__ __launch_bounds__(V3D_BLOCK) void sbn_apply_kernel(const float* __restrict__ x, SbnRows rows, int C,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               int relu, float* __restrict__ y) {
+  const long long total4 = (long long)rows.n() * C / 4;
   const int cmask = C - 1;
   for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total4; t += (long long)gridDim.x * V3D_BLOCK) {
     const int c = (int)((t << 2) & cmask);
@@ -134,12 +148,14 @@ __global__ __launch_bounds__(V3D_BLOCK) void sbn_apply_kernel(const float* __res
 }
 
 // backward sums per chunk: sum(dz) and sum(dz * xhat), dz = dy masked by the ReLU (y > 0)
-__global__ __launch_bounds__(V3D_BLOCK) void sbn_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy, int n,
-                                                                 int C, int rows_per_chunk, const float* __restrict__ mean,
+__global__ __launch_bounds__(V3D_BLOCK) void sbn_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 SbnRows rows, int C, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, int relu,
                                                                  float* __restrict__ part /*[G][2][C]*/) {
   __shared__ float red0[V3D_BLOCK], red1[V3D_BLOCK];
+  const int n = rows.n(), G = sbn_chunks(n), rows_per_chunk = (n + G - 1) / G;
+  if ((int)blockIdx.x >= G) return;
   const int tid = threadIdx.x, c = tid % C, rl = tid / C, RL = V3D_BLOCK / C;
   const int r0 = blockIdx.x * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
   const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
@@ -167,9 +183,10 @@ __global__ __launch_bounds__(V3D_BLOCK) void sbn_bwd_sums_kernel(const float* __
   }
 }
 
-__global__ __launch_bounds__(V3D_BLOCK) void sbn_bwd_merge_kernel(const float* __restrict__ part, int G, int C,
+__global__ __launch_bounds__(V3D_BLOCK) void sbn_bwd_merge_kernel(const float* __restrict__ part, SbnRows rows, int C,
                                                                   float* __restrict__ dbeta, float* __restrict__ dgamma) {
   __shared__ double s_a[V3D_BLOCK], s_b[V3D_BLOCK];
+  const int G = sbn_chunks(rows.n());
   const int tid = threadIdx.x, c = tid % C, q = tid / C, Q = V3D_BLOCK / C;
   double a = 0.0, b = 0.0;
 #pragma unroll 8
@@ -192,12 +209,14 @@ __global__ __launch_bounds__(V3D_BLOCK) void sbn_bwd_merge_kernel(const float* _
 }
 
 __global__ __launch_bounds__(V3D_BLOCK) void sbn_bwd_apply_kernel(const float* __restrict__ x,
-                                                                  const float* __restrict__ dy, long long total4, int C, int n,
+                                                                  const float* __restrict__ dy, SbnRows rows, int C,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   const float* __restrict__ dbeta,
                                                                   const float* __restrict__ dgamma, int relu,
                                                                   float* __restrict__ dx) {
+  const int n = rows.n();
+  const long long total4 = (long long)n * C / 4;
   const float inv_n = 1.f / (float)n;
   const int cmask = C - 1;
   for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total4; t += (long long)gridDim.x * V3D_BLOCK) {
@@ -224,44 +243,58 @@ extern "C" size_t v3d_sparse_bn_workspace(int n, int C) {
 
 static bool sbn_shape_ok(int n, int C) { return n >= 1 && C >= 4 && C <= V3D_BLOCK && (C & (C - 1)) == 0; }  // power of two
 
-extern "C" int v3d_sparse_bn_relu_fwd(const float* x, int n, int C, const float* gamma, const float* beta, float eps, int relu,
-                                      float* y, float* save_mean, float* save_invstd, float* var_unbiased, float* running_mean,
-                                      float* running_var, float momentum, int64_t* num_batches_tracked, void* workspace,
-                                      size_t workspace_bytes, v3d_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
+// n_dev == nullptr: n rows (host count).  n_dev != nullptr: min(*n_dev, n) rows, n = capacity of the buffers.
+int v3d_i_sparse_bn_relu_fwd(const float* x, int n, const int32_t* n_dev, int C, const float* gamma, const float* beta, float eps,
+                             int relu, float* y, float* save_mean, float* save_invstd, float* var_unbiased, float* running_mean,
+                             float* running_var, float momentum, int64_t* num_batches_tracked, void* workspace,
+                             size_t workspace_bytes, hipStream_t st) {
   if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !var_unbiased || !workspace) return V3D_EINVAL;
   if (!sbn_shape_ok(n, C)) return V3D_EUNSUPPORTED;
   if ((running_mean == nullptr) != (running_var == nullptr)) return V3D_EINVAL;
   if (workspace_bytes < v3d_sparse_bn_workspace(n, C)) return V3D_EWORKSPACE;
-  const int G = sbn_chunks(n), rows_per_chunk = (n + G - 1) / G;
+  const SbnRows rows{n_dev, n};
   float* part = (float*)workspace;
-  hipLaunchKernelGGL(sbn_stats_kernel, dim3(G), dim3(V3D_BLOCK), 0, st, x, n, C, rows_per_chunk, part);
-  hipLaunchKernelGGL(sbn_merge_kernel, dim3(1), dim3(V3D_BLOCK), 0, st, part, G, C, n, eps, save_mean, save_invstd,
+  hipLaunchKernelGGL(sbn_stats_kernel, dim3(sbn_chunks(n)), dim3(V3D_BLOCK), 0, st, x, rows, C, part);
+  hipLaunchKernelGGL(sbn_merge_kernel, dim3(1), dim3(V3D_BLOCK), 0, st, part, rows, C, eps, save_mean, save_invstd,
                      var_unbiased, running_mean, running_var, momentum, (long long*)num_batches_tracked);
   const long long total = (long long)n * C / 4;
   const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
-  hipLaunchKernelGGL(sbn_apply_kernel, dim3(blocks > 8192 ? 8192 : blocks), dim3(V3D_BLOCK), 0, st, x, total, C, save_mean,
+  hipLaunchKernelGGL(sbn_apply_kernel, dim3(blocks > 8192 ? 8192 : blocks), dim3(V3D_BLOCK), 0, st, x, rows, C, save_mean,
                      save_invstd, gamma, beta, relu, y);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
 
-extern "C" int v3d_sparse_bn_relu_bwd(const float* x, const float* dy, int n, int C, const float* gamma, const float* beta,
-                                      const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
-                                      float* dbeta, void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
+int v3d_i_sparse_bn_relu_bwd(const float* x, const float* dy, int n, const int32_t* n_dev, int C, const float* gamma,
+                             const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dx,
+                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace) return V3D_EINVAL;
   if (!sbn_shape_ok(n, C)) return V3D_EUNSUPPORTED;
   if (workspace_bytes < v3d_sparse_bn_workspace(n, C)) return V3D_EWORKSPACE;
-  const int G = sbn_chunks(n), rows_per_chunk = (n + G - 1) / G;
+  const SbnRows rows{n_dev, n};
   float* part = (float*)workspace;
-  hipLaunchKernelGGL(sbn_bwd_sums_kernel, dim3(G), dim3(V3D_BLOCK), 0, st, x, dy, n, C, rows_per_chunk, save_mean, save_invstd,
+  hipLaunchKernelGGL(sbn_bwd_sums_kernel, dim3(sbn_chunks(n)), dim3(V3D_BLOCK), 0, st, x, dy, rows, C, save_mean, save_invstd,
                      gamma, beta, relu, part);
-  hipLaunchKernelGGL(sbn_bwd_merge_kernel, dim3(1), dim3(V3D_BLOCK), 0, st, part, G, C, dbeta, dgamma);
+  hipLaunchKernelGGL(sbn_bwd_merge_kernel, dim3(1), dim3(V3D_BLOCK), 0, st, part, rows, C, dbeta, dgamma);
   const long long total = (long long)n * C / 4;
   const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
-  hipLaunchKernelGGL(sbn_bwd_apply_kernel, dim3(blocks > 8192 ? 8192 : blocks), dim3(V3D_BLOCK), 0, st, x, dy, total, C, n,
+  hipLaunchKernelGGL(sbn_bwd_apply_kernel, dim3(blocks > 8192 ? 8192 : blocks), dim3(V3D_BLOCK), 0, st, x, dy, rows, C,
                      save_mean, save_invstd, gamma, beta, dbeta, dgamma, relu, dx);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
+}
+
+extern "C" int v3d_sparse_bn_relu_fwd(const float* x, int n, int C, const float* gamma, const float* beta, float eps, int relu,
+                                      float* y, float* save_mean, float* save_invstd, float* var_unbiased, float* running_mean,
+                                      float* running_var, float momentum, int64_t* num_batches_tracked, void* workspace,
+                                      size_t workspace_bytes, v3d_stream_t stream) {
+  return v3d_i_sparse_bn_relu_fwd(x, n, nullptr, C, gamma, beta, eps, relu, y, save_mean, save_invstd, var_unbiased, running_mean,
+                                  running_var, momentum, num_batches_tracked, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int v3d_sparse_bn_relu_bwd(const float* x, const float* dy, int n, int C, const float* gamma, const float* beta,
+                                      const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
+                                      float* dbeta, void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
+  return v3d_i_sparse_bn_relu_bwd(x, dy, n, nullptr, C, gamma, beta, save_mean, save_invstd, relu, dx, dgamma, dbeta, workspace,
+                                  workspace_bytes, (hipStream_t)stream);
 }

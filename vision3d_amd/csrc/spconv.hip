@@ -970,17 +970,25 @@ extern "C" int v3d_sparse_conv_fwd(const float* in, const float* weight, const i
 #define BW_MAX_SPLITS 64
 #define BW_Q 128
 
+// Rows per slab from the LIVE row count (device-side): the grid always has BW_MAX_SPLITS slabs, so a plan that passes a
+// capacity several times the live count still spreads the live rows over all of them.  A multiple of 256 (4 waves x 64).
+__host__ __device__ static inline int bw_rows_per_block(int n) {
+  const int r = ((n + BW_MAX_SPLITS - 1) / BW_MAX_SPLITS + 255) & ~255;
+  return r < 256 ? 256 : r;
+}
+
 template <int TI, int TJ>
 __global__ __launch_bounds__(V3D_BLOCK) void spconv_bwd_weight_tiles(const float* __restrict__ X,
                                                                      const float* __restrict__ dY,
                                                                      const int* __restrict__ nbr,
                                                                      const int* __restrict__ n_ptr, int cap, int Cin,
-                                                                     int Cout, int rows_per_block, int groups_j,
+                                                                     int Cout, int groups_j,
                                                                      float* __restrict__ partial /*[S][K][Cin][Cout]*/) {
   __shared__ int q_src[4][BW_Q];
   __shared__ int q_out[4][BW_Q];
   __shared__ float red[TI * TJ * 256];
   const int n = min(*n_ptr, cap);
+  const int rows_per_block = bw_rows_per_block(n);
   const int slab = blockIdx.x, k = blockIdx.y, K = gridDim.y;
   const int lo = slab * rows_per_block;
   if (lo >= n) return;  // the reduce kernel only reads the live slabs
@@ -1077,8 +1085,9 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_bwd_weight_tiles(const float
 }
 
 __global__ void spconv_bwd_weight_reduce_kernel(const float* __restrict__ partial, const int* __restrict__ n_ptr, int cap,
-                                                int rows_per_block, long long elems, float* __restrict__ dW) {
+                                                long long elems, float* __restrict__ dW) {
   const int n = min(*n_ptr, cap);
+  const int rows_per_block = bw_rows_per_block(n);
   const int slabs = (n + rows_per_block - 1) / rows_per_block;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (long long)gridDim.x * blockDim.x) {
     float s = 0.f;
@@ -1093,10 +1102,10 @@ extern "C" size_t v3d_sparse_conv_bwd_weight_workspace(int K, int Cin, int Cout)
 
 template <int TI, int TJ>
 static void launch_bwd_weight(const float* X, const float* dY, const int* nbr, const int* n_out, int cap, int K, int Cin,
-                              int Cout, int rows_per_block, int slabs, float* partial, hipStream_t st) {
+                              int Cout, int slabs, float* partial, hipStream_t st) {
   const int gi = ((Cin + 15) / 16 + TI - 1) / TI, gj = ((Cout + 15) / 16 + TJ - 1) / TJ;
   hipLaunchKernelGGL((spconv_bwd_weight_tiles<TI, TJ>), dim3(slabs, K, gi * gj), dim3(V3D_BLOCK), 0, st, X, dY, nbr, n_out,
-                     cap, Cin, Cout, rows_per_block, gj, partial);
+                     cap, Cin, Cout, gj, partial);
 }
 
 // X (>= n_in, Cin) forward input, dY (cap_out, Cout) output gradient, nbr (K, cap_out) the FORWARD rulebook.
@@ -1107,18 +1116,16 @@ extern "C" int v3d_sparse_conv_bwd_weight(const float* X, const float* dY, const
   if (!X || !dY || !nbr || !n_out || !dW || !workspace || cap_out < 1 || K < 1 || K > 65535 || Cin < 1 || Cout < 1)
     return V3D_EINVAL;
   if (workspace_bytes < v3d_sparse_conv_bwd_weight_workspace(K, Cin, Cout)) return V3D_EWORKSPACE;
-  int rows_per_block = ((cap_out + BW_MAX_SPLITS - 1) / BW_MAX_SPLITS + 255) & ~255;
-  if (rows_per_block < 256) rows_per_block = 256;
-  const int slabs = (cap_out + rows_per_block - 1) / rows_per_block;
+  const int slabs = std::min(BW_MAX_SPLITS, v3d_ceil_div(cap_out, 256));  // slabs beyond the live rows leave at once
   const int ti = Cin > 32 ? 4 : (Cin > 16 ? 2 : 1), tj = Cout > 32 ? 4 : (Cout > 16 ? 2 : 1);
   float* partial = (float*)workspace;
 #define BW_CASE(A, B)                                                                                              \
-  if (ti == A && tj == B) launch_bwd_weight<A, B>(X, dY, nbr, n_out, cap_out, K, Cin, Cout, rows_per_block, slabs, partial, st)
+  if (ti == A && tj == B) launch_bwd_weight<A, B>(X, dY, nbr, n_out, cap_out, K, Cin, Cout, slabs, partial, st)
   BW_CASE(1, 1); BW_CASE(1, 2); BW_CASE(1, 4); BW_CASE(2, 1); BW_CASE(2, 2); BW_CASE(2, 4); BW_CASE(4, 1); BW_CASE(4, 2); BW_CASE(4, 4);
 #undef BW_CASE
   const long long elems = (long long)K * Cin * Cout;
   hipLaunchKernelGGL(spconv_bwd_weight_reduce_kernel, dim3((int)((elems + 255) / 256)), dim3(256), 0, st,
-                     (const float*)workspace, n_out, cap_out, rows_per_block, elems, dW);
+                     (const float*)workspace, n_out, cap_out, elems, dW);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }

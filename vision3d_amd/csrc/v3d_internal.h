@@ -36,3 +36,13 @@ int v3d_i_nms_sorted(const void* prep_sorted, const int* order, int N, float iou
 int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                  int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
                                  float* out, int rows_hint, hipStream_t st);
+
+// sparse_bn.hip: the C-ABI BatchNorm entry points with the row count optionally in device memory (n_dev != nullptr:
+// min(*n_dev, n) rows, n = the buffers' capacity).  Same chunking, bit-identical results either way.
+int v3d_i_sparse_bn_relu_fwd(const float* x, int n, const int32_t* n_dev, int C, const float* gamma, const float* beta, float eps,
+                             int relu, float* y, float* save_mean, float* save_invstd, float* var_unbiased, float* running_mean,
+                             float* running_var, float momentum, int64_t* num_batches_tracked, void* workspace,
+                             size_t workspace_bytes, hipStream_t st);
+int v3d_i_sparse_bn_relu_bwd(const float* x, const float* dy, int n, const int32_t* n_dev, int C, const float* gamma,
+                             const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dx,
+                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t st);

@@ -19,7 +19,26 @@ from .sparse_cnn import SpMiddleFHD
 class Middle(SpMiddleFHD):
     """Sparse backbone straight to the BEV map (skips the metric-coordinate outputs)."""
 
+    native_train = True  # training: the whole backbone as one native call each way (runtime.PlanTrainFunction)
+
+    def _train_plan(self, n_voxels, batch_size, device):
+        from ..runtime import BackbonePlan, PlanCache
+        cap = 1 << max(14, (max(n_voxels, 1) - 1).bit_length())  # voxel capacity min(points, B * MAX_VOXELS) >= n_voxels
+        key = (str(device), int(batch_size), cap)
+        plans = self.__dict__.setdefault("_train_plans", PlanCache())
+        if key not in plans:
+            plans[key] = BackbonePlan(self, self.cfg, max_batch=int(batch_size), max_points=max(cap, int(batch_size) * 16384),
+                                      device=device, growth=self.__dict__.get("plan_growth", 2.0))
+        return plans[key]
+
     def forward(self, features, coordinates, batch_size):
+        if self.training and torch.is_grad_enabled():
+            if (self.native_train and features.is_cuda and features.dtype == torch.float32 and features.shape[0] > 0
+                    and coordinates.dtype == torch.int32):
+                from ..runtime import PlanTrainFunction
+                plan = self._train_plan(features.shape[0], batch_size, features.device)
+                if plan.train_supported():
+                    return PlanTrainFunction.apply(plan, features, coordinates, batch_size, *plan.train_parameters())
         x = spconv.SparseConvTensor(features, coordinates.int(), self.grid_shape, batch_size)
         if self.training and torch.is_grad_enabled():
             spconv.prebuild_rulebooks(self.blocks, x)  # every host read of the step happens here, before any conv is enqueued
@@ -150,8 +169,8 @@ class Second(nn.Module):
     def backbone_plan(self, max_batch, max_points, slot=0):
         """Plans own their arena (hash tables, rulebooks, per-layer outputs): frames in flight at the same time need
         one plan each -- `slot` keys them."""
-        from ..runtime import BackbonePlan
-        plans = self.__dict__.setdefault("_plans", {})
+        from ..runtime import BackbonePlan, PlanCache
+        plans = self.__dict__.setdefault("_plans", PlanCache())
         dev = next(self.parameters()).device
         key = (str(dev), int(max_batch), int(max_points)) + ((int(slot),) if slot else ())
         if key not in plans:

@@ -15,6 +15,14 @@ from .spconv.conv import _SparseConvBase
 from .spconv.modules import fold_batchnorm
 
 
+class PlanCache(dict):
+    """Per-module cache of native plans.  Plans own device arenas through a C handle: a deep copy of the module
+    (copy.deepcopy(model), EMA / checkpoint helpers) starts with an empty cache instead of aliasing the handles."""
+
+    def __deepcopy__(self, memo):
+        return PlanCache()
+
+
 def flatten_sparse_layers(module):
     """[(conv, bn|None, relu: bool)] in execution order from a tree of SparseSequential."""
     mods = []
@@ -187,6 +195,83 @@ class BackbonePlan(object):
             return self.forward_voxels_split(voxel_mean, coordinates, batch_size)
         return hi, lo
 
+    # ---- training: the sparse half of a train step, one native call each way (csrc/second_plan.hip, "Training plan")
+    def train_parameters(self):
+        """[w0, gamma0, beta0, w1, ...]: the tensors the training plan differentiates, in the order of `train_forward`'s
+        gradients."""
+        out = []
+        for conv, bn, _ in self.layers:
+            out += [conv.weight, bn.weight, bn.bias]
+        return out
+
+    def train_supported(self):
+        """Every layer conv (no bias) + BatchNorm1d in training mode with running statistics and a fixed momentum."""
+        for conv, bn, _ in self.layers:
+            if conv.bias is not None or bn is None or not bn.training or not bn.affine or bn.momentum is None:
+                return False
+            if (bn.running_mean is None) != (not bn.track_running_stats):
+                return False
+            c = conv.out_channels
+            if c < 4 or c > 256 or (c & (c - 1)):
+                return False
+        return True
+
+    def _train_io(self, grads=None):
+        """Host array of v3d_train_layer for the CURRENT parameter tensors (+ gradient slices of one flat buffer)."""
+        io = (L.TrainLayer * len(self.layers))()
+        for i, (d, (conv, bn, _)) in enumerate(zip(io, self.layers)):
+            for t in (conv.weight, bn.weight, bn.bias):
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                    raise RuntimeError("training plan: parameters must be contiguous float32 tensors on the plan's device")
+            d.weight, d.gamma, d.beta = conv.weight.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr()
+            if bn.track_running_stats and bn.running_mean is not None:
+                d.running_mean, d.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                d.num_batches_tracked = bn.num_batches_tracked.data_ptr()
+            d.eps, d.momentum = float(bn.eps), float(bn.momentum)
+            if grads is not None:
+                d.grad_weight, d.grad_gamma, d.grad_beta = (g.data_ptr() for g in grads[3 * i:3 * i + 3])
+        return io
+
+    def train_forward(self, voxel_mean, coordinates, batch_size):
+        """item voxels -> BEV map (B, C_out * D, H, W) through conv + batch-statistics BatchNorm + ReLU layers; keeps what
+        `train_backward` needs inside the plan.  No host synchronisation (except before the first call, which tunes the
+        kernel choice from the row counts of a coordinate-only pass and checks the capacities)."""
+        mean = L.as_f32("backbone", voxel_mean)
+        coords = L.as_i32("backbone", coordinates)
+        m, b = mean.shape[0], int(batch_size)
+        if coords.shape != (m, 4) or mean.shape[1] != self.cfg.C_IN:
+            raise RuntimeError("backbone: voxel_mean (M, C_IN) / coordinates (M, 4) expected")
+        d, h, w = self.out_shape
+        out = torch.empty((b, self.out_channels * d, h, w), dtype=torch.float32, device=mean.device)
+        io = self._train_io()
+        with torch.cuda.device(mean.device):
+            if not self.__dict__.get("_tuned") and not torch.cuda.is_current_stream_capturing():
+                # first step: a coordinate-only pass picks the kernels from the row counts BEFORE the step runs (the step
+                # itself is not repeatable: it updates the running statistics)
+                L.check(L.lib().v3d_backbone_tune_from_voxels(self._handle, L.ptr(coords), m, b, L.stream_ptr()),
+                        "backbone_tune_from_voxels")
+                self._tuned = True
+                if not self.__dict__.get("allow_overflow"):
+                    self.check_overflow()
+            L.check(L.lib().v3d_backbone_train_forward(self._handle, L.ptr(mean), L.ptr(coords), m, b, io, L.ptr(out),
+                                                       L.stream_ptr()), "backbone_train_forward")
+        return out
+
+    def train_backward(self, grad_bev, batch_size):
+        """d(BEV) -> [dW0, dgamma0, dbeta0, dW1, ...] (views of one flat buffer), for the last `train_forward`."""
+        g = L.as_f32("backbone", grad_bev)
+        params = self.train_parameters()
+        flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=g.device)
+        grads, off = [], 0
+        for p in params:
+            grads.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        io = self._train_io(grads)
+        with torch.cuda.device(g.device):
+            L.check(L.lib().v3d_backbone_train_backward(self._handle, L.ptr(g), int(batch_size), io, L.stream_ptr()),
+                    "backbone_train_backward")
+        return grads
+
     def layer_output(self, layer):
         """(features (cap, C) view, coords (cap, 4) view, n_rows device int32 (1,), shape) of the last forward;
         layer = -1 is the voxelizer output.  Views alias the plan's arena: valid until the next forward."""
@@ -216,6 +301,21 @@ class BackbonePlan(object):
             hit = [i for i, f in enumerate(self.overflow()[:-1].tolist()) if f]
             raise RuntimeError(f"sparse backbone: layers {hit} exceeded their active-site capacity (rows were dropped); "
                                "build the plan with a larger `growth`")
+
+
+class PlanTrainFunction(torch.autograd.Function):
+    """Autograd node for the whole sparse backbone: forward / backward are ONE native call each (BackbonePlan.train_*).
+    The parameters are passed so that autograd routes their gradients; the plan reads them through the modules."""
+
+    @staticmethod
+    def forward(ctx, plan, voxel_mean, coordinates, batch_size, *params):
+        ctx.plan, ctx.batch_size = plan, int(batch_size)
+        return plan.train_forward(voxel_mean.detach(), coordinates, batch_size)
+
+    @staticmethod
+    def backward(ctx, grad_bev):
+        grads = ctx.plan.train_backward(grad_bev.contiguous(), ctx.batch_size)
+        return (None, None, None, None) + tuple(grads)
 
 
 class _DevMem(object):
