@@ -291,7 +291,7 @@ int v3d_backbone_forward_voxels(v3d_backbone* plan, const float* voxel_mean, con
  * Parameters are read from the caller's device pointers on every call (they change every optimiser step); the running
  * statistics are updated in place exactly as nn.BatchNorm1d would (momentum, unbiased variance, num_batches_tracked += 1).
  * forward:  voxel_mean (n_voxels, C) f32, coords (n_voxels, 4) i32 [b, z, y, x] (the Preprocessor's item) -> dense_out
- *           (B, Cout, D, H, W) f32; activations needed by the backward stay in the plan's training arena (allocated by the
+ *           (B, Cout, D, H, W) f32 or dense_nhwc_bf16; activations needed by the backward stay in the plan's training arena (allocated by the
  *           first call: v3d_backbone_train_arena_bytes).
  * backward: grad_dense (B, Cout, D, H, W) f32 -> grad_weight (K, Cin, Cout), grad_gamma (Cout), grad_beta (Cout) of every
  *           layer.  Must follow a train_forward of the same plan; the layer array is the same (host) array of device pointers.
@@ -309,9 +309,12 @@ typedef struct {
   float* grad_beta;
 } v3d_train_layer;
 int v3d_backbone_train_forward(v3d_backbone* plan, const float* voxel_mean, const int32_t* coords, int n_voxels, int B,
-                               const v3d_train_layer* layers_host, float* dense_out, v3d_stream_t stream);
-int v3d_backbone_train_backward(v3d_backbone* plan, const float* grad_dense, int B, const v3d_train_layer* layers_host,
-                                v3d_stream_t stream);
+                               const v3d_train_layer* layers_host, float* dense_out /*exactly one of the two outputs*/,
+                               void* dense_nhwc_bf16 /*(B, H, W, Cout * D) bf16, channel = c * D + z: the BEV map as the bf16
+                               autocast RPN consumes it (torch channels_last), rounded to nearest even*/,
+                               v3d_stream_t stream);
+int v3d_backbone_train_backward(v3d_backbone* plan, const float* grad_dense /*exactly one of the two gradients*/,
+                                const void* grad_nhwc_bf16, int B, const v3d_train_layer* layers_host, v3d_stream_t stream);
 size_t v3d_backbone_train_arena_bytes(const v3d_backbone* plan);
 /* Coordinate-only pass + v3d_backbone_tune: builds the rulebooks for these voxels (no convolution), waits for `stream` and takes
  * the kernel-choice hints from the row counts.  Lets the FIRST training step run the kernels of all later steps (a training

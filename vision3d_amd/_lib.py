@@ -63,8 +63,8 @@ _SIGNATURES = {
     "v3d_backbone_overflow_flags": (_vp, [_vp]),
     "v3d_backbone_forward2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "v3d_backbone_forward_voxels": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
-    "v3d_backbone_train_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
-    "v3d_backbone_train_backward": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "v3d_backbone_train_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "v3d_backbone_train_backward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "v3d_backbone_train_arena_bytes": (_sz, [_vp]),
     "v3d_backbone_tune_from_voxels": (_i, [_vp, _vp, _i, _i, _vp]),
     "v3d_conv2d_weight_image_bytes": (_sz, [_i, _i, _i]),

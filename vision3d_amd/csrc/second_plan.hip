@@ -535,9 +535,37 @@ __global__ __launch_bounds__(V3D_BLOCK) void plan_densify_bwd_kernel(const float
   }
 }
 
+// BEV map straight in the layout / type the autocast RPN consumes: (B, H, W, C * D) bf16 (torch: a (B, C * D, H, W) tensor in
+// channels_last), channel = c * D + z as volume.dense().flatten(1, 2) orders them; RNE rounding like torch's .to(bfloat16).
+// Saves the fp32 NCHW write, the channels_last copy and the cast of a 144 MB tensor per step (and their backward twins).
+__global__ __launch_bounds__(V3D_BLOCK) void plan_densify_nhwc_bf16_kernel(const float* __restrict__ feat, const int4* __restrict__ coords,
+                                                                           const int* __restrict__ n_ptr, int cap, int C, int D, int H,
+                                                                           int Wd, __bf16* __restrict__ out) {
+  const int n = min(*n_ptr, cap);
+  const long long total = (long long)n * C;
+  for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * V3D_BLOCK) {
+    const int i = (int)(t / C), ch = (int)(t % C);
+    const int4 c = coords[i];
+    out[(((size_t)c.x * H + c.z) * Wd + c.w) * ((size_t)C * D) + (size_t)ch * D + c.y] = (__bf16)feat[t];
+  }
+}
+
+__global__ __launch_bounds__(V3D_BLOCK) void plan_densify_nhwc_bf16_bwd_kernel(const __bf16* __restrict__ g, const int4* __restrict__ coords,
+                                                                               const int* __restrict__ n_ptr, int cap, int C, int D,
+                                                                               int H, int Wd, float* __restrict__ rows) {
+  const int n = min(*n_ptr, cap);
+  const long long total = (long long)n * C;
+  for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * V3D_BLOCK) {
+    const int i = (int)(t / C), ch = (int)(t % C);
+    const int4 c = coords[i];
+    rows[t] = (float)g[(((size_t)c.x * H + c.z) * Wd + c.w) * ((size_t)C * D) + (size_t)ch * D + c.y];
+  }
+}
+
 extern "C" int v3d_backbone_train_forward(v3d_backbone* p, const float* voxel_mean, const int32_t* coords, int n_voxels, int B,
-                                          const v3d_train_layer* io, float* dense_out, v3d_stream_t stream) {
-  if (!p || !voxel_mean || !coords || !io || !dense_out || B < 1 || B > p->cfg.max_batch || n_voxels < 1 ||
+                                          const v3d_train_layer* io, float* dense_out, void* dense_nhwc_bf16,
+                                          v3d_stream_t stream) {
+  if (!p || !voxel_mean || !coords || !io || (dense_out == nullptr) == (dense_nhwc_bf16 == nullptr) || B < 1 || B > p->cfg.max_batch || n_voxels < 1 ||
       n_voxels > p->stages[0].cap)
     return V3D_EINVAL;
   for (size_t l = 0; l < p->layers.size(); l++)
@@ -575,15 +603,25 @@ extern "C" int v3d_backbone_train_forward(v3d_backbone* p, const float* voxel_me
     feat = L.out;
   }
   PlanStage& sl = p->stages.back();
-  rc = v3d_densify(feat, sl.coords, sl.n_dev, sl.cap, B, p->out_channels, sl.shape, dense_out, st);
-  if (rc) return rc;
+  if (dense_out) {
+    rc = v3d_densify(feat, sl.coords, sl.n_dev, sl.cap, B, p->out_channels, sl.shape, dense_out, st);
+    if (rc) return rc;
+  } else {
+    const size_t bytes = (size_t)B * sl.shape[0] * sl.shape[1] * sl.shape[2] * p->out_channels * 2;
+    V3D_CHECK_HIP(v3d_fill_async(dense_nhwc_bf16, 0, bytes, st));
+    const long long total = (long long)sl.cap * p->out_channels;
+    hipLaunchKernelGGL(plan_densify_nhwc_bf16_kernel, dim3((int)std::min<long long>(v3d_ceil_div(total, V3D_BLOCK), 4096)),
+                       dim3(V3D_BLOCK), 0, st, feat, (const int4*)sl.coords, sl.n_dev, sl.cap, p->out_channels, sl.shape[0],
+                       sl.shape[1], sl.shape[2], (__bf16*)dense_nhwc_bf16);
+    V3D_CHECK_LAUNCH();
+  }
   t->forward_done = true;
   return V3D_OK;
 }
 
-extern "C" int v3d_backbone_train_backward(v3d_backbone* p, const float* grad_dense, int B, const v3d_train_layer* io,
-                                           v3d_stream_t stream) {
-  if (!p || !grad_dense || !io || B < 1 || B > p->cfg.max_batch) return V3D_EINVAL;
+extern "C" int v3d_backbone_train_backward(v3d_backbone* p, const float* grad_dense, const void* grad_nhwc_bf16, int B,
+                                           const v3d_train_layer* io, v3d_stream_t stream) {
+  if (!p || (grad_dense == nullptr) == (grad_nhwc_bf16 == nullptr) || !io || B < 1 || B > p->cfg.max_batch) return V3D_EINVAL;
   if (!p->train || !p->train->forward_done) return V3D_EINVAL;  // backward of what?
   for (size_t l = 0; l < p->layers.size(); l++)
     if (!io[l].weight || !io[l].gamma || !io[l].beta || !io[l].grad_weight || !io[l].grad_gamma || !io[l].grad_beta)
@@ -594,9 +632,14 @@ extern "C" int v3d_backbone_train_backward(v3d_backbone* p, const float* grad_de
   {
     PlanStage& sl = p->stages.back();
     const long long total = (long long)sl.cap * p->out_channels;
-    hipLaunchKernelGGL(plan_densify_bwd_kernel, dim3((int)std::min<long long>(v3d_ceil_div(total, V3D_BLOCK), 4096)),
-                       dim3(V3D_BLOCK), 0, st, grad_dense, (const int4*)sl.coords, sl.n_dev, sl.cap, p->out_channels, sl.shape[0],
-                       sl.shape[1], sl.shape[2], t->g[0]);
+    const dim3 grid((int)std::min<long long>(v3d_ceil_div(total, V3D_BLOCK), 4096));
+    if (grad_dense)
+      hipLaunchKernelGGL(plan_densify_bwd_kernel, grid, dim3(V3D_BLOCK), 0, st, grad_dense, (const int4*)sl.coords, sl.n_dev,
+                         sl.cap, p->out_channels, sl.shape[0], sl.shape[1], sl.shape[2], t->g[0]);
+    else
+      hipLaunchKernelGGL(plan_densify_nhwc_bf16_bwd_kernel, grid, dim3(V3D_BLOCK), 0, st, (const __bf16*)grad_nhwc_bf16,
+                         (const int4*)sl.coords, sl.n_dev, sl.cap, p->out_channels, sl.shape[0], sl.shape[1], sl.shape[2],
+                         t->g[0]);
   }
   int cur = 0;
   for (int l = (int)p->layers.size() - 1; l >= 0; l--) {

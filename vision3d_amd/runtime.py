@@ -232,8 +232,9 @@ class BackbonePlan(object):
                 d.grad_weight, d.grad_gamma, d.grad_beta = (g.data_ptr() for g in grads[3 * i:3 * i + 3])
         return io
 
-    def train_forward(self, voxel_mean, coordinates, batch_size):
-        """item voxels -> BEV map (B, C_out * D, H, W) through conv + batch-statistics BatchNorm + ReLU layers; keeps what
+    def train_forward(self, voxel_mean, coordinates, batch_size, bf16_nhwc=False):
+        """item voxels -> BEV map (B, C_out * D, H, W) [bf16_nhwc: bfloat16 in channels_last, what the autocast RPN consumes:
+        no fp32 NCHW map, layout copy or cast of a 144 MB tensor per step] through conv + batch-statistics BatchNorm + ReLU layers; keeps what
         `train_backward` needs inside the plan.  No host synchronisation (except before the first call, which tunes the
         kernel choice from the row counts of a coordinate-only pass and checks the capacities)."""
         mean = L.as_f32("backbone", voxel_mean)
@@ -242,7 +243,11 @@ class BackbonePlan(object):
         if coords.shape != (m, 4) or mean.shape[1] != self.cfg.C_IN:
             raise RuntimeError("backbone: voxel_mean (M, C_IN) / coordinates (M, 4) expected")
         d, h, w = self.out_shape
-        out = torch.empty((b, self.out_channels * d, h, w), dtype=torch.float32, device=mean.device)
+        if bf16_nhwc:
+            out = torch.empty((b, self.out_channels * d, h, w), dtype=torch.bfloat16, device=mean.device,
+                              memory_format=torch.channels_last)
+        else:
+            out = torch.empty((b, self.out_channels * d, h, w), dtype=torch.float32, device=mean.device)
         io = self._train_io()
         with torch.cuda.device(mean.device):
             if not self.__dict__.get("_tuned") and not torch.cuda.is_current_stream_capturing():
@@ -253,13 +258,17 @@ class BackbonePlan(object):
                 self._tuned = True
                 if not self.__dict__.get("allow_overflow"):
                     self.check_overflow()
-            L.check(L.lib().v3d_backbone_train_forward(self._handle, L.ptr(mean), L.ptr(coords), m, b, io, L.ptr(out),
+            L.check(L.lib().v3d_backbone_train_forward(self._handle, L.ptr(mean), L.ptr(coords), m, b, io,
+                                                       0 if bf16_nhwc else L.ptr(out), L.ptr(out) if bf16_nhwc else 0,
                                                        L.stream_ptr()), "backbone_train_forward")
         return out
 
     def train_backward(self, grad_bev, batch_size):
         """d(BEV) -> [dW0, dgamma0, dbeta0, dW1, ...] (views of one flat buffer), for the last `train_forward`."""
-        g = L.as_f32("backbone", grad_bev)
+        if grad_bev.dtype == torch.bfloat16:
+            g, nhwc = grad_bev.contiguous(memory_format=torch.channels_last), True
+        else:
+            g, nhwc = L.as_f32("backbone", grad_bev), False
         params = self.train_parameters()
         flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=g.device)
         grads, off = [], 0
@@ -268,8 +277,8 @@ class BackbonePlan(object):
             off += p.numel()
         io = self._train_io(grads)
         with torch.cuda.device(g.device):
-            L.check(L.lib().v3d_backbone_train_backward(self._handle, L.ptr(g), int(batch_size), io, L.stream_ptr()),
-                    "backbone_train_backward")
+            L.check(L.lib().v3d_backbone_train_backward(self._handle, 0 if nhwc else L.ptr(g), L.ptr(g) if nhwc else 0,
+                                                        int(batch_size), io, L.stream_ptr()), "backbone_train_backward")
         return grads
 
     def layer_output(self, layer):
@@ -308,14 +317,14 @@ class PlanTrainFunction(torch.autograd.Function):
     The parameters are passed so that autograd routes their gradients; the plan reads them through the modules."""
 
     @staticmethod
-    def forward(ctx, plan, voxel_mean, coordinates, batch_size, *params):
+    def forward(ctx, plan, voxel_mean, coordinates, batch_size, bf16_nhwc, *params):
         ctx.plan, ctx.batch_size = plan, int(batch_size)
-        return plan.train_forward(voxel_mean.detach(), coordinates, batch_size)
+        return plan.train_forward(voxel_mean.detach(), coordinates, batch_size, bf16_nhwc)
 
     @staticmethod
     def backward(ctx, grad_bev):
-        grads = ctx.plan.train_backward(grad_bev.contiguous(), ctx.batch_size)
-        return (None, None, None, None) + tuple(grads)
+        grads = ctx.plan.train_backward(grad_bev, ctx.batch_size)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 class _DevMem(object):
