@@ -270,6 +270,28 @@ int v3d_conv2d_pack_weights(const float* weight, const float* scale, int Cout, i
 int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias, int relu,
                            int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo, float* y_nchw,
                            v3d_stream_t stream);
+/* Background skipping for the BEV head.  The BEV map of a sparse scene is mostly empty: an output pixel of layer L whose
+ * receptive field through layers 1..L (`reach` pixels: +1 per 3x3 layer) contains no occupied BEV pixel sees exactly the inputs it
+ * sees in an EMPTY map, so its value is the empty map's response at that position -- bit for bit, borders included.  The caller
+ * computes that response once per weight set (the same convolutions on an all-zero map, occ = NULL) and passes it as bg_hi / bg_lo
+ * ((H, W, Cout) split planes of ONE image); tiles whose pixels are all further than `reach` (Chebyshev) from every occupied pixel
+ * become a copy of that response instead of a convolution.  Results are identical
+ * to v3d_conv2d_nhwc_bf16x3 (which is this call with occ = NULL).  Applies to the large-tile kernel with split-plane output;
+ * any other configuration computes every pixel.
+ * occ: BEV occupancy, one bit per pixel, INVERTED (bit cleared = occupied; a 0xFF fill = empty map), rows (b, y) of ceil(W / 32)
+ * words.  A plan keeps one for its last forward (v3d_backbone_bev_occupancy: cleared by the per-frame 0xFF fill, set by the
+ * densify kernel -- no extra launch); v3d_bev_occupancy_bits builds one from a site list. */
+size_t v3d_bev_occupancy_words(int B, int H, int W);
+int v3d_bev_occupancy_bits(const int32_t* coords /*(cap,4) b,z,y,x*/, const int32_t* n, int cap, int B, int H, int W,
+                           uint32_t* occ, v3d_stream_t stream);
+uint32_t* v3d_backbone_bev_occupancy(v3d_backbone* plan);
+int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias, int relu, int B,
+                              int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo, float* y_nchw,
+                              const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo,
+                              uint32_t* work /*nullable: two zeroed words owned by the caller for THIS call site (one pair per
+                              layer and stream in flight).  With it the skipping kernel runs as a persistent grid that draws
+                              80-pixel tiles from work[0]; the pair resets itself to zero when the kernel ends*/,
+                              v3d_stream_t stream);
 /* .dense() of the last sparse stage straight into that input format: planes (B,H,W,C*D), channel = c*D + z. */
 int v3d_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
                            const int32_t* spatial_shape_host, void* out_hi, void* out_lo, v3d_stream_t stream);

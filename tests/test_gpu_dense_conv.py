@@ -92,3 +92,151 @@ def test_inference_points_paths_agree():
         a = model.inference_points(clouds, anchors, dense="mfma")
         b = model.inference_points(clouds, anchors, dense="torch")
     assert a[0].shape[1] == 7 and abs(len(a[0]) - len(b[0])) <= max(2, len(b[0]) // 10)
+
+
+def _occupancy_numpy(occ, b, h, w):
+    """inverted bitmap (B * H, ceil(W / 32)) int32 -> bool (B, H, W) occupied"""
+    words = occ.cpu().numpy().astype(np.uint32)
+    bits = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(words.shape[0], -1)[:, :w]
+    return (bits == 0).reshape(b, h, w)
+
+
+def _tiles_with_background(occupied, reach, tile=80):
+    """fraction of `tile`-pixel runs (flattened B*H*W order) whose every pixel is further than `reach` from all occupied ones"""
+    b, h, w = occupied.shape
+    near = np.zeros_like(occupied)
+    padded = np.pad(occupied, ((0, 0), (reach, reach), (reach, reach)))
+    for dy in range(2 * reach + 1):
+        for dx in range(2 * reach + 1):
+            near |= padded[:, dy:dy + h, dx:dx + w]
+    flat = near.reshape(-1)
+    flat = np.concatenate([flat, np.zeros((-len(flat)) % tile, dtype=bool)])
+    return float((~flat.reshape(-1, tile).any(1)).mean())
+
+
+def test_bev_occupancy_bitmap_matches_numpy():
+    """v3d_bev_occupancy_bits and the plan's own bitmap (written by its densify kernel): bit (b, y, x) cleared <=> occupied."""
+    from vision3d_amd import _lib as L
+    rng = np.random.default_rng(0)
+    B, H, W, n, cap = 2, 23, 75, 60, 64
+    coords = np.stack([rng.integers(0, B, n), rng.integers(0, 2, n), rng.integers(0, H, n), rng.integers(0, W, n)], 1).astype(np.int32)
+    coords[0] = (0, 0, 0, 0)
+    coords[1] = (1, 1, H - 1, W - 1)
+    c = torch.zeros((cap, 4), dtype=torch.int32, device="cuda")
+    c[:n] = torch.from_numpy(coords).cuda()
+    n_dev = torch.tensor([n], dtype=torch.int32, device="cuda")
+    occ = torch.empty((B * H, (W + 31) // 32), dtype=torch.int32, device="cuda")
+    assert L.lib().v3d_bev_occupancy_words(B, H, W) == occ.numel()
+    L.check(L.lib().v3d_bev_occupancy_bits(L.ptr(c), L.ptr(n_dev), cap, B, H, W, L.ptr(occ), L.stream_ptr()), "bev_occupancy_bits")
+    ref = np.zeros((B, H, W), dtype=bool)
+    ref[coords[:, 0], coords[:, 2], coords[:, 3]] = True
+    np.testing.assert_array_equal(_occupancy_numpy(occ, B, H, W), ref)
+    model = build_model(3)
+    clouds = [torch.from_numpy(synth.make_cloud(s)).cuda() for s in (5, 6)]
+    with torch.no_grad():
+        plan, flat, offsets = model._plan_for(clouds)
+        plan.forward_split(flat, offsets)
+        _, sites, n_rows, shape = plan.layer_output(len(plan.layers) - 1)
+        sites = sites[:int(n_rows)].cpu().numpy()
+        ref = np.zeros((2, shape[1], shape[2]), dtype=bool)
+        ref[sites[:, 0], sites[:, 2], sites[:, 3]] = True
+        np.testing.assert_array_equal(_occupancy_numpy(plan.bev_occupancy(2), 2, shape[1], shape[2]), ref)
+
+
+@pytest.mark.parametrize("frames", [(0,), (3, 4)])
+def test_background_skipping_is_bit_identical_and_skips(frames):
+    """RPN with tiles far from every occupied pixel copied from the empty-map response == RPN with every tile convolved."""
+    from vision3d_amd.runtime import conv2d_split
+    model = build_model(3)
+    clouds = [torch.from_numpy(synth.make_cloud(s)).cuda() for s in frames]
+    with torch.no_grad():
+        plan, flat, offsets = model._plan_for(clouds)
+        hi, lo = plan.forward_split(flat, offsets)
+        occ = plan.bev_occupancy(len(clouds)).clone()
+        dense = model.dense_plan()
+        full = dense.forward(hi, lo)
+        skipped = dense.forward(hi, lo, occ=occ)
+        assert torch.equal(full, skipped)
+        # layer by layer (split planes), and how much the sparse map lets the kernel skip
+        occupied = _occupancy_numpy(occ, len(clouds), hi.shape[1], hi.shape[2])
+        bg = dense.background(hi.shape[1], hi.shape[2], hi.device)
+        x_hi, x_lo, reach = hi, lo, 0
+        for i, ly in enumerate(dense.layers[:-1]):
+            reach += ly["k"] // 2
+            (a_hi, a_lo), _ = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"])
+            (b_hi, b_lo), _ = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"],
+                                           occ=occ, reach=reach, bg=bg[i])
+            assert torch.equal(a_hi, b_hi) and torch.equal(a_lo, b_lo), f"layer {i}"
+            work = torch.zeros(2, dtype=torch.int32, device="cuda")  # persistent grid drawing 80-pixel tiles from a counter
+            (c_hi, c_lo), _ = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"],
+                                           occ=occ, reach=reach, bg=bg[i], work=work)
+            assert torch.equal(a_hi, c_hi) and torch.equal(a_lo, c_lo), f"layer {i} (persistent)"
+            assert int(work.abs().sum()) == 0, "the counter pair resets itself"
+            assert _tiles_with_background(occupied, reach) > 0.2, f"layer {i}: a sparse BEV map should leave background tiles"
+            x_hi, x_lo = a_hi, a_lo
+    model.skip_background = False
+    with torch.no_grad():
+        maps_off = model.fused_head_from_points(clouds)
+    model.skip_background = True
+    with torch.no_grad():
+        maps_on = model.fused_head_from_points(clouds)
+    assert torch.equal(maps_on, maps_off)
+
+
+@pytest.mark.parametrize("b,h,w", [(1, 200, 176), (3, 21, 40), (2, 16, 16), (1, 9, 300)])
+def test_background_skipping_random_occupancy_and_shapes(b, h, w):
+    """Tile / row / image-boundary geometry of the skip test: random sparse maps at sizes where a 144-pixel tile spans
+    several rows or images; a few isolated occupied pixels, some on the borders."""
+    from vision3d_amd.runtime import conv2d_split, pack_conv_weight, to_split_nhwc
+    g = torch.Generator().manual_seed(b * 1000 + h + w)
+    cin = cout = 128
+    wt1 = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda()
+    wt2 = (torch.randn(cout, cout, 3, 3, generator=g) / (cout * 9) ** 0.5).cuda()
+    bias1, bias2 = torch.randn(cout, generator=g).cuda() * 0.2, torch.randn(cout, generator=g).cuda() * 0.2
+    img1, img2 = pack_conv_weight(wt1), pack_conv_weight(wt2)
+    x = torch.zeros(b, cin, h, w)
+    n_sites = max(2, b * h * w // 400)
+    ys, xs, bs = torch.randint(0, h, (n_sites,), generator=g), torch.randint(0, w, (n_sites,), generator=g), torch.randint(0, b, (n_sites,), generator=g)
+    ys[0], xs[0], bs[0] = 0, 0, 0
+    ys[1], xs[1], bs[1] = h - 1, w - 1, b - 1
+    x[bs, :, ys, xs] = torch.randn(n_sites, cin, generator=g)
+    x = x.cuda()
+    occ = torch.full((b * h, (w + 31) // 32), -1, dtype=torch.int32)
+    occ_np = occ.numpy().view(np.uint32)
+    for bb, yy, xx in zip(bs.tolist(), ys.tolist(), xs.tolist()):
+        occ_np[bb * h + yy, xx // 32] &= ~np.uint32(1 << (xx % 32))
+    occ = occ.cuda()
+    hi, lo = to_split_nhwc(x)
+    z_hi, z_lo = to_split_nhwc(torch.zeros(1, cin, h, w, device="cuda"))
+    (bg1_hi, bg1_lo), _ = conv2d_split(z_hi, z_lo, img1, bias1, True, cin, cout, 3)
+    (bg2_hi, bg2_lo), _ = conv2d_split(bg1_hi, bg1_lo, img2, bias2, True, cout, cout, 3)
+    (a1_hi, a1_lo), _ = conv2d_split(hi, lo, img1, bias1, True, cin, cout, 3)
+    (a2_hi, a2_lo), _ = conv2d_split(a1_hi, a1_lo, img2, bias2, True, cout, cout, 3)
+    (s1_hi, s1_lo), _ = conv2d_split(hi, lo, img1, bias1, True, cin, cout, 3, occ=occ, reach=1, bg=(bg1_hi, bg1_lo))
+    (s2_hi, s2_lo), _ = conv2d_split(s1_hi, s1_lo, img2, bias2, True, cout, cout, 3, occ=occ, reach=2, bg=(bg2_hi, bg2_lo))
+    assert torch.equal(a1_hi, s1_hi) and torch.equal(a1_lo, s1_lo)
+    assert torch.equal(a2_hi, s2_hi) and torch.equal(a2_lo, s2_lo)
+    work = torch.zeros(2, dtype=torch.int32, device="cuda")
+    (p1_hi, p1_lo), _ = conv2d_split(hi, lo, img1, bias1, True, cin, cout, 3, occ=occ, reach=1, bg=(bg1_hi, bg1_lo), work=work)
+    (p2_hi, p2_lo), _ = conv2d_split(p1_hi, p1_lo, img2, bias2, True, cout, cout, 3, occ=occ, reach=2, bg=(bg2_hi, bg2_lo), work=work)
+    assert torch.equal(a1_hi, p1_hi) and torch.equal(a1_lo, p1_lo)
+    assert torch.equal(a2_hi, p2_hi) and torch.equal(a2_lo, p2_lo)
+    assert int(work.abs().sum()) == 0
+
+
+def test_background_skipping_on_an_empty_and_a_full_map():
+    """No occupied pixel: every tile is background (the result is the empty-map response itself).  Every pixel occupied:
+    nothing is skipped."""
+    from vision3d_amd.runtime import split_planes_like, to_split_nhwc
+    model = build_model(4)
+    dense = model.dense_plan()
+    h, w = 200, 176
+    with torch.no_grad():
+        hi, lo = split_planes_like(1, h, w, 128, "cuda")
+        hi.zero_(); lo.zero_()
+        none = torch.full((h, (w + 31) // 32), -1, dtype=torch.int32, device="cuda")
+        assert torch.equal(dense.forward(hi, lo), dense.forward(hi, lo, occ=none))
+        x = torch.randn(1, 128, h, w, device="cuda")
+        hi, lo = to_split_nhwc(x)
+        every = torch.zeros((h, (w + 31) // 32), dtype=torch.int32, device="cuda")
+        assert torch.equal(dense.forward(hi, lo), dense.forward(hi, lo, occ=every))

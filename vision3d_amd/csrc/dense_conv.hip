@@ -105,12 +105,14 @@ __global__ __launch_bounds__(V3D_BLOCK) void densify_split_kernel(const float* _
                                                                   const int4* __restrict__ coords,
                                                                   const int* __restrict__ n_ptr, int cap, int C, int D,
                                                                   int H, int Wd, bf16_t* __restrict__ hi,
-                                                                  bf16_t* __restrict__ lo) {
+                                                                  bf16_t* __restrict__ lo, unsigned* __restrict__ occ) {
   const int n = min(*n_ptr, cap);
   const long long total = (long long)n * C;
   for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * V3D_BLOCK) {
     const int i = (int)(t / C), ch = (int)(t % C);
     const int4 c = coords[i];
+    if (occ && ch == 0)  // the occupancy bitmap of the background-skipping head rides along (inverted bits, see bev_occupancy_kernel)
+      atomicAnd(occ + ((size_t)c.x * H + c.z) * ((Wd + 31) >> 5) + (c.w >> 5), ~(1u << (c.w & 31)));
     const size_t o = (((size_t)c.x * H + c.z) * Wd + c.w) * ((size_t)C * D) + (size_t)ch * D + c.y;
     bf16_t h, l;
     split_bf16(feat[t], h, l);
@@ -122,7 +124,12 @@ __global__ __launch_bounds__(V3D_BLOCK) void densify_split_kernel(const float* _
 extern "C" int v3d_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
                                       const int32_t* spatial_shape_host, void* out_hi, void* out_lo,
                                       v3d_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
+  return v3d_i_densify_nhwc_split(feat, coords, n, cap, B, C, spatial_shape_host, out_hi, out_lo, nullptr, (hipStream_t)stream);
+}
+
+// occ_inv (nullable): inverted occupancy bitmap, ALREADY filled with 0xFF by the caller; bits of the occupied pixels are cleared
+int v3d_i_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
+                             const int32_t* spatial_shape_host, void* out_hi, void* out_lo, uint32_t* occ_inv, hipStream_t st) {
   if (!feat || !coords || !n || cap < 1 || B < 1 || C < 1 || !spatial_shape_host || !out_hi || !out_lo) return V3D_EINVAL;
   const int D = spatial_shape_host[0], H = spatial_shape_host[1], Wd = spatial_shape_host[2];
   const size_t bytes = (size_t)B * H * Wd * C * D * sizeof(bf16_t);
@@ -135,7 +142,7 @@ extern "C" int v3d_densify_nhwc_split(const float* feat, const int32_t* coords, 
   const long long total = (long long)cap * C;
   const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
   hipLaunchKernelGGL(densify_split_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(V3D_BLOCK), 0, st, feat,
-                     (const int4*)coords, n, cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo);
+                     (const int4*)coords, n, cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo, occ_inv);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -171,6 +178,13 @@ struct DcParams {
   int B, H, W, Cin, Cout, CoutPad, ks, relu;
   int M;          // B*H*W
   int cout_store; // channels actually written
+  // background skipping (large-tile kernel, split-plane output only; see v3d_conv2d_nhwc_bf16x3_bg)
+  const unsigned* occ;   // BEV occupancy, one bit per pixel, INVERTED (0 = occupied), rows of ceil(W / 32) words (nullptr:
+                         // compute every tile)
+  int reach;             // output pixels further than this (Chebyshev) from every occupied pixel equal the empty-map response
+  const bf16_t* bg_hi;   // that response for ONE image, (H, W, Cout) split planes
+  const bf16_t* bg_lo;
+  unsigned* work;        // [2] tile counter + workgroups-done counter of the persistent grid (zero between launches)
 };
 
 template <int KS>
@@ -395,15 +409,15 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
 //     4 waves did both);
 //   * one barrier per stage (9 per 3x3 convolution at Cin = 128).
 // ------------------------------------------------------------------------------------------------
-#define DL_BM 144
-#define DL_MT (DL_BM / 16)
 #define DL_KC 128
 #define DL_SS (DL_KC / 32)  // MFMA k-substeps per stage
 #define DL_THREADS 512
-#define DL_A_PLANE (DL_BM * DL_KC * 2)  // bytes of one plane of one stage: 36 KB
-#define DL_STAGE (2 * DL_A_PLANE)       // hi + lo
 #define DL_TS (DC_BN + 4)
-#define DL_SMEM (DL_BM * DL_TS * 4 > 2 * DL_STAGE ? DL_BM * DL_TS * 4 : 2 * DL_STAGE)
+// dynamic LDS of a tile of MT fragments: two stages (hi + lo planes of MT * 16 pixels x 128 channels) or the fp32 epilogue tile
+static constexpr int dl_smem(int mt) {
+  const int bm = mt * 16, stages = 2 * 2 * bm * DL_KC * 2, tile = bm * DL_TS * 4;
+  return tile > stages ? tile : stages;
+}
 
 #ifndef DL_DBG
 #define DL_DBG 0
@@ -433,25 +447,55 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, uns
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t));
 }
 
-template <int KS>
-__global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const bf16_t* __restrict__ x_hi,
-                                                                         const bf16_t* __restrict__ x_lo,
-                                                                         const bf16_t* __restrict__ w_img,
-                                                                         const float* __restrict__ bias, const DcParams p,
-                                                                         bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo,
-                                                                         float* __restrict__ y_nchw) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_l[];
+// one tile (MT 16-pixel fragments x 128 couts) by the whole workgroup; returns with every thread past its last LDS access
+// except the epilogue reads (the caller separates tiles with a barrier)
+template <int KS, int MT>  // MT = 16-pixel fragments per tile: 9 (144 pixels), or 5 (80 pixels) with background skipping
+__device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __restrict__ x_hi, const bf16_t* __restrict__ x_lo,
+                                        const bf16_t* __restrict__ w_img, const float* __restrict__ bias, const DcParams& p,
+                                        bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo, float* __restrict__ y_nchw,
+                                        const int mtile) {
+  constexpr int BM = MT * 16, A_PLANE = BM * DL_KC * 2, STAGE = 2 * A_PLANE;  // pixels per tile; bytes of one plane / of hi + lo of a stage
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave >= 4;
-  const int nt = gridDim.x;
-  int mtile = blockIdx.x;
-  {  // XCD-aware order (see the 64-pixel kernel)
-    const int q = nt / 8, rmd = nt % 8, xcd = mtile % 8, idx = mtile / 8;
-    mtile = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;
-  }
-  const int m0 = mtile * DL_BM;
+  const int m0 = mtile * BM;
   const int n0 = blockIdx.y * DC_BN;
+  if (p.occ) {
+    // Background tiles.  An output pixel whose receptive field (through ALL layers so far: `reach` pixels) holds no occupied
+    // BEV pixel sees exactly the inputs it sees in an empty map, so its value is the empty map's response at that position,
+    // bit for bit -- precomputed once per weight set by this same kernel (bg planes).  Every wave takes the decision from
+    // the occupancy bitmap (wave-uniform, no barrier); a background tile is a 74 KB copy instead of 1 944 MFMAs per wave.
+    // "is any occupied pixel within `reach` of any pixel of this tile": the tile is a run of consecutive pixels = one
+    // segment per image row it crosses; a segment's neighbourhood is the rectangle (rows +- reach, columns +- reach),
+    // tested against the bitmap one (row, word) pair per lane
+    const int R = p.reach, wpr = (p.W + 31) >> 5, span = 2 * R + 1;
+    const int mlast = min(m0 + BM, p.M) - 1;
+    const int r0 = m0 / p.W, r1 = mlast / p.W;  // global rows b * H + y
+    const int per_seg = span * wpr, total = (r1 - r0 + 1) * per_seg;
+    bool near_any = false;
+    for (int q = lane; q < total; q += 64) {
+      const int seg = q / per_seg, rem = q - seg * per_seg, dy = rem / wpr - R, wd = rem % wpr;
+      const int r = r0 + seg, rr = r + dy;
+      if (rr < 0 || rr >= p.B * p.H || rr / p.H != r / p.H) continue;  // neighbours live in the same image
+      const int xs = (r == r0 ? m0 - r0 * p.W : 0) - R, xe = (r == r1 ? mlast - r1 * p.W : p.W - 1) + R;
+      const int lo = max(xs, wd * 32), hi = min(min(xe, p.W - 1), wd * 32 + 31);
+      if (lo > hi) continue;
+      const unsigned mask = (0xFFFFFFFFu >> (31 - (hi - wd * 32))) & (0xFFFFFFFFu << (lo - wd * 32));
+      near_any |= (~p.occ[(size_t)rr * wpr + wd] & mask) != 0u;
+    }
+    if (!__builtin_amdgcn_readfirstlane(__ballot(near_any) != 0ull)) {
+      const int HW = p.H * p.W, parts = (min(p.cout_store, n0 + DC_BN) - n0) >> 3;  // 16-byte parts of this cout block
+      for (int q = tid; q < BM * parts; q += DL_THREADS) {
+        const int row = q / parts, part = q - row * parts;
+        const int m = m0 + row;
+        if (m >= p.M) break;
+        const size_t src = (size_t)(m % HW) * p.cout_store + n0 + part * 8, dst = (size_t)m * p.cout_store + n0 + part * 8;
+        *reinterpret_cast<u32x4*>(y_hi + dst) = *reinterpret_cast<const u32x4*>(p.bg_hi + src);
+        *reinterpret_cast<u32x4*>(y_lo + dst) = *reinterpret_cast<const u32x4*>(p.bg_lo + src);
+      }
+      return;
+    }
+  }
   const int chunks = (p.Cin + DL_KC - 1) / DL_KC;  // 128-channel stages per tap (the last one may be partial: zero-filled)
   const int stages = KS * KS * chunks;
   // LDS image of one plane: pixel rows of 256 B (16 parts of 16 B), the part slot XOR-ed with px & 15.  Every row
@@ -460,9 +504,9 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
   // ds_write_b128 group (8 parts of one pixel).
   auto a_slot = [](int px, int part) { return px * 256 + ((part ^ (px & 15)) << 4); };
 
-  f32x4 acc[DL_MT][2];
+  f32x4 acc[MT][2];
 #pragma unroll
-  for (int i = 0; i < DL_MT; i++) {
+  for (int i = 0; i < MT; i++) {
     acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -474,13 +518,13 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
     // L/16 with channel part (L%16) ^ (px & 15).  Halo / out-of-range lanes read a 16-byte block of zeros.
     const int lw = wave - 4;
     const int sub = lane >> 4, slot = lane & 15;
-    int a_pix[DL_MT], a_hw[DL_MT];  // this lane's 9 pixels: px = (lw*9 + j)*4 + sub; flattened index (-1: beyond M), (h << 16 | w)
+    int a_pix[MT], a_hw[MT];  // this lane's 9 pixels: px = (lw*9 + j)*4 + sub; flattened index (-1: beyond M), (h << 16 | w)
     {
-      const int m = m0 + lw * DL_MT * 4 + sub;
+      const int m = m0 + lw * MT * 4 + sub;
       const int b = m / (p.H * p.W), rem = m - b * p.H * p.W;
       int h = rem / p.W, w = rem - h * p.W;
 #pragma unroll
-      for (int j = 0; j < DL_MT; j++) {
+      for (int j = 0; j < MT; j++) {
         const int mj = m + 4 * j;
         a_pix[j] = mj < p.M ? mj : -1;
         a_hw[j] = mj < p.M ? ((h << 16) | w) : 0;
@@ -496,10 +540,10 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
     int tap = 0, chunk = 0;
     auto gather = [&](int buf) {
       const int dy = KS == 3 ? tap / 3 - 1 : 0, dx = KS == 3 ? tap % 3 - 1 : 0;
-      unsigned char* A = smem_l + buf * DL_STAGE + lw * DL_MT * 1024;
+      unsigned char* A = smem_l + buf * STAGE + lw * MT * 1024;
 #pragma unroll
-      for (int j = 0; j < DL_MT; j++) {
-        const int px = (lw * DL_MT + j) * 4 + sub;
+      for (int j = 0; j < MT; j++) {
+        const int px = (lw * MT + j) * 4 + sub;
         const int ch = chunk * DL_KC + ((slot ^ (px & 15)) << 3);
         const int hh = (a_hw[j] >> 16) + dy, ww = (a_hw[j] & 0xFFFF) + dx;
         const bool ok = a_pix[j] >= 0 && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W && ch < p.Cin;
@@ -507,7 +551,7 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
         const bf16_t* sh = ok ? x_hi + off : reinterpret_cast<const bf16_t*>(dl_zero16);
         const bf16_t* sl = ok ? x_lo + off : reinterpret_cast<const bf16_t*>(dl_zero16);
         __builtin_amdgcn_global_load_lds((gptr_t)sh, (lptr_t)(A + j * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)sl, (lptr_t)(A + DL_A_PLANE + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)sl, (lptr_t)(A + A_PLANE + j * 1024), 16, 0, 0);
       }
       if (++chunk == chunks) {
         chunk = 0;
@@ -552,14 +596,14 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
     // dependent-issue latency (~40 clocks) stalled every MFMA (measured 25 instead of 16 clocks per MFMA).  The A
     // fragments of step u+2 are requested before step u's MFMAs issue (ring of 3 slots).
     auto multiply = [&](int buf, bool more, bool stamp) {
-      const unsigned char* A = smem_l + buf * DL_STAGE;
-      constexpr int NSTEP = DL_SS * DL_MT / 2;
+      const unsigned char* A = smem_l + buf * STAGE;
+      constexpr int NSTEP = DL_SS * MT / 2;
       bf16x8 fh[3][2], fl[3][2];
       auto frag = [&](int t, bf16x8& h, bf16x8& l) {
-        const int ss = t / DL_MT, i = t % DL_MT;
+        const int ss = t / MT, i = t % MT;
         const int off = a_slot(i * 16 + (lane & 15), ss * 4 + (lane >> 4));
         h = *reinterpret_cast<const bf16x8*>(A + off);
-        l = *reinterpret_cast<const bf16x8*>(A + DL_A_PLANE + off);
+        l = *reinterpret_cast<const bf16x8*>(A + A_PLANE + off);
       };
       frag(0, fh[0][0], fl[0][0]);
       frag(1, fh[0][1], fl[0][1]);
@@ -576,7 +620,7 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
           frag(2 * u + 5, fh[(u + 2) % 3][1], fl[(u + 2) % 3][1]);
         }
         const int t0 = 2 * u, t1 = 2 * u + 1;
-        const int s0 = t0 / DL_MT, i0 = t0 % DL_MT, s1 = t1 / DL_MT, i1 = t1 % DL_MT;
+        const int s0 = t0 / MT, i0 = t0 % MT, s1 = t1 / MT, i1 = t1 % MT;
         const bf16x8 b0h0 = __builtin_bit_cast(bf16x8, cb[s0][0]), b0l0 = __builtin_bit_cast(bf16x8, cb[s0][1]);
         const bf16x8 b0h1 = __builtin_bit_cast(bf16x8, cb[s0][2]), b0l1 = __builtin_bit_cast(bf16x8, cb[s0][3]);
         const bf16x8 b1h0 = __builtin_bit_cast(bf16x8, cb[s1][0]), b1l0 = __builtin_bit_cast(bf16x8, cb[s1][1]);
@@ -599,8 +643,8 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
         // a substep's B registers are free once its last tile has issued: refill them for the next stage
         // (unconditionally -- the last stage re-reads its own fragments: a branch here makes the compiler's
         // s_waitcnt bookkeeping merge two histories and wait for vmcnt(0) in the middle of the stage, 1350 clocks)
-        if (i0 == DL_MT - 1 && !(DL_DBG & 8)) load_b(s0);
-        if (i1 == DL_MT - 1 && !(DL_DBG & 8)) load_b(s1);
+        if (i0 == MT - 1 && !(DL_DBG & 8)) load_b(s0);
+        if (i1 == MT - 1 && !(DL_DBG & 8)) load_b(s1);
         __builtin_amdgcn_sched_barrier(0);
 #if DL_TIMELINE
         if (stamp && (u == 0 || u == 1 || u == 8 || u == 16 || u == 17)) DL_STAMP(0, 40 + u);
@@ -640,7 +684,7 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
   }
   if (!loader) {
 #pragma unroll
-    for (int i = 0; i < DL_MT; i++)
+    for (int i = 0; i < MT; i++)
 #pragma unroll
       for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -656,10 +700,10 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
     const int c8 = tid & 15, co = n0 + c8 * 8;
     if (co < p.cout_store) {
 #pragma unroll
-      for (int k = 0; k < (DL_BM + 31) / 32; k++) {
+      for (int k = 0; k < (BM + 31) / 32; k++) {
         const int row = (tid >> 4) + 32 * k;
         const int m = m0 + row;
-        if (row < DL_BM && m < p.M) {
+        if (row < BM && m < p.M) {
           const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + row * DL_TS + c8 * 8);
           const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + row * DL_TS + c8 * 8 + 4);
           float v[8] = {t0[0] + eb0[0], t0[1] + eb0[1], t0[2] + eb0[2], t0[3] + eb0[3],
@@ -685,8 +729,8 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
   }
   if (y_nchw) {
     const int HW = p.H * p.W;
-    for (int q = tid; q < (DL_BM / 4) * DC_BN; q += DL_THREADS) {
-      const int col = q / (DL_BM / 4), r4 = q % (DL_BM / 4);
+    for (int q = tid; q < (BM / 4) * DC_BN; q += DL_THREADS) {
+      const int col = q / (BM / 4), r4 = q % (BM / 4);
       const int co = n0 + col;
       if (co >= p.cout_store) continue;
       const float bv = bias ? bias[co] : 0.f;
@@ -702,6 +746,46 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
     }
   }
   DL_STAMP(loader ? 1 : 0, 33);
+}
+
+// The kernel: one tile per workgroup in launch order (XCD-contiguous remap), or -- p.work set: background skipping -- a
+// PERSISTENT grid of at most one workgroup per CU that draws tiles from a counter.  Why persistent: on a sparse map fewer than
+// half of the tiles convolve (the others are a copy), a kernel lasts as long as the CU that drew the most live tiles, and the
+// hardware dispatcher hands out workgroups in order, not to the first free CU (measured: 440 80-pixel tiles of which ~200 live
+// took as long as 440 live ones).  Drawing from a counter, CUs that hit background tiles come back within a few microseconds
+// and take the next tile: ~200 live tiles spread over 256 CUs, one each.  The counter pair resets itself (last workgroup out).
+template <int KS, int MT>
+__global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const bf16_t* __restrict__ x_hi,
+                                                                         const bf16_t* __restrict__ x_lo,
+                                                                         const bf16_t* __restrict__ w_img,
+                                                                         const float* __restrict__ bias, const DcParams p,
+                                                                         bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo,
+                                                                         float* __restrict__ y_nchw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_l[];
+  __shared__ int s_next;
+  if (!p.work) {
+    const int nt = gridDim.x;
+    int mtile = blockIdx.x;
+    {  // XCD-aware order (see the 64-pixel kernel)
+      const int q = nt / 8, rmd = nt % 8, xcd = mtile % 8, idx = mtile / 8;
+      mtile = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;
+    }
+    dl_tile<KS, MT>(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, y_nchw, mtile);
+    return;
+  }
+  const int ntiles = (p.M + MT * 16 - 1) / (MT * 16);
+  for (;;) {
+    if (threadIdx.x == 0) s_next = (int)atomicAdd(p.work, 1u);
+    __syncthreads();
+    const int mtile = s_next;
+    if (mtile >= ntiles) break;  // workgroup-uniform
+    dl_tile<KS, MT>(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, y_nchw, mtile);
+    __syncthreads();  // everyone is done with this tile's LDS and has read s_next
+  }
+  if (threadIdx.x == 0 && atomicAdd(p.work + 1, 1u) == gridDim.x - 1) {  // last workgroup out: every draw has happened
+    p.work[0] = 0u;
+    p.work[1] = 0u;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -759,7 +843,41 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_small_cout_kernel(const bf
 extern "C" int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
                                       int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
                                       float* y_nchw, v3d_stream_t stream) {
+  return v3d_conv2d_nhwc_bf16x3_bg(x_hi, x_lo, weight_image, bias, relu, B, H, W, Cin, Cout, ksize, y_hi, y_lo, y_nchw, nullptr, 0,
+                                   nullptr, nullptr, nullptr, stream);
+}
+
+// BEV occupancy bitmap, INVERTED (bit cleared = occupied) so that the 0xFF fill that resets the rest of a plan's per-frame
+// state also resets it: row (b, y) = ceil(W / 32) words, bit x % 32 of word x / 32.  From the site list of the last sparse
+// stage (rows (b, z, y, x); z is folded into the channels).
+__global__ __launch_bounds__(V3D_BLOCK) void bev_occupancy_kernel(const int4* __restrict__ coords, const int* __restrict__ n_ptr,
+                                                                  int cap, int H, int W, unsigned* __restrict__ occ) {
+  const int n = min(*n_ptr, cap), wpr = (W + 31) >> 5;
+  for (int i = blockIdx.x * V3D_BLOCK + threadIdx.x; i < n; i += gridDim.x * V3D_BLOCK) {
+    const int4 c = coords[i];
+    atomicAnd(occ + ((size_t)c.x * H + c.z) * wpr + (c.w >> 5), ~(1u << (c.w & 31)));
+  }
+}
+
+extern "C" size_t v3d_bev_occupancy_words(int B, int H, int W) { return (size_t)B * H * ((W + 31) >> 5); }
+
+extern "C" int v3d_bev_occupancy_bits(const int32_t* coords, const int32_t* n, int cap, int B, int H, int W, uint32_t* occ,
+                                      v3d_stream_t stream) {
+  if (!coords || !n || !occ || cap < 1 || B < 1 || H < 1 || W < 1) return V3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  V3D_CHECK_HIP(v3d_fill_async(occ, 0xFF, v3d_bev_occupancy_words(B, H, W) * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(bev_occupancy_kernel, dim3(std::min(v3d_ceil_div(cap, V3D_BLOCK), 1024)), dim3(V3D_BLOCK), 0, st,
+                     (const int4*)coords, n, cap, H, W, occ);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
+                                         int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
+                                         float* y_nchw, const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo,
+                                         uint32_t* work, v3d_stream_t stream) {
   if (!x_hi || !x_lo || !weight_image || B < 1 || H < 1 || W < 1 || Cout < 1) return V3D_EINVAL;
+  if (occ && (!bg_hi || !bg_lo || reach < 0 || reach > 64)) return V3D_EINVAL;
   if (Cin < DC_KC || Cin % DC_KC || (ksize != 1 && ksize != 3)) return V3D_EUNSUPPORTED;
   if ((y_hi == nullptr) != (y_lo == nullptr) || (!y_hi && !y_nchw)) return V3D_EINVAL;
   if (y_hi && (Cout % 8)) return V3D_EUNSUPPORTED;
@@ -768,6 +886,14 @@ extern "C" int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const 
   p.CoutPad = (Cout + DC_BN - 1) / DC_BN * DC_BN;
   p.M = B * H * W;
   p.cout_store = Cout;
+  // background skipping applies to the large-tile kernel writing split planes only (an fp32 NCHW consumer gets every
+  // pixel computed: the background planes hold the SPLIT value, not the fp32 one)
+  const bool skip = occ && y_hi && !y_nchw;
+  p.occ = skip ? occ : nullptr;
+  p.reach = reach;
+  p.bg_hi = (const bf16_t*)bg_hi;
+  p.bg_lo = (const bf16_t*)bg_lo;
+  p.work = nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (ksize == 1 && !y_hi && Cout <= 16 && (Cin == 128 || Cin == 256)) {  // the head: stream kernel
     const dim3 sgrid(v3d_ceil_div(v3d_ceil_div(p.M, 16), 4));
@@ -782,10 +908,25 @@ extern "C" int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const 
   }
   const bool large_ok = Cin >= 64 && H < 32768 && W < 65536 && W >= 16;  // (Cin % 32 == 0 checked above) else: the 64-pixel kernel
   if (large_ok && Cout > 32) {
-    dim3 lgrid(v3d_ceil_div(p.M, DL_BM), p.CoutPad / DC_BN);
-    auto kern = ksize == 3 ? conv2d_bf16x3_large_kernel<3> : conv2d_bf16x3_large_kernel<1>;
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, DL_SMEM));
-    hipLaunchKernelGGL(kern, lgrid, dim3(DL_THREADS), DL_SMEM, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+    // With background skipping (and a work counter) the tiles are 80 pixels instead of 144 and the grid is persistent, one
+    // workgroup per CU drawing tiles from the counter: see the kernel.  The LDS request is padded past half a CU's LDS so that
+    // two workgroups never share a CU.
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      V3D_CHECK_HIP(hipGetDevice(&dev));
+      V3D_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const bool persistent = p.occ && work && p.CoutPad == DC_BN;
+    const int mt = persistent ? 5 : 9;  // (in launch order the small tiles only add rounds: 33 vs 27 us on a full map)
+    const int tiles = v3d_ceil_div(p.M, mt * 16);
+    p.work = persistent ? work : nullptr;
+    dim3 lgrid(persistent ? std::min(tiles, n_cu) : tiles, p.CoutPad / DC_BN);
+    auto kern = mt == 9 ? (ksize == 3 ? conv2d_bf16x3_large_kernel<3, 9> : conv2d_bf16x3_large_kernel<1, 9>)
+                        : (ksize == 3 ? conv2d_bf16x3_large_kernel<3, 5> : conv2d_bf16x3_large_kernel<1, 5>);
+    const int smem = std::max(dl_smem(mt), 84 * 1024);
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    hipLaunchKernelGGL(kern, lgrid, dim3(DL_THREADS), smem, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
                        (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo, y_nchw);
     V3D_CHECK_LAUNCH();
     return V3D_OK;

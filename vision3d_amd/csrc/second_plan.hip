@@ -62,6 +62,7 @@ struct v3d_backbone {
   char* ff_begin = nullptr;     // arena region reset to 0xFF by one memset per forward
   size_t ff_bytes = 0;
   int out_channels = 0;
+  uint32_t* bev_occ = nullptr;  // (max_batch * H, ceil(W / 32)) inverted occupancy bits of the last stage (in the 0xFF region)
   struct PlanTrain* train = nullptr;  // training buffers, allocated by the first v3d_backbone_train_forward
 };
 
@@ -163,6 +164,10 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
     for (size_t i = 0; i < p->nbr.size(); i++)
       if (rbSparse[i]) p->nbr[i] = ar.take<int32_t>((size_t)rbK[i] * p->nbr_cap[i]);  // strided tables start as -1
     p->overflow = ar.take<int32_t>(p->layers.size() + 1);
+    {  // inverted BEV occupancy bitmap of the last stage (0xFF = nothing occupied): input of the background-skipping head
+      const PlanStage& sl = p->stages.back();
+      p->bev_occ = ar.take<uint32_t>(v3d_bev_occupancy_words(cfg->max_batch, sl.shape[1], sl.shape[2]));
+    }
     for (auto& L : p->layers)  // strided layers: per-layer count slots, -1 = "not published" at the start of a frame
       if (!L.d.subm) L.chunk_counts = ar.take<int>((size_t)((long long)p->stages[L.stage_in].cap * L.K / V3D_SCAN_CHUNK + 2));
     p->ff_bytes = (size_t)((ar.base + ar.off) - p->ff_begin);
@@ -339,7 +344,8 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
   }
   if (dense_hi || dense_lo) {
     PlanStage& sl = p->stages.back();
-    rc = v3d_densify_nhwc_split(feat, sl.coords, sl.n_dev, sl.cap, B, p->out_channels, sl.shape, dense_hi, dense_lo, st);
+    rc = v3d_i_densify_nhwc_split(feat, sl.coords, sl.n_dev, sl.cap, B, p->out_channels, sl.shape, dense_hi, dense_lo, p->bev_occ,
+                                  st);
     if (rc) return rc;
   }
   return V3D_OK;
@@ -409,6 +415,10 @@ extern "C" int v3d_backbone_tune_from_voxels(v3d_backbone* p, const int32_t* coo
   V3D_CHECK_HIP(hipStreamSynchronize(st));
   return v3d_backbone_tune(p);
 }
+
+// Inverted BEV occupancy bitmap of the LAST forward that produced split planes (v3d_backbone_forward2 / _forward_voxels): device
+// pointer into the plan's arena, (B * H, ceil(W / 32)) words; what v3d_conv2d_nhwc_bf16x3_bg takes as `occ`.
+extern "C" uint32_t* v3d_backbone_bev_occupancy(v3d_backbone* p) { return p ? p->bev_occ : nullptr; }
 
 extern "C" int32_t* v3d_backbone_occupancy(v3d_backbone* p) { return p ? p->occupancy : nullptr; }
 // flags[l] = layer l hit its active-site capacity; flags[n_layers] = any of them (one word for the caller's per-frame read)

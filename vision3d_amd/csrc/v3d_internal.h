@@ -46,3 +46,8 @@ int v3d_i_sparse_bn_relu_fwd(const float* x, int n, const int32_t* n_dev, int C,
 int v3d_i_sparse_bn_relu_bwd(const float* x, const float* dy, int n, const int32_t* n_dev, int C, const float* gamma,
                              const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dx,
                              float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t st);
+
+// dense_conv.hip: v3d_densify_nhwc_split that also clears the bits of the occupied pixels in an inverted BEV occupancy bitmap
+// (pre-filled with 0xFF by the caller): the input of the background-skipping dense head.
+int v3d_i_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
+                             const int32_t* spatial_shape_host, void* out_hi, void* out_lo, uint32_t* occ_inv, hipStream_t st);

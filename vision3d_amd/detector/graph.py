@@ -29,6 +29,7 @@ class GraphedSecond(object):
         cap_pts = 1 << max(14, (self.offsets[-1] - 1).bit_length())
         self.plan = model.backbone_plan(len(self.frame_sizes), cap_pts, slot)
         self.dense = model.dense_plan()
+        self.work = self.dense.new_work(dev) if model.skip_background else None  # this slot's tile counters (self-resetting)
         self.graph = None  # captured on the first call, after a warm-up on THAT frame (see _capture)
 
     def _capture(self):
@@ -52,7 +53,8 @@ class GraphedSecond(object):
     def _body(self):
         hi, lo = self.plan.forward_split(self.static_points, self.offsets)
         head = self.model.head
-        maps = self.dense.forward(hi, lo)
+        maps = self.dense.forward(hi, lo, occ=self.plan.bev_occupancy(len(self.offsets) - 1) if self.model.skip_background else None,
+                                  work=self.work)
         self.native = head.native_supported(len(self.frame_sizes), self.anchors.numel() // (7 * self.model.cfg.NUM_CLASSES))
         if self.native:
             return head.native_proposals(maps, self.anchors)

@@ -5,6 +5,8 @@
 vision3d_amd.core.Preprocessor (same keys as the reference's).  Parameter tree = the reference's
 (vfe | cnn.blocks.* | rpn.down_block.* / rpn.up_block.* | head.conv_cls / head.conv_reg).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -122,6 +124,9 @@ class RPN(nn.Module):
 
 
 class Second(nn.Module):
+    # native inference paths: RPN tiles far from every occupied BEV pixel are copied from the empty-map response instead of
+    # convolved (runtime.DenseHeadPlan.forward(occ=...)); the values are identical, False only for A/B measurements
+    skip_background = os.environ.get("V3D_SKIP_BACKGROUND", "1") != "0"
 
     def __init__(self, cfg):
         super().__init__()
@@ -160,7 +165,7 @@ class Second(nn.Module):
         cap_pts = 1 << max(14, (max(m, 1) - 1).bit_length())  # the plan's voxel capacity is min(points, B * MAX_VOXELS) >= M
         plan = self.backbone_plan(b, max(cap_pts, b * 16384))
         hi, lo = plan.forward_voxels_split(item["voxel_mean"], item["coordinates"], b)
-        return self.dense_plan().forward(hi, lo), plan
+        return self.dense_plan().forward(hi, lo, occ=plan.bev_occupancy(b) if self.skip_background else None), plan
 
     def forward(self, item):
         if self._native_item(item):
@@ -224,7 +229,7 @@ class Second(nn.Module):
         """raw points -> (B, n_anchor*(1+DOF), H, W) fp32: the [cls | reg] output of the fused 1x1 head."""
         plan, flat, offsets = self._plan_for(clouds)
         hi, lo = plan.forward_split(flat, offsets)
-        return self.dense_plan().forward(hi, lo)
+        return self.dense_plan().forward(hi, lo, occ=plan.bev_occupancy(len(clouds)) if self.skip_background else None)
 
     def graphed_inference(self, anchors, frame_sizes):
         """Capture raw points -> candidates+NMS as ONE HIP graph for a fixed batch geometry (frame_sizes = points
@@ -252,6 +257,8 @@ class Second(nn.Module):
         if proposals == "native":
             plan, flat, offsets = self._plan_for(clouds)
             hi, lo = plan.forward_split(flat, offsets)
-            return self.head.inference_native(self.dense_plan().forward(hi, lo), anchors, overflow_flag=plan.overflow_any())
+            occ = plan.bev_occupancy(len(clouds)) if self.skip_background else None
+            return self.head.inference_native(self.dense_plan().forward(hi, lo, occ=occ), anchors,
+                                              overflow_flag=plan.overflow_any())
         cls_map, reg_map = self.head_maps_from_points(clouds)
         return self.head.inference_from_maps(cls_map, reg_map, anchors)

@@ -195,6 +195,15 @@ class BackbonePlan(object):
             return self.forward_voxels_split(voxel_mean, coordinates, batch_size)
         return hi, lo
 
+    def bev_occupancy(self, batch_size):
+        """(B * H, ceil(W / 32)) int32 device view of the plan's BEV occupancy bitmap for the LAST forward_split /
+        forward_voxels_split: one bit per BEV pixel, inverted (0 = occupied).  Reset by the plan's per-frame fill and written
+        by its densify kernel (no extra launch); feeds the background-skipping dense head (DenseHeadPlan.forward(occ=...)).
+        Aliases plan memory: valid until the next forward."""
+        d, h, w = self.out_shape
+        ptr = L.lib().v3d_backbone_bev_occupancy(self._handle)
+        return _view(ptr, (int(batch_size) * h, (w + 31) // 32), torch.int32, self.device)
+
     # ---- training: the sparse half of a train step, one native call each way (csrc/second_plan.hip, "Training plan")
     def train_parameters(self):
         """[w0, gamma0, beta0, w1, ...]: the tensors the training plan differentiates, in the order of `train_forward`'s
@@ -349,8 +358,10 @@ def split_planes_like(b, h, w, c, device):
     return both[0], both[1]
 
 
-def conv2d_split(x_hi, x_lo, image, bias, relu, cin, cout, ksize, out_split=True, out_nchw=False):
-    """One bf16x3 convolution on split NHWC planes; returns (y_hi, y_lo) and/or fp32 (B,cout,H,W)."""
+def conv2d_split(x_hi, x_lo, image, bias, relu, cin, cout, ksize, out_split=True, out_nchw=False, occ=None, reach=0, bg=None, work=None):
+    """One bf16x3 convolution on split NHWC planes; returns (y_hi, y_lo) and/or fp32 (B,cout,H,W).
+    occ / reach / bg = (bg_hi, bg_lo) [/ work: 2 zeroed int32 of the caller's, see the header]: background skipping
+    (v3d_conv2d_nhwc_bf16x3_bg), same values."""
     b, h, w, c = x_hi.shape
     assert c == cin
     dev = x_hi.device
@@ -360,9 +371,15 @@ def conv2d_split(x_hi, x_lo, image, bias, relu, cin, cout, ksize, out_split=True
     if out_nchw:
         y = torch.empty((b, cout, h, w), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        L.check(L.lib().v3d_conv2d_nhwc_bf16x3(L.ptr(x_hi), L.ptr(x_lo), L.ptr(image), L.ptr(bias), int(bool(relu)), b, h, w,
-                                               cin, cout, ksize, L.ptr(y_hi), L.ptr(y_lo), L.ptr(y), L.stream_ptr()),
-                "conv2d_nhwc_bf16x3")
+        if occ is not None and bg is not None:
+            L.check(L.lib().v3d_conv2d_nhwc_bf16x3_bg(L.ptr(x_hi), L.ptr(x_lo), L.ptr(image), L.ptr(bias), int(bool(relu)), b, h,
+                                                      w, cin, cout, ksize, L.ptr(y_hi), L.ptr(y_lo), L.ptr(y), L.ptr(occ),
+                                                      int(reach), L.ptr(bg[0]), L.ptr(bg[1]), L.ptr(work), L.stream_ptr()),
+                    "conv2d_nhwc_bf16x3_bg")
+        else:
+            L.check(L.lib().v3d_conv2d_nhwc_bf16x3(L.ptr(x_hi), L.ptr(x_lo), L.ptr(image), L.ptr(bias), int(bool(relu)), b, h, w,
+                                                   cin, cout, ksize, L.ptr(y_hi), L.ptr(y_lo), L.ptr(y), L.stream_ptr()),
+                    "conv2d_nhwc_bf16x3")
     return (y_hi, y_lo), y
 
 
@@ -396,6 +413,7 @@ class DenseHeadPlan(object):
         self.rpn, self.head = rpn, head
         self._stamp = None
         self.layers = []
+        self._background = {}
 
     def _pairs(self):
         mods = list(self.rpn.down_block) + list(self.rpn.up_block)
@@ -427,15 +445,48 @@ class DenseHeadPlan(object):
             bias = torch.cat((self.head.conv_cls.bias, self.head.conv_reg.bias), 0).float().contiguous()
             layers.append(dict(img=pack_conv_weight(w), bias=bias, relu=False, cin=w.shape[1], cout=w.shape[0], k=1))
         self.layers, self._stamp = layers, stamp
+        self._background = {}  # responses to an empty map belong to the old weights
 
-    def forward(self, x_hi, x_lo, want_features=False):
-        """split BEV planes -> fp32 head maps (B, n_cls*n_yaw*(1+DOF), H, W) [+ fp32 RPN features]."""
+    def new_work(self, device):
+        """Zeroed tile-counter scratch for `forward(..., work=...)`: keep one per stream / captured graph."""
         self.sync_weights()
+        return torch.zeros(2 * len(self.layers), dtype=torch.int32, device=device)
+
+    def background(self, h, w, device):
+        """Per RPN layer: its output on an EMPTY (all-zero) BEV map of one image, as split planes -- what every pixel far
+        enough from all occupied pixels evaluates to, borders included (`forward(..., occ=...)`).  Computed once per weight
+        set and map size by the same kernels."""
+        key = (int(h), int(w), str(device))
+        if key not in self._background:
+            x_hi, x_lo = split_planes_like(1, h, w, self.layers[0]["cin"], device)
+            x_hi.zero_()
+            x_lo.zero_()
+            planes = []
+            for ly in self.layers[:-1]:
+                (x_hi, x_lo), _ = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"])
+                planes.append((x_hi, x_lo))
+            self._background[key] = planes
+        return self._background[key]
+
+    def forward(self, x_hi, x_lo, want_features=False, occ=None, work=None):
+        """split BEV planes -> fp32 head maps (B, n_cls*n_yaw*(1+DOF), H, W) [+ fp32 RPN features].
+        occ: BackbonePlan.bev_occupancy() of the same frame -- tiles of the RPN layers whose receptive field holds no occupied
+        BEV pixel are copied from the empty-map response instead of convolved (identical values; a sparse scene leaves more
+        than half of the map in that state).
+        work: (2 * RPN layers,) zeroed int32 scratch owned by the caller, one per stream in flight (`new_work()`): the tile
+        counters of the persistent skipping kernels, which leave them zeroed.  None: allocated (one fill) per call."""
+        self.sync_weights()
+        if occ is not None and work is None:
+            work = self.new_work(x_hi.device)
         feats = None
+        bg = self.background(x_hi.shape[1], x_hi.shape[2], x_hi.device) if occ is not None else None
+        reach = 0
         for i, ly in enumerate(self.layers[:-1]):
             last = i == len(self.layers) - 2
+            reach += ly["k"] // 2
             (x_hi, x_lo), f = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"],
-                                           out_split=True, out_nchw=want_features and last)
+                                           out_split=True, out_nchw=want_features and last, occ=occ, reach=reach,
+                                           bg=None if bg is None else bg[i], work=None if work is None else work[2 * i:2 * i + 2])
             feats = f if last else feats
         ly = self.layers[-1]
         _, maps = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"],
