@@ -75,6 +75,13 @@ int v3d_proposals(const float* head_maps, const float* anchors, int B, int n_cls
                   const float* score_thresh_host, float iou_threshold, float* out_boxes, int64_t* out_batch_idx,
                   int64_t* out_class_idx, float* out_scores, int32_t* n_out, void* workspace, size_t workspace_bytes,
                   v3d_stream_t stream);
+/* Same, and the last kernel also copies one device word into n_out[1] (n_out then has TWO words): the backbone plan's
+ * capacity-overflow summary (v3d_backbone_overflow_flags()[n_layers]), so that the caller's single host read of the frame --
+ * the proposal count -- brings the "this frame dropped rows" verdict with it. */
+int v3d_proposals_flag(const float* head_maps, const float* anchors, int B, int n_cls, int n_yaw, int H, int W, int topk,
+                       const float* score_thresh_host, float iou_threshold, float* out_boxes, int64_t* out_batch_idx,
+                       int64_t* out_class_idx, float* out_scores, int32_t* n_out /*[2]*/, const int32_t* aux_flag,
+                       void* workspace, size_t workspace_bytes, v3d_stream_t stream);
 
 /* ---- Training-mode BatchNorm1d (+ ReLU) over sparse features (n, C), C a power of two in [4, 256].
  * Replaces nn.BatchNorm1d(eps, momentum) + nn.ReLU on SparseConvTensor.features (detector/sparse_cnn.py:15-30) in

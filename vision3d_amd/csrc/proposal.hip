@@ -334,7 +334,7 @@ __global__ __launch_bounds__(PROP_THREADS) void prop_finalize_kernel(const long 
                                                                      long long* __restrict__ out_batch,
                                                                      long long* __restrict__ out_class,
                                                                      float* __restrict__ out_scores,
-                                                                     int* __restrict__ n_out) {
+                                                                     int* __restrict__ n_out, const int* __restrict__ aux_flag) {
   __shared__ int wave_cnt[PROP_WAVES];
   __shared__ int base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -370,7 +370,10 @@ __global__ __launch_bounds__(PROP_THREADS) void prop_finalize_kernel(const long 
     }
     __syncthreads();
   }
-  if (tid == 0) *n_out = base;
+  if (tid == 0) {
+    n_out[0] = base;
+    if (aux_flag) n_out[1] = *aux_flag;  // rides in the caller's one host read of the frame (see v3d_proposals_flag)
+  }
 }
 
 static size_t prop_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -387,6 +390,14 @@ extern "C" int v3d_proposals(const float* head_maps, const float* anchors, int B
                              int topk, const float* score_thresh_host, float iou_threshold, float* out_boxes,
                              int64_t* out_batch_idx, int64_t* out_class_idx, float* out_scores, int32_t* n_out,
                              void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
+  return v3d_proposals_flag(head_maps, anchors, B, n_cls, n_yaw, H, W, topk, score_thresh_host, iou_threshold, out_boxes,
+                            out_batch_idx, out_class_idx, out_scores, n_out, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int v3d_proposals_flag(const float* head_maps, const float* anchors, int B, int n_cls, int n_yaw, int H, int W,
+                                  int topk, const float* score_thresh_host, float iou_threshold, float* out_boxes,
+                                  int64_t* out_batch_idx, int64_t* out_class_idx, float* out_scores, int32_t* n_out,
+                                  const int32_t* aux_flag, void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!head_maps || !anchors || !score_thresh_host || !out_boxes || !out_batch_idx || !out_class_idx || !out_scores ||
       !n_out || !workspace)
@@ -442,7 +453,7 @@ extern "C" int v3d_proposals(const float* head_maps, const float* anchors, int B
   }
   (void)bev;
   hipLaunchKernelGGL(prop_finalize_kernel, dim3(1), dim3(PROP_THREADS), 0, st, keep, n_keep, g, boxes, bidx, cidx, cand_score,
-                     out_boxes, (long long*)out_batch_idx, (long long*)out_class_idx, out_scores, n_out);
+                     out_boxes, (long long*)out_batch_idx, (long long*)out_class_idx, out_scores, n_out, aux_flag);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }

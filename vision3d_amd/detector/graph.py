@@ -57,7 +57,7 @@ class GraphedSecond(object):
                                   work=self.work)
         self.native = head.native_supported(len(self.frame_sizes), self.anchors.numel() // (7 * self.model.cfg.NUM_CLASSES))
         if self.native:
-            return head.native_proposals(maps, self.anchors)
+            return head.native_proposals(maps, self.anchors, self.plan.overflow_any())
         return head.proposals_padded(*head.maps_from_fused(maps), self.anchors)
 
     def load(self, clouds):
@@ -119,6 +119,10 @@ class PipelinedSecond(object):
         run.submit(clouds)        # copy + graph launch on the next slot's stream, returns immediately
         run.collect()             # oldest frame in flight: waits for ITS stream only, -> (boxes, batch, class, scores)
 
+    There is one slot MORE than frames in flight: the tensors `collect()` returns are views of the collected slot's static
+    output buffers, and that slot is the last one the ring hands out again -- they stay valid until the NEXT collect()
+    (no per-frame clone kernels; `collect(copy=True)` clones for callers that keep results longer).
+
     Which streams: two HIP streams only overlap if their hardware queues sit on different command-processor pipes,
     and the runtime gives no handle on that (measured on one MI355X with 2 / 3 / 4 streams taken in creation order
     and GPU_MAX_HW_QUEUES = 4, 8, 16: 434 / 530 / 445, 468 / 347 / 523, 483 / 644 / 369 us per frame -- luck of the
@@ -132,11 +136,11 @@ class PipelinedSecond(object):
 
     def __init__(self, model, anchors, frame_sizes, depth=2, autotune=False):
         dev = next(model.parameters()).device
-        self.slots = [GraphedSecond(model, anchors, frame_sizes, slot=i) for i in range(depth)]
+        self.slots = [GraphedSecond(model, anchors, frame_sizes, slot=i) for i in range(depth + 1)]
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
         self.autotune, self.tuned = bool(autotune), None
-        self.pending = []  # slot indices in submission order
-        self.next_slot = 0
+        self.pending = []  # (slot, stream index) in submission order
+        self.next_slot = self.next_stream = 0
 
     @property
     def depth(self):
@@ -188,31 +192,34 @@ class PipelinedSecond(object):
             self._launch(i, cands[0], clouds)
             self._finish(i, cands[0])
         chosen, log = choose_streams(lambda ids: self._time_streams([cands[x] for x in ids], clouds, self.TUNE_FRAMES + len(ids) - 2),
-                                     len(cands), len(self.slots))
+                                     len(cands), len(self.slots) - 1)
         self.streams = [cands[x] for x in chosen]
         self.tuned = dict(depth=len(chosen), us_per_frame={k: round(v * 1e6, 1) for k, v in log.items()})
-        self.pending, self.next_slot = [], 0
+        self.pending, self.next_slot, self.next_stream = [], 0, 0
         return self.tuned
 
     # ---- the pipeline ----------------------------------------------------------------------------------------
     def submit(self, clouds):
         if self.autotune and self.tuned is None:
             self.tune(clouds)
-        i = self.next_slot
-        assert i not in self.pending, "collect() the oldest frame before reusing its slot"
-        self._launch(i, self.streams[i], clouds)
-        self.pending.append(i)
-        self.next_slot = (i + 1) % self.depth
+        assert len(self.pending) < self.depth, "collect() the oldest frame before submitting another one"
+        i, j = self.next_slot, self.next_stream
+        self._launch(i, self.streams[j], clouds)
+        self.pending.append((i, j))
+        self.next_slot = (i + 1) % (self.depth + 1)  # depth + 1 slots in the ring (tuning may have shortened the stream list)
+        self.next_stream = (j + 1) % self.depth
 
-    def collect(self):
-        i = self.pending.pop(0)
-        out = self._finish(i, self.streams[i])
+    def collect(self, copy=False):
+        """Oldest frame in flight -> [boxes, batch_idx, class_idx, scores].  The tensors alias that slot's static buffers and
+        stay valid until the NEXT collect() (the ring has one slot more than frames in flight); copy=True clones them."""
+        i, j = self.pending.pop(0)
+        out = self._finish(i, self.streams[j])  # synchronises the slot's stream: the data is complete for any consumer
+        if not copy:
+            return out
         consumer = torch.cuda.current_stream()
-        with torch.cuda.stream(self.streams[i]):
-            res = [t.clone() for t in out]  # the slot's static buffers are overwritten by its next frame
-        # the clones were produced on the slot's stream: order the caller's stream behind them and tell the caching allocator
-        # that the blocks are in use there (they were allocated on the slot's stream)
-        consumer.wait_stream(self.streams[i])
+        with torch.cuda.stream(self.streams[j]):
+            res = [t.clone() for t in out]
+        consumer.wait_stream(self.streams[j])
         for t in res:
             t.record_stream(consumer)
         return res

@@ -106,10 +106,12 @@ class ProposalLayer(nn.Module):
             ok = ok and anchors_per_class <= 8192 * min(40, 4096 // self.TOPK)
         return ok
 
-    def native_proposals(self, head_maps, anchors):
+    def native_proposals(self, head_maps, anchors, overflow_flag=None):
         """The whole stage after the 1x1 heads in libvision3d_hip.so (csrc/proposal.hip: 8 launches, no host
         sync): head_maps (B, n_anchor*(1+DOF), H, W) = [cls | reg] channels of the fused head.  Returns padded
-        (boxes (N,7), batch_idx, class_idx, scores, n_out (1,) int32 on the device); capturable in a HIP graph."""
+        (boxes (N,7), batch_idx, class_idx, scores, n_out int32 on the device); capturable in a HIP graph.
+        overflow_flag (a plan's (1,) device word): copied into n_out[1] by the last kernel, so that `finalize_native` reads
+        the count and the plan's capacity verdict with ONE 8-byte copy."""
         cfg = self.cfg
         L.require_gpu("proposals", head_maps, anchors)
         maps, anc = L.as_f32("proposals", head_maps), L.as_f32("proposals", anchors)
@@ -123,14 +125,14 @@ class ProposalLayer(nn.Module):
         batch_idx = torch.empty((N,), dtype=torch.int64, device=dev)
         class_idx = torch.empty((N,), dtype=torch.int64, device=dev)
         scores = torch.empty((N,), dtype=torch.float32, device=dev)
-        n_out = torch.empty((1,), dtype=torch.int32, device=dev)  # always written by the last kernel
+        n_out = torch.empty((1 if overflow_flag is None else 2,), dtype=torch.int32, device=dev)  # written by the last kernel
         lib = L.lib()
         ws = L.workspace(lib.v3d_proposals_workspace(B, n_cls, self.TOPK), dev)
         thresh = L.host_f32([a["score_thresh"] for a in cfg.ANCHORS[:n_cls]])
         with torch.cuda.device(dev):
-            L.check(lib.v3d_proposals(L.ptr(maps), L.ptr(anc), B, n_cls, n_yaw, H, W, self.TOPK, thresh, 0.01, L.ptr(boxes),
-                                      L.ptr(batch_idx), L.ptr(class_idx), L.ptr(scores), L.ptr(n_out), L.ptr(ws), ws.numel(),
-                                      L.stream_ptr()), "proposals")
+            L.check(lib.v3d_proposals_flag(L.ptr(maps), L.ptr(anc), B, n_cls, n_yaw, H, W, self.TOPK, thresh, 0.01, L.ptr(boxes),
+                                           L.ptr(batch_idx), L.ptr(class_idx), L.ptr(scores), L.ptr(n_out), L.ptr(overflow_flag),
+                                           L.ptr(ws), ws.numel(), L.stream_ptr()), "proposals")
         return boxes, batch_idx, class_idx, scores, n_out
 
     @staticmethod
@@ -138,12 +140,15 @@ class ProposalLayer(nn.Module):
         """The one host read of the frame (the reference synchronises inside its NMS): the number of proposals and, when
         the frame came through a BackbonePlan, that plan's capacity-overflow word in the same synchronisation -- a stage
         that hit its active-site capacity has dropped rows, so the BEV map is wrong and the frame must not be returned."""
-        if overflow_flag is None:
+        if overflow_flag is None and n_out.numel() == 1:
             n = int(n_out.item())
         else:
             host = _pinned_pair(n_out.device)
-            host[0:1].copy_(n_out, non_blocking=True)
-            host[1:2].copy_(overflow_flag, non_blocking=True)
+            if n_out.numel() == 2:  # the proposal stage already put the plan's verdict next to the count: one copy
+                host.copy_(n_out, non_blocking=True)
+            else:
+                host[0:1].copy_(n_out, non_blocking=True)
+                host[1:2].copy_(overflow_flag, non_blocking=True)
             torch.cuda.current_stream(n_out.device).synchronize()
             n, ovf = int(host[0]), int(host[1])
             if ovf > 0:
@@ -158,7 +163,7 @@ class ProposalLayer(nn.Module):
             if overflow_flag is not None and int(overflow_flag.item()) > 0:
                 raise RuntimeError("sparse backbone: a stage exceeded its active-site capacity (rows were dropped)")
             return out
-        return self.finalize_native(*self.native_proposals(head_maps, anchors), overflow_flag=overflow_flag)
+        return self.finalize_native(*self.native_proposals(head_maps, anchors, overflow_flag))
 
     def finalize(self, boxes, batch_idx, class_idx, scores, keep, n_keep):
         keep = keep[: int(n_keep.item())]
