@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvision3d_hip.so")
+# V3D_HIP_LIB: another build of the SAME library (A/B measurements of kernel changes on one box); never a fallback
+LIB_PATH = os.environ.get("V3D_HIP_LIB") or os.path.join(_HERE, "lib", "libvision3d_hip.so")
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 

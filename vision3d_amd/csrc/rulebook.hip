@@ -119,53 +119,32 @@ __device__ __forceinline__ unsigned rb_first_flags(const int* __restrict__ cand_
   return flags;
 }
 
-// count + scan in ONE launch (the highest-index block scans the published counts, v3d_common.h): chunk_counts
-// (-1 at launch) become exclusive offsets, the total is clipped to cap_out
-__global__ __launch_bounds__(V3D_BLOCK) void rb_count_scan_kernel(const int* __restrict__ cand_slot,
-                                                                  const unsigned* __restrict__ first_ticket,
-                                                                  const int* __restrict__ n_ptr, int cap_in, int K,
-                                                                  int* __restrict__ chunk_counts, int n_chunks, int cap_out,
-                                                                  int* __restrict__ n_out, int* __restrict__ overflow,
-                                                                  int* __restrict__ overflow_any) {
-  __shared__ int lds[8];
-  const long long nt = (long long)min(*n_ptr, cap_in) * K;
-  const long long base = (long long)blockIdx.x * V3D_SCAN_CHUNK;
-  int cnt = 0;
-  if (base < nt) {  // block-uniform.  Thread = RB_PER_THREAD consecutive tickets (two 16-byte loads), ONE block reduction
-    const unsigned flags = rb_first_flags(cand_slot, first_ticket, base + (long long)threadIdx.x * RB_PER_THREAD, nt);
-    int mine = __popc(flags);
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = mine;
-    __syncthreads();
-    cnt = lds[0] + lds[1] + lds[2] + lds[3];
-  }
-  if (threadIdx.x == 0) v3d_publish_count(chunk_counts + blockIdx.x, cnt);
-  if (blockIdx.x != gridDim.x - 1) return;
-  const int total = v3d_block_exclusive_scan_global(chunk_counts, n_chunks, lds);
-  if (threadIdx.x == 0) {
-    if (total > cap_out) {
-      atomicExch(overflow, 1);
-      if (overflow_any) atomicExch(overflow_any, 1);
-    }
-    *n_out = min(total, cap_out);
-  }
-}
-
-__global__ __launch_bounds__(V3D_BLOCK) void rb_emit_kernel(const int4* __restrict__ coords,
-                                                            const int* __restrict__ n_ptr, int cap_in, const RbGeom g,
-                                                            const int* __restrict__ cand_slot,
-                                                            const unsigned* __restrict__ first_ticket,
-                                                            const int* __restrict__ chunk_offsets, int cap_out,
-                                                            int4* __restrict__ coords_out, int* __restrict__ vals) {
+// count + scan + emit in ONE launch: a single-pass chained scan (decoupled look-back) over 2 048-ticket chunks.
+// Every block counts its first-toucher tickets and PUBLISHES the count at once (agent-scope atomic store into a slot that reads
+// -1 at launch: part of the frame's 0xFF fill, no fence needed); wave 0 then walks back over its predecessors, 64 at a time,
+// adding their counts until it meets one whose INCLUSIVE prefix is already published, publishes its own inclusive prefix and
+// the block emits its output rows at prefix + local rank.  Workgroups are dispatched in index order and publish their count
+// before they wait for anything, so every wait is on a block that is already running or done.  The highest-index block adds
+// up the total (clipped to cap_out).  This replaces a count+scan launch and an emit launch (~7 us each in the frame: the
+// rulebook kernels are launch-latency, not work).
+//   chunk_counts[n_chunks] | chunk_incl[n_chunks], all -1 at launch.
+__global__ __launch_bounds__(V3D_BLOCK) void rb_scan_emit_kernel(const int4* __restrict__ coords, const int* __restrict__ n_ptr,
+                                                                 int cap_in, const RbGeom g, const int* __restrict__ cand_slot,
+                                                                 const unsigned* __restrict__ first_ticket,
+                                                                 int* __restrict__ chunk_counts, int* __restrict__ chunk_incl,
+                                                                 int cap_out, int4* __restrict__ coords_out,
+                                                                 int* __restrict__ vals, int* __restrict__ n_out,
+                                                                 int* __restrict__ overflow, int* __restrict__ overflow_any) {
   __shared__ int lds[4];
+  __shared__ int s_prefix;
   const long long nt = (long long)min(*n_ptr, cap_in) * g.K;
-  const long long base = (long long)blockIdx.x * V3D_SCAN_CHUNK;
-  if (base >= nt) return;  // block-uniform
-  // thread = 8 consecutive tickets: ranks follow from ONE block-wide exclusive scan of the per-thread counts
-  const long long t0 = base + (long long)threadIdx.x * RB_PER_THREAD;
-  const unsigned flags = rb_first_flags(cand_slot, first_ticket, t0, nt);
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long long base = (long long)b * V3D_SCAN_CHUNK;
+  const bool live = base < nt, last = b == (int)gridDim.x - 1;
+  if (!live && !last) return;  // nothing to count, and nobody looks at a dead block's slots
+  const long long t0 = base + (long long)tid * RB_PER_THREAD;
+  const unsigned flags = live ? rb_first_flags(cand_slot, first_ticket, t0, nt) : 0u;
   const int mine = __popc(flags);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int incl = mine;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -174,7 +153,43 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_emit_kernel(const int4* __restri
   }
   if (lane == 63) lds[w] = incl;
   __syncthreads();
-  int rank = chunk_offsets[blockIdx.x] + incl - mine;
+  const int cnt = lds[0] + lds[1] + lds[2] + lds[3];
+  if (tid == 0 && live) v3d_publish_count(chunk_counts + b, cnt);
+  if (w == 0) {
+    const int n_live = (int)((nt + V3D_SCAN_CHUNK - 1) / V3D_SCAN_CHUNK);
+    int prefix = 0;
+    for (int pos = min(b, n_live) - 1; pos >= 0; pos -= 64) {
+      const int idx = pos - lane;
+      int c = 0, inc = -1;
+      if (idx >= 0) {
+        c = v3d_wait_count(chunk_counts + idx);
+        inc = v3d_load_coherent(chunk_incl + idx);
+      }
+      const unsigned long long ready = __ballot(inc >= 0);
+      const int first = ready ? __ffsll((long long)ready) - 1 : 64;  // nearest predecessor whose inclusive prefix is known
+      int part = lane < first ? c : (lane == first ? inc : 0);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+      prefix += part;
+      if (ready) break;
+    }
+    if (lane == 0) {
+      s_prefix = prefix;
+      if (live) v3d_publish_count(chunk_incl + b, prefix + cnt);
+    }
+  }
+  __syncthreads();
+  const int prefix = s_prefix;
+  if (last && tid == 0) {
+    const int total = prefix + cnt;
+    if (total > cap_out) {
+      atomicExch(overflow, 1);
+      if (overflow_any) atomicExch(overflow_any, 1);
+    }
+    *n_out = min(total, cap_out);
+  }
+  if (!live) return;
+  int rank = prefix + incl - mine;
   for (int i = 0; i < w; i++) rank += lds[i];
   unsigned f = flags;
   while (f) {
@@ -283,7 +298,7 @@ int v3d_i_subm_nbr(const int32_t* coords, const int32_t* n, int cap, const int32
 }
 
 // scratch: first_ticket[out.hcap] (must directly follow out.keys and precede out.vals in memory so that ONE
-// memset resets keys|first_ticket|vals), cand_slot[cap_in*K], chunk_counts[ceil(cap_in*K/2048)].
+// memset resets keys|first_ticket|vals), cand_slot[cap_in*K], chunk_counts[2 * ceil(cap_in*K/2048)] (counts | inclusive prefixes).
 int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap_in, const int32_t* shape,
                           const int32_t* ksize, const int32_t* stride, const int32_t* padding, int32_t* coords_out,
                           int32_t* n_out, int cap_out, int32_t* nbr, int32_t* overflow, V3dRbHash out,
@@ -303,16 +318,15 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
     V3D_CHECK_HIP(v3d_fill_async(out.keys, 0xFF, (size_t)out.hcap * 16, st));
     V3D_CHECK_HIP(v3d_fill_async(nbr, 0xFF, (size_t)g.K * cap_out * 4, st));
     V3D_CHECK_HIP(v3d_fill_async(overflow, 0, 4, st));
-    V3D_CHECK_HIP(v3d_fill_async(chunk_counts, 0xFF, (size_t)chunks * 4, st));  // -1 = "count not published yet"
+    V3D_CHECK_HIP(v3d_fill_async(chunk_counts, 0xFF, (size_t)chunks * 8, st));  // counts | inclusive prefixes: -1 = "not published yet"
   }
   V3dHash h = v3d_make_hash(out.keys, out.hcap);
   const int tblocks = min(v3d_ceil_div(tickets, V3D_BLOCK), 4096);
   hipLaunchKernelGGL(rb_candidates_kernel, dim3(tblocks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in,
                      g, h, first_ticket, cand_slot, overflow, overflow_any);
-  hipLaunchKernelGGL(rb_count_scan_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, cand_slot, first_ticket, n_in, cap_in, g.K,
-                     chunk_counts, chunks, cap_out, n_out, overflow, overflow_any);
-  hipLaunchKernelGGL(rb_emit_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in, g,
-                     cand_slot, first_ticket, chunk_counts, cap_out, (int4*)coords_out, out.vals);
+  hipLaunchKernelGGL(rb_scan_emit_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in, g,
+                     cand_slot, first_ticket, chunk_counts, chunk_counts + chunks, cap_out, (int4*)coords_out, out.vals, n_out,
+                     overflow, overflow_any);
   RbGeom sg = g;
   int subm_blocks = 0;
   if (next_subm_ksize && next_subm_nbr) {
@@ -333,7 +347,7 @@ extern "C" size_t v3d_rulebook_workspace(int cap_in, int cap_out, int K) {
   const size_t hcap = v3d_hash_capacity((long long)(ci > co ? ci : co));
   const size_t tickets = ci * (size_t)(K > 0 ? K : 1);
   const size_t chunks = (tickets + V3D_SCAN_CHUNK - 1) / V3D_SCAN_CHUNK;
-  return v3d_align(hcap * 8) + 2 * v3d_align(hcap * 4) + v3d_align(tickets * 4) + v3d_align(chunks * 4) + 256;
+  return v3d_align(hcap * 8) + 2 * v3d_align(hcap * 4) + v3d_align(tickets * 4) + v3d_align(chunks * 8) + 256;
 }
 
 extern "C" int v3d_rulebook_subm(const int32_t* coords, const int32_t* n, int cap, const int32_t* spatial_shape_host,
@@ -375,7 +389,7 @@ extern "C" int v3d_rulebook_sparse(const int32_t* coords_in, const int32_t* n_in
   h.vals = ar.take<int>(hcap);
   h.hcap = hcap;
   int* cand_slot = ar.take<int>((size_t)tickets);
-  int* chunk_counts = ar.take<int>(chunks);
+  int* chunk_counts = ar.take<int>((size_t)2 * chunks);
   if (!ar.ok()) return V3D_EWORKSPACE;
   return v3d_i_sparse_rulebook(coords_in, n_in, cap_in, spatial_shape_host, ksize_host, stride_host, padding_host,
                                coords_out, n_out, cap_out, nbr, overflow, h, first_ticket, cand_slot, chunk_counts,
