@@ -3,22 +3,26 @@
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = one pass of the hot path over one batch (bs=1/GPU, configs[1]): device voxelizer + VFE ->
-14-layer sparse 3-D conv backbone -> .dense() BEV -> dense RPN (MFMA) -> proposal stage (top-k, decode, rotated
-NMS, score cut), all hand-written HIP, replayed as one HIP graph (~55 kernels) with a single 4-byte host read.  By default several frames are in flight per
-GPU (one graph, stream and plan arena each: the launch-latency-bound sparse half of one frame overlaps the MFMA-bound dense
-half of the others; up to 4, streams and depth picked by measurement before the warm-up -- config.pipeline_tuning); every step
-submits one frame and the timed region completes exactly K of them.  The same
-graph run one frame at a time is reported as single_frame_ms / frames_per_s_one_at_a_time.  The cloud is resident in HBM before the timed region.  Frames are independent, so N GPUs run N
-replicas on different frames with no data-path collective (weak scaling); the only communication is the
-timing barrier / max-reduce.  Rank 0 prints ONE JSON line.
+One step = one pass of the hot path over one batch (bs=1/GPU, configs[1]): device voxelizer + VFE -> 14-layer sparse 3-D conv
+backbone -> .dense() BEV -> dense RPN (MFMA, background tiles skipped) -> proposal stage (top-k, decode, rotated NMS, score
+cut), all hand-written HIP, replayed as one HIP graph (49 kernels) with a single 8-byte host read (proposal count + the plan's
+capacity-overflow word).  The timed loop cycles through --stream (default 8) DIFFERENT clouds per rank, resident in HBM before
+the timed region.  By default several frames are in flight per GPU (one graph and plan arena per slot, one slot more than
+frames in flight; up to 4, streams and depth picked by measurement before the warm-up -- config.pipeline_tuning); every step
+submits one frame and the timed region completes exactly K of them.  The same graph run one frame at a time is reported as
+single_frame_ms / frames_per_s_one_at_a_time.  Frames are independent, so N GPUs run N replicas on different frames with no
+data-path collective (weak scaling); the only communication is the timing barrier / max-reduce.  Rank 0 prints ONE JSON line.
+Other lines of BASELINE.json: --workload waymo (configs[4]), --mode train (configs[2]), --mode pvrcnn (configs[3]).
 
 Extra objects on that line:
-  roofline      the dominant kernel (spconv_fwd_rows_ring<64,64>, the 3x3x3 64->64 sparse conv: 7 launches/frame): algorithmic bytes
-                A_min = 4*(N_in*Cin + N_out*Cout + K*Cin*Cout) + 8*R per launch divided
-                by its average duration measured with HIP events on the launch stream, vs 8 TB/s.
-  cpu_baseline  oracle/ (scalar C sparse path + torch CPU dense path, 1 thread) timed on the host on a
-                bounded sample of the same workload -- N=1, rank 0 only.  Baseline only.
+  roofline        the dominant sparse kernel (KITTI: spconv_fwd_rows_ring<64,64>, 7 launches/frame; Waymo:
+                  spconv_fwd_rows_big<64,64>): algorithmic bytes A_min = 4*(N_in*Cin + N_out*Cout + K*Cin*Cout) + 8*R per launch
+                   divided by its average duration measured with HIP events over graph-captured repeats on the launch
+                  stream, vs 8 TB/s; `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/).
+  roofline_dense  the 3x3 RPN convolution against the bf16 MFMA peak (every tile convolved, random input).
+  cpu_baseline    oracle/ (scalar C sparse path + torch CPU dense path) timed on the host on a bounded sample of the same
+                  workload -- N=1, rank 0 only: 1 thread, and `all_cores` = the same frames on up to 32 single-thread workers;
+                  `cpu_model`, `host_cores` name the box.  Baseline only.
 """
 import argparse
 import json
@@ -487,10 +491,13 @@ def main():
         torch.cuda.synchronize()
         t_dense = e0.elapsed_time(e1) * 1e-3 / 20
         fl = 2.0 * args.batch * ny * nx * cdim * cdim * 9
-        roofline_dense = dict(bound="mfma", kernel="conv2d_bf16x3_large_kernel<3>", launches_per_frame=6, flops_per_launch=fl,
+        roofline_dense = dict(bound="mfma", kernel="conv2d_bf16x3_large_kernel<3,9>", launches_per_frame=6, flops_per_launch=fl,
                               avg_us=t_dense * 1e6, achieved=fl / t_dense / 1e12, issued=3 * fl / t_dense / 1e12, peak=2500.0,
                               unit="TFLOP/s", frac=fl / t_dense / 1e12 / 2500.0, frac_issued=3 * fl / t_dense / 1e12 / 2500.0,
-                              note="peak = dense bf16 MFMA; 3 bf16 terms per fp32-class product")
+                              note="every tile convolved, random dense input (the frame itself runs the background-skipping "
+                                   "<3,5> form on a sparse map: fewer MFMAs, not a faster loop); peak = dense bf16 MFMA at the "
+                                   "data-sheet 2.4 GHz, 3 bf16 terms per fp32-class product; the loop is issue-bound at the "
+                                   "sustained clock (profiles/r02_e_dense_tile_timeline.txt)")
         tot_bytes = sum(l["bytes"] for l in layers)
         tot_t = sum(l["t_avg_us"] for l in layers) * 1e-6
         stages = dict(sparse_conv_launches=len(layers), sparse_conv_us=tot_t * 1e6, sparse_conv_algorithmic_MB=tot_bytes / 1e6,
