@@ -47,8 +47,60 @@ def test_two_rank_sharding_timing_and_gradient_allreduce():
         torch.testing.assert_close(ra, rb)
 
 
+def _worker_two_phase(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from vision3d_amd import dist_util as D
+    r, _, w = D.init_from_env("gloo")
+    torch.manual_seed(0)
+    first = torch.nn.Linear(6, 5)    # "late": its gradients come out of the backward last (the sparse backbone's role)
+    second = torch.nn.Linear(5, 3)   # "early": complete when the backward reaches `first`
+    reducer = D.TwoPhaseGradReducer(list(second.parameters()), list(first.parameters()), w)
+    fired = []
+
+    class Mark(torch.autograd.Function):  # stands where PlanTrainFunction.backward calls plan.pre_backward_hook
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            fired.append(all(p.grad is not None for p in second.parameters()))
+            reducer.start_early()
+            return g
+
+    x = torch.full((4, 6), float(r + 1))
+    second(Mark.apply(torch.relu(first(x)))).sum().backward()
+    local = [p.grad.clone() for p in list(first.parameters()) + list(second.parameters())]
+    n = reducer.finish()
+    reduced = [p.grad.clone() for p in list(first.parameters()) + list(second.parameters())]
+    # the hook-less path (module-by-module training) reduces the same two buckets inside finish()
+    for p, g in zip(list(first.parameters()) + list(second.parameters()), local):
+        p.grad.copy_(g)
+    n2 = reducer.finish()
+    again = [p.grad.clone() for p in list(first.parameters()) + list(second.parameters())]
+    out[rank] = dict(n=n, n2=n2, local=local, reduced=reduced, again=again, fired=fired)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_phase_gradient_reducer_overlapped_bucket_equals_flat_mean():
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker_two_phase, args=(world, port, out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    assert a["fired"] == [True] and b["fired"] == [True]  # the early bucket's gradients were complete when the hook fired
+    assert a["n"] == a["n2"] == sum(p.numel() for p in a["local"])
+    for ga, gb, ra, rb, aa in zip(a["local"], b["local"], a["reduced"], b["reduced"], a["again"]):
+        torch.testing.assert_close(ra, (ga + gb) / 2)
+        torch.testing.assert_close(ra, rb)
+        torch.testing.assert_close(aa, ra)
+
+
 def test_single_rank_paths_are_noops():
     from vision3d_amd import dist_util as D
     assert D.shard_frames(3, 0, 1) == [0, 1, 2]
     assert D.max_over_ranks(0.25, 1) == 0.25
     assert D.allreduce_gradients_flat([], 1) == 0
+    red = D.TwoPhaseGradReducer([], [], 1)
+    red.start_early()
+    assert red.finish() == 0

@@ -160,3 +160,30 @@ def test_rpn_training_forward_equals_padded_module_sequence():
     (gx2,) = torch.autograd.grad(y2.square().sum(), x2)
     torch.testing.assert_close(y, y2, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(gx, gx2, rtol=1e-3, atol=1e-3 * float(gx2.abs().max()))
+
+
+def test_dense_gradients_are_complete_when_the_plan_backward_starts():
+    """dist_util.TwoPhaseGradReducer reduces the dense half's bucket from `plan.pre_backward_hook`, i.e. while the native sparse
+    backward runs: every RPN / head gradient must already hold its final value at that moment (under bf16 autocast too)."""
+    from vision3d_amd.core import ProposalTargetAssigner
+    from vision3d_amd.detector import ProposalLoss
+    cfg, model, item = _model_and_item(2)
+    assigner, targets = ProposalTargetAssigner(cfg), []
+    for f in range(2):
+        gt = torch.from_numpy(synth.make_gt_boxes(f))
+        targets.append(assigner(dict(boxes=gt, class_idx=torch.zeros(len(gt), dtype=torch.long),
+                                     box_ignore=torch.zeros(len(gt), dtype=torch.bool))))
+    item.update({k: torch.stack([t[k] for t in targets]).cuda() for k in ("G_cls", "G_reg", "M_cls", "M_reg")})
+    sparse_ids = {id(p) for p in model.cnn.parameters()}
+    dense = [p for p in model.parameters() if id(p) not in sparse_ids]
+    snap = []
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        losses = ProposalLoss(cfg)(model(item))
+    plans = list(model.cnn.__dict__["_train_plans"].values())
+    assert len(plans) == 1
+    plans[0].pre_backward_hook = lambda: snap.append([None if p.grad is None else p.grad.detach().clone() for p in dense])
+    losses["loss"].backward()
+    assert len(snap) == 1 and len(dense) == 25
+    for at_hook, p in zip(snap[0], dense):
+        assert at_hook is not None and torch.equal(at_hook, p.grad)
+    assert all(p.grad is not None for p in model.cnn.parameters())

@@ -59,3 +59,61 @@ def allreduce_gradients_flat(params, world):
         g.copy_(flat[off:off + n].view_as(g))
         off += n
     return flat.numel()
+
+
+class TwoPhaseGradReducer(object):
+    """The train step's gradient all-reduce in two buckets, the first one overlapped with the backward.
+
+    Autograd reaches the sparse backbone LAST (it is the first thing the forward runs), and the backbone's backward is one
+    native call of ~5 ms (runtime.PlanTrainFunction).  When that call starts, every gradient of the dense half (RPN + heads:
+    the `early` parameters) has already been accumulated, so their bucket is reduced ASYNCHRONOUSLY while the sparse backward
+    runs (`start_early()`, hooked in through `BackbonePlan.pre_backward_hook`); `finish()` reduces the `late` bucket (the
+    backbone's own gradients), waits for both and writes the averages back.  Two collectives of ~4 MB and ~3 MB per step instead
+    of one of 7 MB after the backward; results are identical to `allreduce_gradients_flat` (sums of the same values).
+    """
+
+    def __init__(self, early_params, late_params, world):
+        self.early, self.late, self.world = list(early_params), list(late_params), int(world)
+        self._work, self._flat, self._grads = None, None, None
+
+    @staticmethod
+    def _bucket(params):
+        grads = [p.grad for p in params if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads]) if grads else None
+        return grads, flat
+
+    @staticmethod
+    def _scatter(grads, flat, world):
+        flat.div_(world)
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+
+    def start_early(self):
+        """Call once per step when the early parameters' gradients are complete (idempotent until `finish`)."""
+        if self.world == 1 or self._work is not None:
+            return
+        self._grads, self._flat = self._bucket(self.early)
+        if self._flat is not None:
+            self._work = dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        """After backward(): reduce the late bucket, complete the early one.  Returns the number of reduced elements."""
+        if self.world == 1:
+            return 0
+        if self._work is None:  # the hook never fired (e.g. the module path was taken): plain two-bucket reduction
+            self.start_early()
+        n = 0
+        grads, flat = self._bucket(self.late)
+        if flat is not None:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            self._scatter(grads, flat, self.world)
+            n += flat.numel()
+        if self._work is not None:
+            self._work.wait()
+            self._scatter(self._grads, self._flat, self.world)
+            n += self._flat.numel()
+        self._work, self._flat, self._grads = None, None, None
+        return n

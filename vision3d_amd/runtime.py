@@ -332,6 +332,9 @@ class PlanTrainFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_bev):
+        hook = ctx.plan.__dict__.get("pre_backward_hook")
+        if hook is not None:  # everything downstream of the BEV map has its gradients by now (dist_util.TwoPhaseGradReducer)
+            hook()
         grads = ctx.plan.train_backward(grad_bev, ctx.batch_size)
         return (None, None, None, None, None) + tuple(grads)
 
