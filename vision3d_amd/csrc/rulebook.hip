@@ -119,24 +119,23 @@ __device__ __forceinline__ unsigned rb_first_flags(const int* __restrict__ cand_
   return flags;
 }
 
-// count + scan + emit in ONE launch: a single-pass chained scan (decoupled look-back) over 2 048-ticket chunks.
+// count + scan + emit in ONE launch: a single-pass scan over 2 048-ticket chunks through published counts.
 // Every block counts its first-toucher tickets and PUBLISHES the count at once (agent-scope atomic store into a slot that reads
-// -1 at launch: part of the frame's 0xFF fill, no fence needed); wave 0 then walks back over its predecessors, 64 at a time,
-// adding their counts until it meets one whose INCLUSIVE prefix is already published, publishes its own inclusive prefix and
-// the block emits its output rows at prefix + local rank.  Workgroups are dispatched in index order and publish their count
-// before they wait for anything, so every wait is on a block that is already running or done.  The highest-index block adds
-// up the total (clipped to cap_out).  This replaces a count+scan launch and an emit launch (~7 us each in the frame: the
-// rulebook kernels are launch-latency, not work).
-//   chunk_counts[n_chunks] | chunk_incl[n_chunks], all -1 at launch.
+// -1 at launch: part of the frame's 0xFF fill, no fence needed), then adds up the counts of ALL its live predecessors -- every
+// thread its share, spinning on slots that still read -1 -- and emits its output rows at prefix + local rank.  Workgroups are
+// dispatched in index order and publish before they wait for anything, so every wait is on a block that is already running
+// or done; the counts appear within ~2 us of the launch, so the prefix is ONE round of coherent loads (a wave-0 look-back over
+// inclusive prefixes took up to three dependent rounds for the late blocks: 12 us per launch instead of ~8).  The
+// highest-index block adds up the total (clipped to cap_out).  Replaces a count+scan launch and an emit launch.
+//   chunk_counts[n_chunks], all -1 at launch.
 __global__ __launch_bounds__(V3D_BLOCK) void rb_scan_emit_kernel(const int4* __restrict__ coords, const int* __restrict__ n_ptr,
                                                                  int cap_in, const RbGeom g, const int* __restrict__ cand_slot,
                                                                  const unsigned* __restrict__ first_ticket,
-                                                                 int* __restrict__ chunk_counts, int* __restrict__ chunk_incl,
-                                                                 int cap_out, int4* __restrict__ coords_out,
+                                                                 int* __restrict__ chunk_counts, int cap_out, int4* __restrict__ coords_out,
                                                                  int* __restrict__ vals, int* __restrict__ n_out,
                                                                  int* __restrict__ overflow, int* __restrict__ overflow_any) {
   __shared__ int lds[4];
-  __shared__ int s_prefix;
+  __shared__ int s_part[4];
   const long long nt = (long long)min(*n_ptr, cap_in) * g.K;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const long long base = (long long)b * V3D_SCAN_CHUNK;
@@ -155,31 +154,16 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_scan_emit_kernel(const int4* __r
   __syncthreads();
   const int cnt = lds[0] + lds[1] + lds[2] + lds[3];
   if (tid == 0 && live) v3d_publish_count(chunk_counts + b, cnt);
-  if (w == 0) {
+  int part = 0;
+  {
     const int n_live = (int)((nt + V3D_SCAN_CHUNK - 1) / V3D_SCAN_CHUNK);
-    int prefix = 0;
-    for (int pos = min(b, n_live) - 1; pos >= 0; pos -= 64) {
-      const int idx = pos - lane;
-      int c = 0, inc = -1;
-      if (idx >= 0) {
-        c = v3d_wait_count(chunk_counts + idx);
-        inc = v3d_load_coherent(chunk_incl + idx);
-      }
-      const unsigned long long ready = __ballot(inc >= 0);
-      const int first = ready ? __ffsll((long long)ready) - 1 : 64;  // nearest predecessor whose inclusive prefix is known
-      int part = lane < first ? c : (lane == first ? inc : 0);
+    for (int i = tid; i < min(b, n_live); i += V3D_BLOCK) part += v3d_wait_count(chunk_counts + i);
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-      prefix += part;
-      if (ready) break;
-    }
-    if (lane == 0) {
-      s_prefix = prefix;
-      if (live) v3d_publish_count(chunk_incl + b, prefix + cnt);
-    }
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) s_part[w] = part;
   }
   __syncthreads();
-  const int prefix = s_prefix;
+  const int prefix = s_part[0] + s_part[1] + s_part[2] + s_part[3];
   if (last && tid == 0) {
     const int total = prefix + cnt;
     if (total > cap_out) {
@@ -298,7 +282,7 @@ int v3d_i_subm_nbr(const int32_t* coords, const int32_t* n, int cap, const int32
 }
 
 // scratch: first_ticket[out.hcap] (must directly follow out.keys and precede out.vals in memory so that ONE
-// memset resets keys|first_ticket|vals), cand_slot[cap_in*K], chunk_counts[2 * ceil(cap_in*K/2048)] (counts | inclusive prefixes).
+// memset resets keys|first_ticket|vals), cand_slot[cap_in*K], chunk_counts[ceil(cap_in*K/2048)].
 int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap_in, const int32_t* shape,
                           const int32_t* ksize, const int32_t* stride, const int32_t* padding, int32_t* coords_out,
                           int32_t* n_out, int cap_out, int32_t* nbr, int32_t* overflow, V3dRbHash out,
@@ -318,15 +302,14 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
     V3D_CHECK_HIP(v3d_fill_async(out.keys, 0xFF, (size_t)out.hcap * 16, st));
     V3D_CHECK_HIP(v3d_fill_async(nbr, 0xFF, (size_t)g.K * cap_out * 4, st));
     V3D_CHECK_HIP(v3d_fill_async(overflow, 0, 4, st));
-    V3D_CHECK_HIP(v3d_fill_async(chunk_counts, 0xFF, (size_t)chunks * 8, st));  // counts | inclusive prefixes: -1 = "not published yet"
+    V3D_CHECK_HIP(v3d_fill_async(chunk_counts, 0xFF, (size_t)chunks * 4, st));  // -1 = "count not published yet"
   }
   V3dHash h = v3d_make_hash(out.keys, out.hcap);
   const int tblocks = min(v3d_ceil_div(tickets, V3D_BLOCK), 4096);
   hipLaunchKernelGGL(rb_candidates_kernel, dim3(tblocks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in,
                      g, h, first_ticket, cand_slot, overflow, overflow_any);
   hipLaunchKernelGGL(rb_scan_emit_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in, g,
-                     cand_slot, first_ticket, chunk_counts, chunk_counts + chunks, cap_out, (int4*)coords_out, out.vals, n_out,
-                     overflow, overflow_any);
+                     cand_slot, first_ticket, chunk_counts, cap_out, (int4*)coords_out, out.vals, n_out, overflow, overflow_any);
   RbGeom sg = g;
   int subm_blocks = 0;
   if (next_subm_ksize && next_subm_nbr) {
@@ -347,7 +330,7 @@ extern "C" size_t v3d_rulebook_workspace(int cap_in, int cap_out, int K) {
   const size_t hcap = v3d_hash_capacity((long long)(ci > co ? ci : co));
   const size_t tickets = ci * (size_t)(K > 0 ? K : 1);
   const size_t chunks = (tickets + V3D_SCAN_CHUNK - 1) / V3D_SCAN_CHUNK;
-  return v3d_align(hcap * 8) + 2 * v3d_align(hcap * 4) + v3d_align(tickets * 4) + v3d_align(chunks * 8) + 256;
+  return v3d_align(hcap * 8) + 2 * v3d_align(hcap * 4) + v3d_align(tickets * 4) + v3d_align(chunks * 4) + 256;
 }
 
 extern "C" int v3d_rulebook_subm(const int32_t* coords, const int32_t* n, int cap, const int32_t* spatial_shape_host,
@@ -389,7 +372,7 @@ extern "C" int v3d_rulebook_sparse(const int32_t* coords_in, const int32_t* n_in
   h.vals = ar.take<int>(hcap);
   h.hcap = hcap;
   int* cand_slot = ar.take<int>((size_t)tickets);
-  int* chunk_counts = ar.take<int>((size_t)2 * chunks);
+  int* chunk_counts = ar.take<int>(chunks);
   if (!ar.ok()) return V3D_EWORKSPACE;
   return v3d_i_sparse_rulebook(coords_in, n_in, cap_in, spatial_shape_host, ksize_host, stride_host, padding_host,
                                coords_out, n_out, cap_out, nbr, overflow, h, first_ticket, cand_slot, chunk_counts,

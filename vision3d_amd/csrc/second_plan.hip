@@ -169,8 +169,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       p->bev_occ = ar.take<uint32_t>(v3d_bev_occupancy_words(cfg->max_batch, sl.shape[1], sl.shape[2]));
     }
     for (auto& L : p->layers)  // strided layers: per-layer count slots, -1 = "not published" at the start of a frame
-      if (!L.d.subm)  // counts | inclusive prefixes of the chained scan, one pair of slots per 2 048-ticket chunk
-        L.chunk_counts = ar.take<int>((size_t)2 * v3d_ceil_div((long long)p->stages[L.stage_in].cap * L.K, V3D_SCAN_CHUNK) + 2);
+      if (!L.d.subm) L.chunk_counts = ar.take<int>((size_t)v3d_ceil_div((long long)p->stages[L.stage_in].cap * L.K, V3D_SCAN_CHUNK) + 2);
     p->ff_bytes = (size_t)((ar.base + ar.off) - p->ff_begin);
     // ---- the rest needs no per-frame initialisation
     for (size_t i = 0; i < p->nbr.size(); i++)
