@@ -331,6 +331,7 @@ class PlanTrainFunction(torch.autograd.Function):
         return plan.train_forward(voxel_mean.detach(), coordinates, batch_size, bf16_nhwc)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_bev):
         hook = ctx.plan.__dict__.get("pre_backward_hook")
         if hook is not None:  # everything downstream of the BEV map has its gradients by now (dist_util.TwoPhaseGradReducer)
