@@ -174,7 +174,9 @@ def train_main(args):
 def pvrcnn_main(args):
     """configs[3]: PV-RCNN stage 2 on SECOND proposals -- FPS keypoints (16 384 -> 2 048), 5-level voxel-set abstraction
     (ball query + group + shared MLP + max), BEV bilinear gather, RoI-grid pooling of 100 proposals, refinement MLP.
-    Stage-1 outputs (sparse feature volumes, BEV map, proposals) are resident before the timed region."""
+    Stage-1 outputs (sparse feature volumes, BEV map, proposals) are resident before the timed region.  `value` = throughput
+    with --pipeline frames in flight (default 4: independent frames on separate streams, one host thread, no host
+    synchronisation inside a step); `single_frame_ms` = the same step one frame at a time."""
     from vision3d_amd import dist_util, synth
     from vision3d_amd.core import Preprocessor
     from vision3d_amd.core.config import second_car_cfg
@@ -187,14 +189,19 @@ def pvrcnn_main(args):
     torch.manual_seed(0)
     model = PV_RCNN(cfg).cuda().eval()
     bs = args.batch
-    clouds = [synth.make_cloud(rank * bs + i, args.points or 16384) for i in range(bs)]
+    depth = args.pipeline if args.pipeline >= 1 else 4  # frames in flight (independent frames on separate streams; 1 = one at a time)
+    n_prop = 100
+    slots = []
     with torch.no_grad():
-        item = model.proposal(Preprocessor(cfg, seed=0)(dict(points=clouds)))
-        gts = [synth.make_gt_boxes(rank * bs + i) for i in range(bs)]
-        n_prop = 100
-        props = torch.from_numpy(np.stack([np.resize(g, (n_prop, 7)) for g in gts])).cuda()
+        for sl in range(depth):  # every slot works on its own frame(s): stage-1 outputs resident before the timed region
+            clouds = [synth.make_cloud((rank * depth + sl) * bs + i, args.points or 16384) for i in range(bs)]
+            item = model.proposal(Preprocessor(cfg, seed=0)(dict(points=clouds)))
+            gts = [synth.make_gt_boxes((rank * depth + sl) * bs + i) for i in range(bs)]
+            props = torch.from_numpy(np.stack([np.resize(g, (n_prop, 7)) for g in gts])).cuda()
+            slots.append((item, props, torch.cuda.Stream()))
 
-        def step():
+        def step(sl=0):
+            item, props, _ = slots[sl]
             item["keypoints"] = model.sample_keypoints(item["points"])
             pf = model.point_feature_extract(item, item["_cnn_features"], item["_bev_map"])
             pooled = model.roi_grid_pool(props, item["keypoints"], pf)
@@ -206,12 +213,29 @@ def pvrcnn_main(args):
                 dist.barrier()
             torch.cuda.synchronize()
 
-        for _ in range(args.warmup):
-            out = step()
+        # one frame at a time on the current stream (latency), then `depth` frames in flight: FPS is ONE workgroup's dependent
+        # chain (2.5 ms on one CU), so the set abstraction / RoI pooling of other frames runs beside it on the rest of the chip
+        for _ in range(max(args.warmup, 2)):
+            out = step(0)
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
+        for _ in range(max(args.steps // 2, 1)):
+            out = step(0)
+        torch.cuda.synchronize()
+        single_ms = 1e3 * (time.perf_counter() - t0) / max(args.steps // 2, 1)
+        for sl in range(depth):
+            slots[sl][2].wait_stream(torch.cuda.current_stream())
+        for i in range(args.warmup):
+            with torch.cuda.stream(slots[i % depth][2]):
+                out = step(i % depth)
+        fence()
+        t0 = time.perf_counter()
+        enq = 0.0
+        for i in range(args.steps):
+            e0 = time.perf_counter()
+            with torch.cuda.stream(slots[i % depth][2]):
+                out = step(i % depth)
+            enq += time.perf_counter() - e0
         fence()
     elapsed = dist_util.max_over_ranks(time.perf_counter() - t0, world, device=REDUCE_DEVICE)
     if rank == 0:
@@ -221,8 +245,10 @@ def pvrcnn_main(args):
             scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
             config=dict(workload="PV-RCNN stage 2 (BASELINE configs[3]): FPS 2048 keypoints + 5-level VSA + BEV gather + "
                                  "RoI-grid pool (100 proposals) + refinement MLP", frames_per_gpu_per_step=bs,
-                        points_per_frame=args.points or 16384, parallelism=f"frame-parallel replicas x{world}"),
-            roofline=None, cpu_baseline=None)))
+                        points_per_frame=args.points or 16384, parallelism=f"frame-parallel replicas x{world}",
+                        frames_in_flight=depth, path="eager launches from one host thread, one stream per frame in flight"),
+            single_frame_ms=single_ms, frames_per_s_one_at_a_time=bs * 1e3 / single_ms,
+            host_enqueue_ms_per_step=1e3 * enq / args.steps, roofline=None, cpu_baseline=None)))
     if world > 1:
         dist.destroy_process_group()
 

@@ -32,16 +32,25 @@ class BEVFeatureGatherer(nn.Module):
         self.register_buffer("pixel_offset", voxel_offset[:2].detach().clone(), persistent=False)
         self.register_buffer("base_pixel_size", base_voxel_size[:2].detach().clone(), persistent=False)
 
+    def _limit(self, like, height, width):
+        """[W - 1, H - 1] on the device, cached per map size: `new_tensor([...])` is a pageable host-to-device copy, i.e. a host
+        synchronisation per frame (it serialised frames in flight on different streams)."""
+        cache = self.__dict__.setdefault("_limit_cache", {})
+        key = (int(height), int(width), str(like.device), like.dtype)
+        if key not in cache:
+            cache[key] = torch.tensor([width - 1, height - 1], dtype=like.dtype, device=like.device)
+        return cache[key]
+
     def _to_grid(self, xy, height, width):
         pixel = self.base_pixel_size * self.cfg.STRIDES[-1]
         frac = (xy - self.pixel_offset) / pixel
-        limit = frac.new_tensor([width - 1, height - 1])
+        limit = self._limit(frac, height, width)
         frac = torch.min(frac.clamp(min=0), limit)
         return (2 * (frac / (limit - 1)) - 1).flip(-1)
 
     # reference method names, kept for callers that used them
     def normalize_indices(self, indices, H, W):
-        limit = indices.new_tensor([W - 1, H - 1])
+        limit = self._limit(indices, H, W)
         return 2 * (torch.min(indices.clamp(min=0), limit) / (limit - 1)) - 1
 
     def compute_bev_indices(self, keypoint_xyz, H, W):
