@@ -554,8 +554,8 @@ def main():
                               unit="TFLOP/s", frac=fl / t_dense / 1e12 / 2500.0, frac_issued=3 * fl / t_dense / 1e12 / 2500.0,
                               note="every tile convolved, random dense input (the frame itself runs the background-skipping "
                                    "<3,5> form on a sparse map: fewer MFMAs, not a faster loop); peak = dense bf16 MFMA at the "
-                                   "data-sheet 2.4 GHz, 3 bf16 terms per fp32-class product; the loop is issue-bound at the "
-                                   "sustained clock (profiles/r02_e_dense_tile_timeline.txt)")
+                                   "data-sheet 2.4 GHz, 3 bf16 terms per fp32-class product; matrix instructions are spaced out by "
+                                   "power management, 16 busy cycles each (profiles/r02_e_dense_tile_timeline.txt)")
         tot_bytes = sum(l["bytes"] for l in layers)
         tot_t = sum(l["t_avg_us"] for l in layers) * 1e-6
         stages = dict(sparse_conv_launches=len(layers), sparse_conv_us=tot_t * 1e6, sparse_conv_algorithmic_MB=tot_bytes / 1e6,
