@@ -201,6 +201,10 @@ int v3d_gather_points(const float* feat, const int32_t* idx, int B, int C, int N
                       v3d_stream_t stream);
 int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M, float radius, int nsample,
                    int32_t* idx, v3d_stream_t stream);
+/* Two radii around the same queries in one scan of the database (what PointnetSAModuleMSG asks for per feature source): per
+ * (query, radius) the same result as v3d_ball_query. */
+int v3d_ball_query2(const float* xyz, const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a, int32_t* idx_a,
+                    float radius_b, int nsample_b, int32_t* idx_b, v3d_stream_t stream);
 int v3d_group_points(const float* feat, const int32_t* idx, int B, int C, int N, int M, int nsample, float* out,
                      v3d_stream_t stream);
 

@@ -270,3 +270,17 @@ def test_pv_rcnn_stage_pieces_run():
         assert pooled.shape == (2, 20, 256)
         deltas, conf = model.refinement_layer(None, pooled, props)
         assert deltas.shape == (2, 20, 7) and conf.shape == (2, 20, 1)
+
+
+@pytest.mark.parametrize("n,m,ra,nsa,rb,nsb", [(16384, 2048, 0.4, 16, 0.8, 16), (4204, 2048, 2.4, 16, 4.8, 32), (777, 130, 1.0, 5, 3.0, 64),
+                                               (2500, 37, 0.01, 16, 100.0, 32)])
+def test_ball_query_pair_equals_two_single_queries(n, m, ra, nsa, rb, nsb):
+    """v3d_ball_query2 (two radii in one scan) == v3d_ball_query per radius (itself exact against the oracle above): ragged
+    sizes, a radius that finds nothing, one that finds everything."""
+    from vision3d_amd.pointnet2 import pointnet2_utils as PU
+    g = torch.Generator().manual_seed(n + m)
+    xyz = (torch.rand(2, n, 3, generator=g) * torch.tensor([70.0, 80.0, 4.0])).cuda()
+    new_xyz = xyz[:, torch.randperm(n, generator=g)[:m]].contiguous() + 0.05
+    ia, ib = PU.ball_query_pair(ra, nsa, rb, nsb, xyz, new_xyz)
+    assert torch.equal(ia, PU.ball_query(ra, nsa, xyz, new_xyz))
+    assert torch.equal(ib, PU.ball_query(rb, nsb, xyz, new_xyz))

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "v3d_furthest_point_sample": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "v3d_gather_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "v3d_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
+    "v3d_ball_query2": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _f, _i, _vp, _vp]),
     "v3d_group_points": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "v3d_sa_mlp_layer": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "v3d_backbone_create": (_i, [_vp, _vp, _vp]),

@@ -416,6 +416,103 @@ __global__ __launch_bounds__(V3D_BLOCK) void ball_query_kernel(const float* __re
   }
 }
 
+// Two radii around the same queries in ONE scan of the database (the multi-scale set-abstraction modules always ask for two:
+// detector/model.py:58-66, roi_grid_pool.py:64-72): a step loads its 64 database points from the LDS tile once and tests them
+// against BQ2_QPW queries x 2 radii, where the single-radius kernel re-read the tile per query and the caller scanned the
+// database once per radius.  Per (query, radius) the result is the single kernel's: the first nsample points inside the ball in
+// index order, unfilled slots repeat the first hit.  PV-RCNN stage 2: 4.08 -> 3.80 ms per frame (2 queries per wave: 4 leave half
+// the chip idle at 2 048 queries -- no gain --, 1 gives 3.68 ms one at a time but less with frames in flight).
+#define BQ2_QPW 2
+__global__ __launch_bounds__(V3D_BLOCK) void ball_query2_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                                int N, int M, float r2a, int nsa, int* __restrict__ idxa,
+                                                                float r2b, int nsb, int* __restrict__ idxb) {
+  __shared__ float tile[BQ_TILE * 3];
+  __shared__ int open_queries;
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q0 = (blockIdx.x * (V3D_BLOCK / V3D_WAVE) + wave) * BQ2_QPW;
+  float qx[BQ2_QPW], qy[BQ2_QPW], qz[BQ2_QPW];
+  int cnta[BQ2_QPW], cntb[BQ2_QPW], firsta[BQ2_QPW], firstb[BQ2_QPW];  // wave-uniform
+#pragma unroll
+  for (int u = 0; u < BQ2_QPW; u++) {
+    const int j = q0 + u;
+    const float* q = new_xyz + ((size_t)b * M + (j < M ? j : 0)) * 3;
+    qx[u] = q[0];
+    qy[u] = q[1];
+    qz[u] = q[2];
+    cnta[u] = j < M ? 0 : nsa;  // a query beyond M is "full" from the start
+    cntb[u] = j < M ? 0 : nsb;
+    firsta[u] = firstb[u] = 0;
+  }
+  const float* base = xyz + (size_t)b * N * 3;
+  for (int n0 = 0; n0 < N; n0 += BQ_TILE) {
+    const int tn = min(BQ_TILE, N - n0);
+    __syncthreads();
+    if (threadIdx.x == 0) open_queries = 0;
+    for (int t = threadIdx.x; t < tn * 3; t += V3D_BLOCK) tile[t] = base[(size_t)n0 * 3 + t];
+    __syncthreads();
+    bool wave_open = false;
+#pragma unroll
+    for (int u = 0; u < BQ2_QPW; u++) wave_open = wave_open || cnta[u] < nsa || cntb[u] < nsb;
+    for (int t0 = 0; t0 < tn && wave_open; t0 += 64) {
+      const int t = t0 + lane;
+      const bool in = t < tn;
+      const float px = in ? tile[3 * t] : 0.f, py = in ? tile[3 * t + 1] : 0.f, pz = in ? tile[3 * t + 2] : 0.f;
+      wave_open = false;
+#pragma unroll
+      for (int u = 0; u < BQ2_QPW; u++) {
+        const float dx = qx[u] - px, dy = qy[u] - py, dz = qz[u] - pz;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        const size_t row = (size_t)b * M + (q0 + u < M ? q0 + u : 0);
+        if (cnta[u] < nsa) {
+          const bool hit = in && d2 < r2a;
+          const unsigned long long m = __ballot(hit);
+          if (m) {
+            if (cnta[u] == 0) firsta[u] = n0 + t0 + __ffsll((long long)m) - 1;
+            const int pos = cnta[u] + __popcll(m & ((1ull << lane) - 1ull));
+            if (hit && pos < nsa) idxa[row * nsa + pos] = n0 + t;
+            cnta[u] = min(nsa, cnta[u] + __popcll(m));
+          }
+        }
+        if (cntb[u] < nsb) {
+          const bool hit = in && d2 < r2b;
+          const unsigned long long m = __ballot(hit);
+          if (m) {
+            if (cntb[u] == 0) firstb[u] = n0 + t0 + __ffsll((long long)m) - 1;
+            const int pos = cntb[u] + __popcll(m & ((1ull << lane) - 1ull));
+            if (hit && pos < nsb) idxb[row * nsb + pos] = n0 + t;
+            cntb[u] = min(nsb, cntb[u] + __popcll(m));
+          }
+        }
+        wave_open = wave_open || cnta[u] < nsa || cntb[u] < nsb;
+      }
+    }
+    if (lane == 0 && wave_open) atomicOr(&open_queries, 1);
+    __syncthreads();
+    if (open_queries == 0) break;  // workgroup-uniform
+  }
+#pragma unroll
+  for (int u = 0; u < BQ2_QPW; u++) {
+    if (q0 + u < M) {
+      const size_t row = (size_t)b * M + q0 + u;
+      for (int sidx = cnta[u] + lane; sidx < nsa; sidx += 64) idxa[row * nsa + sidx] = firsta[u];
+      for (int sidx = cntb[u] + lane; sidx < nsb; sidx += 64) idxb[row * nsb + sidx] = firstb[u];
+    }
+  }
+}
+
+extern "C" int v3d_ball_query2(const float* xyz, const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a,
+                               int32_t* idx_a, float radius_b, int nsample_b, int32_t* idx_b, v3d_stream_t stream) {
+  if (B < 0 || N < 1 || M < 0 || nsample_a < 1 || nsample_b < 1) return V3D_EINVAL;
+  if (B == 0 || M == 0) return V3D_OK;
+  if (!xyz || !new_xyz || !idx_a || !idx_b) return V3D_EINVAL;
+  hipLaunchKernelGGL(ball_query2_kernel, dim3(v3d_ceil_div(M, (V3D_BLOCK / V3D_WAVE) * BQ2_QPW), B), dim3(V3D_BLOCK), 0,
+                     (hipStream_t)stream, xyz, new_xyz, N, M, radius_a * radius_a, nsample_a, idx_a, radius_b * radius_b, nsample_b,
+                     idx_b);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 extern "C" int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M, float radius, int nsample,
                               int32_t* idx, v3d_stream_t stream) {
   if (B < 0 || N < 1 || M < 0 || nsample < 1) return V3D_EINVAL;

@@ -91,10 +91,15 @@ class PointnetSAModuleMSG(nn.Module):
         feat = features_pm.contiguous() if kf == c else torch.nn.functional.pad(features_pm, (0, kf - c)).contiguous()
         xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
         outs = []
+        if len(self.groupers) == 2:  # both scales in one scan of the database
+            ga, gb = self.groupers
+            neighbours = PU.ball_query_pair(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, new_xyz)
+        else:
+            neighbours = [PU.ball_query(g.radius, g.nsample, xyz, new_xyz) for g in self.groupers]
         for k, grouper in enumerate(self.groupers):
             layers = self._packed_layers(k)
             ns = grouper.nsample
-            idx = PU.ball_query(grouper.radius, ns, xyz, new_xyz)
+            idx = neighbours[k]
             x = PU.sa_mlp_layer(feat, layers[0][0], layers[0][1], True, len(layers) == 1, xyz=xyz, new_xyz=new_xyz, idx=idx)
             for li in range(1, len(layers)):
                 x = PU.sa_mlp_layer(x, layers[li][0], layers[li][1], True, li == len(layers) - 1, groups=(b, m, ns))

@@ -87,6 +87,21 @@ def ball_query(radius, nsample, xyz, new_xyz):
     return idx
 
 
+def ball_query_pair(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz):
+    """Two ball queries around the same `new_xyz` in one scan of `xyz` (the two scales of a multi-scale set-abstraction module):
+    -> (idx_a (B, M, nsample_a), idx_b (B, M, nsample_b)), each exactly what `ball_query` returns for its radius."""
+    L.require_gpu("ball_query", xyz, new_xyz)
+    p, q = L.as_f32("ball_query", xyz), L.as_f32("ball_query", new_xyz)
+    b, n, _ = p.shape
+    m = q.shape[1]
+    idx_a = torch.empty((b, m, nsample_a), dtype=torch.int32, device=p.device)
+    idx_b = torch.empty((b, m, nsample_b), dtype=torch.int32, device=p.device)
+    with torch.cuda.device(p.device):
+        L.check(L.lib().v3d_ball_query2(L.ptr(p), L.ptr(q), b, n, m, float(radius_a), int(nsample_a), L.ptr(idx_a),
+                                        float(radius_b), int(nsample_b), L.ptr(idx_b), L.stream_ptr()), "ball_query2")
+    return idx_a, idx_b
+
+
 def grouping_operation(features, idx):
     """features (B, C, N), idx (B, M, ns) int32 -> (B, C, M, ns); differentiable in `features`."""
     if torch.is_grad_enabled() and features.requires_grad:
