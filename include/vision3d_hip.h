@@ -207,6 +207,11 @@ int v3d_ball_query2(const float* xyz, const float* new_xyz, int B, int N, int M,
                     float radius_b, int nsample_b, int32_t* idx_b, v3d_stream_t stream);
 int v3d_group_points(const float* feat, const int32_t* idx, int B, int C, int N, int M, int nsample, float* out,
                      v3d_stream_t stream);
+/* Bilinear lookup of BEV features at keypoints: F.grid_sample(feature_map, grid, bilinear, zeros, align_corners=True) for a
+ * (B, 1, K, 2) grid, as BEVFeatureGatherer.forward calls it (detector/layers.py:29-47).  feature_map (B, C, H, W) f32, grid
+ * (B, K, 2) f32 = (x, y) in [-1, 1], out (B, C, K).  Same taps, weights and summation order as torch's kernel. */
+int v3d_bev_bilinear(const float* feature_map, const float* grid, int B, int C, int H, int W, int K, float* out,
+                     v3d_stream_t stream);
 
 /* ---- T5: one layer of a set-abstraction shared MLP on gathered rows, exact fp32 on the matrix cores (csrc/sa_mlp.hip).
  * Replaces, per scale of pointnet2_modules.PointnetSAModuleMSG (call sites detector/model.py:58-66, detector/roi_grid_pool.py:

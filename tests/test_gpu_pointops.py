@@ -284,3 +284,32 @@ def test_ball_query_pair_equals_two_single_queries(n, m, ra, nsa, rb, nsb):
     ia, ib = PU.ball_query_pair(ra, nsa, rb, nsb, xyz, new_xyz)
     assert torch.equal(ia, PU.ball_query(ra, nsa, xyz, new_xyz))
     assert torch.equal(ib, PU.ball_query(rb, nsb, xyz, new_xyz))
+
+
+def test_bev_bilinear_equals_grid_sample():
+    """v3d_bev_bilinear == F.grid_sample(bilinear, zeros, align_corners=True) on a (B, 1, K, 2) grid, including points on and
+    beyond the border (the gatherer clamps, the kernel must still zero-pad like torch)."""
+    import torch.nn.functional as F
+    from vision3d_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    fmap = torch.randn(2, 37, 25, 19, generator=g).cuda()
+    grid = (torch.rand(2, 1, 400, 2, generator=g) * 2.4 - 1.2).cuda()
+    grid[0, 0, 0] = torch.tensor([-1.0, -1.0])
+    grid[0, 0, 1] = torch.tensor([1.0, 1.0])
+    grid[1, 0, 2] = torch.tensor([0.0, 1.0])
+    ref = F.grid_sample(fmap, grid, align_corners=True).squeeze(2)
+    out = torch.empty_like(ref)
+    L.check(L.lib().v3d_bev_bilinear(L.ptr(fmap), L.ptr(grid.reshape(2, 400, 2).contiguous()), 2, 37, 25, 19, 400, L.ptr(out),
+                                     L.stream_ptr()), "bev_bilinear")
+    torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-6)
+    # and through the module (eval: the custom lookup; with autograd: torch's)
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.detector.layers import BEVFeatureGatherer
+    cfg = second_car_cfg()
+    gat = BEVFeatureGatherer(cfg, torch.tensor(cfg.GRID_BOUNDS[:3]), torch.tensor(cfg.VOXEL_SIZE)).cuda()
+    bev = torch.randn(1, 16, 200, 176, generator=g).cuda()
+    kp = (torch.rand(1, 300, 3, generator=g) * torch.tensor([80.0, 90.0, 4.0]) + torch.tensor([-5.0, -45.0, -3.0])).cuda()
+    with torch.no_grad():
+        fast = gat(bev, kp)
+    slow = gat(bev.requires_grad_(True), kp)
+    torch.testing.assert_close(fast, slow.detach(), rtol=1e-6, atol=1e-6)

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "v3d_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "v3d_ball_query2": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _f, _i, _vp, _vp]),
     "v3d_group_points": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "v3d_bev_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "v3d_sa_mlp_layer": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "v3d_backbone_create": (_i, [_vp, _vp, _vp]),
     "v3d_backbone_destroy": (None, [_vp]),

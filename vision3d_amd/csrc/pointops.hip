@@ -10,6 +10,8 @@
 //     reduction leaves ties unspecified).
 //   * ball query: one WAVE per query (ballot = hit mask, popcount prefix = slot), database points streamed through
 //     LDS tiles shared by the workgroup; first-nsample-in-index-order semantics with first-hit prefill.
+#include <algorithm>
+
 #include "v3d_common.h"
 
 // ------------------------------------------------------------------------------------------ FPS
@@ -520,6 +522,47 @@ extern "C" int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int
   if (!xyz || !new_xyz || !idx) return V3D_EINVAL;
   hipLaunchKernelGGL(ball_query_kernel, dim3(v3d_ceil_div(M, (V3D_BLOCK / V3D_WAVE) * BQ_QPW), B), dim3(V3D_BLOCK), 0, (hipStream_t)stream,
                      xyz, new_xyz, N, M, radius * radius, nsample, idx);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------ bilinear BEV lookup
+// F.grid_sample(feature_map (B, C, H, W), grid (B, 1, K, 2) in [-1, 1], bilinear, zeros padding, align_corners=True) as the
+// BEVFeatureGatherer calls it (vision3d/detector/layers.py:29-47): out (B, C, K).  torch's generic kernel walks the channels of
+// a point serially in one thread (153 us for 2 048 keypoints x 128 channels at 200 x 176); here a thread = (point, channel),
+// same tap order and weights (nw, ne, sw, se; weight = product of the distances to the opposite corner).
+__global__ __launch_bounds__(V3D_BLOCK) void bev_bilinear_kernel(const float* __restrict__ fmap, const float* __restrict__ grid,
+                                                                 int C, int H, int W, int K, long long total,
+                                                                 float* __restrict__ out) {
+  for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * V3D_BLOCK) {
+    const int k = (int)(t % K);
+    const long long bc = t / K;
+    const int b = (int)(bc / C);
+    const float gx = grid[((size_t)b * K + k) * 2], gy = grid[((size_t)b * K + k) * 2 + 1];
+    const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1), iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float nw = ((float)x1 - ix) * ((float)y1 - iy), ne = (ix - x0f) * ((float)y1 - iy);
+    const float sw = ((float)x1 - ix) * (iy - y0f), se = (ix - x0f) * (iy - y0f);
+    const float* plane = fmap + (size_t)bc * H * W;
+    auto tap = [&](int y, int x) { return (y >= 0 && y < H && x >= 0 && x < W) ? plane[(size_t)y * W + x] : 0.f; };
+    float v = 0.f;
+    v += tap(y0, x0) * nw;
+    v += tap(y0, x1) * ne;
+    v += tap(y1, x0) * sw;
+    v += tap(y1, x1) * se;
+    out[t] = v;
+  }
+}
+
+extern "C" int v3d_bev_bilinear(const float* feature_map, const float* grid, int B, int C, int H, int W, int K, float* out,
+                                v3d_stream_t stream) {
+  if (B < 0 || C < 1 || H < 1 || W < 1 || K < 0) return V3D_EINVAL;
+  const long long total = (long long)B * C * K;
+  if (total == 0) return V3D_OK;
+  if (!feature_map || !grid || !out) return V3D_EINVAL;
+  hipLaunchKernelGGL(bev_bilinear_kernel, dim3((int)std::min<long long>(v3d_ceil_div(total, V3D_BLOCK), 8192)), dim3(V3D_BLOCK), 0,
+                     (hipStream_t)stream, feature_map, grid, C, H, W, K, total, out);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }

@@ -59,6 +59,17 @@ class BEVFeatureGatherer(nn.Module):
     def forward(self, feature_map, keypoint_xyz):
         height, width = feature_map.shape[-2:]
         grid = self._to_grid(keypoint_xyz[:, None, :, :2], height, width)
+        if (feature_map.is_cuda and feature_map.dtype == torch.float32 and feature_map.is_contiguous()
+                and not (torch.is_grad_enabled() and (feature_map.requires_grad or grid.requires_grad))):
+            from .. import _lib as L  # the same lookup, a thread per (keypoint, channel): csrc/pointops.hip
+            b, c = feature_map.shape[:2]
+            k = grid.shape[2]
+            g = grid.reshape(b, k, 2).contiguous()
+            out = torch.empty((b, c, k), dtype=torch.float32, device=feature_map.device)
+            with torch.cuda.device(feature_map.device):
+                L.check(L.lib().v3d_bev_bilinear(L.ptr(feature_map), L.ptr(g), b, c, height, width, k, L.ptr(out), L.stream_ptr()),
+                        "bev_bilinear")
+            return out
         return F.grid_sample(feature_map, grid, align_corners=True).squeeze(2)
 
 
