@@ -53,8 +53,8 @@ MAX_PIPELINE = int(os.environ.get("V3D_BENCH_MAX_PIPELINE", "4"))  # slots the a
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (a 50-step window is 16 ms at KITTI size: too short to be stable)")
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (configs[1] = 1)")
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--workload", choices=["kitti", "waymo"], default="kitti",
