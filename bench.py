@@ -21,8 +21,10 @@ Extra objects on that line:
                   stream, vs 8 TB/s; `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/).
   roofline_dense  the 3x3 RPN convolution against the bf16 MFMA peak (every tile convolved, random input).
   cpu_baseline    oracle/ (scalar C sparse path + torch CPU dense path) timed on the host on a bounded sample of the same
-                  workload -- N=1, rank 0 only: 1 thread, and `all_cores` = the same frames on up to 32 single-thread workers;
-                  `cpu_model`, `host_cores` name the box.  Baseline only.
+                  workload -- N=1, rank 0 only: 1 thread, and `all_cores` = one frame per single-thread worker on ALL PHYSICAL cores;
+                  `cpu_model`, `host_cores`, `host_threads` name the box.  Baseline only.
+  value_p10/p90   spread of the per-window throughput over `windows` back-to-back K-step windows (`value` = the median window);
+  with_h2d        the same windows with every step's cloud copied in from pinned host memory (SURVEY 8d timing variant).
 """
 import argparse
 import json
@@ -78,6 +80,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch event timing pass (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (about 1.4 s each on one core: ~11 s)")
+    ap.add_argument("--windows", type=int, default=31,
+                    help="forward mode: back-to-back timed windows of --steps steps each (barrier + synchronize on both sides of every "
+                         "window, pipeline empty at its start, max over ranks per window); `value` is the MEDIAN window, "
+                         "value_p10 / value_p90 the spread.  The count is cut down so that the windows take at most ~20 s")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the with_h2d line (pinned host cloud copied in every step)")
     return ap.parse_args()
 
 
@@ -295,9 +302,28 @@ def _cpu_frame(job):
     return time.perf_counter() - c0
 
 
-def run_cpu_baseline(model, cfg, anchors, make, args):
-    """cpu_baseline object: the CPU restatement timed on the host of THIS box -- one thread (value) and all cores (one frame
-    per worker process, one thread each: frames are independent, so that is how a CPU deployment would use its cores)."""
+def physical_cores():
+    """(physical cores available to this process, hardware threads available): distinct (package, core id) pairs of the CPUs in the
+    affinity mask, from /proc/cpuinfo; falls back to the thread count."""
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    try:
+        cores, cur = {}, {}
+        for ln in list(open("/proc/cpuinfo")) + [""]:
+            if ":" in ln:
+                k, v = ln.split(":", 1)
+                cur[k.strip()] = v.strip()
+            elif cur:
+                cores[int(cur["processor"])] = (cur.get("physical id", "0"), cur.get("core id", cur["processor"]))
+                cur = {}
+        phys = len({cores[c] for c in avail if c in cores})
+        return max(1, phys), len(avail)
+    except (OSError, KeyError, ValueError):
+        return len(avail), len(avail)
+
+
+def run_cpu_baseline(model, cfg, anchors, make, args, workload="kitti"):
+    """cpu_baseline object: the CPU restatement timed on the host of THIS box -- one thread (value) and ALL PHYSICAL CORES (one
+    frame per single-thread worker process: frames are independent, so that is how a CPU deployment would use its cores)."""
     import multiprocessing as mp
     cpu_model = "unknown"
     try:
@@ -307,29 +333,34 @@ def run_cpu_baseline(model, cfg, anchors, make, args):
                 break
     except OSError:
         pass
-    n_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_phys, n_threads = physical_cores()
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     cfgd = dict(VOXEL_SIZE=list(cfg.VOXEL_SIZE), GRID_BOUNDS=list(cfg.GRID_BOUNDS), MAX_OCCUPANCY=cfg.MAX_OCCUPANCY,
                 MAX_VOXELS=cfg.MAX_VOXELS, TOPK=cfg.PROPOSAL.TOPK, THRESH=[a["score_thresh"] for a in cfg.ANCHORS])
     anc = anchors.cpu().numpy()
     n_frames, t_cpu = 0, 0.0
-    while n_frames < args.cpu_frames and t_cpu < 30.0:
-        t_cpu += _cpu_frame((sd, 100 + n_frames, args.points, cfgd, anc, "kitti"))
+    while n_frames < args.cpu_frames and t_cpu < (20.0 if workload == "kitti" else 1.0):
+        t_cpu += _cpu_frame((sd, 100 + n_frames, args.points, cfgd, anc, workload))
         n_frames += 1
-    out = dict(value=n_frames / t_cpu, unit="frames/s", cores=1, kind="port", cpu_model=cpu_model, host_cores=n_cores,
-               sample=f"{n_frames} frame(s) of the same 16k-pt workload, oracle/ (scalar C sparse path + torch CPU dense path, "
-                      f"1 thread), {t_cpu:.1f} s")
-    workers = max(1, min(n_cores, 32))
+    out = dict(value=n_frames / t_cpu, unit="frames/s", cores=1, kind="port", cpu_model=cpu_model, host_cores=n_phys,
+               host_threads=n_threads,
+               sample=f"{n_frames} frame(s) of the same {args.points}-pt workload, oracle/ (scalar C sparse path + torch CPU dense "
+                      f"path, 1 thread), {t_cpu:.1f} s")
+    workers = n_phys
+    per_frame = t_cpu / n_frames
+    if per_frame > 30.0:  # bounded sample: a frame that takes this long is not repeated on every core
+        out["all_cores"] = dict(value=None, note=f"skipped: one frame takes {per_frame:.0f} s on one thread")
+        return out
     try:
         ctx = mp.get_context("spawn")
-        jobs = [(sd, 200 + i, args.points, cfgd, anc, "kitti") for i in range(workers)]
+        jobs = [(sd, 200 + i, args.points, cfgd, anc, workload) for i in range(workers)]
         w0 = time.perf_counter()
         with ctx.Pool(workers) as pool:
-            per = pool.map(_cpu_frame, jobs)
+            per = pool.map(_cpu_frame, jobs, chunksize=1)
         wall = time.perf_counter() - w0
         out["all_cores"] = dict(value=workers / max(per), unit="frames/s", cores=workers,
-                                sample=f"{workers} frames in {workers} single-thread worker processes, slowest frame {max(per):.2f} s "
-                                       f"(wall incl. process start {wall:.1f} s)")
+                                sample=f"{workers} frames in {workers} single-thread worker processes (= all physical cores), "
+                                       f"slowest frame {max(per):.2f} s, fastest {min(per):.2f} s (wall incl. process start {wall:.1f} s)")
     except Exception as e:  # the 1-thread figure stands on its own
         out["all_cores"] = dict(value=None, error=str(e)[:200])
     return out
@@ -410,24 +441,68 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    pipelined = args.pipeline != 1 and args.path == "graph"
+    n_ranks_seen = world
+    if world > 1:  # the collective really spans `world` ranks (RCCL): all-reduce of ones
+        ones = torch.ones(1, device=REDUCE_DEVICE)
+        dist.all_reduce(ones)
+        n_ranks_seen = int(ones.item())
+
+    def window(src, steps):
+        """One timed window: EXACTLY `steps` steps, barrier + synchronize on both sides, pipeline empty at its start; the frames
+        still in flight after the last submit are collected inside the window (steps == frames)."""
+        nonlocal stream
+        keep, stream = stream, src
+        if pipelined:
+            graphed.flush()
+        fence()
+        t0 = time.perf_counter()
+        o = None
+        for _ in range(steps):
+            o = step()
+        if pipelined:
+            rest = graphed.flush()
+            o = rest[-1] if rest else last_out[0]
+        fence()
+        dt = time.perf_counter() - t0
+        stream = keep
+        return dt, o
+
+    def windows(src, steps, count):
+        """`count` back-to-back windows; returns (per-window seconds as max over ranks, last output)."""
+        ts, o = [], None
+        for _ in range(count):
+            dt, o = window(src, steps)
+            ts.append(dt)
+        if world > 1:
+            t = torch.tensor(ts, dtype=torch.float64, device=REDUCE_DEVICE)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ts = [float(x) for x in t.tolist()]
+        return ts, o
+
     for _ in range(args.warmup):
         out = step()
-    pipelined = args.pipeline != 1 and args.path == "graph"
-    if pipelined:
-        graphed.flush()  # the timed region starts with an empty pipeline
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    if pipelined:
-        # K steps submitted K frames; the ones still in flight are collected inside the timed region: steps == frames
-        rest = graphed.flush()
-        out = rest[-1] if rest else last_out[0]
-    fence()
-    elapsed = time.perf_counter() - t0
-    elapsed = dist_util.max_over_ranks(elapsed, world, device=REDUCE_DEVICE)
+    first, out = windows(stream, args.steps, 1)  # also sizes the window count (same on every rank: max-reduced)
+    n_win = max(5, min(args.windows, int(20.0 / max(first[0], 1e-6)))) if args.windows > 1 else 1
+    rest_t, out2 = windows(stream, args.steps, n_win - 1) if n_win > 1 else ([], None)
+    out = out2 if out2 is not None else out
+    win_t = np.sort(np.asarray(first + rest_t))
+    elapsed = float(np.median(win_t))
     frames = world * args.steps * args.batch
     value = frames / elapsed
+    spread = dict(windows=int(len(win_t)), value_p10=frames / float(np.percentile(win_t, 90)),
+                  value_p90=frames / float(np.percentile(win_t, 10)), value_min=frames / float(win_t[-1]),
+                  value_max=frames / float(win_t[0]), value_first_window=frames / first[0])
+    # SURVEY 8(d) timing variant "with H->D copy": the same windows with every step's cloud copied from PINNED host memory into
+    # the slot's static buffer on the slot's stream (256 KB per KITTI frame); never part of `value`
+    with_h2d = None
+    if args.path == "graph" and not args.no_h2d:
+        pinned = [[torch.from_numpy(c).pin_memory() for c in frame] for frame in stream_np]
+        h_t, _ = windows(pinned, args.steps, max(3, min(n_win, 11)))
+        h_med = float(np.median(h_t))
+        with_h2d = dict(value=frames / h_med, unit="frames/s", ms_per_step=1e3 * h_med / args.steps, windows=len(h_t),
+                        bytes_per_frame=int(sum(c.nbytes for c in stream_np[0])),
+                        note="pinned host cloud -> device static buffer (async copy on the frame's stream) inside every step")
     # one frame at a time through the same captured graph (latency view of the same work), not part of `value`
     single_ms = None
     if args.path == "graph":
@@ -566,8 +641,11 @@ def main():
                       layers=[{k: (round(v, 2) if isinstance(v, float) else v) for k, v in l.items()} for l in layers])
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not waymo:
-        cpu_baseline = run_cpu_baseline(model, cfg, anchors, make, args)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu_baseline = run_cpu_baseline(model, cfg, anchors, make, args, "waymo" if waymo else "kitti")
+        except Exception as e:  # the baseline is a reported extra: never lose the bench line over it
+            cpu_baseline = dict(value=None, unit="frames/s", error=f"{type(e).__name__}: {str(e)[:200]}")
 
     if rank == 0:
         wl = ("SECOND forward, bs=1, 180000-pt synthetic Waymo-range sweep per GPU, 0.05 m voxels over +-75.2 m "
@@ -575,6 +653,8 @@ def main():
                                                       "synthetic KITTI-range cloud per GPU (BASELINE configs[1])")
         line = dict(metric=("frames/sec SECOND fwd, 180k-pt Waymo-range sweep" if waymo else "frames/sec SECOND fwd, 16k-pt KITTI cloud"), value=value, unit="frames/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
+                    value_is="median over `windows` back-to-back timed windows of `steps` steps each (each window: barrier + "
+                             "synchronize on both sides, empty pipeline at its start, max over ranks)",
                     scaling="weak", vs_baseline=None, dtype="bf16x3 (fp32 operands split hi+lo, 3 bf16 MFMAs, fp32 accumulate: fp32-class, parity 1e-4)", data="synthetic",
                     config=dict(workload=wl,
                                 frames_per_gpu_per_step=args.batch, points_per_frame=args.points,
@@ -585,6 +665,7 @@ def main():
                                                "frame" + (f", {graphed.depth} frames in flight" if pipelined else ""),
                                       "native": "native backbone plan + bf16x3 MFMA dense head", "fused": "native backbone plan + torch RPN",
                                       "eager": "eager python -> C ABI"}[args.path]),
+                    **spread, with_h2d=with_h2d, n_ranks_seen=n_ranks_seen,
                     single_frame_ms=single_ms,
                     frames_per_s_one_at_a_time=(world * args.batch * 1e3 / single_ms) if single_ms else None,
                     roofline=roofline, cpu_baseline=cpu_baseline, roofline_dense=roofline_dense, stages=stages,

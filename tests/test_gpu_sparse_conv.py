@@ -77,14 +77,17 @@ def test_strided_conv_forward_ragged_tail(oracle, algo):
         assert_features_close(got, oracle.sparse_conv_fwd(feats, w, onbr, relu=True), f"strided {cin}->{cout} algo {algo}")
 
 
-@pytest.mark.parametrize("variant", [1, 5, 10], ids=["16rows", "64rows_lds_weights", "lds_ring"])
+@pytest.mark.parametrize("variant", [1, 5, 6, 7, 10, 16],
+                         ids=["16rows", "64rows_lds_weights", "offset_outer_staged", "offset_outer_regs", "lds_ring", "lds_ring_regs"])
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 32), (64, 64)])
 def test_packed_kernel_variants(oracle, cin, cout, variant):
     """Every kernel of the packed (algo 4) product -- the 16-row kernel, the two-tile LDS-ring kernel (3x3x3, the default
-    up to 16 k rows: wave-specialised weight movers, three LDS round buffers) and the 64-row LDS-shared-weights kernel (the
-    default from 32 k rows) -- forced on a small problem through the per-call variant argument (a negative rows_hint at
-    the C ABI; the library has no global switch): same result as the oracle, ragged tail (5003 rows: a half-empty last
-    workgroup), fused affine + ReLU, submanifold and strided (3,1,1) tables."""
+    up to 16 k rows: wave-specialised weight movers; in the form chosen per shape -- rows staged through LDS by
+    row-contiguous LDS-DMA for 64->64 and 32->32 -- and in its register-gather form), the 64-row LDS-shared-weights kernel
+    and the offset-outer persistent kernel (the 64->64 default from 32 k rows; staged and register forms) -- forced on a
+    small problem through the per-call variant argument (a negative rows_hint at the C ABI; the library has no global
+    switch): same result as the oracle, ragged tail (5003 rows: a half-empty last workgroup / pass), fused affine + ReLU,
+    submanifold and strided (3,1,1) tables."""
     from vision3d_amd.spconv.conv import build_sparse_rulebook, build_subm_rulebook, sparse_conv_forward
     rng = np.random.default_rng(cin + cout + variant)
     coords = kitti_coords(oracle, [5])[:5003]

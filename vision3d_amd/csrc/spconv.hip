@@ -647,6 +647,243 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __
   }
 }
 
+__device__ __attribute__((aligned(256))) const float spr_zero_row[128] = {};
+
+// Large-N variant, offset-outer ("k-outer") and persistent: the answer to the weight re-stream of the kernel above (875
+// workgroups x 442 KB = 387 MB per launch at 56 k rows).  A workgroup of 8 waves (two per SIMD) owns 8 * T consecutive 16-row
+// tiles per pass and walks the K offsets ONCE for all of them: W[k] crosses L2 -> LDS once per pass (global -> registers ->
+// ds_write, double buffered: 2 x 16 KB), every wave reads the offset's fragments from LDS once into registers and applies them
+// to its T tiles (accumulators T x NB f32x4 stay in registers for the whole pass).  Neighbour indices and gathered rows are
+// prefetched through registers (index two offsets ahead, rows one offset ahead); nothing but the weights touches LDS.
+// All fragment reads of an offset are issued before its first MFMA and the MFMAs are ordered term-major over the NB
+// accumulators (sched_group_barrier): left alone the scheduler emitted read -> wait -> three DEPENDENT MFMAs per fragment.
+// Grid = min(passes, 256) workgroups, pass -> rows XCD-contiguous.
+// The loads of the offset loop are HAND-ISSUED (inline asm) and hand-counted.  With plain C++ loads the compiler (ROCm 7.2)
+// (a) sank the row gathers behind the step's MFMAs, (b) turned "load, then select" into a conditional load and (c) -- taking the
+// conservative merge of outstanding-load counts at every branch join -- waited for loads issued IN the step: one memory round
+// trip per offset (64 us at 56 k rows, 33 us with the gathers removed).  Here every step issues the same loads in the same
+// order -- next weights, indices two offsets ahead, rows one offset ahead -- and every consumer sits behind
+// `vm_wait_tie<N>(regs)`: s_waitcnt vmcnt(N) with the registers named as in/out operands, so no use can be scheduled above
+// its wait.  Loads return in order, so "all but the newest N have landed" is exact; compiler-issued memory operations in
+// between can only make a wait more conservative.  Addresses are clamped, results masked afterwards (no branch).
+__device__ __forceinline__ void asm_gld16(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void asm_gld16_16(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void asm_gld16_128(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void asm_gld16_144(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off offset:144" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void asm_gld4(int& d, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+template <int N> __device__ __forceinline__ void vm_wait_tie(f32x4 (&a)[2]) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void vm_wait_tie(f32x4 (&a)[4]) { asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void vm_wait_tie(f32x4 (&a)[8]) {
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void vm_wait_tie(f32x4 (&a)[1]) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a[0]) : "n"(N) : "memory"); }
+// (the same, additionally ordered behind the instruction that produces `after`: e.g. the last MFMA of a step)
+template <int N> __device__ __forceinline__ void vm_wait_tie_after(f32x4 (&a)[1], f32x4& after) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(after) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void vm_wait_tie_after(f32x4 (&a)[2], f32x4& after) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(after) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void vm_wait_tie(int (&a)[1]) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a[0]) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void vm_wait_tie(int (&a)[2]) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(N) : "memory"); }
+
+__device__ __forceinline__ void asm_gld16_64(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void asm_gld16_192(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off offset:192" : "=v"(d) : "v"(p) : "memory"); }
+// LDS-DMA of one 16-byte piece per lane: global address per lane, LDS destination = wave-uniform `lds_dst` + lane * 16 (M0 is
+// compiler-reserved: saved and restored inside the statement).  No register destination: completion = the wave's vmcnt.
+__device__ __forceinline__ void asm_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// LDS byte address of a __shared__ object: the low half of its generic address (flat aperture base in the high half)
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(unsigned long long)p; }
+
+// STAGE = 1: the gathered rows go through LDS.  What a row gather costs is set by the CU's address/tag pipe, not by bytes
+// (tools/mb_gather.hip): in the MFMA operand layout the four lanes of a quad read four DIFFERENT rows -- 64 tag look-ups per
+// instruction, 113 ns per 16-row x 256-byte gather per CU whatever the rows are -- while quads that read 64 contiguous bytes of
+// ONE row cost 39 ns, and quads of an absent neighbour (the zero row) next to nothing.  So the rows are fetched row-contiguous
+// (lane -> row lane >> 2, 16-byte chunk (lane & 3) ^ swizzle) by LDS-DMA into a 4 KB slot per (wave, tile) and the MFMA
+// fragments are read back with ds_read_b128 (the swizzle (row >> 3) & 1 makes those reads conflict-free).  One slot per tile is
+// enough: the fragments of offset k are in registers before the requests of k + 1 overwrite the slot piece by piece, each piece
+// behind the MFMA group that consumed it.
+template <int CIN, int COUT, int T, int K, int STAGE = 1, int DBG = 0>  // DBG 4 (experiment, wrong results): quad-coalesced register gathers
+__global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __restrict__ in,
+                                                              const unsigned short* __restrict__ wimg,
+                                                              const int* __restrict__ nbr, const int* __restrict__ n_ptr,
+                                                              int cap, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int relu,
+                                                              float* __restrict__ out) {
+  static_assert(CIN % 32 == 0 && CIN <= 64 && (T == 1 || T == 2), "shape not covered by the offset-outer kernel");
+  constexpr int KI = CIN / 32, NB = COUT / 16, NW = 8;
+  constexpr int NF = KI * NB * 2;                 // 1 KB weight fragments per offset
+  constexpr int WBYTES = NF * 1024;               // one W[k] image
+  constexpr int WPT = (WBYTES + NW * 64 * 16 - 1) / (NW * 64 * 16);  // 16-byte pieces per thread per offset
+  constexpr int G = T * KI * 2;                   // row-gather loads per step and lane
+  static_assert(WPT == 1 || WPT == 2, "weight image / workgroup shape");
+  __shared__ __attribute__((aligned(16))) unsigned char wbuf[2][WBYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char aslot[STAGE ? NW * T * CIN * 64 : 16];  // [wave][tile][piece][16 rows][64 B]
+  const int n = min(*n_ptr, cap);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, kg = lane >> 4;
+  const int rows_per_pass = 16 * T * NW;
+  const int npass = (n + rows_per_pass - 1) / rows_per_pass;
+
+  f32x4 wreg[WPT];
+  auto issue_w = [&](int k) {  // (threads beyond a small image re-read its last piece: no branch)
+    const f32x4* wp = reinterpret_cast<const f32x4*>(wimg) + (size_t)min(k, K - 1) * NF * 64;
+#pragma unroll
+    for (int i = 0; i < WPT; i++) asm_gld16(wreg[i], wp + min(i * NW * 64 + tid, NF * 64 - 1));
+  };
+  auto store_w = [&](int buf) {
+    f32x4* dst = reinterpret_cast<f32x4*>(wbuf[buf]) + tid;
+#pragma unroll
+    for (int i = 0; i < WPT; i++)
+      if ((i * NW * 64 + tid) * 16 < WBYTES) dst[(size_t)i * NW * 64] = wreg[i];
+  };
+
+  for (int v = blockIdx.x; v < npass; v += gridDim.x) {
+    int pass;
+    {  // each XCD (private L2; workgroup b runs on XCD b % 8, gridDim.x is a multiple of 8) walks one contiguous run of rows
+      const int q = npass / 8, rmd = npass % 8, xcd = v % 8, idx = v / 8;
+      pass = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;  // bijective on [0, npass)
+    }
+    const int row0 = (pass * NW + wave) * T * 16;  // first row of this wave's T tiles
+    int src[2][T];
+    auto issue_idx = [&](int k, int (&dst)[T]) {
+#pragma unroll
+      for (int t = 0; t < T; t++)
+        asm_gld4(dst[t], nbr + (size_t)min(k, K - 1) * cap + min(row0 + t * 16 + (STAGE ? (lane >> 2) : r), cap - 1));
+    };
+    f32x4 araw[STAGE ? 1 : 2][G];
+    const float* prow[T];  // this lane's slice of the rows being requested
+    auto row_ptrs = [&](int k, const int (&sidx)[T]) {  // sidx = the (landed) indices of offset k
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        int sq = (k < K && row0 + t * 16 + (STAGE ? (lane >> 2) : r) < n) ? sidx[t] : -1;
+        if (DBG & 4) sq = __shfl(sq, lane >> 2);
+        prow[t] = (sq >= 0 ? in + (size_t)sq * CIN : spr_zero_row) +
+                  (STAGE ? ((lane & 3) ^ ((lane >> 5) & 1)) * 4 : ((DBG & 4) ? (lane & 3) * 4 : kg * 8));
+      }
+    };
+    const unsigned slot0 = STAGE ? __builtin_amdgcn_readfirstlane(lds_addr_of(aslot) + wave * (T * CIN * 64)) : 0u;
+    auto issue_chunk = [&](int t, int ki, f32x4 (&a)[G]) {  // the two loads of (tile t, channel block ki)
+      if constexpr (STAGE) {
+        asm_dma16(prow[t] + (ki * 2) * 16, slot0 + t * (CIN * 64) + (ki * 2) * 1024);
+        asm_dma16(prow[t] + (ki * 2 + 1) * 16, slot0 + t * (CIN * 64) + (ki * 2 + 1) * 1024);
+      } else if (ki == 0) {
+        asm_gld16(a[t * KI * 2], prow[t]);
+        if (DBG & 4) asm_gld16_64(a[t * KI * 2 + 1], prow[t]); else asm_gld16_16(a[t * KI * 2 + 1], prow[t]);
+      } else {
+        asm_gld16_128(a[t * KI * 2 + 2], prow[t]);
+        if (DBG & 4) asm_gld16_192(a[t * KI * 2 + 3], prow[t]); else asm_gld16_144(a[t * KI * 2 + 3], prow[t]);
+      }
+    };
+    f32x4 acc[T][NB];
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+      for (int j = 0; j < NB; j++) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // one offset: rows of k are in araw[cur] (requested during the previous step), indices of k + 1 in src[cur ^ 1].
+    // The row requests of k + 1 are ISSUED BETWEEN THE MFMA GROUPS of k (two loads behind every 3 NB MFMAs): a wave whose
+    // vector-memory instruction waits for a slot in the CU's address pipe cannot issue anything else, so twelve loads in a row
+    // at the top of the step stalled every wave of the workgroup at the same time (measured: gather time ADDED to the MFMA time
+    // instead of hiding behind it); spread out, the stall of one wave overlaps the matrix work of the other wave on its SIMD.
+    auto step = [&](int k, int cur) {
+      issue_idx(k + 2, src[cur]);              // [T]
+      issue_w(k + 1);                          // [WPT]
+      if constexpr (!STAGE) vm_wait_tie<T + WPT>(araw[cur]);  // rows of k (and, older still, the indices of k + 1)
+      vm_wait_tie<T + WPT>(src[cur ^ 1]);
+      row_ptrs(k + 1, src[cur ^ 1]);
+      if constexpr (STAGE) {  // this wave's slots hold the rows of k: fragments into registers
+        const unsigned char* sl = aslot + wave * (T * CIN * 64) + ((kg >> 1) * 1024 + r * 64);
+        const int sw = (r >> 3) & 1;
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+          for (int ki = 0; ki < KI; ki++)
+#pragma unroll
+            for (int v = 0; v < 2; v++)
+              araw[0][(t * KI + ki) * 2 + v] =
+                  *reinterpret_cast<const f32x4*>(sl + t * (CIN * 64) + ki * 2048 + ((((kg & 1) * 2 + v) ^ sw) * 16));
+      }
+      const bf16x8_t* bw = reinterpret_cast<const bf16x8_t*>(wbuf[cur]) + lane;
+      bf16x8_t bh[KI][NB], bl[KI][NB];
+#pragma unroll
+      for (int ki = 0; ki < KI; ki++)
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+          bh[ki][j] = bw[(size_t)((ki * NB + j) * 2) * 64];
+          bl[ki][j] = bw[(size_t)((ki * NB + j) * 2 + 1) * 64];
+        }
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+#pragma unroll
+        for (int ki = 0; ki < KI; ki++) {
+          const f32x4 v0 = araw[STAGE ? 0 : cur][(t * KI + ki) * 2], v1 = araw[STAGE ? 0 : cur][(t * KI + ki) * 2 + 1];
+          const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          bf16x8_t ah, am, al;
+          split_act(x, ah, am, al);
+#pragma unroll
+          for (int j = 0; j < NB; j++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ki][j], acc[t][j], 0, 0, 0);  // smallest terms first
+          if constexpr (SPC_TERMS == 4) {
+#pragma unroll
+            for (int j = 0; j < NB; j++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[ki][j], acc[t][j], 0, 0, 0);
+          }
+#pragma unroll
+          for (int j = 0; j < NB; j++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ki][j], acc[t][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < NB; j++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ki][j], acc[t][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          issue_chunk(t, ki, araw[STAGE ? 0 : cur ^ 1]);   // [2]  (STAGE: overwrites the slot piece this MFMA group consumed)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      vm_wait_tie_after<G>(wreg, acc[T - 1][NB - 1]);  // W[k + 1]: asked for only once the step's MFMAs are issued
+      store_w(cur ^ 1);
+      __syncthreads();
+    };
+
+    issue_idx(0, src[0]);
+    issue_idx(1, src[1]);
+    issue_w(0);
+    vm_wait_tie<T + WPT>(src[0]);
+    row_ptrs(0, src[0]);
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+      for (int ki = 0; ki < KI; ki++) issue_chunk(t, ki, araw[0]);
+    vm_wait_tie<G>(wreg);
+    store_w(0);
+    __syncthreads();  // W[0] in place (and every wave is done with the previous pass's buffers)
+    // two offsets per trip (the two register sets alternate); an odd K is padded by one offset whose rows are all absent
+    // (3.7 % more MFMAs at K = 27, and not one branch in the loop)
+#pragma unroll 1
+    for (int k = 0; k < K; k += 2) {
+      step(k, 0);
+      step(k + 1, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the padded prefetches of the last step
+    // epilogue straight from the accumulators: D[row = kg*4 + rr][col = j*16 + r] of each of this wave's tiles
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        const int col = j * 16 + r;
+        const float sc = scale ? scale[col] : 1.f, sh = scale ? shift[col] : 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int row = row0 + t * 16 + kg * 4 + rr;
+          if (row < n) {
+            float vv = acc[t][j][rr];
+            if (scale) vv = vv * sc + sh;
+            if (relu) vv = fmaxf(vv, 0.f);
+            out[(size_t)row * COUT + col] = vv;
+          }
+        }
+      }
+  }
+}
+
 // Mid-size variant for K = 27 (3x3x3), the KITTI bs = 1 operating point.  The cycle-counter timeline of the 16-row
 // kernel (tools/mb_rows_timeline.py, -DSPR_TIMELINE=1) shows it bound by the CU's 64 B/clk vector-memory path:
 // every wave pulls its own 16 KB W[k] image plus 4 KB of gathered rows per offset -- 1.08 MB per CU per launch at
@@ -666,10 +903,11 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __
 //          multipliers: gather(r+2), multiply(r) from buffer r%3.
 // Two rounds of weights are in flight while one multiplies.  Absent neighbours gather a row of zeros (branch-free:
 // the vmcnt bookkeeping needs a fixed number of loads per round).
-__device__ __attribute__((aligned(256))) const float spr_zero_row[128] = {};
 
-template <int CIN, int COUT, int OG>
-__global__ __launch_bounds__((2 * OG + 2) * 64) void spconv_fwd_rows_ring(const float* __restrict__ in,
+// STAGE = 1 (see spconv_fwd_rows_kouter): gathered rows fetched row-contiguous by LDS-DMA into ALOOK 4 KB slots per multiplying
+// wave, MFMA fragments read back from LDS.
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int DBG = 0>  // DBG (experiments, wrong results): 1 no gathers, 2 no weight DMA, 3 neither
+__global__ __launch_bounds__((2 * OG + NMV) * 64) void spconv_fwd_rows_ring(const float* __restrict__ in,
                                                                           const unsigned short* __restrict__ wimg,
                                                                           const int* __restrict__ nbr,
                                                                           const int* __restrict__ n_ptr, int cap,
@@ -682,8 +920,9 @@ __global__ __launch_bounds__((2 * OG + 2) * 64) void spconv_fwd_rows_ring(const 
   // is mostly its barrier and the LDS read burst behind it, not the matrix pipe, so fewer, longer rounds win.  Also
   // tried and dropped: splitting (R, ki+1) while the MFMAs of (R, ki) run, with and without sched_group_barrier
   // interleave (12.9 / 13.2 us).  Only OG = 3 is instantiated.
-  constexpr int K = 27, TILES = 2, ROUNDS = (K + OG - 1) / OG, NCW = TILES * OG, NMV = 2;
-  constexpr int NBUF = OG == 2 ? 4 : 3, LOOK = NBUF - 1;  // rounds of weights / gathered rows in flight ahead of the multiply
+  constexpr int K = 27, TILES = 2, ROUNDS = (K + OG - 1) / OG, NCW = TILES * OG;
+  constexpr int LOOK = NBUF - 1;  // rounds of weights in flight ahead of the multiply
+  constexpr int ABUF = ALOOK + 1;  // ALOOK rounds of gathered rows in flight ahead of the multiply (registers)
   constexpr int KI = CIN / 32, NB = COUT / 16;
   constexpr int NF = KI * NB * 2;          // 1 KB weight fragments per offset
   constexpr int WBYTES = NF * 1024;        // one W[k] image
@@ -692,11 +931,13 @@ __global__ __launch_bounds__((2 * OG + 2) * 64) void spconv_fwd_rows_ring(const 
   constexpr int NSTG = (ROUNDS + 3) / 4;   // neighbour-table entries a multiplier lane stages
   static_assert(CIN % 32 == 0 && CIN <= 128 && (OG * NF) % NMV == 0 && (LOOK - 1) * FPM < 64, "shape not covered by the ring kernel");
   static_assert(RB >= TILES * OG * NB * 4 * 64 * 4, "partials must fit one round buffer");
+  static_assert(ALOOK >= 1 && ALOOK <= 4 && (ALOOK * KI * 2 <= 8 || ALOOK * KI * 2 == 12 || ALOOK * KI * 2 == 16), "gather look-ahead");
   __shared__ __attribute__((aligned(16))) unsigned char wb0[RB];
   __shared__ __attribute__((aligned(16))) unsigned char wb1[RB];
-  __shared__ __attribute__((aligned(16))) unsigned char wb2[RB];
+  __shared__ __attribute__((aligned(16))) unsigned char wb2[NBUF >= 3 ? RB : 16];
   __shared__ __attribute__((aligned(16))) unsigned char wb3[NBUF == 4 ? RB : 16];
   __shared__ int nbr_all[TILES * K * 16];
+  __shared__ __attribute__((aligned(16))) unsigned char aslot[STAGE ? NCW * ALOOK * CIN * 64 : 16];  // [wave][slot][piece][16 rows][64 B]
 #define SPR_RING(i) ((i) % NBUF == 0 ? wb0 : ((i) % NBUF == 1 ? wb1 : ((i) % NBUF == 2 ? wb2 : wb3)))
   const int n = min(*n_ptr, cap);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -723,7 +964,7 @@ __global__ __launch_bounds__((2 * OG + 2) * 64) void spconv_fwd_rows_ring(const 
     const unsigned char* gsrc = wsrc + (size_t)(R) * RB;                                                            \
     _Pragma("unroll") for (int i = 0; i < FPM; i++) {                                                               \
       const bool ok = (R) * OG + (mv * FPM + i) / NF < K;                                                           \
-      __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + i * 1024 - (ok ? 0 : WBYTES)),                               \
+      if (!(DBG & 2)) __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + i * 1024 - (ok ? 0 : WBYTES)),                               \
                                        (lptr_t)(SPR_RING(R) + (mv * FPM + i) * 1024), 16, 0, 0);                    \
     }                                                                                                               \
   }
@@ -750,77 +991,141 @@ __global__ __launch_bounds__((2 * OG + 2) * 64) void spconv_fwd_rows_ring(const 
   int* nbr_s = nbr_all + t * K * 16;
   const int row0 = (wg * TILES + t) * 16;
   const int r = lane & 15, kg = lane >> 4;
-  typedef const __attribute__((address_space(1))) f32x4* gf4_t;  // keeps the gathers global_load (a generic select would be flat_load)
-  float araw[NBUF][KI][8];
+  // Gathered rows: hand-issued loads (asm_gld16*), hand-counted waits (vm_wait_tie) -- see spconv_fwd_rows_kouter.  The
+  // rows of round R + ALOOK are requested at the TOP of round R from an index that was read out of LDS one round earlier
+  // (left to the compiler the gathers sank behind the round's MFMAs: the index read, its wait and the address arithmetic
+  // sat in front of them).  ALOOK rounds of rows stay in flight across the round barrier.
+  f32x4 araw[STAGE ? 1 : ABUF][KI * 2];
   f32x4 acc[NB];
 #pragma unroll
   for (int j = 0; j < NB; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#define SPR_GATHER(R, SRC)                                                                                       \
-  {                                                                                                              \
-    const int src = (SRC);                                                                                       \
-    const gf4_t prow = (src >= 0 ? (gf4_t)(in + (size_t)src * CIN) : (gf4_t)spr_zero_row) + kg * 2;              \
-    _Pragma("unroll") for (int ki = 0; ki < KI; ki++) {                                                          \
-      const f32x4 v0 = prow[ki * 8], v1 = prow[ki * 8 + 1];                                                      \
-      float* a = araw[(R) % NBUF][ki];                                                                           \
-      a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;    \
-    }                                                                                                            \
-  }
+  const int rsel = STAGE ? (lane >> 2) : r;  // the tile row whose index this lane holds: its MFMA row / its DMA row
+  const float* prow = spr_zero_row;  // this lane's slice of the row being requested
+  auto row_ptr = [&](int src_i) {
+    const int src = (DBG & 1) ? -1 : src_i;
+    prow = (src >= 0 ? in + (size_t)src * CIN : spr_zero_row) + (STAGE ? ((lane & 3) ^ ((lane >> 5) & 1)) * 4 : kg * 8);
+  };
+  const unsigned slot0 = STAGE ? __builtin_amdgcn_readfirstlane(lds_addr_of(aslot) + wv * (ALOOK * CIN * 64)) : 0u;
+  auto issue_chunk = [&](int ki, int Rr) {  // the two requests of channel block ki for round Rr
+    if constexpr (STAGE) {
+      asm_dma16(prow + (ki * 2) * 16, slot0 + (Rr % ALOOK) * (CIN * 64) + (ki * 2) * 1024);
+      asm_dma16(prow + (ki * 2 + 1) * 16, slot0 + (Rr % ALOOK) * (CIN * 64) + (ki * 2 + 1) * 1024);
+    } else {
+      f32x4 (&a)[KI * 2] = araw[Rr % ABUF];
+      if (ki == 0) {
+        asm_gld16(a[0], prow);
+        asm_gld16_16(a[1], prow);
+      } else {
+        asm_gld16_128(a[2], prow);
+        asm_gld16_144(a[3], prow);
+      }
+    }
+  };
+  int nsrc = -1;  // index of the round whose rows are requested next
   {
-    // entries of the first LOOK rounds straight from global (the first gathers do not wait for the staging barrier),
-    // then this wave's share of the tile's table for the later rounds: offsets k = g, g + OG, ... x 16 rows, a quarter
-    // of the rounds per 16-lane group
+    // entries of the first ALOOK rounds straight from global (the first gathers do not wait for the staging), then this
+    // wave's share of the tile's table for the later rounds: offsets k = g, g + OG, ... x 16 rows, a quarter of the rounds
+    // per 16-lane group.  The table of (tile, offset group) is written AND read by this wave only.
     const bool live = row0 + r < n;
-    int first[LOOK], stage[NSTG];
+    int first[ALOOK], stage[NSTG];
 #pragma unroll
-    for (int i = 0; i < LOOK; i++) first[i] = (live && i * OG + g < K) ? nbr[(size_t)(i * OG + g) * cap + row0 + r] : -1;
+    for (int i = 0; i < ALOOK; i++) first[i] = (row0 + rsel < n && i * OG + g < K) ? nbr[(size_t)(i * OG + g) * cap + row0 + rsel] : -1;
 #pragma unroll
     for (int i = 0; i < NSTG; i++) {
       const int kk = (kg + 4 * i) * OG + g;
       stage[i] = (live && kk < K) ? nbr[(size_t)kk * cap + row0 + r] : -1;
     }
 #pragma unroll
-    for (int i = 0; i < LOOK; i++) SPR_GATHER(i, first[i])
+    for (int i = 0; i < ALOOK; i++) {
+      row_ptr(first[i]);
+#pragma unroll
+      for (int ki = 0; ki < KI; ki++) issue_chunk(ki, i);
+    }
 #pragma unroll
     for (int i = 0; i < NSTG; i++)
       if ((kg + 4 * i) * OG + g < K) nbr_s[((kg + 4 * i) * OG + g) * 16 + r] = stage[i];
+    if (ALOOK < ROUNDS && ALOOK * OG + g < K) nsrc = nbr_s[(ALOOK * OG + g) * 16 + rsel];
   }
   SPR_STAMP(1);
 #pragma unroll
   for (int R = 0; R < ROUNDS; R++) {
-    // (round 0: also "the tile's neighbour table is staged" -- hence the lgkmcnt; no vmcnt: the gathers stay in flight)
+    // (no vmcnt: the gathers stay in flight across the barrier)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (R + LOOK < ROUNDS) SPR_GATHER(R + LOOK, ((R + LOOK) * OG + g < K) ? nbr_s[((R + LOOK) * OG + g) * 16 + r] : -1)
-    const bf16x8_t* bw = reinterpret_cast<const bf16x8_t*>(SPR_RING(R) + g * WBYTES) + lane;
+    // The rows of round R + ALOOK are requested BETWEEN the MFMA groups of this round (two loads behind every 3 NB MFMAs): a
+    // wave whose vector-memory instruction waits for a slot in the CU's address pipe can issue nothing else, so requests
+    // bunched at the top of the round stall every multiplier at once; spread out they overlap the other waves' matrix work.
+    if (R + ALOOK < ROUNDS) row_ptr(nsrc);
+    if (R + ALOOK + 1 < ROUNDS) nsrc = ((R + ALOOK + 1) * OG + g < K) ? nbr_s[((R + ALOOK + 1) * OG + g) * 16 + rsel] : -1;
+    {  // rows of round R have landed once only the (up to ALOOK - 1) younger rounds' loads are outstanding
+      const int younger = (ROUNDS - 1 - R < ALOOK - 1 ? ROUNDS - 1 - R : ALOOK - 1) * KI * 2;  // a constant after unrolling
+      if constexpr (STAGE) {
+        if (younger == 0) vm_wait<0>();
+        else if (younger == 2) vm_wait<2>();
+        else if (younger == 4) vm_wait<4>();
+        else if (younger == 6) vm_wait<6>();
+        else if (younger == 8) vm_wait<8>();
+        else vm_wait<12>();
+        // this wave's slot holds the rows of round R: fragments into registers
+        const unsigned char* sl = aslot + (wv * ALOOK + R % ALOOK) * (CIN * 64) + ((kg >> 1) * 1024 + r * 64);
+        const int sw = (r >> 3) & 1;
 #pragma unroll
-    for (int ki = 0; ki < KI; ki++) {
-      bf16x8_t ah, am, al, bh[NB], bl[NB];
+        for (int ki = 0; ki < KI; ki++)
+#pragma unroll
+          for (int v = 0; v < 2; v++)
+            araw[0][ki * 2 + v] = *reinterpret_cast<const f32x4*>(sl + ki * 2048 + ((((kg & 1) * 2 + v) ^ sw) * 16));
+      } else {
+        f32x4 (&ar)[KI * 2] = araw[R % ABUF];
+        if (younger == 0) vm_wait_tie<0>(ar);
+        else if (younger == 2) vm_wait_tie<2>(ar);
+        else if (younger == 4) vm_wait_tie<4>(ar);
+        else if (younger == 6) vm_wait_tie<6>(ar);
+        else if (younger == 8) vm_wait_tie<8>(ar);
+        else if (younger == 12) vm_wait_tie<12>(ar);
+        else vm_wait_tie<16>(ar);
+      }
+    }
+    const bf16x8_t* bw = reinterpret_cast<const bf16x8_t*>(SPR_RING(R) + g * WBYTES) + lane;
+    bf16x8_t ah[KI], am[KI], al[KI], bh[KI][NB], bl[KI][NB];
+#pragma unroll
+    for (int ki = 0; ki < KI; ki++)
 #pragma unroll
       for (int j = 0; j < NB; j++) {
-        bh[j] = bw[(size_t)((ki * NB + j) * 2) * 64];
-        bl[j] = bw[(size_t)((ki * NB + j) * 2 + 1) * 64];
+        bh[ki][j] = bw[(size_t)((ki * NB + j) * 2) * 64];
+        bl[ki][j] = bw[(size_t)((ki * NB + j) * 2 + 1) * 64];
       }
-      split_act(araw[R % NBUF][ki], ah, am, al);
 #pragma unroll
-      for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[j], 0, 0, 0);  // smallest terms first
+    for (int ki = 0; ki < KI; ki++) {
+      const f32x4 v0 = araw[STAGE ? 0 : R % ABUF][ki * 2], v1 = araw[STAGE ? 0 : R % ABUF][ki * 2 + 1];
+      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      split_act(x, ah[ki], am[ki], al[ki]);
+    }
+#pragma unroll
+    for (int ki = 0; ki < KI; ki++) {
+#pragma unroll
+      for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ki], bh[ki][j], acc[j], 0, 0, 0);  // smallest terms first
       if constexpr (SPC_TERMS == 4) {
 #pragma unroll
-        for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[ki], bh[ki][j], acc[j], 0, 0, 0);
       }
 #pragma unroll
-      for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[j], 0, 0, 0);
+      for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ki], bl[ki][j], acc[j], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[j], 0, 0, 0);
+      for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ki], bh[ki][j], acc[j], 0, 0, 0);
+      if (R + ALOOK < ROUNDS) {  // (STAGE: overwrites the slot piece this MFMA group consumed)
+        __builtin_amdgcn_sched_barrier(0);
+        issue_chunk(ki, R + ALOOK);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 #if SPR_TIMELINE
     __builtin_amdgcn_sched_barrier(0);
     SPR_STAMP(3 + (R < 9 ? R : 8));
 #endif
   }
-#undef SPR_GATHER
   // partial tiles of the OG offset groups meet in round buffer 0 (its last reader round is followed by at least one
   // more round barrier: every wave is past it)
-  static_assert((ROUNDS - 1) % NBUF != 0, "round buffer 0 must not be the last one read");
-  float* part = reinterpret_cast<float*>(wb0) + t * (OG * NB * 4 * 64);  // [TILES][OG][NB][4][64]
+  // (the buffer used is not the one the last round reads; its own last reader round lies behind a round barrier)
+  float* part = reinterpret_cast<float*>((ROUNDS - 1) % NBUF != 0 ? wb0 : wb1) + t * (OG * NB * 4 * 64);  // [TILES][OG][NB][4][64]
 #pragma unroll
   for (int j = 0; j < NB; j++)
 #pragma unroll
@@ -844,10 +1149,10 @@ __global__ __launch_bounds__((2 * OG + 2) * 64) void spconv_fwd_rows_ring(const 
 #undef SPR_RING
 }
 
-template <int CIN, int COUT, int OG>
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int DBG = 0>
 static int launch_rows_ring(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
                             const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
-  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG>), dim3(v3d_ceil_div(cap, 32)), dim3((2 * OG + 2) * 64), 0, st, in,
+  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, DBG>), dim3(v3d_ceil_div(cap, 32)), dim3((2 * OG + NMV) * 64), 0, st, in,
                        (const unsigned short*)wimg, nbr, n_ptr, cap, scale, shift, relu, out);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
@@ -862,10 +1167,20 @@ static void launch_rows_big(const float* in, const void* wimg, const int* nbr, c
                        (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out);
 }
 
+template <int CIN, int COUT, int T, int STAGE = 1, int DBG = 0>
+static void launch_rows_kouter(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
+                               const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
+  const int passes = v3d_ceil_div(cap, 16 * T * 8);
+  const int grid = passes >= 256 ? 256 : ((passes + 7) / 8) * 8;  // a multiple of 8: the pass -> XCD map assumes it
+  hipLaunchKernelGGL((spconv_fwd_rows_kouter<CIN, COUT, T, 27, STAGE, DBG>), dim3(grid), dim3(512), 0, st, in, (const unsigned short*)wimg,
+                     nbr, n_ptr, cap, scale, shift, relu, out);
+}
+
 // rows_hint > 0: expected number of LIVE rows (the live count itself is device-side): the caller's best knowledge -- the
 // capacity when it is exact (per-op Python path), the counts observed on earlier frames (v3d_backbone_tune); 0 = unknown.
-// rows_hint < 0 forces a kernel (tests, benchmarks): -1 the 16-row kernel, -5 the 64-row LDS-shared-weights kernel, -10 the
-// LDS-ring kernel (the last two where the shape has them, else the 16-row kernel).
+// rows_hint < 0 forces a kernel (tests, benchmarks): -1 the 16-row kernel, -5 the 64-row LDS-shared-weights kernel, -6 / -7 the
+// offset-outer persistent kernel (rows staged through LDS / gathered into registers), -10 the LDS-ring kernel in the form chosen
+// for the shape, -16 its register-gather form (each where the shape has it, else the 16-row kernel).
 #define V3D_BIG_ROWS 32768
 #define V3D_RING_ROWS 16384  // two full rounds of 32-row workgroups on 256 CUs; beyond, the 16-row kernel wins again (36 k rows: 47 vs 53 us)
 template <int CIN, int COUT>
@@ -873,6 +1188,15 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
                        const float* scale, const float* shift, int relu, float* out, int rows_hint, hipStream_t st) {
   const int force = rows_hint < 0 ? -rows_hint : 0;
   if constexpr (CIN >= 32 && CIN <= 64 && COUT >= 32 && COUT <= 64) {
+    // the offset-outer persistent kernel (3x3x3 only; 6: rows staged through LDS, 7: rows gathered into registers): 64->64 at
+    // 56 k rows 58 -> 47.5 us.  It needs a full round of 256-row passes to pay: the 32-channel shapes and the mid sizes stay on
+    // the kernels below (32->32 at 81 k rows: 316 passes on 256 workgroups = 2 rounds, 43 vs 30 us)
+    if (K == 27 && (force == 6 || force == 7 || (force == 0 && CIN == 64 && COUT == 64 && rows_hint >= V3D_BIG_ROWS))) {
+      if (force == 7) launch_rows_kouter<CIN, COUT, 2, 0>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+      else launch_rows_kouter<CIN, COUT, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+      V3D_CHECK_LAUNCH();
+      return V3D_OK;
+    }
     // the 64-row LDS-shared-weights kernel: from ~32 k live rows on the 16-row kernel is bound by the L2 -> CU weight
     // stream (64->64 at 36 k rows 54 vs 53 us, at 56 k 82 vs 66 us, at 81 k 110 vs 85 us)
     if (force == 5 || (force == 0 && rows_hint >= V3D_BIG_ROWS)) {
@@ -880,9 +1204,21 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
       V3D_CHECK_LAUNCH();
       return V3D_OK;
     }
-    // the two-tile LDS-ring kernel (3x3x3 only): 64->64 at 8 160 rows 14.4 -> 12.3 us, 32->32 at 13 731 rows 10.9 -> 9.6 us
-    if (K == 27 && (force == 10 || (force == 0 && rows_hint <= V3D_RING_ROWS)))
-      return launch_rows_ring<CIN, COUT, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+#ifdef V3D_EXPERIMENTS
+    if (K == 27 && force == 26) { launch_rows_kouter<CIN, COUT, 2, 0, 4>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st); return V3D_OK; }
+    if (K == 27 && force == 21) return launch_rows_ring<CIN, COUT, 3, 3, 2, 2, 0, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+    if (K == 27 && force == 22) return launch_rows_ring<CIN, COUT, 3, 3, 2, 2, 0, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+    if (K == 27 && force == 23) return launch_rows_ring<CIN, COUT, 3, 3, 2, 2, 0, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+#endif
+    // the two-tile LDS-ring kernel (3x3x3 only, <= 16 384 rows).  10 = the form chosen per shape by measurement (same box, KITTI
+    // layers): 64->64 rows staged through LDS, one slot, 2 weight buffers, 4 movers (11.2 -> 9.9 us at 8 160 rows); 32->32 staged,
+    // two slots, 2 movers (8.4 -> 7.4 us at 13 731 rows); 32->64 / 64->32 register gathers, 3 weight buffers (7.2 us; staged 7.6-8.3).
+    // 16 = the register-gather form for every shape (cross-check).
+    if (K == 27 && (force == 10 || force == 16 || (force == 0 && rows_hint <= V3D_RING_ROWS))) {
+      if (force != 16 && CIN == 64 && COUT == 64) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+      if (force != 16 && CIN == 32 && COUT == 32) return launch_rows_ring<CIN, COUT, 3, 2, 2, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+      return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+    }
   }
   const size_t lds = (size_t)4 * (COUT / 16) * 4 * 64 * 4 + (size_t)K * 16 * 4;
   hipLaunchKernelGGL((spconv_fwd_rows<CIN, COUT>), dim3(v3d_ceil_div(cap, 16)), dim3(V3D_BLOCK), lds, st, in,

@@ -56,8 +56,13 @@ def _ray_scene(rng, az, el, n_cars, x_rng, y_rng, wall_rng):
 
 
 def make_cloud(seed=0, n_points=16384, bounds=KITTI_BOUNDS, fov_deg=45.0, az_steps=1000, n_beams=64,
-               n_cars=12, return_boxes=False):
-    """One synthetic sweep, float32 (n_points, 4).  Deterministic in `seed`."""
+               n_cars=12, return_boxes=False, order="shuffled"):
+    """One synthetic sweep, float32 (n_points, 4).  Deterministic in `seed`.
+
+    order="shuffled" (default; what every test and golden fixture uses): the returns in random order -- what the TRAINING
+    dataset hands over (`kitti_dataset.py:154` shuffles the points).  order="scan": the SAME returns in firing order (azimuth
+    step by azimuth step, 64 beams each) -- what the inference dataset hands over (`kitti_dataset.py:135-140`: `read_velo`,
+    the .bin file in sensor order)."""
     rng = np.random.default_rng(seed)
     bounds = np.asarray(bounds, np.float64)
     x_rng = (max(bounds[0], -65.0) + 6.0, min(bounds[3], 71.0) - 5.4) if bounds[0] >= 0 else (bounds[0] + 8, bounds[3] - 8)
@@ -75,8 +80,13 @@ def make_cloud(seed=0, n_points=16384, bounds=KITTI_BOUNDS, fov_deg=45.0, az_ste
         if pts.shape[0] >= n_points:
             break
         steps *= 2  # denser azimuth sampling until the crop holds enough returns
-    sub.shuffle(pts)
-    pts = pts[:n_points]
+    if order == "scan":  # the same subset as the shuffled sweep (same generator draws), restored to firing order
+        sel = np.arange(pts.shape[0])
+        sub.shuffle(sel)
+        pts = pts[np.sort(sel[:n_points])]
+    else:
+        sub.shuffle(pts)
+        pts = pts[:n_points]
     inten = sub.uniform(0.0, 1.0, (pts.shape[0], 1)).astype(np.float32)
     cloud = np.ascontiguousarray(np.concatenate([pts, inten], 1), dtype=np.float32)
     if return_boxes:
@@ -88,9 +98,9 @@ def make_kitti_batch(batch_size=1, seed0=0, n_points=16384):
     return [make_cloud(seed0 + i, n_points) for i in range(batch_size)]
 
 
-def make_waymo_cloud(seed=0, n_points=180000):
+def make_waymo_cloud(seed=0, n_points=180000, order="shuffled"):
     """configs[4]: 360 degree sweep, 0.05 m voxels over +-75.2 m (HBM-bound stress case)."""
-    return make_cloud(seed, n_points, WAYMO_BOUNDS, fov_deg=180.0, az_steps=3000, n_beams=64, n_cars=40)
+    return make_cloud(seed, n_points, WAYMO_BOUNDS, fov_deg=180.0, az_steps=3000, n_beams=64, n_cars=40, order=order)
 
 
 def make_gt_boxes(seed=0, n_extra=15):
