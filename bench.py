@@ -62,9 +62,9 @@ def parse():
     ap.add_argument("--workload", choices=["kitti", "waymo"], default="kitti",
                     help="kitti: BASELINE configs[1] (16k-pt KITTI-range cloud, the headline metric); "
                          "waymo: configs[4] (180k-pt sweep, +-75.2 m, 0.05 m voxels: the HBM stress case)")
-    ap.add_argument("--path", choices=["graph", "native", "fused", "eager"], default="graph",
-                    help="graph: native path captured in one HIP graph; native: backbone plan + MFMA dense head; "
-                         "fused: backbone plan + torch (MIOpen) RPN; eager: per-op python -> C ABI")
+    ap.add_argument("--path", choices=["graph", "native", "eager"], default="graph",
+                    help="graph: native path captured in one HIP graph; native: backbone plan + MFMA dense head, eager "
+                         "launches; eager: per-op python -> C ABI (every path runs the hand-written kernels: there is no torch dense path)")
     ap.add_argument("--mode", choices=["forward", "train", "pvrcnn"], default="forward",
                     help="forward: the headline metric; train: BASELINE configs[2] (SECOND train step, bs=8/GPU, gradient "
                          "all-reduce over RCCL) -- a secondary line, same JSON contract")
@@ -84,8 +84,21 @@ def parse():
                     help="forward mode: back-to-back timed windows of --steps steps each (barrier + synchronize on both sides of every "
                          "window, pipeline empty at its start, max over ranks per window); `value` is the MEDIAN window, "
                          "value_p10 / value_p90 the spread.  The count is cut down so that the windows take at most ~20 s")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="--mode pvrcnn: time PV_RCNN.inference(item) from raw points (device voxelizer + sparse CNN + stage-1 head + "
+                         "stage 2 + refinement NMS), one frame at a time, instead of stage 2 on resident stage-1 outputs")
     ap.add_argument("--no-h2d", action="store_true", help="skip the with_h2d line (pinned host cloud copied in every step)")
     return ap.parse_args()
+
+
+def ranks_seen(world):
+    """An all-reduce of ones over the job: what the collective backend (RCCL) really spans."""
+    if world == 1:
+        return 1
+    import torch.distributed as dist
+    ones = torch.ones(1, device=REDUCE_DEVICE)
+    dist.all_reduce(ones)
+    return int(ones.item())
 
 
 def layer_algorithmic_bytes(stats):
@@ -167,10 +180,11 @@ def train_main(args):
         loss = step()
     fence()
     elapsed = dist_util.max_over_ranks(time.perf_counter() - t0, world, device=REDUCE_DEVICE)
+    seen = ranks_seen(world)
     if rank == 0:
         print(json.dumps(dict(
             metric="frames/sec SECOND train step, 16k-pt KITTI cloud", value=world * bs * args.steps / elapsed, unit="frames/s",
-            n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
+            n_gpus=world, n_ranks_seen=seen, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
             scaling="weak", vs_baseline=None,
             dtype=("bf16 autocast dense RPN/head; " if amp else "fp32 dense RPN/head; ") + "sparse convs bf16-split MFMA fwd/dX, fp32 MFMA dW",
             data="synthetic",
@@ -199,6 +213,8 @@ def pvrcnn_main(args):
     torch.manual_seed(0)
     model = PV_RCNN(cfg).cuda().eval()
     bs = args.batch
+    if args.end_to_end:
+        return pvrcnn_end_to_end(args, model, cfg, rank, world)
     depth = args.pipeline if args.pipeline >= 1 else 4  # frames in flight (independent frames on separate streams; 1 = one at a time)
     n_prop = 100
     slots = []
@@ -284,6 +300,52 @@ def pvrcnn_main(args):
                              ", one host thread, one stream per frame in flight"),
             single_frame_ms=single_ms, frames_per_s_one_at_a_time=bs * 1e3 / single_ms,
             host_enqueue_ms_per_step=1e3 * enq / args.steps, roofline=None, cpu_baseline=None)))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def pvrcnn_end_to_end(args, model, cfg, rank, world):
+    """PV_RCNN.inference(item) from raw points, one frame at a time: device voxelizer -> sparse CNN (4 levels + BEV) -> stage-1
+    head (MFMA 1x1) -> FPS keypoints + VSA + BEV gather -> top-k proposals -> RoI-grid pool -> refinement -> rotated NMS.
+    (Upstream's PV_RCNN.forward raises: this is the repository's wiring of the reference's pieces, detector/model.py.)"""
+    from vision3d_amd import dist_util, synth
+    from vision3d_amd.core import AnchorGenerator, Preprocessor
+    import torch.distributed as dist
+    pre = Preprocessor(cfg, seed=0)
+    anchors = AnchorGenerator(cfg).anchors.cuda()
+    bs = args.batch
+    frames = [[torch.from_numpy(synth.make_cloud((j * world + rank) * bs + i, args.points or 16384)).cuda() for i in range(bs)]
+              for j in range(max(1, args.stream))]
+
+    def step(i):
+        with torch.no_grad():
+            item = pre(dict(points=frames[i % len(frames)], anchors=anchors))
+            return model.inference(item)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(max(args.warmup, 2)):
+        out = step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    fence()
+    elapsed = dist_util.max_over_ranks(time.perf_counter() - t0, world, device=REDUCE_DEVICE)
+    if rank == 0:
+        print(json.dumps(dict(
+            metric="frames/sec PV-RCNN inference end to end, 16k-pt KITTI cloud", value=world * bs * args.steps / elapsed,
+            unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
+            higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32 (set abstraction) / bf16x3 (sparse CNN, head)",
+            data="synthetic",
+            config=dict(workload="PV_RCNN.inference from raw points (stage 1 + BASELINE configs[3] stage 2 + refinement NMS), one "
+                                 "frame at a time, eager launches", frames_per_gpu_per_step=bs,
+                        points_per_frame=args.points or 16384, parallelism=f"frame-parallel replicas x{world}"),
+            n_detections=int(out[0].shape[0]), roofline=None, cpu_baseline=None)))
     if world > 1:
         dist.destroy_process_group()
 
@@ -430,8 +492,6 @@ def main():
                 return r
             if args.path == "native":
                 return model.inference_points(clouds, anchors, dense="mfma")
-            if args.path == "fused":
-                return model.inference_points(clouds, anchors, dense="torch")
             item = pre(dict(points=clouds, anchors=anchors))
             return model.inference(item)
 
@@ -442,11 +502,7 @@ def main():
         torch.cuda.synchronize()
 
     pipelined = args.pipeline != 1 and args.path == "graph"
-    n_ranks_seen = world
-    if world > 1:  # the collective really spans `world` ranks (RCCL): all-reduce of ones
-        ones = torch.ones(1, device=REDUCE_DEVICE)
-        dist.all_reduce(ones)
-        n_ranks_seen = int(ones.item())
+    n_ranks_seen = ranks_seen(world)  # the collective really spans `world` ranks (RCCL)
 
     def window(src, steps):
         """One timed window: EXACTLY `steps` steps, barrier + synchronize on both sides, pipeline empty at its start; the frames
@@ -663,7 +719,7 @@ def main():
                                 pipeline_tuning=(graphed.tuned if pipelined else None),
                                 path={"graph": "native backbone plan + bf16x3 MFMA dense head + device proposal stage, one HIP graph per "
                                                "frame" + (f", {graphed.depth} frames in flight" if pipelined else ""),
-                                      "native": "native backbone plan + bf16x3 MFMA dense head", "fused": "native backbone plan + torch RPN",
+                                      "native": "native backbone plan + bf16x3 MFMA dense head",
                                       "eager": "eager python -> C ABI"}[args.path]),
                     **spread, with_h2d=with_h2d, n_ranks_seen=n_ranks_seen,
                     single_frame_ms=single_ms,

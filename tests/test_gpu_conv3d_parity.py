@@ -1,0 +1,115 @@
+"""Sparse backbone vs torch.nn.functional.conv3d on the densified grid, stage by stage, on a FULL 16 384-point frame --
+independent of oracle/ (VERDICT r2 item 7).
+
+spconv's sources are absent from /root/reference, so the oracle's rulebook / sparse-convolution restatement is "parity
+unpinned"; what IS pinned is the semantics the reference relies on (spconv/conv.py header): a
+SubMConv3d / SparseConv3d equals nn.Conv3d with weight.permute(4, 3, 0, 1, 2) on the densified input, evaluated at the active
+output sites, and a strided layer's output sites are exactly the positions whose receptive field holds an active input.
+This test checks every one of the 14 layers of SpMiddleFHD (sparse_cnn.py:151-175) that way: the HIP layer's own input
+(features + coordinates) is densified, F.conv3d (MIOpen / torch, fp32) is the reference, compared at the layer's output sites.
+The grid is 41 x 1600 x 1408, so the dense reference runs in slabs of output rows with their halo.
+
+Reported beside the repository's feature bar (gpu_util.assert_features_close: 1e-4 |ref| + 1e-4 rms_active, max norm):
+the STRICT elementwise relative error on the entries with |ref| > 1e-3 max|ref|.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import assert_features_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense_ref(feats, idx, shape, weight, stride, padding, out_idx, slab=160):
+    """F.conv3d reference at `out_idx` (+ the reference's own set of active output sites), slab by slab along y."""
+    dev = feats.device
+    D, H, W = shape
+    kz, ky, kx, cin, cout = weight.shape
+    w = weight.permute(4, 3, 0, 1, 2).contiguous()
+    ones = torch.ones((1, 1, kz, ky, kx), device=dev)
+    Ho = (H + 2 * padding[1] - ky) // stride[1] + 1
+    ref = torch.zeros((out_idx.shape[0], cout), dtype=torch.float32, device=dev)
+    seen = torch.zeros(out_idx.shape[0], dtype=torch.bool, device=dev)
+    n_ref_sites = 0
+    for o0 in range(0, Ho, slab):
+        o1 = min(Ho, o0 + slab)
+        i0, i1 = o0 * stride[1] - padding[1], (o1 - 1) * stride[1] - padding[1] + ky  # input rows [i0, i1), may leave the grid
+        sel = (idx[:, 2] >= i0) & (idx[:, 2] < i1)
+        sub = idx[sel].long()
+        dense = torch.zeros((1, cin, D, i1 - i0, W), dtype=torch.float32, device=dev)
+        dense[0, :, sub[:, 1], sub[:, 2] - i0, sub[:, 3]] = feats[sel].t()
+        occ = torch.zeros((1, 1, D, i1 - i0, W), dtype=torch.float32, device=dev)
+        occ[0, 0, sub[:, 1], sub[:, 2] - i0, sub[:, 3]] = 1.0
+        pad = (padding[0], 0, padding[2])  # the slab carries its own y halo (rows outside the grid are zero rows)
+        out = F.conv3d(dense, w, None, stride, pad)          # (1, cout, Do, o1 - o0, Wo)
+        cnt = F.conv3d(occ, ones, None, stride, pad)
+        assert out.shape[3] == o1 - o0, (out.shape, o0, o1)
+        n_ref_sites += int((cnt > 0.5).sum().item())
+        osel = (out_idx[:, 2] >= o0) & (out_idx[:, 2] < o1)
+        oi = out_idx[osel].long()
+        ref[osel] = out[0, :, oi[:, 1], oi[:, 2] - o0, oi[:, 3]].t()
+        assert bool((cnt[0, 0, oi[:, 1], oi[:, 2] - o0, oi[:, 3]] > 0.5).all()), "an output site with no active input in its field"
+        seen |= osel
+        del dense, occ, out, cnt
+    assert bool(seen.all())
+    return ref, n_ref_sites
+
+
+def test_every_backbone_layer_equals_dense_conv3d_on_a_full_frame():
+    from vision3d_amd import spconv, synth
+    from vision3d_amd.core import Preprocessor
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.detector import Second
+    from vision3d_amd.spconv.conv import _SparseConvBase
+    cfg = second_car_cfg()
+    torch.manual_seed(0)
+    model = Second(cfg).cuda().eval()
+    cloud = torch.from_numpy(synth.make_cloud(11, 16384)).cuda()
+    captured = []
+
+    def hook(mod, args, out):
+        x = args[0]
+        captured.append((mod, x.features.detach().clone(), x.indices.clone(), list(x.spatial_shape), args[1:],
+                         out.features.detach().clone(), out.indices.clone(), list(out.spatial_shape)))
+    hooks = [m.register_forward_hook(hook) for m in model.cnn.modules() if isinstance(m, _SparseConvBase)]
+    with torch.no_grad():
+        it = Preprocessor(cfg, seed=0)(dict(points=[cloud]))
+        x = spconv.SparseConvTensor(it["voxel_mean"], it["coordinates"].int(), model.cnn.grid_shape, 1)
+        model.cnn.blocks(x)
+    for h in hooks:
+        h.remove()
+    assert len(captured) == 14, len(captured)
+    assert captured[0][1].shape[0] > 10000  # a full frame, not a crop
+    torch.backends.cudnn.allow_tf32 = False
+    worst_strict, report = 0.0, []
+    for li, (mod, fin, iin, shp, extra, fout, iout, oshp) in enumerate(captured):
+        n_out = fout.shape[0]
+        scale, shift, relu = (list(extra) + [None, None, False])[:3]
+        with torch.no_grad():
+            ref, n_sites = _dense_ref(fin, iin, shp, mod.weight.detach().float(), mod.stride, mod.padding, iout[:n_out])
+            if mod.bias is not None:
+                ref = ref + mod.bias
+            if scale is not None:
+                ref = ref * scale + shift
+            if relu:
+                ref = torch.relu(ref)
+        if mod.subm:
+            assert torch.equal(iin[:n_out], iout[:n_out])  # submanifold: the output sites ARE the input sites
+        else:
+            assert n_sites == n_out, f"layer {li}: {n_out} output sites, dense occupancy conv has {n_sites}"
+            assert len(torch.unique(iout[:n_out], dim=0)) == n_out
+            assert [int(v) for v in oshp] == [(shp[j] + 2 * mod.padding[j] - mod.kernel_size[j]) // mod.stride[j] + 1 for j in range(3)]
+        got, r = fout.cpu().numpy(), ref.cpu().numpy()
+        assert_features_close(got, r, f"layer {li} {mod.in_channels}->{mod.out_channels} vs F.conv3d")
+        big = np.abs(r) > 1e-3 * np.abs(r).max()
+        strict = float((np.abs(got - r)[big] / np.abs(r)[big]).max())
+        worst_strict = max(worst_strict, strict)
+        report.append((li, mod.in_channels, mod.out_channels, n_out, strict, float(np.abs(got - r).max() / np.abs(r).max())))
+    for row in report:
+        print("layer %2d %3d->%3d rows %6d: strict rel err on |ref| > 1e-3 max = %.2e, max-norm err = %.2e" % row)
+    # The split-precision product carries an ABSOLUTE error of a few 1e-6 of the layer's largest output,
+    # so relative to an entry a thousand times smaller than the largest one it may reach a few 1e-3: the strict figure is
+    # reported, and bounded at the value that mechanism allows.
+    assert worst_strict < 1e-2, worst_strict

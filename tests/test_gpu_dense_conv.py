@@ -89,8 +89,10 @@ def test_inference_points_paths_agree():
     anchors = AnchorGenerator(second_car_cfg()).anchors.cuda()
     clouds = [torch.from_numpy(synth.make_cloud(5)).cuda()]
     with torch.no_grad():
-        a = model.inference_points(clouds, anchors, dense="mfma")
-        b = model.inference_points(clouds, anchors, dense="torch")
+        a = model.inference_points(clouds, anchors)                     # device proposal stage
+        b = model.inference_points(clouds, anchors, proposals="torch")  # op-by-op torch statement of the proposal stage
+        with pytest.raises(ValueError):
+            model.inference_points(clouds, anchors, dense="torch")      # the MIOpen dense path no longer exists
     assert a[0].shape[1] == 7 and abs(len(a[0]) - len(b[0])) <= max(2, len(b[0]) // 10)
 
 

@@ -187,3 +187,29 @@ def test_dense_gradients_are_complete_when_the_plan_backward_starts():
     for at_hook, p in zip(snap[0], dense):
         assert at_hook is not None and torch.equal(at_hook, p.grad)
     assert all(p.grad is not None for p in model.cnn.parameters())
+
+
+def test_plan_state_belongs_to_one_forward_and_the_capacity_word_is_read_every_step():
+    """(1) the plan holds the saved activations / rulebooks of ONE forward -- a backward that belongs to an
+    earlier forward (two train-mode forwards before a backward) raises instead of returning the gradients of the wrong
+    frame; (2) the capacity-overflow word of EVERY step is checked (copied to pinned memory behind the
+    step, read when the next step begins), not only the first one; (3) a train forward bumps the version counters of the
+    running statistics it updated through raw pointers, so caches keyed on (data_ptr, _version) see it."""
+    cfg, model, item = _model_and_item(1)
+    cnn = model.cnn
+    bn = next(m for m in cnn.modules() if isinstance(m, torch.nn.BatchNorm1d))
+    v0 = bn.running_mean._version
+    bev1 = cnn(item["voxel_mean"], item["coordinates"], item["batch_size"])
+    assert bn.running_mean._version > v0 and bn.num_batches_tracked._version > 0
+    bev2 = cnn(item["voxel_mean"], item["coordinates"], item["batch_size"])   # overwrites the plan's saved state
+    with pytest.raises(RuntimeError, match="belongs to forward"):
+        bev1.sum().backward()
+    bev2.sum().backward()                                                     # the forward whose state the plan holds: fine
+    # (2): simulate a step that dropped rows: raise the summary word, post it the way train_forward does, next step reports it
+    plan = next(iter(cnn.__dict__["_train_plans"].values()))
+    assert plan.__dict__["_ovf_state"]["pending"]  # every step posts its word
+    plan._check_deferred_overflow()                # ... and a clean one passes
+    plan.overflow_any().fill_(1)
+    plan._post_deferred_overflow()
+    with pytest.raises(RuntimeError, match="exceeded an active-site capacity"):
+        cnn(item["voxel_mean"], item["coordinates"], item["batch_size"])

@@ -187,7 +187,28 @@ class ProposalLayer(nn.Module):
         return reg_map.view(B, self.cfg.NUM_CLASSES, self.cfg.BOX_DOF, -1, ny, nx).permute(0, 1, 3, 4, 5, 2)
 
     def forward(self, feature_map):
+        if not self.training and not torch.is_grad_enabled() and feature_map.is_cuda:
+            return self.maps_from_fused(self.native_head(feature_map))  # inference on the GPU: csrc/dense_conv.hip, not MIOpen
         return self.reshape_cls(self.conv_cls(feature_map)), self.reshape_reg(self.conv_reg(feature_map))
+
+    def native_head(self, feature_map):
+        """fp32 (B, C_IN, H, W) cuda -> fused [cls | reg] maps (B, n_anchor * (1 + DOF), H, W) fp32 on the streaming bf16x3 MFMA
+        1x1 kernel (csrc/dense_conv.hip:conv1x1_bf16x3_small_cout_kernel); the packed weight image is cached until a head
+        tensor changes.  (Second's inference paths get the same maps from DenseHeadPlan, which feeds the kernel split planes
+        directly; this entry is for callers that hold an fp32 feature map: PV_RCNN.proposal, `model.head(features)`.)"""
+        from ..runtime import conv2d_split, pack_conv_weight, to_split_nhwc
+        tensors = (self.conv_cls.weight, self.conv_cls.bias, self.conv_reg.weight, self.conv_reg.bias)
+        stamp = tuple((t.data_ptr(), t._version) for t in tensors)
+        cache = self.__dict__.get("_native_head")
+        if cache is None or cache[0] != stamp:
+            with torch.no_grad():
+                w = torch.cat((self.conv_cls.weight, self.conv_reg.weight), 0)
+                bias = torch.cat((self.conv_cls.bias, self.conv_reg.bias), 0).float().contiguous()
+                cache = (stamp, pack_conv_weight(w), bias, w.shape[1], w.shape[0])
+            self.__dict__["_native_head"] = cache
+        _, img, bias, cin, cout = cache
+        hi, lo = to_split_nhwc(feature_map.float())
+        return conv2d_split(hi, lo, img, bias, False, cin, cout, 1, out_split=False, out_nchw=True)[1]
 
 
 class ProposalLoss(nn.Module):

@@ -83,7 +83,9 @@ class RPN(nn.Module):
 
     def forward(self, x):
         if not self.training and not torch.is_grad_enabled():
-            return self.fused_forward(x)
+            if x.is_cuda:  # inference on the GPU: the bf16x3 MFMA convolutions of csrc/dense_conv.hip, never torch / MIOpen
+                return self.native_forward(x)
+            return self.fused_forward(x)  # host tensors (the CPU golden tests of the module arithmetic)
         mods = list(self.down_block)
         if (isinstance(mods[0], nn.ZeroPad2d) and isinstance(mods[1], nn.Conv2d) and mods[1].padding == (0, 0)
                 and mods[1].padding_mode == "zeros" and mods[0].padding == (1, 1, 1, 1)):
@@ -114,8 +116,18 @@ class RPN(nn.Module):
             self.__dict__["_fold_cache"] = cache
         return cache[1]
 
+    def native_forward(self, x):
+        """fp32 (B, C, H, W) cuda -> fp32 (B, C_up, H, W): the seven conv + folded-BN + ReLU layers on csrc/dense_conv.hip
+        (split bf16 NHWC planes in between).  What `model.rpn(bev)` runs in eval mode on the GPU."""
+        from ..runtime import DenseHeadPlan, to_split_nhwc
+        plan = self.__dict__.get("_native_plan")
+        if plan is None:
+            plan = self.__dict__["_native_plan"] = DenseHeadPlan(self, None)
+        hi, lo = to_split_nhwc(x.float())
+        return plan.forward(hi, lo, want_features=True)[1]
+
     def fused_forward(self, x):
-        """Inference path: 7 x (conv with folded BN, in-place ReLU) -- a third of the module calls."""
+        """Host path (CPU tensors): 7 x (conv with folded BN, in-place ReLU)."""
         folded = self._folded()
         x = F.pad(x, (1, 1, 1, 1))
         for w, b, pad in folded:
@@ -247,13 +259,12 @@ class Second(nn.Module):
         return PipelinedSecond(self, anchors, frame_sizes, depth, autotune)
 
     def inference_points(self, clouds, anchors, dense="mfma", proposals="native"):
-        """Same result as `inference(Preprocessor(cfg)(...))` without materialising the intermediate dict.
-        dense = "mfma": RPN + heads on the hand-written bf16x3 MFMA convolution (csrc/dense_conv.hip);
-        dense = "torch": fp32 nn.Conv2d (MIOpen) -- the comparison point.
+        """Same result as `inference(Preprocessor(cfg)(...))` without materialising the intermediate dict.  RPN + heads run on
+        the hand-written bf16x3 MFMA convolution (csrc/dense_conv.hip) -- there is no torch / MIOpen inference path.
         proposals = "native": top-k / decode / NMS / score cut in csrc/proposal.hip; "torch": the op-by-op
         statement of proposal.py:61-80 (ties in the top-k are then torch.topk's)."""
-        if dense == "torch":
-            return self.head.inference(self.rpn(self.bev_from_points(clouds)), anchors)
+        if dense != "mfma":
+            raise ValueError("inference_points: the torch (MIOpen) dense path was removed; dense must be 'mfma'")
         if proposals == "native":
             plan, flat, offsets = self._plan_for(clouds)
             hi, lo = plan.forward_split(flat, offsets)

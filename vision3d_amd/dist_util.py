@@ -74,7 +74,7 @@ class TwoPhaseGradReducer(object):
 
     def __init__(self, early_params, late_params, world):
         self.early, self.late, self.world = list(early_params), list(late_params), int(world)
-        self._work, self._flat, self._grads = None, None, None
+        self._work, self._flat, self._grads, self._deferred, self._early_ids = None, None, None, False, set()
 
     @staticmethod
     def _bucket(params):
@@ -92,19 +92,43 @@ class TwoPhaseGradReducer(object):
             off += n
 
     def start_early(self):
-        """Call once per step when the early parameters' gradients are complete (idempotent until `finish`)."""
+        """Call once per step when the early parameters' gradients are complete (idempotent until `finish`).
+
+        Only started when EVERY early parameter that requires a gradient has one: a gradient that arrives later (or is still
+        being accumulated) would be left unreduced -- in that case the whole reduction is deferred to `finish()`.
+        Stream order: the bucket is built by kernels on the CALLER's stream (torch.cat inside autograd's backward); the
+        collective runs on the backend's own stream (RCCL) -- torch's ProcessGroupNCCL makes its stream wait for the
+        current stream at enqueue time, and an explicit event marks the point for backends that do not."""
         if self.world == 1 or self._work is not None:
             return
+        if any(p.requires_grad and p.grad is None for p in self.early):
+            self._deferred = True
+            return
         self._grads, self._flat = self._bucket(self.early)
+        self._early_ids = {id(g) for g in self._grads}
         if self._flat is not None:
+            if self._flat.is_cuda:
+                self._ready = torch.cuda.Event()
+                self._ready.record()           # the bucket is complete at this point of the caller's stream
+                self._ready.wait()             # (a no-op for the recording stream; the collective's enqueue follows it)
             self._work = dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def finish(self):
         """After backward(): reduce the late bucket, complete the early one.  Returns the number of reduced elements."""
         if self.world == 1:
             return 0
-        if self._work is None:  # the hook never fired (e.g. the module path was taken): plain two-bucket reduction
-            self.start_early()
+        if self._work is None:  # the hook never fired or deferred: plain two-bucket reduction now (all gradients are final)
+            self._grads, self._flat = self._bucket(self.early)
+            self._early_ids = {id(g) for g in self._grads}
+            if self._flat is not None:
+                self._work = dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            # an early parameter whose gradient tensor appeared after start_early (it had none then, so it is not in the bucket)
+            stragglers = [p for p in self.early if p.grad is not None and id(p.grad) not in self._early_ids]
+            if stragglers:
+                g2, f2 = self._bucket(stragglers)
+                dist.all_reduce(f2, op=dist.ReduceOp.SUM)
+                self._scatter(g2, f2, self.world)
         n = 0
         grads, flat = self._bucket(self.late)
         if flat is not None:
@@ -115,5 +139,5 @@ class TwoPhaseGradReducer(object):
             self._work.wait()
             self._scatter(self._grads, self._flat, self.world)
             n += self._flat.numel()
-        self._work, self._flat, self._grads = None, None, None
+        self._work, self._flat, self._grads, self._deferred = None, None, None, False
         return n

@@ -41,7 +41,25 @@ class PointnetSAModuleMSG(nn.Module):
             mods = list(mlp)
             if not mods or any(not isinstance(m, (nn.Conv2d, nn.BatchNorm2d, nn.ReLU)) for m in mods):
                 return False
+            # what v3d_sa_mlp_layer covers: 1x1 stride-1 convolutions, each followed by [BatchNorm2d] and a ReLU (relu is fixed
+            # in the kernel), padded output widths it is instantiated for -- anything else takes the grouped torch path
+            i = 0
+            while i < len(mods):
+                c = mods[i]
+                if (not isinstance(c, nn.Conv2d) or c.kernel_size != (1, 1) or c.stride != (1, 1) or c.padding != (0, 0)
+                        or c.groups != 1 or c.dilation != (1, 1) or (-(-c.out_channels // 16) * 16) not in self.FUSED_WIDTHS):
+                    return False
+                i += 1
+                if i < len(mods) and isinstance(mods[i], nn.BatchNorm2d):
+                    if mods[i].num_features != c.out_channels or not mods[i].track_running_stats:
+                        return False
+                    i += 1
+                if i >= len(mods) or not isinstance(mods[i], nn.ReLU):
+                    return False
+                i += 1
         return True
+
+    FUSED_WIDTHS = (16, 32, 64, 96, 128, 192, 256)  # padded Nout of csrc/sa_mlp.hip:sa_mlp_layer_kernel<Nout/16>
 
     def _packed_layers(self, k):
         """[(W (K_in, Nout_pad), bias (Nout_pad))] of scale k: eval BatchNorm folded in, rows laid out for sa_mlp_layer (first

@@ -267,13 +267,51 @@ class BackbonePlan(object):
                 self._tuned = True
                 if not self.__dict__.get("allow_overflow"):
                     self.check_overflow()
+            if not torch.cuda.is_current_stream_capturing():
+                self._check_deferred_overflow()  # the PREVIOUS step's capacity word, copied to pinned memory behind that step
             L.check(L.lib().v3d_backbone_train_forward(self._handle, L.ptr(mean), L.ptr(coords), m, b, io,
                                                        0 if bf16_nhwc else L.ptr(out), L.ptr(out) if bf16_nhwc else 0,
                                                        L.stream_ptr()), "backbone_train_forward")
+            # the kernels updated the running statistics through raw pointers: bump the tensors' version counters so that every
+            # cache keyed on (data_ptr, _version) -- folded BatchNorm of the inference plans -- sees the change even when no
+            # optimizer step follows (statistics-only passes, skipped steps)
+            stats = [t for _, bn, _ in self.layers if bn.track_running_stats and bn.running_mean is not None
+                     for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked)]
+            if stats:  # (a host-side counter bump: no kernel)
+                torch._C._autograd._unsafe_set_version_counter(stats, [t._version + 1 for t in stats])
+            if not torch.cuda.is_current_stream_capturing() and not self.__dict__.get("allow_overflow"):
+                self._post_deferred_overflow()
+        self.forward_generation = self.__dict__.get("forward_generation", 0) + 1
         return out
+
+    # ---- capacity check of EVERY training step without a stall: the summary word of step s is copied to pinned host memory on
+    # the step's stream and read when step s + 1 begins (by then the copy has long finished; the event query is the guard)
+    def _post_deferred_overflow(self):
+        st = self.__dict__.setdefault("_ovf_state", {})
+        if "host" not in st:
+            st["host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
+            st["event"] = torch.cuda.Event()
+        st["host"].copy_(self.overflow_any(), non_blocking=True)
+        st["event"].record()
+        st["pending"] = True
+
+    def _check_deferred_overflow(self):
+        st = self.__dict__.get("_ovf_state")
+        if not st or not st.get("pending"):
+            return
+        st["event"].synchronize()  # recorded one whole step ago: returns at once
+        st["pending"] = False
+        if int(st["host"][0]) > 0:
+            raise RuntimeError("sparse backbone (training plan): the previous step exceeded an active-site capacity -- rows were "
+                               "dropped, its BEV map, batch statistics and gradients are wrong; build the plan with a larger "
+                               "`growth` (Middle.plan_growth) or set plan.allow_overflow to accept clamping")
 
     def train_backward(self, grad_bev, batch_size):
         """d(BEV) -> [dW0, dgamma0, dbeta0, dW1, ...] (views of one flat buffer), for the last `train_forward`."""
+        if not self.__dict__.get("forward_generation"):
+            raise RuntimeError("training plan: backward before any train_forward")
+        # (the saved state is read, not consumed: a second backward of the SAME forward -- retain_graph -- is valid; a backward
+        # of an EARLIER forward is caught by PlanTrainFunction through the generation counter)
         if grad_bev.dtype == torch.bfloat16:
             g, nhwc = grad_bev.contiguous(memory_format=torch.channels_last), True
         else:
@@ -328,11 +366,18 @@ class PlanTrainFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, voxel_mean, coordinates, batch_size, bf16_nhwc, *params):
         ctx.plan, ctx.batch_size = plan, int(batch_size)
-        return plan.train_forward(voxel_mean.detach(), coordinates, batch_size, bf16_nhwc)
+        out = plan.train_forward(voxel_mean.detach(), coordinates, batch_size, bf16_nhwc)
+        ctx.generation = plan.forward_generation  # the plan holds the saved state of ONE forward: see backward
+        return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_bev):
+        if ctx.generation != ctx.plan.forward_generation:
+            raise RuntimeError("training plan: this backward belongs to forward #%d but the plan now holds the state of forward #%d "
+                               "(two train-mode forwards through one plan before a backward: the saved activations and rulebooks "
+                               "were overwritten).  Run one forward/backward pair at a time per plan, or set "
+                               "Middle.native_train = False for this pattern." % (ctx.generation, ctx.plan.forward_generation))
         hook = ctx.plan.__dict__.get("pre_backward_hook")
         if hook is not None:  # everything downstream of the BEV map has its gradients by now (dist_util.TwoPhaseGradReducer)
             hook()
@@ -429,7 +474,8 @@ class DenseHeadPlan(object):
     def sync_weights(self):
         pairs = self._pairs()
         tensors = [t for c, b in pairs for t in (c.weight, b.running_mean, b.running_var, b.weight, b.bias)]
-        tensors += [self.head.conv_cls.weight, self.head.conv_cls.bias, self.head.conv_reg.weight, self.head.conv_reg.bias]
+        if self.head is not None:
+            tensors += [self.head.conv_cls.weight, self.head.conv_cls.bias, self.head.conv_reg.weight, self.head.conv_reg.bias]
         stamp = tuple((t.data_ptr(), t._version) for t in tensors)
         if stamp == self._stamp:
             return
@@ -445,9 +491,12 @@ class DenseHeadPlan(object):
                 shift = (bn.bias - bn.running_mean * scale).float().contiguous()
                 layers.append(dict(img=pack_conv_weight(conv.weight, scale), bias=shift, relu=True, cin=conv.in_channels,
                                    cout=conv.out_channels, k=k))
-            w = torch.cat((self.head.conv_cls.weight, self.head.conv_reg.weight), 0)
-            bias = torch.cat((self.head.conv_cls.bias, self.head.conv_reg.bias), 0).float().contiguous()
-            layers.append(dict(img=pack_conv_weight(w), bias=bias, relu=False, cin=w.shape[1], cout=w.shape[0], k=1))
+            if self.head is not None:
+                w = torch.cat((self.head.conv_cls.weight, self.head.conv_reg.weight), 0)
+                bias = torch.cat((self.head.conv_cls.bias, self.head.conv_reg.bias), 0).float().contiguous()
+                layers.append(dict(img=pack_conv_weight(w), bias=bias, relu=False, cin=w.shape[1], cout=w.shape[0], k=1))
+            else:
+                layers.append(None)  # RPN only (RPN.native_forward): no head layer
         self.layers, self._stamp = layers, stamp
         self._background = {}  # responses to an empty map belong to the old weights
 
@@ -493,6 +542,8 @@ class DenseHeadPlan(object):
                                            bg=None if bg is None else bg[i], work=None if work is None else work[2 * i:2 * i + 2])
             feats = f if last else feats
         ly = self.layers[-1]
+        if ly is None:
+            return (None, feats)
         _, maps = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"],
                                out_split=False, out_nchw=True)
         return (maps, feats) if want_features else maps

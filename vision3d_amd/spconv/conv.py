@@ -2,7 +2,7 @@
 
 Weight layout is spconv-1.x's (k0, k1, k2, Cin, Cout), so a reference-trained state_dict
 (`cnn.blocks.{b}.{l}.0.weight`) loads unchanged.  Semantics: cross-correlation,
-identical to nn.Conv3d with weight.permute(4, 3, 0, 1, 2) (tests/test_sparse_conv_oracle.py).
+identical to nn.Conv3d with weight.permute(4, 3, 0, 1, 2) (tests/test_oracle_selfcheck.py, tests/test_gpu_conv3d_parity.py).
 
 When gradients are required (training) the layer runs through spconv/functional.py (data gradient = the same
 gather kernel on the transposed rulebook, weight gradient = deterministic MFMA reduction); inference keeps the
