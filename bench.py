@@ -130,7 +130,8 @@ def train_main(args):
     bs = args.batch if args.batch > 1 else 8
     torch.manual_seed(0)
     model = Second(cfg).cuda().train()
-    if not args.no_channels_last:  # dense RPN/head in NHWC: MIOpen's bf16 igemm kernels are NHWC-native (no per-conv transposes)
+    native_dense = os.environ.get("V3D_DENSE_TRAIN", "native") == "native" and not args.no_amp
+    if not args.no_channels_last and not native_dense:  # torch dense path only: MIOpen's bf16 igemm kernels are NHWC-native
         model.rpn = model.rpn.to(memory_format=torch.channels_last)
         model.head = model.head.to(memory_format=torch.channels_last)
         model.rpn.register_forward_pre_hook(lambda m, a: (a[0].contiguous(memory_format=torch.channels_last),))
@@ -186,7 +187,9 @@ def train_main(args):
             metric="frames/sec SECOND train step, 16k-pt KITTI cloud", value=world * bs * args.steps / elapsed, unit="frames/s",
             n_gpus=world, n_ranks_seen=seen, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
             scaling="weak", vs_baseline=None,
-            dtype=("bf16 autocast dense RPN/head; " if amp else "fp32 dense RPN/head; ") + "sparse convs bf16-split MFMA fwd/dX, fp32 MFMA dW",
+            dtype=(("bf16 dense RPN/head on hand-written MFMA kernels (csrc/dense_train.hip), fp32 accumulate; " if native_dense else
+                    "bf16 autocast dense RPN/head (torch / MIOpen); ") if amp else "fp32 dense RPN/head (torch / MIOpen); ")
+            + "sparse convs bf16-split MFMA fwd/dX, fp32 MFMA dW",
             data="synthetic",
             config=dict(workload="SECOND train step (BASELINE configs[2]): fwd + ProposalLoss + bwd + grad all-reduce + clip + Adam",
                         frames_per_gpu_per_step=bs, points_per_frame=args.points, parallelism=f"data-parallel x{world}, two-bucket all-reduce (dense bucket overlapped with the sparse backward)"),

@@ -359,6 +359,71 @@ size_t v3d_backbone_train_arena_bytes(const v3d_backbone* plan);
  * forward cannot be repeated after tuning: it updates the running statistics).  Blocking; never during stream capture. */
 int v3d_backbone_tune_from_voxels(v3d_backbone* plan, const int32_t* coords, int n_voxels, int B, v3d_stream_t stream);
 
+
+/* ---- Dense TRAIN path of the BEV head (csrc/dense_train.hip): the RPN's Conv2d(128 -> 128, 3x3 pad 1 | 1x1, bias-free) +
+ * BatchNorm2d (batch statistics) + ReLU layers and the fused 1x1 [cls | reg] head, forward and backward, bf16 storage / fp32
+ * accumulation (the arithmetic of the reference's stack under torch autocast).  Replaces what train.py:58-66 runs through
+ * cuDNN for detector/second.py:58-94 and detector/proposal.py:19-22.  All activations: bf16 NHWC (B, H, W, 128) = torch
+ * channels_last bfloat16; every reduction is two-level in a fixed order (bit-repeatable).  128 channels are fixed. */
+size_t v3d_dense_train_weight_image_bytes(int ksize);
+/* weight (128, 128, k, k) fp32 -> bf16 fragment image; transpose = 0: forward, 1: data gradient (channels swapped, taps flipped) */
+int v3d_dense_train_pack_weights(const float* weight, int ksize, int transpose, void* image, v3d_stream_t stream);
+int v3d_dense_train_conv_tiles(int B, int H, int W); /* tiles of one convolution = rows of its `stats` output */
+/* y = conv(x) (no bias, stride 1, pad k/2); stats (nullable): (tiles, 2, 128) fp32 per-tile channel sums / sums of squares of y */
+int v3d_dense_train_conv(const void* x, const void* image, int B, int H, int W, int ksize, void* y, float* stats,
+                         v3d_stream_t stream);
+/* per-tile sums -> mean / invstd (biased variance, eps); running statistics (nullable pair; momentum, unbiased variance) and
+ * num_batches_tracked (nullable) updated in place -- nn.BatchNorm2d's training-mode bookkeeping */
+int v3d_dense_train_bn_finalize(const float* stats, int tiles, long long count, float eps, float momentum, float* mean,
+                                float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                v3d_stream_t stream);
+/* y = relu?((x - mean) * invstd * gamma + beta), M = B*H*W pixels */
+int v3d_dense_train_bn_relu_apply(const void* x, long long M, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, int relu, void* y, v3d_stream_t stream);
+size_t v3d_dense_train_bn_bwd_workspace(void);
+/* x = the layer's raw convolution output, dy = gradient w.r.t. the post-ReLU output -> dx (may alias dy), dgamma, dbeta */
+int v3d_dense_train_bn_relu_bwd(const void* x, const void* dy, long long M, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, int relu, void* dx, float* dgamma, float* dbeta,
+                                void* workspace, size_t workspace_bytes, v3d_stream_t stream);
+/* Weight gradient operands: zero-bordered channel planes (ns, B, 128, H + 2, Wp) bf16, Wp = v3d_dense_train_planar_width;
+ * ns = 3: copies shifted by -1 / 0 / +1 elements (the layer INPUT of a 3x3 layer), ns = 1: unshifted.  The buffer must be
+ * zero-filled once by the caller (rows 0 and H + 1 of every plane are never written). */
+int v3d_dense_train_planar_width(int H, int W);
+int v3d_dense_train_to_planar(const void* x, int B, int H, int W, int ns, void* planar, v3d_stream_t stream);
+size_t v3d_dense_train_wgrad_workspace(int ksize);
+/* dW (128, 128, k, k) fp32 = sum over pixels of dy (x) x shifted by the tap; xs / dy as produced by v3d_dense_train_to_planar */
+int v3d_dense_train_wgrad(const void* xs, const void* dy, int B, int H, int W, int ksize, float* dw, void* workspace,
+                          size_t workspace_bytes, v3d_stream_t stream);
+/* fused 1x1 head, O in {8, 16, 24, 32, 48, 64} outputs with bias: maps fp32 (B, O, H, W) */
+size_t v3d_dense_train_head_workspace(int O);
+int v3d_dense_train_head_fwd(const void* feat, int B, int H, int W, const float* weight, const float* bias, int O, float* maps,
+                             v3d_stream_t stream);
+int v3d_dense_train_head_bwd(const void* feat, const float* dmaps, int B, int H, int W, const float* weight, int O, void* dfeat,
+                             float* dweight, float* dbias, void* workspace, size_t workspace_bytes, v3d_stream_t stream);
+/* The whole dense half of a train step, one call per direction (n_layers x [conv + batch-statistics BatchNorm + ReLU] + head).
+ * arena: a device buffer of v3d_dense_train_arena_bytes owned by the caller, cleared once by v3d_dense_train_arena_init; it
+ * carries the forward's activations and statistics to the backward of the SAME step.  bev / dbev: bf16 NHWC (B, H, W, 128). */
+typedef struct {
+  const float* weight;               /* (128, 128, k, k) */
+  const float* gamma;                /* BatchNorm2d weight / bias */
+  const float* beta;
+  float* running_mean;               /* nullable pair; updated by the forward */
+  float* running_var;
+  int64_t* num_batches_tracked;      /* nullable */
+  float eps, momentum;
+  int32_t ksize;                     /* 1 or 3 */
+  float* grad_weight;                /* outputs of the backward (unused by the forward) */
+  float* grad_gamma;
+  float* grad_beta;
+} v3d_dense_train_layer;
+size_t v3d_dense_train_arena_bytes(int B, int H, int W, int n_layers, int O);
+int v3d_dense_train_arena_init(void* arena, int B, int H, int W, int n_layers, int O, v3d_stream_t stream);
+int v3d_dense_train_forward(const void* bev, int B, int H, int W, const v3d_dense_train_layer* layers, int n_layers,
+                            const float* head_weight, const float* head_bias, int O, void* arena, float* maps, v3d_stream_t stream);
+int v3d_dense_train_backward(const void* bev, const float* dmaps, int B, int H, int W, const v3d_dense_train_layer* layers,
+                             int n_layers, const float* head_weight, int O, void* arena, float* dhead_weight, float* dhead_bias,
+                             void* dbev, v3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,25 @@ _SIGNATURES = {
     "v3d_conv2d_nhwc_bf16x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "v3d_densify_nhwc_split": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "v3d_nchw_to_split_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "v3d_dense_train_weight_image_bytes": (_sz, [_i]),
+    "v3d_dense_train_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
+    "v3d_dense_train_conv_tiles": (_i, [_i, _i, _i]),
+    "v3d_dense_train_conv": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "v3d_dense_train_bn_finalize": (_i, [_vp, _i, C.c_longlong, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "v3d_dense_train_bn_relu_apply": (_i, [_vp, C.c_longlong, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "v3d_dense_train_bn_bwd_workspace": (_sz, []),
+    "v3d_dense_train_bn_relu_bwd": (_i, [_vp, _vp, C.c_longlong, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "v3d_dense_train_planar_width": (_i, [_i, _i]),
+    "v3d_dense_train_to_planar": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "v3d_dense_train_wgrad_workspace": (_sz, [_i]),
+    "v3d_dense_train_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "v3d_dense_train_head_workspace": (_sz, [_i]),
+    "v3d_dense_train_head_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "v3d_dense_train_head_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "v3d_dense_train_arena_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "v3d_dense_train_arena_init": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "v3d_dense_train_forward": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "v3d_dense_train_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
 }
 
 
@@ -101,6 +120,13 @@ class TrainLayer(C.Structure):
     _fields_ = [("weight", _vp), ("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp),
                 ("num_batches_tracked", _vp), ("eps", C.c_float), ("momentum", C.c_float), ("grad_weight", _vp),
                 ("grad_gamma", _vp), ("grad_beta", _vp)]
+
+
+class DenseTrainLayer(C.Structure):
+    """v3d_dense_train_layer: device pointers of one RPN conv + BatchNorm2d group (parameters in, gradients out)."""
+    _fields_ = [("weight", _vp), ("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp),
+                ("num_batches_tracked", _vp), ("eps", C.c_float), ("momentum", C.c_float), ("ksize", C.c_int32),
+                ("grad_weight", _vp), ("grad_gamma", _vp), ("grad_beta", _vp)]
 
 
 _lib = None

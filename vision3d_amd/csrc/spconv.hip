@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__((2 * OG + NMV) * 64) void spconv_fwd_rows_ring(cons
       if (ki == 0) {
         asm_gld16(a[0], prow);
         asm_gld16_16(a[1], prow);
-      } else {
+      } else if constexpr (KI == 2) {
         asm_gld16_128(a[2], prow);
         asm_gld16_144(a[3], prow);
       }

@@ -179,11 +179,34 @@ class Second(nn.Module):
         hi, lo = plan.forward_voxels_split(item["voxel_mean"], item["coordinates"], b)
         return self.dense_plan().forward(hi, lo, occ=plan.bev_occupancy(b) if self.skip_background else None), plan
 
+    # training: RPN + heads forward / backward on csrc/dense_train.hip (bf16 storage, fp32 accumulation) instead of torch / MIOpen,
+    # when the step runs under bf16 autocast -- the precision contract of that path -- and the shapes are covered
+    native_dense_train = os.environ.get("V3D_DENSE_TRAIN", "native") == "native"
+
+    def _train_head_maps(self, item):
+        """-> fused fp32 head maps of a TRAINING forward through the native dense plan [or the (scores, boxes) pair of the torch
+        modules where the plan does not apply], or None outside bf16-autocast training."""
+        if not (self.native_dense_train and self.training and torch.is_grad_enabled() and torch.is_autocast_enabled("cuda")
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            return None
+        from .. import dense_train
+        features = item["voxel_mean"] if "voxel_mean" in item else self.vfe(item["features"], item["occupancy"])
+        bev = self.cnn(features, item["coordinates"], item["batch_size"])
+        if not bev.is_cuda or bev.dim() != 4 or bev.shape[1] != 128:
+            return self.head(self.rpn(bev))
+        if bev.dtype != torch.bfloat16 or not bev.is_contiguous(memory_format=torch.channels_last):
+            bev = bev.to(dtype=torch.bfloat16, memory_format=torch.channels_last)  # what autocast's first conv would do
+        if not dense_train.supported(self.rpn, self.head, bev):
+            return self.head(self.rpn(bev))
+        return dense_train.train_head_maps(self.rpn, self.head, bev, self.__dict__.setdefault("_dense_train_plans", {}))
+
     def forward(self, item):
         if self._native_item(item):
             maps, plan = self._head_maps_from_item(item)
             plan.check_overflow()  # no count is read on this path: one blocking word
             scores, boxes = self.head.maps_from_fused(maps)
+        elif (maps := self._train_head_maps(item)) is not None:
+            scores, boxes = maps if isinstance(maps, tuple) else self.head.maps_from_fused(maps)
         else:
             scores, boxes = self.head(self.feature_extract(item))
         item.update(dict(P_cls=scores, P_reg=boxes))
