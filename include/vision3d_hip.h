@@ -385,14 +385,10 @@ size_t v3d_dense_train_bn_bwd_workspace(void);
 int v3d_dense_train_bn_relu_bwd(const void* x, const void* dy, long long M, const float* mean, const float* invstd,
                                 const float* gamma, const float* beta, int relu, void* dx, float* dgamma, float* dbeta,
                                 void* workspace, size_t workspace_bytes, v3d_stream_t stream);
-/* Weight gradient operands: zero-bordered channel planes (ns, B, 128, H + 2, Wp) bf16, Wp = v3d_dense_train_planar_width;
- * ns = 3: copies shifted by -1 / 0 / +1 elements (the layer INPUT of a 3x3 layer), ns = 1: unshifted.  The buffer must be
- * zero-filled once by the caller (rows 0 and H + 1 of every plane are never written). */
-int v3d_dense_train_planar_width(int H, int W);
-int v3d_dense_train_to_planar(const void* x, int B, int H, int W, int ns, void* planar, v3d_stream_t stream);
+/* dW (128, 128, k, k) fp32 = sum over pixels of dy (x) x shifted by the tap, straight from the NHWC tensors (x: the layer's bf16
+ * input, dy: the bf16 gradient of its raw output).  Bit-repeatable (fixed-order two-level reduction). */
 size_t v3d_dense_train_wgrad_workspace(int ksize);
-/* dW (128, 128, k, k) fp32 = sum over pixels of dy (x) x shifted by the tap; xs / dy as produced by v3d_dense_train_to_planar */
-int v3d_dense_train_wgrad(const void* xs, const void* dy, int B, int H, int W, int ksize, float* dw, void* workspace,
+int v3d_dense_train_wgrad(const void* x, const void* dy, int B, int H, int W, int ksize, float* dw, void* workspace,
                           size_t workspace_bytes, v3d_stream_t stream);
 /* fused 1x1 head, O in {8, 16, 24, 32, 48, 64} outputs with bias: maps fp32 (B, O, H, W) */
 size_t v3d_dense_train_head_workspace(int O);

@@ -88,8 +88,6 @@ _SIGNATURES = {
     "v3d_dense_train_bn_relu_apply": (_i, [_vp, C.c_longlong, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "v3d_dense_train_bn_bwd_workspace": (_sz, []),
     "v3d_dense_train_bn_relu_bwd": (_i, [_vp, _vp, C.c_longlong, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "v3d_dense_train_planar_width": (_i, [_i, _i]),
-    "v3d_dense_train_to_planar": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "v3d_dense_train_wgrad_workspace": (_sz, [_i]),
     "v3d_dense_train_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "v3d_dense_train_head_workspace": (_sz, [_i]),
