@@ -42,11 +42,17 @@ buf = (C.c_ulonglong * 256)()
 fn(buf)
 t = np.array(buf, dtype=np.int64).reshape(2, 128)
 t0 = t[t > 0].min()
-for role, name in ((0, "multiplier wave 0: stage | at barrier | released | MFMAs issued | reads done"), (1, "loader wave 4: stage | before wait | landed | released | issued")):
+for role, name in ((0, "multiplier wave 0: stage | top | first-half MFMAs issued | fragment reads returned | barrier passed"),
+                   (1, "loader wave 8: stage | before wait | landed | barrier passed | requests issued")):
     print(name)
-    for g in range(24):
+    for g in range(28):
         r = t[role, 4 * g:4 * g + 4]
         if r.min() <= 0:
             continue
         nxt = t[role, 4 * g + 4] if 4 * g + 4 < 128 else 0
         print(f"  {g:3d} | " + " | ".join(f"{int(v - t0):7d}" for v in r) + f" | stage total {int(nxt - r[0]) if nxt > 0 else -1}")
+print("tile epilogues of multiplier wave 0 (start, end, clocks):")
+for k in range(8):
+    a, b = t[0, 112 + 2 * k], t[0, 113 + 2 * k]
+    if a > 0 and b > 0:
+        print(f"  tile {k}: {int(a - t0):8d} {int(b - t0):8d} {int(b - a):7d}")

@@ -257,13 +257,23 @@ __global__ __launch_bounds__(DT_THREADS) void dt_conv_kernel(const dt_bf16* __re
 // ------------------------------------------------------------------------------------------------ 3x3 convolution, 2-D tiles
 // The kernel above reads every input pixel row once PER TAP: nine times the activation tensor (650 MB per layer at bs = 8) through
 // L2 slices that cannot hold a tile's three-row neighbourhood for every CU -- measured 135-172 us per layer, HBM / Infinity-Cache
-// bound, against 33 us of MFMA.  Here a tile is an 8 x 16 block of output pixels and its (8 + 2) x (16 + 2) input neighbourhood
-// (180 pixel rows x 256 B = 45 KB, zero halo) is brought into LDS ONCE -- for the next tile while the current one multiplies --
-// and all nine taps read their fragments from it (a tap = a pixel-row offset into the same LDS image).  Only the weights stream per
-// stage: stage = (tap, 64-channel half) = 16 KB of fragments through a ring of 3 slots, two stages ahead (they are the same 288 KB
-// for every tile: L2 hits).  Same wave roles as above: waves 4-7 load (LDS-DMA, hand-counted vmcnt), waves 0-3 multiply (pixel tile
-// i = row i of the block; wave (ph, ch) owns rows 4 ph .. 4 ph + 3 x cout tiles 4 ch .. 4 ch + 3), one barrier per stage, epilogue
-// in four quarters of 32 pixels through the scratch, statistics per workgroup.
+// bound, against 33 us of MFMA.  Here a tile is a 16 x 16 block of output pixels x all 128 couts; its (16 + 2) x (16 + 2) input
+// neighbourhood is brought into LDS ONCE, as two 64-channel slices (324 pixel rows x 128 B = 41 KB each, zero halo, chunk p of
+// pixel row hp stored at chunk p ^ (hp & 7): every ds_read_b128 lane group then covers the 16 slots of the 256-byte bank row once,
+// for every tap alignment), each slice loaded while the other multiplies.  The reduction runs slice-outer, tap-inner: stage =
+// (slice, tap) = 64 channels x 128 couts = 16 KB of weight fragments through a ring of 4 slots.
+//
+// What bounds this kernel is the ISSUE cost of LDS-DMA requests while the LDS is busy serving fragment reads (100-185 clocks per
+// 1 KB request, MI355X_MICROARCH.md): the first version (8 x 16 tiles, 256-byte pixel rows) issued 333 requests per 128 pixels
+// -- 12 k clocks per loading wave against 9.2 k clocks of MFMA, measured 107 us per layer; with 256-pixel tiles the weight stages
+// are amortised over twice the MFMAs (185 requests per 128 pixels).
+//
+// Waves 8-11 load.  Waves 0-7 multiply, two per SIMD: wave (pq, ch) owns block rows 4 pq .. 4 pq + 3 (four 16-pixel tiles) x couts
+// 64 ch .. 64 ch + 63 (four tiles): 16 accumulators, 16 fragment reads per 32 MFMAs.  The WEIGHTS are the MFMA's row operand, so a
+// lane ends up with four consecutive couts of one pixel: the epilogue is one 8-byte store per accumulator straight from registers
+// (no LDS round trip, no barrier), and the batch statistics accumulate in registers over all tiles of the workgroup.
+// One barrier per stage, in the MIDDLE of its MFMAs: the second half's fragments are requested before the first half multiplies,
+// the next stage's first half (its weights landed a stage early) before the second half does.
 #ifndef DT_TIMELINE
 #define DT_TIMELINE 0  // 1: cycle-counter stamps of workgroup 8 (tools/mb_dense_train.py prints them)
 #endif
@@ -276,219 +286,286 @@ extern "C" int v3d_debug_dense_train_timeline(unsigned long long* host_out) {
 #else
 #define DT_STAMP(role, idx)
 #endif
-#define DT3_TH 8
+#define DT3_TH 8                                  // (tile of the weight-gradient kernel)
 #define DT3_TW 16
-#define DT3_HALO ((DT3_TH + 2) * (DT3_TW + 2))   // 180 pixel rows
-#define DT3_ABUF (DT3_HALO * 256)                // 46 080 B
-#define DT3_APIECES ((DT3_HALO + 3) / 4)         // 45 LDS-DMA requests of 4 pixel rows
-#define DT3_BSLOT 16384
-#define DT3_NB 4                                 // weight stages in the ring: three in flight ahead of the multiply
-#define DT3_SMEM (2 * DT3_ABUF + DT3_NB * DT3_BSLOT)  // 92 160 + 65 536 = 157 696 B; the epilogue scratch is the finished tile's image
-#define DT3_THREADS 768  // 8 multiplying waves (two per SIMD) + 4 loading waves
-#define DT3_TS2 (DT_C + 4)
-__global__ __launch_bounds__(DT3_THREADS) void dt_conv3_kernel(const dt_bf16* __restrict__ x, const dt_bf16* __restrict__ w_img,
+#define DT3_HALO ((DT3_TH + 2) * (DT3_TW + 2))
+#define DC3_T 16                                  // 16 x 16 output pixels
+#define DC3_HW (DC3_T + 2)
+#define DC3_HALO (DC3_HW * DC3_HW)                // 324 pixel rows
+#define DC3_APIECES ((DC3_HALO + 7) / 8)          // 41 LDS-DMA requests of 8 pixel rows x 128 B
+#define DC3_ABUF (DC3_APIECES * 1024)             // 41 984 B per slice
+#define DC3_BSLOT 16384
+#define DC3_NB 4
+#define DC3_SMEM (2 * DC3_ABUF + DC3_NB * DC3_BSLOT)  // 83 968 + 65 536 = 149 504 B
+#define DC3_THREADS 768                           // 8 multiplying waves (two per SIMD) + 4 loading waves
+#define DC3_SPT 18                                // stages per tile: 2 slices x 9 taps
+// Reduce-scatter over the 16 lanes that share lane >> 4: returns, to lane l (= lane & 15), the sum over those lanes of v[l].
+// Four halving steps (lane bit 3 picks the upper or lower eight values and sends the others to its partner, ...): a fixed tree.
+// The exchanges are DPP row rotations / quad permutes and one ds_swizzle: no address arithmetic, no LDS traffic.
+__device__ __forceinline__ float dt_x8(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128 /* row_ror:8 */, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dt_x4(float x) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x101f /* xor 4 */)); }
+__device__ __forceinline__ float dt_x2(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4e /* quad_perm 2,3,0,1 */, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dt_x1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xb1 /* quad_perm 1,0,3,2 */, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dt_rs16(const float (&v)[16], int l) {
+  float k8[8], k4[4], k2[2];
+  const bool h3 = l & 8, h2 = l & 4, h1 = l & 2, h0 = l & 1;
+#pragma unroll
+  for (int i = 0; i < 8; i++) k8[i] = (h3 ? v[8 + i] : v[i]) + dt_x8(h3 ? v[i] : v[8 + i]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) k4[i] = (h2 ? k8[4 + i] : k8[i]) + dt_x4(h2 ? k8[i] : k8[4 + i]);
+#pragma unroll
+  for (int i = 0; i < 2; i++) k2[i] = (h1 ? k4[2 + i] : k4[i]) + dt_x2(h1 ? k4[i] : k4[2 + i]);
+  return (h0 ? k2[1] : k2[0]) + dt_x1(h0 ? k2[0] : k2[1]);
+}
+template <int N> __device__ __forceinline__ void dt_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__global__ __launch_bounds__(DC3_THREADS) void dt_conv3_kernel(const dt_bf16* __restrict__ x, const dt_bf16* __restrict__ w_img,
                                                                int B, int H, int W, dt_bf16* __restrict__ y,
                                                                float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dt_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tx_n = (W + DT3_TW - 1) / DT3_TW, ty_n = (H + DT3_TH - 1) / DT3_TH;
+  const int tx_n = (W + DC3_T - 1) / DC3_T, ty_n = (H + DC3_T - 1) / DC3_T;
   const int ntiles = B * ty_n * tx_n;
-  constexpr int SPT = 18;  // stages per tile: 9 taps x 2 channel halves
   const int my_tiles = blockIdx.x < ntiles ? (ntiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
-  const int nstage = my_tiles * SPT;
-  unsigned char* const abuf = dt_smem;                      // [2][180][256 B]
-  unsigned char* const bring = dt_smem + 2 * DT3_ABUF;      // [4][16 KB]
-  static_assert(64 * DT3_TS2 * 4 <= DT3_ABUF && 32 * 2 * DT_C * 4 <= DT3_ABUF, "epilogue scratch lives in a neighbourhood buffer");
+  const int nstage = my_tiles * DC3_SPT;
+  unsigned char* const abuf = dt_smem;                      // [2 slices][41 x 1 KB]
+  unsigned char* const bring = dt_smem + 2 * DC3_ABUF;      // [4][16 KB]
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  // (wave-uniform: scalar registers, computed once per tile -- per-lane integer divisions in the loaders' issue path cost
-  // more than the requests themselves)
-  auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
+  auto tile_origin = [&](int t, int& b, int& y0, int& x0) {  // wave-uniform: scalar registers
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x + t * gridDim.x);
     b = tile / (ty_n * tx_n);
     const int r = tile - b * ty_n * tx_n;
-    y0 = (r / tx_n) * DT3_TH;
-    x0 = (r % tx_n) * DT3_TW;
+    y0 = (r / tx_n) * DC3_T;
+    x0 = (r % tx_n) * DC3_T;
   };
 
   if (wave >= 8) {
     // ------------------------------------------------------------------ loaders
+    // (they share their SIMDs with two multiplying waves each: at equal priority every address instruction of a request waits
+    // for a gap between MFMAs -- measured ~160 clocks per weight request, ~900 per slice request)
+    __builtin_amdgcn_s_setprio(3);
     const int lw = wave - 8;
-    const int sub = lane >> 4, slot = lane & 15;
-    int nb = 0, ny0 = 0, nx0 = 0;  // origin of the tile whose neighbourhood is being requested
-    auto issue_a = [&](int t, int piece) {  // 4 pixel rows of tile t's input neighbourhood (origin in nb / ny0 / nx0)
-      const int hp = piece * 4 + sub;
-      const int hy = hp / (DT3_TW + 2), hx = hp - hy * (DT3_TW + 2);
-      const int yy = ny0 - 1 + hy, xx = nx0 - 1 + hx;
-      const bool ok = hp < DT3_HALO && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      const int part = slot ^ (hp & 15);
-      const dt_bf16* src = ok ? x + (((size_t)nb * H + yy) * W + xx) * DT_C + part * 8 : reinterpret_cast<const dt_bf16*>(dt_zero16);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abuf + (t & 1) * DT3_ABUF + piece * 1024), 16, 0, 0);
+    const int sub = lane >> 3, slot = lane & 7;
+    int nb = 0, ny0 = 0, nx0 = 0;  // origin of the tile whose slice is being requested
+    // request k of this loader = piece 4 k + lw: the lane's pixel row (hy, hx) of the neighbourhood and its byte offset from the
+    // tile's first pixel are fixed -- tabulated once (computed per request, this address arithmetic was most of a request's cost)
+    int tab_yx[11], tab_rel[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+      const int hp = (4 * k + lw) * 8 + sub;
+      const int hy = hp / DC3_HW, hx = hp - hy * DC3_HW;
+      tab_yx[k] = hp < DC3_HALO ? (hy | (hx << 16)) : 0x7fff;  // (row 32767 is outside every image)
+      tab_rel[k] = ((hy - 1) * W + (hx - 1)) * (DT_C * 2) + ((slot ^ (hp & 7)) << 4);
+    }
+    const unsigned char* tile_base = nullptr;  // first pixel of the tile being requested (wave-uniform)
+    auto issue_a = [&](int h, int k) {  // 8 pixel rows x 64 channels of slice h of the tile at (nb, ny0, nx0)
+      const int yy = ny0 - 1 + (tab_yx[k] & 0xffff), xx = nx0 - 1 + (tab_yx[k] >> 16);
+      const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const unsigned char* src = ok ? tile_base + (long long)(tab_rel[k] + h * 128) : reinterpret_cast<const unsigned char*>(dt_zero16);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abuf + h * DC3_ABUF + (4 * k + lw) * 1024), 16, 0, 0);
     };
-    auto issue_b = [&](int G) {  // stage G = (tile G / 18, tap (G % 18) / 2, half G % 2): 16 KB of weight fragments
-      const int s = G % SPT;
-      const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(w_img) + (size_t)(s >> 1) * DT_B_BYTES + (s & 1) * 16384 + lw * 4096 + lane * 16;
-      unsigned char* Bd = bring + (G % DT3_NB) * DT3_BSLOT + lw * 4096;
+    auto new_tile = [&](int t) {
+      tile_origin(t, nb, ny0, nx0);
+      tile_base = reinterpret_cast<const unsigned char*>(x + (((size_t)nb * H + ny0) * W + nx0) * DT_C);
+    };
+    auto issue_b = [&](int G) {  // stage G = (tile, slice h, tap): 16 KB of weight fragments
+      const int s = G % DC3_SPT, h = s / 9, tap = s - 9 * h;
+      const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(w_img) + (size_t)tap * DT_B_BYTES + h * 16384 + lw * 4096 + lane * 16;
+      unsigned char* Bd = bring + (G % DC3_NB) * DC3_BSLOT + lw * 4096;
 #pragma unroll
       for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + j * 1024), (lptr_t)(Bd + j * 1024), 16, 0, 0);
     };
-    // prologue: the first tile's neighbourhood (12 requests per loader: 45 pieces, the surplus repeats the last one), three stages
-    if (nstage > 0) {
-      tile_origin(0, nb, ny0, nx0);
-#pragma unroll 1
-      for (int q = 0; q < 12; q++) issue_a(0, min(q * 4 + lw, DT3_APIECES - 1));
-      for (int a = 0; a < DT3_NB - 1; a++)
-        if (a < nstage) issue_b(a);
-      // the multipliers read the first tile's fragments behind this barrier (the neighbourhood is older than every weight stage)
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");
-    }
-    for (int G = 0; G < nstage; G++) {
-      // stage G's weights (and everything older) have landed once only the younger weight stages (4 requests each) are outstanding;
-      // neighbourhood pieces issued in the last iterations are waited for as well: conservative, they are small
-      if (G < 32) DT_STAMP(1, 4 * G);
-      if (G + 2 < nstage) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (G + 1 < nstage) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (G < 32) DT_STAMP(1, 4 * G + 1);
-      asm volatile("s_barrier" ::: "memory");  // stage G readable; stage G - 1 finished everywhere (its weight slot is free)
-      if (G < 32) DT_STAMP(1, 4 * G + 2);
-      if (G + DT3_NB - 1 < nstage) issue_b(G + DT3_NB - 1);
-      const int t = G / SPT, s = G - t * SPT;
-      if (s == 0 && t + 1 < my_tiles) tile_origin(t + 1, nb, ny0, nx0);
-      if (s < 12 && t + 1 < my_tiles) issue_a(t + 1, min(s * 4 + lw, DT3_APIECES - 1));  // next tile's neighbourhood, one piece per stage
-      if (G < 32) DT_STAMP(1, 4 * G + 3);
-      if (s == SPT - 1) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) asm volatile("s_barrier" ::: "memory");  // the multipliers' epilogue
+    // Slice sl (= 2 tile + h, multiplied in stages 9 sl .. 9 sl + 8) is requested in iterations 9 sl - 9 .. 9 sl - 2 -- its buffer is
+    // released by barrier 9 sl - 9, and a request issued in iteration i is older than weight stage i + 3, whose landing barrier
+    // i + 2 waits for.  11 requests per loader in 8 iterations: k = i' and, for i' < 3, k = 8 + i'; piece = 4 k + lw (< 41).
+    auto issue_slice_part = [&](int G) -> int {  // returns the number of requests issued
+      const int sl = G / 9 + 1, ip = G - 9 * (sl - 1);
+      if (sl >= 2 * my_tiles || ip >= 8) return 0;
+      if (ip == 0 && (sl & 1) == 0) new_tile(sl >> 1);
+      // (k as a compile-time index of the tables: a switch over the iteration within the slice)
+      int n = 1;
+      switch (ip) {
+        case 0: issue_a(sl & 1, 0); if (32 + lw < DC3_APIECES) { issue_a(sl & 1, 8); n = 2; } break;
+        case 1: issue_a(sl & 1, 1); if (36 + lw < DC3_APIECES) { issue_a(sl & 1, 9); n = 2; } break;
+        case 2: issue_a(sl & 1, 2); if (40 + lw < DC3_APIECES) { issue_a(sl & 1, 10); n = 2; } break;
+        case 3: issue_a(sl & 1, 3); break;
+        case 4: issue_a(sl & 1, 4); break;
+        case 5: issue_a(sl & 1, 5); break;
+        case 6: issue_a(sl & 1, 6); break;
+        default: issue_a(sl & 1, 7); break;
       }
+      return n;
+    };
+    int na_prev = 0;
+    if (nstage > 0) {
+      new_tile(0);
+#pragma unroll
+      for (int k = 0; k < 11; k++)
+        if (4 * k + lw < DC3_APIECES) issue_a(0, k);
+      issue_b(0);
+      issue_b(1);
+      issue_b(2);
+      dt_vmwait<4>();  // slice 0, stages 0 and 1
+      asm volatile("s_barrier" ::: "memory");
+      na_prev = issue_slice_part(0);
+      if (3 < nstage) issue_b(3);
     }
-    asm volatile("s_barrier\n\ts_barrier" ::: "memory");  // the statistics exchange
+    for (int G = 1; G < nstage; G++) {
+      // barrier G promises: weight stage G + 1 and every request older than it have landed.  Younger than it: the slice requests of
+      // iteration G - 1 and weight stage G + 2.
+      const int younger = __builtin_amdgcn_readfirstlane((G + 1 < nstage ? na_prev : 0) + (G + 2 < nstage ? 4 : 0));
+      DT_STAMP(1, 4 * G);
+      if (younger >= 6) dt_vmwait<6>();
+      else if (younger == 5) dt_vmwait<5>();
+      else if (younger == 4) dt_vmwait<4>();
+      else dt_vmwait<0>();
+      DT_STAMP(1, 4 * G + 1);
+      asm volatile("s_barrier" ::: "memory");  // stage G - 1 is finished everywhere: its weight slot is free
+      DT_STAMP(1, 4 * G + 2);
+      na_prev = issue_slice_part(G);
+      if (G + 3 < nstage) issue_b(G + 3);
+      DT_STAMP(1, 4 * G + 3);
+    }
+    if (nstage > 0) asm volatile("s_barrier" ::: "memory");  // the multipliers' last one
+    asm volatile("s_barrier\n\ts_barrier" ::: "memory");     // the statistics exchange
   } else {
-    // ------------------------------------------------------------------ multipliers: wave (ph = w & 1, ch = w >> 1) owns block rows
-    // 4 ph .. 4 ph + 3 x cout tiles 2 ch, 2 ch + 1; two of them share a SIMD, so one's LDS waits sit under the other's MFMAs
-    const int ph = wave & 1, ch = wave >> 1;
-    const int c8 = tid & 15, rg = tid >> 4;  // epilogue role of the 512 multiplier threads: 8 consecutive couts, scratch rows rg, rg + 32
-    float s1[8], s2[8];
+    // ------------------------------------------------------------------ multipliers
+    const int pq = wave & 3, ch = wave >> 2;
+    const int kg = lane >> 4, pxl = lane & 15;
+    dt_f32x4 acc[4][4];   // [cout tile][pixel tile]
+    // batch statistics: after every tile the 16 pixel-column lanes of a cout group reduce-scatter their 16 (cout tile, r) sums in a
+    // fixed tree (dt_rs16), so that lane (pxl, kg) carries ONE channel -- 64 ch + 16 (pxl >> 2) + 4 kg + (pxl & 3) -- over all tiles
+    float st1 = 0.f, st2 = 0.f;
+    dt_bf16x8 wf[2][4], xf[2][4];  // [32-channel substep][tile]
+    // Fragment addresses.  Pixel fragment of (tap (ty, tx), pixel tile pt, substep ss), lane (pxl, kg): pixel row hp = q + c with
+    // q = 72 pq + pxl (the lane's part) and c = 18 (ty + pt) + tx (a constant of the unrolled stage); byte address
+    // 128 hp + 16 ((4 ss + kg) ^ (hp & 7)).  (hp & 7) only depends on c through c & 7: eight per-lane bases pw[c & 7], everything
+    // else is the instruction's immediate offset; substep 1 is the same address with bit 6 flipped.  (Computed per read, these
+    // addresses were ~40 VALU instructions per half stage in the shadow of 16 MFMAs.)
+    typedef const __attribute__((address_space(3))) unsigned char* lds_t;
+    const lds_t lds = (lds_t)dt_smem;
+    unsigned pw[8];
+    {
+      const int q = pq * 4 * DC3_HW + pxl;
 #pragma unroll
-    for (int e = 0; e < 8; e++) s1[e] = s2[e] = 0.f;
-    dt_f32x4 acc[4][2];
-    // A fragments of stage G: pixel tile i = block row ph * 4 + i shifted by the tap, channel half hf, both 32-channel substeps.
-    // They come from the tile's RESIDENT neighbourhood image, so the fragments of stage G + 1 are requested while stage G
-    // multiplies (the image of the next tile is complete several stages before the current tile ends); only the weight fragments
-    // of a stage are read behind its barrier.
-    dt_bf16x8 fa[2][2][4];  // [parity of the stage][substep][pixel tile]
-    const int lane_off = (lane & 15);
-    auto read_a = [&](int G2, dt_bf16x8 (&a)[2][4]) {
-      const int t2 = G2 / SPT, s2 = G2 - t2 * SPT;
-      const int tap = s2 >> 1, hf = s2 & 1;
-      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-      const unsigned char* A = abuf + (t2 & 1) * DT3_ABUF;
-      const int hp0 = (ph * 4 + 1 + dy) * (DT3_TW + 2) + 1 + dx + lane_off;
+      for (int jj = 0; jj < 8; jj++) pw[jj] = (unsigned)(q * 128 + ((kg ^ ((q + jj) & 7)) << 4));
+    }
+    const unsigned wlane = (unsigned)(2 * DC3_ABUF + ch * 4096 + lane * 16);
+    auto read_w = [&](unsigned wb, int ss, dt_bf16x8 (&w)[4]) {  // wb: wlane + 16 KB x ring slot
 #pragma unroll
-      for (int ss = 0; ss < 2; ss++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int hp = hp0 + i * (DT3_TW + 2);
-          a[ss][i] = *reinterpret_cast<const dt_bf16x8*>(A + hp * 256 + (((hf * 8 + ss * 4 + (lane >> 4)) ^ (hp & 15)) << 4));
-        }
+      for (int ct = 0; ct < 4; ct++) w[ct] = *reinterpret_cast<const __attribute__((address_space(3))) dt_bf16x8*>(lds + wb + (ss * 8 + ct) * 1024);
     };
-    auto stage = [&](int G, dt_bf16x8 (&cur)[2][4], dt_bf16x8 (&nxt)[2][4]) {
-      const int t = G / SPT, s = G - t * SPT;
-      if (s == 0) {
+    auto read_x = [&](int s, int ss, dt_bf16x8 (&xv)[4]) {  // s = stage within the tile: a constant of the unrolled body
+      const int h = s >= 9 ? 1 : 0, tap = s - 9 * h;
+      const int ty = tap / 3, tx = tap - 3 * ty;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = dt_f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      if (G < 32) DT_STAMP(0, 4 * G);
-      asm volatile("s_barrier" ::: "memory");
-      if (G < 32) DT_STAMP(0, 4 * G + 1);
-      const unsigned char* Bs = bring + (G % DT3_NB) * DT3_BSLOT;
-      dt_bf16x8 fb[2][2];
-#pragma unroll
-      for (int ss = 0; ss < 2; ss++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) fb[ss][j] = *reinterpret_cast<const dt_bf16x8*>(Bs + (ss * 8 + ch * 2 + j) * 1024 + lane * 16);
-      if (G + 1 < nstage) read_a(G + 1, nxt);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ss = 0; ss < 2; ss++)
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[ss][i], fb[ss][j], acc[i][j], 0, 0, 0);
-#if DT_TIMELINE
-      __builtin_amdgcn_sched_barrier(0);
-      if (G < 32) DT_STAMP(0, 4 * G + 2);
-#endif
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (G < 32) DT_STAMP(0, 4 * G + 3);
-      if (s == SPT - 1) {
-        // ---- epilogue: two halves of 64 pixels (block rows 4 h .. 4 h + 3) through the finished tile's image buffer
-        int b, y0, x0;
-        tile_origin(t, b, y0, x0);
-        float* const tl = reinterpret_cast<float*>(abuf + (t & 1) * DT3_ABUF);  // this tile's image is dead: its last stage is behind every wave
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          if (ph == h) {
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-              for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                  tl[(i * 16 + (lane >> 4) * 4 + r) * DT3_TS2 + (ch * 2 + j) * 16 + (lane & 15)] = acc[i][j][r];
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-          for (int k = 0; k < 2; k++) {
-            const int row = rg + 32 * k;                       // scratch row = (block row 4 h + row / 16, column row % 16)
-            const int yy = y0 + 4 * h + (row >> 4), xx = x0 + (row & 15);
-            if (yy < H && xx < W) {
-              const size_t m = ((size_t)b * H + yy) * W + xx;
-              const dt_f32x4 t0 = *reinterpret_cast<const dt_f32x4*>(tl + row * DT3_TS2 + c8 * 8);
-              const dt_f32x4 t1 = *reinterpret_cast<const dt_f32x4*>(tl + row * DT3_TS2 + c8 * 8 + 4);
-              const dt_u32x4 v = {dt_pack2(t0[0], t0[1]), dt_pack2(t0[2], t0[3]), dt_pack2(t1[0], t1[1]), dt_pack2(t1[2], t1[3])};
-              *reinterpret_cast<dt_u32x4*>(y + m * DT_C + c8 * 8) = v;
-              if (stats) {
-                float xr[8];
-                dt_unpack8(v, xr);
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                  s1[e] += xr[e];
-                  s2[e] = fmaf(xr[e], xr[e], s2[e]);
-                }
-              }
-            }
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
+      for (int pt = 0; pt < 4; pt++) {
+        const int c = (ty + pt) * DC3_HW + tx;
+        xv[pt] = *reinterpret_cast<const __attribute__((address_space(3))) dt_bf16x8*>(lds + (pw[c & 7] ^ (unsigned)(ss << 6)) + (h * DC3_ABUF + c * 128));
       }
     };
     if (nstage > 0) {
-      asm volatile("s_barrier" ::: "memory");  // the first tile's image is complete and visible
-      read_a(0, fa[0]);
+      asm volatile("s_barrier" ::: "memory");  // slice 0 and weight stages 0, 1 are readable
+      read_w(wlane, 0, wf[0]);
+      read_x(0, 0, xf[0]);
     }
-    for (int G = 0; G < nstage; G += 2) {  // 18 stages per tile: always an even number
-      stage(G, fa[0], fa[1]);
-      stage(G + 1, fa[1], fa[0]);
-    }
-    // ---- the workgroup's statistics: 32 row groups -> one partial per channel, in row-group order
-    float* const tl = reinterpret_cast<float*>(abuf);  // (every request has landed: the loaders' last wait was vmcnt(0))
-    if (stats) {
+#pragma unroll 1
+    for (int t = 0; t < my_tiles; t++) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        tl[(rg * 2 + 0) * DT_C + c8 * 8 + e] = s1[e];
-        tl[(rg * 2 + 1) * DT_C + c8 * 8 + e] = s2[e];
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) acc[a][p] = dt_f32x4{0.f, 0.f, 0.f, 0.f};
+      const int slot0 = __builtin_amdgcn_readfirstlane((2 * t) & 3);  // 18 stages per tile: the ring position advances by 2 per tile
+#pragma unroll
+      for (int s = 0; s < DC3_SPT; s++) {
+        const unsigned wb = wlane + (unsigned)(((slot0 + s) & 3) << 14), wbn = wlane + (unsigned)(((slot0 + s + 1) & 3) << 14);
+        if (t == 0 && s < 14) DT_STAMP(0, 4 * s);
+        read_w(wb, 1, wf[1]);
+        read_x(s, 1, xf[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int p = 0; p < 4; p++) acc[a][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][a], xf[0][p], acc[a][p], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // every fragment read of this stage has returned: its weight slot may be overwritten behind this barrier
+        if (t == 0 && s < 14) DT_STAMP(0, 4 * s + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t == 0 && s < 14) DT_STAMP(0, 4 * s + 2);
+        asm volatile("s_barrier" ::: "memory");
+        if (t == 0 && s < 14) DT_STAMP(0, 4 * s + 3);
+        read_w(wbn, 0, wf[0]);  // (behind the last stage: a read of valid LDS nobody uses -- unconditional, so that no branch join
+        read_x(s == DC3_SPT - 1 ? 0 : s + 1, 0, xf[0]);  //  makes the compiler wait for these before the MFMAs below)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int p = 0; p < 4; p++) acc[a][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][a], xf[1][p], acc[a][p], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      {
+        // ---- epilogue straight from the accumulators: lane = (pixel column pxl, couts 64 ch + 16 ct + 4 kg .. + 3) of rows 4 pq + pt
+        int b, y0, x0;
+        DT_STAMP(0, 112 + 2 * t);
+        tile_origin(t, b, y0, x0);
+        const int xx = x0 + pxl;
+        dt_f32x2 u1[8], u2[8];  // this tile, this lane's pixels: [2 cout tile + r / 2][r & 1]
+#pragma unroll
+        for (int e = 0; e < 8; e++) u1[e] = u2[e] = dt_f32x2{0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          const int yy = y0 + pq * 4 + p;
+          const bool valid = yy < H && xx < W;
+          // 16-byte stores (the tail is bound by the NUMBER of store instructions -- ~75 clocks each per CU whatever their width:
+          // 16 x 8 B per lane took 9.6 k clocks per tile, into an L2-resident target just the same): v_permlane16_swap trades cout
+          // tile a of the odd-kg lanes against tile a + 2 of the even-kg lanes, after which an even lane holds couts
+          // 16 a + 4 kg .. + 7 and an odd lane couts 16 (a + 2) + 4 (kg - 1) .. + 7 of its pixel
+          dt_bf16* dst = y + (((size_t)b * H + yy) * W + xx) * DT_C + ch * 64 + ((kg & 1) ? 32 + (kg - 1) * 4 : kg * 4);
+          unsigned lo[4], hi[4];
+#pragma unroll
+          for (int a = 0; a < 4; a++) {
+            lo[a] = valid ? dt_pack2(acc[a][p][0], acc[a][p][1]) : 0u;
+            hi[a] = valid ? dt_pack2(acc[a][p][2], acc[a][p][3]) : 0u;
+            // statistics of the ROUNDED values: what the next kernel reads
+            const dt_f32x2 va = {__uint_as_float(lo[a] << 16), __uint_as_float(lo[a] & 0xFFFF0000u)};
+            const dt_f32x2 vb = {__uint_as_float(hi[a] << 16), __uint_as_float(hi[a] & 0xFFFF0000u)};
+            u1[a * 2] += va; u2[a * 2] = __builtin_elementwise_fma(va, va, u2[a * 2]);          // (packed fp32 instructions)
+            u1[a * 2 + 1] += vb; u2[a * 2 + 1] = __builtin_elementwise_fma(vb, vb, u2[a * 2 + 1]);
+          }
+#pragma unroll
+          for (int a = 0; a < 2; a++) {
+            const auto s0 = __builtin_amdgcn_permlane16_swap(lo[a], lo[a + 2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(hi[a], hi[a + 2], false, false);
+            if (valid) *reinterpret_cast<dt_u32x4*>(dst + a * 16) = dt_u32x4{s0[0], s1[0], s0[1], s1[1]};
+          }
+        }
+        if (stats) {
+          float f1[16], f2[16];
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            f1[2 * e] = u1[e][0]; f1[2 * e + 1] = u1[e][1];
+            f2[2 * e] = u2[e][0]; f2[2 * e + 1] = u2[e][1];
+          }
+          st1 += dt_rs16(f1, pxl);
+          st2 += dt_rs16(f2, pxl);
+        }
+        DT_STAMP(0, 113 + 2 * t);
+      }
+    }
+    // ---- the workgroup's statistics: the four row groups of a channel, in order
+    float* const red = reinterpret_cast<float*>(abuf);  // (every request has landed and every fragment read has returned)
+    if (stats) {
+      const int c = ch * 64 + (pxl >> 2) * 16 + kg * 4 + (pxl & 3);
+      red[(pq * 2 + 0) * DT_C + c] = st1;
+      red[(pq * 2 + 1) * DT_C + c] = st2;
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (stats && tid < 2 * DT_C) {
       const int which = tid / DT_C, c = tid % DT_C;
       float a = 0.f;
-      for (int g = 0; g < 32; g++) a += tl[(g * 2 + which) * DT_C + c];
+#pragma unroll
+      for (int g = 0; g < 4; g++) a += red[(g * 2 + which) * DT_C + c];
       stats[((size_t)blockIdx.x * 2 + which) * DT_C + c] = a;
     }
     asm volatile("s_barrier" ::: "memory");
@@ -498,7 +575,7 @@ __global__ __launch_bounds__(DT3_THREADS) void dt_conv3_kernel(const dt_bf16* __
 // rows of the `stats` output of v3d_dense_train_conv = workgroups of its persistent grid
 extern "C" int v3d_dense_train_conv_tiles(int B, int H, int W) {
   const long long t1 = ((long long)B * H * W + DT_BM - 1) / DT_BM;                                          // 1x1: runs of 128 pixels
-  const long long t3 = (long long)B * ((H + DT3_TH - 1) / DT3_TH) * ((W + DT3_TW - 1) / DT3_TW);            // 3x3: 8 x 16 blocks
+  const long long t3 = (long long)B * ((H + DC3_T - 1) / DC3_T) * ((W + DC3_T - 1) / DC3_T);                    // 3x3: 16 x 16 blocks
   const long long tiles = t1 < t3 ? t1 : t3;  // both kernels get a workgroup per row of `stats`, none without a tile
   return (int)(tiles < DT_CONV_GRID ? tiles : DT_CONV_GRID);
 }
@@ -512,8 +589,8 @@ extern "C" int v3d_dense_train_conv(const void* x, const void* image, int B, int
   hipStream_t st = (hipStream_t)stream;
   if (ksize == 3) {
     static bool attr3 = false;
-    if (!attr3) { V3D_CHECK_HIP(hipFuncSetAttribute((const void*)dt_conv3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DT3_SMEM)); attr3 = true; }
-    hipLaunchKernelGGL(dt_conv3_kernel, dim3(grid), dim3(DT3_THREADS), DT3_SMEM, st, (const dt_bf16*)x, (const dt_bf16*)image, B, H, W,
+    if (!attr3) { V3D_CHECK_HIP(hipFuncSetAttribute((const void*)dt_conv3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DC3_SMEM)); attr3 = true; }
+    hipLaunchKernelGGL(dt_conv3_kernel, dim3(grid), dim3(DC3_THREADS), DC3_SMEM, st, (const dt_bf16*)x, (const dt_bf16*)image, B, H, W,
                        (dt_bf16*)y, stats);
   } else {
     static bool attr1 = false;
@@ -526,40 +603,42 @@ extern "C" int v3d_dense_train_conv(const void* x, const void* image, int B, int
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm (batch statistics)
-// Column sums of a (rows, cols) fp32 matrix of partials, in double, in a FIXED order: a workgroup of 256 threads owns 32 columns,
-// thread (column j = tid & 31, part = tid >> 5) adds rows part, part + 8, ...; the 8 parts are then added in part order.
-// Returns the sum of column `col0 + j` to the threads with part == 0 (others: 0); `red` = 8 x 32 doubles of LDS.
+// Column sums of a (rows, cols) fp32 matrix of partials, in double, in a FIXED order: a workgroup of 1024 threads owns 32 columns,
+// thread (column j = tid & 31, part = tid >> 5) adds rows part, part + 32, ...; the 32 parts are then added in part order.
+// Returns the sum of column `col0 + j` to the threads with part == 0 (others: 0); `red` = 32 x 32 doubles of LDS.
+// (These kernels are latency chains, not streams: with 8 parts a thread walked 128 rows one dependent load after the other -- 38 us.)
+#define DT_COLSUM_THREADS 1024
 __device__ __forceinline__ double dt_colsum32(const float* __restrict__ partial, int rows, int cols, int col0, double (*red)[32]) {
   const int j = threadIdx.x & 31, part = threadIdx.x >> 5;
   double a = 0.0;
   if (col0 + j < cols)
-    for (int r = part; r < rows; r += 8) a += (double)partial[(size_t)r * cols + col0 + j];
+    for (int r = part; r < rows; r += 32) a += (double)partial[(size_t)r * cols + col0 + j];
   red[part][j] = a;
   __syncthreads();
   double t = 0.0;
   if (part == 0)
-    for (int q = 0; q < 8; q++) t += red[q][j];
+    for (int q = 0; q < 32; q++) t += red[q][j];
   return t;
 }
 
 // partial (tiles, 2, 128) -> mean, invstd (biased variance, as torch normalises), running statistics with the unbiased variance
 // (momentum update, num_batches_tracked += 1).  8 workgroups x 16 channels: columns {c, 128 + c} of the same channels share a block.
-__global__ __launch_bounds__(256) void dt_bn_finalize_kernel(const float* __restrict__ partial, int tiles, long long count, float eps,
+__global__ __launch_bounds__(DT_COLSUM_THREADS) void dt_bn_finalize_kernel(const float* __restrict__ partial, int tiles, long long count, float eps,
                                                              float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
                                                              long long* __restrict__ nbt) {
-  __shared__ double red[8][32];
+  __shared__ double red[32][32];
   __shared__ double tot[32];
   const int j = threadIdx.x & 31, part = threadIdx.x >> 5;
   const int which = j >> 4, c = blockIdx.x * 16 + (j & 15);
   // (a 32-column window of the (tiles, 256) matrix is not contiguous here: gather the two 16-column halves by hand)
   double a = 0.0;
-  for (int r = part; r < tiles; r += 8) a += (double)partial[((size_t)r * 2 + which) * DT_C + c];
+  for (int r = part; r < tiles; r += 32) a += (double)partial[((size_t)r * 2 + which) * DT_C + c];
   red[part][j] = a;
   __syncthreads();
   if (part == 0) {
     double t = 0.0;
-    for (int q = 0; q < 8; q++) t += red[q][j];
+    for (int q = 0; q < 32; q++) t += red[q][j];
     tot[j] = t;
   }
   __syncthreads();
@@ -583,7 +662,7 @@ extern "C" int v3d_dense_train_bn_finalize(const float* partial, int tiles, long
                                            float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                            v3d_stream_t stream) {
   if (!partial || tiles < 1 || count < 1 || !mean || !invstd || ((running_mean == nullptr) != (running_var == nullptr))) return V3D_EINVAL;
-  hipLaunchKernelGGL(dt_bn_finalize_kernel, dim3(DT_C / 16), dim3(256), 0, (hipStream_t)stream, partial, tiles, count, eps, momentum, mean,
+  hipLaunchKernelGGL(dt_bn_finalize_kernel, dim3(DT_C / 16), dim3(DT_COLSUM_THREADS), 0, (hipStream_t)stream, partial, tiles, count, eps, momentum, mean,
                      invstd, running_mean, running_var, (long long*)num_batches_tracked);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
@@ -627,7 +706,7 @@ extern "C" int v3d_dense_train_bn_relu_apply(const void* x, long long M, const f
 //   g = dy * [y > 0];  dbeta = sum g;  dgamma = sum g * x_hat;  dx = gamma * invstd * (g - dbeta / M - x_hat * dgamma / M).
 // Pass 1 (this kernel): per-block partial (sum g, sum g * x_hat) per channel, blocks in a fixed grid, thread = 8 channels of a pixel,
 // the 16 pixel rows of a block reduced through LDS in row order.
-#define DT_RED_BLOCKS 1024
+#define DT_RED_BLOCKS 512
 __global__ __launch_bounds__(256) void dt_bn_bwd_reduce_kernel(const dt_bf16* __restrict__ x, const dt_bf16* __restrict__ dy, long long M,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -666,9 +745,9 @@ __global__ __launch_bounds__(256) void dt_bn_bwd_reduce_kernel(const dt_bf16* __
 }
 
 // blocks partials (blocks, 2, 128) -> dbeta, dgamma: 8 workgroups x 32 columns of the (blocks, 256) matrix
-__global__ __launch_bounds__(256) void dt_bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ dbeta,
+__global__ __launch_bounds__(DT_COLSUM_THREADS) void dt_bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ dbeta,
                                                                  float* __restrict__ dgamma) {
-  __shared__ double red[8][32];
+  __shared__ double red[32][32];
   const double t = dt_colsum32(partial, blocks, 2 * DT_C, blockIdx.x * 32, red);
   if ((threadIdx.x >> 5) == 0) {
     const int col = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -720,7 +799,7 @@ extern "C" int v3d_dense_train_bn_relu_bwd(const void* x, const void* dy, long l
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(dt_bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const dt_bf16*)x, (const dt_bf16*)dy, M, mean, invstd, gamma,
                      beta, relu, partial);
-  hipLaunchKernelGGL(dt_bn_bwd_finalize_kernel, dim3(2 * DT_C / 32), dim3(256), 0, st, partial, blocks, dbeta, dgamma);
+  hipLaunchKernelGGL(dt_bn_bwd_finalize_kernel, dim3(2 * DT_C / 32), dim3(DT_COLSUM_THREADS), 0, st, partial, blocks, dbeta, dgamma);
   hipLaunchKernelGGL(dt_bn_bwd_apply_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, st, (const dt_bf16*)x, (const dt_bf16*)dy, M,
                      mean, invstd, gamma, beta, dbeta, dgamma, relu, (dt_bf16*)dx);
   V3D_CHECK_LAUNCH();
@@ -871,25 +950,25 @@ __global__ __launch_bounds__(768) void dt_wgrad_kernel(const dt_bf16* __restrict
       }
 }
 
-// partial (slabs, taps, ci, co) -> dW (co, ci, taps) fp32.  One workgroup per input channel: thread (co, g) sums slabs
-// 8 g .. 8 g + 7 in slab order for every tap (coalesced 512-byte rows), the eight group sums are combined in a fixed tree, and the
-// (co, tap) results leave as 9 consecutive floats per cout.  Bit-repeatable.
+// partial (slabs, taps, ci, co) -> dW (co, ci, taps) fp32.  One workgroup per (input channel, group of <= 3 taps): thread (co, g) sums
+// slabs 8 g .. 8 g + 7 in slab order (coalesced 512-byte rows), the eight group sums are combined in a fixed tree.  Bit-repeatable.
 __global__ __launch_bounds__(1024) void dt_wgrad_reduce_kernel(const float* __restrict__ partial, int slabs, int taps, float* __restrict__ dw) {
-  __shared__ float grp[8][9][DT_C];
-  const int ci = blockIdx.x, co = threadIdx.x & (DT_C - 1), g = threadIdx.x >> 7;
+  __shared__ float grp[8][3][DT_C];
+  const int ci = blockIdx.x, a0 = blockIdx.y * 3, na = taps - a0 < 3 ? taps - a0 : 3;
+  const int co = threadIdx.x & (DT_C - 1), g = threadIdx.x >> 7;
   const size_t total = (size_t)taps * DT_C * DT_C;
-  for (int a = 0; a < taps; a++) {
+  for (int a = 0; a < na; a++) {
     float v = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; s++)
-      if (8 * g + s < slabs) v += partial[(size_t)(8 * g + s) * total + ((size_t)a * DT_C + ci) * DT_C + co];
+      if (8 * g + s < slabs) v += partial[(size_t)(8 * g + s) * total + ((size_t)(a0 + a) * DT_C + ci) * DT_C + co];
     grp[g][a][co] = v;
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < DT_C * taps; idx += 1024) {
-    const int c = idx / taps, a = idx - c * taps;
+  for (int idx = threadIdx.x; idx < DT_C * na; idx += 1024) {
+    const int c = idx / na, a = idx - c * na;
     const float v = ((grp[0][a][c] + grp[1][a][c]) + (grp[2][a][c] + grp[3][a][c])) + ((grp[4][a][c] + grp[5][a][c]) + (grp[6][a][c] + grp[7][a][c]));
-    dw[((size_t)c * DT_C + ci) * taps + a] = v;
+    dw[((size_t)c * DT_C + ci) * taps + a0 + a] = v;
   }
 }
 
@@ -914,7 +993,7 @@ extern "C" int v3d_dense_train_wgrad(const void* x, const void* dy, int B, int H
     hipLaunchKernelGGL(dt_wgrad_kernel<9>, dim3(4 * slabs), dim3(768), DT_W2_SMEM, st, (const dt_bf16*)x, (const dt_bf16*)dy, B, H, W, slabs, partial);
   else
     hipLaunchKernelGGL(dt_wgrad_kernel<1>, dim3(4 * slabs), dim3(768), DT_W2_SMEM, st, (const dt_bf16*)x, (const dt_bf16*)dy, B, H, W, slabs, partial);
-  hipLaunchKernelGGL(dt_wgrad_reduce_kernel, dim3(DT_C), dim3(1024), 0, st, partial, slabs, ksize * ksize, dw);
+  hipLaunchKernelGGL(dt_wgrad_reduce_kernel, dim3(DT_C, (ksize * ksize + 2) / 3), dim3(1024), 0, st, partial, slabs, ksize * ksize, dw);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -1013,9 +1092,9 @@ __global__ __launch_bounds__(256) void dt_head_bwd_weight_kernel(const dt_bf16* 
   if (oh == 0) outp[O * DT_C + c] = c < O ? db : 0.f;
 }
 
-__global__ __launch_bounds__(256) void dt_head_bwd_reduce_kernel(const float* __restrict__ partial, int blocks, int O, float* __restrict__ dw,
-                                                                 float* __restrict__ db) {
-  __shared__ double red[8][32];
+__global__ __launch_bounds__(DT_COLSUM_THREADS) void dt_head_bwd_reduce_kernel(const float* __restrict__ partial, int blocks, int O,
+                                                                               float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ double red[32][32];
   const int total = (O + 1) * DT_C;
   const double t = dt_colsum32(partial, blocks, total, blockIdx.x * 32, red);
   if ((threadIdx.x >> 5) == 0) {
@@ -1062,7 +1141,7 @@ extern "C" int v3d_dense_train_head_bwd(const void* feat, const float* dmaps, in
   } else
   DT_HEAD_CASE(8) DT_HEAD_CASE(16) DT_HEAD_CASE(24) DT_HEAD_CASE(32) DT_HEAD_CASE(48) DT_HEAD_CASE(64) return V3D_EUNSUPPORTED;
 #undef DT_HEAD_CASE
-  hipLaunchKernelGGL(dt_head_bwd_reduce_kernel, dim3(((O + 1) * DT_C + 31) / 32), dim3(256), 0, st, (const float*)workspace, wb, O, dweight, dbias);
+  hipLaunchKernelGGL(dt_head_bwd_reduce_kernel, dim3(((O + 1) * DT_C + 31) / 32), dim3(DT_COLSUM_THREADS), 0, st, (const float*)workspace, wb, O, dweight, dbias);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }

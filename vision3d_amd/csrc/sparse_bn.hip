@@ -95,19 +95,21 @@ __global__ __launch_bounds__(V3D_BLOCK) void sbn_stats_kernel(const float* __res
   }
 }
 
-// merge of the chunk triples by ONE 256-thread workgroup, thread = (group q, channel c), in double precision:
+// merge of the chunk triples by ONE 1024-thread workgroup, thread = (group q, channel c), in double precision:
 //   mean = sum_b n_b * mean_b / n ;  M2 = sum_b [ M2_b + n_b * (mean_b - mean)^2 ]        (exact regrouping of the
 // deviations about the global mean).  Two sweeps over the partials with independent loads and no division inside the
-// loops (a serial Chan update over 512 chunks took 166 us, a grouped one 34 us: dependent loads + fp64 divisions).
-__global__ __launch_bounds__(V3D_BLOCK) void sbn_merge_kernel(const float* __restrict__ part, SbnRows rows, int C, float eps,
+// loops (a serial Chan update over 512 chunks took 166 us, a grouped one 34 us: dependent loads + fp64 divisions; 256 threads
+// 12 us -- a latency chain of 2 x 128 loads per thread -- 1024 threads a quarter of that).
+#define SBN_MERGE_THREADS 1024
+__global__ __launch_bounds__(SBN_MERGE_THREADS) void sbn_merge_kernel(const float* __restrict__ part, SbnRows rows, int C, float eps,
                                                               float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                               float* __restrict__ var_unbiased, float* __restrict__ running_mean,
                                                               float* __restrict__ running_var, float momentum,
                                                               long long* __restrict__ num_batches_tracked) {
-  __shared__ double s_a[V3D_BLOCK];
-  __shared__ double s_mean[V3D_BLOCK];
+  __shared__ double s_a[SBN_MERGE_THREADS];
+  __shared__ double s_mean[SBN_MERGE_THREADS];
   const int n = rows.n(), G = sbn_chunks(n);
-  const int tid = threadIdx.x, c = tid % C, q = tid / C, Q = V3D_BLOCK / C;
+  const int tid = threadIdx.x, c = tid % C, q = tid / C, Q = SBN_MERGE_THREADS / C;
   double a = 0.0;
 #pragma unroll 8
   for (int g = q; g < G; g += Q) {  // independent loads: keep 8 in flight
@@ -224,11 +226,11 @@ __global__ __launch_bounds__(V3D_BLOCK) void sbn_bwd_sums_kernel(const float* __
   }
 }
 
-__global__ __launch_bounds__(V3D_BLOCK) void sbn_bwd_merge_kernel(const float* __restrict__ part, SbnRows rows, int C,
+__global__ __launch_bounds__(SBN_MERGE_THREADS) void sbn_bwd_merge_kernel(const float* __restrict__ part, SbnRows rows, int C,
                                                                   float* __restrict__ dbeta, float* __restrict__ dgamma) {
-  __shared__ double s_a[V3D_BLOCK], s_b[V3D_BLOCK];
+  __shared__ double s_a[SBN_MERGE_THREADS], s_b[SBN_MERGE_THREADS];
   const int G = sbn_chunks(rows.n());
-  const int tid = threadIdx.x, c = tid % C, q = tid / C, Q = V3D_BLOCK / C;
+  const int tid = threadIdx.x, c = tid % C, q = tid / C, Q = SBN_MERGE_THREADS / C;
   double a = 0.0, b = 0.0;
 #pragma unroll 8
   for (int g = q; g < G; g += Q) {
@@ -296,7 +298,7 @@ int v3d_i_sparse_bn_relu_fwd(const float* x, int n, const int32_t* n_dev, int C,
   const SbnRows rows{n_dev, n};
   float* part = (float*)workspace;
   hipLaunchKernelGGL(sbn_stats_kernel, dim3(sbn_chunks(n)), dim3(V3D_BLOCK), 0, st, x, rows, C, part);
-  hipLaunchKernelGGL(sbn_merge_kernel, dim3(1), dim3(V3D_BLOCK), 0, st, part, rows, C, eps, save_mean, save_invstd,
+  hipLaunchKernelGGL(sbn_merge_kernel, dim3(1), dim3(SBN_MERGE_THREADS), 0, st, part, rows, C, eps, save_mean, save_invstd,
                      var_unbiased, running_mean, running_var, momentum, (long long*)num_batches_tracked);
   const long long total = (long long)n * C / 4;
   const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
@@ -316,7 +318,7 @@ int v3d_i_sparse_bn_relu_bwd(const float* x, const float* dy, int n, const int32
   float* part = (float*)workspace;
   hipLaunchKernelGGL(sbn_bwd_sums_kernel, dim3(sbn_chunks(n)), dim3(V3D_BLOCK), 0, st, x, dy, rows, C, save_mean, save_invstd,
                      gamma, beta, relu, part);
-  hipLaunchKernelGGL(sbn_bwd_merge_kernel, dim3(1), dim3(V3D_BLOCK), 0, st, part, rows, C, dbeta, dgamma);
+  hipLaunchKernelGGL(sbn_bwd_merge_kernel, dim3(1), dim3(SBN_MERGE_THREADS), 0, st, part, rows, C, dbeta, dgamma);
   const long long total = (long long)n * C / 4;
   const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
   hipLaunchKernelGGL(sbn_bwd_apply_kernel, dim3(blocks > 8192 ? 8192 : blocks), dim3(V3D_BLOCK), 0, st, x, dy, rows, C,
