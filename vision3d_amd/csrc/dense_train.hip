@@ -73,6 +73,30 @@ __global__ void dt_pack_weights_kernel(const float* __restrict__ w, int taps, in
 
 extern "C" size_t v3d_dense_train_weight_image_bytes(int ksize) { return (size_t)ksize * ksize * DT_B_BYTES; }
 
+// every layer's two images (forward, data gradient) in ONE launch: blockIdx.y = 2 layer + transpose (a pack is ~5 us of launch
+// and ~1 us of work; 14 of them per step were 1 % of it)
+struct DtPackJobs {
+  const float* w[16];
+  int taps[16];
+};
+__global__ void dt_pack_all_kernel(DtPackJobs jobs, unsigned char* __restrict__ images, size_t stride) {
+  const int l = blockIdx.y >> 1, transpose = blockIdx.y & 1, taps = jobs.taps[l];
+  const float* __restrict__ w = jobs.w[l];
+  dt_bf16* __restrict__ img = reinterpret_cast<dt_bf16*>(images + (size_t)blockIdx.y * stride);
+  const int total = taps * 4 * 8 * 64 * 8;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    int r = t;
+    const int e = r % 8; r /= 8;
+    const int lane = r % 64; r /= 64;
+    const int nt = r % 8; r /= 8;
+    const int ss = r % 4; r /= 4;
+    const int tap = r;
+    const int k = ss * 32 + (lane >> 4) * 8 + e, n = nt * 16 + (lane & 15);
+    const float v = transpose ? w[((size_t)k * DT_C + n) * taps + (taps - 1 - tap)] : w[((size_t)n * DT_C + k) * taps + tap];
+    img[t] = dt_from_f32(v);
+  }
+}
+
 extern "C" int v3d_dense_train_pack_weights(const float* weight, int ksize, int transpose, void* image, v3d_stream_t stream) {
   if (!weight || !image || (ksize != 1 && ksize != 3)) return V3D_EINVAL;
   hipLaunchKernelGGL(dt_pack_weights_kernel, dim3(128), dim3(256), 0, (hipStream_t)stream, weight, ksize * ksize, transpose ? 1 : 0,
@@ -1201,15 +1225,23 @@ extern "C" int v3d_dense_train_forward(const void* bev, int B, int H, int W, con
   const long long M = (long long)B * H * W;
   const void* x = bev;
   const size_t img_stride = (((size_t)9 * DT_B_BYTES) + 255) & ~(size_t)255;
+  DtPackJobs jobs;
   for (int l = 0; l < n_layers; l++) {
     const v3d_dense_train_layer& L = layers[l];
     if (!L.weight || !L.gamma || !L.beta || (L.ksize != 1 && L.ksize != 3)) return V3D_EINVAL;
+    jobs.w[l] = L.weight;
+    jobs.taps[l] = L.ksize * L.ksize;
+  }
+  // image 2 l: forward, 2 l + 1: transposed / tap-flipped for the data gradient (read by v3d_dense_train_backward: the weights
+  // do not change between the two calls of a step)
+  hipLaunchKernelGGL(dt_pack_all_kernel, dim3(32, 2 * n_layers), dim3(256), 0, (hipStream_t)stream, jobs, base + a.off_img, img_stride);
+  for (int l = 0; l < n_layers; l++) {
+    const v3d_dense_train_layer& L = layers[l];
     void* img = base + a.off_img + (size_t)(2 * l) * img_stride;
     void* raw = base + a.off_raw + (size_t)l * a.act_bytes;
     void* act = base + a.off_act + (size_t)l * a.act_bytes;
     float* mean = (float*)(base + a.off_stat) + (size_t)l * 2 * DT_C;
     float* partial = (float*)(base + a.off_partial);
-    DT_TRY(v3d_dense_train_pack_weights(L.weight, L.ksize, 0, img, stream));
     DT_TRY(v3d_dense_train_conv(x, img, B, H, W, L.ksize, raw, partial, stream));
     DT_TRY(v3d_dense_train_bn_finalize(partial, a.tiles, M, L.eps, L.momentum, mean, mean + DT_C, L.running_mean, L.running_var,
                                        L.num_batches_tracked, stream));
@@ -1245,8 +1277,7 @@ extern "C" int v3d_dense_train_backward(const void* bev, const float* dmaps, int
     DT_TRY(v3d_dense_train_bn_relu_bwd(raw, g[cur], M, mean, mean + DT_C, L.gamma, L.beta, 1, g[cur], L.grad_gamma, L.grad_beta, ws,
                                        ws_bytes, stream));
     DT_TRY(v3d_dense_train_wgrad(xin, g[cur], B, H, W, L.ksize, L.grad_weight, ws, ws_bytes, stream));
-    void* img = base + a.off_img + (size_t)(2 * l + 1) * img_stride;
-    DT_TRY(v3d_dense_train_pack_weights(L.weight, L.ksize, 1, img, stream));
+    void* img = base + a.off_img + (size_t)(2 * l + 1) * img_stride;  // packed by the forward call
     void* out = l == 0 ? dbev : g[cur ^ 1];
     DT_TRY(v3d_dense_train_conv(g[cur], img, B, H, W, L.ksize, out, nullptr, stream));
     cur ^= 1;

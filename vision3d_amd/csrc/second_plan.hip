@@ -444,6 +444,7 @@ struct PlanTrainLayer {
   float* conv_out = nullptr;  // (cap_out, cout) pre-BatchNorm rows
   float* stats = nullptr;     // save_mean | save_invstd | unbiased variance, 3 x cout
   void* wimg_t = nullptr;     // packed image of the transposed weights (Cin >= 16 layers)
+  bool wimg_t_ready = false;  // packed by this step's forward call
   int32_t* nbr_t = nullptr;   // strided layers: (K, cap_in) transposed rulebook
 };
 
@@ -594,16 +595,37 @@ extern "C" int v3d_backbone_train_forward(v3d_backbone* p, const float* voxel_me
   std::vector<char> rb_done(p->layers.size(), 0);
   bool hash0_done = false;
   const float* feat = p->mean;
+  {
+    // every packed weight image of the step in one launch: the forward image of each layer and the image of its transposed
+    // weights (the data gradient of v3d_backbone_train_backward; the weights do not change between the two calls of a step)
+    V3dPackJobs jobs;
+    int nj = 0;
+    for (size_t l = 0; l < p->layers.size(); l++) {
+      PlanLayer& L = p->layers[l];
+      PlanTrainLayer& T = t->tl[l];
+      if (L.d.cin >= 16 && L.d.cout % 16 == 0 && nj < V3D_PACK_JOBS_MAX) {
+        jobs.w[nj] = io[l].weight; jobs.img[nj] = L.wimg; jobs.K[nj] = L.K; jobs.cin[nj] = L.d.cin; jobs.cout[nj] = L.d.cout; jobs.mode[nj] = 0;
+        nj++;
+      }
+      T.wimg_t_ready = false;
+      if (l > 0 && T.wimg_t && L.d.cout >= 16 && nj < V3D_PACK_JOBS_MAX) {  // transposed layer: Cin' = cout, Cout' = cin
+        jobs.w[nj] = io[l].weight; jobs.img[nj] = T.wimg_t; jobs.K[nj] = L.K; jobs.cin[nj] = L.d.cout; jobs.cout[nj] = L.d.cin;
+        jobs.mode[nj] = L.d.subm ? 2 : 1;
+        nj++;
+        T.wimg_t_ready = true;
+      }
+    }
+    if (nj) {
+      rc = v3d_i_sparse_conv_pack_batch(jobs, nj, st);
+      if (rc) return rc;
+    }
+  }
   for (size_t l = 0; l < p->layers.size(); l++) {
     PlanLayer& L = p->layers[l];
     PlanTrainLayer& T = t->tl[l];
     PlanStage& so = p->stages[L.stage_out];
     rc = plan_layer_rulebook(p, l, rb_done, hash0_done, st);
     if (rc) return rc;
-    if (L.d.cin >= 16 && L.d.cout % 16 == 0) {
-      rc = v3d_sparse_conv_pack_weights(io[l].weight, L.K, L.d.cin, L.d.cout, L.wimg, stream);
-      if (rc) return rc;
-    }
     rc = plan_layer_conv(p, L, feat, L.wimg, io[l].weight, nullptr, nullptr, 0, T.conv_out, st);
     if (rc) return rc;
     rc = v3d_i_sparse_bn_relu_fwd(T.conv_out, so.cap, so.n_dev, L.d.cout, io[l].gamma, io[l].beta, io[l].eps, L.d.relu, L.out,
@@ -665,9 +687,12 @@ extern "C" int v3d_backbone_train_backward(v3d_backbone* p, const float* grad_de
                                     io[l].grad_weight, t->dw_ws, t->dw_ws_bytes, stream);
     if (rc) return rc;
     if (l == 0) break;  // the voxel features need no gradient
-    const int total = L.K * L.d.cin * L.d.cout;
-    hipLaunchKernelGGL(plan_transpose_weights_kernel, dim3(std::min(v3d_ceil_div(total, V3D_BLOCK), 1024)), dim3(V3D_BLOCK), 0,
-                       st, io[l].weight, L.K, L.d.cin, L.d.cout, L.d.subm ? 1 : 0, t->w_t);
+    const bool packed_t = T.wimg_t && T.wimg_t_ready && L.d.cout >= 16;
+    if (!packed_t) {  // fp32 transposed weights for the wave kernel below
+      const int total = L.K * L.d.cin * L.d.cout;
+      hipLaunchKernelGGL(plan_transpose_weights_kernel, dim3(std::min(v3d_ceil_div(total, V3D_BLOCK), 1024)), dim3(V3D_BLOCK), 0,
+                         st, io[l].weight, L.K, L.d.cin, L.d.cout, L.d.subm ? 1 : 0, t->w_t);
+    }
     const int32_t* nbr_t = p->nbr[L.rulebook];
     if (!L.d.subm) {
       rc = v3d_rulebook_transpose(p->nbr[L.rulebook], so.n_dev, so.cap, L.K, si.cap, T.nbr_t, stream);
@@ -675,15 +700,19 @@ extern "C" int v3d_backbone_train_backward(v3d_backbone* p, const float* grad_de
       nbr_t = T.nbr_t;
     }
     rc = V3D_EUNSUPPORTED;
-    if (T.wimg_t && L.d.cout >= 16) {  // transposed layer: Cin' = cout, Cout' = cin
-      rc = v3d_sparse_conv_pack_weights(t->w_t, L.K, L.d.cout, L.d.cin, T.wimg_t, stream);
-      if (rc) return rc;
+    if (packed_t) {  // transposed layer: Cin' = cout, Cout' = cin
       rc = v3d_i_sparse_conv_fwd_packed(t->g_conv, T.wimg_t, nbr_t, si.n_dev, si.cap, L.K, L.d.cout, L.d.cin, nullptr, nullptr,
                                         0, t->g[cur ^ 1], L.rows_hint_in, st);
     }
-    if (rc == V3D_EUNSUPPORTED)
+    if (rc == V3D_EUNSUPPORTED) {
+      if (packed_t) {  // (the packed kernel declined the shape: the fp32 transposed weights were skipped above)
+        const int total = L.K * L.d.cin * L.d.cout;
+        hipLaunchKernelGGL(plan_transpose_weights_kernel, dim3(std::min(v3d_ceil_div(total, V3D_BLOCK), 1024)), dim3(V3D_BLOCK), 0,
+                           st, io[l].weight, L.K, L.d.cin, L.d.cout, L.d.subm ? 1 : 0, t->w_t);
+      }
       rc = v3d_sparse_conv_fwd(t->g_conv, t->w_t, nbr_t, si.n_dev, si.cap, L.K, L.d.cout, L.d.cin, nullptr, nullptr, 0,
                                t->g[cur ^ 1], 0, stream);
+    }
     if (rc) return rc;
     cur ^= 1;
   }

@@ -37,6 +37,16 @@ int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, cons
                                  int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
                                  float* out, int rows_hint, hipStream_t st);
 
+// spconv.hip: several packed weight images in one launch (mode 0: W (K, Cin, Cout); 1 / 2: the transposed layer of a source
+// (K, Cout, Cin), 2 with the offsets reversed)
+#define V3D_PACK_JOBS_MAX 32
+struct V3dPackJobs {
+  const float* w[V3D_PACK_JOBS_MAX];
+  void* img[V3D_PACK_JOBS_MAX];
+  int K[V3D_PACK_JOBS_MAX], cin[V3D_PACK_JOBS_MAX], cout[V3D_PACK_JOBS_MAX], mode[V3D_PACK_JOBS_MAX];
+};
+int v3d_i_sparse_conv_pack_batch(const V3dPackJobs& jobs, int n, hipStream_t stream);
+
 // sparse_bn.hip: the C-ABI BatchNorm entry points with the row count optionally in device memory (n_dev != nullptr:
 // min(*n_dev, n) rows, n = the buffers' capacity).  Same chunking, bit-identical results either way.
 int v3d_i_sparse_bn_relu_fwd(const float* x, int n, const int32_t* n_dev, int C, const float* gamma, const float* beta, float eps,

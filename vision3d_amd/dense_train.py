@@ -76,11 +76,18 @@ class DenseTrainPlan(object):
 
     def _io(self, grads=None):
         io = (L.DenseTrainLayer * len(self.convs))()
+        self._keep = []  # contiguous copies of parameters stored in another memory format (e.g. a channels_last module)
         for i, (d, c, b) in enumerate(zip(io, self.convs, self.bns)):
+            ptrs = []
             for t in (c.weight, b.weight, b.bias):
-                if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
-                    raise RuntimeError("dense train plan: parameters must be contiguous float32 tensors on the plan's device")
-            d.weight, d.gamma, d.beta = c.weight.data_ptr(), b.weight.data_ptr(), b.bias.data_ptr()
+                if t.dtype != torch.float32 or t.device != self.device:
+                    raise RuntimeError("dense train plan: parameters must be float32 tensors on the plan's device")
+                t = t.detach()
+                if not t.is_contiguous():
+                    t = t.contiguous()
+                    self._keep.append(t)
+                ptrs.append(t.data_ptr())
+            d.weight, d.gamma, d.beta = ptrs
             if b.track_running_stats and b.running_mean is not None:
                 d.running_mean, d.running_var = b.running_mean.data_ptr(), b.running_var.data_ptr()
                 d.num_batches_tracked = b.num_batches_tracked.data_ptr()
