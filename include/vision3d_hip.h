@@ -307,7 +307,13 @@ int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, const void* we
                               uint32_t* work /*nullable: two zeroed words owned by the caller for THIS call site (one pair per
                               layer and stream in flight).  With it the skipping kernel runs as a persistent grid that draws
                               80-pixel tiles from work[0]; the pair resets itself to zero when the kernel ends*/,
+                              uint32_t* tile_state /*nullable; with `work`, when y_hi / y_lo are PERSISTENT buffers of this call
+                              site (the same pair every frame): v3d_conv2d_bg_tiles words, nonzero = the tile holds computed
+                              values (initialise to nonzero).  A layer's empty-map response does not depend on the frame, so a
+                              background tile whose word is 0 already holds it and is not written at all; the kernel keeps the
+                              words up to date.  Reset them to nonzero when the weights (hence bg_hi / bg_lo) change*/,
                               v3d_stream_t stream);
+int v3d_conv2d_bg_tiles(int B, int H, int W);
 /* .dense() of the last sparse stage straight into that input format: planes (B,H,W,C*D), channel = c*D + z. */
 int v3d_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
                            const int32_t* spatial_shape_host, void* out_hi, void* out_lo, v3d_stream_t stream);

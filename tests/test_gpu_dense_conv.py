@@ -145,6 +145,41 @@ def test_bev_occupancy_bitmap_matches_numpy():
         np.testing.assert_array_equal(_occupancy_numpy(plan.bev_occupancy(2), 2, shape[1], shape[2]), ref)
 
 
+def test_background_left_in_place_across_frames_is_bit_identical():
+    """DenseHeadState: persistent RPN planes + tile states.  A sequence of different frames (and a repeated one) through the same
+    state gives, frame by frame, exactly the maps of the all-tiles forward; tiles that were background in the frame before are
+    not written (their state word stays 0), tiles that turn live / background flip their word."""
+    model = build_model(3)
+    dense = model.dense_plan()
+    state = dense.new_state(torch.device("cuda"))
+    seeds = [0, 1, 1, 5, 0]
+    with torch.no_grad():
+        prev_live = None
+        for j, seed in enumerate(seeds):
+            clouds = [torch.from_numpy(synth.make_cloud(seed)).cuda()]
+            plan, flat, offsets = model._plan_for(clouds)
+            hi, lo = plan.forward_split(flat, offsets)
+            occ = plan.bev_occupancy(1).clone()
+            full = dense.forward(hi, lo)
+            got = dense.forward(hi, lo, occ=occ, work=state)
+            assert torch.equal(full, got), f"frame {j} (seed {seed})"
+            assert int(state.counters.abs().sum()) == 0
+            live = [t.clone() for t in state.tiles]
+            for t in live:
+                assert set(t.unique().tolist()) <= {0, 1}
+                assert 0 < int(t.sum()) < t.numel()  # a sparse map: some tiles convolve, some hold the response
+            if j > 0 and seeds[j] == seeds[j - 1]:
+                assert all(torch.equal(a, b) for a, b in zip(live, prev_live))  # same frame again: same set of live tiles
+            prev_live = live
+        # the state follows the weights: a changed parameter re-creates the planes with every tile marked "not in place"
+        next(m for m in model.rpn.down_block if isinstance(m, torch.nn.Conv2d)).weight.mul_(1.01)  # (under no_grad: bumps the version)
+        clouds = [torch.from_numpy(synth.make_cloud(2)).cuda()]
+        plan, flat, offsets = model._plan_for(clouds)
+        hi, lo = plan.forward_split(flat, offsets)
+        occ = plan.bev_occupancy(1).clone()
+        assert torch.equal(dense.forward(hi, lo), dense.forward(hi, lo, occ=occ, work=state))
+
+
 @pytest.mark.parametrize("frames", [(0,), (3, 4)])
 def test_background_skipping_is_bit_identical_and_skips(frames):
     """RPN with tiles far from every occupied pixel copied from the empty-map response == RPN with every tile convolved."""

@@ -185,6 +185,9 @@ struct DcParams {
   const bf16_t* bg_hi;   // that response for ONE image, (H, W, Cout) split planes
   const bf16_t* bg_lo;
   unsigned* work;        // [2] tile counter + workgroups-done counter of the persistent grid (zero between launches)
+  unsigned* tile_state;  // nullable, one word per tile of a PERSISTENT output buffer: nonzero = the tile holds computed values.
+                         // The empty-map response of a layer does not depend on the frame, so a background tile whose state
+                         // is 0 already holds it from an earlier frame and is not written at all.
 };
 
 template <int KS>
@@ -484,6 +487,11 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
       near_any |= (~p.occ[(size_t)rr * wpr + wd] & mask) != 0u;
     }
     if (!__builtin_amdgcn_readfirstlane(__ballot(near_any) != 0ull)) {
+      if (p.tile_state) {
+        if (p.tile_state[mtile] == 0u) return;  // the response is already in place (workgroup-uniform: one word)
+        __syncthreads();                        // every thread has read the word before it is cleared
+        if (tid == 0) p.tile_state[mtile] = 0u;
+      }
       const int HW = p.H * p.W, parts = (min(p.cout_store, n0 + DC_BN) - n0) >> 3;  // 16-byte parts of this cout block
       for (int q = tid; q < BM * parts; q += DL_THREADS) {
         const int row = q / parts, part = q - row * parts;
@@ -496,6 +504,7 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
       return;
     }
   }
+  if (p.tile_state && tid == 0) p.tile_state[mtile] = 1u;
   const int chunks = (p.Cin + DL_KC - 1) / DL_KC;  // 128-channel stages per tap (the last one may be partial: zero-filled)
   const int stages = KS * KS * chunks;
   // LDS image of one plane: pixel rows of 256 B (16 parts of 16 B), the part slot XOR-ed with px & 15.  Every row
@@ -840,11 +849,12 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_small_cout_kernel(const bf
   }
 }
 
+extern "C" int v3d_conv2d_bg_tiles(int B, int H, int W);
 extern "C" int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
                                       int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
                                       float* y_nchw, v3d_stream_t stream) {
   return v3d_conv2d_nhwc_bf16x3_bg(x_hi, x_lo, weight_image, bias, relu, B, H, W, Cin, Cout, ksize, y_hi, y_lo, y_nchw, nullptr, 0,
-                                   nullptr, nullptr, nullptr, stream);
+                                   nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 // BEV occupancy bitmap, INVERTED (bit cleared = occupied) so that the 0xFF fill that resets the rest of a plan's per-frame
@@ -872,10 +882,13 @@ extern "C" int v3d_bev_occupancy_bits(const int32_t* coords, const int32_t* n, i
   return V3D_OK;
 }
 
+// tiles of the persistent background-skipping grid over a (B, H, W) map = words of a `tile_state` array
+extern "C" int v3d_conv2d_bg_tiles(int B, int H, int W) { return (int)(((long long)B * H * W + 5 * 16 - 1) / (5 * 16)); }
+
 extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
                                          int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
                                          float* y_nchw, const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo,
-                                         uint32_t* work, v3d_stream_t stream) {
+                                         uint32_t* work, uint32_t* tile_state, v3d_stream_t stream) {
   if (!x_hi || !x_lo || !weight_image || B < 1 || H < 1 || W < 1 || Cout < 1) return V3D_EINVAL;
   if (occ && (!bg_hi || !bg_lo || reach < 0 || reach > 64)) return V3D_EINVAL;
   if (Cin < DC_KC || Cin % DC_KC || (ksize != 1 && ksize != 3)) return V3D_EUNSUPPORTED;
@@ -894,6 +907,7 @@ extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, con
   p.bg_hi = (const bf16_t*)bg_hi;
   p.bg_lo = (const bf16_t*)bg_lo;
   p.work = nullptr;
+  p.tile_state = nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (ksize == 1 && !y_hi && Cout <= 16 && (Cin == 128 || Cin == 256)) {  // the head: stream kernel
     const dim3 sgrid(v3d_ceil_div(v3d_ceil_div(p.M, 16), 4));
@@ -921,6 +935,9 @@ extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, con
     const int mt = persistent ? 5 : 9;  // (in launch order the small tiles only add rounds: 33 vs 27 us on a full map)
     const int tiles = v3d_ceil_div(p.M, mt * 16);
     p.work = persistent ? work : nullptr;
+    p.tile_state = persistent ? tile_state : nullptr;
+    if (tile_state && y_hi && !persistent)  // every pixel of the persistent buffer is about to be computed
+      V3D_CHECK_HIP(v3d_fill_async(tile_state, 0x01, (size_t)v3d_conv2d_bg_tiles(B, H, W) * sizeof(uint32_t), st));
     dim3 lgrid(persistent ? std::min(tiles, n_cu) : tiles, p.CoutPad / DC_BN);
     auto kern = mt == 9 ? (ksize == 3 ? conv2d_bf16x3_large_kernel<3, 9> : conv2d_bf16x3_large_kernel<1, 9>)
                         : (ksize == 3 ? conv2d_bf16x3_large_kernel<3, 5> : conv2d_bf16x3_large_kernel<1, 5>);
@@ -931,6 +948,7 @@ extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, con
     V3D_CHECK_LAUNCH();
     return V3D_OK;
   }
+  if (tile_state && y_hi) V3D_CHECK_HIP(v3d_fill_async(tile_state, 0x01, (size_t)v3d_conv2d_bg_tiles(B, H, W) * sizeof(uint32_t), st));
   dim3 grid(v3d_ceil_div(p.M, DC_BM), p.CoutPad / DC_BN);
   if (ksize == 3)
     hipLaunchKernelGGL(conv2d_bf16x3_kernel<3>, grid, dim3(DC_THREADS), 0, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,

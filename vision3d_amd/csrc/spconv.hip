@@ -1256,6 +1256,8 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
     // two slots, 2 movers (8.4 -> 7.4 us at 13 731 rows); 32->64 / 64->32 register gathers, 3 weight buffers (7.2 us; staged 7.6-8.3).
     // 16 = the register-gather form for every shape (cross-check).
     if (K == 27 && (force == 10 || force == 16 || (force == 0 && rows_hint <= V3D_RING_ROWS))) {
+      static const bool regs_only = [] { const char* e = getenv("V3D_RING_REGS"); return e && e[0] == '1'; }();  // A/B in whole-frame runs
+      if (regs_only && force == 0) return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
       if (force != 16 && CIN == 64 && COUT == 64) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
       if (force != 16 && CIN == 32 && COUT == 32) return launch_rows_ring<CIN, COUT, 3, 2, 2, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
       return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);

@@ -29,7 +29,8 @@ class GraphedSecond(object):
         cap_pts = 1 << max(14, (self.offsets[-1] - 1).bit_length())
         self.plan = model.backbone_plan(len(self.frame_sizes), cap_pts, slot)
         self.dense = model.dense_plan()
-        self.work = self.dense.new_work(dev) if model.skip_background else None  # this slot's tile counters (self-resetting)
+        # this slot's tile counters (self-resetting), persistent RPN planes and tile states
+        self.work = self.dense.new_state(dev) if model.skip_background else None
         self.graph = None  # captured on the first call, after a warm-up on THAT frame (see _capture)
 
     def _capture(self):

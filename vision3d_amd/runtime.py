@@ -407,23 +407,29 @@ def split_planes_like(b, h, w, c, device):
     return both[0], both[1]
 
 
-def conv2d_split(x_hi, x_lo, image, bias, relu, cin, cout, ksize, out_split=True, out_nchw=False, occ=None, reach=0, bg=None, work=None):
+def conv2d_split(x_hi, x_lo, image, bias, relu, cin, cout, ksize, out_split=True, out_nchw=False, occ=None, reach=0, bg=None, work=None,
+                 out=None, tile_state=None):
     """One bf16x3 convolution on split NHWC planes; returns (y_hi, y_lo) and/or fp32 (B,cout,H,W).
     occ / reach / bg = (bg_hi, bg_lo) [/ work: 2 zeroed int32 of the caller's, see the header]: background skipping
-    (v3d_conv2d_nhwc_bf16x3_bg), same values."""
+    (v3d_conv2d_nhwc_bf16x3_bg), same values.  out = (y_hi, y_lo): write into these planes; with tile_state (one int32 per
+    tile of a PERSISTENT `out`, see the header) background tiles that already hold the empty-map response are not written."""
     b, h, w, c = x_hi.shape
     assert c == cin
     dev = x_hi.device
     y_hi = y_lo = y = None
     if out_split:
-        y_hi, y_lo = split_planes_like(b, h, w, cout, dev)
+        y_hi, y_lo = out if out is not None else split_planes_like(b, h, w, cout, dev)
+        if tuple(y_hi.shape) != (b, h, w, cout) or tuple(y_lo.shape) != (b, h, w, cout):
+            raise RuntimeError("conv2d_split: `out` planes do not match the output geometry")
     if out_nchw:
         y = torch.empty((b, cout, h, w), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         if occ is not None and bg is not None:
             L.check(L.lib().v3d_conv2d_nhwc_bf16x3_bg(L.ptr(x_hi), L.ptr(x_lo), L.ptr(image), L.ptr(bias), int(bool(relu)), b, h,
                                                       w, cin, cout, ksize, L.ptr(y_hi), L.ptr(y_lo), L.ptr(y), L.ptr(occ),
-                                                      int(reach), L.ptr(bg[0]), L.ptr(bg[1]), L.ptr(work), L.stream_ptr()),
+                                                      int(reach), L.ptr(bg[0]), L.ptr(bg[1]), L.ptr(work),
+                                                      L.ptr(tile_state) if (work is not None and out is not None) else None,
+                                                      L.stream_ptr()),
                     "conv2d_nhwc_bf16x3_bg")
         else:
             L.check(L.lib().v3d_conv2d_nhwc_bf16x3(L.ptr(x_hi), L.ptr(x_lo), L.ptr(image), L.ptr(bias), int(bool(relu)), b, h, w,
@@ -452,6 +458,27 @@ def to_split_nhwc(x):
     with torch.cuda.device(x.device):
         L.check(L.lib().v3d_nchw_to_split_nhwc(L.ptr(x), b, c, h, w, L.ptr(hi), L.ptr(lo), L.stream_ptr()), "nchw_to_split_nhwc")
     return hi, lo
+
+
+class DenseHeadState(object):
+    """Per stream / captured graph state of a DenseHeadPlan: the tile counters of the persistent skipping kernels, one pair of
+    output planes per RPN layer that stays put from frame to frame, and per layer one word per 80-pixel tile saying whether the
+    tile currently holds computed values (1) or the layer's empty-map response (0).  That response only depends on the weights:
+    a background tile that was background in the frame before needs no write (csrc/dense_conv.hip, DcParams::tile_state)."""
+
+    def __init__(self, plan, device):
+        self.device = device
+        self.counters = torch.zeros(2 * len(plan.layers), dtype=torch.int32, device=device)
+        self.key, self.out, self.tiles = None, None, None
+
+    def ensure(self, plan, b, h, w):
+        key = (int(b), int(h), int(w), plan._stamp)
+        if key == self.key:
+            return
+        self.out = [split_planes_like(b, h, w, ly["cout"], self.device) for ly in plan.layers[:-1]]
+        n = int(L.lib().v3d_conv2d_bg_tiles(int(b), int(h), int(w)))
+        self.tiles = [torch.ones(n, dtype=torch.int32, device=self.device) for _ in plan.layers[:-1]]  # nothing is in place yet
+        self.key = key
 
 
 class DenseHeadPlan(object):
@@ -505,6 +532,12 @@ class DenseHeadPlan(object):
         self.sync_weights()
         return torch.zeros(2 * len(self.layers), dtype=torch.int32, device=device)
 
+    def new_state(self, device):
+        """`new_work` plus PERSISTENT output planes for every RPN layer and their tile states (DenseHeadState): background tiles
+        that already hold the layer's empty-map response from an earlier frame are then not written at all."""
+        self.sync_weights()
+        return DenseHeadState(self, device)
+
     def background(self, h, w, device):
         """Per RPN layer: its output on an EMPTY (all-zero) BEV map of one image, as split planes -- what every pixel far
         enough from all occupied pixels evaluates to, borders included (`forward(..., occ=...)`).  Computed once per weight
@@ -531,6 +564,10 @@ class DenseHeadPlan(object):
         self.sync_weights()
         if occ is not None and work is None:
             work = self.new_work(x_hi.device)
+        state = work if isinstance(work, DenseHeadState) else None
+        if state is not None:
+            state.ensure(self, *x_hi.shape[:3])
+            work = state.counters
         feats = None
         bg = self.background(x_hi.shape[1], x_hi.shape[2], x_hi.device) if occ is not None else None
         reach = 0
@@ -539,7 +576,9 @@ class DenseHeadPlan(object):
             reach += ly["k"] // 2
             (x_hi, x_lo), f = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"],
                                            out_split=True, out_nchw=want_features and last, occ=occ, reach=reach,
-                                           bg=None if bg is None else bg[i], work=None if work is None else work[2 * i:2 * i + 2])
+                                           bg=None if bg is None else bg[i], work=None if work is None else work[2 * i:2 * i + 2],
+                                           out=None if state is None else state.out[i],
+                                           tile_state=None if state is None else state.tiles[i])
             feats = f if last else feats
         ly = self.layers[-1]
         if ly is None:
