@@ -16,7 +16,7 @@ Other lines of BASELINE.json: --workload waymo (configs[4]), --mode train (confi
 
 Extra objects on that line:
   roofline        the dominant sparse kernel (KITTI: spconv_fwd_rows_ring<64,64>, 7 launches/frame; Waymo:
-                  spconv_fwd_rows_big<64,64>): algorithmic bytes A_min = 4*(N_in*Cin + N_out*Cout + K*Cin*Cout) + 8*R per launch
+                  spconv_fwd_rows_kouter<64,64>): algorithmic bytes A_min = 4*(N_in*Cin + N_out*Cout + K*Cin*Cout) + 8*R per launch
                    divided by its average duration measured with HIP events over graph-captured repeats on the launch
                   stream, vs 8 TB/s; `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/).
   roofline_dense  the 3x3 RPN convolution against the bf16 MFMA peak (every tile convolved, random input).
@@ -649,7 +649,7 @@ def main():
         # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed summary of the
         # two rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_h_pmc_traffic.txt) is
         # attached when the workload is the one it was collected on, else null
-        DOM_KERNEL = "spconv_fwd_rows_big<64,64>" if (big and dom[0]["n_out"] >= 32768) else "spconv_fwd_rows_ring<64,64>"
+        DOM_KERNEL = "spconv_fwd_rows_kouter<64,64>" if (big and dom[0]["n_out"] >= 32768) else "spconv_fwd_rows_ring<64,64>"
         traffic, traffic_src = None, None
         pmc_path = os.path.join(REPO, "profiles", "pmc_traffic_waymo.json" if waymo else "pmc_traffic.json")
         if os.path.exists(pmc_path) and args.batch == 1 and args.points == (180000 if waymo else 16384):
@@ -657,9 +657,11 @@ def main():
             traffic, traffic_src = pmc[DOM_KERNEL]["traffic_bytes"] if DOM_KERNEL in pmc else None, pmc["source"]
         # the same kernel against the matrix pipe: MFMAs it ISSUES (16-row tiles incl. the padded one of the last workgroup x
         # 27 offsets x Cin/32 x Cout/16 x 3 split terms, 16 384 flop each) and the useful flops (2 Cin Cout per rulebook pair)
-        dom_tiles = float(np.mean([(l["n_out"] + 15) // 16 for l in dom])) if DOM_KERNEL.startswith("spconv_fwd_rows_big") else \
-            float(np.mean([2 * ((l["n_out"] + 31) // 32) for l in dom]))
-        mfma_issued = dom_tiles * 27 * 2 * 4 * 3 * 16384  # Cin/32 = 2, Cout/16 = 4, 3 split terms (csrc/spconv.hip SPC_TERMS)
+        # 16-row MFMA tiles: the offset-outer kernel walks 32-row tiles over 28 offset steps (27 padded to even), the ring kernel
+        # 32-row tiles over 27
+        kouter = DOM_KERNEL.startswith("spconv_fwd_rows_kouter")
+        dom_tiles = float(np.mean([2 * ((l["n_out"] + 31) // 32) for l in dom]))
+        mfma_issued = dom_tiles * (28 if kouter else 27) * 2 * 4 * 3 * 16384  # Cin/32 = 2, Cout/16 = 4, 3 split terms (csrc/spconv.hip SPC_TERMS)
         mfma_useful = float(np.mean([l["pairs"] for l in dom])) * 2 * 64 * 64
         mfma_view = dict(issued_tflops=mfma_issued / dom_t / 1e12, frac_issued=mfma_issued / dom_t / 1e12 / 2500.0,
                          useful_tflops=mfma_useful / dom_t / 1e12, peak_tflops=2500.0,

@@ -4,9 +4,9 @@ import collections, csv, glob, json, os, sys
 
 out_dir = sys.argv[1]
 workload = sys.argv[2] if len(sys.argv) > 2 else "kitti"
-tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
-KERNELS = {"spconv_fwd_rows_ring<64,64>": "spconv_fwd_rows_ring<64, 64, 3>", "conv2d_bf16x3_large_kernel<3>": "conv2d_bf16x3_large_kernel<3>",
-           "spconv_fwd_rows_big<64,64>": "spconv_fwd_rows_big<64, 64>"}
+tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
+KERNELS = {"spconv_fwd_rows_ring<64,64>": "spconv_fwd_rows_ring<64, 64, ", "conv2d_bf16x3_large_kernel<3>": "conv2d_bf16x3_large_kernel<3>",
+           "spconv_fwd_rows_kouter<64,64>": "spconv_fwd_rows_kouter<64, 64, ", "spconv_fwd_rows_big<64,64>": "spconv_fwd_rows_big<64, 64>"}
 mean = collections.defaultdict(dict)
 print("== rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, each with --kernel-trace only) -- "
       f"python bench.py --steps 3 --warmup 2 --no-cpu-baseline{' --workload waymo' if workload == 'waymo' else ''}")

@@ -5,7 +5,7 @@
 # usage: bash tools/pmc_traffic.sh [kitti|waymo] [tag]
 set -u
 WL=${1:-kitti}
-TAG=${2:-r02}
+TAG=${2:-r03}
 EXTRA=""
 [ "$WL" = "waymo" ] && EXTRA="--workload waymo"
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
