@@ -111,8 +111,9 @@ def train_main(args):
     """configs[2]: one optimiser step of SECOND per GPU batch; gradients all-reduced over RCCL in two buckets, the dense half's
     while the native sparse backward runs (dist_util.TwoPhaseGradReducer).
 
-    step = device voxelizer -> sparse backbone (autograd through the HIP kernels) -> dense RPN/head (torch, bf16
-    autocast) -> ProposalLoss -> backward -> all-reduce -> clip_grad_norm_(35) -> Adam   (reference train.py:58-70)."""
+    step = device voxelizer -> sparse backbone (training plan: HIP kernels forward and backward) -> dense RPN/head (hand-written bf16
+    MFMA kernels forward and backward, csrc/dense_train.hip; V3D_DENSE_TRAIN=torch: torch modules under bf16 autocast) ->
+    ProposalLoss -> backward -> all-reduce -> clip_grad_norm_(35) -> Adam   (reference train.py:58-70)."""
     from vision3d_amd import dist_util, synth
     from vision3d_amd.core import Preprocessor, ProposalTargetAssigner
     from vision3d_amd.core.config import second_car_cfg
@@ -121,8 +122,8 @@ def train_main(args):
     rank, local, world = dist_util.env_world()
     torch.cuda.set_device(local % torch.cuda.device_count())
     dist_util.init_from_env(BACKEND)
-    # the dense RPN / heads train through MIOpen: let it search its solvers during the warm-up (811 -> 868 frames/s on the same
-    # box against the default heuristic pick; V3D_TRAIN_BENCHMARK=0 switches the search off)
+    # (only matters with V3D_DENSE_TRAIN=torch, where the dense RPN / heads train through MIOpen: let it search its solvers during
+    # the warm-up -- 811 -> 868 frames/s on the same box against the default heuristic pick; V3D_TRAIN_BENCHMARK=0 switches it off)
     torch.backends.cudnn.benchmark = os.environ.get("V3D_TRAIN_BENCHMARK", "1") != "0"
     cfg = second_car_cfg()
     if args.points is None:
@@ -136,7 +137,9 @@ def train_main(args):
         model.head = model.head.to(memory_format=torch.channels_last)
         model.rpn.register_forward_pre_hook(lambda m, a: (a[0].contiguous(memory_format=torch.channels_last),))
     loss_fn = ProposalLoss(cfg)
-    opt = torch.optim.Adam(model.parameters(), lr=0.01, betas=(0.9, 0.99), weight_decay=0.01)
+    # fused = one kernel per parameter-group chunk instead of ~15 multi-tensor launches (0.23 ms of a 7.4 ms step); same update rule
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, betas=(0.9, 0.99), weight_decay=0.01,
+                           fused=os.environ.get("V3D_FUSED_ADAM", "1") != "0")
     pre, assigner = Preprocessor(cfg, seed=0), ProposalTargetAssigner(cfg)
     fids = [rank * bs + i for i in range(bs)]
     clouds = [torch.from_numpy(synth.make_cloud(f, args.points)).cuda() for f in fids]
