@@ -1256,8 +1256,11 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
     // two slots, 2 movers (8.4 -> 7.4 us at 13 731 rows); 32->64 / 64->32 register gathers, 3 weight buffers (7.2 us; staged 7.6-8.3).
     // 16 = the register-gather form for every shape (cross-check).
     if (K == 27 && (force == 10 || force == 16 || (force == 0 && rows_hint <= V3D_RING_ROWS))) {
-      static const bool regs_only = [] { const char* e = getenv("V3D_RING_REGS"); return e && e[0] == '1'; }();  // A/B in whole-frame runs
-      if (regs_only && force == 0) return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+      static const int ring_form = [] { const char* e = getenv("V3D_RING_REGS"); return e ? atoi(e) : 0; }();  // A/B in whole-frame runs
+      if (ring_form == 1 && force == 0) return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+      // (measured and not kept: two offsets per round + two weight buffers + register gathers = 69 KB of LDS at 64 -> 64, so that
+      // two such workgroups -- the same layer of another frame in flight -- or one and an 80-pixel dense tile could share a CU:
+      // 12.9 vs 10.0 us in isolation and 3 121 vs 3 306 frames/s pipelined)
       if (force != 16 && CIN == 64 && COUT == 64) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
       if (force != 16 && CIN == 32 && COUT == 32) return launch_rows_ring<CIN, COUT, 3, 2, 2, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
       return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
