@@ -59,3 +59,44 @@ for a in cap:
         assert v > 20 or (ref - o).abs().max() <= 1e-4 * ref.abs().max()  # codes > 20: ablations (-DV3D_EXPERIMENTS builds), results wrong by construction
         row += f"  {'auto' if v == 0 else 'v' + str(v)}={t:7.1f}us"
     print(row)
+
+# the same layers launched in FRAME ORDER (one after the other, REP frames in a graph): what the sequence costs when every
+# layer finds the caches as the previous layers left them, against the sum of the isolated (hot) timings above
+if os.environ.get("MB_SEQUENCE", "1") != "0":
+    layers = [a for a in cap if a[1].shape[-2] >= 16]
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad():
+        for a in layers:
+            orig(a[0], a[1], a[2], a[3], a[4], a[5], 4, a[7], 0)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            for _ in range(REP):
+                for a in layers:
+                    orig(a[0], a[1], a[2], a[3], a[4], a[5], 4, a[7], 0)
+    ts = []
+    for trial in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        if trial: ts.append(e0.elapsed_time(e1) * 1e3 / REP)
+    iso = sum(timed(a, 0)[0] for a in layers)
+    print(f"frame order: {float(np.mean(ts)):7.1f} us per {len(layers)}-layer sequence; sum of the isolated timings {iso:7.1f} us")
+    # with 64 MB of unrelated traffic between the sequences (another frame's dense head in flight)
+    junk = torch.empty(16 * 1024 * 1024, device="cuda")
+    g2 = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g2):
+        for _ in range(REP):
+            junk.add_(1.0)
+            for a in layers:
+                orig(a[0], a[1], a[2], a[3], a[4], a[5], 4, a[7], 0)
+    g3 = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g3):
+        for _ in range(REP):
+            junk.add_(1.0)
+    def tg(gr):
+        ts = []
+        for trial in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
+            if trial: ts.append(e0.elapsed_time(e1) * 1e3 / REP)
+        return float(np.mean(ts))
+    print(f"frame order behind a 128 MB stream: {tg(g2) - tg(g3):7.1f} us per sequence")
