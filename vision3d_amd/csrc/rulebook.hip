@@ -38,15 +38,10 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_hash_build_kernel(const int4* __
 }
 
 // ---------------------------------------------------------------------------------- submanifold table
-// grid = (ceil(cap/256), K): blockIdx.y = kernel offset, threads = output rows.
-__global__ __launch_bounds__(V3D_BLOCK) void rb_subm_nbr_kernel(const int4* __restrict__ coords,
-                                                                const int* __restrict__ n_ptr, int cap,
-                                                                const RbGeom g, const V3dHash h,
-                                                                const int* __restrict__ vals, int* __restrict__ nbr) {
-  const int n = min(*n_ptr, cap);
-  const int o = blockIdx.x * V3D_BLOCK + threadIdx.x;
+// nbr[k][o] of offset k for output row o (the kernels that call this are further down: they can carry a candidate job)
+__device__ __forceinline__ void rb_subm_entry(const int4* __restrict__ coords, int n, int cap, const RbGeom& g, const V3dHash& h,
+                                              const int* __restrict__ vals, int* __restrict__ nbr, int k, int o) {
   if (o >= n) return;
-  const int k = blockIdx.y;
   const int kx = k % g.ks[2], ky = (k / g.ks[2]) % g.ks[1], kz = k / (g.ks[2] * g.ks[1]);
   const int4 c = coords[o];
   const int z = c.y + kz - g.ks[0] / 2, y = c.z + ky - g.ks[1] / 2, x = c.w + kx - g.ks[2] / 2;
@@ -73,14 +68,29 @@ __device__ __forceinline__ bool rb_candidate(const int4 c, int k, const RbGeom& 
   return oz < g.out_shape[0] && oy < g.out_shape[1] && ox < g.out_shape[2];
 }
 
-__global__ __launch_bounds__(V3D_BLOCK) void rb_candidates_kernel(const int4* __restrict__ coords,
-                                                                  const int* __restrict__ n_ptr, int cap_in,
-                                                                  const RbGeom g, const V3dHash h,
-                                                                  unsigned* __restrict__ first_ticket,
-                                                                  int* __restrict__ cand_slot,
-                                                                  int* __restrict__ overflow, int* __restrict__ overflow_any) {
+// The candidate pass of a strided layer as a job that can ride in another launch (blocks == 0: none): it only needs the input
+// site list, which exists as soon as the PREVIOUS stage's sites are numbered -- long before the layer itself runs.  The plan
+// lets it ride in the launch that fills the previous strided layer's table (or builds stage 0's submanifold table): one launch
+// less per strided layer on a chain of dependent ~7 us launches.
+struct RbCandJob {
+  const int4* coords;
+  const int* n_ptr;
+  int cap_in;
+  RbGeom g;
+  V3dHash h;
+  unsigned* first_ticket;
+  int* cand_slot;
+  int* overflow;
+  int* overflow_any;
+  int blocks;
+};
+
+__device__ __forceinline__ void rb_candidates_body(const int4* __restrict__ coords, const int* __restrict__ n_ptr, int cap_in,
+                                                   const RbGeom& g, const V3dHash& h, unsigned* __restrict__ first_ticket,
+                                                   int* __restrict__ cand_slot, int* __restrict__ overflow,
+                                                   int* __restrict__ overflow_any, int block, int nblocks) {
   const long long nt = (long long)min(*n_ptr, cap_in) * g.K;
-  for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < nt; t += (long long)gridDim.x * V3D_BLOCK) {
+  for (long long t = (long long)block * V3D_BLOCK + threadIdx.x; t < nt; t += (long long)nblocks * V3D_BLOCK) {
     const int i = (int)(t / g.K), k = (int)(t % g.K);
     const int4 c = coords[i];
     int oz, oy, ox, s = -1;
@@ -94,6 +104,30 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_candidates_kernel(const int4* __
     }
     cand_slot[t] = s;
   }
+}
+
+__global__ __launch_bounds__(V3D_BLOCK) void rb_candidates_kernel(const int4* __restrict__ coords,
+                                                                  const int* __restrict__ n_ptr, int cap_in,
+                                                                  const RbGeom g, const V3dHash h,
+                                                                  unsigned* __restrict__ first_ticket,
+                                                                  int* __restrict__ cand_slot,
+                                                                  int* __restrict__ overflow, int* __restrict__ overflow_any) {
+  rb_candidates_body(coords, n_ptr, cap_in, g, h, first_ticket, cand_slot, overflow, overflow_any, blockIdx.x, gridDim.x);
+}
+
+// grid = ceil(cap/256) * K blocks (block -> (kernel offset, 256 output rows)) + the blocks of a candidate job riding along
+__global__ __launch_bounds__(V3D_BLOCK) void rb_subm_nbr_kernel(const int4* __restrict__ coords,
+                                                                const int* __restrict__ n_ptr, int cap,
+                                                                const RbGeom g, const V3dHash h,
+                                                                const int* __restrict__ vals, int* __restrict__ nbr,
+                                                                int subm_blocks, const RbCandJob job) {
+  if ((int)blockIdx.x >= subm_blocks) {
+    rb_candidates_body(job.coords, job.n_ptr, job.cap_in, job.g, job.h, job.first_ticket, job.cand_slot, job.overflow,
+                       job.overflow_any, blockIdx.x - subm_blocks, job.blocks);
+    return;
+  }
+  const int nbx = (cap + V3D_BLOCK - 1) / V3D_BLOCK;
+  rb_subm_entry(coords, min(*n_ptr, cap), cap, g, h, vals, nbr, blockIdx.x / nbx, (blockIdx.x % nbx) * V3D_BLOCK + threadIdx.x);
 }
 
 __device__ __forceinline__ bool rb_is_first(const int* cand_slot, const unsigned* first_ticket, long long t,
@@ -202,7 +236,8 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_fill_nbr_kernel(const int* __res
                                                                 int* __restrict__ nbr, int fill_blocks,
                                                                 const int4* __restrict__ coords_out,
                                                                 const int* __restrict__ n_out_ptr, const RbGeom sg,
-                                                                const V3dHash sh, int* __restrict__ subm_nbr) {
+                                                                const V3dHash sh, int* __restrict__ subm_nbr, int subm_blocks,
+                                                                const RbCandJob job) {
   if ((int)blockIdx.x < fill_blocks) {
     const long long nt = (long long)min(*n_ptr, cap_in) * K;
     for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < nt; t += (long long)fill_blocks * V3D_BLOCK) {
@@ -214,23 +249,15 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_fill_nbr_kernel(const int* __res
     }
     return;
   }
-  // ---- submanifold table of the output sites (same arithmetic as rb_subm_nbr_kernel)
+  if ((int)blockIdx.x >= fill_blocks + subm_blocks) {  // the NEXT strided layer's candidate pass (its inputs = these output sites)
+    rb_candidates_body(job.coords, job.n_ptr, job.cap_in, job.g, job.h, job.first_ticket, job.cand_slot, job.overflow,
+                       job.overflow_any, blockIdx.x - fill_blocks - subm_blocks, job.blocks);
+    return;
+  }
+  // ---- submanifold table of the output sites
   const int idx = blockIdx.x - fill_blocks;
   const int nbx = (cap_out + V3D_BLOCK - 1) / V3D_BLOCK;
-  const int k = idx / nbx, o = (idx % nbx) * V3D_BLOCK + threadIdx.x;
-  const int n = min(*n_out_ptr, cap_out);
-  if (o >= n) return;
-  const int kx = k % sg.ks[2], ky = (k / sg.ks[2]) % sg.ks[1], kz = k / (sg.ks[2] * sg.ks[1]);
-  const int4 c = coords_out[o];
-  const int z = c.y + kz - sg.ks[0] / 2, y = c.z + ky - sg.ks[1] / 2, x = c.w + kx - sg.ks[2] / 2;
-  int v = -1;
-  if (2 * k + 1 == sg.K) {
-    v = o;
-  } else if (z >= 0 && z < sg.in_shape[0] && y >= 0 && y < sg.in_shape[1] && x >= 0 && x < sg.in_shape[2]) {
-    const int s = v3d_hash_find(sh, rb_key(c.x, z, y, x, sg.in_shape));
-    if (s >= 0) v = vals[s];
-  }
-  subm_nbr[(size_t)k * cap_out + o] = v;
+  rb_subm_entry(coords_out, min(*n_out_ptr, cap_out), cap_out, sg, sh, vals, subm_nbr, idx / nbx, (idx % nbx) * V3D_BLOCK + threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------- host side
@@ -267,16 +294,43 @@ int v3d_i_hash_build(const int32_t* coords, const int32_t* n, int cap, const int
   return V3D_OK;
 }
 
+// the candidate pass of a strided layer as a job for another launch (see RbCandJob); next == nullptr: an empty job
+static int make_cand_job(const V3dRbCandNext* next, RbCandJob& job) {
+  job = RbCandJob{};
+  if (!next) return V3D_OK;
+  int rc = fill_geom(job.g, next->shape, next->ksize, next->stride, next->padding);
+  if (rc) return rc;
+  const long long tickets = (long long)next->cap_in * job.g.K;
+  if (tickets >= (1ll << 31)) return V3D_EUNSUPPORTED;
+  if ((char*)next->first_ticket != (char*)next->out.keys + (size_t)next->out.hcap * 8 ||
+      (char*)next->out.vals != (char*)next->first_ticket + (size_t)next->out.hcap * 4)
+    return V3D_EINVAL;
+  job.coords = (const int4*)next->coords_in;
+  job.n_ptr = next->n_in;
+  job.cap_in = next->cap_in;
+  job.h = v3d_make_hash(next->out.keys, next->out.hcap);
+  job.first_ticket = next->first_ticket;
+  job.cand_slot = next->cand_slot;
+  job.overflow = next->overflow;
+  job.overflow_any = next->overflow_any;
+  job.blocks = min(v3d_ceil_div(tickets, V3D_BLOCK), 4096);
+  return V3D_OK;
+}
+
 int v3d_i_subm_nbr(const int32_t* coords, const int32_t* n, int cap, const int32_t* shape, const int32_t* ksize,
-                   V3dRbHash h, int32_t* nbr, hipStream_t st) {
+                   V3dRbHash h, int32_t* nbr, hipStream_t st, const V3dRbCandNext* next) {
   RbGeom g;
   int rc = fill_geom(g, shape, ksize, nullptr, nullptr);
   if (rc) return rc;
   for (int j = 0; j < 3; j++)
     if (!(g.ks[j] & 1)) return V3D_EINVAL;  // submanifold needs odd kernels
   V3dHash hh = v3d_make_hash(h.keys, h.hcap);
-  hipLaunchKernelGGL(rb_subm_nbr_kernel, dim3(v3d_ceil_div(cap, V3D_BLOCK), g.K), dim3(V3D_BLOCK), 0, st,
-                     (const int4*)coords, n, cap, g, hh, h.vals, nbr);
+  RbCandJob job;
+  rc = make_cand_job(next, job);
+  if (rc) return rc;
+  const int subm_blocks = v3d_ceil_div(cap, V3D_BLOCK) * g.K;
+  hipLaunchKernelGGL(rb_subm_nbr_kernel, dim3(subm_blocks + job.blocks), dim3(V3D_BLOCK), 0, st,
+                     (const int4*)coords, n, cap, g, hh, h.vals, nbr, subm_blocks, job);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -287,7 +341,8 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
                           const int32_t* ksize, const int32_t* stride, const int32_t* padding, int32_t* coords_out,
                           int32_t* n_out, int cap_out, int32_t* nbr, int32_t* overflow, V3dRbHash out,
                           unsigned* first_ticket, int* cand_slot, int* chunk_counts, int32_t* out_shape, int clear,
-                          const int32_t* next_subm_ksize, int32_t* next_subm_nbr, hipStream_t st, int32_t* overflow_any) {
+                          const int32_t* next_subm_ksize, int32_t* next_subm_nbr, hipStream_t st, int32_t* overflow_any,
+                          int candidates_done, const V3dRbCandNext* next) {
   RbGeom g;
   int rc = fill_geom(g, shape, ksize, stride, padding);
   if (rc) return rc;
@@ -306,8 +361,9 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
   }
   V3dHash h = v3d_make_hash(out.keys, out.hcap);
   const int tblocks = min(v3d_ceil_div(tickets, V3D_BLOCK), 4096);
-  hipLaunchKernelGGL(rb_candidates_kernel, dim3(tblocks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in,
-                     g, h, first_ticket, cand_slot, overflow, overflow_any);
+  if (!candidates_done)  // (else: the pass rode in an earlier launch of the caller's -- v3d_i_subm_nbr / the previous strided layer)
+    hipLaunchKernelGGL(rb_candidates_kernel, dim3(tblocks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in,
+                       g, h, first_ticket, cand_slot, overflow, overflow_any);
   hipLaunchKernelGGL(rb_scan_emit_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in, g,
                      cand_slot, first_ticket, chunk_counts, cap_out, (int4*)coords_out, out.vals, n_out, overflow, overflow_any);
   RbGeom sg = g;
@@ -319,8 +375,11 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
       if (!(sg.ks[j] & 1)) return V3D_EINVAL;
     subm_blocks = v3d_ceil_div(cap_out, V3D_BLOCK) * sg.K;
   }
-  hipLaunchKernelGGL(rb_fill_nbr_kernel, dim3(tblocks + subm_blocks), dim3(V3D_BLOCK), 0, st, n_in, cap_in, g.K, cand_slot,
-                     out.vals, cap_out, nbr, tblocks, (const int4*)coords_out, n_out, sg, h, next_subm_nbr);
+  RbCandJob job;
+  rc = make_cand_job(next, job);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rb_fill_nbr_kernel, dim3(tblocks + subm_blocks + job.blocks), dim3(V3D_BLOCK), 0, st, n_in, cap_in, g.K, cand_slot,
+                     out.vals, cap_out, nbr, tblocks, (const int4*)coords_out, n_out, sg, h, next_subm_nbr, subm_blocks, job);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -347,7 +406,7 @@ extern "C" int v3d_rulebook_subm(const int32_t* coords, const int32_t* n, int ca
   if (!ar.ok()) return V3D_EWORKSPACE;
   int rc = v3d_i_hash_build(coords, n, cap, spatial_shape_host, h, 1, st);
   if (rc) return rc;
-  return v3d_i_subm_nbr(coords, n, cap, spatial_shape_host, ksize_host, h, nbr, st);
+  return v3d_i_subm_nbr(coords, n, cap, spatial_shape_host, ksize_host, h, nbr, st, nullptr);
 }
 
 extern "C" int v3d_rulebook_sparse(const int32_t* coords_in, const int32_t* n_in, int cap_in,
@@ -376,7 +435,7 @@ extern "C" int v3d_rulebook_sparse(const int32_t* coords_in, const int32_t* n_in
   if (!ar.ok()) return V3D_EWORKSPACE;
   return v3d_i_sparse_rulebook(coords_in, n_in, cap_in, spatial_shape_host, ksize_host, stride_host, padding_host,
                                coords_out, n_out, cap_out, nbr, overflow, h, first_ticket, cand_slot, chunk_counts,
-                               nullptr, 1, nullptr, nullptr, st);
+                               nullptr, 1, nullptr, nullptr, st, nullptr, 0, nullptr);
 }
 
 // ---------------------------------------------------------------------------------- transposed table (backward)

@@ -29,6 +29,7 @@ struct PlanLayer {
   int* chunk_counts;  // strided layers: published per-chunk counts -> offsets (inside the per-frame 0xFF region)
   int rows_hint;      // expected live output rows (kernel choice): capacity-free estimate, refined by v3d_backbone_tune
   int rows_hint_in;   // same for the input stage (the data-gradient pass of the training plan gathers over input rows)
+  int cand_buf;       // strided rulebook builders: which of the plan's two ticket scratch buffers (alternating)
 };
 
 struct PlanTrain;
@@ -57,7 +58,7 @@ struct v3d_backbone {
   int32_t* occupancy = nullptr;
   float* mean = nullptr;
   // strided-rulebook scratch
-  int* cand_slot = nullptr;
+  int* cand_slot[2] = {nullptr, nullptr};  // two: a strided layer's candidate pass may run while the previous layer's table is filled
   int32_t* overflow = nullptr;  // one flag per layer (<= 0 fine, 1 = capacity hit)
   char* ff_begin = nullptr;     // arena region reset to 0xFF by one memset per forward
   size_t ff_bytes = 0;
@@ -94,7 +95,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
   p->stages.push_back(s0);
   std::vector<int> key_to_rb;  // (stage, key) -> rulebook
   std::vector<int> key_stage, key_id;
-  int cur = 0, cin = cfg->point_channels;
+  int cur = 0, cin = cfg->point_channels, n_strided = 0;
   long long max_tickets = 1;
   for (int l = 0; l < cfg->n_layers; l++) {
     PlanLayer L{};
@@ -140,6 +141,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       L.stage_out = cur;
       L.rulebook = (int)p->nbr_cap.size();
       L.builds_rulebook = true;
+      L.cand_buf = n_strided++ & 1;
       p->nbr_cap.push_back(ns.cap);
     }
     L.rows_hint = L.rows_hint_in = 0;  // unknown until tuned: the 16-row kernel (right for KITTI-size frames)
@@ -185,7 +187,8 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       st.coords = ar.take<int32_t>((size_t)st.cap * 4);
       st.n_dev = ar.take<int32_t>(1);
     }
-    p->cand_slot = ar.take<int>((size_t)max_tickets);
+    p->cand_slot[0] = ar.take<int>((size_t)max_tickets);
+    p->cand_slot[1] = ar.take<int>((size_t)max_tickets);
     for (auto& L : p->layers) {
       L.weight = ar.take<float>((size_t)L.K * L.d.cin * L.d.cout);
       L.wimg = ar.take<char>(v3d_sparse_conv_weight_image_bytes(L.K, L.d.cin, L.d.cout));
@@ -301,27 +304,52 @@ extern "C" int v3d_backbone_forward_voxels(v3d_backbone* p, const float* voxel_m
 }
 
 // rulebook of layer l (and, riding in the strided builder's last launch, the submanifold table of the layer after it)
-static int plan_layer_rulebook(v3d_backbone* p, size_t l, std::vector<char>& rb_done, bool& hash0_done, hipStream_t st) {
+// `cand_done` (inference chain, nullable): the candidate pass of a strided layer rides in the launch that produces its input
+// sites' last table -- stage 0's submanifold table or the previous strided layer's fill (rulebook.hip RbCandJob) -- and is
+// marked done here.
+static bool plan_next_strided(v3d_backbone* p, size_t l, int stage, std::vector<char>* cand_done, V3dRbCandNext& nx) {
+  if (!cand_done) return false;
+  for (size_t m = l + 1; m < p->layers.size(); m++) {
+    PlanLayer& M = p->layers[m];
+    if (!M.builds_rulebook || M.d.subm || M.stage_in != stage) continue;
+    if ((*cand_done)[m]) return false;
+    PlanStage &mi = p->stages[M.stage_in], &mo = p->stages[M.stage_out];
+    nx.coords_in = mi.coords; nx.n_in = mi.n_dev; nx.cap_in = mi.cap; nx.shape = mi.shape;
+    nx.ksize = M.d.ksize; nx.stride = M.d.stride; nx.padding = M.d.padding;
+    nx.out = mo.hash; nx.first_ticket = mo.first_ticket; nx.cand_slot = p->cand_slot[M.cand_buf];
+    nx.overflow = p->overflow + m; nx.overflow_any = p->overflow + p->layers.size();
+    (*cand_done)[m] = 1;
+    return true;
+  }
+  return false;
+}
+
+static int plan_layer_rulebook(v3d_backbone* p, size_t l, std::vector<char>& rb_done, bool& hash0_done, hipStream_t st,
+                               std::vector<char>* cand_done = nullptr) {
   PlanLayer& L = p->layers[l];
   if (!L.builds_rulebook || rb_done[l]) return V3D_OK;
   PlanStage& si = p->stages[L.stage_in];
   PlanStage& so = p->stages[L.stage_out];
   int rc;
+  V3dRbCandNext nx;
   if (L.d.subm) {
     if (!si.hash_ready_by_sparse && !(L.stage_in == 0 && hash0_done)) {
       rc = v3d_i_hash_build(si.coords, si.n_dev, si.cap, si.shape, si.hash, 0, st);
       if (rc) return rc;
       if (L.stage_in == 0) hash0_done = true;
     }
-    return v3d_i_subm_nbr(si.coords, si.n_dev, si.cap, si.shape, L.d.ksize, si.hash, p->nbr[L.rulebook], st);
+    const bool carry = plan_next_strided(p, l, L.stage_in, cand_done, nx);
+    return v3d_i_subm_nbr(si.coords, si.n_dev, si.cap, si.shape, L.d.ksize, si.hash, p->nbr[L.rulebook], st, carry ? &nx : nullptr);
   }
   const bool fuse = l + 1 < p->layers.size() && p->layers[l + 1].d.subm && p->layers[l + 1].builds_rulebook &&
                     p->layers[l + 1].stage_in == L.stage_out;
+  const int mine_done = cand_done && (*cand_done)[l];
+  const bool carry = plan_next_strided(p, l, L.stage_out, cand_done, nx);
   rc = v3d_i_sparse_rulebook(si.coords, si.n_dev, si.cap, si.shape, L.d.ksize, L.d.stride, L.d.padding, so.coords, so.n_dev,
-                             so.cap, p->nbr[L.rulebook], p->overflow + l, so.hash, so.first_ticket, p->cand_slot, L.chunk_counts,
-                             nullptr, 0, fuse ? p->layers[l + 1].d.ksize : nullptr,
+                             so.cap, p->nbr[L.rulebook], p->overflow + l, so.hash, so.first_ticket, p->cand_slot[L.cand_buf],
+                             L.chunk_counts, nullptr, 0, fuse ? p->layers[l + 1].d.ksize : nullptr,
                              fuse ? p->nbr[p->layers[l + 1].rulebook] : nullptr, st,
-                             p->overflow + p->layers.size() /*summary flag: any layer*/);
+                             p->overflow + p->layers.size() /*summary flag: any layer*/, mine_done, carry ? &nx : nullptr);
   if (fuse) rb_done[l + 1] = 1;
   return rc;
 }
@@ -349,13 +377,16 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
   const float* feat = p->mean;
   const bool fork = p->rb_stream != nullptr;
   std::vector<char> waited(p->nbr_cap.size(), 0);
+  std::vector<char> cand_done_v(p->layers.size(), 0);
+  static const bool chain = [] { const char* e = getenv("V3D_RB_CHAIN"); return !(e && e[0] == '0'); }();  // "0": A/B measurements
+  std::vector<char>* cand_done = chain ? &cand_done_v : nullptr;
   if (fork) {  // the whole rulebook chain on the second stream, one event per finished rulebook
     V3D_CHECK_HIP(hipEventRecord(p->ev_fork, st));
     V3D_CHECK_HIP(hipStreamWaitEvent(p->rb_stream, p->ev_fork, 0));
     for (size_t l = 0; l < p->layers.size(); l++) {
       PlanLayer& L = p->layers[l];
       if (!L.builds_rulebook || rb_done[l]) continue;
-      rc = plan_layer_rulebook(p, l, rb_done, hash0_done, p->rb_stream);
+      rc = plan_layer_rulebook(p, l, rb_done, hash0_done, p->rb_stream, cand_done);
       if (rc) return rc;
       V3D_CHECK_HIP(hipEventRecord(p->ev_rb[L.rulebook], p->rb_stream));
       if (l + 1 < p->layers.size() && rb_done[l + 1] && p->layers[l + 1].builds_rulebook)  // rode in the same launch
@@ -370,7 +401,7 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
         waited[L.rulebook] = 1;
       }
     } else {
-      rc = plan_layer_rulebook(p, l, rb_done, hash0_done, st);
+      rc = plan_layer_rulebook(p, l, rb_done, hash0_done, st, cand_done);
       if (rc) return rc;
     }
     rc = plan_layer_conv(p, L, feat, L.wimg, L.weight, L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr,

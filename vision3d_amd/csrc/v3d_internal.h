@@ -17,8 +17,22 @@ int v3d_i_voxelize(const float* points, int n_points, int C, const int32_t* fram
                    const int32_t* site_shape /*(D, H, W) of the grid that hash is keyed on*/, hipStream_t st);
 int v3d_i_hash_build(const int32_t* coords, const int32_t* n, int cap, const int32_t* shape, V3dRbHash h, int clear,
                      hipStream_t st);
+// The candidate pass of a strided rulebook handed to an EARLIER launch (rulebook.hip RbCandJob): the next strided layer's
+// inputs (= the sites the carrying launch's stage owns), geometry, output hash and scratch.
+struct V3dRbCandNext {
+  const int32_t* coords_in;
+  const int32_t* n_in;
+  int cap_in;
+  const int32_t* shape;  // input grid of that layer
+  const int32_t *ksize, *stride, *padding;
+  V3dRbHash out;
+  unsigned* first_ticket;
+  int* cand_slot;
+  int32_t* overflow;
+  int32_t* overflow_any;
+};
 int v3d_i_subm_nbr(const int32_t* coords, const int32_t* n, int cap, const int32_t* shape, const int32_t* ksize,
-                   V3dRbHash h, int32_t* nbr, hipStream_t st);
+                   V3dRbHash h, int32_t* nbr, hipStream_t st, const V3dRbCandNext* next = nullptr);
 int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap_in, const int32_t* shape,
                           const int32_t* ksize, const int32_t* stride, const int32_t* padding, int32_t* coords_out,
                           int32_t* n_out, int cap_out, int32_t* nbr, int32_t* overflow, V3dRbHash out,
@@ -26,7 +40,9 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
                           int32_t* out_shape, int clear,
                           const int32_t* next_subm_ksize /*nullable: also build the submanifold table of the OUTPUT sites*/,
                           int32_t* next_subm_nbr, hipStream_t st,
-                          int32_t* overflow_any = nullptr /*nullable: a second flag raised together with *overflow (the plan's summary)*/);
+                          int32_t* overflow_any = nullptr /*nullable: a second flag raised together with *overflow (the plan's summary)*/,
+                          int candidates_done = 0 /*the candidate pass already ran as `next` of an earlier launch*/,
+                          const V3dRbCandNext* next = nullptr /*carry the NEXT strided layer's candidate pass in the last launch*/);
 
 // iou_nms.hip: mask + greedy reduction on boxes already sorted by (score desc, index asc) and prepped (BoxPrep rows)
 int v3d_i_nms_sorted(const void* prep_sorted, const int* order, int N, float iou_threshold, int64_t* keep, int32_t* n_keep,
