@@ -757,6 +757,260 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
   DL_STAMP(loader ? 1 : 0, 33);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 2-D tiles for the 3x3 layers of the background-skipping path (Cin = 128, one cout block, split output).
+// dl_tile gathers a tile's input once PER TAP: 9 stages x 40 KB = 360 LDS-DMA requests for 80 pixels, and a live tile lasts as
+// long as that chain of gathers (~20 us for 7 us of MFMA) -- with the persistent grid a kernel lasts as long as ONE live tile.
+// Here a tile is 5 rows x 16 columns and its (5 + 2) x (16 + 2) neighbourhood goes to LDS ONCE (64 requests): per plane two
+// 64-channel halves of 126 pixel rows x 128 B, chunk p of pixel row hp at chunk p ^ (hp & 7) (every ds_read_b128 lane group
+// covers the bank row once, for every tap alignment); the nine taps read their fragments from it at immediate offsets of eight
+// per-lane bases, the weights come straight from L2 as before, and there is no barrier between the taps.
+// ------------------------------------------------------------------------------------------------
+#define D2_TH 5
+#define D2_TW 16
+#define D2_HW (D2_TW + 2)
+#define D2_HALO ((D2_TH + 2) * D2_HW)    // 126 pixel rows
+#define D2_PIECES ((D2_HALO + 7) / 8)    // 16 requests of 8 pixel rows x 128 B per (plane, half)
+#define D2_HALF (D2_PIECES * 1024)
+#define D2_PLANE (2 * D2_HALF)
+static_assert(2 * D2_PLANE <= dl_smem(D2_TH), "the neighbourhood image lives in the tile kernel's LDS request");
+__device__ __forceinline__ void dl_tile2d(unsigned char* smem_l, const bf16_t* __restrict__ x_hi, const bf16_t* __restrict__ x_lo,
+                                          const bf16_t* __restrict__ w_img, const float* __restrict__ bias, const DcParams& p,
+                                          bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo, const int mtile) {
+  constexpr int MT = D2_TH, BM = MT * 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 4;
+  const int tx_n = (p.W + D2_TW - 1) / D2_TW, ty_n = (p.H + D2_TH - 1) / D2_TH;
+  const int b = mtile / (ty_n * tx_n), rt = mtile - b * ty_n * tx_n;
+  const int y0 = (rt / tx_n) * D2_TH, x0 = (rt % tx_n) * D2_TW;
+  if (p.occ) {
+    // background tile <=> no occupied pixel within `reach` of any pixel of the tile: the rectangle (rows y0 - R .. y0 + 4 + R,
+    // columns x0 - R .. x0 + 15 + R, clipped to the image) against the bitmap, one (row, word) pair per lane
+    const int R = p.reach, wpr = (p.W + 31) >> 5;
+    const int ylo = max(y0 - R, 0), yhi = min(min(y0 + D2_TH - 1, p.H - 1) + R, p.H - 1);
+    const int xlo = max(x0 - R, 0), xhi = min(min(x0 + D2_TW - 1, p.W - 1) + R, p.W - 1);
+    const int w0 = xlo >> 5, nw = (xhi >> 5) - w0 + 1, total = (yhi - ylo + 1) * nw;
+    const unsigned in_place = p.tile_state ? p.tile_state[mtile] : 1u;  // (requested with the occupancy words, not behind them)
+    bool near_any = false;
+    for (int q = lane; q < total; q += 64) {
+      const int row = ylo + q / nw, wd = w0 + q % nw;
+      const int lo = max(xlo, wd * 32), hi = min(xhi, wd * 32 + 31);
+      const unsigned mask = (0xFFFFFFFFu >> (31 - (hi - wd * 32))) & (0xFFFFFFFFu << (lo - wd * 32));
+      near_any |= (~p.occ[((size_t)b * p.H + row) * wpr + wd] & mask) != 0u;
+    }
+    if (!__builtin_amdgcn_readfirstlane(__ballot(near_any) != 0ull)) {
+      if (p.tile_state) {
+        if (in_place == 0u) return;  // the response is already in place (workgroup-uniform: one word)
+        __syncthreads();             // every thread has read the word before it is cleared
+        if (tid == 0) p.tile_state[mtile] = 0u;
+      }
+      const int parts = p.cout_store >> 3;
+      for (int q = tid; q < BM * parts; q += DL_THREADS) {
+        const int row = q / parts, part = q - row * parts;
+        const int yy = y0 + (row >> 4), xx = x0 + (row & 15);
+        if (yy >= p.H || xx >= p.W) continue;
+        const size_t src = ((size_t)yy * p.W + xx) * p.cout_store + part * 8, dst = (((size_t)b * p.H + yy) * p.W + xx) * p.cout_store + part * 8;
+        *reinterpret_cast<u32x4*>(y_hi + dst) = *reinterpret_cast<const u32x4*>(p.bg_hi + src);
+        *reinterpret_cast<u32x4*>(y_lo + dst) = *reinterpret_cast<const u32x4*>(p.bg_lo + src);
+      }
+      return;
+    }
+  }
+  if (p.tile_state && tid == 0) p.tile_state[mtile] = 1u;
+
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; i++) {
+    acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (loader) {
+    // loader lw brings (plane lw & 1, half lw >> 1): 16 requests of 8 pixel rows x 128 B, zero rows outside the image
+    const int lw = wave - 4, plane = lw & 1, half = lw >> 1;
+    const int sub = lane >> 3, slot = lane & 7;
+    const bf16_t* xp = plane ? x_lo : x_hi;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    unsigned char* dstb = smem_l + plane * D2_PLANE + half * D2_HALF;
+#pragma unroll
+    for (int j = 0; j < D2_PIECES; j++) {
+      const int hp = j * 8 + sub;
+      const int hy = hp / D2_HW, hx = hp - hy * D2_HW;
+      const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+      const bool ok = hp < D2_HALO && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+      const int part = half * 8 + (slot ^ (hp & 7));
+      const bf16_t* src = ok ? xp + (((size_t)b * p.H + yy) * p.W + xx) * p.Cin + part * 8 : reinterpret_cast<const bf16_t*>(dl_zero16);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dstb + j * 1024), 16, 0, 0);
+    }
+    __syncthreads();  // image complete (the compiler waits for the requests in front of the barrier)
+  } else {
+    // ---- matrix role: as dl_tile (4 waves side by side along Cout, B fragments straight from L2), A fragments from the image
+    const size_t plane_elems = (size_t)(p.CoutPad / 16) * 4 * 16 * 8;
+    u32x4 cb[DL_SS][4];
+    int tapn = 0;  // tap whose B fragments are requested next
+    auto load_b = [&](int ss) {
+      const size_t step = (size_t)min(tapn, 8) * DL_SS + ss;
+      const bf16_t* wb = w_img + step * 2 * plane_elems + ((size_t)(wave * 2) * 64 + lane) * 8;
+#pragma unroll
+      for (int nt2 = 0; nt2 < 2; nt2++) {
+        cb[ss][nt2 * 2 + 0] = *reinterpret_cast<const u32x4*>(wb + (size_t)nt2 * 512);
+        cb[ss][nt2 * 2 + 1] = *reinterpret_cast<const u32x4*>(wb + plane_elems + (size_t)nt2 * 512);
+      }
+    };
+    typedef const __attribute__((address_space(3))) unsigned char* lds_t;
+    const lds_t lds = (lds_t)smem_l;
+    const int pxl = lane & 15, kg = lane >> 4;
+    unsigned pw[8];  // pixel row hp = c + pxl (c: a constant of the unrolled code): byte 128 hp + 16 ((4 (ss & 1) + kg) ^ (hp & 7))
+#pragma unroll
+    for (int j = 0; j < 8; j++) pw[j] = (unsigned)(pxl * 128 + ((kg ^ ((pxl + j) & 7)) << 4));
+    auto multiply = [&](auto tapc) {
+      constexpr int TAP = decltype(tapc)::value;
+      constexpr int dyc = TAP / 3, dxc = TAP % 3;  // halo offsets (the image starts one row / column before the tile)
+      constexpr int NSTEP = DL_SS * MT / 2;
+      bf16x8 fh[3][2], fl[3][2];
+      auto frag = [&](auto tc, bf16x8& h, bf16x8& l) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int ss = t / MT, i = t % MT;
+        constexpr int c = (i + dyc) * D2_HW + dxc;
+        const unsigned a = (pw[c & 7] ^ (unsigned)((ss & 1) << 6)) + (unsigned)((ss >> 1) * D2_HALF + c * 128);
+        h = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(lds + a);
+        l = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(lds + a + D2_PLANE);
+      };
+#define D2_IC(v) std::integral_constant<int, (v)>{}
+      frag(D2_IC(0), fh[0][0], fl[0][0]);
+      frag(D2_IC(1), fh[0][1], fl[0][1]);
+      frag(D2_IC(2), fh[1][0], fl[1][0]);
+      frag(D2_IC(3), fh[1][1], fl[1][1]);
+      auto step = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        if constexpr (u + 2 < NSTEP) {
+          frag(D2_IC(2 * u + 4), fh[(u + 2) % 3][0], fl[(u + 2) % 3][0]);
+          frag(D2_IC(2 * u + 5), fh[(u + 2) % 3][1], fl[(u + 2) % 3][1]);
+        }
+        constexpr int t0 = 2 * u, t1 = 2 * u + 1;
+        constexpr int s0 = t0 / MT, i0 = t0 % MT, s1 = t1 / MT, i1 = t1 % MT;
+        const bf16x8 b0h0 = __builtin_bit_cast(bf16x8, cb[s0][0]), b0l0 = __builtin_bit_cast(bf16x8, cb[s0][1]);
+        const bf16x8 b0h1 = __builtin_bit_cast(bf16x8, cb[s0][2]), b0l1 = __builtin_bit_cast(bf16x8, cb[s0][3]);
+        const bf16x8 b1h0 = __builtin_bit_cast(bf16x8, cb[s1][0]), b1l0 = __builtin_bit_cast(bf16x8, cb[s1][1]);
+        const bf16x8 b1h1 = __builtin_bit_cast(bf16x8, cb[s1][2]), b1l1 = __builtin_bit_cast(bf16x8, cb[s1][3]);
+        const bf16x8 a0h = fh[u % 3][0], a0l = fl[u % 3][0], a1h = fh[u % 3][1], a1l = fl[u % 3][1];
+        acc[i0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, b0h0, acc[i0][0], 0, 0, 0);
+        acc[i0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, b0h1, acc[i0][1], 0, 0, 0);
+        acc[i1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, b1h0, acc[i1][0], 0, 0, 0);
+        acc[i1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, b1h1, acc[i1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[i0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0l0, acc[i0][0], 0, 0, 0);
+        acc[i0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0l1, acc[i0][1], 0, 0, 0);
+        acc[i1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1l0, acc[i1][0], 0, 0, 0);
+        acc[i1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1l1, acc[i1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[i0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0h0, acc[i0][0], 0, 0, 0);
+        acc[i0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0h1, acc[i0][1], 0, 0, 0);
+        acc[i1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1h0, acc[i1][0], 0, 0, 0);
+        acc[i1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1h1, acc[i1][1], 0, 0, 0);
+        // a substep's B registers are free once its last tile has issued: refill them for the next tap (unconditionally:
+        // behind the last tap a re-read nobody uses -- see dl_tile)
+        if constexpr (i0 == MT - 1) load_b(s0);
+        if constexpr (i1 == MT - 1) load_b(s1);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      step(D2_IC(0)); step(D2_IC(1)); step(D2_IC(2)); step(D2_IC(3)); step(D2_IC(4));
+      step(D2_IC(5)); step(D2_IC(6)); step(D2_IC(7)); step(D2_IC(8)); step(D2_IC(9));
+      static_assert(NSTEP == 10, "the steps are written out");
+    };
+#pragma unroll
+    for (int ss = 0; ss < DL_SS; ss++) load_b(ss);
+    tapn = 1;
+    __syncthreads();  // image complete
+    multiply(D2_IC(0)); tapn = 2;
+    multiply(D2_IC(1)); tapn = 3;
+    multiply(D2_IC(2)); tapn = 4;
+    multiply(D2_IC(3)); tapn = 5;
+    multiply(D2_IC(4)); tapn = 6;
+    multiply(D2_IC(5)); tapn = 7;
+    multiply(D2_IC(6)); tapn = 8;
+    multiply(D2_IC(7));
+    multiply(D2_IC(8));
+#undef D2_IC
+  }
+  __syncthreads();  // every fragment read is behind us: the image's LDS becomes the epilogue tile
+  // ---- epilogue (all 8 waves): accumulators -> LDS tile [80 px][128 + 4] fp32 -> bias + ReLU -> split planes
+  float* tile = reinterpret_cast<float*>(smem_l);
+  f32x4 eb0 = f32x4{0.f, 0.f, 0.f, 0.f}, eb1 = eb0;
+  {
+    const int co = (tid & 15) * 8;
+    if (bias && co < p.cout_store) {
+      eb0 = *reinterpret_cast<const f32x4*>(bias + co);
+      eb1 = *reinterpret_cast<const f32x4*>(bias + co + 4);
+    }
+  }
+  if (!loader) {
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) tile[(i * 16 + (lane >> 4) * 4 + r) * DL_TS + wave * 32 + j * 16 + (lane & 15)] = acc[i][j][r];
+  }
+  __syncthreads();
+  const int c8 = tid & 15, co = c8 * 8;
+  if (co < p.cout_store) {
+#pragma unroll
+    for (int k = 0; k < (BM + 31) / 32; k++) {
+      const int row = (tid >> 4) + 32 * k;
+      const int yy = y0 + (row >> 4), xx = x0 + (row & 15);
+      if (row < BM && yy < p.H && xx < p.W) {
+        const size_t m = ((size_t)b * p.H + yy) * p.W + xx;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + row * DL_TS + c8 * 8);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + row * DL_TS + c8 * 8 + 4);
+        float v[8] = {t0[0] + eb0[0], t0[1] + eb0[1], t0[2] + eb0[2], t0[3] + eb0[3],
+                      t1[0] + eb1[0], t1[1] + eb1[1], t1[2] + eb1[2], t1[3] + eb1[3]};
+        u32x4 vh, vl;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) {
+          float v0 = v[2 * e2], v1 = v[2 * e2 + 1];
+          if (p.relu) {
+            v0 = fmaxf(v0, 0.f);
+            v1 = fmaxf(v1, 0.f);
+          }
+          unsigned h, l;
+          split_pair(v0, v1, h, l);
+          vh[e2] = h;
+          vl[e2] = l;
+        }
+        *reinterpret_cast<u32x4*>(y_hi + m * p.cout_store + co) = vh;
+        *reinterpret_cast<u32x4*>(y_lo + m * p.cout_store + co) = vl;
+      }
+    }
+  }
+}
+
+// persistent grid drawing 2-D tiles from the counter pair (see conv2d_bf16x3_large_kernel)
+__global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_tile2d_kernel(const bf16_t* __restrict__ x_hi, const bf16_t* __restrict__ x_lo,
+                                                                          const bf16_t* __restrict__ w_img, const float* __restrict__ bias,
+                                                                          const DcParams p, bf16_t* __restrict__ y_hi,
+                                                                          bf16_t* __restrict__ y_lo) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_l[];
+  __shared__ int s_next;
+  const int ntiles = p.B * ((p.H + D2_TH - 1) / D2_TH) * ((p.W + D2_TW - 1) / D2_TW);
+  // the first tile of a workgroup is its own index (no round trip to the counter in front of the first tile); later draws
+  // continue behind the grid
+  // (requesting the NEXT draw before the current tile starts hides the counter's round trip but hands tiles to workgroups
+  // that are busy with a live one: 21.0 -> 32.4 us on the real frame)
+  for (int mtile = blockIdx.x; mtile < ntiles;) {  // workgroup-uniform
+    dl_tile2d(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, mtile);
+    if (threadIdx.x == 0) s_next = (int)(gridDim.x + atomicAdd(p.work, 1u));
+    __syncthreads();  // everyone is done with this tile's LDS
+    mtile = s_next;
+    __syncthreads();  // ... and has read s_next
+  }
+  if (threadIdx.x == 0 && atomicAdd(p.work + 1, 1u) == gridDim.x - 1) {  // last workgroup out: every draw has happened
+    p.work[0] = 0u;
+    p.work[1] = 0u;
+  }
+}
+
 // The kernel: one tile per workgroup in launch order (XCD-contiguous remap), or -- p.work set: background skipping -- a
 // PERSISTENT grid of at most one workgroup per CU that draws tiles from a counter.  Why persistent: on a sparse map fewer than
 // half of the tiles convolve (the others are a copy), a kernel lasts as long as the CU that drew the most live tiles, and the
@@ -783,13 +1037,13 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
     return;
   }
   const int ntiles = (p.M + MT * 16 - 1) / (MT * 16);
-  for (;;) {
-    if (threadIdx.x == 0) s_next = (int)atomicAdd(p.work, 1u);
-    __syncthreads();
-    const int mtile = s_next;
-    if (mtile >= ntiles) break;  // workgroup-uniform
+  // (the first tile of a workgroup is its own index: no round trip to the counter in front of it)
+  for (int mtile = blockIdx.x; mtile < ntiles;) {  // workgroup-uniform
     dl_tile<KS, MT>(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, y_nchw, mtile);
-    __syncthreads();  // everyone is done with this tile's LDS and has read s_next
+    if (threadIdx.x == 0) s_next = (int)(gridDim.x + atomicAdd(p.work, 1u));
+    __syncthreads();  // everyone is done with this tile's LDS
+    mtile = s_next;
+    __syncthreads();  // ... and has read s_next
   }
   if (threadIdx.x == 0 && atomicAdd(p.work + 1, 1u) == gridDim.x - 1) {  // last workgroup out: every draw has happened
     p.work[0] = 0u;
@@ -883,7 +1137,12 @@ extern "C" int v3d_bev_occupancy_bits(const int32_t* coords, const int32_t* n, i
 }
 
 // tiles of the persistent background-skipping grid over a (B, H, W) map = words of a `tile_state` array
-extern "C" int v3d_conv2d_bg_tiles(int B, int H, int W) { return (int)(((long long)B * H * W + 5 * 16 - 1) / (5 * 16)); }
+// (the larger of the two tilings the persistent kernels use: runs of 80 pixels, or 5 x 16 blocks)
+extern "C" int v3d_conv2d_bg_tiles(int B, int H, int W) {
+  const long long flat = ((long long)B * H * W + 5 * 16 - 1) / (5 * 16);
+  const long long blocks = (long long)B * ((H + D2_TH - 1) / D2_TH) * ((W + D2_TW - 1) / D2_TW);
+  return (int)(flat > blocks ? flat : blocks);
+}
 
 extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
                                          int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
@@ -932,6 +1191,18 @@ extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, con
       V3D_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const bool persistent = p.occ && work && p.CoutPad == DC_BN;
+    static const bool no2d = [] { const char* e = getenv("V3D_DENSE_TILE2D"); return e && e[0] == '0'; }();  // A/B measurements
+    if (persistent && ksize == 3 && Cin == DL_KC && !no2d) {  // 2-D tiles with an LDS-resident neighbourhood
+      p.work = work;
+      p.tile_state = tile_state;
+      const int tiles2 = B * v3d_ceil_div(H, D2_TH) * v3d_ceil_div(W, D2_TW);
+      const int smem2 = std::max(dl_smem(D2_TH), 84 * 1024);
+      V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv2d_bf16x3_tile2d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
+      hipLaunchKernelGGL(conv2d_bf16x3_tile2d_kernel, dim3(std::min(tiles2, n_cu)), dim3(DL_THREADS), smem2, st, (const bf16_t*)x_hi,
+                         (const bf16_t*)x_lo, (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo);
+      V3D_CHECK_LAUNCH();
+      return V3D_OK;
+    }
     const int mt = persistent ? 5 : 9;  // (in launch order the small tiles only add rounds: 33 vs 27 us on a full map)
     const int tiles = v3d_ceil_div(p.M, mt * 16);
     p.work = persistent ? work : nullptr;
