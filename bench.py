@@ -695,7 +695,8 @@ def main():
                               avg_us=t_dense * 1e6, achieved=fl / t_dense / 1e12, issued=3 * fl / t_dense / 1e12, peak=2500.0,
                               unit="TFLOP/s", frac=fl / t_dense / 1e12 / 2500.0, frac_issued=3 * fl / t_dense / 1e12 / 2500.0,
                               note="every tile convolved, random dense input (the frame itself runs the background-skipping "
-                                   "<3,5> form on a sparse map: fewer MFMAs, not a faster loop); peak = dense bf16 MFMA at the "
+                                   "2-D tile form, conv2d_bf16x3_tile2d_kernel, on a sparse map: fewer MFMAs and one LDS-resident "
+                                   "neighbourhood per tile instead of a gather per tap); peak = dense bf16 MFMA at the "
                                    "data-sheet 2.4 GHz, 3 bf16 terms per fp32-class product; matrix instructions are spaced out by "
                                    "power management, 16 busy cycles each (profiles/r02_e_dense_tile_timeline.txt)")
         tot_bytes = sum(l["bytes"] for l in layers)
