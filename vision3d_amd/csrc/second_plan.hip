@@ -90,6 +90,10 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
 
   // ---- pass 1: geometry, capacities, rulebook sharing
   PlanStage s0{};
+  if (!getenv("V3D_NO_CAP_PAD")) {  // (same for stage 0's table)
+    cap0 = (cap0 + 63) / 64 * 64;
+    if ((cap0 / 64) % 2 == 0) cap0 += 64;
+  }
   s0.cap = (int)cap0;
   for (int j = 0; j < 3; j++) s0.shape[j] = cfg->grid_shape[j];
   p->stages.push_back(s0);
@@ -132,6 +136,12 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       const long long lim = (long long)(cap0 * (double)growth);
       if (cap > lim) cap = lim;
       if (cap < 1) cap = 1;
+      // The capacity is the row stride of the stage's neighbour tables (nbr[k][o], k-major): a power of two would put the K rows
+      // a tile reads at the same offset of every 128 KB -- one memory channel, one cache set.  Make it an odd multiple of 64 rows.
+      if (!getenv("V3D_NO_CAP_PAD")) {
+        cap = (cap + 63) / 64 * 64;
+        if ((cap / 64) % 2 == 0) cap += 64;
+      }
       ns.cap = (int)cap;
       ns.hash_ready_by_sparse = true;
       const long long tickets = (long long)p->stages[cur].cap * L.K;
