@@ -704,6 +704,43 @@ def main():
         stages = dict(sparse_conv_launches=len(layers), sparse_conv_us=tot_t * 1e6, sparse_conv_algorithmic_MB=tot_bytes / 1e6,
                       sparse_conv_gbs=tot_bytes / tot_t / 1e9,
                       layers=[{k: (round(v, 2) if isinstance(v, float) else v) for k, v in l.items()} for l in layers])
+        # SURVEY 8(d) timing variants: the fused backbone plan of one frame (points -> BEV planes) WITH the voxelizer and the
+        # rulebook build, and the same frame's convolutions on the rulebooks that forward left in the plan (prebuilt); each as a
+        # captured graph of REP frames between two events
+        try:
+            with torch.no_grad():
+                plan, flat, offsets = model._plan_for(clouds)
+                plan.forward_split(flat, offsets)
+                torch.cuda.synchronize()
+
+                def graph_us(fn, rep=10):
+                    g = torch.cuda.CUDAGraph()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        fn()
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(g):
+                        for _ in range(rep):
+                            fn()
+                    ts = []
+                    for trial in range(4):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        g.replay()
+                        e1.record()
+                        torch.cuda.synchronize()
+                        if trial:
+                            ts.append(e0.elapsed_time(e1) * 1e3 / rep)
+                    return float(np.mean(ts))
+                t_full = graph_us(lambda: plan.forward_split(flat, offsets))
+                plan.forward_split(flat, offsets)
+                t_reuse = graph_us(lambda: plan.forward_reuse_split(len(offsets) - 1, flat.device))
+            stages.update(backbone_us_with_voxelizer_and_rulebook_build=t_full, backbone_us_rulebooks_prebuilt=t_reuse,
+                          backbone_note="fused plan, one frame at a time, points -> split BEV planes; 'prebuilt' = only the sparse "
+                                        "convolutions and .dense() on the site lists / neighbour tables the previous call left behind")
+        except Exception as e:  # a reported extra
+            stages.update(backbone_timing_error=repr(e)[:200])
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

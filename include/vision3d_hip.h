@@ -322,6 +322,10 @@ int v3d_nchw_to_split_nhwc(const float* x, int B, int C, int H, int W, void* out
 int v3d_backbone_forward2(v3d_backbone* plan, const float* points, int n_points, const int32_t* frame_offsets_host,
                           int B, float* dense_nchw, void* dense_hi, void* dense_lo, v3d_stream_t stream);
 
+/* The convolutions (+ .dense()) of the frame the plan forwarded LAST, on the site lists and neighbour tables that call left
+ * behind: no voxelizer, no rulebook build -- the "rulebooks prebuilt" timing variant.  Same outputs. */
+int v3d_backbone_forward_reuse(v3d_backbone* plan, int B, float* dense_nchw, void* dense_hi, void* dense_lo, v3d_stream_t stream);
+
 /* The same plan fed with EXISTING voxels -- voxel_mean (M, C) f32 and coords (M, 4) i32 (b, z, y, x), M <= the plan's voxel
  * capacity, rows frame-sorted as core/preprocess.py:26-33 produces them -- instead of raw points: what Second.forward(item) /
  * Second.inference(item) (detector/second.py:26-35, called by train.py:63 and inference.py:38) hold.  Two device copies replace

@@ -51,6 +51,20 @@ def test_plan_matches_eager_path_exactly(seeds, npts):
         assert not torch.equal(again, back)
 
 
+def test_convolutions_on_prebuilt_rulebooks_reproduce_the_forward():
+    """v3d_backbone_forward_reuse (bench.py's 'rulebooks prebuilt' timing variant): the layers run again on the site lists and
+    neighbour tables the last forward left in the plan -- same BEV planes, bit for bit, as often as it is called."""
+    model = build_model(2)
+    clouds = [torch.from_numpy(synth.make_cloud(s)).cuda() for s in (1, 2)]
+    with torch.no_grad():
+        plan, flat, offsets = model._plan_for(clouds)
+        hi, lo = plan.forward_split(flat, offsets)
+        for _ in range(2):
+            hi2, lo2 = plan.forward_reuse_split(len(clouds), flat.device)
+            assert torch.equal(hi, hi2) and torch.equal(lo, lo2)
+        assert int(plan.overflow().sum().item()) == 0
+
+
 def test_plan_tracks_weight_updates_and_matches_oracle():
     from oracle import second_cpu
     cfg = second_car_cfg()

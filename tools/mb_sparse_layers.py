@@ -100,3 +100,32 @@ if os.environ.get("MB_SEQUENCE", "1") != "0":
             if trial: ts.append(e0.elapsed_time(e1) * 1e3 / REP)
         return float(np.mean(ts))
     print(f"frame order behind a 128 MB stream: {tg(g2) - tg(g3):7.1f} us per sequence")
+
+# Does a launch cost more when its inputs were JUST WRITTEN by the previous kernel (as in a frame) than when they are old?
+# [rewrite features; layer] x REP minus [rewrite features] x REP, against [layer] x REP; the same for the neighbour table.
+if os.environ.get("MB_FRESH", "1") != "0":
+    a = [x for x in cap if x[1].shape[-2] == 64 and x[1].shape[-1] == 64 and x[2].nbr.shape[0] == 27][0]
+    feat_src, nbr_src = a[0].clone(), a[2].nbr.clone()
+
+    def tgraph(fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.no_grad():
+            fn(); torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                for _ in range(REP):
+                    fn()
+        ts = []
+        for trial in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+            if trial: ts.append(e0.elapsed_time(e1) * 1e3 / REP)
+        return float(np.mean(ts))
+
+    layer = lambda: orig(a[0], a[1], a[2], a[3], a[4], a[5], 4, a[7], 0)
+    wf = lambda: a[0].mul_(1.0)          # rewrites the feature rows in place (same values)
+    wn = lambda: a[2].nbr.add_(0)        # rewrites the neighbour table in place
+    t_layer, t_wf, t_wn = tgraph(layer), tgraph(wf), tgraph(wn)
+    t_f = tgraph(lambda: (wf(), layer())) - t_wf
+    t_n = tgraph(lambda: (wn(), layer())) - t_wn
+    t_fn = tgraph(lambda: (wf(), wn(), layer())) - t_wf - t_wn
+    print(f"64->64 n={a[2].n}: inputs old {t_layer:6.1f} us | features just rewritten {t_f:6.1f} | neighbour table just rewritten {t_n:6.1f} | both {t_fn:6.1f}")

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "v3d_backbone_occupancy": (_vp, [_vp]),
     "v3d_backbone_overflow_flags": (_vp, [_vp]),
     "v3d_backbone_forward2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "v3d_backbone_forward_reuse": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "v3d_backbone_forward_voxels": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "v3d_backbone_train_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "v3d_backbone_train_backward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),

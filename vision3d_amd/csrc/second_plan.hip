@@ -273,7 +273,7 @@ extern "C" int v3d_backbone_forward(v3d_backbone* p, const float* points, int n_
 }
 
 static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense_out, void* dense_hi, void* dense_lo,
-                           hipStream_t st);
+                           hipStream_t st, bool reuse_rulebooks = false);
 
 extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n_points,
                                      const int32_t* frame_offsets_host, int B, float* dense_out, void* dense_hi,
@@ -291,6 +291,14 @@ extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n
                           vox_hash ? &s0.hash : nullptr, s0.shape, st);
   if (rc) return rc;
   return plan_run_layers(p, B, vox_hash, dense_out, dense_hi, dense_lo, st);
+}
+
+// The convolutions of the LAST forwarded frame once more, on the site lists and neighbour tables that forward left in the plan
+// (no voxelizer, no rulebook build): the "rulebooks prebuilt" timing variant of SURVEY.md section 8(d).  Same outputs.
+extern "C" int v3d_backbone_forward_reuse(v3d_backbone* p, int B, float* dense_out, void* dense_hi, void* dense_lo,
+                                          v3d_stream_t stream) {
+  if (!p || B < 1 || B > p->cfg.max_batch) return V3D_EINVAL;
+  return plan_run_layers(p, B, true, dense_out, dense_hi, dense_lo, (hipStream_t)stream, true);
 }
 
 // Same plan fed with voxels that already exist (the `item` of the reference's Preprocessor: voxel_mean + coordinates,
@@ -381,11 +389,11 @@ static int plan_layer_conv(v3d_backbone* p, PlanLayer& L, const float* feat, con
 }
 
 static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense_out, void* dense_hi, void* dense_lo,
-                           hipStream_t st) {
+                           hipStream_t st, bool reuse_rulebooks) {
   int rc = V3D_OK;
   std::vector<char> rb_done(p->layers.size(), 0);
   const float* feat = p->mean;
-  const bool fork = p->rb_stream != nullptr;
+  const bool fork = p->rb_stream != nullptr && !reuse_rulebooks;
   std::vector<char> waited(p->nbr_cap.size(), 0);
   std::vector<char> cand_done_v(p->layers.size(), 0);
   static const bool chain = [] { const char* e = getenv("V3D_RB_CHAIN"); return !(e && e[0] == '0'); }();  // "0": A/B measurements
@@ -410,7 +418,7 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
         V3D_CHECK_HIP(hipStreamWaitEvent(st, p->ev_rb[L.rulebook], 0));
         waited[L.rulebook] = 1;
       }
-    } else {
+    } else if (!reuse_rulebooks) {
       rc = plan_layer_rulebook(p, l, rb_done, hash0_done, st, cand_done);
       if (rc) return rc;
     }

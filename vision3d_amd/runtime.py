@@ -177,6 +177,16 @@ class BackbonePlan(object):
             return self.forward_split(points, frame_offsets)
         return hi, lo
 
+    def forward_reuse_split(self, batch_size, device):
+        """The convolutions of the frame forwarded last, on the rulebooks that call left in the plan (timing variant: no
+        voxelizer, no rulebook build); same planes as forward_split returned."""
+        d, h, w = self.out_shape
+        hi, lo = split_planes_like(int(batch_size), h, w, self.out_channels * d, device)
+        with torch.cuda.device(device):
+            L.check(L.lib().v3d_backbone_forward_reuse(self._handle, int(batch_size), 0, L.ptr(hi), L.ptr(lo), L.stream_ptr()),
+                    "backbone_forward_reuse")
+        return hi, lo
+
     def forward_voxels_split(self, voxel_mean, coordinates, batch_size):
         """The plan fed with EXISTING voxels (`item['voxel_mean']` (M, C), `item['coordinates']` (M, 4) int32 of the
         Preprocessor) instead of raw points: split bf16 NHWC planes of the BEV map, as forward_split."""
