@@ -1,11 +1,22 @@
-import os, sys, torch
-sys.argv=["bench.py","--mode","train","--steps","3","--warmup","3"]
+"""Which Python lines of a train step launch the small torch kernels (fills, copies, conversions)?  torch.profiler with stacks over
+bench.py --mode train; prints, per (op, innermost frame inside this repository), the calls per step and the device time."""
+import collections, os, runpy, sys, torch
 from torch.profiler import profile, ProfilerActivity
-import runpy
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False, record_shapes=True) as prof:
+STEPS = 4
+sys.argv = ["bench.py", "--mode", "train", "--steps", str(STEPS), "--warmup", "3"]
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     runpy.run_path("bench.py", run_name="__main__")
-ka = prof.key_averages(group_by_input_shape=True)
-rows=[e for e in ka if e.key in ("aten::fill_","aten::zero_","aten::zeros","aten::copy_","aten::add","aten::add_","aten::mul","aten::mul_","aten::cat","aten::_to_copy","aten::contiguous","aten::clone","aten::zeros_like","aten::index_put_")]
-rows.sort(key=lambda e:-e.count)
-for e in rows[:60]:
-    print(f"{e.key:18s} n={e.count:4d} cuda_us={e.device_time_total:9.1f} shapes={str(e.input_shapes)[:110]}")
+agg = collections.defaultdict(lambda: [0, 0.0])
+WANT = ("aten::fill_", "aten::zero_", "aten::copy_", "aten::_to_copy", "aten::cat", "aten::add", "aten::add_", "aten::mul", "aten::mul_",
+        "aten::zeros", "aten::clone", "aten::contiguous", "aten::index_put_", "aten::sum", "aten::where", "aten::masked_fill_")
+for e in prof.events():
+    if e.name not in WANT or e.device_time_total <= 0:
+        continue
+    frame = next((f for f in e.stack if "/root/repo" in f or "vision3d_amd" in f or "bench.py" in f), e.stack[0] if e.stack else "?")
+    k = (e.name, frame.strip()[-110:])
+    agg[k][0] += 1
+    agg[k][1] += e.device_time_total
+rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+tot = STEPS + 3
+for (name, frame), (n, us) in rows[:45]:
+    print(f"{name:16s} {n / tot:5.1f}/step {us / tot:7.1f} us/step  {frame}")
