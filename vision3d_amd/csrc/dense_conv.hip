@@ -1191,7 +1191,11 @@ extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, con
       V3D_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const bool persistent = p.occ && work && p.CoutPad == DC_BN;
-    static const bool no2d = [] { const char* e = getenv("V3D_DENSE_TILE2D"); return e && e[0] == '0'; }();  // A/B measurements
+#ifdef V3D_EXPERIMENTS  // A/B switches exist in the experiments build only (tools/build_variant.sh exp -DV3D_EXPERIMENTS)
+    static const bool no2d = [] { const char* e = getenv("V3D_DENSE_TILE2D"); return e && e[0] == '0'; }();
+#else
+    constexpr bool no2d = false;
+#endif
     if (persistent && ksize == 3 && Cin == DL_KC && !no2d) {  // 2-D tiles with an LDS-resident neighbourhood
       p.work = work;
       p.tile_state = tile_state;

@@ -78,6 +78,15 @@ static int conv_fan(const v3d_layer_desc& d) {
   return fan;
 }
 
+// A/B switches (V3D_NO_CAP_PAD, V3D_RB_CHAIN, V3D_RB_FORK) exist in the experiments build only: tools/build_variant.sh exp -DV3D_EXPERIMENTS
+static bool plan_cap_pad() {
+#ifdef V3D_EXPERIMENTS
+  return !getenv("V3D_NO_CAP_PAD");
+#else
+  return true;
+#endif
+}
+
 extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_layer_desc* descs, v3d_backbone** out) {
   if (!cfg || !descs || !out || cfg->n_layers < 1 || cfg->max_batch < 1 || cfg->max_points < 1) return V3D_EINVAL;
   v3d_backbone* p = new (std::nothrow) v3d_backbone();
@@ -90,7 +99,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
 
   // ---- pass 1: geometry, capacities, rulebook sharing
   PlanStage s0{};
-  if (!getenv("V3D_NO_CAP_PAD")) {  // (same for stage 0's table)
+  if (plan_cap_pad()) {  // (same for stage 0's table)
     cap0 = (cap0 + 63) / 64 * 64;
     if ((cap0 / 64) % 2 == 0) cap0 += 64;
   }
@@ -138,7 +147,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       if (cap < 1) cap = 1;
       // The capacity is the row stride of the stage's neighbour tables (nbr[k][o], k-major): a power of two would put the K rows
       // a tile reads at the same offset of every 128 KB -- one memory channel, one cache set.  Make it an odd multiple of 64 rows.
-      if (!getenv("V3D_NO_CAP_PAD")) {
+      if (plan_cap_pad()) {
         cap = (cap + 63) / 64 * 64;
         if ((cap / 64) % 2 == 0) cap += 64;
       }
@@ -221,7 +230,11 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
   if (e != hipSuccess) { (void)hipFree(p->arena); delete p; return (int)e; }
   // Opt-in (V3D_RB_FORK=1).  Measured on the KITTI frame inside the HIP graph: the fork / join turns into cross-queue barrier
   // packets that cost more than the overlap returns -- headline 3 209 -> 2 526 frames/s with frames pipelined.
+#ifdef V3D_EXPERIMENTS
   const char* fork = getenv("V3D_RB_FORK");
+#else
+  const char* fork = nullptr;  // (the product library has no environment switches)
+#endif
   if (fork && fork[0] == '1') {
     bool ok = hipStreamCreateWithFlags(&p->rb_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -396,7 +409,11 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
   const bool fork = p->rb_stream != nullptr && !reuse_rulebooks;
   std::vector<char> waited(p->nbr_cap.size(), 0);
   std::vector<char> cand_done_v(p->layers.size(), 0);
+#ifdef V3D_EXPERIMENTS
   static const bool chain = [] { const char* e = getenv("V3D_RB_CHAIN"); return !(e && e[0] == '0'); }();  // "0": A/B measurements
+#else
+  constexpr bool chain = true;
+#endif
   std::vector<char>* cand_done = chain ? &cand_done_v : nullptr;
   if (fork) {  // the whole rulebook chain on the second stream, one event per finished rulebook
     V3D_CHECK_HIP(hipEventRecord(p->ev_fork, st));

@@ -1256,8 +1256,8 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
     // two slots, 2 movers (8.4 -> 7.4 us at 13 731 rows); 32->64 / 64->32 register gathers, 3 weight buffers (7.2 us; staged 7.6-8.3).
     // 16 = the register-gather form for every shape (cross-check).
     if (K == 27 && (force == 10 || force == 16 || (force == 0 && rows_hint <= V3D_RING_ROWS))) {
-      static const int ring_form = [] { const char* e = getenv("V3D_RING_REGS"); return e ? atoi(e) : 0; }();  // A/B in whole-frame runs
 #ifdef V3D_EXPERIMENTS
+      static const int ring_form = [] { const char* e = getenv("V3D_RING_REGS"); return e ? atoi(e) : 0; }();  // A/B in whole-frame runs
       // ablations inside the whole frame (results wrong by construction; tools/ring_dbg_in_frame.sh): 1 no gathers, 2 no weight
       // stream, 3 neither.  One frame at a time the register-gather ring takes 14.8 / 12.4 / 11.8 / 11.6 us at 64 -> 64: a floor of
       // ~11.6 us that is neither gathers nor weights (isolated, back to back: 11.1 us WITH both).  Not the dead workgroups of the
@@ -1266,6 +1266,8 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
       if (force == 0 && ring_dbg == 1) return launch_rows_ring<CIN, COUT, 3, 3, 2, 2, 0, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
       if (force == 0 && ring_dbg == 2) return launch_rows_ring<CIN, COUT, 3, 3, 2, 2, 0, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
       if (force == 0 && ring_dbg == 3) return launch_rows_ring<CIN, COUT, 3, 3, 2, 2, 0, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+#else
+      constexpr int ring_form = 0;
 #endif
       if (ring_form == 1 && force == 0) return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
       // (measured and not kept: two offsets per round + two weight buffers + register gathers = 69 KB of LDS at 64 -> 64, so that
