@@ -154,13 +154,17 @@ def train_main(args):
     reducer = dist_util.TwoPhaseGradReducer([p for p in params if id(p) not in sparse_ids],
                                             [p for p in params if id(p) in sparse_ids], world)
     amp = not args.no_amp
+    fused_loss = os.environ.get("V3D_FUSED_LOSS", "1") != "0"  # csrc/proposal_loss.hip (needs the native dense path's fused maps)
 
     def step():
         item = pre(dict(points=clouds))
         item.update(tgt)
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            losses = loss_fn(model(item))
+            out = model(item)
+            if not fused_loss:
+                out.pop("_head_maps", None)  # A/B: ProposalLoss through the torch expressions
+            losses = loss_fn(out)
         if world > 1:  # the dense half's bucket is reduced while the native sparse backward runs
             for plan in model.cnn.__dict__.get("_train_plans", {}).values():
                 plan.pre_backward_hook = reducer.start_early
@@ -195,6 +199,7 @@ def train_main(args):
             + "sparse convs bf16-split MFMA fwd/dX, fp32 MFMA dW",
             data="synthetic",
             config=dict(workload="SECOND train step (BASELINE configs[2]): fwd + ProposalLoss + bwd + grad all-reduce + clip + Adam",
+                        proposal_loss=("native fused pass (csrc/proposal_loss.hip)" if (fused_loss and native_dense) else "torch expressions"),
                         frames_per_gpu_per_step=bs, points_per_frame=args.points, parallelism=f"data-parallel x{world}, two-bucket all-reduce (dense bucket overlapped with the sparse backward)"),
             roofline=None, cpu_baseline=None, final_loss=float(loss))))
     if world > 1:

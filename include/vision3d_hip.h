@@ -333,6 +333,19 @@ int v3d_backbone_forward_reuse(v3d_backbone* plan, int B, float* dense_nchw, voi
 int v3d_backbone_forward_voxels(v3d_backbone* plan, const float* voxel_mean, const int32_t* coords, int n_voxels, int B,
                                 float* dense_nchw, void* dense_hi, void* dense_lo, v3d_stream_t stream);
 
+/* ---- ProposalLoss (detector/proposal.py:100-141) and its gradient with respect to the FUSED head maps (B, n_cls * n_yaw * 8, H, W:
+ * class channel cls * n_yaw + yaw, box channel n_cls * n_yaw + (cls * 7 + d) * n_yaw + yaw -- ProposalLayer.reshape_cls / reshape_reg)
+ * in one pass: sigmoid focal loss (ops/focal_loss.py; alpha < 0 disables the class weight) over M_cls + smooth-L1 over M_reg (yaw
+ * term / pi, counted three times as upstream broadcasts it), both divided by max(#M_reg, 1).  losses[3] = cls_loss, reg_loss,
+ * normalizer; dmaps = d(cls_loss)/d(maps) in the class channels, d(reg_loss)/d(maps) in the box channels; _scale multiplies the two
+ * channel groups with the upstream gradients (device scalars).  fp32, bit-repeatable. */
+size_t v3d_proposal_loss_workspace(void);
+int v3d_proposal_loss_fwd_bwd(const float* maps, const int8_t* g_cls, const uint8_t* m_cls, const float* g_reg, const uint8_t* m_reg,
+                              int B, int n_cls, int n_yaw, int H, int W, float alpha, float gamma, float* losses, float* dmaps,
+                              void* workspace, size_t workspace_bytes, v3d_stream_t stream);
+int v3d_proposal_loss_scale(float* dmaps, int B, int n_cls, int n_yaw, int H, int W, const float* g_cls, const float* g_reg,
+                            v3d_stream_t stream);
+
 /* ---- Training plan: the sparse half of a train step (train.py:63-67 through detector/second.py:41-46 and
  * detector/sparse_cnn.py:15-30,151-175) as ONE call forwards and ONE call backwards, no host synchronisation.
  * Every layer must be conv + BatchNorm1d (training mode: batch statistics) [+ ReLU] with a power-of-two Cout in [4, 256].

@@ -211,6 +211,40 @@ class ProposalLayer(nn.Module):
         return conv2d_split(hi, lo, img, bias, False, cin, cout, 1, out_split=False, out_nchw=True)[1]
 
 
+class FusedProposalLossFunction(torch.autograd.Function):
+    """ProposalLoss.forward and its gradient with respect to the fused head maps in one native pass (csrc/proposal_loss.hip):
+    (maps, G_cls int8, M_cls, G_reg, M_reg) -> (cls_loss, reg_loss).  The gradient is computed with the forward; backward scales
+    its two channel groups with the upstream gradients."""
+
+    @staticmethod
+    def forward(ctx, maps, g_cls, m_cls, g_reg, m_reg, n_cls, n_yaw, alpha, gamma):
+        from .. import _lib as L
+        b, _, h, w = maps.shape
+        losses = torch.empty(3, dtype=torch.float32, device=maps.device)
+        dmaps = torch.empty_like(maps)
+        lib = L.lib()
+        ws = L.workspace(lib.v3d_proposal_loss_workspace(), maps.device)
+        with torch.cuda.device(maps.device):
+            L.check(lib.v3d_proposal_loss_fwd_bwd(L.ptr(maps), L.ptr(g_cls), L.ptr(m_cls), L.ptr(g_reg), L.ptr(m_reg), b, n_cls, n_yaw, h, w,
+                                                  float(alpha), float(gamma), L.ptr(losses), L.ptr(dmaps), L.ptr(ws), ws.numel(),
+                                                  L.stream_ptr()), "proposal_loss_fwd_bwd")
+        ctx.dmaps, ctx.geom = dmaps, (b, n_cls, n_yaw, h, w)
+        return losses[0], losses[1]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_cls_loss, g_reg_loss):
+        from .. import _lib as L
+        dmaps, ctx.dmaps = ctx.dmaps, None
+        if dmaps is None:
+            raise RuntimeError("fused proposal loss: backward called twice (the gradient buffer is consumed by the first call)")
+        gc = g_cls_loss.to(torch.float32).contiguous()
+        gr = g_reg_loss.to(torch.float32).contiguous()
+        with torch.cuda.device(dmaps.device):
+            L.check(L.lib().v3d_proposal_loss_scale(L.ptr(dmaps), *ctx.geom, L.ptr(gc), L.ptr(gr), L.stream_ptr()), "proposal_loss_scale")
+        return (dmaps,) + (None,) * 8
+
+
 class ProposalLoss(nn.Module):
     """Focal classification + smooth-L1 box loss, both divided by max(#positives, 1)
     (proposal.py:100-141).  (P, G, M) = (predicted, ground truth, mask)."""
@@ -231,7 +265,32 @@ class ProposalLoss(nn.Module):
     def cls_loss(self, P_cls, G_cls, M_cls):
         return self.masked_sum(sigmoid_focal_loss(P_cls, G_cls.float(), reduction="none"), M_cls)
 
+    def _fused(self, item):
+        """The native pass applies when the model left its FUSED head maps in the item (`_head_maps`: Second.forward on the native
+        training path) and the targets have the assigner's layout; else None and the torch expressions below run."""
+        maps = item.get("_head_maps")
+        cfg = self.cfg
+        if maps is None or not maps.is_cuda or maps.dtype != torch.float32 or not maps.is_contiguous() or cfg.BOX_DOF != 7:
+            return None
+        G_cls, M_cls, G_reg, M_reg = (item[k] for k in ("G_cls", "M_cls", "G_reg", "M_reg"))
+        b, o, h, w = maps.shape
+        n_cls, n_yaw = cfg.NUM_CLASSES, cfg.NUM_YAW
+        shape = (b, n_cls, n_yaw, h, w)
+        if o != n_cls * n_yaw * 8 or tuple(G_cls.shape) != shape or tuple(M_cls.shape) != shape \
+                or tuple(G_reg.shape) != shape + (7,) or tuple(M_reg.shape) != shape + (1,) or G_reg.dtype != torch.float32:
+            return None
+        if any(t.device != maps.device for t in (G_cls, M_cls, G_reg, M_reg)):
+            return None
+        g_cls = G_cls if G_cls.dtype == torch.int8 else G_cls.to(torch.int8)
+        as_u8 = lambda m: (m if m.dtype in (torch.bool, torch.uint8) else m.ne(0)).contiguous().view(torch.uint8)
+        cls_loss, reg_loss = FusedProposalLossFunction.apply(maps, g_cls.contiguous(), as_u8(M_cls), G_reg.contiguous(), as_u8(M_reg),
+                                                             n_cls, n_yaw, 0.25, 2.0)
+        return dict(cls_loss=cls_loss, reg_loss=reg_loss, loss=cls_loss + self.cfg.TRAIN.LAMBDA * reg_loss)
+
     def forward(self, item):
+        fused = self._fused(item)
+        if fused is not None:
+            return fused
         G_cls, M_cls, P_cls, G_reg, M_reg, P_reg = (item[k] for k in ("G_cls", "M_cls", "P_cls", "G_reg", "M_reg", "P_reg"))
         normalizer = M_reg.type_as(P_reg).sum().clamp_(min=1)
         cls_loss = self.cls_loss(P_cls, G_cls, M_cls) / normalizer

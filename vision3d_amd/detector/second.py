@@ -207,6 +207,8 @@ class Second(nn.Module):
             scores, boxes = self.head.maps_from_fused(maps)
         elif (maps := self._train_head_maps(item)) is not None:
             scores, boxes = maps if isinstance(maps, tuple) else self.head.maps_from_fused(maps)
+            if not isinstance(maps, tuple):
+                item["_head_maps"] = maps  # ProposalLoss takes its native pass on the fused maps (detector/proposal.py)
         else:
             scores, boxes = self.head(self.feature_extract(item))
         item.update(dict(P_cls=scores, P_reg=boxes))
