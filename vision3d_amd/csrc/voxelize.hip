@@ -183,6 +183,25 @@ __global__ __launch_bounds__(V3D_BLOCK) void vox_emit_kernel(const float* __rest
     }
     const int occ = min(cnt, p.max_pts);
     occupancy[v] = occ;
+    if (p.C == 4) {
+      // four channels (x, y, z, intensity): the points as 16-byte loads, all in flight at once (the generic loop below issues
+      // max_pts x C scalar loads); same sums in the same order
+      float4 pv[VOX_MAX_PTS];
+#pragma unroll
+      for (int k = 0; k < VOX_MAX_PTS; k++)
+        pv[k] = (k < p.max_pts && k < occ) ? reinterpret_cast<const float4*>(pts)[best[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < VOX_MAX_PTS; k++) {
+        if (k < p.max_pts) {
+          if (voxels) reinterpret_cast<float4*>(voxels)[(size_t)v * p.max_pts + k] = pv[k];
+          sm.x += pv[k].x; sm.y += pv[k].y; sm.z += pv[k].z; sm.w += pv[k].w;
+        }
+      }
+      const float fo = (float)occ;
+      if (mean) reinterpret_cast<float4*>(mean)[v] = make_float4(sm.x / fo, sm.y / fo, sm.z / fo, sm.w / fo);
+      continue;
+    }
     for (int ch = 0; ch < p.C; ch++) {
       float s = 0.f;
 #pragma unroll
