@@ -36,6 +36,8 @@ struct PlanTrain;
 
 struct PlanStage {
   int cap;
+  int hash_items;  // what the coordinate hash is sized for: the capacity BEFORE it was padded to an odd multiple of 64 rows (the
+                   // few padding rows would otherwise double the table -- and the bytes the per-frame 0xFF fill clears)
   int shape[3];
   int32_t* coords;
   int32_t* n_dev;
@@ -99,6 +101,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
 
   // ---- pass 1: geometry, capacities, rulebook sharing
   PlanStage s0{};
+  s0.hash_items = (int)cap0;
   if (plan_cap_pad()) {  // (same for stage 0's table)
     cap0 = (cap0 + 63) / 64 * 64;
     if ((cap0 / 64) % 2 == 0) cap0 += 64;
@@ -147,6 +150,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       if (cap < 1) cap = 1;
       // The capacity is the row stride of the stage's neighbour tables (nbr[k][o], k-major): a power of two would put the K rows
       // a tile reads at the same offset of every 128 KB -- one memory channel, one cache set.  Make it an odd multiple of 64 rows.
+      ns.hash_items = (int)cap;
       if (plan_cap_pad()) {
         cap = (cap + 63) / 64 * 64;
         if ((cap / 64) % 2 == 0) cap += 64;
@@ -176,7 +180,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
     p->vox_ws_bytes = v3d_voxelize_workspace(cfg->max_points);
     p->vox_ws = ar.take<char>(p->vox_ws_bytes);
     for (auto& st : p->stages) {
-      st.hash.hcap = v3d_hash_capacity(st.cap);
+      st.hash.hcap = v3d_hash_capacity(st.hash_items);  // load factor <= (cap / hash_items) / 2: 0.501 at worst
       st.hash.keys = ar.take<v3d_key_t>(st.hash.hcap);
       st.first_ticket = ar.take<unsigned>(st.hash.hcap);
       st.hash.vals = ar.take<int>(st.hash.hcap);
