@@ -167,7 +167,8 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_scan_emit_kernel(const int4* __r
                                                                  const unsigned* __restrict__ first_ticket,
                                                                  int* __restrict__ chunk_counts, int cap_out, int4* __restrict__ coords_out,
                                                                  int* __restrict__ vals, int* __restrict__ n_out,
-                                                                 int* __restrict__ overflow, int* __restrict__ overflow_any) {
+                                                                 int* __restrict__ overflow, int* __restrict__ overflow_any,
+                                                                 int* __restrict__ nbr_init) {
   __shared__ int lds[4];
   __shared__ int s_part[4];
   const long long nt = (long long)min(*n_ptr, cap_in) * g.K;
@@ -207,6 +208,14 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_scan_emit_kernel(const int4* __r
     *n_out = min(total, cap_out);
   }
   if (!live) return;
+  if (nbr_init) {
+    // the columns of the sites this block creates (ranks prefix .. prefix + cnt - 1) start as "no input" -- the fill kernel behind
+    // this launch writes the live entries -- so the table needs no per-frame -1 fill over its whole K x capacity extent.  All
+    // threads share the work, lanes along the ranks (the emitting threads alone would do 27 stores per site, one after the other).
+    const int c0 = min(prefix, cap_out), c1 = min(prefix + cnt, cap_out), w_ = c1 - c0;
+    for (int kk = tid >> 5; kk < g.K; kk += V3D_BLOCK / 32)  // 8 table rows at a time, 32 lanes along the ranks: no division
+      for (int r = tid & 31; r < w_; r += 32) nbr_init[(size_t)kk * cap_out + c0 + r] = -1;
+  }
   int rank = prefix + incl - mine;
   for (int i = 0; i < w; i++) rank += lds[i];
   unsigned f = flags;
@@ -221,6 +230,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_scan_emit_kernel(const int4* __r
       rb_candidate(c, k, g, oz, oy, ox);
       coords_out[rank] = make_int4(c.x, oz, oy, ox);
       vals[cand_slot[t]] = rank;
+
     }
     rank++;
   }
@@ -342,7 +352,7 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
                           int32_t* n_out, int cap_out, int32_t* nbr, int32_t* overflow, V3dRbHash out,
                           unsigned* first_ticket, int* cand_slot, int* chunk_counts, int32_t* out_shape, int clear,
                           const int32_t* next_subm_ksize, int32_t* next_subm_nbr, hipStream_t st, int32_t* overflow_any,
-                          int candidates_done, const V3dRbCandNext* next) {
+                          int candidates_done, const V3dRbCandNext* next, int init_columns) {
   RbGeom g;
   int rc = fill_geom(g, shape, ksize, stride, padding);
   if (rc) return rc;
@@ -365,7 +375,8 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
     hipLaunchKernelGGL(rb_candidates_kernel, dim3(tblocks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in,
                        g, h, first_ticket, cand_slot, overflow, overflow_any);
   hipLaunchKernelGGL(rb_scan_emit_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in, g,
-                     cand_slot, first_ticket, chunk_counts, cap_out, (int4*)coords_out, out.vals, n_out, overflow, overflow_any);
+                     cand_slot, first_ticket, chunk_counts, cap_out, (int4*)coords_out, out.vals, n_out, overflow, overflow_any,
+                     init_columns ? nbr : nullptr);
   RbGeom sg = g;
   int subm_blocks = 0;
   if (next_subm_ksize && next_subm_nbr) {
@@ -435,7 +446,7 @@ extern "C" int v3d_rulebook_sparse(const int32_t* coords_in, const int32_t* n_in
   if (!ar.ok()) return V3D_EWORKSPACE;
   return v3d_i_sparse_rulebook(coords_in, n_in, cap_in, spatial_shape_host, ksize_host, stride_host, padding_host,
                                coords_out, n_out, cap_out, nbr, overflow, h, first_ticket, cand_slot, chunk_counts,
-                               nullptr, 1, nullptr, nullptr, st, nullptr, 0, nullptr);
+                               nullptr, 1, nullptr, nullptr, st, nullptr, 0, nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------------- transposed table (backward)

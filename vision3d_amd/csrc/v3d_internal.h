@@ -42,7 +42,9 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
                           int32_t* next_subm_nbr, hipStream_t st,
                           int32_t* overflow_any = nullptr /*nullable: a second flag raised together with *overflow (the plan's summary)*/,
                           int candidates_done = 0 /*the candidate pass already ran as `next` of an earlier launch*/,
-                          const V3dRbCandNext* next = nullptr /*carry the NEXT strided layer's candidate pass in the last launch*/);
+                          const V3dRbCandNext* next = nullptr /*carry the NEXT strided layer's candidate pass in the last launch*/,
+                          int init_columns = 0 /*the emit pass writes -1 into the table columns of the sites it creates: the table then
+                          needs no -1 fill (clear = 0 callers that do not pre-fill it)*/);
 
 // iou_nms.hip: mask + greedy reduction on boxes already sorted by (score desc, index asc) and prepped (BoxPrep rows)
 int v3d_i_nms_sorted(const void* prep_sorted, const int* order, int N, float iou_threshold, int64_t* keep, int32_t* n_keep,
