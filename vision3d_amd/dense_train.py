@@ -15,6 +15,9 @@ from torch import nn
 from . import _lib as L
 
 
+MAX_CACHED_PLANS = 4  # (device, batch geometry) -> plan, per model
+
+
 def rpn_pairs(rpn):
     mods = [m for m in list(rpn.down_block) + list(rpn.up_block) if not isinstance(m, (nn.ZeroPad2d, nn.ReLU))]
     convs = [m for m in mods if isinstance(m, nn.Conv2d)]
@@ -168,5 +171,7 @@ def train_head_maps(rpn, head, bev, cache):
     key = (str(bev.device), tuple(bev.shape))
     plan = cache.get(key)
     if plan is None:
+        while len(cache) >= MAX_CACHED_PLANS:  # an arena is ~150 MB per image of the batch: keep the most recent geometries only
+            cache.pop(next(iter(cache)))
         plan = cache[key] = DenseTrainPlan(rpn, head, bev.shape[0], bev.shape[2], bev.shape[3], bev.device)
     return DenseTrainFunction.apply(plan, bev, *plan.parameters())
