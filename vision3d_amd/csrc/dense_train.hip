@@ -106,6 +106,8 @@ extern "C" int v3d_dense_train_pack_weights(const float* weight, int ksize, int 
 }
 
 // ------------------------------------------------------------------------------------------------ convolution
+// (The general form, templated on the kernel size; since the 2-D tile kernel below took over the 3x3 layers only KS = 1 is
+// instantiated -- the RPN's 1x1 layer and its data gradient.)
 // Tile = 128 pixels x 128 couts; stage = 64 input channels of one tap (A: 128 pixel rows x 128 B = 16 KB, B: 2 k-substeps x 8 cout
 // tiles x 1 KB = 16 KB); the stages of ALL tiles of a (persistent) workgroup stream through a ring of 4 LDS slots.
 // Waves 4-7 LOAD, three stages ahead (LDS-DMA, hand-counted vmcnt, raw barriers): 8 consecutive lanes fetch the 128 bytes of one
