@@ -54,7 +54,9 @@ MAX_PIPELINE = int(os.environ.get("V3D_BENCH_MAX_PIPELINE", "4"))  # slots the a
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks of the job = GPUs of this node, one process per GPU.  Under torch.distributed.run (WORLD_SIZE set) it "
+                         "must equal WORLD_SIZE; without a launcher and N > 1 bench.py starts the N ranks itself (launch_plan)")
     ap.add_argument("--steps", type=int, default=300, help="timed steps (a 50-step window is 16 ms at KITTI size: too short to be stable)")
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (configs[1] = 1)")
@@ -91,14 +93,61 @@ def parse():
     return ap.parse_args()
 
 
-def ranks_seen(world):
-    """An all-reduce of ones over the job: what the collective backend (RCCL) really spans."""
-    if world == 1:
-        return 1
-    import torch.distributed as dist
-    ones = torch.ones(1, device=REDUCE_DEVICE)
-    dist.all_reduce(ones)
-    return int(ones.item())
+def launch_plan(gpus, environ, argv, n_devices, backend=BACKEND, port=None):
+    """How `--gpus N` becomes N ranks (the reference has no multi-GPU mode at all, training.md:6: this axis is the repository's).
+
+    Returns None when this process IS a rank of the right job (WORLD_SIZE == N, or N == 1 without a launcher), or the argv of
+    the launcher to re-execute under: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <same arguments>` -- the form the driver uses itself.  Raises instead of quietly running a
+    different job: WORLD_SIZE != N, fewer GPUs than ranks over RCCL (gloo, the control-flow check, lets ranks share devices)."""
+    if gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {gpus}: need at least one rank")
+    world = environ.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != gpus:
+            raise SystemExit(f"bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report "
+                             f"a {world}-rank job as n_gpus={gpus}")
+        return None
+    if backend == "nccl" and n_devices < gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} but this node shows {n_devices} GPU(s): one process per GPU over RCCL needs {gpus} "
+                         "(V3D_BENCH_BACKEND=gloo runs the N-rank control flow on fewer devices)")
+    if gpus == 1:
+        return None
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def ensure_world(args):
+    """Called first by main(): re-executes under the launcher when --gpus N > 1 came without one (never returns then)."""
+    cmd = launch_plan(args.gpus, os.environ, sys.argv[1:], torch.cuda.device_count())
+    if cmd is None:
+        return
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    print(f"bench.py: --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def ranks_seen(world, expect=None):
+    """An all-reduce of ones over the job: what the collective backend (RCCL) really spans.  `expect` (= --gpus): a job whose
+    collective spans a different number of ranks fails here, before anything is timed."""
+    seen = 1
+    if world > 1:
+        import torch.distributed as dist
+        ones = torch.ones(1, device=REDUCE_DEVICE)
+        dist.all_reduce(ones)
+        seen = int(ones.item())
+    if expect is not None and seen != expect:
+        raise SystemExit(f"bench.py: --gpus {expect} but the collective spans {seen} rank(s)")
+    return seen
 
 
 def layer_algorithmic_bytes(stats):
@@ -171,6 +220,7 @@ def train_main(args):
         losses["loss"].backward()
         reducer.finish()
         torch.nn.utils.clip_grad_norm_(params, max_norm=35)
+        model.check_train_overflow()  # this step's capacity word (copied behind the forward): before the weights are touched
         opt.step()
         return losses["loss"].detach()
 
@@ -188,7 +238,7 @@ def train_main(args):
         loss = step()
     fence()
     elapsed = dist_util.max_over_ranks(time.perf_counter() - t0, world, device=REDUCE_DEVICE)
-    seen = ranks_seen(world)
+    seen = ranks_seen(world, args.gpus)
     if rank == 0:
         print(json.dumps(dict(
             metric="frames/sec SECOND train step, 16k-pt KITTI cloud", value=world * bs * args.steps / elapsed, unit="frames/s",
@@ -224,6 +274,7 @@ def pvrcnn_main(args):
     torch.manual_seed(0)
     model = PV_RCNN(cfg).cuda().eval()
     bs = args.batch
+    args.n_ranks_seen = ranks_seen(world, args.gpus)
     if args.end_to_end:
         return pvrcnn_end_to_end(args, model, cfg, rank, world)
     depth = args.pipeline if args.pipeline >= 1 else 4  # frames in flight (independent frames on separate streams; 1 = one at a time)
@@ -301,7 +352,7 @@ def pvrcnn_main(args):
     if rank == 0:
         print(json.dumps(dict(
             metric="frames/sec PV-RCNN stage 2, 16k-pt KITTI cloud", value=world * bs * args.steps / elapsed, unit="frames/s",
-            n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
+            n_gpus=world, n_ranks_seen=args.n_ranks_seen, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
             scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
             config=dict(workload="PV-RCNN stage 2 (BASELINE configs[3]): FPS 2048 keypoints + 5-level VSA + BEV gather + "
                                  "RoI-grid pool (100 proposals) + refinement MLP", frames_per_gpu_per_step=bs,
@@ -350,7 +401,7 @@ def pvrcnn_end_to_end(args, model, cfg, rank, world):
     if rank == 0:
         print(json.dumps(dict(
             metric="frames/sec PV-RCNN inference end to end, 16k-pt KITTI cloud", value=world * bs * args.steps / elapsed,
-            unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
+            unit="frames/s", n_gpus=world, n_ranks_seen=args.n_ranks_seen, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32 (set abstraction) / bf16x3 (sparse CNN, head)",
             data="synthetic",
             config=dict(workload="PV_RCNN.inference from raw points (stage 1 + BASELINE configs[3] stage 2 + refinement NMS), one "
@@ -441,6 +492,7 @@ def run_cpu_baseline(model, cfg, anchors, make, args, workload="kitti"):
 
 def main():
     args = parse()
+    ensure_world(args)
     if args.mode == "train":
         return train_main(args)
     if args.mode == "pvrcnn":
@@ -513,7 +565,7 @@ def main():
         torch.cuda.synchronize()
 
     pipelined = args.pipeline != 1 and args.path == "graph"
-    n_ranks_seen = ranks_seen(world)  # the collective really spans `world` ranks (RCCL)
+    n_ranks_seen = ranks_seen(world, args.gpus)  # the collective really spans --gpus ranks (RCCL)
 
     def window(src, steps):
         """One timed window: EXACTLY `steps` steps, barrier + synchronize on both sides, pipeline empty at its start; the frames

@@ -110,3 +110,53 @@ def test_second_train_forward_hands_its_fused_maps_to_the_loss():
     for n in ga:  # the two head-map gradients differ by fp32 rounding; behind the bf16 dense backward that becomes bf16 ulp flips
         rel = float((ga[n] - gb[n]).norm() / gb[n].norm().clamp_min(1e-30))
         assert rel <= 1e-2, (n, rel)
+
+
+def test_reference_fp32_script_reaches_the_native_dense_kernels_when_opted_in():
+    """The reference's train.py:58-66 runs fp32 with no autocast.  With `model.dense_train_precision = "bf16"` the training forward
+    enters bf16 autocast itself for the dense half: the step takes the native kernels (fused maps present, no torch fallback) and
+    loss / gradients equal those of the same step wrapped in autocast by the caller.  The default ("fp32") keeps the torch modules
+    and hands no fused maps over; a re-used item never carries maps of an earlier forward."""
+    from vision3d_amd import synth
+    from vision3d_amd.core import Preprocessor, ProposalTargetAssigner
+    from vision3d_amd.detector import ProposalLoss, Second
+    cfg = second_car_cfg()
+    clouds = [torch.from_numpy(synth.make_cloud(s)).cuda() for s in range(2)]
+    assigner = ProposalTargetAssigner(cfg)
+    targets = []
+    for s in range(2):
+        gt = torch.from_numpy(synth.make_gt_boxes(s))
+        targets.append(assigner(dict(boxes=gt, class_idx=torch.zeros(len(gt), dtype=torch.long), box_ignore=torch.zeros(len(gt), dtype=torch.bool))))
+    tgt = {k: torch.stack([t[k] for t in targets]).cuda() for k in ("G_cls", "G_reg", "M_cls", "M_reg")}
+
+    def run(mode):
+        torch.manual_seed(0)
+        model = Second(cfg).cuda().train()
+        item = Preprocessor(cfg, seed=0)(dict(points=[c.clone() for c in clouds]))
+        item.update(tgt)
+        if mode == "caller_autocast":
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = model(item)
+                losses = ProposalLoss(cfg)(out)
+        else:
+            model.dense_train_precision = "bf16" if mode == "opt_in" else "fp32"
+            out = model(item)  # train.py:63 -- no autocast anywhere
+            losses = ProposalLoss(cfg)(out)
+        fused = "_head_maps" in out
+        losses["loss"].backward()
+        grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+        # the same dict through the eval path: the training maps must be gone
+        model.eval()
+        with torch.no_grad():
+            out2 = model(out)
+        assert "_head_maps" not in out2
+        return float(losses["loss"]), grads, fused, model.torch_dense_fallbacks
+
+    la, ga, fa, fb_a = run("caller_autocast")
+    lb, gb, fb, fb_b = run("opt_in")
+    lc, _, fc, _ = run("default")
+    assert fa and fb and not fc and fb_a == 0 and fb_b == 0
+    assert la == lb
+    for n in ga:
+        assert torch.equal(ga[n], gb[n]), n
+    assert abs(lc - la) <= 5e-2 * abs(lc)  # fp32 torch modules vs bf16 storage: same step, different precision contract

@@ -1,0 +1,44 @@
+"""CPU: how `bench.py --gpus N` turns into N ranks (launch_plan) -- the reference has no multi-GPU mode (training.md:6), so the
+1/2/4/8-GPU axis of the metric is this repository's.  The 2-rank run itself needs a GPU: tests/test_gpu_bench_launch.py."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    spec = importlib.util.spec_from_file_location("v3d_bench", os.path.join(REPO, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_single_rank_needs_no_launcher(bench):
+    assert bench.launch_plan(1, {}, ["--steps", "5"], 1, backend="nccl") is None
+
+
+def test_a_rank_of_the_right_job_runs_in_place(bench):
+    assert bench.launch_plan(8, {"WORLD_SIZE": "8"}, [], 8, backend="nccl") is None
+
+
+def test_gpus_without_launcher_reexecutes_under_torch_distributed_run(bench):
+    cmd = bench.launch_plan(2, {}, ["--gpus", "2", "--steps", "5"], 2, backend="nccl", port=29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-5:] == [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "5"]
+    assert bench.launch_plan(4, {}, [], 4, backend="nccl")[cmd.index("--master-port") + 1].isdigit()  # a free port is picked
+
+
+def test_mismatches_fail_loudly(bench):
+    with pytest.raises(SystemExit, match="WORLD_SIZE=4"):
+        bench.launch_plan(2, {"WORLD_SIZE": "4"}, [], 8, backend="nccl")
+    with pytest.raises(SystemExit, match="shows 1 GPU"):
+        bench.launch_plan(8, {}, [], 1, backend="nccl")
+    with pytest.raises(SystemExit):
+        bench.launch_plan(0, {}, [], 1, backend="nccl")
+    assert bench.launch_plan(2, {}, [], 1, backend="gloo") is not None  # gloo: ranks may share a device (control-flow check)

@@ -37,9 +37,83 @@ def test_supported_refuses_what_the_kernels_are_not_built_for():
     assert not dense_train.supported(model.rpn, model.head, OnGpu())
 
 
-def test_plan_cache_is_bounded():
-    cache = {("cuda:0", (i, 128, 8, 16)): object() for i in range(dense_train.MAX_CACHED_PLANS)}
-    assert len(cache) == dense_train.MAX_CACHED_PLANS  # (eviction itself needs a GPU: tests/test_gpu_dense_train.py)
+def test_plan_cache_evicts_the_oldest_geometry(monkeypatch):
+    """train_head_maps keeps at most MAX_CACHED_PLANS arenas per model: the eviction runs here with the plan and the autograd node
+    stubbed out (the real ones need a GPU)."""
+    built = []
+
+    class StubPlan(object):
+        def __init__(self, rpn, head, B, H, W, device):
+            built.append((B, H, W))
+
+        def parameters(self):
+            return []
+
+    class StubFunction(object):
+        @staticmethod
+        def apply(plan, bev, *params):
+            return plan
+
+    monkeypatch.setattr(dense_train, "DenseTrainPlan", StubPlan)
+    monkeypatch.setattr(dense_train, "DenseTrainFunction", StubFunction)
+    cache = {}
+    n = dense_train.MAX_CACHED_PLANS
+    for b in range(1, n + 3):
+        dense_train.train_head_maps(None, None, torch.zeros(b, 128, 4, 4), cache)
+        assert len(cache) <= n
+    assert len(built) == n + 2
+    assert [k[1][0] for k in cache] == list(range(3, n + 3))  # the two oldest geometries were dropped
+    first = dense_train.train_head_maps(None, None, torch.zeros(n + 2, 128, 4, 4), cache)
+    assert len(built) == n + 2 and first is cache[("cpu", (n + 2, 128, 4, 4))]  # a cached geometry is reused
+
+
+def test_supported_refuses_frozen_batchnorm_and_cumulative_momentum():
+    model = Second(second_car_cfg())
+
+    class OnGpu(object):
+        is_cuda, dtype, shape = True, torch.bfloat16, (1, 128, 8, 16)
+        def dim(self): return 4
+        def is_contiguous(self, memory_format=None): return True
+    _, bns, _ = dense_train.rpn_pairs(model.rpn)
+    assert dense_train.supported(model.rpn, model.head, OnGpu())
+    bns[3].eval()
+    assert "frozen" in dense_train.why_unsupported(model.rpn, model.head, OnGpu())
+    bns[3].train()
+    bns[1].momentum = None
+    assert "momentum" in dense_train.why_unsupported(model.rpn, model.head, OnGpu())
+    bns[1].momentum = 0.01
+    bns[0].running_var = bns[0].running_var.double()
+    assert "running statistics" in dense_train.why_unsupported(model.rpn, model.head, OnGpu())
+
+
+def test_forward_drops_fused_maps_of_an_earlier_forward():
+    """A re-used item dict must not carry the fused training maps of an earlier forward into ProposalLoss."""
+    cfg = second_car_cfg()
+    model = Second(cfg)
+    stale = torch.zeros(1, 16, 4, 4)
+
+    class Stop(Exception):
+        pass
+
+    def boom(item):
+        raise Stop()
+    model.feature_extract = boom
+    model.eval()
+    item = {"_head_maps": stale, "features": None}
+    try:
+        with torch.no_grad():
+            model(item)
+    except Stop:
+        pass
+    assert "_head_maps" not in item
+
+
+def test_proposal_loss_checks_that_fused_maps_belong_to_the_items_outputs():
+    cfg = second_car_cfg()
+    loss = ProposalLoss(cfg)
+    maps, p_cls, p_reg = torch.zeros(1, 16, 4, 4), torch.zeros(1), torch.zeros(1)
+    # the outputs were replaced after the forward: the fused maps no longer speak for them
+    assert loss._fused({"_head_maps": (maps, p_cls, p_reg), "P_cls": p_cls.clone(), "P_reg": p_reg}) is None
 
 
 def test_proposal_loss_ignores_fused_maps_it_cannot_use():

@@ -10,8 +10,10 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0   # the host driver only supports dmabuf IPC
 NGPUS=${NGPUS:-"1 2 4 8"}; STEPS=${STEPS:-300}; WARMUP=${WARMUP:-30}; PORT=${PORT:-29511}
 run() {  # run <n> <tag> <bench args...>
   local n=$1 tag=$2; shift 2
-  if [ "$n" = 1 ]; then
-    python bench.py --gpus 1 "$@" > "$OUT/${tag}_n1.json" 2> "$OUT/${tag}_n1.err"
+  # bench.py starts the N ranks itself when no launcher is around it (bench.launch_plan: torch.distributed.run, one process
+  # per GPU); LAUNCHER=1 wraps it explicitly, the form the driver uses
+  if [ "$n" = 1 ] || [ "${LAUNCHER:-0}" != 1 ]; then
+    python bench.py --gpus "$n" "$@" > "$OUT/${tag}_n$n.json" 2> "$OUT/${tag}_n$n.err"
   else
     python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port "$PORT" \
       bench.py --gpus "$n" "$@" > "$OUT/${tag}_n$n.json" 2> "$OUT/${tag}_n$n.err"

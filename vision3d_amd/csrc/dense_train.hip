@@ -614,13 +614,13 @@ extern "C" int v3d_dense_train_conv(const void* x, const void* image, int B, int
   const int grid = v3d_dense_train_conv_tiles(B, H, W);
   hipStream_t st = (hipStream_t)stream;
   if (ksize == 3) {
-    static bool attr3 = false;
-    if (!attr3) { V3D_CHECK_HIP(hipFuncSetAttribute((const void*)dt_conv3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DC3_SMEM)); attr3 = true; }
+    static V3dPerDeviceFlag attr3;
+    V3D_CHECK_HIP(v3d_set_max_lds(attr3, (const void*)dt_conv3_kernel, DC3_SMEM));
     hipLaunchKernelGGL(dt_conv3_kernel, dim3(grid), dim3(DC3_THREADS), DC3_SMEM, st, (const dt_bf16*)x, (const dt_bf16*)image, B, H, W,
                        (dt_bf16*)y, stats);
   } else {
-    static bool attr1 = false;
-    if (!attr1) { V3D_CHECK_HIP(hipFuncSetAttribute((const void*)dt_conv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, DT_CONV_SMEM)); attr1 = true; }
+    static V3dPerDeviceFlag attr1;
+    V3D_CHECK_HIP(v3d_set_max_lds(attr1, (const void*)dt_conv_kernel<1>, DT_CONV_SMEM));
     hipLaunchKernelGGL(dt_conv_kernel<1>, dim3(grid), dim3(DT_THREADS), DT_CONV_SMEM, st, (const dt_bf16*)x, (const dt_bf16*)image, B, H, W,
                        (dt_bf16*)y, stats);
   }
@@ -1009,12 +1009,9 @@ extern "C" int v3d_dense_train_wgrad(const void* x, const void* dy, int B, int H
   const int slabs = (int)(tiles < DT_WG_SLABS ? tiles : DT_WG_SLABS);
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
-  static bool attr = false;
-  if (!attr) {
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)dt_wgrad_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, DT_W2_SMEM));
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)dt_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, DT_W2_SMEM));
-    attr = true;
-  }
+  static V3dPerDeviceFlag attr9, attr1;
+  V3D_CHECK_HIP(v3d_set_max_lds(attr9, (const void*)dt_wgrad_kernel<9>, DT_W2_SMEM));
+  V3D_CHECK_HIP(v3d_set_max_lds(attr1, (const void*)dt_wgrad_kernel<1>, DT_W2_SMEM));
   if (ksize == 3)
     hipLaunchKernelGGL(dt_wgrad_kernel<9>, dim3(4 * slabs), dim3(768), DT_W2_SMEM, st, (const dt_bf16*)x, (const dt_bf16*)dy, B, H, W, slabs, partial);
   else

@@ -48,6 +48,23 @@ static inline hipError_t v3d_fill_async(void* ptr, int byte, size_t bytes, hipSt
   return hipGetLastError();
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: remembered per device, not per process (a
+// process that drives a second GPU must raise the limit there too).  A benign race at worst sets the attribute twice.
+#define V3D_MAX_DEVICES 64
+struct V3dPerDeviceFlag {
+  bool done[V3D_MAX_DEVICES] = {};
+};
+static inline hipError_t v3d_set_max_lds(V3dPerDeviceFlag& f, const void* fn, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const bool tracked = dev >= 0 && dev < V3D_MAX_DEVICES;
+  if (tracked && f.done[dev]) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && tracked) f.done[dev] = true;
+  return e;
+}
+
 // Bump allocator over a caller-provided workspace.
 struct V3dArena {
   char* base;

@@ -26,33 +26,58 @@ def rpn_pairs(rpn):
 
 
 def supported(rpn, head, bev):
-    """The kernels cover: bf16 channels_last CUDA input with 128 channels; every RPN conv 128 -> 128, 3x3 (pad 1 / ZeroPad2d + pad
-    0) or 1x1, stride 1, bias-free, each followed by BatchNorm2d (affine) + ReLU; head = two biased 1x1 convs with 8 * n <= 64
-    fused outputs."""
+    return why_unsupported(rpn, head, bev) is None
+
+
+def why_unsupported(rpn, head, bev):
+    """None when the kernels cover the stack, else the reason.  Covered: bf16 channels_last CUDA input with 128 channels; every
+    RPN conv 128 -> 128, 3x3 (pad 1 / ZeroPad2d + pad 0) or 1x1, stride 1, bias-free, fp32 weights, each followed by a
+    BatchNorm2d (affine, in TRAINING mode with a numeric momentum: the kernels always normalise with batch statistics and update
+    the running statistics by `momentum`; fp32 running statistics on the input's device) + ReLU; head = two biased fp32 1x1
+    convs with 8 * n <= 64 fused outputs."""
     if not (bev.is_cuda and bev.dtype == torch.bfloat16 and bev.dim() == 4 and bev.shape[1] == 128 and bev.shape[3] >= 4
             and bev.is_contiguous(memory_format=torch.channels_last)):
-        return False
+        return "input is not a bf16 channels_last CUDA map with 128 channels"
     convs, bns, clean = rpn_pairs(rpn)
     if not clean or len(convs) != len(bns) or not convs or len(convs) > 16:
-        return False
+        return "the RPN is not a stack of (Conv2d, BatchNorm2d, ReLU) triples"
+    dev = getattr(bev, "device", None)
+
+    def off_device(t):  # (stand-in inputs of the CPU tests carry no device: nothing to compare then)
+        return dev is not None and t.device != dev
     mods = list(rpn.down_block) + list(rpn.up_block)
     for i, m in enumerate(mods):  # a ZeroPad2d may only sit in front of a pad-0 3x3 conv (together = pad 1)
         if isinstance(m, nn.ZeroPad2d):
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             if m.padding != (1, 1, 1, 1) or not isinstance(nxt, nn.Conv2d) or nxt.kernel_size != (3, 3) or nxt.padding != (0, 0):
-                return False
+                return "a ZeroPad2d that is not ZeroPad2d(1) in front of a pad-0 3x3 convolution"
     for i, (c, b) in enumerate(zip(convs, bns)):
         k = c.kernel_size[0]
         if (c.in_channels != 128 or c.out_channels != 128 or c.kernel_size not in ((1, 1), (3, 3)) or c.stride != (1, 1)
                 or c.bias is not None or c.groups != 1 or c.dilation != (1, 1) or c.weight.dtype != torch.float32):
-            return False
+            return f"RPN convolution {i} is not a bias-free fp32 128 -> 128 3x3 / 1x1 stride-1 convolution"
         padded = c.padding == (k // 2, k // 2) or (k == 3 and c.padding == (0, 0))  # the latter only behind a ZeroPad2d (checked above)
         if not padded or not isinstance(b, nn.BatchNorm2d) or not b.affine or b.num_features != 128:
-            return False
+            return f"RPN layer {i}: padding / BatchNorm2d(128, affine) pattern not covered"
+        if not b.training:
+            return f"RPN BatchNorm {i} is frozen (eval mode inside a training model): the kernels use batch statistics"
+        if b.track_running_stats and b.running_mean is not None:
+            if b.momentum is None:
+                return f"RPN BatchNorm {i} has momentum=None (cumulative average): the kernels take a numeric momentum"
+            if (b.running_mean.dtype != torch.float32 or b.running_var.dtype != torch.float32 or off_device(b.running_mean)
+                    or off_device(b.running_var)):
+                return f"RPN BatchNorm {i}: running statistics are not fp32 tensors on the input's device"
+        if b.weight.dtype != torch.float32 or off_device(b.weight) or off_device(c.weight):
+            return f"RPN layer {i}: parameters are not fp32 tensors on the input's device"
     for conv in (head.conv_cls, head.conv_reg):
         if conv.kernel_size != (1, 1) or conv.in_channels != 128 or conv.bias is None or conv.stride != (1, 1):
-            return False
-    return (head.conv_cls.out_channels + head.conv_reg.out_channels) in (8, 16, 24, 32, 48, 64)
+            return "head convolutions are not biased 1x1 convolutions on 128 channels"
+        if (conv.weight.dtype != torch.float32 or conv.bias.dtype != torch.float32 or off_device(conv.weight)
+                or off_device(conv.bias)):
+            return "head parameters are not fp32 tensors on the input's device"
+    if (head.conv_cls.out_channels + head.conv_reg.out_channels) not in (8, 16, 24, 32, 48, 64):
+        return "fused head width is not one of 8, 16, 24, 32, 48, 64"
+    return None
 
 
 class DenseTrainPlan(object):
@@ -161,7 +186,9 @@ class DenseTrainFunction(torch.autograd.Function):
         plan = ctx.plan
         if ctx.generation != plan.generation:
             raise RuntimeError("dense train plan: this backward belongs to forward #%d but the plan's arena now holds forward #%d "
-                               "(one forward/backward pair at a time per plan)" % (ctx.generation, plan.generation))
+                               "(one forward/backward pair at a time per plan; V3D_DENSE_TRAIN=torch, or Second.native_dense_train "
+                               "= False, keeps the torch modules, which accept several forwards before a backward)"
+                               % (ctx.generation, plan.generation))
         dbev, grads = plan.backward(dmaps)
         return (None, dbev if ctx.needs_bev_grad else None) + tuple(grads)
 

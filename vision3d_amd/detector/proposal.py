@@ -269,6 +269,12 @@ class ProposalLoss(nn.Module):
         """The native pass applies when the model left its FUSED head maps in the item (`_head_maps`: Second.forward on the native
         training path) and the targets have the assigner's layout; else None and the torch expressions below run."""
         maps = item.get("_head_maps")
+        if isinstance(maps, tuple):
+            # (maps, P_cls, P_reg) as Second.forward leaves them: the fused maps only speak for this item while its P_cls / P_reg
+            # are still the views made from them -- outputs that were replaced or post-processed go through the torch expressions
+            maps, p_cls, p_reg = maps
+            if item.get("P_cls") is not p_cls or item.get("P_reg") is not p_reg:
+                return None
         cfg = self.cfg
         if maps is None or not maps.is_cuda or maps.dtype != torch.float32 or not maps.is_contiguous() or cfg.BOX_DOF != 7:
             return None

@@ -97,8 +97,9 @@ class TwoPhaseGradReducer(object):
         Only started when EVERY early parameter that requires a gradient has one: a gradient that arrives later (or is still
         being accumulated) would be left unreduced -- in that case the whole reduction is deferred to `finish()`.
         Stream order: the bucket is built by kernels on the CALLER's stream (torch.cat inside autograd's backward); the
-        collective runs on the backend's own stream (RCCL) -- torch's ProcessGroupNCCL makes its stream wait for the
-        current stream at enqueue time, and an explicit event marks the point for backends that do not."""
+        collective runs on the backend's own stream (RCCL) -- torch's ProcessGroupNCCL makes that stream wait for the caller's
+        current stream at enqueue time, which is the ordering this relies on (gloo reduces host-visible tensors synchronously
+        with respect to the caller's stream)."""
         if self.world == 1 or self._work is not None:
             return
         if any(p.requires_grad and p.grad is None for p in self.early):
@@ -107,10 +108,6 @@ class TwoPhaseGradReducer(object):
         self._grads, self._flat = self._bucket(self.early)
         self._early_ids = {id(g) for g in self._grads}
         if self._flat is not None:
-            if self._flat.is_cuda:
-                self._ready = torch.cuda.Event()
-                self._ready.record()           # the bucket is complete at this point of the caller's stream
-                self._ready.wait()             # (a no-op for the recording stream; the collective's enqueue follows it)
             self._work = dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def finish(self):

@@ -305,6 +305,13 @@ class BackbonePlan(object):
         st["event"].record()
         st["pending"] = True
 
+    def check_deferred_overflow(self):
+        """Raise if the LAST training forward dropped rows.  Its summary word was copied to pinned memory right behind that
+        forward, so calling this after backward() and BEFORE optimizer.step() costs no stall (the copy finished while the
+        backward was being enqueued) and keeps corrupted gradients out of the weights; the next train_forward calls it too, and
+        a training script should call it once more after its last step (Second.check_train_overflow does both plans)."""
+        self._check_deferred_overflow()
+
     def _check_deferred_overflow(self):
         st = self.__dict__.get("_ovf_state")
         if not st or not st.get("pending"):
@@ -312,7 +319,7 @@ class BackbonePlan(object):
         st["event"].synchronize()  # recorded one whole step ago: returns at once
         st["pending"] = False
         if int(st["host"][0]) > 0:
-            raise RuntimeError("sparse backbone (training plan): the previous step exceeded an active-site capacity -- rows were "
+            raise RuntimeError("sparse backbone (training plan): the last checked step exceeded an active-site capacity -- rows were "
                                "dropped, its BEV map, batch statistics and gradients are wrong; build the plan with a larger "
                                "`growth` (Middle.plan_growth) or set plan.allow_overflow to accept clamping")
 
