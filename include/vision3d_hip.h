@@ -170,7 +170,10 @@ size_t v3d_sparse_conv_weight_image_bytes(int K, int Cin, int Cout);
 int v3d_sparse_conv_pack_weights(const float* weight, int K, int Cin, int Cout, void* image, v3d_stream_t stream);
 /* rows_hint > 0: the caller's estimate of the LIVE row count (*n_out is device-side), used only to choose the kernel: 3x3x3 with
  * Cin, Cout in {32, 64}: LDS-ring kernel up to 16 384 rows, 64-row LDS-shared-weights kernel from 32 768, else the 16-row kernel;
- * 0 = unknown (ring / 16-row).  rows_hint < 0 FORCES a kernel (tests, benchmarks): -1 = 16-row, -5 = 64-row, -10 = LDS ring.
+ * 0 = unknown (ring / 16-row).  The 64 -> 64 ring kernel owns a CU per workgroup: it takes 2, 3 or 4 sixteen-row tiles per workgroup,
+ * the smallest count that keeps rows_hint + 10 % inside one round of 256 workgroups (8 192 / 12 288 / 16 384 rows).
+ * rows_hint < 0 FORCES a kernel (tests, benchmarks): -1 = 16-row, -5 = 64-row, -6 / -7 = offset-outer (staged / register gathers),
+ * -10 = LDS ring, -16 = its register-gather form, -12 / -13 / -14 = the 64 -> 64 ring with 2 / 3 / 4 tiles per workgroup.
  * There is no process-global switch. */
 int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,

@@ -138,6 +138,29 @@ def test_ring_kernel_edge_sizes(oracle, cin, cout):
         assert_features_close(out.features.detach().cpu().numpy(), ref, f"ring n={m}")
 
 
+def test_ring_kernel_tiles_per_workgroup(oracle):
+    """64 -> 64 ring kernel with 2 / 3 / 4 sixteen-row tiles per workgroup (variants 12 / 13 / 14; the plan picks the smallest
+    count that keeps a layer inside one round of 256 LDS-filling workgroups): the oracle's result, and the SAME bits from all
+    three forms (a row's products are accumulated in the same order whatever tile of whatever workgroup holds it), at sizes
+    around every tiling edge."""
+    from vision3d_amd.spconv.conv import build_subm_rulebook, sparse_conv_forward
+    rng = np.random.default_rng(64)
+    all_coords = kitti_coords(oracle, [5])
+    shape = [41, 1600, 1408]
+    w = (rng.standard_normal((3, 3, 3, 64, 64)) / np.sqrt(64 * 9)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, 64).astype(np.float32), rng.standard_normal(64).astype(np.float32) * 0.1
+    for n in (1, 16, 33, 47, 48, 49, 63, 64, 65, 97, 129, 5003):
+        coords = all_coords[:n]
+        feats = rng.standard_normal((n, 64)).astype(np.float32)
+        x = make_tensor(coords, feats, shape, 1)
+        rb = build_subm_rulebook(x, [3, 3, 3])
+        ref = oracle.sparse_conv_fwd(feats, w, oracle.subm_rulebook(coords, shape, 3), sc, sh, True)
+        outs = [sparse_conv_forward(x.features, dev(w), rb, dev(sc), dev(sh), True, 4, None, v).cpu().numpy() for v in (12, 13, 14)]
+        assert_features_close(outs[0], ref, f"ring 2 tiles n={n}")
+        np.testing.assert_array_equal(outs[0], outs[1], err_msg=f"3 tiles vs 2, n={n}")
+        np.testing.assert_array_equal(outs[0], outs[2], err_msg=f"4 tiles vs 2, n={n}")
+
+
 def test_densify_exact(oracle):
     rng = np.random.default_rng(3)
     coords = kitti_coords(oracle, [5, 6])

@@ -12,6 +12,7 @@
 //     readlanes, then the kept rows are OR-ed into the remaining words by all lanes in parallel;
 //   * the descending score sort is an in-LDS bitonic network on (score, index) keys.
 #include "v3d_common.h"
+#include "nms_device.h"
 #include "rotated_iou.h"
 
 using v3d::BoxPrep;
@@ -255,54 +256,15 @@ static void launch_nms_mask(const BoxPrep* prep, int N, int nwords, float thr, u
   }
 }
 
-// NMS step 4: greedy reduction on the device.
-__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
-  return ((unsigned long long)hi << 32) | lo;
-}
-
+// NMS step 4: greedy reduction on the device (nms_device.h: shared with the fused tail of the proposal stage).
 __global__ __launch_bounds__(V3D_BLOCK) void nms_reduce_kernel(const unsigned long long* __restrict__ mask,
                                                                const int* __restrict__ order, int N, int nwords,
                                                                unsigned long long* __restrict__ remv /*nwords*/,
                                                                long long* __restrict__ keep, int* __restrict__ n_keep) {
   __shared__ unsigned long long kept_s;
-  const int tid = threadIdx.x, lane = tid & 63;
-  for (int w = tid; w < nwords; w += V3D_BLOCK) remv[w] = 0ull;
-  __syncthreads();
-  int nk = 0;  // meaningful in wave 0
-  for (int b = 0; b < nwords; b++) {
-    if (tid < 64) {
-      const int i = b * 64 + lane;
-      const unsigned long long diag = i < N ? mask[(size_t)i * nwords + b] : 0ull;
-      unsigned long long r = remv[b];
-      unsigned long long kept = 0ull;
-      const int lim = min(64, N - b * 64);
-      for (int j = 0; j < lim; j++) {
-        if (!((r >> j) & 1ull)) {
-          kept |= 1ull << j;
-          r |= readlane64(diag, j);
-        }
-      }
-      if ((kept >> lane) & 1ull) keep[nk + __popcll(kept & ((1ull << lane) - 1ull))] = (long long)order[i];
-      nk += __popcll(kept);
-      if (lane == 0) kept_s = kept;
-    }
-    __syncthreads();
-    const unsigned long long kept = kept_s;
-    for (int w = b + 1 + tid; w < nwords; w += V3D_BLOCK) {
-      unsigned long long acc = remv[w];
-      unsigned long long bits = kept;
-      while (bits) {
-        const int j = __ffsll((long long)bits) - 1;
-        bits &= bits - 1;
-        acc |= mask[(size_t)(b * 64 + j) * nwords + w];
-      }
-      remv[w] = acc;
-    }
-    __syncthreads();
-  }
-  if (tid == 0) *n_keep = nk;
+  __shared__ int nk_s;
+  const int nk = v3d::nms_greedy_reduce<V3D_BLOCK>(mask, order, N, nwords, remv, keep, &kept_s, &nk_s);
+  if (threadIdx.x == 0) *n_keep = nk;
 }
 
 static inline int next_pow2(int n) {
@@ -313,6 +275,14 @@ static inline int next_pow2(int n) {
 
 // Internal: mask + greedy reduction on boxes that are ALREADY sorted and prepped (csrc/proposal.hip fuses decode,
 // key sort and box prep into one launch).  mask: N * ceil(N/64) words, remv: ceil(N/64) words.
+// the suppression mask alone (the proposal stage reduces it in its own fused launch)
+int v3d_i_nms_mask_sorted(const void* prep_sorted, int N, float iou_threshold, unsigned long long* mask, hipStream_t st) {
+  if (N < 1 || N > 65535) return V3D_EUNSUPPORTED;
+  launch_nms_mask((const BoxPrep*)prep_sorted, N, (N + 63) / 64, iou_threshold, mask, st);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 int v3d_i_nms_sorted(const void* prep_sorted, const int* order, int N, float iou_threshold, int64_t* keep, int32_t* n_keep,
                      unsigned long long* mask, unsigned long long* remv, hipStream_t st) {
   if (N < 1 || N > 65535) return V3D_EUNSUPPORTED;

@@ -1,5 +1,7 @@
 // Fused proposal stage of the BEV head: sigmoid -> top-k per (frame, class) -> VoxelNet decode -> batched rotated
-// NMS -> per-class score cut, entirely on the device, in 6 launches, no host synchronisation.
+// NMS -> per-class score cut, entirely on the device, no host synchronisation.  Launches: level-1 top-k | merge + decode + sort +
+// box prep (ONE workgroup when there are at most two (frame, class) groups, else merge and decode separately) | suppression mask |
+// greedy reduction + score cut = 4 at bs = 1 (6 until round 4).
 //
 // Reference: vision3d/detector/proposal.py:39-80 (ProposalLayer.inference / _multiclass_batch_nms),
 // core/box_encode.py:13-21 (decode), ops/iou_nms.py:90-134 (coordinate-offset batched NMS).  The torch statement
@@ -14,6 +16,7 @@
 #include <stdint.h>
 
 #include "../../include/vision3d_hip.h"
+#include "nms_device.h"
 #include "rotated_iou.h"
 #include "v3d_internal.h"
 
@@ -21,6 +24,7 @@
 #define PROP_WAVES (PROP_THREADS / 64)
 #define PROP_MAX_TOPK 1024
 #define PROP_MAX_CLS 16
+#define PROP_RANK_SORT_MAX 256  // candidate lists up to this (padded) length are rank-sorted, longer ones by a bitonic network
 #define PROP_CHUNKS 40  // upper bound of level-1 slices per (frame, class) group (40 x topk 100 <= 4096 merge inputs)
 
 struct PropGeom {
@@ -54,6 +58,7 @@ __device__ void prop_select(const float* __restrict__ x, const int* __restrict__
   __shared__ int sh_count, sh_eq_total;
   __shared__ int sh_eq[SEL_WAVES];
   __shared__ unsigned long long cand[PROP_MAX_TOPK];
+  __shared__ int rank_s[PROP_RANK_SORT_MAX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Ke = min(K, n);  // rows that can be real
   float xv[EPT];  // element e of thread t is index t + e*256 (coalesced)
@@ -177,23 +182,45 @@ __device__ void prop_select(const float* __restrict__ x, const int* __restrict__
     }
   }
   __syncthreads();
-  // bitonic sort of the candidates, descending on (ordered score key, ~position); zero keys (padding) sink
+  // sort the candidates, descending on (ordered score key, ~position); zero keys (padding) sink
   int npad = 1;
   while (npad < K) npad <<= 1;
-  for (int i = Ke + tid; i < npad; i += SEL_THREADS) cand[i] = 0ull;
-  __syncthreads();
-  for (int k = 2; k <= npad; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < npad; i += SEL_THREADS) {
-        const int p = i ^ j;
-        if (p > i) {
-          const unsigned long long a = cand[i], bb = cand[p];
-          const bool desc = (i & k) == 0;
-          if (desc ? a < bb : a > bb) { cand[i] = bb; cand[p] = a; }
-        }
-      }
-      __syncthreads();
+  if (npad <= PROP_RANK_SORT_MAX) {
+    // RANK sort: the keys are distinct (the position is part of the key), so a candidate's place is the number of larger keys.
+    // SEL_THREADS / npad threads share a candidate's count (LDS broadcast reads), one barrier pair instead of the
+    // log2(npad) * (log2(npad) + 1) / 2 = 28 barrier-separated passes of a bitonic network at K = 100.
+    const int i = tid & (npad - 1), part = tid / npad, parts = SEL_THREADS / npad;
+    if (tid < npad) rank_s[tid] = 0;
+    __syncthreads();
+    unsigned long long mine = 0ull;
+    if (i < Ke) {
+      mine = cand[i];
+      int cnt = 0;
+      for (int j = part; j < Ke; j += parts) cnt += cand[j] > mine ? 1 : 0;
+      if (cnt) atomicAdd(&rank_s[i], cnt);
     }
+    __syncthreads();
+    if (tid < Ke) mine = cand[tid];
+    const int place = tid < Ke ? rank_s[tid] : 0;
+    __syncthreads();
+    if (tid < Ke) cand[place] = mine;
+    __syncthreads();
+  } else {
+    for (int i = Ke + tid; i < npad; i += SEL_THREADS) cand[i] = 0ull;
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < npad; i += SEL_THREADS) {
+          const int p = i ^ j;
+          if (p > i) {
+            const unsigned long long a = cand[i], bb = cand[p];
+            const bool desc = (i & k) == 0;
+            if (desc ? a < bb : a > bb) { cand[i] = bb; cand[p] = a; }
+          }
+        }
+        __syncthreads();
+      }
+  }
   for (int i = tid; i < K; i += SEL_THREADS) {
     if (i < Ke) {
       const unsigned long long v = cand[i];
@@ -235,15 +262,11 @@ __global__ __launch_bounds__(SEL_THREADS) void prop_topk_merge_kernel(const floa
 // shift the BEV boxes by group (ops/iou_nms.py:127-133: offset = group * (max_coord - min_coord + 1), added to x and
 // y), sort (score descending, index ascending) in LDS and emit the NMS inputs in sorted order -- what were four
 // launches (decode, keys, bitonic sort, gather + box prep).  N <= 1024.
-__global__ __launch_bounds__(PROP_THREADS) void prop_decode_sort_kernel(const float* __restrict__ maps,
-                                                                        const float* __restrict__ anchors, PropGeom g,
-                                                                        const int* __restrict__ cand_anchor,
-                                                                        const float* __restrict__ cand_score,
-                                                                        float* __restrict__ boxes /*(N,7)*/,
-                                                                        long long* __restrict__ batch_idx,
-                                                                        long long* __restrict__ class_idx,
-                                                                        int* __restrict__ order,
-                                                                        v3d::BoxPrep* __restrict__ prep) {
+__device__ __forceinline__ void prop_decode_sort_body(const float* __restrict__ maps, const float* __restrict__ anchors,
+                                                      const PropGeom& g, const int* cand_anchor, const float* cand_score,
+                                                      float* __restrict__ boxes /*(N,7)*/, long long* __restrict__ batch_idx,
+                                                      long long* __restrict__ class_idx, int* __restrict__ order,
+                                                      v3d::BoxPrep* __restrict__ prep) {
   __shared__ float red_hi[PROP_WAVES], red_lo[PROP_WAVES];
   __shared__ unsigned long long keys[PROP_THREADS];
   __shared__ float sbev[PROP_THREADS][5];
@@ -304,6 +327,26 @@ __global__ __launch_bounds__(PROP_THREADS) void prop_decode_sort_kernel(const fl
   __syncthreads();
   int npad = 1;
   while (npad < N) npad <<= 1;
+  if (npad <= PROP_RANK_SORT_MAX) {
+    // rank sort (distinct keys: the candidate index is part of the key): the place of candidate i is the number of smaller keys
+    __shared__ int place_s[PROP_RANK_SORT_MAX];
+    const int i = t & (npad - 1), part = t / npad, parts = PROP_THREADS / npad;
+    if (t < npad) place_s[t] = 0;
+    __syncthreads();
+    if (i < N) {
+      const unsigned long long mine = keys[i];
+      int cnt = 0;
+      for (int j = part; j < N; j += parts) cnt += keys[j] < mine ? 1 : 0;
+      if (cnt) atomicAdd(&place_s[i], cnt);
+    }
+    __syncthreads();
+    if (t < N) {
+      const int dst = place_s[t];  // candidate t is the dst-th of the sorted order
+      order[dst] = t;
+      prep[dst] = v3d::prep_box(sbev[t]);
+    }
+    return;
+  }
   for (int k = 2; k <= npad; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       if (t < npad) {
@@ -323,25 +366,53 @@ __global__ __launch_bounds__(PROP_THREADS) void prop_decode_sort_kernel(const fl
   }
 }
 
-// keep (sorted by score, from the NMS) -> ordered compaction of the rows that pass their class threshold
-__global__ __launch_bounds__(PROP_THREADS) void prop_finalize_kernel(const long long* __restrict__ keep,
-                                                                     const int* __restrict__ n_keep, PropGeom g,
-                                                                     const float* __restrict__ boxes,
-                                                                     const long long* __restrict__ batch_idx,
-                                                                     const long long* __restrict__ class_idx,
-                                                                     const float* __restrict__ scores,
-                                                                     float* __restrict__ out_boxes,
-                                                                     long long* __restrict__ out_batch,
-                                                                     long long* __restrict__ out_class,
-                                                                     float* __restrict__ out_scores,
-                                                                     int* __restrict__ n_out, const int* __restrict__ aux_flag) {
-  __shared__ int wave_cnt[PROP_WAVES];
+__global__ __launch_bounds__(PROP_THREADS) void prop_decode_sort_kernel(const float* __restrict__ maps,
+                                                                        const float* __restrict__ anchors, PropGeom g,
+                                                                        const int* __restrict__ cand_anchor,
+                                                                        const float* __restrict__ cand_score,
+                                                                        float* __restrict__ boxes, long long* __restrict__ batch_idx,
+                                                                        long long* __restrict__ class_idx, int* __restrict__ order,
+                                                                        v3d::BoxPrep* __restrict__ prep) {
+  prop_decode_sort_body(maps, anchors, g, cand_anchor, cand_score, boxes, batch_idx, class_idx, order, prep);
+}
+
+// Level-2 merge of every group AND the decode / sort / box prep in ONE workgroup (at most PROP_FUSE_GROUPS groups: the bs = 1
+// frame has one): the candidates go through global memory (a few hundred bytes, written and read by this workgroup with a
+// barrier in between) because the score cut of the last launch reads them again.
+#define PROP_FUSE_GROUPS 2
+__global__ __launch_bounds__(PROP_THREADS) void prop_merge_decode_sort_kernel(const float* __restrict__ part_score,
+                                                                              const int* __restrict__ part_idx, int chunks,
+                                                                              const float* __restrict__ maps,
+                                                                              const float* __restrict__ anchors, PropGeom g,
+                                                                              int* cand_anchor, float* cand_score,
+                                                                              float* __restrict__ boxes, long long* __restrict__ batch_idx,
+                                                                              long long* __restrict__ class_idx, int* __restrict__ order,
+                                                                              v3d::BoxPrep* __restrict__ prep) {
+  static_assert(SEL_THREADS == PROP_THREADS, "one workgroup runs both bodies");
+  const int groups = g.B * g.n_cls;
+  for (int grp = 0; grp < groups; grp++) {
+    const size_t o = (size_t)grp * chunks * g.topk;
+    prop_select<2, 4>(part_score + o, part_idx + o, chunks * g.topk, 0, g.topk, cand_score + (size_t)grp * g.topk,
+                      cand_anchor + (size_t)grp * g.topk);
+    __syncthreads();  // (also: the next group reuses the selection's LDS)
+  }
+  prop_decode_sort_body(maps, anchors, g, cand_anchor, cand_score, boxes, batch_idx, class_idx, order, prep);
+}
+
+// keep (sorted by score, from the NMS) -> ordered compaction of the rows that pass their class threshold (one workgroup)
+template <int THREADS>
+__device__ __forceinline__ void prop_finalize_body(const long long* keep, int nk, const PropGeom& g, const float* __restrict__ boxes,
+                                                   const long long* __restrict__ batch_idx, const long long* __restrict__ class_idx,
+                                                   const float* __restrict__ scores, float* __restrict__ out_boxes,
+                                                   long long* __restrict__ out_batch, long long* __restrict__ out_class,
+                                                   float* __restrict__ out_scores, int* __restrict__ n_out,
+                                                   const int* __restrict__ aux_flag) {
+  __shared__ int wave_cnt[THREADS / 64];
   __shared__ int base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nk = *n_keep;
   if (tid == 0) base = 0;
   __syncthreads();
-  for (int i0 = 0; i0 < nk; i0 += PROP_THREADS) {
+  for (int i0 = 0; i0 < nk; i0 += THREADS) {
     const int i = i0 + tid;
     long long j = 0;
     bool pass = false;
@@ -365,7 +436,7 @@ __global__ __launch_bounds__(PROP_THREADS) void prop_finalize_kernel(const long 
     __syncthreads();
     if (tid == 0) {
       int tot = 0;
-      for (int w = 0; w < PROP_WAVES; w++) tot += wave_cnt[w];
+      for (int w = 0; w < THREADS / 64; w++) tot += wave_cnt[w];
       base += tot;
     }
     __syncthreads();
@@ -374,6 +445,34 @@ __global__ __launch_bounds__(PROP_THREADS) void prop_finalize_kernel(const long 
     n_out[0] = base;
     if (aux_flag) n_out[1] = *aux_flag;  // rides in the caller's one host read of the frame (see v3d_proposals_flag)
   }
+}
+
+// Greedy NMS reduction + score cut in ONE launch (they were two single-workgroup launches with a global round trip per 64-box
+// block in between).  A mask of at most PROP_NMS_LDS_WORDS words is first copied into LDS in one parallel read -- the reduction's
+// dependent look-ups (diagonal word, kept rows) then never leave the CU; larger masks are reduced from global memory.
+#define PROP_NMS_THREADS 256
+#define PROP_NMS_LDS_WORDS 2048
+__global__ __launch_bounds__(PROP_NMS_THREADS) void prop_nms_reduce_finalize_kernel(
+    const unsigned long long* __restrict__ mask, const int* __restrict__ order, int N, unsigned long long* __restrict__ remv_g,
+    long long* keep, PropGeom g, const float* __restrict__ boxes, const long long* __restrict__ batch_idx,
+    const long long* __restrict__ class_idx, const float* __restrict__ scores, float* __restrict__ out_boxes,
+    long long* __restrict__ out_batch, long long* __restrict__ out_class, float* __restrict__ out_scores, int* __restrict__ n_out,
+    const int* __restrict__ aux_flag) {
+  __shared__ unsigned long long mask_s[PROP_NMS_LDS_WORDS];
+  __shared__ unsigned long long remv_s[64];
+  __shared__ unsigned long long kept_s;
+  __shared__ int nk_s;
+  const int nwords = (N + 63) / 64;
+  const bool in_lds = (long long)N * nwords <= PROP_NMS_LDS_WORDS && nwords <= 64;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < N * nwords; i += PROP_NMS_THREADS) mask_s[i] = (i % nwords) >= ((i / nwords) >> 6) ? mask[i] : 0ull;
+    __syncthreads();
+  }
+  const int nk = v3d::nms_greedy_reduce<PROP_NMS_THREADS>(in_lds ? mask_s : mask, order, N, nwords, in_lds ? remv_s : remv_g, keep,
+                                                          &kept_s, &nk_s);
+  // (keep[] was written by wave 0 of this workgroup; nms_greedy_reduce ends with a barrier)
+  prop_finalize_body<PROP_NMS_THREADS>(keep, nk, g, boxes, batch_idx, class_idx, scores, out_boxes, out_batch, out_class, out_scores,
+                                       n_out, aux_flag);
 }
 
 static size_t prop_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -438,22 +537,29 @@ extern "C" int v3d_proposals_flag(const float* head_maps, const float* anchors, 
   else
     hipLaunchKernelGGL(prop_topk_chunk_kernel<8>, dim3(chunks, B * n_cls), dim3(SEL_THREADS), 0, st, head_maps, g, chunk_len,
                        part_score, part_idx);
-  hipLaunchKernelGGL(prop_topk_merge_kernel, dim3(B * n_cls), dim3(SEL_THREADS), 0, st, part_score, part_idx, chunks, topk,
-                     cand_score, cand_anchor);
   if (N > PROP_THREADS) return V3D_EUNSUPPORTED;  // one workgroup decodes and sorts all candidates
   int* order = (int*)take(N * 4);
   v3d::BoxPrep* prep = (v3d::BoxPrep*)take(N * sizeof(v3d::BoxPrep));
-  hipLaunchKernelGGL(prop_decode_sort_kernel, dim3(1), dim3(PROP_THREADS), 0, st, head_maps, anchors, g, cand_anchor,
-                     cand_score, boxes, bidx, cidx, order, prep);
+  if (B * n_cls <= PROP_FUSE_GROUPS) {
+    hipLaunchKernelGGL(prop_merge_decode_sort_kernel, dim3(1), dim3(PROP_THREADS), 0, st, part_score, part_idx, chunks, head_maps,
+                       anchors, g, cand_anchor, cand_score, boxes, bidx, cidx, order, prep);
+  } else {
+    hipLaunchKernelGGL(prop_topk_merge_kernel, dim3(B * n_cls), dim3(SEL_THREADS), 0, st, part_score, part_idx, chunks, topk,
+                       cand_score, cand_anchor);
+    hipLaunchKernelGGL(prop_decode_sort_kernel, dim3(1), dim3(PROP_THREADS), 0, st, head_maps, anchors, g, cand_anchor,
+                       cand_score, boxes, bidx, cidx, order, prep);
+  }
   {
     const size_t nwords = (N + 63) / 64;
     unsigned long long* mask = (unsigned long long*)nms_ws;  // N*nwords + nwords words <= v3d_nms_rotated_workspace(N)
-    const int rc = v3d_i_nms_sorted(prep, order, (int)N, iou_threshold, (int64_t*)keep, n_keep, mask, mask + N * nwords, st);
+    const int rc = v3d_i_nms_mask_sorted(prep, (int)N, iou_threshold, mask, st);
     if (rc != V3D_OK) return rc;
+    hipLaunchKernelGGL(prop_nms_reduce_finalize_kernel, dim3(1), dim3(PROP_NMS_THREADS), 0, st, mask, order, (int)N, mask + N * nwords,
+                       keep, g, boxes, bidx, cidx, cand_score, out_boxes, (long long*)out_batch_idx, (long long*)out_class_idx,
+                       out_scores, n_out, aux_flag);
   }
   (void)bev;
-  hipLaunchKernelGGL(prop_finalize_kernel, dim3(1), dim3(PROP_THREADS), 0, st, keep, n_keep, g, boxes, bidx, cidx, cand_score,
-                     out_boxes, (long long*)out_batch_idx, (long long*)out_class_idx, out_scores, n_out, aux_flag);
+  (void)n_keep;
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }

@@ -947,8 +947,14 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __res
 
 // STAGE = 1 (see spconv_fwd_rows_kouter): gathered rows fetched row-contiguous by LDS-DMA into ALOOK 4 KB slots per multiplying
 // wave, MFMA fragments read back from LDS.
-template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int DBG = 0>  // DBG (experiments, wrong results): 1 no gathers, 2 no weight DMA, 3 neither
-__global__ __launch_bounds__((2 * OG + NMV) * 64) void spconv_fwd_rows_ring(const float* __restrict__ in,
+// TILES = 16-row tiles per workgroup (2, 3 or 4 -> 32 / 48 / 64 rows, TILES * OG multiplying waves).  One 64 -> 64 workgroup
+// fills a CU's LDS, so a layer runs in ROUNDS of 256 workgroups: 8 160 live rows are 255 two-tile workgroups, but 8 300 rows are
+// 260 -- a second round for 4 workgroups, 20 us instead of 10 (round 4 trace: every KITTI frame but the one the kernel was tuned on
+// sat just above 8 192 rows in its three stage-2 layers).  More tiles per workgroup share the same weight rounds (the movers' work
+// does not grow) and put up to 16 waves on the CU, whose matrix pipes idle half of a two-tile round: the caller picks the smallest
+// TILES that keeps the expected row count inside ONE round.
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int DBG = 0, int TILES = 2>  // DBG (experiments, wrong results): 1 no gathers, 2 no weight DMA, 3 neither
+__global__ __launch_bounds__((TILES * OG + NMV) * 64) void spconv_fwd_rows_ring(const float* __restrict__ in,
                                                                           const unsigned short* __restrict__ wimg,
                                                                           const int* __restrict__ nbr,
                                                                           const int* __restrict__ n_ptr, int cap,
@@ -961,7 +967,7 @@ __global__ __launch_bounds__((2 * OG + NMV) * 64) void spconv_fwd_rows_ring(cons
   // is mostly its barrier and the LDS read burst behind it, not the matrix pipe, so fewer, longer rounds win.  Also
   // tried and dropped: splitting (R, ki+1) while the MFMAs of (R, ki) run, with and without sched_group_barrier
   // interleave (12.9 / 13.2 us).  Only OG = 3 is instantiated.
-  constexpr int K = 27, TILES = 2, ROUNDS = (K + OG - 1) / OG, NCW = TILES * OG;
+  constexpr int K = 27, ROUNDS = (K + OG - 1) / OG, NCW = TILES * OG;
   constexpr int LOOK = NBUF - 1;  // rounds of weights in flight ahead of the multiply
   constexpr int ABUF = ALOOK + 1;  // ALOOK rounds of gathered rows in flight ahead of the multiply (registers)
   constexpr int KI = CIN / 32, NB = COUT / 16;
@@ -1190,11 +1196,11 @@ __global__ __launch_bounds__((2 * OG + NMV) * 64) void spconv_fwd_rows_ring(cons
 #undef SPR_RING
 }
 
-template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int DBG = 0>
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int DBG = 0, int TILES = 2>
 static int launch_rows_ring(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
                             const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
-  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, DBG>), dim3(v3d_ceil_div(cap, 32)), dim3((2 * OG + NMV) * 64), 0, st, in,
-                       (const unsigned short*)wimg, nbr, n_ptr, cap, scale, shift, relu, out);
+  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, DBG, TILES>), dim3(v3d_ceil_div(cap, 16 * TILES)),
+                     dim3((TILES * OG + NMV) * 64), 0, st, in, (const unsigned short*)wimg, nbr, n_ptr, cap, scale, shift, relu, out);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -1255,7 +1261,7 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
     // layers): 64->64 rows staged through LDS, one slot, 2 weight buffers, 4 movers (11.2 -> 9.9 us at 8 160 rows); 32->32 staged,
     // two slots, 2 movers (8.4 -> 7.4 us at 13 731 rows); 32->64 / 64->32 register gathers, 3 weight buffers (7.2 us; staged 7.6-8.3).
     // 16 = the register-gather form for every shape (cross-check).
-    if (K == 27 && (force == 10 || force == 16 || (force == 0 && rows_hint <= V3D_RING_ROWS))) {
+    if (K == 27 && (force == 10 || force == 16 || (force >= 12 && force <= 14) || (force == 0 && rows_hint <= V3D_RING_ROWS))) {
 #ifdef V3D_EXPERIMENTS
       static const int ring_form = [] { const char* e = getenv("V3D_RING_REGS"); return e ? atoi(e) : 0; }();  // A/B in whole-frame runs
       // ablations inside the whole frame (results wrong by construction; tools/ring_dbg_in_frame.sh): 1 no gathers, 2 no weight
@@ -1273,7 +1279,18 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
       // (measured and not kept: two offsets per round + two weight buffers + register gathers = 69 KB of LDS at 64 -> 64, so that
       // two such workgroups -- the same layer of another frame in flight -- or one and an 80-pixel dense tile could share a CU:
       // 12.9 vs 10.0 us in isolation and 3 121 vs 3 306 frames/s pipelined)
-      if (force != 16 && CIN == 64 && COUT == 64) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+      if constexpr (CIN == 64 && COUT == 64) {
+        if (force != 16) {
+          // one LDS-filling workgroup per CU: keep the layer inside ONE round of 256 workgroups.  The live count is device-side and
+          // moves from frame to frame (KITTI stage 2: 8 100 - 8 700 rows), so the tile count is picked with 10 % of headroom over
+          // the count the plan was tuned on; force 12 / 13 / 14 pin the 2 / 3 / 4-tile form (tests, microbenchmarks)
+          const long long want = force ? 0 : (long long)rows_hint + rows_hint / 10;
+          const int tiles = force == 12 ? 2 : force == 13 ? 3 : force == 14 ? 4 : (want <= 32 * 256 ? 2 : want <= 48 * 256 ? 3 : 4);
+          if (tiles == 2) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 0, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+          if (tiles == 3) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 0, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+          return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 0, 4>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+        }
+      }
       if (force != 16 && CIN == 32 && COUT == 32) return launch_rows_ring<CIN, COUT, 3, 2, 2, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
       return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
     }

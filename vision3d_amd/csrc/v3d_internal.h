@@ -50,6 +50,8 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
 int v3d_i_nms_sorted(const void* prep_sorted, const int* order, int N, float iou_threshold, int64_t* keep, int32_t* n_keep,
                      unsigned long long* mask, unsigned long long* remv, hipStream_t st);
 
+int v3d_i_nms_mask_sorted(const void* prep_sorted, int N, float iou_threshold, unsigned long long* mask, hipStream_t st);
+
 // spconv.hip: v3d_sparse_conv_fwd_packed with an explicit estimate of the live row count (kernel choice only)
 int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                  int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
