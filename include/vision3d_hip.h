@@ -304,6 +304,12 @@ size_t v3d_bev_occupancy_words(int B, int H, int W);
 int v3d_bev_occupancy_bits(const int32_t* coords /*(cap,4) b,z,y,x*/, const int32_t* n, int cap, int B, int H, int W,
                            uint32_t* occ, v3d_stream_t stream);
 uint32_t* v3d_backbone_bev_occupancy(v3d_backbone* plan);
+/* The plan's PERSISTENT split BEV planes ((max_batch, H, W, C_out * D) bf16 each, hi then lo, adjacent).  Passing exactly these two
+ * pointers as dense_hi / dense_lo to v3d_backbone_forward2 / _forward_voxels / _forward_reuse makes the plan keep them zero outside
+ * the occupied pixels itself: each frame clears the few thousand pixels the previous one wrote (in the launch of its per-frame fill)
+ * instead of filling 2 x 9 MB per KITTI frame -- what .dense() (detector/sparse_cnn.py:128-133: zeros + scatter) costs.  Valid until the
+ * next forward into them; nobody else may write them. */
+int v3d_backbone_bev_planes(v3d_backbone* plan, void** hi, void** lo);
 int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias, int relu, int B,
                               int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo, float* y_nchw,
                               const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo,

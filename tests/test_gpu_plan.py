@@ -171,3 +171,27 @@ def test_graph_capacity_accepts_shorter_frames():
                 np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
         with pytest.raises(RuntimeError, match="capacity"):
             run([torch.from_numpy(synth.make_cloud(1)).cuda(), torch.from_numpy(synth.make_cloud(2)[:10241]).cuda()])
+
+
+def test_persistent_bev_planes_equal_fresh_planes_over_a_sequence_of_frames():
+    """forward_split(persistent=True): the plan's own BEV planes, where a frame zeroes only the pixels the previous frame wrote
+    (no fill of the map) -- bit-identical to freshly zeroed planes for every frame of a sequence that alternates dense, sparse,
+    empty-ish and repeated frames, batch 2 (also through the prebuilt-rulebook timing variant)."""
+    model = build_model(3)
+    frames = [[synth.make_cloud(1), synth.make_cloud(2)[:9000]], [synth.make_cloud(3)[:700], synth.make_cloud(4)],
+              [synth.make_cloud(5)[:40], synth.make_cloud(6)[:3]], [synth.make_cloud(1), synth.make_cloud(2)[:9000]],
+              [synth.make_cloud(7), synth.make_cloud(8)]]
+    with torch.no_grad():
+        for k, frame in enumerate(frames):
+            clouds = [torch.from_numpy(c).cuda() for c in frame]
+            plan, flat, offsets = model._plan_for(clouds)
+            hi, lo = plan.forward_split(flat, offsets)
+            fresh = (hi.clone(), lo.clone())
+            phi, plo = plan.forward_split(flat, offsets, persistent=True)
+            assert phi.data_ptr() == plan.own_planes(2)[0].data_ptr()
+            assert torch.equal(phi, fresh[0]) and torch.equal(plo, fresh[1]), f"frame {k}"
+            if k == 1:  # the timing variant into the same planes: clear + rewrite of the same pixels
+                rhi, rlo = plan.own_planes(2)
+                from vision3d_amd import _lib as L
+                L.check(L.lib().v3d_backbone_forward_reuse(plan._handle, 2, 0, L.ptr(rhi), L.ptr(rlo), L.stream_ptr()), "reuse")
+                assert torch.equal(rhi, fresh[0]) and torch.equal(rlo, fresh[1])

@@ -13,8 +13,9 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     want = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-    # a frame starts at its per-frame 0xFF fill that is followed by vox_insert (the graph's first two kernels)
-    starts = [i for i in range(len(ev) - 1) if ev[i][2].startswith("v3d_fill_kernel") and ev[i + 1][2].startswith("vox_")]
+    # a frame starts at the kernel in front of vox_insert: its per-frame fill (v3d_fill_kernel / plan_frame_start_kernel), the
+    # graph's first node
+    starts = [i for i in range(len(ev) - 1) if ev[i + 1][2].startswith("vox_insert") and "fill" in ev[i][2] + "fill" * ev[i][2].startswith("plan_frame_start")]
     frames = [ev[a:b] for a, b in zip(starts[:-1], starts[1:])]
     if not frames:
         print("no frames found")

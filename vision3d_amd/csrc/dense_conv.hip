@@ -105,14 +105,18 @@ __global__ __launch_bounds__(V3D_BLOCK) void densify_split_kernel(const float* _
                                                                   const int4* __restrict__ coords,
                                                                   const int* __restrict__ n_ptr, int cap, int C, int D,
                                                                   int H, int Wd, bf16_t* __restrict__ hi,
-                                                                  bf16_t* __restrict__ lo, unsigned* __restrict__ occ) {
+                                                                  bf16_t* __restrict__ lo, unsigned* __restrict__ occ,
+                                                                  int* __restrict__ written_pix, int* __restrict__ written_n) {
   const int n = min(*n_ptr, cap);
   const long long total = (long long)n * C;
+  if (written_n && blockIdx.x == 0 && threadIdx.x == 0) *written_n = n;
   for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * V3D_BLOCK) {
     const int i = (int)(t / C), ch = (int)(t % C);
     const int4 c = coords[i];
     if (occ && ch == 0)  // the occupancy bitmap of the background-skipping head rides along (inverted bits, see bev_occupancy_kernel)
       atomicAnd(occ + ((size_t)c.x * H + c.z) * ((Wd + 31) >> 5) + (c.w >> 5), ~(1u << (c.w & 31)));
+    // PERSISTENT planes (second_plan.hip): the pixels this frame writes, so that the next frame zeroes exactly those
+    if (written_pix && ch == 0) written_pix[i] = (c.x * H + c.z) * Wd + c.w;
     const size_t o = (((size_t)c.x * H + c.z) * Wd + c.w) * ((size_t)C * D) + (size_t)ch * D + c.y;
     bf16_t h, l;
     split_bf16(feat[t], h, l);
@@ -127,13 +131,41 @@ extern "C" int v3d_densify_nhwc_split(const float* feat, const int32_t* coords, 
   return v3d_i_densify_nhwc_split(feat, coords, n, cap, B, C, spatial_shape_host, out_hi, out_lo, nullptr, (hipStream_t)stream);
 }
 
+// Zero the pixels a list names in both planes (16-byte stores): the start-of-frame job of a plan's PERSISTENT BEV planes.
+__global__ __launch_bounds__(V3D_BLOCK) void bev_clear_pixels_kernel(const int* __restrict__ pix, const int* __restrict__ n_ptr, int cap,
+                                                                     int units /*16-byte units per pixel and plane*/,
+                                                                     uint4* __restrict__ hi, uint4* __restrict__ lo) {
+  const long long total = (long long)min(*n_ptr, cap) * units;
+  for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * V3D_BLOCK) {
+    const size_t o = (size_t)pix[t / units] * units + (size_t)(t % units);
+    hi[o] = make_uint4(0u, 0u, 0u, 0u);
+    lo[o] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+int v3d_i_bev_clear_pixels(const int32_t* pix, const int32_t* n, int cap, int channels, void* hi, void* lo, hipStream_t st) {
+  if (!pix || !n || cap < 1 || channels < 8 || channels % 8 || !hi || !lo) return V3D_EINVAL;
+  const int units = channels / 8;
+  const long long total = (long long)cap * units;
+  hipLaunchKernelGGL(bev_clear_pixels_kernel, dim3((int)std::min<long long>(v3d_ceil_div(total, V3D_BLOCK), 2048)), dim3(V3D_BLOCK), 0, st,
+                     pix, n, cap, units, (uint4*)hi, (uint4*)lo);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 // occ_inv (nullable): inverted occupancy bitmap, ALREADY filled with 0xFF by the caller; bits of the occupied pixels are cleared
+// written_pix / written_n (nullable, together): the planes are PERSISTENT and already zero outside the pixels the caller has just
+// cleared (v3d_i_bev_clear_pixels on the list the previous call left here): no fill, and this call's pixel list is left behind.
 int v3d_i_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
-                             const int32_t* spatial_shape_host, void* out_hi, void* out_lo, uint32_t* occ_inv, hipStream_t st) {
+                             const int32_t* spatial_shape_host, void* out_hi, void* out_lo, uint32_t* occ_inv, hipStream_t st,
+                             int32_t* written_pix, int32_t* written_n) {
   if (!feat || !coords || !n || cap < 1 || B < 1 || C < 1 || !spatial_shape_host || !out_hi || !out_lo) return V3D_EINVAL;
+  if ((written_pix == nullptr) != (written_n == nullptr)) return V3D_EINVAL;
   const int D = spatial_shape_host[0], H = spatial_shape_host[1], Wd = spatial_shape_host[2];
   const size_t bytes = (size_t)B * H * Wd * C * D * sizeof(bf16_t);
-  if ((char*)out_lo == (char*)out_hi + bytes) {  // planes allocated back to back: one launch
+  if (written_pix) {
+    // (nothing to fill)
+  } else if ((char*)out_lo == (char*)out_hi + bytes) {  // planes allocated back to back: one launch
     V3D_CHECK_HIP(v3d_fill_async(out_hi, 0, 2 * bytes, st));
   } else {
     V3D_CHECK_HIP(v3d_fill_async(out_hi, 0, bytes, st));
@@ -142,7 +174,7 @@ int v3d_i_densify_nhwc_split(const float* feat, const int32_t* coords, const int
   const long long total = (long long)cap * C;
   const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
   hipLaunchKernelGGL(densify_split_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(V3D_BLOCK), 0, st, feat,
-                     (const int4*)coords, n, cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo, occ_inv);
+                     (const int4*)coords, n, cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo, occ_inv, written_pix, written_n);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }

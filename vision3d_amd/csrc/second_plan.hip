@@ -66,6 +66,11 @@ struct v3d_backbone {
   size_t ff_bytes = 0;
   int out_channels = 0;
   uint32_t* bev_occ = nullptr;  // (max_batch * H, ceil(W / 32)) inverted occupancy bits of the last stage (in the 0xFF region)
+  // PERSISTENT split BEV planes (v3d_backbone_bev_planes): zero everywhere but the pixels of the last frame written into them, which
+  // that frame's densify kernel listed in bev_pix -- the next frame clears exactly those (a few thousand 256-byte rows instead of
+  // an 18 MB fill per KITTI frame) before it writes its own.
+  void *bev_hi = nullptr, *bev_lo = nullptr;
+  int32_t *bev_pix = nullptr, *bev_pix_n = nullptr;
   struct PlanTrain* train = nullptr;  // training buffers, allocated by the first v3d_backbone_train_forward
   // The rulebook chain only depends on COORDINATES: the inference forward runs it on a second stream, ahead of the convolutions
   // (which wait, per rulebook, for the event recorded behind its builder).  Captured into a HIP graph this becomes a fork / join.
@@ -206,6 +211,14 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       st.coords = ar.take<int32_t>((size_t)st.cap * 4);
       st.n_dev = ar.take<int32_t>(1);
     }
+    {
+      const PlanStage& sl = p->stages.back();
+      const size_t plane = (size_t)cfg->max_batch * sl.shape[0] * sl.shape[1] * sl.shape[2] * p->out_channels * 2;  // bf16
+      p->bev_hi = ar.take<char>(plane);
+      p->bev_lo = ar.take<char>(plane);
+      p->bev_pix = ar.take<int32_t>(sl.cap);
+      p->bev_pix_n = ar.take<int32_t>(1);
+    }
     p->cand_slot[0] = ar.take<int>((size_t)max_tickets);
     p->cand_slot[1] = ar.take<int>((size_t)max_tickets);
     for (auto& L : p->layers) {
@@ -227,6 +240,8 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
   carve(ar);
   if (!ar.ok()) { (void)hipFree(p->arena); delete p; return V3D_EWORKSPACE; }
   e = hipMemset(p->ff_begin, 0xFF, p->ff_bytes);
+  if (e == hipSuccess) e = hipMemset(p->bev_hi, 0, (size_t)((char*)p->bev_lo - (char*)p->bev_hi) * 2);  // the planes are adjacent
+  if (e == hipSuccess) e = hipMemset(p->bev_pix_n, 0, sizeof(int32_t));
   if (e != hipSuccess) { (void)hipFree(p->arena); delete p; return (int)e; }
   // Opt-in (V3D_RB_FORK=1).  Measured on the KITTI frame inside the HIP graph: the fork / join turns into cross-queue barrier
   // packets that cost more than the overlap returns -- headline 3 209 -> 2 526 frames/s with frames pipelined.
@@ -288,6 +303,71 @@ extern "C" int v3d_backbone_forward(v3d_backbone* p, const float* points, int n_
 static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense_out, void* dense_hi, void* dense_lo,
                            hipStream_t st, bool reuse_rulebooks = false);
 
+// Start of a frame: the 0xFF fill of the plan's per-frame region and -- when the caller asked for the plan's OWN persistent planes
+// -- the zeroing of the pixels the previous frame wrote, in ONE launch (the clear rides in the fill's launch, a dozen launches
+// ahead of the densify kernel that needs it).
+__global__ __launch_bounds__(256) void plan_frame_start_kernel(uint4* __restrict__ ff, size_t nvec, int fill_blocks,
+                                                               const int* __restrict__ pix, const int* __restrict__ n_ptr, int cap,
+                                                               int units, uint4* __restrict__ hi, uint4* __restrict__ lo) {
+  if ((int)blockIdx.x < fill_blocks) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)fill_blocks * 256)
+      ff[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    return;
+  }
+  const long long total = (long long)min(*n_ptr, cap) * units;
+  const int nb = gridDim.x - fill_blocks;
+  for (long long t = (long long)(blockIdx.x - fill_blocks) * 256 + threadIdx.x; t < total; t += (long long)nb * 256) {
+    const size_t o = (size_t)pix[t / units] * units + (size_t)(t % units);
+    hi[o] = make_uint4(0u, 0u, 0u, 0u);
+    lo[o] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+static int plan_own_planes(v3d_backbone* p, void* dense_hi, void* dense_lo, bool& own) {
+  own = false;
+  if (!dense_hi && !dense_lo) return V3D_OK;
+  if ((dense_hi == p->bev_hi) != (dense_lo == p->bev_lo)) return V3D_EINVAL;  // both planes of the plan, or neither
+  own = dense_hi == p->bev_hi;
+  return V3D_OK;
+}
+
+static int plan_frame_start(v3d_backbone* p, void* dense_hi, void* dense_lo, hipStream_t st) {
+  bool own;
+  int rc = plan_own_planes(p, dense_hi, dense_lo, own);
+  if (rc) return rc;
+  if (!own || (p->ff_bytes & 15) || ((uintptr_t)p->ff_begin & 15)) {
+    V3D_CHECK_HIP(v3d_fill_async(p->ff_begin, 0xFF, p->ff_bytes, st));  // all hash tables, count slots, flags, the occupancy bitmap
+    if (!own) return V3D_OK;
+    const PlanStage& sl = p->stages.back();
+    return v3d_i_bev_clear_pixels(p->bev_pix, p->bev_pix_n, sl.cap, p->out_channels * sl.shape[0], p->bev_hi, p->bev_lo, st);
+  }
+  const PlanStage& sl = p->stages.back();
+  const int units = p->out_channels * sl.shape[0] / 8;
+  const size_t nvec = p->ff_bytes / 16;
+  const int fill_blocks = (int)std::min<size_t>((nvec + 255) / 256, 4096);
+  const int clear_blocks = (int)std::min<long long>(v3d_ceil_div((long long)sl.cap * units, 256), 1024);
+  hipLaunchKernelGGL(plan_frame_start_kernel, dim3(fill_blocks + clear_blocks), dim3(256), 0, st, (uint4*)p->ff_begin, nvec, fill_blocks,
+                     p->bev_pix, p->bev_pix_n, sl.cap, units, (uint4*)p->bev_hi, (uint4*)p->bev_lo);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+// (timing variant without a per-frame fill: only the planes' clear)
+static int plan_clear_own_planes(v3d_backbone* p, void* dense_hi, void* dense_lo, hipStream_t st) {
+  bool own;
+  int rc = plan_own_planes(p, dense_hi, dense_lo, own);
+  if (rc || !own) return rc;
+  const PlanStage& sl = p->stages.back();
+  return v3d_i_bev_clear_pixels(p->bev_pix, p->bev_pix_n, sl.cap, p->out_channels * sl.shape[0], p->bev_hi, p->bev_lo, st);
+}
+
+extern "C" int v3d_backbone_bev_planes(v3d_backbone* p, void** hi, void** lo) {
+  if (!p || !hi || !lo) return V3D_EINVAL;
+  *hi = p->bev_hi;
+  *lo = p->bev_lo;
+  return V3D_OK;
+}
+
 extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n_points,
                                      const int32_t* frame_offsets_host, int B, float* dense_out, void* dense_hi,
                                      void* dense_lo, v3d_stream_t stream) {
@@ -296,7 +376,10 @@ extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n
   hipStream_t st = (hipStream_t)stream;
   const v3d_backbone_config& c = p->cfg;
   PlanStage& s0 = p->stages[0];
-  V3D_CHECK_HIP(v3d_fill_async(p->ff_begin, 0xFF, p->ff_bytes, st));  // all hash tables, strided nbr tables, flags
+  {
+    const int rcc = plan_frame_start(p, dense_hi, dense_lo, st);
+    if (rcc) return rcc;
+  }
   // the voxelizer also fills stage 0's coordinate hash (what rb_hash_build would do in a launch of its own)
   const bool vox_hash = !p->layers.empty() && p->layers[0].d.subm && p->layers[0].builds_rulebook;
   int rc = v3d_i_voxelize(points, n_points, c.point_channels, frame_offsets_host, B, c.voxel_size, c.bounds, c.max_pts,
@@ -311,6 +394,10 @@ extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n
 extern "C" int v3d_backbone_forward_reuse(v3d_backbone* p, int B, float* dense_out, void* dense_hi, void* dense_lo,
                                           v3d_stream_t stream) {
   if (!p || B < 1 || B > p->cfg.max_batch) return V3D_EINVAL;
+  {
+    const int rcc = plan_clear_own_planes(p, dense_hi, dense_lo, (hipStream_t)stream);
+    if (rcc) return rcc;
+  }
   return plan_run_layers(p, B, true, dense_out, dense_hi, dense_lo, (hipStream_t)stream, true);
 }
 
@@ -324,7 +411,10 @@ extern "C" int v3d_backbone_forward_voxels(v3d_backbone* p, const float* voxel_m
     return V3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   PlanStage& s0 = p->stages[0];
-  V3D_CHECK_HIP(v3d_fill_async(p->ff_begin, 0xFF, p->ff_bytes, st));
+  {
+    const int rcc = plan_frame_start(p, dense_hi, dense_lo, st);
+    if (rcc) return rcc;
+  }
   if (n_voxels > 0) {
     V3D_CHECK_HIP(hipMemcpyAsync(s0.coords, coords, (size_t)n_voxels * 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     V3D_CHECK_HIP(hipMemcpyAsync(p->mean, voxel_mean, (size_t)n_voxels * p->cfg.point_channels * sizeof(float),
@@ -452,8 +542,9 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
   }
   if (dense_hi || dense_lo) {
     PlanStage& sl = p->stages.back();
+    const bool own = dense_hi == p->bev_hi && dense_lo == p->bev_lo;  // (plan_clear_own_planes ran at the start of this frame)
     rc = v3d_i_densify_nhwc_split(feat, sl.coords, sl.n_dev, sl.cap, B, p->out_channels, sl.shape, dense_hi, dense_lo, p->bev_occ,
-                                  st);
+                                  st, own ? p->bev_pix : nullptr, own ? p->bev_pix_n : nullptr);
     if (rc) return rc;
   }
   return V3D_OK;

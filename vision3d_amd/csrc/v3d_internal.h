@@ -80,4 +80,8 @@ int v3d_i_sparse_bn_relu_bwd(const float* x, const float* dy, int n, const int32
 // dense_conv.hip: v3d_densify_nhwc_split that also clears the bits of the occupied pixels in an inverted BEV occupancy bitmap
 // (pre-filled with 0xFF by the caller): the input of the background-skipping dense head.
 int v3d_i_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
-                             const int32_t* spatial_shape_host, void* out_hi, void* out_lo, uint32_t* occ_inv, hipStream_t st);
+                             const int32_t* spatial_shape_host, void* out_hi, void* out_lo, uint32_t* occ_inv, hipStream_t st,
+                             int32_t* written_pix = nullptr /*with written_n: PERSISTENT planes -- no fill, the written pixels are listed*/,
+                             int32_t* written_n = nullptr);
+// zero the listed pixels (channels bf16 values each) of both planes: start-of-frame job of persistent BEV planes
+int v3d_i_bev_clear_pixels(const int32_t* pix, const int32_t* n, int cap, int channels, void* hi, void* lo, hipStream_t st);

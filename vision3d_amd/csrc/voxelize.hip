@@ -8,12 +8,13 @@
 //   K1 insert : every point inserts its linear voxel key into a hash table; per slot an
 //               atomicMin keeps the smallest point index (the "first toucher") and an atomicExch
 //               threads the point onto the slot's linked list.
-//   K2 count  : flag[i] = "point i is the first toucher of its voxel"; per-2048-chunk popcounts
+//   K2 count  : flag[i] = "point i is the first toucher of its voxel"; per-256-chunk popcounts
 //               (wave64 ballots).
 //   K3 scan   : exclusive scan of the chunk counts (+ per-frame voxel bases, for max_voxels).
 //   K4 emit   : rank of a first toucher (chunk offset + ballot prefix) == voxel id of the
 //               sequential loop.  The same thread walks its voxel's list, keeps the max_pts smallest
 //               point indices (== first-come order), writes coords/occupancy/points and the mean.
+//   (K2 + K3 share a launch; for ONE frame K2 + K3 + K4 are a single-pass chained scan in one launch.)
 // No host synchronisation: the voxel count stays in device memory.
 #include "v3d_internal.h"
 
@@ -129,31 +130,52 @@ __global__ __launch_bounds__(V3D_BLOCK) void vox_count_scan_kernel(const int* __
   }
 }
 
+// CHAINED (one frame, B == 1): count, scan and emit in ONE launch -- every block counts the first touchers of its chunk, PUBLISHES the
+// count (chunk_offsets reads -1 at launch: part of the frame's 0xFF fill), adds up the counts of all its predecessors (spinning on
+// slots that still read -1: workgroups are dispatched in index order and publish before they wait, so every wait is on a block that
+// is running or done) and emits at prefix + rank; the highest-index block writes the voxel count.  The same single-pass chained
+// scan as rb_scan_emit_kernel (rulebook.hip); replaces vox_count_scan_kernel + this kernel's unchained form, which stay for
+// batches (B > 1: the per-frame bases need every earlier frame's total).
+template <bool CHAINED>
 __global__ __launch_bounds__(V3D_BLOCK) void vox_emit_kernel(const float* __restrict__ pts, const VoxParams p,
                                                              const int* __restrict__ pt_slot,
                                                              const unsigned* __restrict__ first,
                                                              const int* __restrict__ head, const int* __restrict__ next,
-                                                             const int* __restrict__ chunk_offsets,
+                                                             int* __restrict__ chunk_offsets,
                                                              const int* __restrict__ frame_base,
                                                              const int* __restrict__ out_base,
                                                              float* __restrict__ voxels, int* __restrict__ coords,
                                                              int* __restrict__ occupancy, float* __restrict__ mean,
                                                              const V3dHash site_hash, int* __restrict__ site_vals,
-                                                             int site_d, int site_h, int site_w) {
+                                                             int site_d, int site_h, int site_w, int* __restrict__ n_voxels) {
   __shared__ int lds[4];
+  static_assert(VOX_CHUNK == V3D_BLOCK, "one round per block");
   const int base = blockIdx.x * VOX_CHUNK;
-  int running = chunk_offsets[blockIdx.x];
+  int running = CHAINED ? 0 : chunk_offsets[blockIdx.x];
   for (int r = 0; r < VOX_CHUNK / V3D_BLOCK; r++) {
     const int i = base + r * V3D_BLOCK + threadIdx.x;
     const bool flag = vox_is_first(pt_slot, first, i, p.n_points);
     int tot;
-    const int rank = running + v3d_block_rank(flag, tot, lds);
+    int rank = running + v3d_block_rank(flag, tot, lds);
     running += tot;
+    if constexpr (CHAINED) {
+      __shared__ int s_part[V3D_BLOCK / V3D_WAVE];
+      if (threadIdx.x == 0) v3d_publish_count(chunk_offsets + blockIdx.x, tot);
+      int part = 0;
+      for (int c = threadIdx.x; c < (int)blockIdx.x; c += V3D_BLOCK) part += v3d_wait_count(chunk_offsets + c);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+      if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+      __syncthreads();
+      const int prefix = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+      rank += prefix;
+      if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_voxels = min(prefix + tot, p.max_voxels);
+    }
     if (!flag) continue;
-    const int b = frame_of(p, i);
-    const int local = rank - frame_base[b];
+    const int b = CHAINED ? 0 : frame_of(p, i);
+    const int local = CHAINED ? rank : rank - frame_base[b];
     if (local >= p.max_voxels) continue;  // `continue` variant of the max_voxels rule
-    const int v = out_base[b] + local;
+    const int v = CHAINED ? local : out_base[b] + local;
     // voxel coordinates from the first toucher itself
     const float* q = pts + (size_t)i * p.C;
     int c[3];
@@ -287,13 +309,18 @@ int v3d_i_voxelize(const float* points, int n_points, int C, const int32_t* fram
   const int ins_blocks = min(v3d_ceil_div(n_points, V3D_BLOCK), 2048);
   hipLaunchKernelGGL(vox_insert_kernel, dim3(ins_blocks), dim3(V3D_BLOCK), 0, st, points, p, h, first, head, pt_slot,
                      next);
-  hipLaunchKernelGGL(vox_count_scan_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, pt_slot, first, p, chunk_counts, chunks,
-                     frame_base, out_base, n_voxels);
   V3dHash sh = v3d_make_hash(site_hash ? site_hash->keys : keys, site_hash ? site_hash->hcap : cap);
-  hipLaunchKernelGGL(vox_emit_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, points, p, pt_slot, first, head, next,
-                     chunk_counts, frame_base, out_base, voxels, coords, occupancy, mean, sh,
-                     (site_hash && site_shape) ? site_hash->vals : (int*)nullptr, site_shape ? site_shape[0] : 0,
-                     site_shape ? site_shape[1] : 0, site_shape ? site_shape[2] : 0);
+  int* site_vals = (site_hash && site_shape) ? site_hash->vals : (int*)nullptr;
+  const int sd = site_shape ? site_shape[0] : 0, shh = site_shape ? site_shape[1] : 0, sw = site_shape ? site_shape[2] : 0;
+  if (B == 1) {  // one frame: count + scan + emit as a single-pass chained scan, 2 launches per voxelization instead of 3
+    hipLaunchKernelGGL(vox_emit_kernel<true>, dim3(chunks), dim3(V3D_BLOCK), 0, st, points, p, pt_slot, first, head, next,
+                       chunk_counts, frame_base, out_base, voxels, coords, occupancy, mean, sh, site_vals, sd, shh, sw, n_voxels);
+  } else {
+    hipLaunchKernelGGL(vox_count_scan_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, pt_slot, first, p, chunk_counts, chunks,
+                       frame_base, out_base, n_voxels);
+    hipLaunchKernelGGL(vox_emit_kernel<false>, dim3(chunks), dim3(V3D_BLOCK), 0, st, points, p, pt_slot, first, head, next,
+                       chunk_counts, frame_base, out_base, voxels, coords, occupancy, mean, sh, site_vals, sd, shh, sw, n_voxels);
+  }
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }

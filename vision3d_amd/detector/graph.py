@@ -52,7 +52,8 @@ class GraphedSecond(object):
             self.outputs = self._body()
 
     def _body(self):
-        hi, lo = self.plan.forward_split(self.static_points, self.offsets)
+        # (the slot's plan keeps its own BEV planes: a frame clears the pixels the previous one wrote, no 18 MB fill)
+        hi, lo = self.plan.forward_split(self.static_points, self.offsets, persistent=True)
         head = self.model.head
         maps = self.dense.forward(hi, lo, occ=self.plan.bev_occupancy(len(self.offsets) - 1) if self.model.skip_background else None,
                                   work=self.work)

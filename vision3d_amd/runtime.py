@@ -162,19 +162,31 @@ class BackbonePlan(object):
             return True
         return False
 
-    def forward_split(self, points, frame_offsets):
+    def own_planes(self, batch_size):
+        """The plan's PERSISTENT split BEV planes as (B, H, W, C_out * D) int16 views (v3d_backbone_bev_planes): a forward into
+        them clears only the pixels the previous frame wrote instead of filling both planes.  They alias plan memory: valid until
+        the next forward of this plan, and nobody else may write them."""
+        hi, lo = C.c_void_p(), C.c_void_p()
+        L.check(L.lib().v3d_backbone_bev_planes(self._handle, C.byref(hi), C.byref(lo)), "backbone_bev_planes")
+        d, h, w = self.out_shape
+        full = (self.max_batch, h, w, self.out_channels * d)
+        return (_view(hi.value, full, torch.int16, self.device)[:int(batch_size)],
+                _view(lo.value, full, torch.int16, self.device)[:int(batch_size)])
+
+    def forward_split(self, points, frame_offsets, persistent=False):
         """Same as forward() but the BEV map comes out as the dense head's input format: two bf16 NHWC
-        planes (B, H, W, C_out*D) hi/lo (stored as int16)."""
+        planes (B, H, W, C_out*D) hi/lo (stored as int16).  persistent: into the plan's own planes (`own_planes`) -- no per-frame
+        fill of the map; what the captured graphs use (one plan per graph slot)."""
         self.sync_weights()
         pts = L.as_f32("backbone", points)
         b = len(frame_offsets) - 1
         d, h, w = self.out_shape
-        hi, lo = split_planes_like(b, h, w, self.out_channels * d, pts.device)
+        hi, lo = self.own_planes(b) if persistent else split_planes_like(b, h, w, self.out_channels * d, pts.device)
         with torch.cuda.device(pts.device):
             L.check(L.lib().v3d_backbone_forward2(self._handle, L.ptr(pts), pts.shape[0], L.host_i32(frame_offsets), b, 0,
                                                   L.ptr(hi), L.ptr(lo), L.stream_ptr()), "backbone_forward2")
         if self._maybe_tune():  # once: kernels are now picked by the observed sparsity
-            return self.forward_split(points, frame_offsets)
+            return self.forward_split(points, frame_offsets, persistent)
         return hi, lo
 
     def forward_reuse_split(self, batch_size, device):
@@ -410,7 +422,7 @@ class _DevMem(object):
 
 
 def _view(ptr, shape, dtype, device):
-    typestr = {torch.float32: "<f4", torch.int32: "<i4"}[dtype]
+    typestr = {torch.float32: "<f4", torch.int32: "<i4", torch.int16: "<i2"}[dtype]
     with torch.cuda.device(device):
         return torch.as_tensor(_DevMem(ptr, shape, typestr), device=device)
 
