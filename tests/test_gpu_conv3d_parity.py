@@ -111,5 +111,5 @@ def test_every_backbone_layer_equals_dense_conv3d_on_a_full_frame():
         print("layer %2d %3d->%3d rows %6d: strict rel err on |ref| > 1e-3 max = %.2e, max-norm err = %.2e" % row)
     # The split-precision product carries an ABSOLUTE error of a few 1e-6 of the layer's largest output,
     # so relative to an entry a thousand times smaller than the largest one it may reach a few 1e-3: the strict figure is
-    # reported, and bounded at the value that mechanism allows.
-    assert worst_strict < 1e-2, worst_strict
+    # reported, and bounded at the value that mechanism allows (observed 1.2e-3 .. 2.0e-3 over the 14 layers).
+    assert worst_strict < 3e-3, worst_strict

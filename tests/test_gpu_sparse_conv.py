@@ -161,6 +161,28 @@ def test_ring_kernel_tiles_per_workgroup(oracle):
         np.testing.assert_array_equal(outs[0], outs[2], err_msg=f"4 tiles vs 2, n={n}")
 
 
+def test_offset_outer_kernel_picks_its_pass_size_from_the_live_row_count(oracle):
+    """spconv_fwd_rows_kouter (the 64 -> 64 kernel from 32 k rows): above 65 536 live rows a launch walks 384-row passes (three tiles
+    per wave) so that the layer stays inside one round of 256 workgroups, below 256-row passes; the count is device-side.  Same
+    bits as the 256-row-pass form (variant 8) on both sides of the switch, and the 16-row kernel's result within the feature bar."""
+    from vision3d_amd.spconv.conv import build_subm_rulebook, sparse_conv_forward
+    rng = np.random.default_rng(7)
+    coords = kitti_coords(oracle, [1, 2, 3, 4, 5, 6, 7])
+    assert len(coords) > 70000
+    shape = [41, 1600, 1408]
+    w = (rng.standard_normal((3, 3, 3, 64, 64)) / np.sqrt(64 * 9)).astype(np.float32)
+    for n in (len(coords), 65536 + 17, 65536, 40001):
+        c = coords[:n]
+        feats = rng.standard_normal((n, 64)).astype(np.float32)
+        x = make_tensor(c, feats, shape, 7)
+        rb = build_subm_rulebook(x, [3, 3, 3])
+        auto = sparse_conv_forward(x.features, dev(w), rb, None, None, True, 4, None, 6).cpu().numpy()
+        two = sparse_conv_forward(x.features, dev(w), rb, None, None, True, 4, None, 8).cpu().numpy()
+        rows16 = sparse_conv_forward(x.features, dev(w), rb, None, None, True, 4, None, 1).cpu().numpy()
+        np.testing.assert_array_equal(auto, two, err_msg=f"n={n}")
+        assert_features_close(auto, rows16, f"offset-outer vs 16-row kernel, n={n}")
+
+
 def test_densify_exact(oracle):
     rng = np.random.default_rng(3)
     coords = kitti_coords(oracle, [5, 6])

@@ -144,3 +144,34 @@ def test_iou_3d_known_answers(oracle):
     np.testing.assert_allclose(iou[0, 3], 1 / 3, rtol=1e-6)   # crossed at 90 degrees: 2 x 2 x 2 shared of 16 + 16 - 8
     assert iou[0, 4] == 0 and iou[0, 5] == 0                    # disjoint in BEV; z extents only touch
     np.testing.assert_array_equal(iou, iou.T)
+
+
+def test_cpu_train_step_port_runs_and_its_sparse_conv_is_the_oracles():
+    """oracle/train_cpu.py (the cpu_baseline of bench.py --mode train): its gather-GEMM-scatter sparse convolution equals the scalar
+    C oracle's, and two optimiser steps on a small cloud give finite, decreasing-or-changing losses and move the parameters."""
+    import torch
+    from oracle import oracle as O, train_cpu
+    from vision3d_amd import synth
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.detector import Second
+    rng = np.random.default_rng(0)
+    cfg = second_car_cfg()
+    cloud = synth.make_cloud(0, 16384)[:1500]
+    vox, coords, occ = O.voxelize(cloud, cfg.VOXEL_SIZE, cfg.GRID_BOUNDS, cfg.MAX_OCCUPANCY, cfg.MAX_VOXELS)
+    c4 = np.concatenate([np.zeros((len(coords), 1), np.int32), coords], 1)
+    nbr = O.subm_rulebook(c4, [41, 1600, 1408], 3)
+    feats = rng.standard_normal((len(c4), 16)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 16, 32)) / 20).astype(np.float32)
+    got = train_cpu._sparse_conv(torch.from_numpy(feats), torch.from_numpy(w), torch.from_numpy(nbr.astype(np.int64)), len(c4)).numpy()
+    np.testing.assert_allclose(got, O.sparse_conv_fwd(feats, w, nbr), rtol=1e-4, atol=1e-5)
+    torch.manual_seed(0)
+    sd = {k: v.detach().numpy().copy() for k, v in Second(cfg).state_dict().items()}
+    tg = dict(G_cls=(rng.random((1, 1, 2, 200, 176)) < 0.001).astype(np.int8), M_cls=np.ones((1, 1, 2, 200, 176), bool))
+    tg["M_reg"] = (tg["G_cls"] > 0)[..., None]
+    tg["G_reg"] = rng.standard_normal((1, 1, 2, 200, 176, 7)).astype(np.float32) * 0.1
+    kw = dict(lam=float(cfg.TRAIN.LAMBDA), max_pts=cfg.MAX_OCCUPANCY, max_voxels=cfg.MAX_VOXELS)
+    l0, _, params, opt = train_cpu.train_step(sd, [cloud], tg, cfg.VOXEL_SIZE, cfg.GRID_BOUNDS, **kw)
+    before = params["rpn.down_block.1.weight"].detach().clone()
+    l1, _, params, opt = train_cpu.train_step(params, [cloud], tg, cfg.VOXEL_SIZE, cfg.GRID_BOUNDS, optimizer=opt, **kw)
+    assert np.isfinite(l0) and np.isfinite(l1) and l0 != l1
+    assert not torch.equal(before, params["rpn.down_block.1.weight"].detach())

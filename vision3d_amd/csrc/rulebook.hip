@@ -32,7 +32,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_hash_build_kernel(const int4* __
   const int n = min(*n_ptr, cap);
   for (int i = blockIdx.x * V3D_BLOCK + threadIdx.x; i < n; i += gridDim.x * V3D_BLOCK) {
     const int4 c = coords[i];
-    const int s = v3d_hash_insert(h, rb_key(c.x, c.y, c.z, c.w, g.in_shape));
+    const int s = v3d_site_insert(h, rb_key(c.x, c.y, c.z, c.w, g.in_shape), (unsigned)i);
     if (s >= 0) vals[s] = i;
   }
 }
@@ -49,8 +49,7 @@ __device__ __forceinline__ void rb_subm_entry(const int4* __restrict__ coords, i
   if (2 * k + 1 == g.K) {
     v = o;  // centre tap: the site itself
   } else if (z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2]) {
-    const int s = v3d_hash_find(h, rb_key(c.x, z, y, x, g.in_shape));
-    if (s >= 0) v = vals[s];
+    v = v3d_site_find_row(h, rb_key(c.x, z, y, x, g.in_shape));  // one access: the row rides in the key word
   }
   nbr[(size_t)k * cap + o] = v;
 }
@@ -95,7 +94,7 @@ __device__ __forceinline__ void rb_candidates_body(const int4* __restrict__ coor
     const int4 c = coords[i];
     int oz, oy, ox, s = -1;
     if (rb_candidate(c, k, g, oz, oy, ox)) {
-      s = v3d_hash_insert(h, rb_key(c.x, oz, oy, ox, g.out_shape));
+      s = v3d_site_insert(h, rb_key(c.x, oz, oy, ox, g.out_shape), V3D_SITE_NO_ROW);  // numbered by the emit pass
       if (s >= 0) atomicMin(&first_ticket[s], (unsigned)t);
       else {
         atomicExch(overflow, 1);
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_scan_emit_kernel(const int4* __r
                                                                  int* __restrict__ chunk_counts, int cap_out, int4* __restrict__ coords_out,
                                                                  int* __restrict__ vals, int* __restrict__ n_out,
                                                                  int* __restrict__ overflow, int* __restrict__ overflow_any,
-                                                                 int* __restrict__ nbr_init) {
+                                                                 int* __restrict__ nbr_init, const V3dHash out_hash) {
   __shared__ int lds[4];
   __shared__ int s_part[4];
   const long long nt = (long long)min(*n_ptr, cap_in) * g.K;
@@ -229,7 +228,9 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_scan_emit_kernel(const int4* __r
       int oz, oy, ox;
       rb_candidate(c, k, g, oz, oy, ox);
       coords_out[rank] = make_int4(c.x, oz, oy, ox);
-      vals[cand_slot[t]] = rank;
+      const int s = cand_slot[t];
+      vals[s] = rank;
+      v3d_site_set_row(out_hash, s, rb_key(c.x, oz, oy, ox, g.out_shape), (unsigned)rank);  // look-ups read the row with the key
 
     }
     rank++;
@@ -283,6 +284,8 @@ static int fill_geom(RbGeom& g, const int32_t* shape, const int32_t* ks, const i
     if (g.out_shape[j] < 1) return V3D_EINVAL;
     g.K *= g.ks[j];
   }
+  // linear cell keys (batch index in front: up to 64 frames) must fit the 40 key bits of a site table's words (v3d_common.h)
+  if ((long long)g.in_shape[0] * g.in_shape[1] * g.in_shape[2] >= (1ll << 34)) return V3D_EUNSUPPORTED;
   return V3D_OK;
 }
 
@@ -296,6 +299,7 @@ int v3d_i_hash_build(const int32_t* coords, const int32_t* n, int cap, const int
   const int32_t ones[3] = {1, 1, 1};
   int rc = fill_geom(g, shape, ones, nullptr, nullptr);
   if (rc) return rc;
+  if (cap > V3D_SITE_MAX_ROWS) return V3D_EUNSUPPORTED;  // rows ride in 24 bits of the site table's key words
   if (clear) V3D_CHECK_HIP(v3d_fill_async(h.keys, 0xFF, (size_t)h.hcap * 8, st));
   V3dHash hh = v3d_make_hash(h.keys, h.hcap);
   hipLaunchKernelGGL(rb_hash_build_kernel, dim3(min(v3d_ceil_div(cap, V3D_BLOCK), 2048)), dim3(V3D_BLOCK), 0, st,
@@ -359,7 +363,7 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
   if (out_shape)
     for (int j = 0; j < 3; j++) out_shape[j] = g.out_shape[j];
   const long long tickets = (long long)cap_in * g.K;
-  if (tickets >= (1ll << 31)) return V3D_EUNSUPPORTED;
+  if (tickets >= (1ll << 31) || cap_out > V3D_SITE_MAX_ROWS) return V3D_EUNSUPPORTED;
   const int chunks = v3d_ceil_div(tickets, V3D_SCAN_CHUNK);
   if ((char*)first_ticket != (char*)out.keys + (size_t)out.hcap * 8 || (char*)out.vals != (char*)first_ticket + (size_t)out.hcap * 4)
     return V3D_EINVAL;
@@ -376,7 +380,7 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
                        g, h, first_ticket, cand_slot, overflow, overflow_any);
   hipLaunchKernelGGL(rb_scan_emit_kernel, dim3(chunks), dim3(V3D_BLOCK), 0, st, (const int4*)coords_in, n_in, cap_in, g,
                      cand_slot, first_ticket, chunk_counts, cap_out, (int4*)coords_out, out.vals, n_out, overflow, overflow_any,
-                     init_columns ? nbr : nullptr);
+                     init_columns ? nbr : nullptr, h);
   RbGeom sg = g;
   int subm_blocks = 0;
   if (next_subm_ksize && next_subm_nbr) {

@@ -723,6 +723,7 @@ template <int N> __device__ __forceinline__ void vm_wait_tie_after(f32x4 (&a)[1]
 template <int N> __device__ __forceinline__ void vm_wait_tie_after(f32x4 (&a)[2], f32x4& after) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(after) : "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void vm_wait_tie(int (&a)[1]) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a[0]) : "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void vm_wait_tie(int (&a)[2]) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void vm_wait_tie(int (&a)[3]) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "n"(N) : "memory"); }
 
 __device__ __forceinline__ void asm_gld16_64(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(d) : "v"(p) : "memory"); }
 __device__ __forceinline__ void asm_gld16_192(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off offset:192" : "=v"(d) : "v"(p) : "memory"); }
@@ -745,23 +746,20 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigne
 // fragments are read back with ds_read_b128 (the swizzle (row >> 3) & 1 makes those reads conflict-free).  One slot per tile is
 // enough: the fragments of offset k are in registers before the requests of k + 1 overwrite the slot piece by piece, each piece
 // behind the MFMA group that consumed it.
-template <int CIN, int COUT, int T, int K, int STAGE = 1, int DBG = 0>  // DBG 4 (experiment, wrong results): quad-coalesced register gathers
-__global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __restrict__ in,
-                                                              const unsigned short* __restrict__ wimg,
-                                                              const int* __restrict__ nbr, const int* __restrict__ n_ptr,
-                                                              int cap, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, int relu,
-                                                              float* __restrict__ out) {
-  static_assert(CIN % 32 == 0 && CIN <= 64 && (T == 1 || T == 2), "shape not covered by the offset-outer kernel");
+// The pass of T tiles per wave as a device function: the kernel below picks T per LAUNCH from the live row count (device-side).
+template <int CIN, int COUT, int T, int K, int STAGE, int DBG>  // DBG 4 (experiment, wrong results): quad-coalesced register gathers
+__device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in, const unsigned short* __restrict__ wimg,
+                                                   const int* __restrict__ nbr, const int n, int cap, const float* __restrict__ scale,
+                                                   const float* __restrict__ shift, int relu, float* __restrict__ out,
+                                                   unsigned char* wbuf0 /*LDS: 2 x one W[k] image*/,
+                                                   unsigned char* aslot /*LDS: [wave][tile][piece][16 rows][64 B]*/) {
+  static_assert(CIN % 32 == 0 && CIN <= 64 && T >= 1 && T <= 3, "shape not covered by the offset-outer kernel");
   constexpr int KI = CIN / 32, NB = COUT / 16, NW = 8;
   constexpr int NF = KI * NB * 2;                 // 1 KB weight fragments per offset
   constexpr int WBYTES = NF * 1024;               // one W[k] image
   constexpr int WPT = (WBYTES + NW * 64 * 16 - 1) / (NW * 64 * 16);  // 16-byte pieces per thread per offset
   constexpr int G = T * KI * 2;                   // row-gather loads per step and lane
   static_assert(WPT == 1 || WPT == 2, "weight image / workgroup shape");
-  __shared__ __attribute__((aligned(16))) unsigned char wbuf[2][WBYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char aslot[STAGE ? NW * T * CIN * 64 : 16];  // [wave][tile][piece][16 rows][64 B]
-  const int n = min(*n_ptr, cap);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, kg = lane >> 4;
@@ -775,7 +773,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __res
     for (int i = 0; i < WPT; i++) asm_gld16(wreg[i], wp + min(i * NW * 64 + tid, NF * 64 - 1));
   };
   auto store_w = [&](int buf) {
-    f32x4* dst = reinterpret_cast<f32x4*>(wbuf[buf]) + tid;
+    f32x4* dst = reinterpret_cast<f32x4*>(wbuf0 + buf * WBYTES) + tid;
 #pragma unroll
     for (int i = 0; i < WPT; i++)
       if ((i * NW * 64 + tid) * 16 < WBYTES) dst[(size_t)i * NW * 64] = wreg[i];
@@ -847,7 +845,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __res
               araw[0][(t * KI + ki) * 2 + v] =
                   *reinterpret_cast<const f32x4*>(sl + t * (CIN * 64) + ki * 2048 + ((((kg & 1) * 2 + v) ^ sw) * 16));
       }
-      const bf16x8_t* bw = reinterpret_cast<const bf16x8_t*>(wbuf[cur]) + lane;
+      const bf16x8_t* bw = reinterpret_cast<const bf16x8_t*>(wbuf0 + cur * WBYTES) + lane;
       bf16x8_t bh[KI][NB], bl[KI][NB];
 #pragma unroll
       for (int ki = 0; ki < KI; ki++)
@@ -922,6 +920,32 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __res
           }
         }
       }
+  }
+}
+
+// T = tiles per wave and pass (rows per pass = 128 T).  TMAX = 3: the pass size is picked per LAUNCH from the live row count, which
+// is device-side and moves from sweep to sweep (Waymo-range stage 2: 56 k - 75 k rows): up to 65 536 rows two tiles per wave fill ONE
+// round of 256 workgroups; beyond, 256-row passes would need a second, nearly empty round (49 -> 91 us in the frame, round 4
+// trace) -- three tiles per wave keep up to 98 304 rows in one round.  Both bodies live in the one kernel (registers and LDS of the
+// larger); every wave of the grid reads the same count, so the choice is uniform.
+template <int CIN, int COUT, int TMAX, int K, int STAGE = 1, int DBG = 0>
+__global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __restrict__ in,
+                                                              const unsigned short* __restrict__ wimg,
+                                                              const int* __restrict__ nbr, const int* __restrict__ n_ptr,
+                                                              int cap, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int relu,
+                                                              float* __restrict__ out) {
+  constexpr int WBYTES = (CIN / 32) * (COUT / 16) * 2 * 1024;
+  __shared__ __attribute__((aligned(16))) unsigned char wbuf[2 * WBYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char aslot[STAGE ? 8 * TMAX * CIN * 64 : 16];
+  const int n = min(*n_ptr, cap);
+  if constexpr (TMAX == 3) {
+    if (n > 2 * 128 * 256)
+      spconv_kouter_body<CIN, COUT, 3, K, STAGE, DBG>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot);
+    else
+      spconv_kouter_body<CIN, COUT, 2, K, STAGE, DBG>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot);
+  } else {
+    spconv_kouter_body<CIN, COUT, TMAX, K, STAGE, DBG>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot);
   }
 }
 
@@ -1217,7 +1241,7 @@ static void launch_rows_big(const float* in, const void* wimg, const int* nbr, c
 template <int CIN, int COUT, int T, int STAGE = 1, int DBG = 0>
 static void launch_rows_kouter(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
                                const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
-  const int passes = v3d_ceil_div(cap, 16 * T * 8);
+  const int passes = v3d_ceil_div(cap, 16 * (T == 3 ? 2 : T) * 8);  // (T = 3: the kernel may walk 256-row passes)
   const int grid = passes >= 256 ? 256 : ((passes + 7) / 8) * 8;  // a multiple of 8: the pass -> XCD map assumes it
   hipLaunchKernelGGL((spconv_fwd_rows_kouter<CIN, COUT, T, 27, STAGE, DBG>), dim3(grid), dim3(512), 0, st, in, (const unsigned short*)wimg,
                      nbr, n_ptr, cap, scale, shift, relu, out);
@@ -1238,9 +1262,10 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
     // the offset-outer persistent kernel (3x3x3 only; 6: rows staged through LDS, 7: rows gathered into registers): 64->64 at
     // 56 k rows 58 -> 47.5 us.  It needs a full round of 256-row passes to pay: the 32-channel shapes and the mid sizes stay on
     // the kernels below (32->32 at 81 k rows: 316 passes on 256 workgroups = 2 rounds, 43 vs 30 us)
-    if (K == 27 && (force == 6 || force == 7 || (force == 0 && CIN == 64 && COUT == 64 && rows_hint >= V3D_BIG_ROWS))) {
+    if (K == 27 && (force == 6 || force == 7 || force == 8 || (force == 0 && CIN == 64 && COUT == 64 && rows_hint >= V3D_BIG_ROWS))) {
       if (force == 7) launch_rows_kouter<CIN, COUT, 2, 0>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
-      else launch_rows_kouter<CIN, COUT, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+      else if (force == 8) launch_rows_kouter<CIN, COUT, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);  // 256-row passes only
+      else launch_rows_kouter<CIN, COUT, 3, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);  // 256 / 384-row passes by live count
       V3D_CHECK_LAUNCH();
       return V3D_OK;
     }

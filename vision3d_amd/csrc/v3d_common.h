@@ -138,6 +138,52 @@ __device__ __forceinline__ int v3d_hash_find(const V3dHash h, v3d_key_t key) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// SITE tables (the coordinate hashes of the rulebooks): the row index of a site rides in the low 24 bits of its key word,
+//   word = key << 24 | row      (row = 0xFFFFFF: not numbered yet, or clipped by a capacity),
+// so a neighbour look-up is ONE random access (key match and row in the same 8 bytes) instead of the key probe followed by a
+// dependent read of vals[slot] -- the look-ups are the bulk of the rulebook kernels (27 per row; 2.8 M per launch on the
+// Waymo-range sweep) and one memory round trip of every rulebook launch's dependent chain.  Keys are linear cell indices
+// (< 2^40: batch x D x H x W), rows < 2^24 - 1 (checked where tables are sized).  EMPTY stays all ones; the per-slot payload
+// arrays (vals, first_ticket) are kept for the users that reach a slot by index.
+// ------------------------------------------------------------------------------------------------
+#define V3D_SITE_ROW_BITS 24
+#define V3D_SITE_NO_ROW 0xFFFFFFu
+#define V3D_SITE_MAX_ROWS (int)(V3D_SITE_NO_ROW - 1)
+
+// insert-or-find of `key` with a row (or V3D_SITE_NO_ROW); returns the slot, -1 if the table is full.  Concurrent inserts of
+// the same key must pass the same row (in practice: all V3D_SITE_NO_ROW, or the key is inserted once).
+__device__ __forceinline__ int v3d_site_insert(const V3dHash h, v3d_key_t key, unsigned row) {
+  const v3d_key_t word = (key << V3D_SITE_ROW_BITS) | row;
+  unsigned s = v3d_hash_start(key, h);
+  for (unsigned probes = 0; probes <= h.mask; probes++) {
+    const v3d_key_t prev = atomicCAS(&h.keys[s], V3D_EMPTY_KEY, word);
+    if (prev == V3D_EMPTY_KEY || (prev >> V3D_SITE_ROW_BITS) == key) return (int)s;
+    s = (s + 1) & h.mask;
+  }
+  return -1;
+}
+
+// the row of a site in a table completed by an EARLIER kernel (or numbered by v3d_site_set_row), -1 if absent / not numbered
+__device__ __forceinline__ int v3d_site_find_row(const V3dHash h, v3d_key_t key) {
+  unsigned s = v3d_hash_start(key, h);
+  for (unsigned probes = 0; probes <= h.mask; probes++) {
+    const v3d_key_t w = h.keys[s];
+    if ((w >> V3D_SITE_ROW_BITS) == key) {
+      const unsigned row = (unsigned)w & V3D_SITE_NO_ROW;
+      return row == V3D_SITE_NO_ROW ? -1 : (int)row;
+    }
+    if (w == V3D_EMPTY_KEY) return -1;
+    s = (s + 1) & h.mask;
+  }
+  return -1;
+}
+
+// number the site in slot `s` (its only writer at this point: no insert runs concurrently)
+__device__ __forceinline__ void v3d_site_set_row(const V3dHash h, int s, v3d_key_t key, unsigned row) {
+  h.keys[s] = (key << V3D_SITE_ROW_BITS) | row;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Wave64 ballot + popcount compaction.  One flag per thread, 256-thread blocks.
 // Returns the exclusive rank of this thread's flag inside the block; `total` = flags set in the block.
 // `lds` must hold >= 4 ints and is free for reuse on return.

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void vox_emit_kernel(const float* __rest
     if (site_vals) {  // the coordinate hash the first submanifold rulebook needs (saves the rb_hash_build launch)
       // key over the RULEBOOK's grid (D, H, W), which may be larger than the voxel grid (SECOND pads z by one)
       const v3d_key_t key = (((v3d_key_t)b * site_d + c[2]) * site_h + c[1]) * site_w + c[0];
-      const int hs = v3d_hash_insert(site_hash, key);
+      const int hs = v3d_site_insert(site_hash, key, (unsigned)v);  // (each voxel is inserted once, with its row)
       if (hs >= 0) site_vals[hs] = v;
     }
     // the max_pts smallest point indices on this voxel's list, ascending (first-come order)
