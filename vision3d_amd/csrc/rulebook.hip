@@ -18,6 +18,7 @@ struct RbGeom {
   int out_shape[3];  // D, H, W of the output grid
   int ks[3], stride[3], pad[3];
   int K;
+  int kc[3], Kc;     // strided layers: ceil(ks / stride) per axis and their product -- tickets per input row (see rb_ticket)
 };
 
 __device__ __forceinline__ v3d_key_t rb_key(int b, int z, int y, int x, const int* shape) {
@@ -55,7 +56,29 @@ __device__ __forceinline__ void rb_subm_entry(const int4* __restrict__ coords, i
 }
 
 // ---------------------------------------------------------------------------------- strided conv
-// candidate output coordinate of ticket (input coord c, offset k); false if not on the output lattice
+// TICKETS.  The sequential rule numbers the outputs in the order a loop over (input row i, kernel offset k) first touches them.
+// Of the K offsets of an input only those on the output lattice can touch anything: along an axis with stride s an input at v =
+// c + pad reaches the offsets k = v % s, v % s + s, ... (< ks) -- ceil(ks / s) of them, 2 x 2 x 2 = 8 of 27 for a 3x3x3 stride-2
+// layer.  A ticket is t = i * Kc + j with j = (jz, jy, jx) enumerating those offsets in increasing k: the same relative order as
+// i * K + k over the offsets that can hit, so "smallest ticket per output slot" numbers the outputs exactly as before -- on a
+// ticket space 3.4x smaller (candidate pass, flag scan and table fill all walk it).
+// rb_ticket: the kernel offset k and the output cell of ticket slot j of input c; false if that slot is empty / outside.
+__device__ __forceinline__ bool rb_ticket(const int4 c, int j, const RbGeom& g, int& k, int& oz, int& oy, int& ox) {
+  const int jx = j % g.kc[2], jy = (j / g.kc[2]) % g.kc[1], jz = j / (g.kc[2] * g.kc[1]);
+  const int vz = c.y + g.pad[0], vy = c.z + g.pad[1], vx = c.w + g.pad[2];
+  const int kz = vz % g.stride[0] + jz * g.stride[0], ky = vy % g.stride[1] + jy * g.stride[1], kx = vx % g.stride[2] + jx * g.stride[2];
+  if (kz >= g.ks[0] || ky >= g.ks[1] || kx >= g.ks[2] || kz > vz || ky > vy || kx > vx) return false;
+  oz = (vz - kz) / g.stride[0];
+  oy = (vy - ky) / g.stride[1];
+  ox = (vx - kx) / g.stride[2];
+  k = (kz * g.ks[1] + ky) * g.ks[2] + kx;
+  return oz < g.out_shape[0] && oy < g.out_shape[1] && ox < g.out_shape[2];
+}
+// a candidate word: the output slot and the kernel offset of a live ticket, -1 for a dead one (slot < 2^26, k < 63)
+#define RB_SLOT_BITS 26
+#define RB_SLOT_MASK ((1 << RB_SLOT_BITS) - 1)
+
+// candidate output coordinate of (input coord c, offset k); false if not on the output lattice
 __device__ __forceinline__ bool rb_candidate(const int4 c, int k, const RbGeom& g, int& oz, int& oy, int& ox) {
   const int kx = k % g.ks[2], ky = (k / g.ks[2]) % g.ks[1], kz = k / (g.ks[2] * g.ks[1]);
   const int vz = c.y + g.pad[0] - kz, vy = c.z + g.pad[1] - ky, vx = c.w + g.pad[2] - kx;
@@ -88,15 +111,17 @@ __device__ __forceinline__ void rb_candidates_body(const int4* __restrict__ coor
                                                    const RbGeom& g, const V3dHash& h, unsigned* __restrict__ first_ticket,
                                                    int* __restrict__ cand_slot, int* __restrict__ overflow,
                                                    int* __restrict__ overflow_any, int block, int nblocks) {
-  const long long nt = (long long)min(*n_ptr, cap_in) * g.K;
+  const long long nt = (long long)min(*n_ptr, cap_in) * g.Kc;
   for (long long t = (long long)block * V3D_BLOCK + threadIdx.x; t < nt; t += (long long)nblocks * V3D_BLOCK) {
-    const int i = (int)(t / g.K), k = (int)(t % g.K);
+    const int i = (int)(t / g.Kc), j = (int)(t % g.Kc);
     const int4 c = coords[i];
-    int oz, oy, ox, s = -1;
-    if (rb_candidate(c, k, g, oz, oy, ox)) {
+    int k, oz, oy, ox, s = -1;
+    if (rb_ticket(c, j, g, k, oz, oy, ox)) {
       s = v3d_site_insert(h, rb_key(c.x, oz, oy, ox, g.out_shape), V3D_SITE_NO_ROW);  // numbered by the emit pass
-      if (s >= 0) atomicMin(&first_ticket[s], (unsigned)t);
-      else {
+      if (s >= 0) {
+        atomicMin(&first_ticket[s], (unsigned)t);
+        s |= k << RB_SLOT_BITS;
+      } else {
         atomicExch(overflow, 1);
         if (overflow_any) atomicExch(overflow_any, 1);
       }
@@ -133,7 +158,7 @@ __device__ __forceinline__ bool rb_is_first(const int* cand_slot, const unsigned
                                             long long nt) {
   if (t >= nt) return false;
   const int s = cand_slot[t];
-  return s >= 0 && first_ticket[s] == (unsigned)t;
+  return s != -1 && first_ticket[s & RB_SLOT_MASK] == (unsigned)t;
 }
 
 #define RB_PER_THREAD (V3D_SCAN_CHUNK / V3D_BLOCK)  // 8 consecutive tickets per thread
@@ -148,7 +173,7 @@ __device__ __forceinline__ unsigned rb_first_flags(const int* __restrict__ cand_
   unsigned flags = 0u;
 #pragma unroll
   for (int r = 0; r < 8; r++)
-    if (t0 + r < nt && s[r] >= 0 && first_ticket[s[r]] == (unsigned)(t0 + r)) flags |= 1u << r;
+    if (t0 + r < nt && s[r] != -1 && first_ticket[s[r] & RB_SLOT_MASK] == (unsigned)(t0 + r)) flags |= 1u << r;
   return flags;
 }
 
@@ -170,7 +195,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_scan_emit_kernel(const int4* __r
                                                                  int* __restrict__ nbr_init, const V3dHash out_hash) {
   __shared__ int lds[4];
   __shared__ int s_part[4];
-  const long long nt = (long long)min(*n_ptr, cap_in) * g.K;
+  const long long nt = (long long)min(*n_ptr, cap_in) * g.Kc;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const long long base = (long long)b * V3D_SCAN_CHUNK;
   const bool live = base < nt, last = b == (int)gridDim.x - 1;
@@ -188,6 +213,30 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_scan_emit_kernel(const int4* __r
   __syncthreads();
   const int cnt = lds[0] + lds[1] + lds[2] + lds[3];
   if (tid == 0 && live) v3d_publish_count(chunk_counts + b, cnt);
+  // Emit runs one output per thread: the chunk's first-toucher tickets are compacted into an LDS list at their local ranks (a
+  // thread that walked its own up to 8 flagged tickets one after the other put 8 dependent look-up chains in a row -- in the
+  // compact ticket space most of a thread's 8 tickets are live), and thread q emits local rank q.  Its loads do not depend on the
+  // chunk's global prefix, so the first round's are ISSUED here, in front of the wait for the predecessors' counts.
+  __shared__ unsigned short list[V3D_SCAN_CHUNK];
+  {
+    int lr = incl - mine;
+    for (int i = 0; i < w; i++) lr += lds[i];
+    unsigned f = flags;
+    while (f) {
+      const int r = __ffs(f) - 1;
+      f &= f - 1;
+      list[lr++] = (unsigned short)(tid * RB_PER_THREAD + r);
+    }
+  }
+  __syncthreads();
+  int word0 = -1;
+  int4 c0 = make_int4(0, 0, 0, 0);
+  if (tid < cnt) {
+    const long long t = base + list[tid];
+    word0 = cand_slot[t];
+    c0 = coords[(int)(t / g.Kc)];
+  }
+  asm volatile("" ::: "memory");  // (the loads above stay in front of the spin below)
   int part = 0;
   {
     const int n_live = (int)((nt + V3D_SCAN_CHUNK - 1) / V3D_SCAN_CHUNK);
@@ -211,29 +260,26 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_scan_emit_kernel(const int4* __r
     // the columns of the sites this block creates (ranks prefix .. prefix + cnt - 1) start as "no input" -- the fill kernel behind
     // this launch writes the live entries -- so the table needs no per-frame -1 fill over its whole K x capacity extent.  All
     // threads share the work, lanes along the ranks (the emitting threads alone would do 27 stores per site, one after the other).
-    const int c0 = min(prefix, cap_out), c1 = min(prefix + cnt, cap_out), w_ = c1 - c0;
+    const int c0r = min(prefix, cap_out), c1r = min(prefix + cnt, cap_out), w_ = c1r - c0r;
     for (int kk = tid >> 5; kk < g.K; kk += V3D_BLOCK / 32)  // 8 table rows at a time, 32 lanes along the ranks: no division
-      for (int r = tid & 31; r < w_; r += 32) nbr_init[(size_t)kk * cap_out + c0 + r] = -1;
+      for (int r = tid & 31; r < w_; r += 32) nbr_init[(size_t)kk * cap_out + c0r + r] = -1;
   }
-  int rank = prefix + incl - mine;
-  for (int i = 0; i < w; i++) rank += lds[i];
-  unsigned f = flags;
-  while (f) {
-    const int r = __ffs(f) - 1;
-    f &= f - 1;
-    if (rank < cap_out) {
-      const long long t = t0 + r;
-      const int i = (int)(t / g.K), k = (int)(t % g.K);
-      const int4 c = coords[i];
-      int oz, oy, ox;
-      rb_candidate(c, k, g, oz, oy, ox);
-      coords_out[rank] = make_int4(c.x, oz, oy, ox);
-      const int s = cand_slot[t];
-      vals[s] = rank;
-      v3d_site_set_row(out_hash, s, rb_key(c.x, oz, oy, ox, g.out_shape), (unsigned)rank);  // look-ups read the row with the key
-
+  for (int q = tid; q < cnt; q += V3D_BLOCK) {
+    const int rank = prefix + q;
+    if (rank >= cap_out) break;
+    int word = word0;
+    int4 c = c0;
+    if (q != tid) {
+      const long long t = base + list[q];
+      word = cand_slot[t];
+      c = coords[(int)(t / g.Kc)];
     }
-    rank++;
+    const int s = word & RB_SLOT_MASK;
+    int oz, oy, ox;
+    rb_candidate(c, (int)((unsigned)word >> RB_SLOT_BITS), g, oz, oy, ox);
+    coords_out[rank] = make_int4(c.x, oz, oy, ox);
+    vals[s] = rank;
+    v3d_site_set_row(out_hash, s, rb_key(c.x, oz, oy, ox, g.out_shape), (unsigned)rank);  // look-ups read the row with the key
   }
 }
 
@@ -250,13 +296,13 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_fill_nbr_kernel(const int* __res
                                                                 const V3dHash sh, int* __restrict__ subm_nbr, int subm_blocks,
                                                                 const RbCandJob job) {
   if ((int)blockIdx.x < fill_blocks) {
-    const long long nt = (long long)min(*n_ptr, cap_in) * K;
+    const long long nt = (long long)min(*n_ptr, cap_in) * K;  // K: tickets per input row here (RbGeom::Kc)
     for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < nt; t += (long long)fill_blocks * V3D_BLOCK) {
-      const int s = cand_slot[t];
-      if (s < 0) continue;
-      const int o = vals[s];
+      const int word = cand_slot[t];
+      if (word == -1) continue;
+      const int o = vals[word & RB_SLOT_MASK];
       if (o < 0) continue;  // clipped by cap_out
-      nbr[(size_t)(t % K) * cap_out + o] = (int)(t / K);
+      nbr[(size_t)((unsigned)word >> RB_SLOT_BITS) * cap_out + o] = (int)(t / K);
     }
     return;
   }
@@ -284,6 +330,12 @@ static int fill_geom(RbGeom& g, const int32_t* shape, const int32_t* ks, const i
     if (g.out_shape[j] < 1) return V3D_EINVAL;
     g.K *= g.ks[j];
   }
+  g.Kc = 1;
+  for (int j = 0; j < 3; j++) {
+    g.kc[j] = (g.ks[j] + g.stride[j] - 1) / g.stride[j];
+    g.Kc *= g.kc[j];
+  }
+  if (g.K > 62) return V3D_EUNSUPPORTED;  // the kernel offset rides in 6 bits of a candidate word beside the slot (-1 = dead)
   // linear cell keys (batch index in front: up to 64 frames) must fit the 40 key bits of a site table's words (v3d_common.h)
   if ((long long)g.in_shape[0] * g.in_shape[1] * g.in_shape[2] >= (1ll << 34)) return V3D_EUNSUPPORTED;
   return V3D_OK;
@@ -314,8 +366,8 @@ static int make_cand_job(const V3dRbCandNext* next, RbCandJob& job) {
   if (!next) return V3D_OK;
   int rc = fill_geom(job.g, next->shape, next->ksize, next->stride, next->padding);
   if (rc) return rc;
-  const long long tickets = (long long)next->cap_in * job.g.K;
-  if (tickets >= (1ll << 31)) return V3D_EUNSUPPORTED;
+  const long long tickets = (long long)next->cap_in * job.g.Kc;
+  if (tickets >= (1ll << 31) || next->out.hcap > (1u << RB_SLOT_BITS)) return V3D_EUNSUPPORTED;
   if ((char*)next->first_ticket != (char*)next->out.keys + (size_t)next->out.hcap * 8 ||
       (char*)next->out.vals != (char*)next->first_ticket + (size_t)next->out.hcap * 4)
     return V3D_EINVAL;
@@ -362,8 +414,8 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
   if (rc) return rc;
   if (out_shape)
     for (int j = 0; j < 3; j++) out_shape[j] = g.out_shape[j];
-  const long long tickets = (long long)cap_in * g.K;
-  if (tickets >= (1ll << 31) || cap_out > V3D_SITE_MAX_ROWS) return V3D_EUNSUPPORTED;
+  const long long tickets = (long long)cap_in * g.Kc;
+  if (tickets >= (1ll << 31) || cap_out > V3D_SITE_MAX_ROWS || out.hcap > (1u << RB_SLOT_BITS)) return V3D_EUNSUPPORTED;
   const int chunks = v3d_ceil_div(tickets, V3D_SCAN_CHUNK);
   if ((char*)first_ticket != (char*)out.keys + (size_t)out.hcap * 8 || (char*)out.vals != (char*)first_ticket + (size_t)out.hcap * 4)
     return V3D_EINVAL;
@@ -393,7 +445,7 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
   RbCandJob job;
   rc = make_cand_job(next, job);
   if (rc) return rc;
-  hipLaunchKernelGGL(rb_fill_nbr_kernel, dim3(tblocks + subm_blocks + job.blocks), dim3(V3D_BLOCK), 0, st, n_in, cap_in, g.K, cand_slot,
+  hipLaunchKernelGGL(rb_fill_nbr_kernel, dim3(tblocks + subm_blocks + job.blocks), dim3(V3D_BLOCK), 0, st, n_in, cap_in, g.Kc, cand_slot,
                      out.vals, cap_out, nbr, tblocks, (const int4*)coords_out, n_out, sg, h, next_subm_nbr, subm_blocks, job);
   V3D_CHECK_LAUNCH();
   return V3D_OK;

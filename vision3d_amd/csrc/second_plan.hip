@@ -123,7 +123,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
     L.d = descs[l];
     if (L.d.cin != cin) { delete p; return V3D_EINVAL; }
     L.K = L.d.ksize[0] * L.d.ksize[1] * L.d.ksize[2];
-    if (L.K < 1 || L.K > 64) { delete p; return V3D_EUNSUPPORTED; }
+    if (L.K < 1 || L.K > 62) { delete p; return V3D_EUNSUPPORTED; }
     L.stage_in = cur;
     if (L.d.subm) {
       L.stage_out = cur;
@@ -162,7 +162,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       }
       ns.cap = (int)cap;
       ns.hash_ready_by_sparse = true;
-      const long long tickets = (long long)p->stages[cur].cap * L.K;
+      const long long tickets = (long long)p->stages[cur].cap * conv_fan(L.d);  // tickets per input row: rulebook.hip rb_ticket
       if (tickets > max_tickets) max_tickets = tickets;
       p->stages.push_back(ns);
       cur = (int)p->stages.size() - 1;
@@ -201,7 +201,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       p->bev_occ = ar.take<uint32_t>(v3d_bev_occupancy_words(cfg->max_batch, sl.shape[1], sl.shape[2]));
     }
     for (auto& L : p->layers)  // strided layers: per-layer count slots, -1 = "not published" at the start of a frame
-      if (!L.d.subm) L.chunk_counts = ar.take<int>((size_t)v3d_ceil_div((long long)p->stages[L.stage_in].cap * L.K, V3D_SCAN_CHUNK) + 2);
+      if (!L.d.subm) L.chunk_counts = ar.take<int>((size_t)v3d_ceil_div((long long)p->stages[L.stage_in].cap * conv_fan(L.d), V3D_SCAN_CHUNK) + 2);
     p->ff_bytes = (size_t)((ar.base + ar.off) - p->ff_begin);
     // ---- the rest needs no per-frame initialisation
     for (size_t i = 0; i < p->nbr.size(); i++) p->nbr[i] = ar.take<int32_t>((size_t)rbK[i] * p->nbr_cap[i]);

@@ -150,49 +150,25 @@ __global__ __launch_bounds__(V3D_BLOCK) void vox_emit_kernel(const float* __rest
                                                              int site_d, int site_h, int site_w, int* __restrict__ n_voxels) {
   __shared__ int lds[4];
   static_assert(VOX_CHUNK == V3D_BLOCK, "one round per block");
-  const int base = blockIdx.x * VOX_CHUNK;
-  int running = CHAINED ? 0 : chunk_offsets[blockIdx.x];
-  for (int r = 0; r < VOX_CHUNK / V3D_BLOCK; r++) {
-    const int i = base + r * V3D_BLOCK + threadIdx.x;
-    const bool flag = vox_is_first(pt_slot, first, i, p.n_points);
-    int tot;
-    int rank = running + v3d_block_rank(flag, tot, lds);
-    running += tot;
-    if constexpr (CHAINED) {
-      __shared__ int s_part[V3D_BLOCK / V3D_WAVE];
-      if (threadIdx.x == 0) v3d_publish_count(chunk_offsets + blockIdx.x, tot);
-      int part = 0;
-      for (int c = threadIdx.x; c < (int)blockIdx.x; c += V3D_BLOCK) part += v3d_wait_count(chunk_offsets + c);
+  const int i = blockIdx.x * VOX_CHUNK + threadIdx.x;
+  const bool flag = vox_is_first(pt_slot, first, i, p.n_points);
+  int tot;
+  int rank = v3d_block_rank(flag, tot, lds);
+  if constexpr (CHAINED) {
+    if (threadIdx.x == 0) v3d_publish_count(chunk_offsets + blockIdx.x, tot);
+  }
+  // ---- everything about the voxel that does not depend on its NUMBER, in front of the (chained) wait for the number: the cell,
+  //      the walk of the voxel's point list (the max_pts smallest point indices, ascending = first-come order) and the points
+  int c[3] = {0, 0, 0};
+  int best[VOX_MAX_PTS];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-      if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
-      __syncthreads();
-      const int prefix = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-      rank += prefix;
-      if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_voxels = min(prefix + tot, p.max_voxels);
-    }
-    if (!flag) continue;
-    const int b = CHAINED ? 0 : frame_of(p, i);
-    const int local = CHAINED ? rank : rank - frame_base[b];
-    if (local >= p.max_voxels) continue;  // `continue` variant of the max_voxels rule
-    const int v = CHAINED ? local : out_base[b] + local;
-    // voxel coordinates from the first toucher itself
-    const float* q = pts + (size_t)i * p.C;
-    int c[3];
+  for (int k = 0; k < VOX_MAX_PTS; k++) best[k] = 0x7FFFFFFF;
+  int cnt = 0;
+  float4 pv[VOX_MAX_PTS];
+  if (flag) {
+    const float* q = pts + (size_t)i * p.C;  // voxel coordinates from the first toucher itself
 #pragma unroll
     for (int j = 0; j < 3; j++) c[j] = (int)floorf((q[j] - p.lo[j]) / p.vs[j]);
-    reinterpret_cast<int4*>(coords)[v] = make_int4(b, c[2], c[1], c[0]);
-    if (site_vals) {  // the coordinate hash the first submanifold rulebook needs (saves the rb_hash_build launch)
-      // key over the RULEBOOK's grid (D, H, W), which may be larger than the voxel grid (SECOND pads z by one)
-      const v3d_key_t key = (((v3d_key_t)b * site_d + c[2]) * site_h + c[1]) * site_w + c[0];
-      const int hs = v3d_site_insert(site_hash, key, (unsigned)v);  // (each voxel is inserted once, with its row)
-      if (hs >= 0) site_vals[hs] = v;
-    }
-    // the max_pts smallest point indices on this voxel's list, ascending (first-come order)
-    int best[VOX_MAX_PTS];
-#pragma unroll
-    for (int k = 0; k < VOX_MAX_PTS; k++) best[k] = 0x7FFFFFFF;
-    int cnt = 0;
     for (int j = head[pt_slot[i]], guard = 0; j >= 0 && guard < p.n_points; j = next[j], guard++) {
       cnt++;
       int x = j;
@@ -203,39 +179,67 @@ __global__ __launch_bounds__(V3D_BLOCK) void vox_emit_kernel(const float* __rest
         best[k] = lo_;
       }
     }
-    const int occ = min(cnt, p.max_pts);
-    occupancy[v] = occ;
-    if (p.C == 4) {
-      // four channels (x, y, z, intensity): the points as 16-byte loads, all in flight at once (the generic loop below issues
-      // max_pts x C scalar loads); same sums in the same order
-      float4 pv[VOX_MAX_PTS];
+  }
+  const int occ = min(cnt, p.max_pts);
+  if (p.C == 4) {
+    // four channels (x, y, z, intensity): the points as 16-byte loads, all in flight at once (the generic loop below issues
+    // max_pts x C scalar loads); same sums in the same order
 #pragma unroll
-      for (int k = 0; k < VOX_MAX_PTS; k++)
-        pv[k] = (k < p.max_pts && k < occ) ? reinterpret_cast<const float4*>(pts)[best[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < VOX_MAX_PTS; k++)
+      pv[k] = (flag && k < p.max_pts && k < occ) ? reinterpret_cast<const float4*>(pts)[best[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if constexpr (CHAINED) {
+    __shared__ int s_part[V3D_BLOCK / V3D_WAVE];
+    asm volatile("" ::: "memory");  // (the loads above are issued in front of the spin)
+    int part = 0;
+    for (int cb = threadIdx.x; cb < (int)blockIdx.x; cb += V3D_BLOCK) part += v3d_wait_count(chunk_offsets + cb);
 #pragma unroll
-      for (int k = 0; k < VOX_MAX_PTS; k++) {
-        if (k < p.max_pts) {
-          if (voxels) reinterpret_cast<float4*>(voxels)[(size_t)v * p.max_pts + k] = pv[k];
-          sm.x += pv[k].x; sm.y += pv[k].y; sm.z += pv[k].z; sm.w += pv[k].w;
-        }
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const int prefix = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    rank += prefix;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_voxels = min(prefix + tot, p.max_voxels);
+  } else {
+    rank += chunk_offsets[blockIdx.x];
+  }
+  if (!flag) return;
+  const int b = CHAINED ? 0 : frame_of(p, i);
+  const int local = CHAINED ? rank : rank - frame_base[b];
+  if (local >= p.max_voxels) return;  // `continue` variant of the max_voxels rule
+  const int v = CHAINED ? local : out_base[b] + local;
+  reinterpret_cast<int4*>(coords)[v] = make_int4(b, c[2], c[1], c[0]);
+  if (site_vals) {  // the coordinate hash the first submanifold rulebook needs (saves the rb_hash_build launch)
+    // key over the RULEBOOK's grid (D, H, W), which may be larger than the voxel grid (SECOND pads z by one)
+    const v3d_key_t key = (((v3d_key_t)b * site_d + c[2]) * site_h + c[1]) * site_w + c[0];
+    const int hs = v3d_site_insert(site_hash, key, (unsigned)v);  // (each voxel is inserted once, with its row)
+    if (hs >= 0) site_vals[hs] = v;
+  }
+  occupancy[v] = occ;
+  if (p.C == 4) {
+    float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < VOX_MAX_PTS; k++) {
+      if (k < p.max_pts) {
+        if (voxels) reinterpret_cast<float4*>(voxels)[(size_t)v * p.max_pts + k] = pv[k];
+        sm.x += pv[k].x; sm.y += pv[k].y; sm.z += pv[k].z; sm.w += pv[k].w;
       }
-      const float fo = (float)occ;
-      if (mean) reinterpret_cast<float4*>(mean)[v] = make_float4(sm.x / fo, sm.y / fo, sm.z / fo, sm.w / fo);
-      continue;
     }
-    for (int ch = 0; ch < p.C; ch++) {
-      float s = 0.f;
+    const float fo = (float)occ;
+    if (mean) reinterpret_cast<float4*>(mean)[v] = make_float4(sm.x / fo, sm.y / fo, sm.z / fo, sm.w / fo);
+    return;
+  }
+  for (int ch = 0; ch < p.C; ch++) {
+    float sacc = 0.f;
 #pragma unroll
-      for (int k = 0; k < VOX_MAX_PTS; k++) {
-        if (k < p.max_pts) {
-          const float val = k < occ ? pts[(size_t)best[k] * p.C + ch] : 0.f;
-          if (voxels) voxels[((size_t)v * p.max_pts + k) * p.C + ch] = val;
-          s += val;
-        }
+    for (int k = 0; k < VOX_MAX_PTS; k++) {
+      if (k < p.max_pts) {
+        const float val = k < occ ? pts[(size_t)best[k] * p.C + ch] : 0.f;
+        if (voxels) voxels[((size_t)v * p.max_pts + k) * p.C + ch] = val;
+        sacc += val;
       }
-      if (mean) mean[(size_t)v * p.C + ch] = s / (float)occ;
     }
+    if (mean) mean[(size_t)v * p.C + ch] = sacc / (float)occ;
   }
 }
 
