@@ -56,7 +56,7 @@ for a in cap:
     for v in VARIANTS:
         t, o = timed(a, v)
         ref = o.clone() if ref is None else ref
-        assert v > 20 or (ref - o).abs().max() <= 1e-4 * ref.abs().max()  # codes > 20: ablations (-DV3D_EXPERIMENTS builds), results wrong by construction
+        assert (ref - o).abs().max() <= 1e-4 * ref.abs().max()
         row += f"  {'auto' if v == 0 else 'v' + str(v)}={t:7.1f}us"
     print(row)
 

@@ -454,9 +454,6 @@ static constexpr int dl_smem(int mt) {
   return tile > stages ? tile : stages;
 }
 
-#ifndef DL_DBG
-#define DL_DBG 0
-#endif
 #ifndef DL_TIMELINE
 #define DL_TIMELINE 0  // 1: cycle-counter stamps of one workgroup (tools/mb_dense.py prints them)
 #endif
@@ -650,13 +647,9 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
       frag(1, fh[0][1], fl[0][1]);
       frag(2, fh[1][0], fl[1][0]);
       frag(3, fh[1][1], fl[1][1]);
-      if (DL_DBG & 4) {
-        frag(4, fh[2][0], fl[2][0]);
-        frag(5, fh[2][1], fl[2][1]);
-      }
 #pragma unroll
       for (int u = 0; u < NSTEP; u++) {
-        if (u + 2 < NSTEP && !(DL_DBG & 4)) {
+        if (u + 2 < NSTEP) {
           frag(2 * u + 4, fh[(u + 2) % 3][0], fl[(u + 2) % 3][0]);
           frag(2 * u + 5, fh[(u + 2) % 3][1], fl[(u + 2) % 3][1]);
         }
@@ -684,8 +677,8 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
         // a substep's B registers are free once its last tile has issued: refill them for the next stage
         // (unconditionally -- the last stage re-reads its own fragments: a branch here makes the compiler's
         // s_waitcnt bookkeeping merge two histories and wait for vmcnt(0) in the middle of the stage, 1350 clocks)
-        if (i0 == MT - 1 && !(DL_DBG & 8)) load_b(s0);
-        if (i1 == MT - 1 && !(DL_DBG & 8)) load_b(s1);
+        if (i0 == MT - 1) load_b(s0);
+        if (i1 == MT - 1) load_b(s1);
         __builtin_amdgcn_sched_barrier(0);
 #if DL_TIMELINE
         if (stamp && (u == 0 || u == 1 || u == 8 || u == 16 || u == 17)) DL_STAMP(0, 40 + u);
@@ -1223,12 +1216,7 @@ extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, con
       V3D_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const bool persistent = p.occ && work && p.CoutPad == DC_BN;
-#ifdef V3D_EXPERIMENTS  // A/B switches exist in the experiments build only (tools/build_variant.sh exp -DV3D_EXPERIMENTS)
-    static const bool no2d = [] { const char* e = getenv("V3D_DENSE_TILE2D"); return e && e[0] == '0'; }();
-#else
-    constexpr bool no2d = false;
-#endif
-    if (persistent && ksize == 3 && Cin == DL_KC && !no2d) {  // 2-D tiles with an LDS-resident neighbourhood
+    if (persistent && ksize == 3 && Cin == DL_KC) {  // 2-D tiles with an LDS-resident neighbourhood
       p.work = work;
       p.tile_state = tile_state;
       const int tiles2 = B * v3d_ceil_div(H, D2_TH) * v3d_ceil_div(W, D2_TW);

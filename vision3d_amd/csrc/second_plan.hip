@@ -72,26 +72,14 @@ struct v3d_backbone {
   void *bev_hi = nullptr, *bev_lo = nullptr;
   int32_t *bev_pix = nullptr, *bev_pix_n = nullptr;
   struct PlanTrain* train = nullptr;  // training buffers, allocated by the first v3d_backbone_train_forward
-  // The rulebook chain only depends on COORDINATES: the inference forward runs it on a second stream, ahead of the convolutions
-  // (which wait, per rulebook, for the event recorded behind its builder).  Captured into a HIP graph this becomes a fork / join.
-  hipStream_t rb_stream = nullptr;
-  hipEvent_t ev_fork = nullptr;
-  std::vector<hipEvent_t> ev_rb;  // per rulebook
+  // (Measured and removed in round 4: the rulebook chain on a second stream with one event per finished rulebook -- inside a
+  // captured graph the fork / join costs more than the overlap returns, 3 209 -> 2 526 frames/s pipelined)
 };
 
 static int conv_fan(const v3d_layer_desc& d) {
   int fan = 1;
   for (int j = 0; j < 3; j++) fan *= (d.ksize[j] + d.stride[j] - 1) / d.stride[j];
   return fan;
-}
-
-// A/B switches (V3D_NO_CAP_PAD, V3D_RB_CHAIN, V3D_RB_FORK) exist in the experiments build only: tools/build_variant.sh exp -DV3D_EXPERIMENTS
-static bool plan_cap_pad() {
-#ifdef V3D_EXPERIMENTS
-  return !getenv("V3D_NO_CAP_PAD");
-#else
-  return true;
-#endif
 }
 
 extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_layer_desc* descs, v3d_backbone** out) {
@@ -107,7 +95,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
   // ---- pass 1: geometry, capacities, rulebook sharing
   PlanStage s0{};
   s0.hash_items = (int)cap0;
-  if (plan_cap_pad()) {  // (same for stage 0's table)
+  if (true) {  // (same for stage 0's table)
     cap0 = (cap0 + 63) / 64 * 64;
     if ((cap0 / 64) % 2 == 0) cap0 += 64;
   }
@@ -156,7 +144,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       // The capacity is the row stride of the stage's neighbour tables (nbr[k][o], k-major): a power of two would put the K rows
       // a tile reads at the same offset of every 128 KB -- one memory channel, one cache set.  Make it an odd multiple of 64 rows.
       ns.hash_items = (int)cap;
-      if (plan_cap_pad()) {
+      if (true) {
         cap = (cap + 63) / 64 * 64;
         if ((cap / 64) % 2 == 0) cap += 64;
       }
@@ -243,20 +231,6 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
   if (e == hipSuccess) e = hipMemset(p->bev_hi, 0, (size_t)((char*)p->bev_lo - (char*)p->bev_hi) * 2);  // the planes are adjacent
   if (e == hipSuccess) e = hipMemset(p->bev_pix_n, 0, sizeof(int32_t));
   if (e != hipSuccess) { (void)hipFree(p->arena); delete p; return (int)e; }
-  // Opt-in (V3D_RB_FORK=1).  Measured on the KITTI frame inside the HIP graph: the fork / join turns into cross-queue barrier
-  // packets that cost more than the overlap returns -- headline 3 209 -> 2 526 frames/s with frames pipelined.
-#ifdef V3D_EXPERIMENTS
-  const char* fork = getenv("V3D_RB_FORK");
-#else
-  const char* fork = nullptr;  // (the product library has no environment switches)
-#endif
-  if (fork && fork[0] == '1') {
-    bool ok = hipStreamCreateWithFlags(&p->rb_stream, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess;
-    p->ev_rb.assign(p->nbr_cap.size(), nullptr);
-    for (size_t r = 0; ok && r < p->ev_rb.size(); r++) ok = hipEventCreateWithFlags(&p->ev_rb[r], hipEventDisableTiming) == hipSuccess;
-    if (!ok) { v3d_backbone_destroy(p); return V3D_EWORKSPACE; }
-  }
   *out = p;
   return V3D_OK;
 }
@@ -266,10 +240,6 @@ static void plan_train_free(v3d_backbone* p);
 extern "C" void v3d_backbone_destroy(v3d_backbone* p) {
   if (!p) return;
   plan_train_free(p);
-  for (hipEvent_t e : p->ev_rb)
-    if (e) (void)hipEventDestroy(e);
-  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-  if (p->rb_stream) (void)hipStreamDestroy(p->rb_stream);
   if (p->arena) (void)hipFree(p->arena);
   delete p;
 }
@@ -497,37 +467,12 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
   int rc = V3D_OK;
   std::vector<char> rb_done(p->layers.size(), 0);
   const float* feat = p->mean;
-  const bool fork = p->rb_stream != nullptr && !reuse_rulebooks;
-  std::vector<char> waited(p->nbr_cap.size(), 0);
-  std::vector<char> cand_done_v(p->layers.size(), 0);
-#ifdef V3D_EXPERIMENTS
-  static const bool chain = [] { const char* e = getenv("V3D_RB_CHAIN"); return !(e && e[0] == '0'); }();  // "0": A/B measurements
-#else
-  constexpr bool chain = true;
-#endif
-  std::vector<char>* cand_done = chain ? &cand_done_v : nullptr;
-  if (fork) {  // the whole rulebook chain on the second stream, one event per finished rulebook
-    V3D_CHECK_HIP(hipEventRecord(p->ev_fork, st));
-    V3D_CHECK_HIP(hipStreamWaitEvent(p->rb_stream, p->ev_fork, 0));
-    for (size_t l = 0; l < p->layers.size(); l++) {
-      PlanLayer& L = p->layers[l];
-      if (!L.builds_rulebook || rb_done[l]) continue;
-      rc = plan_layer_rulebook(p, l, rb_done, hash0_done, p->rb_stream, cand_done);
-      if (rc) return rc;
-      V3D_CHECK_HIP(hipEventRecord(p->ev_rb[L.rulebook], p->rb_stream));
-      if (l + 1 < p->layers.size() && rb_done[l + 1] && p->layers[l + 1].builds_rulebook)  // rode in the same launch
-        V3D_CHECK_HIP(hipEventRecord(p->ev_rb[p->layers[l + 1].rulebook], p->rb_stream));
-    }
-  }
+  // the candidate pass of a strided layer rides in the launch that produces its input sites' last table (rulebook.hip RbCandJob)
+  std::vector<char> cand_done(p->layers.size(), 0);
   for (size_t l = 0; l < p->layers.size(); l++) {
     PlanLayer& L = p->layers[l];
-    if (fork) {
-      if (!waited[L.rulebook]) {
-        V3D_CHECK_HIP(hipStreamWaitEvent(st, p->ev_rb[L.rulebook], 0));
-        waited[L.rulebook] = 1;
-      }
-    } else if (!reuse_rulebooks) {
-      rc = plan_layer_rulebook(p, l, rb_done, hash0_done, st, cand_done);
+    if (!reuse_rulebooks) {
+      rc = plan_layer_rulebook(p, l, rb_done, hash0_done, st, &cand_done);
       if (rc) return rc;
     }
     rc = plan_layer_conv(p, L, feat, L.wimg, L.weight, L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr,

@@ -747,7 +747,7 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigne
 // enough: the fragments of offset k are in registers before the requests of k + 1 overwrite the slot piece by piece, each piece
 // behind the MFMA group that consumed it.
 // The pass of T tiles per wave as a device function: the kernel below picks T per LAUNCH from the live row count (device-side).
-template <int CIN, int COUT, int T, int K, int STAGE, int DBG>  // DBG 4 (experiment, wrong results): quad-coalesced register gathers
+template <int CIN, int COUT, int T, int K, int STAGE>
 __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in, const unsigned short* __restrict__ wimg,
                                                    const int* __restrict__ nbr, const int n, int cap, const float* __restrict__ scale,
                                                    const float* __restrict__ shift, int relu, float* __restrict__ out,
@@ -798,9 +798,8 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
 #pragma unroll
       for (int t = 0; t < T; t++) {
         int sq = (k < K && row0 + t * 16 + (STAGE ? (lane >> 2) : r) < n) ? sidx[t] : -1;
-        if (DBG & 4) sq = __shfl(sq, lane >> 2);
         prow[t] = (sq >= 0 ? in + (size_t)sq * CIN : spr_zero_row) +
-                  (STAGE ? ((lane & 3) ^ ((lane >> 5) & 1)) * 4 : ((DBG & 4) ? (lane & 3) * 4 : kg * 8));
+                  (STAGE ? ((lane & 3) ^ ((lane >> 5) & 1)) * 4 : kg * 8);
       }
     };
     const unsigned slot0 = STAGE ? __builtin_amdgcn_readfirstlane(lds_addr_of(aslot) + wave * (T * CIN * 64)) : 0u;
@@ -810,10 +809,10 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
         asm_dma16(prow[t] + (ki * 2 + 1) * 16, slot0 + t * (CIN * 64) + (ki * 2 + 1) * 1024);
       } else if (ki == 0) {
         asm_gld16(a[t * KI * 2], prow[t]);
-        if (DBG & 4) asm_gld16_64(a[t * KI * 2 + 1], prow[t]); else asm_gld16_16(a[t * KI * 2 + 1], prow[t]);
+        asm_gld16_16(a[t * KI * 2 + 1], prow[t]);
       } else {
         asm_gld16_128(a[t * KI * 2 + 2], prow[t]);
-        if (DBG & 4) asm_gld16_192(a[t * KI * 2 + 3], prow[t]); else asm_gld16_144(a[t * KI * 2 + 3], prow[t]);
+        asm_gld16_144(a[t * KI * 2 + 3], prow[t]);
       }
     };
     f32x4 acc[T][NB];
@@ -928,7 +927,7 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
 // round of 256 workgroups; beyond, 256-row passes would need a second, nearly empty round (49 -> 91 us in the frame, round 4
 // trace) -- three tiles per wave keep up to 98 304 rows in one round.  Both bodies live in the one kernel (registers and LDS of the
 // larger); every wave of the grid reads the same count, so the choice is uniform.
-template <int CIN, int COUT, int TMAX, int K, int STAGE = 1, int DBG = 0>
+template <int CIN, int COUT, int TMAX, int K, int STAGE = 1>
 __global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __restrict__ in,
                                                               const unsigned short* __restrict__ wimg,
                                                               const int* __restrict__ nbr, const int* __restrict__ n_ptr,
@@ -941,11 +940,11 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __res
   const int n = min(*n_ptr, cap);
   if constexpr (TMAX == 3) {
     if (n > 2 * 128 * 256)
-      spconv_kouter_body<CIN, COUT, 3, K, STAGE, DBG>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot);
+      spconv_kouter_body<CIN, COUT, 3, K, STAGE>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot);
     else
-      spconv_kouter_body<CIN, COUT, 2, K, STAGE, DBG>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot);
+      spconv_kouter_body<CIN, COUT, 2, K, STAGE>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot);
   } else {
-    spconv_kouter_body<CIN, COUT, TMAX, K, STAGE, DBG>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot);
+    spconv_kouter_body<CIN, COUT, TMAX, K, STAGE>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot);
   }
 }
 
@@ -977,7 +976,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __res
 // sat just above 8 192 rows in its three stage-2 layers).  More tiles per workgroup share the same weight rounds (the movers' work
 // does not grow) and put up to 16 waves on the CU, whose matrix pipes idle half of a two-tile round: the caller picks the smallest
 // TILES that keeps the expected row count inside ONE round.
-template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int DBG = 0, int TILES = 2>  // DBG (experiments, wrong results): 1 no gathers, 2 no weight DMA, 3 neither
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int TILES = 2>
 __global__ __launch_bounds__((TILES * OG + NMV) * 64) void spconv_fwd_rows_ring(const float* __restrict__ in,
                                                                           const unsigned short* __restrict__ wimg,
                                                                           const int* __restrict__ nbr,
@@ -1035,7 +1034,7 @@ __global__ __launch_bounds__((TILES * OG + NMV) * 64) void spconv_fwd_rows_ring(
     const unsigned char* gsrc = wsrc + (size_t)(R) * RB;                                                            \
     _Pragma("unroll") for (int i = 0; i < FPM; i++) {                                                               \
       const bool ok = (R) * OG + (mv * FPM + i) / NF < K;                                                           \
-      if (!(DBG & 2)) __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + i * 1024 - (ok ? 0 : WBYTES)),                               \
+      __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + i * 1024 - (ok ? 0 : WBYTES)),                               \
                                        (lptr_t)(SPR_RING(R) + (mv * FPM + i) * 1024), 16, 0, 0);                    \
     }                                                                                                               \
   }
@@ -1073,7 +1072,7 @@ __global__ __launch_bounds__((TILES * OG + NMV) * 64) void spconv_fwd_rows_ring(
   const int rsel = STAGE ? (lane >> 2) : r;  // the tile row whose index this lane holds: its MFMA row / its DMA row
   const float* prow = spr_zero_row;  // this lane's slice of the row being requested
   auto row_ptr = [&](int src_i) {
-    const int src = (DBG & 1) ? -1 : src_i;
+    const int src = src_i;
     prow = (src >= 0 ? in + (size_t)src * CIN : spr_zero_row) + (STAGE ? ((lane & 3) ^ ((lane >> 5) & 1)) * 4 : kg * 8);
   };
   const unsigned slot0 = STAGE ? __builtin_amdgcn_readfirstlane(lds_addr_of(aslot) + wv * (ALOOK * CIN * 64)) : 0u;
@@ -1220,10 +1219,10 @@ __global__ __launch_bounds__((TILES * OG + NMV) * 64) void spconv_fwd_rows_ring(
 #undef SPR_RING
 }
 
-template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int DBG = 0, int TILES = 2>
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int TILES = 2>
 static int launch_rows_ring(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
                             const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
-  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, DBG, TILES>), dim3(v3d_ceil_div(cap, 16 * TILES)),
+  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES>), dim3(v3d_ceil_div(cap, 16 * TILES)),
                      dim3((TILES * OG + NMV) * 64), 0, st, in, (const unsigned short*)wimg, nbr, n_ptr, cap, scale, shift, relu, out);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
@@ -1238,12 +1237,12 @@ static void launch_rows_big(const float* in, const void* wimg, const int* nbr, c
                        (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out);
 }
 
-template <int CIN, int COUT, int T, int STAGE = 1, int DBG = 0>
+template <int CIN, int COUT, int T, int STAGE = 1>
 static void launch_rows_kouter(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
                                const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
   const int passes = v3d_ceil_div(cap, 16 * (T == 3 ? 2 : T) * 8);  // (T = 3: the kernel may walk 256-row passes)
   const int grid = passes >= 256 ? 256 : ((passes + 7) / 8) * 8;  // a multiple of 8: the pass -> XCD map assumes it
-  hipLaunchKernelGGL((spconv_fwd_rows_kouter<CIN, COUT, T, 27, STAGE, DBG>), dim3(grid), dim3(512), 0, st, in, (const unsigned short*)wimg,
+  hipLaunchKernelGGL((spconv_fwd_rows_kouter<CIN, COUT, T, 27, STAGE>), dim3(grid), dim3(512), 0, st, in, (const unsigned short*)wimg,
                      nbr, n_ptr, cap, scale, shift, relu, out);
 }
 
@@ -1276,31 +1275,11 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
       V3D_CHECK_LAUNCH();
       return V3D_OK;
     }
-#ifdef V3D_EXPERIMENTS
-    if (K == 27 && force == 26) { launch_rows_kouter<CIN, COUT, 2, 0, 4>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st); return V3D_OK; }
-    if (K == 27 && force == 21) return launch_rows_ring<CIN, COUT, 3, 3, 2, 2, 0, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
-    if (K == 27 && force == 22) return launch_rows_ring<CIN, COUT, 3, 3, 2, 2, 0, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
-    if (K == 27 && force == 23) return launch_rows_ring<CIN, COUT, 3, 3, 2, 2, 0, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
-#endif
     // the two-tile LDS-ring kernel (3x3x3 only, <= 16 384 rows).  10 = the form chosen per shape by measurement (same box, KITTI
     // layers): 64->64 rows staged through LDS, one slot, 2 weight buffers, 4 movers (11.2 -> 9.9 us at 8 160 rows); 32->32 staged,
     // two slots, 2 movers (8.4 -> 7.4 us at 13 731 rows); 32->64 / 64->32 register gathers, 3 weight buffers (7.2 us; staged 7.6-8.3).
     // 16 = the register-gather form for every shape (cross-check).
     if (K == 27 && (force == 10 || force == 16 || (force >= 12 && force <= 14) || (force == 0 && rows_hint <= V3D_RING_ROWS))) {
-#ifdef V3D_EXPERIMENTS
-      static const int ring_form = [] { const char* e = getenv("V3D_RING_REGS"); return e ? atoi(e) : 0; }();  // A/B in whole-frame runs
-      // ablations inside the whole frame (results wrong by construction; tools/ring_dbg_in_frame.sh): 1 no gathers, 2 no weight
-      // stream, 3 neither.  One frame at a time the register-gather ring takes 14.8 / 12.4 / 11.8 / 11.6 us at 64 -> 64: a floor of
-      // ~11.6 us that is neither gathers nor weights (isolated, back to back: 11.1 us WITH both).  Not the dead workgroups of the
-      // capacity-sized grid either: a grid sized from the expected rows with a strided tile loop measured the same 14.3 us.
-      static const int ring_dbg = [] { const char* e = getenv("V3D_RING_DBG"); return e ? atoi(e) : 0; }();
-      if (force == 0 && ring_dbg == 1) return launch_rows_ring<CIN, COUT, 3, 3, 2, 2, 0, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
-      if (force == 0 && ring_dbg == 2) return launch_rows_ring<CIN, COUT, 3, 3, 2, 2, 0, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
-      if (force == 0 && ring_dbg == 3) return launch_rows_ring<CIN, COUT, 3, 3, 2, 2, 0, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
-#else
-      constexpr int ring_form = 0;
-#endif
-      if (ring_form == 1 && force == 0) return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
       // (measured and not kept: two offsets per round + two weight buffers + register gathers = 69 KB of LDS at 64 -> 64, so that
       // two such workgroups -- the same layer of another frame in flight -- or one and an 80-pixel dense tile could share a CU:
       // 12.9 vs 10.0 us in isolation and 3 121 vs 3 306 frames/s pipelined)
@@ -1311,9 +1290,9 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
           // the count the plan was tuned on; force 12 / 13 / 14 pin the 2 / 3 / 4-tile form (tests, microbenchmarks)
           const long long want = force ? 0 : (long long)rows_hint + rows_hint / 10;
           const int tiles = force == 12 ? 2 : force == 13 ? 3 : force == 14 ? 4 : (want <= 32 * 256 ? 2 : want <= 48 * 256 ? 3 : 4);
-          if (tiles == 2) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 0, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
-          if (tiles == 3) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 0, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
-          return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 0, 4>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+          if (tiles == 2) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+          if (tiles == 3) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+          return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 4>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
         }
       }
       if (force != 16 && CIN == 32 && COUT == 32) return launch_rows_ring<CIN, COUT, 3, 2, 2, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
