@@ -25,7 +25,9 @@
 #define PROP_MAX_TOPK 1024
 #define PROP_MAX_CLS 16
 #define PROP_RANK_SORT_MAX 256  // candidate lists up to this (padded) length are rank-sorted, longer ones by a bitonic network
-#define PROP_CHUNKS 40  // upper bound of level-1 slices per (frame, class) group (40 x topk 100 <= 4096 merge inputs)
+#ifndef PROP_CHUNKS
+#define PROP_CHUNKS 40
+#endif  // upper bound of level-1 slices per (frame, class) group (40 x topk 100 <= 4096 merge inputs)
 
 struct PropGeom {
   int B, n_cls, n_yaw, HW, topk, ctot;  // ctot = n_cls*n_yaw*(1+7) channels of the fused head map

@@ -449,13 +449,17 @@ static int plan_layer_rulebook(v3d_backbone* p, size_t l, std::vector<char>& rb_
 // out = act((sum_k feat[nbr[k]] @ W[k]) * scale + shift) of layer l: the packed bf16x3 kernels where the reduction dim fills
 // an MFMA (Cin >= 16), the exact-fp32 wave kernel else
 static int plan_layer_conv(v3d_backbone* p, PlanLayer& L, const float* feat, const void* wimg, const float* weight,
-                           const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
+                           const float* scale, const float* shift, int relu, float* out, hipStream_t st,
+                           const V3dDensifyOut* densify = nullptr, bool* densified = nullptr) {
   const v3d_backbone_config& c = p->cfg;
   PlanStage& so = p->stages[L.stage_out];
   int rc = V3D_EUNSUPPORTED;
-  if (c.conv_algo == 4 || (c.conv_algo == 0 && L.d.cin >= 16))
+  if (densified) *densified = false;
+  if (c.conv_algo == 4 || (c.conv_algo == 0 && L.d.cin >= 16)) {
     rc = v3d_i_sparse_conv_fwd_packed(feat, wimg, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout, scale, shift,
-                                      relu, out, L.rows_hint, st);
+                                      relu, out, L.rows_hint, st, densify);
+    if (rc == V3D_OK && densify && densified) *densified = true;
+  }
   if (rc == V3D_EUNSUPPORTED)
     rc = v3d_sparse_conv_fwd(feat, weight, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout, scale, shift, relu,
                              out, (c.conv_algo == 4 || c.conv_algo == 0) ? 3 : c.conv_algo, st);
@@ -469,14 +473,24 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
   const float* feat = p->mean;
   // the candidate pass of a strided layer rides in the launch that produces its input sites' last table (rulebook.hip RbCandJob)
   std::vector<char> cand_done(p->layers.size(), 0);
+  bool densified = false;
   for (size_t l = 0; l < p->layers.size(); l++) {
     PlanLayer& L = p->layers[l];
     if (!reuse_rulebooks) {
       rc = plan_layer_rulebook(p, l, rb_done, hash0_done, st, &cand_done);
       if (rc) return rc;
     }
+    // the LAST layer writes the plan's own BEV planes from its epilogue (.dense() without a launch of its own) where it runs the
+    // 16-row kernel anyway: not 3x3x3 (the SECOND backbone ends in a (3, 1, 1) layer) and below the 64-row kernel's row counts
+    V3dDensifyOut dn{};
+    const bool want_dn = l + 1 == p->layers.size() && !dense_out && dense_hi == p->bev_hi && dense_lo == p->bev_lo && dense_hi &&
+                         L.K != 27 && L.rows_hint < 32768 && L.d.cin >= 16 && L.d.cout % 16 == 0;
+    if (want_dn) {
+      const PlanStage& sl = p->stages.back();
+      dn = V3dDensifyOut{sl.coords, sl.shape[0], sl.shape[1], sl.shape[2], p->bev_hi, p->bev_lo, p->bev_occ, p->bev_pix, p->bev_pix_n};
+    }
     rc = plan_layer_conv(p, L, feat, L.wimg, L.weight, L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr,
-                         L.d.relu, L.out, st);
+                         L.d.relu, L.out, st, want_dn ? &dn : nullptr, &densified);
     if (rc) return rc;
     feat = L.out;
   }
@@ -485,7 +499,7 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
     rc = v3d_densify(feat, sl.coords, sl.n_dev, sl.cap, B, p->out_channels, sl.shape, dense_out, st);
     if (rc) return rc;
   }
-  if (dense_hi || dense_lo) {
+  if ((dense_hi || dense_lo) && !densified) {
     PlanStage& sl = p->stages.back();
     const bool own = dense_hi == p->bev_hi && dense_lo == p->bev_lo;  // (plan_clear_own_planes ran at the start of this frame)
     rc = v3d_i_densify_nhwc_split(feat, sl.coords, sl.n_dev, sl.cap, B, p->out_channels, sl.shape, dense_hi, dense_lo, p->bev_occ,

@@ -430,13 +430,21 @@ extern "C" int v3d_debug_rows_timeline(unsigned long long* host_out) {
 #define SPR_STAMP(idx)
 #endif
 
+// fp32 -> bf16, round to nearest even (inf / nan truncated): the split of dense_conv.hip's planes, hi = rne(x), lo = rne(x - hi)
+__device__ __forceinline__ unsigned short spr_bf16_rne(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
 template <int CIN, int COUT>
 __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __restrict__ in,
                                                              const unsigned short* __restrict__ wimg,
                                                              const int* __restrict__ nbr, const int* __restrict__ n_ptr,
                                                              int cap, int K, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, int relu,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, const V3dDensifyOut dn) {
   // workgroup = 16 output rows; its 4 waves split the K kernel offsets (wave w takes k = w, w+4, ...), keep
   // private register accumulators and meet ONCE, in the epilogue, where the 4 partial tiles are summed in a
   // fixed order (deterministic).  4x more waves in flight and a 4x shorter dependent chain per wave than one
@@ -563,9 +571,22 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
         if (scale) v = v * sc + sh;
         if (relu) v = fmaxf(v, 0.f);
         out[(size_t)row * COUT + col] = v;
+        if (dn.hi) {  // .dense() of the last layer: the row straight into the split BEV planes (see V3dDensifyOut)
+          const int4 c = reinterpret_cast<const int4*>(dn.coords)[row];
+          const int pixel = (c.x * dn.H + c.z) * dn.W + c.w;
+          const size_t o = (size_t)pixel * ((size_t)COUT * dn.D) + (size_t)col * dn.D + c.y;
+          const unsigned short h = spr_bf16_rne(v);
+          reinterpret_cast<unsigned short*>(dn.hi)[o] = h;
+          reinterpret_cast<unsigned short*>(dn.lo)[o] = spr_bf16_rne(v - __uint_as_float((unsigned)h << 16));
+          if (col == 0) {
+            if (dn.occ) atomicAnd(dn.occ + ((size_t)c.x * dn.H + c.z) * ((dn.W + 31) >> 5) + (c.w >> 5), ~(1u << (c.w & 31)));
+            dn.pix[row] = pixel;
+          }
+        }
       }
     }
   }
+  if (dn.hi && blockIdx.x == 0 && tid == 0) *dn.pix_n = n;
   SPR_STAMP(14);
 }
 
@@ -1255,8 +1276,9 @@ static void launch_rows_kouter(const float* in, const void* wimg, const int* nbr
 #define V3D_RING_ROWS 16384  // two full rounds of 32-row workgroups on 256 CUs; beyond, the 16-row kernel wins again (36 k rows: 47 vs 53 us)
 template <int CIN, int COUT>
 static int launch_rows(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
-                       const float* scale, const float* shift, int relu, float* out, int rows_hint, hipStream_t st) {
-  const int force = rows_hint < 0 ? -rows_hint : 0;
+                       const float* scale, const float* shift, int relu, float* out, int rows_hint, hipStream_t st,
+                       const V3dDensifyOut* densify) {
+  const int force = densify ? 1 : (rows_hint < 0 ? -rows_hint : 0);  // .dense() rides in the 16-row kernel's epilogue only
   if constexpr (CIN >= 32 && CIN <= 64 && COUT >= 32 && COUT <= 64) {
     // the offset-outer persistent kernel (3x3x3 only; 6: rows staged through LDS, 7: rows gathered into registers): 64->64 at
     // 56 k rows 58 -> 47.5 us.  It needs a full round of 256-row passes to pay: the 32-channel shapes and the mid sizes stay on
@@ -1301,7 +1323,7 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
   }
   const size_t lds = (size_t)4 * (COUT / 16) * 4 * 64 * 4 + (size_t)K * 16 * 4;
   hipLaunchKernelGGL((spconv_fwd_rows<CIN, COUT>), dim3(v3d_ceil_div(cap, 16)), dim3(V3D_BLOCK), lds, st, in,
-                     (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out);
+                     (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, densify ? *densify : V3dDensifyOut{});
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -1316,12 +1338,12 @@ extern "C" int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_im
 
 int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                  int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
-                                 float* out, int rows_hint, hipStream_t st) {
+                                 float* out, int rows_hint, hipStream_t st, const V3dDensifyOut* densify) {
   if (!in || !weight_image || !nbr || !n_out || !out || cap_out < 1 || K < 1) return V3D_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return V3D_EINVAL;
 #define V3D_TRY(ci, co) \
   if (Cin == ci && Cout == co)  \
-    return launch_rows<ci, co>(in, weight_image, nbr, n_out, cap_out, K, scale, shift, relu, out, rows_hint, st);
+    return launch_rows<ci, co>(in, weight_image, nbr, n_out, cap_out, K, scale, shift, relu, out, rows_hint, st, densify);
   V3D_TRY(4, 16)
   V3D_TRY(16, 16)
   V3D_TRY(16, 32)

@@ -52,10 +52,21 @@ int v3d_i_nms_sorted(const void* prep_sorted, const int* order, int N, float iou
 
 int v3d_i_nms_mask_sorted(const void* prep_sorted, int N, float iou_threshold, unsigned long long* mask, hipStream_t st);
 
+// .dense() riding in the epilogue of the LAST sparse layer (the 16-row kernel): besides its rows the layer writes them, split into
+// bf16 hi / lo, into the plan's persistent BEV planes out[(b * H + y) * W + x][c * D + z], clears the pixel's bit in the inverted
+// occupancy bitmap and lists the pixel -- what densify_split_kernel (dense_conv.hip) does in a launch of its own.
+struct V3dDensifyOut {
+  const int32_t* coords;  // (cap, 4) = (b, z, y, x) of the layer's OUTPUT rows
+  int D, H, W;
+  void *hi, *lo;          // hi == nullptr: off
+  uint32_t* occ;          // nullable
+  int32_t *pix, *pix_n;   // written pixel list of the persistent planes
+};
 // spconv.hip: v3d_sparse_conv_fwd_packed with an explicit estimate of the live row count (kernel choice only)
 int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                  int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
-                                 float* out, int rows_hint, hipStream_t st);
+                                 float* out, int rows_hint, hipStream_t st, const V3dDensifyOut* densify = nullptr /*the 16-row
+                                 kernel is used whatever the row count; V3D_EUNSUPPORTED if the shape has no packed kernel*/);
 
 // spconv.hip: several packed weight images in one launch (mode 0: W (K, Cin, Cout); 1 / 2: the transposed layer of a source
 // (K, Cout, Cin), 2 with the offsets reversed)
