@@ -310,6 +310,13 @@ uint32_t* v3d_backbone_bev_occupancy(v3d_backbone* plan);
  * instead of filling 2 x 9 MB per KITTI frame -- what .dense() (detector/sparse_cnn.py:128-133: zeros + scatter) costs.  Valid until the
  * next forward into them; nobody else may write them. */
 int v3d_backbone_bev_planes(v3d_backbone* plan, void** hi, void** lo);
+/* The tail of the SECOND dense head in ONE launch: RPN up-conv 1x1 128 -> 128 (+ folded BatchNorm bias + ReLU, detector/second.py:73-79)
+ * followed by the fused [cls | reg] 1x1 head 128 -> Cout2 <= 16 (detector/proposal.py:19-22), split planes (B, H, W, 128) in, fp32
+ * NCHW (B, Cout2, H, W) out; w1_image / w2_image from v3d_conv2d_pack_weights(.., ksize 1).  Bit-identical to v3d_conv2d_nhwc_bf16x3
+ * applied twice; the intermediate planes never exist.  V3D_EUNSUPPORTED for other widths. */
+int v3d_conv2d_1x1_head_fused(const void* x_hi, const void* x_lo, const void* w1_image, const float* b1, int relu1,
+                              const void* w2_image, const float* b2, int relu2, int B, int H, int W, int Cmid, int Cout2,
+                              float* y_nchw, v3d_stream_t stream);
 int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias, int relu, int B,
                               int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo, float* y_nchw,
                               const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo,

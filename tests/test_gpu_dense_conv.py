@@ -164,7 +164,9 @@ def test_background_left_in_place_across_frames_is_bit_identical():
             got = dense.forward(hi, lo, occ=occ, work=state)
             assert torch.equal(full, got), f"frame {j} (seed {seed})"
             assert int(state.counters.abs().sum()) == 0
-            live = [t.clone() for t in state.tiles]
+            # (with the fused tail -- the default -- the 1x1 up-conv runs inside the head's launch on every pixel: its planes and
+            # tile states are not used)
+            live = [t.clone() for t in (state.tiles[:-1] if dense.fuse_tail else state.tiles)]
             for t in live:
                 assert set(t.unique().tolist()) <= {0, 1}
                 assert 0 < int(t.sum()) < t.numel()  # a sparse map: some tiles convolve, some hold the response
@@ -277,3 +279,53 @@ def test_background_skipping_on_an_empty_and_a_full_map():
         hi, lo = to_split_nhwc(x)
         every = torch.zeros((h, (w + 31) // 32), dtype=torch.int32, device="cuda")
         assert torch.equal(dense.forward(hi, lo), dense.forward(hi, lo, occ=every))
+
+
+@pytest.mark.parametrize("b,h,w,cout2", [(1, 200, 176, 16), (2, 37, 29, 14), (1, 5, 3, 16), (3, 64, 40, 8)])
+def test_fused_1x1_and_head_equal_the_two_launches_bit_for_bit(b, h, w, cout2):
+    """v3d_conv2d_1x1_head_fused (the RPN's 1x1 up-conv + ReLU and the fused [cls | reg] head on top, one pass over the pixels) against
+    the two launches it replaces -- the tile kernel writing split planes, then the streaming head kernel: identical bits, at the
+    KITTI map size, at sizes with a ragged last 16-pixel tile, with fewer than 16 head channels and at batch > 1."""
+    from vision3d_amd import _lib as L
+    from vision3d_amd.runtime import conv2d_split, pack_conv_weight, to_split_nhwc
+    g = torch.Generator().manual_seed(b * 1000 + h + cout2)
+    x = torch.randn(b, 128, h, w, generator=g).cuda()
+    w1 = (torch.randn(128, 128, 1, 1, generator=g) / 128 ** 0.5).cuda()
+    s1 = (torch.rand(128, generator=g) + 0.5).cuda()
+    b1 = (torch.randn(128, generator=g) * 0.2).cuda()
+    w2 = (torch.randn(cout2, 128, 1, 1, generator=g) / 128 ** 0.5).cuda()
+    b2 = (torch.randn(cout2, generator=g) * 0.2).cuda()
+    hi, lo = to_split_nhwc(x)
+    img1, img2 = pack_conv_weight(w1, s1), pack_conv_weight(w2)
+    (m_hi, m_lo), _ = conv2d_split(hi, lo, img1, b1, True, 128, 128, 1, out_split=True, out_nchw=False)
+    _, two = conv2d_split(m_hi, m_lo, img2, b2, False, 128, cout2, 1, out_split=False, out_nchw=True)
+    fused = torch.empty_like(two)
+    L.check(L.lib().v3d_conv2d_1x1_head_fused(L.ptr(hi), L.ptr(lo), L.ptr(img1), L.ptr(b1), 1, L.ptr(img2), L.ptr(b2), 0, b, h, w, 128,
+                                              cout2, L.ptr(fused), L.stream_ptr()), "fused")
+    torch.cuda.synchronize()
+    assert torch.equal(fused, two)
+    ref = F.conv2d(F.relu(F.conv2d(x.double(), (w1 * s1.view(-1, 1, 1, 1)).double(), b1.double())), w2.double(), b2.double()).float()
+    assert_features_close(fused.cpu().numpy(), ref.cpu().numpy(), "fused tail vs float64")
+
+
+def test_dense_head_plan_with_and_without_the_fused_tail():
+    """DenseHeadPlan.forward with the fused tail (the default) and with the two launches: same head maps, bit for bit, with and
+    without background skipping on a real frame's BEV map."""
+    from vision3d_amd.detector import Second
+    cfg = second_car_cfg()
+    torch.manual_seed(0)
+    model = Second(cfg).cuda().eval()
+    randomize_bn(model, 1)
+    clouds = [torch.from_numpy(synth.make_cloud(3)).cuda()]
+    with torch.no_grad():
+        plan, flat, offsets = model._plan_for(clouds)
+        hi, lo = plan.forward_split(flat, offsets)
+        dense = model.dense_plan()
+        occ = plan.bev_occupancy(1)
+        outs = {}
+        for fuse in (True, False):
+            dense.fuse_tail = fuse
+            outs[fuse] = (dense.forward(hi, lo).clone(), dense.forward(hi, lo, occ=occ).clone())
+        dense.fuse_tail = True
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    assert torch.equal(outs[True][0], outs[True][1])

@@ -1128,6 +1128,149 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_small_cout_kernel(const bf
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The RPN's last layer (1x1, 128 -> 128, folded BatchNorm + ReLU: detector/second.py:73-79) and the fused [cls | reg] head on top of
+// it (1x1, 128 -> <= 16: detector/proposal.py:19-22) as ONE pass over the pixels.  Both are per-pixel products: as two launches they
+// cost 15.3 + 7.2 us of the KITTI frame for ~1 us of matrix work (the tile kernel's bitmap test, draw, epilogue and a 36 MB round
+// trip of the intermediate planes through HBM).  Here a wave owns 16 pixels: A fragments straight from the input planes (a lane's 8
+// channels = one 16-byte load), the 64 KB packed image of the 1x1 layer once per workgroup in LDS, 96 MFMAs into eight
+// accumulators (per accumulator the order of the tile kernels: k-steps ascending, lo*Wh, hi*Wl, hi*Wh within a step), then bias +
+// ReLU + the hi / lo split on the hardware converter exactly as the tile kernel's epilogue stores them, a transpose of the wave's
+// 16 x 128 tile through a private LDS slab into A fragments again, and the head's 12 MFMAs with its three term accumulators summed
+// (lh + hl) + hh + bias as in conv1x1_bf16x3_small_cout_kernel.  Bit-identical to the two launches it replaces
+// (tests/test_gpu_dense_conv.py); every pixel is computed (background included: same values as the skipping path, no tile state).
+// Persistent grid: <= one workgroup of FH_WAVES waves per CU, waves stride over the 16-pixel tiles.
+// ------------------------------------------------------------------------------------------------
+#define FH_WAVES 9  // 256 workgroups x 9 waves = 2 304 >= the 2 200 sixteen-pixel tiles of the 200 x 176 KITTI map: one tile per wave, no second pass
+#define FH_ROW 272                                  // bytes of one pixel row of a transpose slab (256 + 16: conflict-free 16-byte reads)
+#define FH_SLAB (2 * 16 * FH_ROW)                   // hi + lo planes of one wave's 16 x 128 tile
+#define FH_W1_BYTES (4 * 2 * 128 * 32 * 2)          // 4 k-steps x (hi, lo) x 128 couts x 32 cins, bf16
+#define FH_SMEM (FH_W1_BYTES + FH_WAVES * FH_SLAB)
+__global__ __launch_bounds__(FH_WAVES * 64) void conv1x1_head_fused_kernel(const bf16_t* __restrict__ x_hi, const bf16_t* __restrict__ x_lo,
+                                                                          const bf16_t* __restrict__ w1_img, const float* __restrict__ b1,
+                                                                          int relu1, const bf16_t* __restrict__ w2_img,
+                                                                          const float* __restrict__ b2, int relu2, int M, int HW,
+                                                                          int cout2, int cout2_pad, float* __restrict__ y_nchw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fh_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {  // the 1x1 layer's packed image, as it lies in memory: [step][plane][n-tile][lane][8]
+    const u32x4* src = reinterpret_cast<const u32x4*>(w1_img);
+    u32x4* dst = reinterpret_cast<u32x4*>(fh_smem);
+    for (int i = tid; i < FH_W1_BYTES / 16; i += FH_WAVES * 64) dst[i] = src[i];
+  }
+  // the head's packed weight column (n-tile 0, hi and lo of the four k-steps) lives in registers for all of the wave's tiles
+  u32x4 h_bh[4], h_bl[4];
+  {
+    const size_t pe2 = (size_t)cout2_pad * 32;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      h_bh[s] = *reinterpret_cast<const u32x4*>(w2_img + (size_t)s * 2 * pe2 + (size_t)lane * 8);
+      h_bl[s] = *reinterpret_cast<const u32x4*>(w2_img + (size_t)s * 2 * pe2 + pe2 + (size_t)lane * 8);
+    }
+  }
+  __syncthreads();
+  const unsigned char* w1s = fh_smem;
+  unsigned char* slab = fh_smem + FH_W1_BYTES + wave * FH_SLAB;
+  const int px_l = lane & 15, kg = lane >> 4;
+  const int ntiles = (M + 15) / 16;
+  for (int t = blockIdx.x * FH_WAVES + wave; t < ntiles; t += gridDim.x * FH_WAVES) {
+    const int m0 = t * 16;
+    const int px = min(m0 + px_l, M - 1);  // rows beyond M are computed on a clamped pixel and not stored
+    u32x4 ah[4], al[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      ah[s] = *reinterpret_cast<const u32x4*>(x_hi + (size_t)px * 128 + s * 32 + kg * 8);
+      al[s] = *reinterpret_cast<const u32x4*>(x_lo + (size_t)px * 128 + s * 32 + kg * 8);
+    }
+    f32x4 acc[8];
+#pragma unroll
+    for (int nf = 0; nf < 8; nf++) acc[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      u32x4 bh[8], bl[8];
+#pragma unroll
+      for (int nf = 0; nf < 8; nf++) {
+        bh[nf] = *reinterpret_cast<const u32x4*>(w1s + s * 16384 + (nf * 64 + lane) * 16);
+        bl[nf] = *reinterpret_cast<const u32x4*>(w1s + s * 16384 + 8192 + (nf * 64 + lane) * 16);
+      }
+      const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[s]), a_l = __builtin_bit_cast(bf16x8, al[s]);
+#pragma unroll
+      for (int nf = 0; nf < 8; nf++) acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, __builtin_bit_cast(bf16x8, bh[nf]), acc[nf], 0, 0, 0);
+#pragma unroll
+      for (int nf = 0; nf < 8; nf++) acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, __builtin_bit_cast(bf16x8, bl[nf]), acc[nf], 0, 0, 0);
+#pragma unroll
+      for (int nf = 0; nf < 8; nf++) acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, __builtin_bit_cast(bf16x8, bh[nf]), acc[nf], 0, 0, 0);
+    }
+    // bias + ReLU + split: D[pixel = kg * 4 + r][cout = nf * 16 + px_l] -> slab[plane][pixel][cout] (bf16)
+#pragma unroll
+    for (int nf = 0; nf < 8; nf++) {
+      const float bv = b1 ? b1[nf * 16 + px_l] : 0.f;
+#pragma unroll
+      for (int r2 = 0; r2 < 2; r2++) {
+        float v0 = acc[nf][2 * r2] + bv, v1 = acc[nf][2 * r2 + 1] + bv;
+        if (relu1) {
+          v0 = fmaxf(v0, 0.f);
+          v1 = fmaxf(v1, 0.f);
+        }
+        unsigned h, l;
+        split_pair(v0, v1, h, l);
+        const int p0 = kg * 4 + 2 * r2, off = (nf * 16 + px_l) * 2;
+        *reinterpret_cast<unsigned short*>(slab + p0 * FH_ROW + off) = (unsigned short)(h & 0xFFFFu);
+        *reinterpret_cast<unsigned short*>(slab + (p0 + 1) * FH_ROW + off) = (unsigned short)(h >> 16);
+        *reinterpret_cast<unsigned short*>(slab + 16 * FH_ROW + p0 * FH_ROW + off) = (unsigned short)(l & 0xFFFFu);
+        *reinterpret_cast<unsigned short*>(slab + 16 * FH_ROW + (p0 + 1) * FH_ROW + off) = (unsigned short)(l >> 16);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own slab: its LDS writes have landed (one wave, in order)
+    f32x4 c_lh = {0.f, 0.f, 0.f, 0.f}, c_hl = c_lh, c_hh = c_lh;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const u32x4 a2h = *reinterpret_cast<const u32x4*>(slab + px_l * FH_ROW + s * 64 + kg * 16);
+      const u32x4 a2l = *reinterpret_cast<const u32x4*>(slab + 16 * FH_ROW + px_l * FH_ROW + s * 64 + kg * 16);
+      c_lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a2l), __builtin_bit_cast(bf16x8, h_bh[s]), c_lh, 0, 0, 0);
+      c_hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a2h), __builtin_bit_cast(bf16x8, h_bl[s]), c_hl, 0, 0, 0);
+      c_hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a2h), __builtin_bit_cast(bf16x8, h_bh[s]), c_hh, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the fragment reads are done before the next tile overwrites the slab
+    const int co = px_l;
+    if (co < cout2) {
+      const float bv = b2 ? b2[co] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int m = m0 + kg * 4 + r;
+        if (m >= M) continue;
+        float v = ((c_lh[r] + c_hl[r]) + c_hh[r]) + bv;  // small terms first
+        if (relu2) v = fmaxf(v, 0.f);
+        const int b = m / HW, pix = m - b * HW;
+        y_nchw[((size_t)b * cout2 + co) * HW + pix] = v;
+      }
+    }
+  }
+}
+
+extern "C" int v3d_conv2d_1x1_head_fused(const void* x_hi, const void* x_lo, const void* w1_image, const float* b1, int relu1,
+                                         const void* w2_image, const float* b2, int relu2, int B, int H, int W, int Cmid, int Cout2,
+                                         float* y_nchw, v3d_stream_t stream) {
+  if (!x_hi || !x_lo || !w1_image || !w2_image || !y_nchw || B < 1 || H < 1 || W < 1) return V3D_EINVAL;
+  if (Cmid != 128 || Cout2 < 1 || Cout2 > 16) return V3D_EUNSUPPORTED;  // 128 -> 128 -> <= 16: the SECOND RPN tail
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    V3D_CHECK_HIP(hipGetDevice(&dev));
+    V3D_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const int M = B * H * W, ntiles = (M + 15) / 16;
+  const int grid = std::min(v3d_ceil_div(ntiles, FH_WAVES), n_cu);
+  const int cout2_pad = (Cout2 + DC_BN - 1) / DC_BN * DC_BN;
+  V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv1x1_head_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FH_SMEM));
+  hipLaunchKernelGGL(conv1x1_head_fused_kernel, dim3(grid), dim3(FH_WAVES * 64), FH_SMEM, (hipStream_t)stream, (const bf16_t*)x_hi,
+                     (const bf16_t*)x_lo, (const bf16_t*)w1_image, b1, relu1, (const bf16_t*)w2_image, b2, relu2, M, H * W, Cout2,
+                     cout2_pad, y_nchw);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 extern "C" int v3d_conv2d_bg_tiles(int B, int H, int W);
 extern "C" int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
                                       int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,

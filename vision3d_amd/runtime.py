@@ -514,6 +514,8 @@ class DenseHeadPlan(object):
     """RPN (conv+BN+ReLU stack, detector/second.py:58-94) + the two 1x1 heads (proposal.py:19-22) as 8
     bf16x3 MFMA convolutions with folded BatchNorm; weights re-packed automatically when tensors change."""
 
+    fuse_tail = True  # False: the 1x1 up-conv and the head as two launches (cross-check of the fused kernel, tests)
+
     def __init__(self, rpn, head):
         self.rpn, self.head = rpn, head
         self._stamp = None
@@ -600,8 +602,23 @@ class DenseHeadPlan(object):
         feats = None
         bg = self.background(x_hi.shape[1], x_hi.shape[2], x_hi.device) if occ is not None else None
         reach = 0
+        head = self.layers[-1]
+        # the RPN's 1x1 up-conv and the 1x1 head on top of it as ONE pass over the pixels (v3d_conv2d_1x1_head_fused: same bits as the
+        # two launches) whenever nobody asks for the RPN features themselves
+        fuse_tail = (self.fuse_tail and not want_features and head is not None and len(self.layers) >= 2
+                     and self.layers[-2]["k"] == 1 and self.layers[-2]["cin"] == 128 and self.layers[-2]["cout"] == 128
+                     and head["k"] == 1 and head["cin"] == 128 and head["cout"] <= 16)
         for i, ly in enumerate(self.layers[:-1]):
             last = i == len(self.layers) - 2
+            if last and fuse_tail:
+                b, h, w, _ = x_hi.shape
+                maps = torch.empty((b, head["cout"], h, w), dtype=torch.float32, device=x_hi.device)
+                with torch.cuda.device(x_hi.device):
+                    L.check(L.lib().v3d_conv2d_1x1_head_fused(L.ptr(x_hi), L.ptr(x_lo), L.ptr(ly["img"]), L.ptr(ly["bias"]),
+                                                              int(bool(ly["relu"])), L.ptr(head["img"]), L.ptr(head["bias"]),
+                                                              int(bool(head["relu"])), b, h, w, 128, head["cout"], L.ptr(maps),
+                                                              L.stream_ptr()), "conv2d_1x1_head_fused")
+                return maps
             reach += ly["k"] // 2
             (x_hi, x_lo), f = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"],
                                            out_split=True, out_nchw=want_features and last, occ=occ, reach=reach,
