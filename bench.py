@@ -663,7 +663,7 @@ def main():
                 graphed = model.pipelined_inference(anchors, [c.shape[0] for c in clouds], args.pipeline or MAX_PIPELINE,
                                                     autotune=args.pipeline == 0)
                 if args.pipeline == 0:
-                    graphed.tune(clouds)  # outside warm-up and timed region
+                    graphed.tune(clouds, args.steps)  # outside warm-up and timed region; timed on windows of --steps frames
             else:
                 graphed = model.graphed_inference(anchors, [c.shape[0] for c in clouds])
     last_out = [None]

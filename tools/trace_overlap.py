@@ -29,7 +29,8 @@ def main():
         last = t
         active[n] = active.get(n, 0) + d
     wall = t1 - t0
-    frames = sum(1 for e in ev if e[2].startswith("densify_split"))
+    # one per-frame launch marks a frame: the fill at its start (plan_frame_start_kernel since round 4, v3d_fill + densify before)
+    frames = sum(1 for e in ev if e[2].startswith("plan_frame_start")) or sum(1 for e in ev if e[2].startswith("densify_split"))
     print(f"steady-state window {wall / 1e6:.2f} ms, {frames} frames -> {wall / 1e3 / max(frames, 1):.1f} us per frame; queues: {sorted(set(e[3] for e in ev))}")
     for k in sorted(busy):
         print(f"  {k}{'+' if k == 3 else ' '} kernels running: {100.0 * busy[k] / wall:5.1f} % of the time  ({busy[k] / 1e3 / max(frames, 1):6.1f} us per frame)")

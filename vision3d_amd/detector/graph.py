@@ -91,7 +91,7 @@ class GraphedSecond(object):
         return head.finalize(*self.outputs)
 
 
-def choose_streams(time_of, n_candidates, max_depth, min_gain=0.03):
+def choose_streams(time_of, n_candidates, max_depth, min_gain=0.015):
     """The selection rule of PipelinedSecond.tune, free of any device: `time_of(ids)` -> seconds per frame with the
     candidate streams `ids` (one slot each).  Every pair is timed and the best kept; a further stream is added
     greedily -- the one that gives the shortest time -- as long as that beats the current set by `min_gain`.
@@ -167,9 +167,11 @@ class PipelinedSecond(object):
 
     # ---- stream selection by measurement ---------------------------------------------------------------------
     def _time_streams(self, streams, clouds, frames):
+        """seconds per frame of ONE window of `frames` frames on these streams: pipeline empty at its start, the frames still in
+        flight collected inside it -- the definition of a timed window of the benchmark (best of three)."""
         import time
         best = None
-        for _ in range(2):
+        for _ in range(3):
             torch.cuda.synchronize()
             t0, inflight = time.perf_counter(), []
             for f in range(frames):
@@ -186,17 +188,22 @@ class PipelinedSecond(object):
             best = t if best is None else min(best, t)
         return best
 
-    def tune(self, clouds):
-        """Pick the stream set (and depth <= len(slots)) that gives the shortest time per frame on THIS frame."""
+    def tune(self, clouds, window_frames=None):
+        """Pick the stream set (and depth <= len(slots)) that gives the shortest time per frame on THIS frame.
+        window_frames: how many frames the caller's timed windows hold (bench.py: --steps).  The best depth depends on it -- a
+        window starts with an empty pipeline and ends when its last frame is collected, so short windows reward a deeper pipeline
+        (more frames start at once) while long ones are decided by the steady state, where a fourth frame in flight only adds
+        contention (round 4, same box: 20-frame windows 3 705 vs 3 594 frames/s at depth 4 vs 3, 300-frame windows 3 616 vs 3 747).
+        The candidates are therefore timed on windows of that length (8 ... 64 frames)."""
+        frames = self.TUNE_FRAMES if window_frames is None else max(self.TUNE_FRAMES, min(int(window_frames), 64))
         dev = self.slots[0].static_points.device
         cands = [torch.cuda.Stream(device=dev) for _ in range(self.CANDIDATE_STREAMS)]
         for i in range(len(self.slots)):  # capture every slot (tunes the plans on the real frame), one at a time
             self._launch(i, cands[0], clouds)
             self._finish(i, cands[0])
-        chosen, log = choose_streams(lambda ids: self._time_streams([cands[x] for x in ids], clouds, self.TUNE_FRAMES + len(ids) - 2),
-                                     len(cands), len(self.slots) - 1)
+        chosen, log = choose_streams(lambda ids: self._time_streams([cands[x] for x in ids], clouds, frames), len(cands), len(self.slots) - 1)
         self.streams = [cands[x] for x in chosen]
-        self.tuned = dict(depth=len(chosen), us_per_frame={k: round(v * 1e6, 1) for k, v in log.items()})
+        self.tuned = dict(depth=len(chosen), window_frames=frames, us_per_frame={k: round(v * 1e6, 1) for k, v in log.items()})
         self.pending, self.next_slot, self.next_stream = [], 0, 0
         return self.tuned
 
