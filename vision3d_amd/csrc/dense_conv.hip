@@ -799,9 +799,13 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
 #define D2_HALF (D2_PIECES * 1024)
 #define D2_PLANE (2 * D2_HALF)
 static_assert(2 * D2_PLANE <= dl_smem(D2_TH), "the neighbourhood image lives in the tile kernel's LDS request");
-__device__ __forceinline__ void dl_tile2d(unsigned char* smem_l, const bf16_t* __restrict__ x_hi, const bf16_t* __restrict__ x_lo,
+// Returns true (workgroup-uniform) when the tile was LIVE and the workgroup's next tile has already been drawn into *s_next: the
+// draw -- an atomic round trip of ~1.5 us -- is issued behind the matrix phase by one thread of a loader wave and travels while the
+// epilogue stores, instead of standing between this tile's last store and the next tile.  (Asking at the START of a live tile hands
+// tiles to workgroups that stay busy for 15 us: 21 -> 32 us; at this point the workgroup is one epilogue away from being free.)
+__device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* __restrict__ x_hi, const bf16_t* __restrict__ x_lo,
                                           const bf16_t* __restrict__ w_img, const float* __restrict__ bias, const DcParams& p,
-                                          bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo, const int mtile) {
+                                          bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo, const int mtile, int* s_next) {
   constexpr int MT = D2_TH, BM = MT * 16;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -826,7 +830,7 @@ __device__ __forceinline__ void dl_tile2d(unsigned char* smem_l, const bf16_t* _
     }
     if (!__builtin_amdgcn_readfirstlane(__ballot(near_any) != 0ull)) {
       if (p.tile_state) {
-        if (in_place == 0u) return;  // the response is already in place (workgroup-uniform: one word)
+        if (in_place == 0u) return false;  // the response is already in place (workgroup-uniform: one word)
         __syncthreads();             // every thread has read the word before it is cleared
         if (tid == 0) p.tile_state[mtile] = 0u;
       }
@@ -839,7 +843,7 @@ __device__ __forceinline__ void dl_tile2d(unsigned char* smem_l, const bf16_t* _
         *reinterpret_cast<u32x4*>(y_hi + dst) = *reinterpret_cast<const u32x4*>(p.bg_hi + src);
         *reinterpret_cast<u32x4*>(y_lo + dst) = *reinterpret_cast<const u32x4*>(p.bg_lo + src);
       }
-      return;
+      return false;
     }
   }
   if (p.tile_state && tid == 0) p.tile_state[mtile] = 1u;
@@ -960,6 +964,9 @@ __device__ __forceinline__ void dl_tile2d(unsigned char* smem_l, const bf16_t* _
 #undef D2_IC
   }
   __syncthreads();  // every fragment read is behind us: the image's LDS becomes the epilogue tile
+  const bool draws = s_next != nullptr && p.work != nullptr;
+  unsigned drawn = 0u;
+  if (draws && tid == 4 * 64) drawn = gridDim.x + atomicAdd(p.work, 1u);  // the next tile, requested now (see the header)
   // ---- epilogue (all 8 waves): accumulators -> LDS tile [80 px][128 + 4] fp32 -> bias + ReLU -> split planes
   float* tile = reinterpret_cast<float*>(smem_l);
   f32x4 eb0 = f32x4{0.f, 0.f, 0.f, 0.f}, eb1 = eb0;
@@ -1009,6 +1016,8 @@ __device__ __forceinline__ void dl_tile2d(unsigned char* smem_l, const bf16_t* _
       }
     }
   }
+  if (draws && tid == 4 * 64) *s_next = (int)drawn;
+  return draws;
 }
 
 // persistent grid drawing 2-D tiles from the counter pair (see conv2d_bf16x3_large_kernel)
@@ -1024,8 +1033,8 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_tile2d_kernel(const 
   // (requesting the NEXT draw before the current tile starts hides the counter's round trip but hands tiles to workgroups
   // that are busy with a live one: 21.0 -> 32.4 us on the real frame)
   for (int mtile = blockIdx.x; mtile < ntiles;) {  // workgroup-uniform
-    dl_tile2d(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, mtile);
-    if (threadIdx.x == 0) s_next = (int)(gridDim.x + atomicAdd(p.work, 1u));
+    const bool drew = dl_tile2d(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, mtile, &s_next);
+    if (!drew && threadIdx.x == 0) s_next = (int)(gridDim.x + atomicAdd(p.work, 1u));
     __syncthreads();  // everyone is done with this tile's LDS
     mtile = s_next;
     __syncthreads();  // ... and has read s_next
