@@ -329,6 +329,15 @@ int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, const void* we
                               background tile whose word is 0 already holds it and is not written at all; the kernel keeps the
                               words up to date.  Reset them to nonzero when the weights (hence bg_hi / bg_lo) change*/,
                               v3d_stream_t stream);
+/* The same call with the counter pair reset by ANOTHER launch: reset_ptr != NULL makes this launch zero reset_words words at
+ * reset_ptr when it starts (the pairs of call sites whose launches lie behind it in stream order) and leave its own `work` pair as it
+ * ends -- some later launch of the caller's zeroes it.  Saves the atomic round trip every workgroup of a self-resetting launch ends
+ * on.  A chain of layers resets like this: the first layer zeroes the pairs of all the others (the previous frame's), the second
+ * the first layer's.  `work` must read zero at launch. */
+int v3d_conv2d_nhwc_bf16x3_bg2(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias, int relu, int B,
+                               int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo, float* y_nchw,
+                               const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo, uint32_t* work,
+                               uint32_t* tile_state, uint32_t* reset_ptr, int reset_words, v3d_stream_t stream);
 int v3d_conv2d_bg_tiles(int B, int H, int W);
 /* .dense() of the last sparse stage straight into that input format: planes (B,H,W,C*D), channel = c*D + z. */
 int v3d_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,

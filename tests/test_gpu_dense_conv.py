@@ -163,7 +163,7 @@ def test_background_left_in_place_across_frames_is_bit_identical():
             full = dense.forward(hi, lo)
             got = dense.forward(hi, lo, occ=occ, work=state)
             assert torch.equal(full, got), f"frame {j} (seed {seed})"
-            assert int(state.counters.abs().sum()) == 0
+            # (the layers of a persistent state zero each other's tile counters at their start: the pairs are not zero between frames)
             # (with the fused tail -- the default -- the 1x1 up-conv runs inside the head's launch on every pixel: its planes and
             # tile states are not used)
             live = [t.clone() for t in (state.tiles[:-1] if dense.fuse_tail else state.tiles)]

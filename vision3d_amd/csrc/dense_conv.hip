@@ -217,6 +217,10 @@ struct DcParams {
   const bf16_t* bg_hi;   // that response for ONE image, (H, W, Cout) split planes
   const bf16_t* bg_lo;
   unsigned* work;        // [2] tile counter + workgroups-done counter of the persistent grid (zero between launches)
+  unsigned* reset_ptr;   // nullable.  NULL: the pair resets ITSELF (last workgroup out -- every workgroup then ends on an atomic round
+  int reset_words;       // trip, ~1.5 us at the end of every launch).  Else: this launch zeroes reset_words words at reset_ptr when it
+                         // starts -- the counters of OTHER call sites, whose launches lie behind it in stream order -- and leaves
+                         // its own pair for a later launch to zero (runtime.DenseHeadPlan chains the layers that way)
   unsigned* tile_state;  // nullable, one word per tile of a PERSISTENT output buffer: nonzero = the tile holds computed values.
                          // The empty-map response of a layer does not depend on the frame, so a background tile whose state
                          // is 0 already holds it from an earlier frame and is not written at all.
@@ -1032,6 +1036,8 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_tile2d_kernel(const 
   // continue behind the grid
   // (requesting the NEXT draw before the current tile starts hides the counter's round trip but hands tiles to workgroups
   // that are busy with a live one: 21.0 -> 32.4 us on the real frame)
+  if (p.reset_ptr && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < p.reset_words; i += DL_THREADS) p.reset_ptr[i] = 0u;
   for (int mtile = blockIdx.x; mtile < ntiles;) {  // workgroup-uniform
     const bool drew = dl_tile2d(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, mtile, &s_next);
     if (!drew && threadIdx.x == 0) s_next = (int)(gridDim.x + atomicAdd(p.work, 1u));
@@ -1039,7 +1045,7 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_tile2d_kernel(const 
     mtile = s_next;
     __syncthreads();  // ... and has read s_next
   }
-  if (threadIdx.x == 0 && atomicAdd(p.work + 1, 1u) == gridDim.x - 1) {  // last workgroup out: every draw has happened
+  if (!p.reset_ptr && threadIdx.x == 0 && atomicAdd(p.work + 1, 1u) == gridDim.x - 1) {  // last workgroup out: every draw has happened
     p.work[0] = 0u;
     p.work[1] = 0u;
   }
@@ -1071,6 +1077,8 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
     return;
   }
   const int ntiles = (p.M + MT * 16 - 1) / (MT * 16);
+  if (p.reset_ptr && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < p.reset_words; i += DL_THREADS) p.reset_ptr[i] = 0u;
   // (the first tile of a workgroup is its own index: no round trip to the counter in front of it)
   for (int mtile = blockIdx.x; mtile < ntiles;) {  // workgroup-uniform
     dl_tile<KS, MT>(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, y_nchw, mtile);
@@ -1079,7 +1087,7 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
     mtile = s_next;
     __syncthreads();  // ... and has read s_next
   }
-  if (threadIdx.x == 0 && atomicAdd(p.work + 1, 1u) == gridDim.x - 1) {  // last workgroup out: every draw has happened
+  if (!p.reset_ptr && threadIdx.x == 0 && atomicAdd(p.work + 1, 1u) == gridDim.x - 1) {  // last workgroup out: every draw has happened
     p.work[0] = 0u;
     p.work[1] = 0u;
   }
@@ -1325,6 +1333,16 @@ extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, con
                                          int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
                                          float* y_nchw, const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo,
                                          uint32_t* work, uint32_t* tile_state, v3d_stream_t stream) {
+  return v3d_conv2d_nhwc_bf16x3_bg2(x_hi, x_lo, weight_image, bias, relu, B, H, W, Cin, Cout, ksize, y_hi, y_lo, y_nchw, occ, reach, bg_hi,
+                                    bg_lo, work, tile_state, nullptr, 0, stream);
+}
+
+extern "C" int v3d_conv2d_nhwc_bf16x3_bg2(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
+                                          int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
+                                          float* y_nchw, const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo,
+                                          uint32_t* work, uint32_t* tile_state, uint32_t* reset_ptr, int reset_words,
+                                          v3d_stream_t stream) {
+  if (reset_ptr && (reset_words < 0 || reset_words > 4096 || !work)) return V3D_EINVAL;
   if (!x_hi || !x_lo || !weight_image || B < 1 || H < 1 || W < 1 || Cout < 1) return V3D_EINVAL;
   if (occ && (!bg_hi || !bg_lo || reach < 0 || reach > 64)) return V3D_EINVAL;
   if (Cin < DC_KC || Cin % DC_KC || (ksize != 1 && ksize != 3)) return V3D_EUNSUPPORTED;
@@ -1344,6 +1362,8 @@ extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, con
   p.bg_lo = (const bf16_t*)bg_lo;
   p.work = nullptr;
   p.tile_state = nullptr;
+  p.reset_ptr = nullptr;
+  p.reset_words = 0;
   hipStream_t st = (hipStream_t)stream;
   if (ksize == 1 && !y_hi && Cout <= 16 && (Cin == 128 || Cin == 256)) {  // the head: stream kernel
     const dim3 sgrid(v3d_ceil_div(v3d_ceil_div(p.M, 16), 4));
@@ -1371,6 +1391,8 @@ extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, con
     if (persistent && ksize == 3 && Cin == DL_KC) {  // 2-D tiles with an LDS-resident neighbourhood
       p.work = work;
       p.tile_state = tile_state;
+      p.reset_ptr = reset_ptr;
+      p.reset_words = reset_words;
       const int tiles2 = B * v3d_ceil_div(H, D2_TH) * v3d_ceil_div(W, D2_TW);
       const int smem2 = std::max(dl_smem(D2_TH), 84 * 1024);
       V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv2d_bf16x3_tile2d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
@@ -1383,6 +1405,8 @@ extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, con
     const int tiles = v3d_ceil_div(p.M, mt * 16);
     p.work = persistent ? work : nullptr;
     p.tile_state = persistent ? tile_state : nullptr;
+    p.reset_ptr = persistent ? reset_ptr : nullptr;
+    p.reset_words = persistent ? reset_words : 0;
     if (tile_state && y_hi && !persistent)  // every pixel of the persistent buffer is about to be computed
       V3D_CHECK_HIP(v3d_fill_async(tile_state, 0x01, (size_t)v3d_conv2d_bg_tiles(B, H, W) * sizeof(uint32_t), st));
     dim3 lgrid(persistent ? std::min(tiles, n_cu) : tiles, p.CoutPad / DC_BN);

@@ -437,7 +437,7 @@ def split_planes_like(b, h, w, c, device):
 
 
 def conv2d_split(x_hi, x_lo, image, bias, relu, cin, cout, ksize, out_split=True, out_nchw=False, occ=None, reach=0, bg=None, work=None,
-                 out=None, tile_state=None):
+                 out=None, tile_state=None, reset=None):
     """One bf16x3 convolution on split NHWC planes; returns (y_hi, y_lo) and/or fp32 (B,cout,H,W).
     occ / reach / bg = (bg_hi, bg_lo) [/ work: 2 zeroed int32 of the caller's, see the header]: background skipping
     (v3d_conv2d_nhwc_bf16x3_bg), same values.  out = (y_hi, y_lo): write into these planes; with tile_state (one int32 per
@@ -454,12 +454,15 @@ def conv2d_split(x_hi, x_lo, image, bias, relu, cin, cout, ksize, out_split=True
         y = torch.empty((b, cout, h, w), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         if occ is not None and bg is not None:
-            L.check(L.lib().v3d_conv2d_nhwc_bf16x3_bg(L.ptr(x_hi), L.ptr(x_lo), L.ptr(image), L.ptr(bias), int(bool(relu)), b, h,
-                                                      w, cin, cout, ksize, L.ptr(y_hi), L.ptr(y_lo), L.ptr(y), L.ptr(occ),
-                                                      int(reach), L.ptr(bg[0]), L.ptr(bg[1]), L.ptr(work),
-                                                      L.ptr(tile_state) if (work is not None and out is not None) else None,
-                                                      L.stream_ptr()),
-                    "conv2d_nhwc_bf16x3_bg")
+            # reset = (int32 tensor, words): OTHER call sites' counters this launch zeroes at its start (words may be 0) instead of
+            # resetting its own pair at its end (v3d_conv2d_nhwc_bf16x3_bg2; DenseHeadPlan.forward chains the layers)
+            L.check(L.lib().v3d_conv2d_nhwc_bf16x3_bg2(L.ptr(x_hi), L.ptr(x_lo), L.ptr(image), L.ptr(bias), int(bool(relu)), b, h,
+                                                       w, cin, cout, ksize, L.ptr(y_hi), L.ptr(y_lo), L.ptr(y), L.ptr(occ),
+                                                       int(reach), L.ptr(bg[0]), L.ptr(bg[1]), L.ptr(work),
+                                                       L.ptr(tile_state) if (work is not None and out is not None) else None,
+                                                       (reset[0].data_ptr() if reset is not None else None),
+                                                       (int(reset[1]) if reset is not None else 0), L.stream_ptr()),
+                    "conv2d_nhwc_bf16x3_bg2")
         else:
             L.check(L.lib().v3d_conv2d_nhwc_bf16x3(L.ptr(x_hi), L.ptr(x_lo), L.ptr(image), L.ptr(bias), int(bool(relu)), b, h, w,
                                                    cin, cout, ksize, L.ptr(y_hi), L.ptr(y_lo), L.ptr(y), L.stream_ptr()),
@@ -608,6 +611,11 @@ class DenseHeadPlan(object):
         fuse_tail = (self.fuse_tail and not want_features and head is not None and len(self.layers) >= 2
                      and self.layers[-2]["k"] == 1 and self.layers[-2]["cin"] == 128 and self.layers[-2]["cout"] == 128
                      and head["k"] == 1 and head["cin"] == 128 and head["cout"] <= 16)
+        # Tile counters of a persistent state: the layers reset each other's pairs (the first launched layer zeroes the pairs of all the
+        # others -- left by the previous frame --, the second the first's) instead of every launch ending on the atomic round trip
+        # of a self-resetting pair; needs at least two launched skipping layers
+        n_skip = len(self.layers) - 1 - (1 if fuse_tail else 0)
+        chain = state is not None and occ is not None and n_skip >= 2
         for i, ly in enumerate(self.layers[:-1]):
             last = i == len(self.layers) - 2
             if last and fuse_tail:
@@ -624,7 +632,8 @@ class DenseHeadPlan(object):
                                            out_split=True, out_nchw=want_features and last, occ=occ, reach=reach,
                                            bg=None if bg is None else bg[i], work=None if work is None else work[2 * i:2 * i + 2],
                                            out=None if state is None else state.out[i],
-                                           tile_state=None if state is None else state.tiles[i])
+                                           tile_state=None if state is None else state.tiles[i],
+                                           reset=None if not chain else ((work[2:], work.numel() - 2) if i == 0 else (work, 2 if i == 1 else 0)))
             feats = f if last else feats
         ly = self.layers[-1]
         if ly is None:
