@@ -159,6 +159,16 @@ def test_ring_kernel_tiles_per_workgroup(oracle):
         assert_features_close(outs[0], ref, f"ring 2 tiles n={n}")
         np.testing.assert_array_equal(outs[0], outs[1], err_msg=f"3 tiles vs 2, n={n}")
         np.testing.assert_array_equal(outs[0], outs[2], err_msg=f"4 tiles vs 2, n={n}")
+    # the grid is capped at what the chip holds at once and every workgroup strides over the live tile groups: on 40 003 rows of a
+    # 7-frame batch the 2-tile form (1 251 tile groups) takes five trips per workgroup, the 4-tile form three -- same bits, and the
+    # 16-row kernel's result within the feature bar
+    coords = kitti_coords(oracle, [1, 2, 3, 4, 5, 6, 7])[:40003]
+    feats = rng.standard_normal((len(coords), 64)).astype(np.float32)
+    x = make_tensor(coords, feats, shape, 7)
+    rb = build_subm_rulebook(x, [3, 3, 3])
+    big = [sparse_conv_forward(x.features, dev(w), rb, dev(sc), dev(sh), True, 4, None, v).cpu().numpy() for v in (12, 14, 1)]
+    np.testing.assert_array_equal(big[0], big[1])
+    assert_features_close(big[0], big[2], "ring (strided grid) vs 16-row kernel")
 
 
 def test_offset_outer_kernel_picks_its_pass_size_from_the_live_row_count(oracle):

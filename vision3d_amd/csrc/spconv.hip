@@ -997,14 +997,11 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __res
 // sat just above 8 192 rows in its three stage-2 layers).  More tiles per workgroup share the same weight rounds (the movers' work
 // does not grow) and put up to 16 waves on the CU, whose matrix pipes idle half of a two-tile round: the caller picks the smallest
 // TILES that keeps the expected row count inside ONE round.
-template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int TILES = 2>
-__global__ __launch_bounds__((TILES * OG + NMV) * 64) void spconv_fwd_rows_ring(const float* __restrict__ in,
-                                                                          const unsigned short* __restrict__ wimg,
-                                                                          const int* __restrict__ nbr,
-                                                                          const int* __restrict__ n_ptr, int cap,
-                                                                          const float* __restrict__ scale,
-                                                                          const float* __restrict__ shift, int relu,
-                                                                          float* __restrict__ out) {
+// (the body of one workgroup's TILES tiles; the kernel behind it loops over the live tile groups)
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK, int STAGE, int TILES>
+__device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, const unsigned short* __restrict__ wimg,
+                                                 const int* __restrict__ nbr, const int n, int cap, const float* __restrict__ scale,
+                                                 const float* __restrict__ shift, int relu, float* __restrict__ out, const int wg_in) {
   // OG = offsets per round = multiplying waves per tile.  OG = 3: 9 rounds, 3 round buffers, 6 + 2 waves.
   // OG = 2: 14 rounds (the 28th offset is a zero row), 4 round buffers (three rounds of weights in flight), 4 + 2
   // waves -- one multiplying wave per SIMD.  Measured slower (64->64 at 8 160 rows: 12.3 vs 13.0 us): the cost of a round
@@ -1030,13 +1027,11 @@ __global__ __launch_bounds__((TILES * OG + NMV) * 64) void spconv_fwd_rows_ring(
   __shared__ int nbr_all[TILES * K * 16];
   __shared__ __attribute__((aligned(16))) unsigned char aslot[STAGE ? NCW * ALOOK * CIN * 64 : 16];  // [wave][slot][piece][16 rows][64 B]
 #define SPR_RING(i) ((i) % NBUF == 0 ? wb0 : ((i) % NBUF == 1 ? wb1 : ((i) % NBUF == 2 ? wb2 : wb3)))
-  const int n = min(*n_ptr, cap);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int wg = blockIdx.x;
+  int wg = wg_in;
   {
-    const int nwg = (n + 16 * TILES - 1) / (16 * TILES);  // live workgroups; each XCD (private L2) walks one contiguous run
-    if (wg >= nwg) return;
+    const int nwg = (n + 16 * TILES - 1) / (16 * TILES);  // live tile groups; each XCD (private L2) walks one contiguous run
     const int qd = nwg / 8, rmd = nwg % 8, xcd = wg % 8, idx = wg / 8;
     wg = (xcd < rmd ? xcd * (qd + 1) : rmd * (qd + 1) + (xcd - rmd) * qd) + idx;  // bijective on [0, nwg)
   }
@@ -1240,10 +1235,45 @@ __global__ __launch_bounds__((TILES * OG + NMV) * 64) void spconv_fwd_rows_ring(
 #undef SPR_RING
 }
 
+// The grid is what the chip holds at once (launch_rows_ring), not the capacity's, and every workgroup strides over the live tile
+// groups (normally one each).  Why: a 64 -> 64 workgroup owns a CU's LDS, so of a capacity-sized grid (1 026
+// workgroups for a 32 k-row capacity, ~255 of them live) the dead tail cannot be PLACED until a live workgroup retires -- the
+// dispatcher sits on this kernel for its whole duration and, with several frames in flight, no other frame's kernel starts beside
+// it (round-4 overlap trace: the ring kernels ran alone 99.8 % of their time, the dense tile kernel 69 %).
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int TILES = 2>
+__global__ __launch_bounds__((TILES * OG + NMV) * 64) void spconv_fwd_rows_ring(const float* __restrict__ in,
+                                                                          const unsigned short* __restrict__ wimg,
+                                                                          const int* __restrict__ nbr,
+                                                                          const int* __restrict__ n_ptr, int cap,
+                                                                          const float* __restrict__ scale,
+                                                                          const float* __restrict__ shift, int relu,
+                                                                          float* __restrict__ out) {
+  const int n = min(*n_ptr, cap);
+  const int nwg = (n + 16 * TILES - 1) / (16 * TILES);
+  // (the XCD-contiguous remap inside the body is a bijection of [0, nwg) for ANY set of indices below nwg)
+  for (int g = blockIdx.x; g < nwg; g += gridDim.x) {
+    spconv_ring_body<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES>(in, wimg, nbr, n, cap, scale, shift, relu, out, g);
+    __syncthreads();  // the next group's weight DMA and partial sums reuse this group's LDS
+  }
+}
+
 template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int TILES = 2>
 static int launch_rows_ring(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
-                            const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
-  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES>), dim3(v3d_ceil_div(cap, 16 * TILES)),
+                            const float* scale, const float* shift, int relu, float* out, hipStream_t st, int rows_hint = 0) {
+  // grid: never more workgroups than the chip can hold AT ONCE (occupancy of this instantiation x CUs, a multiple of 8 for the XCD
+  // map) -- every workgroup is placed the moment the kernel is dispatched -- and never more than the capacity needs
+  (void)rows_hint;
+  static int slots = 0;  // (same for every device of a node: one GPU type)
+  if (!slots) {
+    int dev = 0, n_cu = 0, per_cu = 0;
+    V3D_CHECK_HIP(hipGetDevice(&dev));
+    V3D_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    V3D_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES>,
+                                                               (TILES * OG + NMV) * 64, 0));
+    slots = std::max(8, per_cu * n_cu / 8 * 8);
+  }
+  const int grid = std::min(v3d_ceil_div(cap, 16 * TILES), slots);
+  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES>), dim3(grid),
                      dim3((TILES * OG + NMV) * 64), 0, st, in, (const unsigned short*)wimg, nbr, n_ptr, cap, scale, shift, relu, out);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
@@ -1312,13 +1342,13 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
           // the count the plan was tuned on; force 12 / 13 / 14 pin the 2 / 3 / 4-tile form (tests, microbenchmarks)
           const long long want = force ? 0 : (long long)rows_hint + rows_hint / 10;
           const int tiles = force == 12 ? 2 : force == 13 ? 3 : force == 14 ? 4 : (want <= 32 * 256 ? 2 : want <= 48 * 256 ? 3 : 4);
-          if (tiles == 2) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
-          if (tiles == 3) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
-          return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 4>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+          if (tiles == 2) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, rows_hint);
+          if (tiles == 3) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, rows_hint);
+          return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 4>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, rows_hint);
         }
       }
-      if (force != 16 && CIN == 32 && COUT == 32) return launch_rows_ring<CIN, COUT, 3, 2, 2, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
-      return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
+      if (force != 16 && CIN == 32 && COUT == 32) return launch_rows_ring<CIN, COUT, 3, 2, 2, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, rows_hint);
+      return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, rows_hint);
     }
   }
   const size_t lds = (size_t)4 * (COUT / 16) * 4 * 64 * 4 + (size_t)K * 16 * 4;
