@@ -310,6 +310,11 @@ uint32_t* v3d_backbone_bev_occupancy(v3d_backbone* plan);
  * instead of filling 2 x 9 MB per KITTI frame -- what .dense() (detector/sparse_cnn.py:128-133: zeros + scatter) costs.  Valid until the
  * next forward into them; nobody else may write them. */
 int v3d_backbone_bev_planes(v3d_backbone* plan, void** hi, void** lo);
+/* Kernel choice of the following forwards: on != 0 = THROUGHPUT mode, for plans whose frames run beside other frames on the same GPU
+ * (one plan per frame in flight): the LDS-filling 64 -> 64 sparse kernel takes four 16-row tiles per workgroup whatever the row count --
+ * fewer, fatter workgroups: ~39 % less CU-time per launch, ~20 % longer launches (results are bit-identical either way).  Default off:
+ * the shortest launch (one frame at a time). */
+int v3d_backbone_set_throughput_mode(v3d_backbone* plan, int on);
 /* The tail of the SECOND dense head in ONE launch: RPN up-conv 1x1 128 -> 128 (+ folded BatchNorm bias + ReLU, detector/second.py:73-79)
  * followed by the fused [cls | reg] 1x1 head 128 -> Cout2 <= 16 (detector/proposal.py:19-22), split planes (B, H, W, 128) in, fp32
  * NCHW (B, Cout2, H, W) out; w1_image / w2_image from v3d_conv2d_pack_weights(.., ksize 1).  Bit-identical to v3d_conv2d_nhwc_bf16x3

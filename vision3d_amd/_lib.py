@@ -76,6 +76,7 @@ _SIGNATURES = {
     "v3d_bev_occupancy_bits": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "v3d_backbone_bev_occupancy": (_vp, [_vp]),
     "v3d_backbone_bev_planes": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "v3d_backbone_set_throughput_mode": (_i, [_vp, _i]),
     "v3d_conv2d_nhwc_bf16x3_bg": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "v3d_conv2d_nhwc_bf16x3_bg2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "v3d_conv2d_bg_tiles": (_i, [_i, _i, _i]),

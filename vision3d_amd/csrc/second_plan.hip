@@ -71,6 +71,7 @@ struct v3d_backbone {
   // an 18 MB fill per KITTI frame) before it writes its own.
   void *bev_hi = nullptr, *bev_lo = nullptr;
   int32_t *bev_pix = nullptr, *bev_pix_n = nullptr;
+  int ring_tiles_min = 2;  // v3d_backbone_set_throughput_mode: 4
   struct PlanTrain* train = nullptr;  // training buffers, allocated by the first v3d_backbone_train_forward
   // (Measured and removed in round 4: the rulebook chain on a second stream with one event per finished rulebook -- inside a
   // captured graph the fork / join costs more than the overlap returns, 3 209 -> 2 526 frames/s pipelined)
@@ -331,6 +332,12 @@ static int plan_clear_own_planes(v3d_backbone* p, void* dense_hi, void* dense_lo
   return v3d_i_bev_clear_pixels(p->bev_pix, p->bev_pix_n, sl.cap, p->out_channels * sl.shape[0], p->bev_hi, p->bev_lo, st);
 }
 
+extern "C" int v3d_backbone_set_throughput_mode(v3d_backbone* p, int on) {
+  if (!p) return V3D_EINVAL;
+  p->ring_tiles_min = on ? 4 : 2;
+  return V3D_OK;
+}
+
 extern "C" int v3d_backbone_bev_planes(v3d_backbone* p, void** hi, void** lo) {
   if (!p || !hi || !lo) return V3D_EINVAL;
   *hi = p->bev_hi;
@@ -457,7 +464,7 @@ static int plan_layer_conv(v3d_backbone* p, PlanLayer& L, const float* feat, con
   if (densified) *densified = false;
   if (c.conv_algo == 4 || (c.conv_algo == 0 && L.d.cin >= 16)) {
     rc = v3d_i_sparse_conv_fwd_packed(feat, wimg, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout, scale, shift,
-                                      relu, out, L.rows_hint, st, densify);
+                                      relu, out, L.rows_hint, st, densify, p->ring_tiles_min);
     if (rc == V3D_OK && densify && densified) *densified = true;
   }
   if (rc == V3D_EUNSUPPORTED)

@@ -1307,7 +1307,7 @@ static void launch_rows_kouter(const float* in, const void* wimg, const int* nbr
 template <int CIN, int COUT>
 static int launch_rows(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
                        const float* scale, const float* shift, int relu, float* out, int rows_hint, hipStream_t st,
-                       const V3dDensifyOut* densify) {
+                       const V3dDensifyOut* densify, int tiles_min) {
   const int force = densify ? 1 : (rows_hint < 0 ? -rows_hint : 0);  // .dense() rides in the 16-row kernel's epilogue only
   if constexpr (CIN >= 32 && CIN <= 64 && COUT >= 32 && COUT <= 64) {
     // the offset-outer persistent kernel (3x3x3 only; 6: rows staged through LDS, 7: rows gathered into registers): 64->64 at
@@ -1341,7 +1341,11 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
           // moves from frame to frame (KITTI stage 2: 8 100 - 8 700 rows), so the tile count is picked with 10 % of headroom over
           // the count the plan was tuned on; force 12 / 13 / 14 pin the 2 / 3 / 4-tile form (tests, microbenchmarks)
           const long long want = force ? 0 : (long long)rows_hint + rows_hint / 10;
-          const int tiles = force == 12 ? 2 : force == 13 ? 3 : force == 14 ? 4 : (want <= 32 * 256 ? 2 : want <= 48 * 256 ? 3 : 4);
+          // tiles_min (the plan's throughput mode): with several frames in flight what counts is the CU-time of a launch, not its
+          // duration -- 4 204 rows are 132 two-tile workgroups x 10.6 us or 66 four-tile workgroups x ~13 us, 39 % less CU-time that
+          // another frame's kernels use (same box: 3 820 -> 3 875 / 3 970 frames/s pipelined, 0.451 -> 0.462 ms one frame at a time)
+          int tiles = force == 12 ? 2 : force == 13 ? 3 : force == 14 ? 4 : (want <= 32 * 256 ? 2 : want <= 48 * 256 ? 3 : 4);
+          if (!force && tiles < tiles_min) tiles = tiles_min > 4 ? 4 : tiles_min;
           if (tiles == 2) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, rows_hint);
           if (tiles == 3) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, rows_hint);
           return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 4>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, rows_hint);
@@ -1368,12 +1372,12 @@ extern "C" int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_im
 
 int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                  int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
-                                 float* out, int rows_hint, hipStream_t st, const V3dDensifyOut* densify) {
+                                 float* out, int rows_hint, hipStream_t st, const V3dDensifyOut* densify, int ring_tiles_min) {
   if (!in || !weight_image || !nbr || !n_out || !out || cap_out < 1 || K < 1) return V3D_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return V3D_EINVAL;
 #define V3D_TRY(ci, co) \
   if (Cin == ci && Cout == co)  \
-    return launch_rows<ci, co>(in, weight_image, nbr, n_out, cap_out, K, scale, shift, relu, out, rows_hint, st, densify);
+    return launch_rows<ci, co>(in, weight_image, nbr, n_out, cap_out, K, scale, shift, relu, out, rows_hint, st, densify, ring_tiles_min);
   V3D_TRY(4, 16)
   V3D_TRY(16, 16)
   V3D_TRY(16, 32)

@@ -66,7 +66,9 @@ struct V3dDensifyOut {
 int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                  int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
                                  float* out, int rows_hint, hipStream_t st, const V3dDensifyOut* densify = nullptr /*the 16-row
-                                 kernel is used whatever the row count; V3D_EUNSUPPORTED if the shape has no packed kernel*/);
+                                 kernel is used whatever the row count; V3D_EUNSUPPORTED if the shape has no packed kernel*/,
+                                 int ring_tiles_min = 2 /*64 -> 64 ring kernel: at least this many 16-row tiles per workgroup
+                                 (throughput mode of a plan: fewer, fatter workgroups = less CU-time per launch)*/);
 
 // spconv.hip: several packed weight images in one launch (mode 0: W (K, Cin, Cout); 1 / 2: the transposed layer of a source
 // (K, Cout, Cin), 2 with the offsets reversed)

@@ -139,6 +139,8 @@ class PipelinedSecond(object):
     def __init__(self, model, anchors, frame_sizes, depth=2, autotune=False):
         dev = next(model.parameters()).device
         self.slots = [GraphedSecond(model, anchors, frame_sizes, slot=i) for i in range(depth + 1)]
+        for g in self.slots:  # frames of different slots share the GPU: kernels chosen for CU-time, not for the shortest launch
+            g.plan.set_throughput_mode(True)
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
         self.autotune, self.tuned = bool(autotune), None
         self.pending = []  # (slot, stream index) in submission order

@@ -162,6 +162,12 @@ class BackbonePlan(object):
             return True
         return False
 
+    def set_throughput_mode(self, on=True):
+        """Kernels picked for frames that run BESIDE other frames on the GPU (v3d_backbone_set_throughput_mode): less CU-time per
+        launch, slightly longer launches; bit-identical results.  PipelinedSecond sets it on the plans of its slots.  Takes effect
+        at the next forward -- a captured graph keeps the kernels it was captured with."""
+        L.check(L.lib().v3d_backbone_set_throughput_mode(self._handle, int(bool(on))), "backbone_set_throughput_mode")
+
     def own_planes(self, batch_size):
         """The plan's PERSISTENT split BEV planes as (B, H, W, C_out * D) int16 views (v3d_backbone_bev_planes): a forward into
         them clears only the pixels the previous frame wrote instead of filling both planes.  They alias plan memory: valid until
