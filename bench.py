@@ -1,11 +1,11 @@
 """bench.py -- frames/sec of the SECOND forward on synthetic 16k-point KITTI-range clouds (BASELINE.json).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1 without a launcher: bench.py starts the N ranks itself, launch_plan)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one pass of the hot path over one batch (bs=1/GPU, configs[1]): device voxelizer + VFE -> 14-layer sparse 3-D conv
 backbone -> .dense() BEV -> dense RPN (MFMA, background tiles skipped) -> proposal stage (top-k, decode, rotated NMS, score
-cut), all hand-written HIP, replayed as one HIP graph (49 kernels) with a single 8-byte host read (proposal count + the plan's
+cut), all hand-written HIP, replayed as one HIP graph (37 kernels) with a single 8-byte host read (proposal count + the plan's
 capacity-overflow word).  The timed loop cycles through --stream (default 8) DIFFERENT clouds per rank, resident in HBM before
 the timed region.  By default several frames are in flight per GPU (one graph and plan arena per slot, one slot more than
 frames in flight; up to 4, streams and depth picked by measurement before the warm-up -- config.pipeline_tuning); every step
@@ -891,7 +891,11 @@ def main():
                             floor_us=t_mfma * 1e6)
         else:
             roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, floor_us=t_hbm * 1e6)
-        roofline.update(kernel=DOM_KERNEL, tiles_per_workgroup=tiles_per_wg, launches_per_frame=len(dom), bytes_per_launch=dom_bytes,
+        roofline.update(kernel=DOM_KERNEL, tiles_per_workgroup=tiles_per_wg,
+                        tiles_note="isolated timing and in-frame statistics: the latency form (2 / 3 tiles per workgroup by row count); the "
+                                   "pipelined graphs that produce `value` run the plan's throughput mode (4 tiles per workgroup: less "
+                                   "CU-time per launch, ~20 % longer launches, same bits)" if not kouter else None,
+                        launches_per_frame=len(dom), bytes_per_launch=dom_bytes,
                         avg_us=dom_t * 1e6, avg_us_in_frame=in_frame["avg_us"] if in_frame else None,
                         frac_in_frame=(in_frame["mfma_frac_algorithmic" if t_mfma >= t_hbm else "hbm_frac"] if in_frame else None),
                         in_frame=in_frame, traffic=traffic, traffic_source=traffic_src, hbm_view=hbm_view, mfma_view=mfma_view,
