@@ -1,4 +1,4 @@
-# round-4 GPU pass C: whole GPU suite, in-frame sequence timeline, pipelined bench (short + long windows)
+# one GPU pass: whole GPU suite, in-frame sequence timeline, pipelined bench (short + long windows)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 T=${1:-r4c}
 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 > gpurun_out/${T}_tests.txt

@@ -1,4 +1,4 @@
-# round-4 GPU pass D: whole suite + KITTI / Waymo one-frame sequence timelines + bench lines
+# one GPU pass: whole suite + KITTI / Waymo one-frame sequence timelines + bench lines
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 T=${1:-r4d}
 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 > gpurun_out/${T}_tests.txt
