@@ -167,6 +167,8 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
   }
   p->out_channels = cin;
 
+  for (const auto& st : p->stages)  // a site's row index rides in 24 bits of its table word (v3d_common.h)
+    if (st.cap > V3D_SITE_MAX_ROWS) { delete p; return V3D_EUNSUPPORTED; }
   // ---- pass 2: size and carve the arena (two passes over the same carving code)
   auto carve = [&](V3dArena& ar) {
     // ---- everything that must read 0xFF at the start of a forward is contiguous: ONE memset per frame

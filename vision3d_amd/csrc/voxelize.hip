@@ -276,6 +276,7 @@ int v3d_i_voxelize(const float* points, int n_points, int C, const int32_t* fram
     return V3D_OK;
   }
   if (!points || !workspace) return V3D_EINVAL;
+  if (site_hash && (long long)B * max_voxels > V3D_SITE_MAX_ROWS && n_points > V3D_SITE_MAX_ROWS) return V3D_EUNSUPPORTED;  // rows ride in 24 bits
   VoxParams p;
   for (int j = 0; j < 3; j++) {
     p.vs[j] = voxel_size_host[j];
