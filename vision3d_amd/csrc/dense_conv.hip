@@ -1396,6 +1396,8 @@ extern "C" int v3d_conv2d_nhwc_bf16x3_bg2(const void* x_hi, const void* x_lo, co
       const int tiles2 = B * v3d_ceil_div(H, D2_TH) * v3d_ceil_div(W, D2_TW);
       const int smem2 = std::max(dl_smem(D2_TH), 84 * 1024);
       V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv2d_bf16x3_tile2d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
+      // (persistent grid on fewer CUs, leaving the rest to other frames' kernels: 192 workgroups +1.8 % pipelined, +3.7 % latency;
+      //  128 neutral, +15 % latency -- profiles/r04_dense_grid.txt; not adopted)
       hipLaunchKernelGGL(conv2d_bf16x3_tile2d_kernel, dim3(std::min(tiles2, n_cu)), dim3(DL_THREADS), smem2, st, (const bf16_t*)x_hi,
                          (const bf16_t*)x_lo, (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo);
       V3D_CHECK_LAUNCH();
