@@ -52,6 +52,17 @@ REDUCE_DEVICE = "cuda" if BACKEND == "nccl" else "cpu"
 MAX_PIPELINE = int(os.environ.get("V3D_BENCH_MAX_PIPELINE", "4"))  # slots the autotuned pipeline may use
 
 
+DTYPE_NOTE = {
+    "fp32": "f16x3-scaled (fp32-class): fp32 operands split into f16 hi + lo pieces of x * s under per-tensor power-of-two scales, "
+            "3 MFMA terms (lo*hi + hi*lo + hi*hi), fp32 accumulate; relative product error 2^-22 -- the result differs from the "
+            "reference's fp32 modules by fp32 summation noise: strict elementwise relative error against float64 <= 2e-4 on entries "
+            "above 1e-3 of a layer's maximum, where torch's own fp32 conv3d shows up to 1.1e-4 (tests/test_gpu_conv3d_parity.py)",
+    "bf16x3": "bf16x3: fp32 operands split into bf16 hi + lo, 3 MFMA terms (lo*hi + hi*lo + hi*hi), fp32 accumulate -- a 16 x 16-bit "
+              "split product, relative product error 2^-17 (NOT fp32: 2^-24); strict elementwise relative error <= 3e-3 on entries "
+              "above 1e-3 of a layer's maximum (tests/test_gpu_conv3d_parity.py)",
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1,
@@ -78,6 +89,10 @@ def parse():
                          "exactly K frames.  0 (default): up to 4 in flight, streams and depth picked by measurement before the "
                          "warm-up (PipelinedSecond.tune); N >= 2: exactly N on streams in creation order; 1: one frame at a time "
                          "(always reported beside it as single_frame_ms / frames_per_s_one_at_a_time)")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="arithmetic of the native inference path: fp32 = f16 hi/lo pieces under calibrated power-of-two scales (the "
+                         "reference's fp32 modules up to summation noise); bf16x3 = bf16 pieces, 2^-17 per product (fast mode)")
+    ap.add_argument("--no-fast-mode", action="store_true", help="forward mode: skip the bf16x3 line measured beside the fp32-class one")
     ap.add_argument("--stream", type=int, default=8, help="different synthetic frames per rank the timed loop cycles through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch event timing pass (profiling runs)")
@@ -638,7 +653,7 @@ def main():
     if args.points is None:
         args.points = 180000 if waymo else 16384
     torch.manual_seed(0)
-    model = Second(cfg).cuda().eval()
+    model = Second(cfg).cuda().eval().set_precision(args.precision)
     pre = Preprocessor(cfg, seed=0)
     acfg = cfg
     if waymo:  # the reference's anchor grid truncates 150.4/0.4 (fp32) to 375 cells while the BEV map has 376:
@@ -777,9 +792,9 @@ def main():
         orig = convmod.sparse_conv_forward
         captured = []
 
-        def capture(features, weight, rb, scale=None, shift=None, relu=False, algo=0, packed=None, variant=0):
+        def capture(features, weight, rb, scale=None, shift=None, relu=False, algo=0, packed=None, variant=0, precision="bf16x3"):
             captured.append((features, weight, rb, scale, shift, relu, algo, packed))
-            return orig(features, weight, rb, scale, shift, relu, algo, packed, variant)
+            return orig(features, weight, rb, scale, shift, relu, algo, packed, variant, precision)
         convmod.sparse_conv_forward = capture
         with torch.no_grad():  # the per-op sparse backbone (Second.inference(item) itself runs the fused plan: nothing to capture there)
             it = pre(dict(points=clouds, anchors=anchors))
@@ -787,19 +802,36 @@ def main():
         convmod.sparse_conv_forward = orig
         REP, layers = 25, []
         side = torch.cuda.Stream()
+        from vision3d_amd import _lib as L
+        from vision3d_amd.runtime import act_entry_from_tensor
         for (features, weight, rb, scale, shift, relu, algo, packed) in captured:
-            if packed is None and features.shape[1] >= 16 and weight.shape[-1] % 16 == 0:
-                packed = convmod.pack_sparse_weight(weight.reshape(-1, weight.shape[-2], weight.shape[-1]).contiguous(),
-                                                    rb.nbr.shape[0], weight.shape[-2], weight.shape[-1])
+            cin_, cout_ = weight.shape[-2], weight.shape[-1]
+            packable = features.shape[1] >= 16 and cout_ % 16 == 0
+            if packable:  # the layer's kernel ALONE, in the arithmetic of the run (f16s: the scale entry is computed once, outside
+                # the timed launches -- in the frame it is a calibrated table entry, not a launch)
+                packed = convmod.pack_sparse_weight(weight.reshape(-1, cin_, cout_).contiguous(), rb.nbr.shape[0], cin_, cout_, args.precision)
+                entry = act_entry_from_tensor(features) if args.precision == "fp32" else None
+                out_buf = torch.empty((rb.n, cout_), dtype=torch.float32, device=features.device)
+                feat_c = features.contiguous()
+
+                def launch(feat_c=feat_c, packed=packed, rb=rb, scale=scale, shift=shift, relu=relu, out_buf=out_buf, entry=entry,
+                           cin_=cin_, cout_=cout_):
+                    L.check(L.lib().v3d_sparse_conv_fwd_packed2(L.ptr(feat_c), L.ptr(packed), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap,
+                                                                rb.nbr.shape[0], cin_, cout_, L.ptr(scale), L.ptr(shift), int(bool(relu)),
+                                                                L.ptr(out_buf), int(rb.n), L.PRECISIONS[args.precision], L.ptr(entry),
+                                                                None, None, L.stream_ptr()), "sparse_conv_fwd_packed2")
+            else:
+                def launch(features=features, weight=weight, rb=rb, scale=scale, shift=shift, relu=relu, algo=algo):
+                    orig(features, weight, rb, scale, shift, relu, algo, None)
             graph = torch.cuda.CUDAGraph()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), torch.no_grad():
-                orig(features, weight, rb, scale, shift, relu, algo, packed)  # warm-up outside the capture
+                launch()  # warm-up outside the capture
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             with torch.no_grad(), torch.cuda.graph(graph):
                 for _ in range(REP):
-                    orig(features, weight, rb, scale, shift, relu, algo, packed)
+                    launch()
             ts = []
             for trial in range(4):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -864,7 +896,7 @@ def main():
         mfma_view = dict(issued_tflops=mfma_issued / dom_t / 1e12, frac_issued=mfma_issued / dom_t / 1e12 / 2500.0,
                          useful_tflops=mfma_useful / dom_t / 1e12, algorithmic_tflops=mfma_alg / dom_t / 1e12,
                          frac_algorithmic=mfma_alg / dom_t / 1e12 / 2500.0, peak_tflops=2500.0,
-                         note="bf16 dense MFMA peak; 3 bf16 terms per product (hi*Wh + hi*Wl + lo*Wh); 'issued' includes the zero rows "
+                         note="dense 16-bit MFMA peak (bf16 = f16 rate); 3 terms per product (lo*Wh + hi*Wl + hi*Wh); 'issued' includes the zero rows "
                               "of absent neighbours, 'algorithmic' = 3 x useful (the floor of a split-precision product on this pipe)")
         # Which roof binds?  The time the launch would take at 100 % of each: A_min at 8 TB/s against the algorithmic matrix work at
         # the dense bf16 peak.  At 64 -> 64 the matrix pipe is the tighter one: `bound` names it and achieved / peak /
@@ -907,15 +939,17 @@ def main():
         from vision3d_amd.runtime import conv2d_split, pack_conv_weight, to_split_nhwc
         ny, nx = anchors.shape[2:4]
         cdim = cfg.PROPOSAL.C_IN
-        xh, xl = to_split_nhwc(torch.randn(args.batch, cdim, ny, nx, device="cuda"))
-        img = pack_conv_weight(torch.randn(cdim, cdim, 3, 3, device="cuda") / (9 * cdim) ** 0.5)
+        xh, xl = to_split_nhwc(torch.randn(args.batch, cdim, ny, nx, device="cuda"), args.precision)
+        img = pack_conv_weight(torch.randn(cdim, cdim, 3, 3, device="cuda") / (9 * cdim) ** 0.5, None, args.precision)
         bz = torch.zeros(cdim, device="cuda")
+        # (f16s: output entry for magnitudes up to 2^5 -- the unit-variance products of this microbenchmark stay far below)
+        pr_d = (xh.v3d_entry, torch.tensor([256.0, 1.0 / 256.0, 128.0, 0.0], device="cuda"), None) if args.precision == "fp32" else None
         for _ in range(3):
-            conv2d_split(xh, xl, img, bz, True, cdim, cdim, 3, out_split=True, out_nchw=False)
+            conv2d_split(xh, xl, img, bz, True, cdim, cdim, 3, out_split=True, out_nchw=False, pr=pr_d)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20):
-            conv2d_split(xh, xl, img, bz, True, cdim, cdim, 3, out_split=True, out_nchw=False)
+            conv2d_split(xh, xl, img, bz, True, cdim, cdim, 3, out_split=True, out_nchw=False, pr=pr_d)
         e1.record()
         torch.cuda.synchronize()
         t_dense = e0.elapsed_time(e1) * 1e-3 / 20
@@ -925,8 +959,8 @@ def main():
                               unit="TFLOP/s", frac=fl / t_dense / 1e12 / 2500.0, frac_issued=3 * fl / t_dense / 1e12 / 2500.0,
                               note="every tile convolved, random dense input (the frame itself runs the background-skipping "
                                    "2-D tile form, conv2d_bf16x3_tile2d_kernel, on a sparse map: fewer MFMAs and one LDS-resident "
-                                   "neighbourhood per tile instead of a gather per tap); peak = dense bf16 MFMA at the "
-                                   "data-sheet 2.4 GHz, 3 bf16 terms per fp32-class product; matrix instructions are spaced out by "
+                                   "neighbourhood per tile instead of a gather per tap); peak = dense 16-bit MFMA at the "
+                                   "data-sheet 2.4 GHz, 3 terms per split-precision product; matrix instructions are spaced out by "
                                    "power management, 16 busy cycles each (profiles/r02_e_dense_tile_timeline.txt)")
         tot_bytes = sum(l["bytes"] for l in layers)
         tot_t = sum(l["t_avg_us"] for l in layers) * 1e-6
@@ -971,6 +1005,48 @@ def main():
         except Exception as e:  # a reported extra
             stages.update(backbone_timing_error=repr(e)[:200])
 
+    # ---- the other arithmetic beside the headline: the same pipeline on a second model in bf16x3 (scale-free, 2^-17 per product),
+    # a few windows of the same definition; every rank takes part (the windows hold barriers)
+    fast_mode = None
+    if args.precision == "fp32" and args.path == "graph" and not args.no_fast_mode:
+        keep_graphed = graphed
+        try:
+            torch.manual_seed(0)
+            model_f = Second(cfg).cuda().eval().set_precision("bf16x3")
+            with torch.no_grad():
+                if pipelined:
+                    graphed = model_f.pipelined_inference(anchors, [c.shape[0] for c in clouds], args.pipeline or MAX_PIPELINE,
+                                                          autotune=args.pipeline == 0)
+                    if args.pipeline == 0:
+                        graphed.tune(clouds, args.steps)
+                else:
+                    graphed = model_f.graphed_inference(anchors, [c.shape[0] for c in clouds])
+            for _ in range(args.warmup):
+                step()
+            f_t, _ = windows(stream, args.steps, max(3, min(n_win, 9)))
+            f_med = float(np.median(f_t))
+            g1f = graphed.slots[0] if pipelined else graphed
+            with torch.no_grad():
+                for i in range(10):
+                    g1f(stream[i % N_STREAM])
+                torch.cuda.synchronize()
+                latf = []
+                for i in range(200):
+                    s0 = time.perf_counter()
+                    g1f(stream[i % N_STREAM])
+                    latf.append(time.perf_counter() - s0)
+            fast_mode = dict(value=frames / f_med, unit="frames/s", ms_per_step=1e3 * f_med / args.steps, windows=len(f_t),
+                             single_frame_ms=1e3 * float(np.median(latf)), pipeline_tuning=(graphed.tuned if pipelined else None),
+                             dtype="bf16x3: bf16 hi + lo pieces, 3 MFMA terms, fp32 accumulate, scale-free; relative product error 2^-17 "
+                                   "(strict elementwise error <= 3e-3 on entries above 1e-3 of a layer's maximum)")
+            if pipelined:
+                graphed.flush()
+            graphed = keep_graphed
+            del model_f
+        except Exception as e:  # a reported extra
+            fast_mode = dict(value=None, error=f"{type(e).__name__}: {str(e)[:200]}")
+            graphed = keep_graphed
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -986,17 +1062,16 @@ def main():
                     steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
                     value_is="median over `windows` back-to-back timed windows of `steps` steps each (each window: barrier + "
                              "synchronize on both sides, empty pipeline at its start, max over ranks)",
-                    scaling="weak", vs_baseline=None, dtype="bf16x3: fp32 operands split into 16-bit hi + lo, 3 bf16 MFMA terms (hi*hi + hi*lo + lo*hi), fp32 accumulate -- a 16 x 16-bit "
-                          "split product, relative product error 2^-17 (NOT fp32: 2^-24); end to end 2e-5 of the BEV maximum, strict "
-                          "elementwise relative error <= 3e-3 on entries above 1e-3 of a layer's maximum (tests/test_gpu_conv3d_parity.py)", data="synthetic",
+                    scaling="weak", vs_baseline=None, dtype=DTYPE_NOTE[args.precision], data="synthetic", precision=args.precision,
+                    fast_mode=fast_mode,
                     config=dict(workload=wl,
                                 frames_per_gpu_per_step=args.batch, points_per_frame=args.points,
                                 distinct_frames_in_timed_loop=N_STREAM,
                                 parallelism=f"frame-parallel replicas x{world}", pipeline_depth=(graphed.depth if pipelined else 1),
                                 pipeline_tuning=(graphed.tuned if pipelined else None),
-                                path={"graph": "native backbone plan + bf16x3 MFMA dense head + device proposal stage, one HIP graph per "
+                                path={"graph": "native backbone plan + split-precision MFMA dense head + device proposal stage, one HIP graph per "
                                                "frame" + (f", {graphed.depth} frames in flight" if pipelined else ""),
-                                      "native": "native backbone plan + bf16x3 MFMA dense head",
+                                      "native": "native backbone plan + split-precision MFMA dense head",
                                       "eager": "eager python -> C ABI"}[args.path]),
                     **spread, with_h2d=with_h2d, n_ranks_seen=n_ranks_seen,
                     single_frame_ms=single_ms, single_frame=single_stats,

@@ -162,12 +162,27 @@ int v3d_sparse_conv_fwd(const float* in, const float* weight, const int32_t* nbr
                         int K, int Cin, int Cout, const float* scale, const float* shift, int relu, float* out,
                         int algo, v3d_stream_t stream);
 
-/* Split-precision variant (algo 4): weights are split into bf16 hi/lo and packed once per layer, the
- * forward runs on v_mfma_f32_16x16x32_bf16 as hi*hi + hi*lo + lo*hi with fp32 accumulation (fp32-class
- * accuracy, ~1e-5 relative); one wave owns 16 output rows with register accumulators.  Cout % 16 == 0.
- */
+/* Split-precision variant (algo 4): operands are split into 16-bit hi + lo pieces (weights once per layer into a packed image,
+ * activations in registers) and multiplied as lo*hi + hi*lo + hi*hi on the 16-bit matrix pipe with fp32 accumulation; one wave owns
+ * 16 output rows with register accumulators.  Cout % 16 == 0.  Two arithmetics (`prec`):
+ *   V3D_PREC_BF16X3 (0)  bf16 pieces, 2^-17 per product, scale-free (any fp32 magnitude).  What the un-suffixed entry points run.
+ *   V3D_PREC_F16S   (1)  f16 pieces of x * s under a power-of-two scale s per tensor, 2^-22 per product: the result differs from
+ *                        the reference's fp32 modules (detector/sparse_cnn.py:15-30 run spconv's fp32 GEMMs) by fp32's own
+ *                        summation noise, at the same three MFMAs.  The weight scale is chosen by the pack call (device-side,
+ *                        from max|W|); the activation scale is the caller's: `act_in` / `act_next` point at device entries
+ *                        {s, 1/s, limit, 0} of the gathered tensor and (nullable) of the output -- an output magnitude beyond
+ *                        `limit` = 2^15 / s raises *range_flag to 2 (atomicMax; nullable): the caller recalibrates and re-runs.
+ *                        v3d_act_scale_from_rows fills an entry from the rows themselves (exact maximum: no flag needed). */
+#define V3D_PREC_BF16X3 0
+#define V3D_PREC_F16S 1
 size_t v3d_sparse_conv_weight_image_bytes(int K, int Cin, int Cout);
 int v3d_sparse_conv_pack_weights(const float* weight, int K, int Cin, int Cout, void* image, v3d_stream_t stream);
+int v3d_sparse_conv_pack_weights2(const float* weight, int K, int Cin, int Cout, int prec, void* image, v3d_stream_t stream);
+/* entry[0..3] = {s, 1/s, 2^15 / s, max} for the n = min(*n_rows, cap) rows of `rows` (cap, C) [n_rows NULL: all cap rows]:
+ * s = the power of two that puts the largest magnitude into [2^(13 - headroom_bits), 2^(14 - headroom_bits)).  One workgroup;
+ * no host synchronisation.  headroom_bits in [0, 12]. */
+int v3d_act_scale_from_rows(const float* rows, const int32_t* n_rows, int cap, int C, int headroom_bits, float* entry,
+                            v3d_stream_t stream);
 /* rows_hint > 0: the caller's estimate of the LIVE row count (*n_out is device-side), used only to choose the kernel: 3x3x3 with
  * Cin, Cout in {32, 64}: LDS-ring kernel up to 16 384 rows, 64-row LDS-shared-weights kernel from 32 768, else the 16-row kernel;
  * 0 = unknown (ring / 16-row).  The 64 -> 64 ring kernel owns a CU per workgroup: it takes 2, 3 or 4 sixteen-row tiles per workgroup,
@@ -178,6 +193,10 @@ int v3d_sparse_conv_pack_weights(const float* weight, int K, int Cin, int Cout, 
 int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
                                float* out, int rows_hint, v3d_stream_t stream);
+int v3d_sparse_conv_fwd_packed2(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
+                                int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
+                                float* out, int rows_hint, int prec, const float* act_in, const float* act_next,
+                                int32_t* range_flag, v3d_stream_t stream);
 
 /* ---- T3 backward (spconv indice_conv backward; the reference trains through it at train.py:65).
  * Data gradient: dX[i] = sum_k dY[nbrT[k][i]] @ W[k]^T -- the forward entry points above on the TRANSPOSED
@@ -315,6 +334,19 @@ int v3d_backbone_bev_planes(v3d_backbone* plan, void** hi, void** lo);
  * fewer, fatter workgroups: ~39 % less CU-time per launch, ~20 % longer launches (results are bit-identical either way).  Default off:
  * the shortest launch (one frame at a time). */
 int v3d_backbone_set_throughput_mode(v3d_backbone* plan, int on);
+/* Arithmetic of the plan's INFERENCE entry points (v3d_backbone_forward* ; the training plan is bf16x3): V3D_PREC_BF16X3 (default of
+ * a new plan) or V3D_PREC_F16S.  Set it BEFORE v3d_backbone_set_layer: the weight images are packed per arithmetic.
+ * f16s: v3d_backbone_act_scales() = (n_layers + 1) x {s, 1/s, limit, max} in device memory, entry l = the rows layer l gathers,
+ * entry n_layers = the BEV map (the scale of the split planes).  New plans hold {1, 1, 2^15, 0}: correct for magnitudes below 2^15,
+ * full precision once calibrated: v3d_backbone_set_calibrating(plan, 1) -> one forward (every layer on the exact-fp32 kernel) ->
+ * v3d_backbone_calibrate(plan, headroom_bits, stream) (entries from that frame's maxima; enqueued, no host sync) ->
+ * v3d_backbone_set_calibrating(plan, 0).  A later frame whose tensors exceed an entry's limit (2^(headroom_bits + 1) x the
+ * calibration frame's maximum) raises v3d_backbone_overflow_flags()[n_layers] to 2: recalibrate on it and run it again. */
+int v3d_backbone_set_precision(v3d_backbone* plan, int prec);
+int v3d_backbone_precision(const v3d_backbone* plan);
+float* v3d_backbone_act_scales(v3d_backbone* plan);
+int v3d_backbone_set_calibrating(v3d_backbone* plan, int on);
+int v3d_backbone_calibrate(v3d_backbone* plan, int headroom_bits, v3d_stream_t stream);
 /* The tail of the SECOND dense head in ONE launch: RPN up-conv 1x1 128 -> 128 (+ folded BatchNorm bias + ReLU, detector/second.py:73-79)
  * followed by the fused [cls | reg] 1x1 head 128 -> Cout2 <= 16 (detector/proposal.py:19-22), split planes (B, H, W, 128) in, fp32
  * NCHW (B, Cout2, H, W) out; w1_image / w2_image from v3d_conv2d_pack_weights(.., ksize 1).  Bit-identical to v3d_conv2d_nhwc_bf16x3
@@ -344,6 +376,32 @@ int v3d_conv2d_nhwc_bf16x3_bg2(const void* x_hi, const void* x_lo, const void* w
                                const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo, uint32_t* work,
                                uint32_t* tile_state, uint32_t* reset_ptr, int reset_words, v3d_stream_t stream);
 int v3d_conv2d_bg_tiles(int B, int H, int W);
+/* ---- the same dense head in fp32-class arithmetic (V3D_PREC_F16S; see the sparse section above for the two arithmetics).
+ * The reference's RPN / heads are fp32 nn.Conv2d modules (detector/second.py:58-79, detector/proposal.py:19-22): f16s reproduces
+ * them up to fp32 summation noise at the cost of bf16x3.  Planes then hold f16 pieces of x * s: every plane pair has a device entry
+ * {s, 1/s, limit = 2^15 / s, ..} (set by the caller's calibration: vision3d_amd.runtime.DenseHeadPlan.calibrate; the BEV planes of
+ * a plan use v3d_backbone_act_scales()[n_layers]), the weight image carries its own scale (v3d_conv2d_pack_weights2), and an output
+ * magnitude beyond its entry's limit raises *range_flag to 2 (atomicMax, nullable).  fp32 NCHW outputs are unscaled.
+ * v3d_conv2d_nhwc_split(.., pr = NULL) is v3d_conv2d_nhwc_bf16x3_bg2; for v3d_conv2d_1x1_head_fused2 `out_entry` is the entry of
+ * the intermediate 128-channel tensor. */
+typedef struct v3d_conv2d_prec {
+  int32_t prec;           /* V3D_PREC_*: the arithmetic the weight image(s) were packed for */
+  const float* in_entry;  /* f16s: device entry of the input planes */
+  const float* out_entry; /* f16s: device entry of the output planes (NULL when only fp32 NCHW is written) */
+  int32_t* range_flag;    /* f16s, nullable */
+} v3d_conv2d_prec;
+int v3d_conv2d_pack_weights2(const float* weight, const float* scale, int Cout, int Cin, int ksize, int prec, void* image,
+                             v3d_stream_t stream);
+int v3d_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias, int relu, int B,
+                          int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo, float* y_nchw,
+                          const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo, uint32_t* work,
+                          uint32_t* tile_state, uint32_t* reset_ptr, int reset_words, const v3d_conv2d_prec* pr,
+                          v3d_stream_t stream);
+int v3d_conv2d_1x1_head_fused2(const void* x_hi, const void* x_lo, const void* w1_image, const float* b1, int relu1,
+                               const void* w2_image, const float* b2, int relu2, int B, int H, int W, int Cmid, int Cout2,
+                               float* y_nchw, const v3d_conv2d_prec* pr, v3d_stream_t stream);
+int v3d_nchw_to_split_nhwc2(const float* x, int B, int C, int H, int W, void* out_hi, void* out_lo, int prec,
+                            const float* act_entry, v3d_stream_t stream);
 /* .dense() of the last sparse stage straight into that input format: planes (B,H,W,C*D), channel = c*D + z. */
 int v3d_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
                            const int32_t* spatial_shape_host, void* out_hi, void* out_lo, v3d_stream_t stream);

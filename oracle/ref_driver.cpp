@@ -5,7 +5,7 @@
 // oracle/Makefile) and exposes detectron2::single_box_iou_rotated<float>
 // (box_iou_rotated_utils.h:313-340) through plain C symbols, so tests can pin oracle/v3d_oracle.c
 // and the HIP kernels against the reference arithmetic itself.  Built only when /root/reference
-// exists; output goes to oracle/_ref/ (git-ignored, travels to the GPU box as a .so).
+// exists; output goes to oracle/_ref/ (git-ignored and gpurun-ignored: a CPU-container artefact).
 //
 // The pairwise loop and the greedy NMS loop below restate box_iou_rotated_cpu.cpp:23-28 and
 // nms_rotated_cpu.cpp:36-58 (those files need ATen and are not compiled here); every IoU value

@@ -12,12 +12,25 @@ def dev(a, dtype=None):
     return t.cuda()
 
 
-def assert_features_close(got, ref, what=""):
+FP32_CLASS_FLOOR = 1e-5  # absolute floor (in units of the active rms) of the bar for the fp32-class arithmetic (f16s)
+STRICT_FP32_CLASS = 2e-4  # strict elementwise bound against float64 on |ref| > 1e-3 max (torch's own fp32 conv3d: up to 1.1e-4)
+
+
+def strict_rel_err(got, ref, cut=1e-3):
+    """largest elementwise relative error over the entries with |ref| > cut * max|ref| (north_star's "1e-4 rel" read literally)"""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    big = np.abs(ref) > cut * np.abs(ref).max()
+    return float((np.abs(got - ref)[big] / np.abs(ref)[big]).max()) if big.any() else 0.0
+
+
+def assert_features_close(got, ref, what="", floor=FEATURE_RTOL):
     """Feature parity bar (BASELINE north_star: "within 1e-4 rel"), applied three ways:
-      elementwise  |got - ref| <= 1e-4 * |ref| + 1e-4 * rms_active   (rms over the NON-ZERO reference entries:
+      elementwise  |got - ref| <= 1e-4 * |ref| + floor * rms_active   (rms over the NON-ZERO reference entries:
                    BEV maps are ~95 % structural zeros, which must not shrink the absolute floor)
       max norm     max|got - ref| <= 1e-4 * max|ref|
-      structure    exact zeros of the reference stay exact zeros."""
+      structure    exact zeros of the reference stay exact zeros.
+    floor: 1e-4 for the bf16x3 arithmetic (2^-17 per product: an ABSOLUTE error of a few 1e-6 of a layer's largest output), 1e-5
+    (FP32_CLASS_FLOOR) for the f16s arithmetic, whose tests also bound the strict elementwise error (strict_rel_err)."""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     if ref.size == 0:
@@ -25,7 +38,7 @@ def assert_features_close(got, ref, what=""):
     active = ref != 0
     scale = max(np.sqrt((ref[active] ** 2).mean()) if active.any() else 0.0, 1e-30)
     err = np.abs(got - ref)
-    bad = err > FEATURE_RTOL * np.abs(ref) + FEATURE_RTOL * scale
+    bad = err > FEATURE_RTOL * np.abs(ref) + floor * scale
     assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} elements off, max err {err.max():.3e}, active rms {scale:.3e}"
     assert err.max() <= FEATURE_RTOL * max(np.abs(ref).max(), 1e-30), f"{what}: max-norm error {err.max():.3e}"
 

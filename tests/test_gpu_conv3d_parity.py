@@ -9,15 +9,20 @@ This test checks every one of the 14 layers of SpMiddleFHD (sparse_cnn.py:151-17
 (features + coordinates) is densified, F.conv3d (MIOpen / torch, fp32) is the reference, compared at the layer's output sites.
 The grid is 41 x 1600 x 1408, so the dense reference runs in slabs of output rows with their halo.
 
-Reported beside the repository's feature bar (gpu_util.assert_features_close: 1e-4 |ref| + 1e-4 rms_active, max norm):
-the STRICT elementwise relative error on the entries with |ref| > 1e-3 max|ref|.
+Both arithmetics of the packed kernels (csrc/spconv.hip "the split-precision product"):
+  "fp32"   (f16s, the default of the inference paths): the STRICT elementwise relative error against float64 on the entries with
+           |ref| > 1e-3 max|ref| must stay below 2e-4 (torch's own fp32 conv3d shows up to 1.1e-4 under the same measure) and
+           the feature bar is applied with its absolute floor cut to 1e-5 rms -- north_star's "within 1e-4 rel" read literally, up
+           to fp32 summation noise;
+  "bf16x3" (training plan, fast mode): the repository's bar of rounds 1-4 (1e-4 |ref| + 1e-4 rms_active, max norm), strict figure
+           reported and bounded at what a 2^-17 product allows (3e-3).
 """
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_util import assert_features_close
+from gpu_util import FP32_CLASS_FLOOR, STRICT_FP32_CLASS, assert_features_close
 
 pytestmark = pytest.mark.gpu
 
@@ -88,12 +93,15 @@ def _strict(got, ref):
     return float(((got.double() - ref.double()).abs()[big] / ref.double().abs()[big]).max())
 
 
-def test_every_backbone_layer_equals_dense_conv3d_on_a_full_frame():
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_every_backbone_layer_equals_dense_conv3d_on_a_full_frame(precision, monkeypatch):
     from vision3d_amd import spconv, synth
     from vision3d_amd.core import Preprocessor
     from vision3d_amd.core.config import second_car_cfg
     from vision3d_amd.detector import Second
     from vision3d_amd.spconv.conv import _SparseConvBase
+    monkeypatch.setattr(_SparseConvBase, "precision", precision)
+    fp32_class = precision == "fp32"
     cfg = second_car_cfg()
     torch.manual_seed(0)
     model = Second(cfg).cuda().eval()
@@ -143,7 +151,8 @@ def test_every_backbone_layer_equals_dense_conv3d_on_a_full_frame():
         kernel_vs_exact, torch_vs_exact = _strict(fout, exact), _strict(ref, exact)
         worst_vs_exact, worst_torch = max(worst_vs_exact, kernel_vs_exact), max(worst_torch, torch_vs_exact)
         got, r = fout.cpu().numpy(), ref.cpu().numpy()
-        assert_features_close(got, r, f"layer {li} {mod.in_channels}->{mod.out_channels} vs F.conv3d")
+        assert_features_close(got, r, f"layer {li} {mod.in_channels}->{mod.out_channels} vs F.conv3d",
+                              floor=FP32_CLASS_FLOOR if fp32_class else 1e-4)
         big = np.abs(r) > 1e-3 * np.abs(r).max()
         strict = float((np.abs(got - r)[big] / np.abs(r)[big]).max())
         worst_strict = max(worst_strict, strict)
@@ -152,11 +161,15 @@ def test_every_backbone_layer_equals_dense_conv3d_on_a_full_frame():
     for row in report:
         print("layer %2d %3d->%3d rows %6d: strict rel err on |ref| > 1e-3 max = %.2e, max-norm err = %.2e | vs float64: kernel %.2e, "
               "torch fp32 conv3d %.2e" % row)
-    # Against the float64 result the kernel's strict error must stay inside the bar, and the fp32 reference's own figure is printed
-    # beside it: two fp32-class computations with different summation orders differ by this much on small entries.
-    print("worst strict error vs float64: kernel %.2e, torch fp32 conv3d %.2e" % (worst_vs_exact, worst_torch))
-    assert worst_vs_exact < 3e-3, worst_vs_exact
-    # The split-precision product carries an ABSOLUTE error of a few 1e-6 of the layer's largest output,
-    # so relative to an entry a thousand times smaller than the largest one it may reach a few 1e-3: the strict figure is
-    # reported, and bounded at the value that mechanism allows (observed 1.2e-3 .. 2.0e-3 over the 14 layers).
-    assert worst_strict < 3e-3, worst_strict
+    # Against the float64 result: the kernel's strict error, with the fp32 reference's own figure printed beside it (two fp32-class
+    # computations with different summation orders differ by that much on small entries).
+    print("%s: worst strict error vs float64: kernel %.2e, torch fp32 conv3d %.2e; kernel vs torch %.2e" %
+          (precision, worst_vs_exact, worst_torch, worst_strict))
+    if fp32_class:
+        assert worst_vs_exact < STRICT_FP32_CLASS, worst_vs_exact
+        assert worst_strict < 2 * STRICT_FP32_CLASS, worst_strict  # (two fp32-class results against each other)
+    else:
+        # the bf16x3 product carries an ABSOLUTE error of a few 1e-6 of the layer's largest output, so relative to an entry a
+        # thousand times smaller it reaches a few 1e-3 (observed 1.2e-3 .. 2.0e-3 over the 14 layers)
+        assert worst_vs_exact < 3e-3, worst_vs_exact
+        assert worst_strict < 3e-3, worst_strict

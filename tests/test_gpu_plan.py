@@ -20,11 +20,22 @@ def build_model(seed=0):
     return model.cuda().eval()
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("seeds,npts", [([0], 16384), ([3, 4, 5], 16384), ([6, 7], 5000)])
-def test_plan_matches_eager_path_exactly(seeds, npts):
+def test_plan_matches_eager_path_exactly(seeds, npts, precision):
+    """bf16x3: the plan runs the per-op path's kernels in the same order: the same bits.  fp32 (f16s): the op-by-op path takes each
+    layer's scale entry from the rows' exact maximum, the plan from its calibration frame with headroom -- powers of two either
+    way, so the two results differ only where a piece falls below f16's subnormal quantum: far inside the fp32-class bar."""
+    from gpu_util import FP32_CLASS_FLOOR
     from vision3d_amd.core import Preprocessor
     cfg = second_car_cfg()
-    model = build_model(1)
+    model = build_model(1).set_precision(precision)
+
+    def same(a, b):
+        if precision == "bf16x3":
+            np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+        else:
+            assert_features_close(a.cpu().numpy(), b.cpu().numpy(), "plan vs op-by-op (f16s)", floor=FP32_CLASS_FLOOR * 0.1)
     clouds_np = [synth.make_cloud(s)[:npts - 37 * i] for i, s in enumerate(seeds)]
     clouds = [torch.from_numpy(c).cuda() for c in clouds_np]
     with torch.no_grad():
@@ -32,7 +43,7 @@ def test_plan_matches_eager_path_exactly(seeds, npts):
         bev_eager = model.cnn(item["voxel_mean"], item["coordinates"], item["batch_size"])
         bev_plan = model.bev_from_points(clouds)
     assert bev_plan.shape == bev_eager.shape
-    np.testing.assert_array_equal(bev_plan.cpu().numpy(), bev_eager.cpu().numpy())
+    same(bev_plan, bev_eager)
     plan = next(iter(model._plans.values()))
     feat, coords, n, shape = plan.layer_output(-1)
     m = int(n.item())
@@ -46,7 +57,8 @@ def test_plan_matches_eager_path_exactly(seeds, npts):
     with torch.no_grad():
         again = model.bev_from_points(clouds[::-1])
         back = model.bev_from_points(clouds)
-    np.testing.assert_array_equal(back.cpu().numpy(), bev_eager.cpu().numpy())
+    same(back, bev_eager)
+    np.testing.assert_array_equal(back.cpu().numpy(), bev_plan.cpu().numpy())  # the plan reproduces ITSELF bit for bit
     if len(seeds) > 1:
         assert not torch.equal(again, back)
 
@@ -195,3 +207,63 @@ def test_persistent_bev_planes_equal_fresh_planes_over_a_sequence_of_frames():
                 from vision3d_amd import _lib as L
                 L.check(L.lib().v3d_backbone_forward_reuse(plan._handle, 2, 0, L.ptr(rhi), L.ptr(rlo), L.stream_ptr()), "reuse")
                 assert torch.equal(rhi, fresh[0]) and torch.equal(rlo, fresh[1])
+
+
+def _same_detections(a, b):
+    assert len(a[0]) == len(b[0]) > 0
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
+
+
+def test_f16s_range_overflow_is_flagged_recalibrated_and_rerun():
+    """f16s scale entries are calibrated on a frame with 2^6 of headroom.  A frame whose tensors leave that range must not return
+    silently wrong detections: the frame's summary word reads 2 (runtime.RangeOverflow at the frame's one host read), the entries
+    are re-derived from THAT frame and it is run again -- eager path and captured graph (whose kernels read the entries from
+    device memory: rewritten in place, no re-capture) -- with the result a freshly calibrated model gives."""
+    from vision3d_amd.core import AnchorGenerator
+    cfg = second_car_cfg()
+    anchors = AnchorGenerator(cfg).anchors.cuda()
+    normal = torch.from_numpy(synth.make_cloud(1)).cuda()
+    loud = normal.clone()
+    loud[:, 3] *= 3.0e4  # reflectance far outside what the calibration frame showed: every layer's input grows ~1e4-fold
+    with torch.no_grad():
+        model = build_model(7)
+        assert model.precision == "fp32"
+        first = model.inference_points([normal], anchors)
+        plan = next(iter(model._plans.values()))
+        gen, dense_gen = plan.calibration_generation, model.dense_plan().calibration_generation
+        # the range check itself: the plan alone raises the summary word to 2 on the loud frame
+        hi, lo = plan.forward_split(loud, [0, loud.shape[0]])
+        assert int(plan.overflow_any().item()) == 2
+        got = model.inference_points([loud], anchors)  # flagged -> recalibrated on this frame -> run again
+        assert plan.calibration_generation == gen + 1 and model.dense_plan().calibration_generation > dense_gen
+        fresh = build_model(7)
+        _same_detections(got, fresh.inference_points([loud], anchors))
+        # ... and back: the quiet frame fits inside the louder calibration (smaller values only lose subnormal pieces)
+        again = model.inference_points([normal], anchors)
+        assert len(again[0]) == len(first[0])
+        # captured graph: calibrated on the quiet frame at capture, then handed the loud one
+        gmodel = build_model(7)
+        run = gmodel.graphed_inference(anchors, [16384])
+        _same_detections(run([normal]), first)
+        gplan = run.plan
+        g0 = gplan.calibration_generation
+        out = run([loud])
+        assert gplan.calibration_generation == g0 + 1
+        _same_detections(out, got)
+        _same_detections(run([loud]), got)  # steady state after the recalibration: plain replays
+
+
+def test_bf16x3_mode_still_available_and_close_to_fp32_class():
+    """Second.set_precision("bf16x3"): the scale-free arithmetic of rounds 1-4 (training plan, fast mode) through the same entry
+    points; its head maps agree with the fp32-class ones inside the repository's 1e-4 bar."""
+    model = build_model(8)
+    clouds = [torch.from_numpy(synth.make_cloud(2)).cuda()]
+    with torch.no_grad():
+        fp32 = model.fused_head_from_points(clouds).clone()
+        model.set_precision("bf16x3")
+        fast = model.fused_head_from_points(clouds).clone()
+        plan = next(iter(model._plans.values()))
+        assert plan.precision == "bf16x3" and plan.bev_entry() is None and model.dense_plan().precision == "bf16x3"
+    assert not torch.equal(fp32, fast)
+    assert_features_close(fast.cpu().numpy(), fp32.cpu().numpy(), "bf16x3 vs f16s head maps")

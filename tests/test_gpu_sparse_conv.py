@@ -4,10 +4,28 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import assert_features_close, dev
+from gpu_util import FP32_CLASS_FLOOR, STRICT_FP32_CLASS, assert_features_close, dev, strict_rel_err
 from vision3d_amd import synth
 
 pytestmark = pytest.mark.gpu
+
+
+def conv64(feats, w, nbr, scale=None, shift=None, relu=False):
+    """The layer in float64 from the oracle's neighbour table (n_out, K): the yardstick of the fp32-class arithmetic."""
+    k = nbr.shape[1]
+    w64 = w.reshape(k, w.shape[-2], w.shape[-1]).astype(np.float64)
+    f64 = np.concatenate([feats.astype(np.float64), np.zeros((1, feats.shape[1]))], 0)  # row -1 = absent neighbour
+    out = np.zeros((nbr.shape[0], w.shape[-1]))
+    for j in range(k):
+        out += f64[nbr[:, j]] @ w64[j]
+    if scale is not None:
+        out = out * scale.astype(np.float64) + shift.astype(np.float64)
+    return np.maximum(out, 0) if relu else out
+
+
+def assert_fp32_class(got, ref64, what):
+    assert_features_close(got, ref64, what, floor=FP32_CLASS_FLOOR)
+    assert strict_rel_err(got, ref64) < STRICT_FP32_CLASS, (what, strict_rel_err(got, ref64))
 
 
 def kitti_coords(oracle, seeds):
@@ -77,10 +95,11 @@ def test_strided_conv_forward_ragged_tail(oracle, algo):
         assert_features_close(got, oracle.sparse_conv_fwd(feats, w, onbr, relu=True), f"strided {cin}->{cout} algo {algo}")
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("variant", [1, 5, 6, 7, 10, 16],
                          ids=["16rows", "64rows_lds_weights", "offset_outer_staged", "offset_outer_regs", "lds_ring", "lds_ring_regs"])
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 32), (64, 64)])
-def test_packed_kernel_variants(oracle, cin, cout, variant):
+def test_packed_kernel_variants(oracle, cin, cout, variant, precision):
     """Every kernel of the packed (algo 4) product -- the 16-row kernel, the two-tile LDS-ring kernel (3x3x3, the default
     up to 16 k rows: wave-specialised weight movers; in the form chosen per shape -- rows staged through LDS by
     row-contiguous LDS-DMA for 64->64 and 32->32 -- and in its register-gather form), the 64-row LDS-shared-weights kernel
@@ -96,14 +115,37 @@ def test_packed_kernel_variants(oracle, cin, cout, variant):
     sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32) * 0.1
     x = make_tensor(coords, feats, shape, 1)
     w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(cin * 9)).astype(np.float32)
-    got = sparse_conv_forward(x.features, dev(w), build_subm_rulebook(x, [3, 3, 3]), dev(sc), dev(sh), True, 4, None, variant).cpu().numpy()
-    ref = oracle.sparse_conv_fwd(feats, w, oracle.subm_rulebook(coords, shape, 3), sc, sh, True)
-    assert_features_close(got, ref, f"subm {cin}->{cout} variant {variant}")
+    got = sparse_conv_forward(x.features, dev(w), build_subm_rulebook(x, [3, 3, 3]), dev(sc), dev(sh), True, 4, None, variant,
+                              precision).cpu().numpy()
+    nbr = oracle.subm_rulebook(coords, shape, 3)
+    if precision == "fp32":  # the f16s arithmetic of every variant against float64: fp32-class, strict elementwise bound
+        assert_fp32_class(got, conv64(feats, w, nbr, sc, sh, True), f"subm {cin}->{cout} variant {variant} f16s")
+    else:
+        assert_features_close(got, oracle.sparse_conv_fwd(feats, w, nbr, sc, sh, True), f"subm {cin}->{cout} variant {variant}")
     w1 = (rng.standard_normal((3, 1, 1, cin, cout)) / np.sqrt(cin * 3)).astype(np.float32)
     rb = build_sparse_rulebook(x, [3, 1, 1], [2, 1, 1], [0, 0, 0])
     _, onbr, _ = oracle.sparse_rulebook(coords, shape, [3, 1, 1], [2, 1, 1], [0, 0, 0])
-    got = sparse_conv_forward(x.features, dev(w1), rb, None, None, False, 4, None, variant).cpu().numpy()
-    assert_features_close(got, oracle.sparse_conv_fwd(feats, w1, onbr), f"strided {cin}->{cout} variant {variant}")
+    got = sparse_conv_forward(x.features, dev(w1), rb, None, None, False, 4, None, variant, precision).cpu().numpy()
+    if precision == "fp32":
+        assert_fp32_class(got, conv64(feats, w1, onbr), f"strided {cin}->{cout} variant {variant} f16s")
+    else:
+        assert_features_close(got, oracle.sparse_conv_fwd(feats, w1, onbr), f"strided {cin}->{cout} variant {variant}")
+
+
+@pytest.mark.parametrize("mag", [1e-6, 1.0, 3.0e4])
+def test_f16s_scales_follow_the_input_magnitude(oracle, mag):
+    """f16s splits x * s with a power-of-two s per tensor: the result must not depend on the tensor's magnitude (features around 1e-6,
+    1 and 3e4 -- beyond f16's own range without the scale) and stays fp32-class against float64."""
+    from vision3d_amd.spconv.conv import build_subm_rulebook, sparse_conv_forward
+    rng = np.random.default_rng(5)
+    coords = kitti_coords(oracle, [6])[:3000]
+    shape = [41, 1600, 1408]
+    feats = (rng.standard_normal((len(coords), 64)) * mag).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 64, 64)) / np.sqrt(64 * 9)).astype(np.float32)
+    x = make_tensor(coords, feats, shape, 1)
+    got = sparse_conv_forward(x.features, dev(w), build_subm_rulebook(x, [3, 3, 3]), None, None, False, 4, None, 0, "fp32").cpu().numpy()
+    assert np.isfinite(got).all()
+    assert_fp32_class(got, conv64(feats, w, oracle.subm_rulebook(coords, shape, 3)), f"f16s magnitude {mag}")
 
 
 def test_tiny_and_empty_inputs(oracle):

@@ -43,6 +43,9 @@ _SIGNATURES = {
     "v3d_sparse_conv_weight_image_bytes": (_sz, [_i, _i, _i]),
     "v3d_sparse_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "v3d_sparse_conv_fwd_packed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "v3d_sparse_conv_pack_weights2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "v3d_sparse_conv_fwd_packed2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "v3d_act_scale_from_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "v3d_rulebook_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "v3d_sparse_conv_bwd_weight_workspace": (_sz, [_i, _i, _i]),
     "v3d_sparse_conv_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
@@ -80,6 +83,15 @@ _SIGNATURES = {
     "v3d_conv2d_nhwc_bf16x3_bg": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "v3d_conv2d_nhwc_bf16x3_bg2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "v3d_conv2d_bg_tiles": (_i, [_i, _i, _i]),
+    "v3d_conv2d_pack_weights2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "v3d_conv2d_nhwc_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "v3d_conv2d_1x1_head_fused2": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "v3d_nchw_to_split_nhwc2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "v3d_backbone_set_precision": (_i, [_vp, _i]),
+    "v3d_backbone_precision": (_i, [_vp]),
+    "v3d_backbone_act_scales": (_vp, [_vp]),
+    "v3d_backbone_set_calibrating": (_i, [_vp, _i]),
+    "v3d_backbone_calibrate": (_i, [_vp, _i, _vp]),
     "v3d_conv2d_1x1_head_fused": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "v3d_proposal_loss_workspace": (_sz, []),
     "v3d_proposal_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
@@ -120,6 +132,15 @@ class BackboneConfig(C.Structure):
                 ("max_batch", C.c_int32), ("max_points", C.c_int32), ("n_layers", C.c_int32), ("growth", C.c_float),
                 ("conv_algo", C.c_int32)]
 
+
+
+class Conv2dPrec(C.Structure):
+    """v3d_conv2d_prec: arithmetic of a dense-head call + the device scale entries of its planes (f16s)."""
+    _fields_ = [("prec", C.c_int32), ("in_entry", _vp), ("out_entry", _vp), ("range_flag", _vp)]
+
+
+PREC_BF16X3, PREC_F16S = 0, 1
+PRECISIONS = {"bf16x3": PREC_BF16X3, "fp32": PREC_F16S, "f16s": PREC_F16S}
 
 
 class TrainLayer(C.Structure):

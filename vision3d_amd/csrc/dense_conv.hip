@@ -4,12 +4,16 @@
 // (detector/proposal.py:19-22), executed by cuDNN in fp32.  This is the only genuinely dense, GEMM-shaped
 // part of the model (63.4 GFLOP/frame), so it is the part that goes to MFMA (BASELINE.json north_star).
 //
-// Precision: "bf16 x 3".  Every fp32 operand is split once into hi = bf16(x), lo = bf16(x - hi) and the
-// product is evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation (v_mfma_f32_16x16x32_bf16).  The
-// dropped lo*lo term and the 16-bit residual of each operand are ~2^-17 relative per product, i.e.
-// fp32-class accuracy (tests: <= 1e-4 of the fp32 reference through all 7 layers) at 3/16 of the
-// fp32-MFMA cost.  Activations travel between layers ALREADY split (two bf16 NHWC planes = the bytes of
-// one fp32 tensor), weights are split and packed once per model, so the inner loop has no conversions.
+// Precision: every fp32 operand is split once into 16-bit pieces hi = rne(x), lo = rne(x - hi) and the product is evaluated as
+// lo*hi + hi*lo + hi*hi with fp32 accumulation on the 16-bit matrix pipe.  Activations travel between layers ALREADY split (two
+// 16-bit NHWC planes = the bytes of one fp32 tensor), weights are split and packed once per model, so the inner loop has no
+// conversions.  Two arithmetics (template parameter PREC; spconv.hip "the split-precision product" has the measurements):
+//   PREC 0 "bf16x3"  bf16 pieces, 2^-17 per product, scale-free.
+//   PREC 1 "f16s"    f16 pieces of x * s under a power-of-two scale s per tensor (weights: per layer, chosen at pack time, inverse
+//                    in the image's trailer; activations: static per layer, a device entry {s, 1/s, limit, ..} set by calibration --
+//                    runtime.DenseHeadPlan.calibrate -- with headroom; an output beyond its entry's limit raises the frame's range
+//                    flag): 2^-22 per product, i.e. the fp32 modules' results up to fp32 summation noise, at the same MFMA count.
+//                    Scaling by powers of two is exact: results do not depend on the scales while nothing leaves the f16 range.
 //
 // Kernel: implicit GEMM, M = B*H*W pixels (flattened), N = Cout, K = taps * Cin.
 //   workgroup  64 pixels x 128 couts, 4 waves as 2 (pixel halves) x 2 (cout halves); wave tile 32 x 64
@@ -26,11 +30,19 @@
 #include "v3d_internal.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef unsigned short bf16_t;  // storage type at the C ABI
+typedef unsigned short bf16_t;  // storage type of a 16-bit piece at the C ABI (bf16 or f16 by the arithmetic)
 // native vector type for the 16-byte staging registers: HIP's uint4 is a struct with a union inside and an
 // array of them is NOT promoted to registers (it round-tripped through scratch every k-step: 142 us/conv)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int PREC>
+__device__ __forceinline__ f32x4 dc_mfma(const u32x4 a, const u32x4 b, const f32x4 c) {
+  if constexpr (PREC == 0)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 
 #define DC_BM 64
 #define DC_BN 128
@@ -44,9 +56,36 @@ __device__ __forceinline__ bf16_t f32_to_bf16_rne(float f) {
   return (bf16_t)(u >> 16);
 }
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
-  hi = f32_to_bf16_rne(x);
-  lo = f32_to_bf16_rne(x - bf16_to_f32(hi));
+// one value -> (hi, lo) pieces; PREC 1: of x * s
+template <int PREC>
+__device__ __forceinline__ void split_val(float x, float s, bf16_t& hi, bf16_t& lo) {
+  if constexpr (PREC == 0) {
+    hi = f32_to_bf16_rne(x);
+    lo = f32_to_bf16_rne(x - bf16_to_f32(hi));
+  } else {
+    const float a = x * s;
+    const _Float16 h = (_Float16)a;
+    const _Float16 l = (_Float16)(a - (float)h);
+    hi = __builtin_bit_cast(bf16_t, h);
+    lo = __builtin_bit_cast(bf16_t, l);
+  }
+}
+// trailer of a packed weight image: {max|w| bits, 1/s_w, s_w, precision}; bf16x3 images carry it unused
+#define DC_WIMG_TRAILER 256
+#define DC_F16S_WEIGHT_TARGET 13  // max|w| * s_w in [2^13, 2^14)
+__host__ __device__ static inline float dc_pow2_scale(unsigned amax_bits, int target) {
+  const int eb = (int)((amax_bits >> 23) & 0xFFu);
+  if (eb == 0 || eb == 255) return 1.f;
+  int sb = 127 + target - (eb - 127);
+  sb = sb < 2 ? 2 : (sb > 252 ? 252 : sb);
+  const unsigned bits = (unsigned)sb << 23;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __uint_as_float(bits);
+#else
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -54,10 +93,36 @@ __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
 // image[s][plane][nf][kg][j][e]  with  s = tap*(Cin/32) + chunk, plane in {hi, lo}, nf = cout/16,
 // kg = (cin%32)/8, j = cout%16, e = cin%8   -- exactly the byte order of the B tile in LDS.
 // ------------------------------------------------------------------------------------------------
+// max |w * scale[co]| into word 0 of the trailer (zeroed by the caller)
+__global__ void dc_wmax_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, long long per_cout,
+                               unsigned* __restrict__ trailer) {
+  unsigned m = 0u;
+  const long long n = (long long)Cout * per_cout;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    float v = w[t];
+    if (scale) v *= scale[t / per_cout];
+    m = max(m, __float_as_uint(v) & 0x7FFFFFFFu);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(trailer, m);
+}
+
+template <int PREC>
 __global__ void dc_pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int Cin,
                                        int ks, int CoutPad, bf16_t* __restrict__ img) {
   const int taps = ks * ks, chunks = Cin / DC_KC;
   const long long total = (long long)taps * chunks * (CoutPad / 16) * 4 * 16 * 8;
+  float sw = 1.f;
+  if constexpr (PREC == 1) {
+    unsigned* trailer = reinterpret_cast<unsigned*>(img + total * 2);
+    sw = dc_pow2_scale(trailer[0], DC_F16S_WEIGHT_TARGET);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      reinterpret_cast<float*>(trailer)[1] = 1.f / sw;
+      reinterpret_cast<float*>(trailer)[2] = sw;
+      trailer[3] = 1u;
+    }
+  }
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     long long r = t;
     const int e = (int)(r % 8); r /= 8;
@@ -73,7 +138,7 @@ __global__ void dc_pack_weights_kernel(const float* __restrict__ w, const float*
       if (scale) v *= scale[co];
     }
     bf16_t hi, lo;
-    split_bf16(v, hi, lo);
+    split_val<PREC>(v, sw, hi, lo);
     const size_t step = (size_t)tap * chunks + chunk;
     const size_t plane_elems = (size_t)(CoutPad / 16) * 4 * 16 * 8;
     const size_t off = ((size_t)(nf * 4 + kg) * 16 + j) * 8 + e;
@@ -82,17 +147,33 @@ __global__ void dc_pack_weights_kernel(const float* __restrict__ w, const float*
   }
 }
 
-extern "C" size_t v3d_conv2d_weight_image_bytes(int Cin, int Cout, int ksize) {
+static size_t dc_image_payload_bytes(int Cin, int Cout, int ksize) {
   const int pad = (Cout + DC_BN - 1) / DC_BN * DC_BN;
   return (size_t)ksize * ksize * (Cin / DC_KC) * 2 * (size_t)pad * DC_KC * sizeof(bf16_t);
+}
+extern "C" size_t v3d_conv2d_weight_image_bytes(int Cin, int Cout, int ksize) {
+  return dc_image_payload_bytes(Cin, Cout, ksize) + DC_WIMG_TRAILER;
 }
 
 extern "C" int v3d_conv2d_pack_weights(const float* weight, const float* scale, int Cout, int Cin, int ksize,
                                        void* image, v3d_stream_t stream) {
+  return v3d_conv2d_pack_weights2(weight, scale, Cout, Cin, ksize, V3D_PREC_BF16X3, image, stream);
+}
+
+extern "C" int v3d_conv2d_pack_weights2(const float* weight, const float* scale, int Cout, int Cin, int ksize, int prec,
+                                        void* image, v3d_stream_t stream) {
   if (!weight || !image || Cout < 1 || Cin < DC_KC || Cin % DC_KC || (ksize != 1 && ksize != 3)) return V3D_EINVAL;
+  if (prec != V3D_PREC_BF16X3 && prec != V3D_PREC_F16S) return V3D_EINVAL;
   const int pad = (Cout + DC_BN - 1) / DC_BN * DC_BN;
-  hipLaunchKernelGGL(dc_pack_weights_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, weight, scale, Cout, Cin, ksize,
-                     pad, (bf16_t*)image);
+  hipStream_t st = (hipStream_t)stream;
+  if (prec == V3D_PREC_F16S) {
+    unsigned* trailer = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(image) + dc_image_payload_bytes(Cin, Cout, ksize));
+    V3D_CHECK_HIP(v3d_fill_async(trailer, 0, DC_WIMG_TRAILER, st));
+    hipLaunchKernelGGL(dc_wmax_kernel, dim3(128), dim3(256), 0, st, weight, scale, Cout, (long long)Cin * ksize * ksize, trailer);
+    hipLaunchKernelGGL(dc_pack_weights_kernel<1>, dim3(512), dim3(256), 0, st, weight, scale, Cout, Cin, ksize, pad, (bf16_t*)image);
+  } else {
+    hipLaunchKernelGGL(dc_pack_weights_kernel<0>, dim3(512), dim3(256), 0, st, weight, scale, Cout, Cin, ksize, pad, (bf16_t*)image);
+  }
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -101,14 +182,18 @@ extern "C" int v3d_conv2d_pack_weights(const float* weight, const float* scale, 
 // .dense() straight into the conv input format: zero planes + scatter of split values.
 // out[(b*H + y)*W + x][c*D + z]  (the reference's (B, C*D, H, W) view, channels innermost)
 // ------------------------------------------------------------------------------------------------
+template <int PREC>
 __global__ __launch_bounds__(V3D_BLOCK) void densify_split_kernel(const float* __restrict__ feat,
                                                                   const int4* __restrict__ coords,
                                                                   const int* __restrict__ n_ptr, int cap, int C, int D,
                                                                   int H, int Wd, bf16_t* __restrict__ hi,
                                                                   bf16_t* __restrict__ lo, unsigned* __restrict__ occ,
-                                                                  int* __restrict__ written_pix, int* __restrict__ written_n) {
+                                                                  int* __restrict__ written_pix, int* __restrict__ written_n,
+                                                                  const float* __restrict__ entry, int* __restrict__ range_flag) {
   const int n = min(*n_ptr, cap);
   const long long total = (long long)n * C;
+  const float s_out = PREC == 1 ? entry[0] : 1.f, limit = PREC == 1 ? entry[2] : 0.f;
+  float vmax = 0.f;
   if (written_n && blockIdx.x == 0 && threadIdx.x == 0) *written_n = n;
   for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * V3D_BLOCK) {
     const int i = (int)(t / C), ch = (int)(t % C);
@@ -119,10 +204,14 @@ __global__ __launch_bounds__(V3D_BLOCK) void densify_split_kernel(const float* _
     if (written_pix && ch == 0) written_pix[i] = (c.x * H + c.z) * Wd + c.w;
     const size_t o = (((size_t)c.x * H + c.z) * Wd + c.w) * ((size_t)C * D) + (size_t)ch * D + c.y;
     bf16_t h, l;
-    split_bf16(feat[t], h, l);
+    const float v = feat[t];
+    if constexpr (PREC == 1) vmax = fmaxf(vmax, fabsf(v));
+    split_val<PREC>(v, s_out, h, l);
     hi[o] = h;
     lo[o] = l;
   }
+  if constexpr (PREC == 1)
+    if (range_flag && vmax > limit) atomicMax(range_flag, V3D_FLAG_RANGE);
 }
 
 extern "C" int v3d_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
@@ -158,8 +247,9 @@ int v3d_i_bev_clear_pixels(const int32_t* pix, const int32_t* n, int cap, int ch
 // cleared (v3d_i_bev_clear_pixels on the list the previous call left here): no fill, and this call's pixel list is left behind.
 int v3d_i_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
                              const int32_t* spatial_shape_host, void* out_hi, void* out_lo, uint32_t* occ_inv, hipStream_t st,
-                             int32_t* written_pix, int32_t* written_n) {
+                             int32_t* written_pix, int32_t* written_n, int prec, const float* act_entry, int32_t* range_flag) {
   if (!feat || !coords || !n || cap < 1 || B < 1 || C < 1 || !spatial_shape_host || !out_hi || !out_lo) return V3D_EINVAL;
+  if (prec == V3D_PREC_F16S ? !act_entry : prec != V3D_PREC_BF16X3) return V3D_EINVAL;
   if ((written_pix == nullptr) != (written_n == nullptr)) return V3D_EINVAL;
   const int D = spatial_shape_host[0], H = spatial_shape_host[1], Wd = spatial_shape_host[2];
   const size_t bytes = (size_t)B * H * Wd * C * D * sizeof(bf16_t);
@@ -173,22 +263,28 @@ int v3d_i_densify_nhwc_split(const float* feat, const int32_t* coords, const int
   }
   const long long total = (long long)cap * C;
   const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
-  hipLaunchKernelGGL(densify_split_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(V3D_BLOCK), 0, st, feat,
-                     (const int4*)coords, n, cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo, occ_inv, written_pix, written_n);
+  if (prec == V3D_PREC_F16S)
+    hipLaunchKernelGGL(densify_split_kernel<1>, dim3(blocks > 4096 ? 4096 : blocks), dim3(V3D_BLOCK), 0, st, feat, (const int4*)coords, n,
+                       cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo, occ_inv, written_pix, written_n, act_entry, range_flag);
+  else
+    hipLaunchKernelGGL(densify_split_kernel<0>, dim3(blocks > 4096 ? 4096 : blocks), dim3(V3D_BLOCK), 0, st, feat, (const int4*)coords, n,
+                       cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo, occ_inv, written_pix, written_n, nullptr, nullptr);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
 
-// fp32 NCHW -> split NHWC planes (entry for callers that hold a torch-style tensor)
+// fp32 NCHW -> split NHWC planes (entry for callers that hold a torch-style tensor); f16s: pieces of x * entry[0]
+template <int PREC>
 __global__ void nchw_to_split_nhwc_kernel(const float* __restrict__ x, int B, int C, int HW, bf16_t* __restrict__ hi,
-                                          bf16_t* __restrict__ lo) {
+                                          bf16_t* __restrict__ lo, const float* __restrict__ entry) {
   const long long total = (long long)B * C * HW;
+  const float s = PREC == 1 ? entry[0] : 1.f;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(t % C);
     const long long bp = t / C;  // b*HW + p
     const int b = (int)(bp / HW), p = (int)(bp % HW);
     bf16_t h, l;
-    split_bf16(x[((size_t)b * C + c) * HW + p], h, l);
+    split_val<PREC>(x[((size_t)b * C + c) * HW + p], s, h, l);
     hi[t] = h;
     lo[t] = l;
   }
@@ -196,9 +292,19 @@ __global__ void nchw_to_split_nhwc_kernel(const float* __restrict__ x, int B, in
 
 extern "C" int v3d_nchw_to_split_nhwc(const float* x, int B, int C, int H, int W, void* out_hi, void* out_lo,
                                       v3d_stream_t stream) {
+  return v3d_nchw_to_split_nhwc2(x, B, C, H, W, out_hi, out_lo, V3D_PREC_BF16X3, nullptr, stream);
+}
+
+extern "C" int v3d_nchw_to_split_nhwc2(const float* x, int B, int C, int H, int W, void* out_hi, void* out_lo, int prec,
+                                       const float* act_entry, v3d_stream_t stream) {
   if (!x || !out_hi || !out_lo || B < 1 || C < 1 || H < 1 || W < 1) return V3D_EINVAL;
-  hipLaunchKernelGGL(nchw_to_split_nhwc_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, B, C, H * W,
-                     (bf16_t*)out_hi, (bf16_t*)out_lo);
+  if (prec == V3D_PREC_F16S ? !act_entry : prec != V3D_PREC_BF16X3) return V3D_EINVAL;
+  if (prec == V3D_PREC_F16S)
+    hipLaunchKernelGGL(nchw_to_split_nhwc_kernel<1>, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, B, C, H * W, (bf16_t*)out_hi,
+                       (bf16_t*)out_lo, act_entry);
+  else
+    hipLaunchKernelGGL(nchw_to_split_nhwc_kernel<0>, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, B, C, H * W, (bf16_t*)out_hi,
+                       (bf16_t*)out_lo, nullptr);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -224,9 +330,41 @@ struct DcParams {
   unsigned* tile_state;  // nullable, one word per tile of a PERSISTENT output buffer: nonzero = the tile holds computed values.
                          // The empty-map response of a layer does not depend on the frame, so a background tile whose state
                          // is 0 already holds it from an earlier frame and is not written at all.
+  // f16s arithmetic (PREC 1; null / unused for bf16x3): device scale entries {s, 1/s, limit, ..} of the input planes and of the
+  // output planes (null when only the fp32 NCHW tensor is written), the weight image's trailer {.., 1/s_w, ..} and the frame's
+  // range flag (nullable)
+  const float* in_entry;
+  const float* out_entry;
+  const float* w_trailer;
+  int* range_flag;
 };
 
-template <int KS>
+// what an epilogue applies: v = acc * undo + bias; [ReLU]; planes <- pieces of v * s_out; |v| > limit raises the range flag
+struct DcScales {
+  float undo, s_out, limit;
+};
+template <int PREC>
+__device__ __forceinline__ DcScales dc_scales(const DcParams& p) {
+  DcScales r{1.f, 1.f, 3.0e38f};
+  if constexpr (PREC == 1) {
+    r.undo = p.in_entry[1] * p.w_trailer[1];
+    if (p.out_entry) {
+      r.s_out = p.out_entry[0];
+      r.limit = p.out_entry[2];
+    }
+  }
+  return r;
+}
+template <int PREC>
+__device__ __forceinline__ float dc_finish(float acc, float bias, const DcScales& sc) {
+  if constexpr (PREC == 1) return acc * sc.undo + bias;
+  else return acc + bias;
+}
+__device__ __forceinline__ void dc_range_check(const DcParams& p, float vmax, float limit) {
+  if (p.range_flag && vmax > limit) atomicMax(p.range_flag, V3D_FLAG_RANGE);
+}
+
+template <int KS, int PREC>
 __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16_t* __restrict__ x_hi,
                                                                       const bf16_t* __restrict__ x_lo,
                                                                       const bf16_t* __restrict__ w_img,
@@ -322,33 +460,33 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
   auto multiply = [&](int buf) {
     const unsigned char* A = smem + buf * (8192 + 16384);
     const unsigned char* Bm = A + 8192;
-    bf16x8 ah[2], al[2], bh[4], bl[4];
+    u32x4 ah[2], al[2], bh[4], bl[4];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int px = (wr * 2 + i) * 16 + (lane & 15);  // fragment row of this lane
       const int off = (px * 4 + ((lane >> 4) ^ ((lane & 8) >> 2))) * 16;
-      ah[i] = *reinterpret_cast<const bf16x8*>(A + off);
-      al[i] = *reinterpret_cast<const bf16x8*>(A + 4096 + off);
+      ah[i] = *reinterpret_cast<const u32x4*>(A + off);
+      al[i] = *reinterpret_cast<const u32x4*>(A + 4096 + off);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int nf = wc * 4 + j;
-      bh[j] = *reinterpret_cast<const bf16x8*>(Bm + (nf * 64 + lane) * 16);
-      bl[j] = *reinterpret_cast<const bf16x8*>(Bm + 8192 + (nf * 64 + lane) * 16);
+      bh[j] = *reinterpret_cast<const u32x4*>(Bm + (nf * 64 + lane) * 16);
+      bl[j] = *reinterpret_cast<const u32x4*>(Bm + 8192 + (nf * 64 + lane) * 16);
     }
     // term-major order: 8 independent accumulators between two uses of the same one
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; j++) acc[i][j] = dc_mfma<PREC>(al[i], bh[j], acc[i][j]);
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; j++) acc[i][j] = dc_mfma<PREC>(ah[i], bl[j], acc[i][j]);
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; j++) acc[i][j] = dc_mfma<PREC>(ah[i], bh[j], acc[i][j]);
   };
 
   // prologue: step 0 -> LDS buffer 0, step 1 in flight in R1
@@ -386,7 +524,9 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
         tile[row * TS + col] = acc[i][j][r];
       }
   __syncthreads();
-  if (y_hi) {  // split bf16 NHWC planes: thread handles 8 consecutive couts of one pixel, 16-byte stores
+  const DcScales sc = dc_scales<PREC>(p);
+  float vmax = 0.f;
+  if (y_hi) {  // split 16-bit NHWC planes: thread handles 8 consecutive couts of one pixel, 16-byte stores
     for (int q = tid; q < DC_BM * (DC_BN / 8); q += DC_THREADS) {
       const int row = q / (DC_BN / 8), c8 = q % (DC_BN / 8);
       const int m = m0 + row, co = n0 + c8 * 8;
@@ -395,20 +535,22 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
 #pragma unroll
       for (int e2 = 0; e2 < 4; e2++) {  // two channels per 32-bit word
         bf16_t h0, l0, h1, l1;
-        float v0 = tile[row * TS + c8 * 8 + 2 * e2] + (bias ? bias[co + 2 * e2] : 0.f);
-        float v1 = tile[row * TS + c8 * 8 + 2 * e2 + 1] + (bias ? bias[co + 2 * e2 + 1] : 0.f);
+        float v0 = dc_finish<PREC>(tile[row * TS + c8 * 8 + 2 * e2], bias ? bias[co + 2 * e2] : 0.f, sc);
+        float v1 = dc_finish<PREC>(tile[row * TS + c8 * 8 + 2 * e2 + 1], bias ? bias[co + 2 * e2 + 1] : 0.f, sc);
         if (p.relu) {
           v0 = fmaxf(v0, 0.f);
           v1 = fmaxf(v1, 0.f);
         }
-        split_bf16(v0, h0, l0);
-        split_bf16(v1, h1, l1);
+        if constexpr (PREC == 1) vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
+        split_val<PREC>(v0, sc.s_out, h0, l0);
+        split_val<PREC>(v1, sc.s_out, h1, l1);
         vh[e2] = (unsigned)h0 | ((unsigned)h1 << 16);
         vl[e2] = (unsigned)l0 | ((unsigned)l1 << 16);
       }
       *reinterpret_cast<u32x4*>(y_hi + (size_t)m * p.cout_store + co) = vh;
       *reinterpret_cast<u32x4*>(y_lo + (size_t)m * p.cout_store + co) = vl;
     }
+    if constexpr (PREC == 1) dc_range_check(p, vmax, sc.limit);
   }
   if (y_nchw) {  // fp32 (B, cout_store, H, W): thread handles 4 consecutive pixels of one cout
     const int HW = p.H * p.W;
@@ -421,7 +563,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv2d_bf16x3_kernel(const bf16
       for (int e = 0; e < 4; e++) {
         const int m = m0 + r4 * 4 + e;
         if (m >= p.M) continue;
-        float v = tile[(r4 * 4 + e) * TS + col] + bv;
+        float v = dc_finish<PREC>(tile[(r4 * 4 + e) * TS + col], bv, sc);
         if (p.relu) v = fmaxf(v, 0.f);
         const int b = m / HW, pix = m - b * HW;
         y_nchw[((size_t)b * p.cout_store + co) * HW + pix] = v;
@@ -475,17 +617,27 @@ __device__ __attribute__((aligned(16))) const unsigned dl_zero16[4] = {0u, 0u, 0
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-// (v0, v1) -> packed bf16 hi pair and lo pair (hi = RNE(v), lo = RNE(v - hi)) on the hardware converter
-__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
-  const bf16x2_t h = __builtin_convertvector(f32x2_t{v0, v1}, bf16x2_t);
-  hi = __builtin_bit_cast(unsigned, h);
-  const float r0 = v0 - __uint_as_float(hi << 16), r1 = v1 - __uint_as_float(hi & 0xFFFF0000u);
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+// (v0, v1) -> packed hi pair and lo pair (hi = RNE(v), lo = RNE(v - hi)) on the hardware converters; PREC 1: f16 pieces of v * s
+template <int PREC>
+__device__ __forceinline__ void split_pair(float v0, float v1, float s, unsigned& hi, unsigned& lo) {
+  if constexpr (PREC == 0) {
+    const bf16x2_t h = __builtin_convertvector(f32x2_t{v0, v1}, bf16x2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+    const float r0 = v0 - __uint_as_float(hi << 16), r1 = v1 - __uint_as_float(hi & 0xFFFF0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t));
+  } else {
+    const float a0 = v0 * s, a1 = v1 * s;
+    const f16x2_t h = __builtin_convertvector(f32x2_t{a0, a1}, f16x2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+    const float r0 = a0 - (float)h[0], r1 = a1 - (float)h[1];
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t));
+  }
 }
 
 // one tile (MT 16-pixel fragments x 128 couts) by the whole workgroup; returns with every thread past its last LDS access
 // except the epilogue reads (the caller separates tiles with a barrier)
-template <int KS, int MT>  // MT = 16-pixel fragments per tile: 9 (144 pixels), or 5 (80 pixels) with background skipping
+template <int KS, int MT, int PREC>  // MT = 16-pixel fragments per tile: 9 (144 pixels), or 5 (80 pixels) with background skipping
 __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __restrict__ x_hi, const bf16_t* __restrict__ x_lo,
                                         const bf16_t* __restrict__ w_img, const float* __restrict__ bias, const DcParams& p,
                                         bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo, float* __restrict__ y_nchw,
@@ -640,12 +792,12 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
     auto multiply = [&](int buf, bool more, bool stamp) {
       const unsigned char* A = smem_l + buf * STAGE;
       constexpr int NSTEP = DL_SS * MT / 2;
-      bf16x8 fh[3][2], fl[3][2];
-      auto frag = [&](int t, bf16x8& h, bf16x8& l) {
+      u32x4 fh[3][2], fl[3][2];
+      auto frag = [&](int t, u32x4& h, u32x4& l) {
         const int ss = t / MT, i = t % MT;
         const int off = a_slot(i * 16 + (lane & 15), ss * 4 + (lane >> 4));
-        h = *reinterpret_cast<const bf16x8*>(A + off);
-        l = *reinterpret_cast<const bf16x8*>(A + A_PLANE + off);
+        h = *reinterpret_cast<const u32x4*>(A + off);
+        l = *reinterpret_cast<const u32x4*>(A + A_PLANE + off);
       };
       frag(0, fh[0][0], fl[0][0]);
       frag(1, fh[0][1], fl[0][1]);
@@ -659,25 +811,25 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
         }
         const int t0 = 2 * u, t1 = 2 * u + 1;
         const int s0 = t0 / MT, i0 = t0 % MT, s1 = t1 / MT, i1 = t1 % MT;
-        const bf16x8 b0h0 = __builtin_bit_cast(bf16x8, cb[s0][0]), b0l0 = __builtin_bit_cast(bf16x8, cb[s0][1]);
-        const bf16x8 b0h1 = __builtin_bit_cast(bf16x8, cb[s0][2]), b0l1 = __builtin_bit_cast(bf16x8, cb[s0][3]);
-        const bf16x8 b1h0 = __builtin_bit_cast(bf16x8, cb[s1][0]), b1l0 = __builtin_bit_cast(bf16x8, cb[s1][1]);
-        const bf16x8 b1h1 = __builtin_bit_cast(bf16x8, cb[s1][2]), b1l1 = __builtin_bit_cast(bf16x8, cb[s1][3]);
-        const bf16x8 a0h = fh[u % 3][0], a0l = fl[u % 3][0], a1h = fh[u % 3][1], a1l = fl[u % 3][1];
-        acc[i0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, b0h0, acc[i0][0], 0, 0, 0);
-        acc[i0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, b0h1, acc[i0][1], 0, 0, 0);
-        acc[i1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, b1h0, acc[i1][0], 0, 0, 0);
-        acc[i1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, b1h1, acc[i1][1], 0, 0, 0);
+        const u32x4 b0h0 = cb[s0][0], b0l0 = cb[s0][1];
+        const u32x4 b0h1 = cb[s0][2], b0l1 = cb[s0][3];
+        const u32x4 b1h0 = cb[s1][0], b1l0 = cb[s1][1];
+        const u32x4 b1h1 = cb[s1][2], b1l1 = cb[s1][3];
+        const u32x4 a0h = fh[u % 3][0], a0l = fl[u % 3][0], a1h = fh[u % 3][1], a1l = fl[u % 3][1];
+        acc[i0][0] = dc_mfma<PREC>(a0l, b0h0, acc[i0][0]);
+        acc[i0][1] = dc_mfma<PREC>(a0l, b0h1, acc[i0][1]);
+        acc[i1][0] = dc_mfma<PREC>(a1l, b1h0, acc[i1][0]);
+        acc[i1][1] = dc_mfma<PREC>(a1l, b1h1, acc[i1][1]);
         __builtin_amdgcn_sched_barrier(0);
-        acc[i0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0l0, acc[i0][0], 0, 0, 0);
-        acc[i0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0l1, acc[i0][1], 0, 0, 0);
-        acc[i1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1l0, acc[i1][0], 0, 0, 0);
-        acc[i1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1l1, acc[i1][1], 0, 0, 0);
+        acc[i0][0] = dc_mfma<PREC>(a0h, b0l0, acc[i0][0]);
+        acc[i0][1] = dc_mfma<PREC>(a0h, b0l1, acc[i0][1]);
+        acc[i1][0] = dc_mfma<PREC>(a1h, b1l0, acc[i1][0]);
+        acc[i1][1] = dc_mfma<PREC>(a1h, b1l1, acc[i1][1]);
         __builtin_amdgcn_sched_barrier(0);
-        acc[i0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0h0, acc[i0][0], 0, 0, 0);
-        acc[i0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0h1, acc[i0][1], 0, 0, 0);
-        acc[i1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1h0, acc[i1][0], 0, 0, 0);
-        acc[i1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1h1, acc[i1][1], 0, 0, 0);
+        acc[i0][0] = dc_mfma<PREC>(a0h, b0h0, acc[i0][0]);
+        acc[i0][1] = dc_mfma<PREC>(a0h, b0h1, acc[i0][1]);
+        acc[i1][0] = dc_mfma<PREC>(a1h, b1h0, acc[i1][0]);
+        acc[i1][1] = dc_mfma<PREC>(a1h, b1h1, acc[i1][1]);
         // a substep's B registers are free once its last tile has issued: refill them for the next stage
         // (unconditionally -- the last stage re-reads its own fragments: a branch here makes the compiler's
         // s_waitcnt bookkeeping merge two histories and wait for vmcnt(0) in the middle of the stage, 1350 clocks)
@@ -709,6 +861,8 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
 
   DL_STAMP(loader ? 1 : 0, 31);
   // ---- epilogue (all 8 waves): accumulators -> LDS tile [144 px][128 + 4] fp32 -> bias + ReLU -> outputs
+  const DcScales sc = dc_scales<PREC>(p);
+  float vmax = 0.f;
   float* tile = reinterpret_cast<float*>(smem_l);
   // this thread's output role: 8 consecutive couts (y_hi requires Cout % 8 == 0); the two bias vectors are requested
   // before the accumulator exchange so their latency hides behind it
@@ -744,8 +898,9 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
         if (row < BM && m < p.M) {
           const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + row * DL_TS + c8 * 8);
           const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + row * DL_TS + c8 * 8 + 4);
-          float v[8] = {t0[0] + eb0[0], t0[1] + eb0[1], t0[2] + eb0[2], t0[3] + eb0[3],
-                        t1[0] + eb1[0], t1[1] + eb1[1], t1[2] + eb1[2], t1[3] + eb1[3]};
+          float v[8] = {dc_finish<PREC>(t0[0], eb0[0], sc), dc_finish<PREC>(t0[1], eb0[1], sc), dc_finish<PREC>(t0[2], eb0[2], sc),
+                        dc_finish<PREC>(t0[3], eb0[3], sc), dc_finish<PREC>(t1[0], eb1[0], sc), dc_finish<PREC>(t1[1], eb1[1], sc),
+                        dc_finish<PREC>(t1[2], eb1[2], sc), dc_finish<PREC>(t1[3], eb1[3], sc)};
           u32x4 vh, vl;
 #pragma unroll
           for (int e2 = 0; e2 < 4; e2++) {
@@ -754,8 +909,9 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
               v0 = fmaxf(v0, 0.f);
               v1 = fmaxf(v1, 0.f);
             }
+            if constexpr (PREC == 1) vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
             unsigned h, l;
-            split_pair(v0, v1, h, l);
+            split_pair<PREC>(v0, v1, sc.s_out, h, l);
             vh[e2] = h;
             vl[e2] = l;
           }
@@ -764,6 +920,7 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
         }
       }
     }
+    if constexpr (PREC == 1) dc_range_check(p, vmax, sc.limit);
   }
   if (y_nchw) {
     const int HW = p.H * p.W;
@@ -776,7 +933,7 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
       for (int e = 0; e < 4; e++) {
         const int m = m0 + r4 * 4 + e;
         if (m >= p.M) continue;
-        float v = tile[(r4 * 4 + e) * DL_TS + col] + bv;
+        float v = dc_finish<PREC>(tile[(r4 * 4 + e) * DL_TS + col], bv, sc);
         if (p.relu) v = fmaxf(v, 0.f);
         const int b = m / HW, pix = m - b * HW;
         y_nchw[((size_t)b * p.cout_store + co) * HW + pix] = v;
@@ -807,6 +964,7 @@ static_assert(2 * D2_PLANE <= dl_smem(D2_TH), "the neighbourhood image lives in 
 // draw -- an atomic round trip of ~1.5 us -- is issued behind the matrix phase by one thread of a loader wave and travels while the
 // epilogue stores, instead of standing between this tile's last store and the next tile.  (Asking at the START of a live tile hands
 // tiles to workgroups that stay busy for 15 us: 21 -> 32 us; at this point the workgroup is one epilogue away from being free.)
+template <int PREC>
 __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* __restrict__ x_hi, const bf16_t* __restrict__ x_lo,
                                           const bf16_t* __restrict__ w_img, const float* __restrict__ bias, const DcParams& p,
                                           bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo, const int mtile, int* s_next) {
@@ -901,14 +1059,14 @@ __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* _
       constexpr int TAP = decltype(tapc)::value;
       constexpr int dyc = TAP / 3, dxc = TAP % 3;  // halo offsets (the image starts one row / column before the tile)
       constexpr int NSTEP = DL_SS * MT / 2;
-      bf16x8 fh[3][2], fl[3][2];
-      auto frag = [&](auto tc, bf16x8& h, bf16x8& l) {
+      u32x4 fh[3][2], fl[3][2];
+      auto frag = [&](auto tc, u32x4& h, u32x4& l) {
         constexpr int t = decltype(tc)::value;
         constexpr int ss = t / MT, i = t % MT;
         constexpr int c = (i + dyc) * D2_HW + dxc;
         const unsigned a = (pw[c & 7] ^ (unsigned)((ss & 1) << 6)) + (unsigned)((ss >> 1) * D2_HALF + c * 128);
-        h = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(lds + a);
-        l = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(lds + a + D2_PLANE);
+        h = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(lds + a);
+        l = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(lds + a + D2_PLANE);
       };
 #define D2_IC(v) std::integral_constant<int, (v)>{}
       frag(D2_IC(0), fh[0][0], fl[0][0]);
@@ -923,25 +1081,25 @@ __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* _
         }
         constexpr int t0 = 2 * u, t1 = 2 * u + 1;
         constexpr int s0 = t0 / MT, i0 = t0 % MT, s1 = t1 / MT, i1 = t1 % MT;
-        const bf16x8 b0h0 = __builtin_bit_cast(bf16x8, cb[s0][0]), b0l0 = __builtin_bit_cast(bf16x8, cb[s0][1]);
-        const bf16x8 b0h1 = __builtin_bit_cast(bf16x8, cb[s0][2]), b0l1 = __builtin_bit_cast(bf16x8, cb[s0][3]);
-        const bf16x8 b1h0 = __builtin_bit_cast(bf16x8, cb[s1][0]), b1l0 = __builtin_bit_cast(bf16x8, cb[s1][1]);
-        const bf16x8 b1h1 = __builtin_bit_cast(bf16x8, cb[s1][2]), b1l1 = __builtin_bit_cast(bf16x8, cb[s1][3]);
-        const bf16x8 a0h = fh[u % 3][0], a0l = fl[u % 3][0], a1h = fh[u % 3][1], a1l = fl[u % 3][1];
-        acc[i0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, b0h0, acc[i0][0], 0, 0, 0);
-        acc[i0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, b0h1, acc[i0][1], 0, 0, 0);
-        acc[i1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, b1h0, acc[i1][0], 0, 0, 0);
-        acc[i1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, b1h1, acc[i1][1], 0, 0, 0);
+        const u32x4 b0h0 = cb[s0][0], b0l0 = cb[s0][1];
+        const u32x4 b0h1 = cb[s0][2], b0l1 = cb[s0][3];
+        const u32x4 b1h0 = cb[s1][0], b1l0 = cb[s1][1];
+        const u32x4 b1h1 = cb[s1][2], b1l1 = cb[s1][3];
+        const u32x4 a0h = fh[u % 3][0], a0l = fl[u % 3][0], a1h = fh[u % 3][1], a1l = fl[u % 3][1];
+        acc[i0][0] = dc_mfma<PREC>(a0l, b0h0, acc[i0][0]);
+        acc[i0][1] = dc_mfma<PREC>(a0l, b0h1, acc[i0][1]);
+        acc[i1][0] = dc_mfma<PREC>(a1l, b1h0, acc[i1][0]);
+        acc[i1][1] = dc_mfma<PREC>(a1l, b1h1, acc[i1][1]);
         __builtin_amdgcn_sched_barrier(0);
-        acc[i0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0l0, acc[i0][0], 0, 0, 0);
-        acc[i0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0l1, acc[i0][1], 0, 0, 0);
-        acc[i1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1l0, acc[i1][0], 0, 0, 0);
-        acc[i1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1l1, acc[i1][1], 0, 0, 0);
+        acc[i0][0] = dc_mfma<PREC>(a0h, b0l0, acc[i0][0]);
+        acc[i0][1] = dc_mfma<PREC>(a0h, b0l1, acc[i0][1]);
+        acc[i1][0] = dc_mfma<PREC>(a1h, b1l0, acc[i1][0]);
+        acc[i1][1] = dc_mfma<PREC>(a1h, b1l1, acc[i1][1]);
         __builtin_amdgcn_sched_barrier(0);
-        acc[i0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0h0, acc[i0][0], 0, 0, 0);
-        acc[i0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0h1, acc[i0][1], 0, 0, 0);
-        acc[i1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1h0, acc[i1][0], 0, 0, 0);
-        acc[i1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1h1, acc[i1][1], 0, 0, 0);
+        acc[i0][0] = dc_mfma<PREC>(a0h, b0h0, acc[i0][0]);
+        acc[i0][1] = dc_mfma<PREC>(a0h, b0h1, acc[i0][1]);
+        acc[i1][0] = dc_mfma<PREC>(a1h, b1h0, acc[i1][0]);
+        acc[i1][1] = dc_mfma<PREC>(a1h, b1h1, acc[i1][1]);
         // a substep's B registers are free once its last tile has issued: refill them for the next tap (unconditionally:
         // behind the last tap a re-read nobody uses -- see dl_tile)
         if constexpr (i0 == MT - 1) load_b(s0);
@@ -972,6 +1130,8 @@ __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* _
   unsigned drawn = 0u;
   if (draws && tid == 4 * 64) drawn = gridDim.x + atomicAdd(p.work, 1u);  // the next tile, requested now (see the header)
   // ---- epilogue (all 8 waves): accumulators -> LDS tile [80 px][128 + 4] fp32 -> bias + ReLU -> split planes
+  const DcScales sc = dc_scales<PREC>(p);
+  float vmax = 0.f;
   float* tile = reinterpret_cast<float*>(smem_l);
   f32x4 eb0 = f32x4{0.f, 0.f, 0.f, 0.f}, eb1 = eb0;
   {
@@ -1000,8 +1160,9 @@ __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* _
         const size_t m = ((size_t)b * p.H + yy) * p.W + xx;
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + row * DL_TS + c8 * 8);
         const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + row * DL_TS + c8 * 8 + 4);
-        float v[8] = {t0[0] + eb0[0], t0[1] + eb0[1], t0[2] + eb0[2], t0[3] + eb0[3],
-                      t1[0] + eb1[0], t1[1] + eb1[1], t1[2] + eb1[2], t1[3] + eb1[3]};
+        float v[8] = {dc_finish<PREC>(t0[0], eb0[0], sc), dc_finish<PREC>(t0[1], eb0[1], sc), dc_finish<PREC>(t0[2], eb0[2], sc),
+                      dc_finish<PREC>(t0[3], eb0[3], sc), dc_finish<PREC>(t1[0], eb1[0], sc), dc_finish<PREC>(t1[1], eb1[1], sc),
+                      dc_finish<PREC>(t1[2], eb1[2], sc), dc_finish<PREC>(t1[3], eb1[3], sc)};
         u32x4 vh, vl;
 #pragma unroll
         for (int e2 = 0; e2 < 4; e2++) {
@@ -1010,8 +1171,9 @@ __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* _
             v0 = fmaxf(v0, 0.f);
             v1 = fmaxf(v1, 0.f);
           }
+          if constexpr (PREC == 1) vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
           unsigned h, l;
-          split_pair(v0, v1, h, l);
+          split_pair<PREC>(v0, v1, sc.s_out, h, l);
           vh[e2] = h;
           vl[e2] = l;
         }
@@ -1020,11 +1182,13 @@ __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* _
       }
     }
   }
+  if constexpr (PREC == 1) dc_range_check(p, vmax, sc.limit);
   if (draws && tid == 4 * 64) *s_next = (int)drawn;
   return draws;
 }
 
 // persistent grid drawing 2-D tiles from the counter pair (see conv2d_bf16x3_large_kernel)
+template <int PREC>
 __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_tile2d_kernel(const bf16_t* __restrict__ x_hi, const bf16_t* __restrict__ x_lo,
                                                                           const bf16_t* __restrict__ w_img, const float* __restrict__ bias,
                                                                           const DcParams p, bf16_t* __restrict__ y_hi,
@@ -1039,7 +1203,7 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_tile2d_kernel(const 
   if (p.reset_ptr && blockIdx.x == 0)
     for (int i = threadIdx.x; i < p.reset_words; i += DL_THREADS) p.reset_ptr[i] = 0u;
   for (int mtile = blockIdx.x; mtile < ntiles;) {  // workgroup-uniform
-    const bool drew = dl_tile2d(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, mtile, &s_next);
+    const bool drew = dl_tile2d<PREC>(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, mtile, &s_next);
     if (!drew && threadIdx.x == 0) s_next = (int)(gridDim.x + atomicAdd(p.work, 1u));
     __syncthreads();  // everyone is done with this tile's LDS
     mtile = s_next;
@@ -1057,7 +1221,7 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_tile2d_kernel(const 
 // hardware dispatcher hands out workgroups in order, not to the first free CU (measured: 440 80-pixel tiles of which ~200 live
 // took as long as 440 live ones).  Drawing from a counter, CUs that hit background tiles come back within a few microseconds
 // and take the next tile: ~200 live tiles spread over 256 CUs, one each.  The counter pair resets itself (last workgroup out).
-template <int KS, int MT>
+template <int KS, int MT, int PREC>
 __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const bf16_t* __restrict__ x_hi,
                                                                          const bf16_t* __restrict__ x_lo,
                                                                          const bf16_t* __restrict__ w_img,
@@ -1073,7 +1237,7 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
       const int q = nt / 8, rmd = nt % 8, xcd = mtile % 8, idx = mtile / 8;
       mtile = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;
     }
-    dl_tile<KS, MT>(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, y_nchw, mtile);
+    dl_tile<KS, MT, PREC>(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, y_nchw, mtile);
     return;
   }
   const int ntiles = (p.M + MT * 16 - 1) / (MT * 16);
@@ -1081,7 +1245,7 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
     for (int i = threadIdx.x; i < p.reset_words; i += DL_THREADS) p.reset_ptr[i] = 0u;
   // (the first tile of a workgroup is its own index: no round trip to the counter in front of it)
   for (int mtile = blockIdx.x; mtile < ntiles;) {  // workgroup-uniform
-    dl_tile<KS, MT>(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, y_nchw, mtile);
+    dl_tile<KS, MT, PREC>(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, y_nchw, mtile);
     if (threadIdx.x == 0) s_next = (int)(gridDim.x + atomicAdd(p.work, 1u));
     __syncthreads();  // everyone is done with this tile's LDS
     mtile = s_next;
@@ -1101,7 +1265,7 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_large_kernel(const b
 // from global memory (a lane's 8 channels are one 16-byte load), 3 MFMAs per 32 channels into one accumulator per term,
 // D[pixel = (lane >> 4) * 4 + r][cout = lane & 15] goes out as NCHW with bias (+ ReLU).  14 -> ~9 us.
 // ------------------------------------------------------------------------------------------------
-template <int STEPS>  // Cin / 32: compile-time, so that the fragment arrays are plain registers (a run-time bound spilled them)
+template <int STEPS, int PREC>  // Cin / 32: compile-time, so that the fragment arrays are plain registers (a run-time bound spilled them)
 __global__ __launch_bounds__(256) void conv1x1_bf16x3_small_cout_kernel(const bf16_t* __restrict__ x_hi,
                                                                         const bf16_t* __restrict__ x_lo,
                                                                         const bf16_t* __restrict__ w_img,
@@ -1126,19 +1290,20 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_small_cout_kernel(const bf
   f32x4 c_lh = {0.f, 0.f, 0.f, 0.f}, c_hl = c_lh, c_hh = c_lh;
 #pragma unroll
   for (int s = 0; s < STEPS; s++) {
-      c_lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[s]), __builtin_bit_cast(bf16x8, bh[s]), c_lh, 0, 0, 0);
-      c_hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[s]), __builtin_bit_cast(bf16x8, bl[s]), c_hl, 0, 0, 0);
-      c_hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[s]), __builtin_bit_cast(bf16x8, bh[s]), c_hh, 0, 0, 0);
+      c_lh = dc_mfma<PREC>(al[s], bh[s], c_lh);
+      c_hl = dc_mfma<PREC>(ah[s], bl[s], c_hl);
+      c_hh = dc_mfma<PREC>(ah[s], bh[s], c_hh);
     }
   const int co = lane & 15;
   if (co >= p.cout_store) return;
+  const DcScales sc = dc_scales<PREC>(p);
   const float bv = bias ? bias[co] : 0.f;
   const int HW = p.H * p.W;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int m = m0 + (lane >> 4) * 4 + r;
     if (m >= p.M) continue;
-    float v = ((c_lh[r] + c_hl[r]) + c_hh[r]) + bv;  // small terms first
+    float v = dc_finish<PREC>((c_lh[r] + c_hl[r]) + c_hh[r], bv, sc);  // small terms first
     if (p.relu) v = fmaxf(v, 0.f);
     const int b = m / HW, pix = m - b * HW;
     y_nchw[((size_t)b * p.cout_store + co) * HW + pix] = v;
@@ -1163,11 +1328,17 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_small_cout_kernel(const bf
 #define FH_SLAB (2 * 16 * FH_ROW)                   // hi + lo planes of one wave's 16 x 128 tile
 #define FH_W1_BYTES (4 * 2 * 128 * 32 * 2)          // 4 k-steps x (hi, lo) x 128 couts x 32 cins, bf16
 #define FH_SMEM (FH_W1_BYTES + FH_WAVES * FH_SLAB)
+struct FhScales {  // f16s (PREC 1): entries of the input planes and of the intermediate tensor, the two images' trailers, the flag
+  const float *in_entry, *mid_entry, *w1_trailer, *w2_trailer;
+  int* range_flag;
+};
+template <int PREC>
 __global__ __launch_bounds__(FH_WAVES * 64) void conv1x1_head_fused_kernel(const bf16_t* __restrict__ x_hi, const bf16_t* __restrict__ x_lo,
                                                                           const bf16_t* __restrict__ w1_img, const float* __restrict__ b1,
                                                                           int relu1, const bf16_t* __restrict__ w2_img,
                                                                           const float* __restrict__ b2, int relu2, int M, int HW,
-                                                                          int cout2, int cout2_pad, float* __restrict__ y_nchw) {
+                                                                          int cout2, int cout2_pad, float* __restrict__ y_nchw,
+                                                                          const FhScales fs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fh_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1187,6 +1358,14 @@ __global__ __launch_bounds__(FH_WAVES * 64) void conv1x1_head_fused_kernel(const
     }
   }
   __syncthreads();
+  DcScales sc1{1.f, 1.f, 3.0e38f}, sc2{1.f, 1.f, 3.0e38f};
+  if constexpr (PREC == 1) {
+    sc1.undo = fs.in_entry[1] * fs.w1_trailer[1];
+    sc1.s_out = fs.mid_entry[0];
+    sc1.limit = fs.mid_entry[2];
+    sc2.undo = fs.mid_entry[1] * fs.w2_trailer[1];
+  }
+  float vmax = 0.f;
   const unsigned char* w1s = fh_smem;
   unsigned char* slab = fh_smem + FH_W1_BYTES + wave * FH_SLAB;
   const int px_l = lane & 15, kg = lane >> 4;
@@ -1211,13 +1390,13 @@ __global__ __launch_bounds__(FH_WAVES * 64) void conv1x1_head_fused_kernel(const
         bh[nf] = *reinterpret_cast<const u32x4*>(w1s + s * 16384 + (nf * 64 + lane) * 16);
         bl[nf] = *reinterpret_cast<const u32x4*>(w1s + s * 16384 + 8192 + (nf * 64 + lane) * 16);
       }
-      const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[s]), a_l = __builtin_bit_cast(bf16x8, al[s]);
+      const u32x4 a_h = ah[s], a_l = al[s];
 #pragma unroll
-      for (int nf = 0; nf < 8; nf++) acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, __builtin_bit_cast(bf16x8, bh[nf]), acc[nf], 0, 0, 0);
+      for (int nf = 0; nf < 8; nf++) acc[nf] = dc_mfma<PREC>(a_l, bh[nf], acc[nf]);
 #pragma unroll
-      for (int nf = 0; nf < 8; nf++) acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, __builtin_bit_cast(bf16x8, bl[nf]), acc[nf], 0, 0, 0);
+      for (int nf = 0; nf < 8; nf++) acc[nf] = dc_mfma<PREC>(a_h, bl[nf], acc[nf]);
 #pragma unroll
-      for (int nf = 0; nf < 8; nf++) acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, __builtin_bit_cast(bf16x8, bh[nf]), acc[nf], 0, 0, 0);
+      for (int nf = 0; nf < 8; nf++) acc[nf] = dc_mfma<PREC>(a_h, bh[nf], acc[nf]);
     }
     // bias + ReLU + split: D[pixel = kg * 4 + r][cout = nf * 16 + px_l] -> slab[plane][pixel][cout] (bf16)
 #pragma unroll
@@ -1225,13 +1404,14 @@ __global__ __launch_bounds__(FH_WAVES * 64) void conv1x1_head_fused_kernel(const
       const float bv = b1 ? b1[nf * 16 + px_l] : 0.f;
 #pragma unroll
       for (int r2 = 0; r2 < 2; r2++) {
-        float v0 = acc[nf][2 * r2] + bv, v1 = acc[nf][2 * r2 + 1] + bv;
+        float v0 = dc_finish<PREC>(acc[nf][2 * r2], bv, sc1), v1 = dc_finish<PREC>(acc[nf][2 * r2 + 1], bv, sc1);
         if (relu1) {
           v0 = fmaxf(v0, 0.f);
           v1 = fmaxf(v1, 0.f);
         }
+        if constexpr (PREC == 1) vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
         unsigned h, l;
-        split_pair(v0, v1, h, l);
+        split_pair<PREC>(v0, v1, sc1.s_out, h, l);
         const int p0 = kg * 4 + 2 * r2, off = (nf * 16 + px_l) * 2;
         *reinterpret_cast<unsigned short*>(slab + p0 * FH_ROW + off) = (unsigned short)(h & 0xFFFFu);
         *reinterpret_cast<unsigned short*>(slab + (p0 + 1) * FH_ROW + off) = (unsigned short)(h >> 16);
@@ -1245,9 +1425,9 @@ __global__ __launch_bounds__(FH_WAVES * 64) void conv1x1_head_fused_kernel(const
     for (int s = 0; s < 4; s++) {
       const u32x4 a2h = *reinterpret_cast<const u32x4*>(slab + px_l * FH_ROW + s * 64 + kg * 16);
       const u32x4 a2l = *reinterpret_cast<const u32x4*>(slab + 16 * FH_ROW + px_l * FH_ROW + s * 64 + kg * 16);
-      c_lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a2l), __builtin_bit_cast(bf16x8, h_bh[s]), c_lh, 0, 0, 0);
-      c_hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a2h), __builtin_bit_cast(bf16x8, h_bl[s]), c_hl, 0, 0, 0);
-      c_hh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a2h), __builtin_bit_cast(bf16x8, h_bh[s]), c_hh, 0, 0, 0);
+      c_lh = dc_mfma<PREC>(a2l, h_bh[s], c_lh);
+      c_hl = dc_mfma<PREC>(a2h, h_bl[s], c_hl);
+      c_hh = dc_mfma<PREC>(a2h, h_bh[s], c_hh);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the fragment reads are done before the next tile overwrites the slab
     const int co = px_l;
@@ -1257,33 +1437,54 @@ __global__ __launch_bounds__(FH_WAVES * 64) void conv1x1_head_fused_kernel(const
       for (int r = 0; r < 4; r++) {
         const int m = m0 + kg * 4 + r;
         if (m >= M) continue;
-        float v = ((c_lh[r] + c_hl[r]) + c_hh[r]) + bv;  // small terms first
+        float v = dc_finish<PREC>((c_lh[r] + c_hl[r]) + c_hh[r], bv, sc2);  // small terms first
         if (relu2) v = fmaxf(v, 0.f);
         const int b = m / HW, pix = m - b * HW;
         y_nchw[((size_t)b * cout2 + co) * HW + pix] = v;
       }
     }
   }
+  if constexpr (PREC == 1)
+    if (fs.range_flag && vmax > sc1.limit) atomicMax(fs.range_flag, V3D_FLAG_RANGE);
+}
+
+static int dc_check_prec(const v3d_conv2d_prec* pr, bool planes_out) {
+  if (!pr || pr->prec == V3D_PREC_BF16X3) return V3D_OK;
+  if (pr->prec != V3D_PREC_F16S || !pr->in_entry || (planes_out && !pr->out_entry)) return V3D_EINVAL;
+  return V3D_OK;
 }
 
 extern "C" int v3d_conv2d_1x1_head_fused(const void* x_hi, const void* x_lo, const void* w1_image, const float* b1, int relu1,
                                          const void* w2_image, const float* b2, int relu2, int B, int H, int W, int Cmid, int Cout2,
                                          float* y_nchw, v3d_stream_t stream) {
+  return v3d_conv2d_1x1_head_fused2(x_hi, x_lo, w1_image, b1, relu1, w2_image, b2, relu2, B, H, W, Cmid, Cout2, y_nchw, nullptr, stream);
+}
+
+extern "C" int v3d_conv2d_1x1_head_fused2(const void* x_hi, const void* x_lo, const void* w1_image, const float* b1, int relu1,
+                                          const void* w2_image, const float* b2, int relu2, int B, int H, int W, int Cmid, int Cout2,
+                                          float* y_nchw, const v3d_conv2d_prec* pr, v3d_stream_t stream) {
   if (!x_hi || !x_lo || !w1_image || !w2_image || !y_nchw || B < 1 || H < 1 || W < 1) return V3D_EINVAL;
   if (Cmid != 128 || Cout2 < 1 || Cout2 > 16) return V3D_EUNSUPPORTED;  // 128 -> 128 -> <= 16: the SECOND RPN tail
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    V3D_CHECK_HIP(hipGetDevice(&dev));
-    V3D_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  if (dc_check_prec(pr, true)) return V3D_EINVAL;  // (out_entry = the entry of the intermediate 128-channel tensor)
+  const int n_cu = v3d_device_cu_count();
+  if (n_cu < 1) return V3D_EINVAL;
   const int M = B * H * W, ntiles = (M + 15) / 16;
   const int grid = std::min(v3d_ceil_div(ntiles, FH_WAVES), n_cu);
   const int cout2_pad = (Cout2 + DC_BN - 1) / DC_BN * DC_BN;
-  V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv1x1_head_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FH_SMEM));
-  hipLaunchKernelGGL(conv1x1_head_fused_kernel, dim3(grid), dim3(FH_WAVES * 64), FH_SMEM, (hipStream_t)stream, (const bf16_t*)x_hi,
+  const bool f16s = pr && pr->prec == V3D_PREC_F16S;
+  FhScales fs{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (f16s) {
+    fs.in_entry = pr->in_entry;
+    fs.mid_entry = pr->out_entry;
+    fs.w1_trailer = reinterpret_cast<const float*>(reinterpret_cast<const char*>(w1_image) + dc_image_payload_bytes(128, 128, 1));
+    fs.w2_trailer = reinterpret_cast<const float*>(reinterpret_cast<const char*>(w2_image) + dc_image_payload_bytes(128, Cout2, 1));
+    fs.range_flag = pr->range_flag;
+  }
+  auto kern = f16s ? conv1x1_head_fused_kernel<1> : conv1x1_head_fused_kernel<0>;
+  V3D_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, FH_SMEM));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(FH_WAVES * 64), FH_SMEM, (hipStream_t)stream, (const bf16_t*)x_hi,
                      (const bf16_t*)x_lo, (const bf16_t*)w1_image, b1, relu1, (const bf16_t*)w2_image, b2, relu2, M, H * W, Cout2,
-                     cout2_pad, y_nchw);
+                     cout2_pad, y_nchw, fs);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -1292,8 +1493,8 @@ extern "C" int v3d_conv2d_bg_tiles(int B, int H, int W);
 extern "C" int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
                                       int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
                                       float* y_nchw, v3d_stream_t stream) {
-  return v3d_conv2d_nhwc_bf16x3_bg(x_hi, x_lo, weight_image, bias, relu, B, H, W, Cin, Cout, ksize, y_hi, y_lo, y_nchw, nullptr, 0,
-                                   nullptr, nullptr, nullptr, nullptr, stream);
+  return v3d_conv2d_nhwc_split(x_hi, x_lo, weight_image, bias, relu, B, H, W, Cin, Cout, ksize, y_hi, y_lo, y_nchw, nullptr, 0,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, stream);
 }
 
 // BEV occupancy bitmap, INVERTED (bit cleared = occupied) so that the 0xFF fill that resets the rest of a plan's per-frame
@@ -1333,8 +1534,8 @@ extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, con
                                          int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
                                          float* y_nchw, const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo,
                                          uint32_t* work, uint32_t* tile_state, v3d_stream_t stream) {
-  return v3d_conv2d_nhwc_bf16x3_bg2(x_hi, x_lo, weight_image, bias, relu, B, H, W, Cin, Cout, ksize, y_hi, y_lo, y_nchw, occ, reach, bg_hi,
-                                    bg_lo, work, tile_state, nullptr, 0, stream);
+  return v3d_conv2d_nhwc_split(x_hi, x_lo, weight_image, bias, relu, B, H, W, Cin, Cout, ksize, y_hi, y_lo, y_nchw, occ, reach, bg_hi,
+                               bg_lo, work, tile_state, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int v3d_conv2d_nhwc_bf16x3_bg2(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
@@ -1342,12 +1543,101 @@ extern "C" int v3d_conv2d_nhwc_bf16x3_bg2(const void* x_hi, const void* x_lo, co
                                           float* y_nchw, const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo,
                                           uint32_t* work, uint32_t* tile_state, uint32_t* reset_ptr, int reset_words,
                                           v3d_stream_t stream) {
+  return v3d_conv2d_nhwc_split(x_hi, x_lo, weight_image, bias, relu, B, H, W, Cin, Cout, ksize, y_hi, y_lo, y_nchw, occ, reach, bg_hi,
+                               bg_lo, work, tile_state, reset_ptr, reset_words, nullptr, stream);
+}
+
+template <int PREC>
+static int dc_launch(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias, DcParams p, int ksize,
+                     void* y_hi, void* y_lo, float* y_nchw, const uint32_t* occ, uint32_t* work, uint32_t* tile_state,
+                     uint32_t* reset_ptr, int reset_words, hipStream_t st) {
+  const int B = p.B, H = p.H, W = p.W, Cin = p.Cin, Cout = p.Cout;
+  if (ksize == 1 && !y_hi && Cout <= 16 && (Cin == 128 || Cin == 256)) {  // the head: stream kernel
+    const dim3 sgrid(v3d_ceil_div(v3d_ceil_div(p.M, 16), 4));
+    if (Cin == 128)
+      hipLaunchKernelGGL((conv1x1_bf16x3_small_cout_kernel<4, PREC>), sgrid, dim3(256), 0, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+                         (const bf16_t*)weight_image, bias, p, y_nchw);
+    else
+      hipLaunchKernelGGL((conv1x1_bf16x3_small_cout_kernel<8, PREC>), sgrid, dim3(256), 0, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+                         (const bf16_t*)weight_image, bias, p, y_nchw);
+    V3D_CHECK_LAUNCH();
+    if (reset_ptr) V3D_CHECK_HIP(v3d_fill_async(reset_ptr, 0, (size_t)reset_words * 4, st));  // (not a persistent path: see below)
+    return V3D_OK;
+  }
+  const bool large_ok = Cin >= 64 && H < 32768 && W < 65536 && W >= 16;  // (Cin % 32 == 0 checked by the caller) else: the 64-pixel kernel
+  if (large_ok && Cout > 32) {
+    // With background skipping (and a work counter) the tiles are 80 pixels instead of 144 and the grid is persistent, one
+    // workgroup per CU drawing tiles from the counter: see the kernel.  The LDS request is padded past half a CU's LDS so that
+    // two workgroups never share a CU.
+    const int n_cu = v3d_device_cu_count();
+    if (n_cu < 1) return V3D_EINVAL;
+    const bool persistent = p.occ && work && p.CoutPad == DC_BN;
+    if (persistent && ksize == 3 && Cin == DL_KC) {  // 2-D tiles with an LDS-resident neighbourhood
+      p.work = work;
+      p.tile_state = tile_state;
+      p.reset_ptr = reset_ptr;
+      p.reset_words = reset_words;
+      const int tiles2 = B * v3d_ceil_div(H, D2_TH) * v3d_ceil_div(W, D2_TW);
+      const int smem2 = std::max(dl_smem(D2_TH), 84 * 1024);
+      static V3dPerDeviceFlag attr2;
+      V3D_CHECK_HIP(v3d_set_max_lds(attr2, (const void*)conv2d_bf16x3_tile2d_kernel<PREC>, smem2));
+      // (persistent grid on fewer CUs, leaving the rest to other frames' kernels: 192 workgroups +1.8 % pipelined, +3.7 % latency;
+      //  128 neutral, +15 % latency -- profiles/r04_dense_grid.txt; not adopted)
+      hipLaunchKernelGGL(conv2d_bf16x3_tile2d_kernel<PREC>, dim3(std::min(tiles2, n_cu)), dim3(DL_THREADS), smem2, st, (const bf16_t*)x_hi,
+                         (const bf16_t*)x_lo, (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo);
+      V3D_CHECK_LAUNCH();
+      return V3D_OK;
+    }
+    const int mt = persistent ? 5 : 9;  // (in launch order the small tiles only add rounds: 33 vs 27 us on a full map)
+    const int tiles = v3d_ceil_div(p.M, mt * 16);
+    p.work = persistent ? work : nullptr;
+    p.tile_state = persistent ? tile_state : nullptr;
+    p.reset_ptr = persistent ? reset_ptr : nullptr;
+    p.reset_words = persistent ? reset_words : 0;
+    if (tile_state && y_hi && !persistent)  // every pixel of the persistent buffer is about to be computed
+      V3D_CHECK_HIP(v3d_fill_async(tile_state, 0x01, (size_t)v3d_conv2d_bg_tiles(B, H, W) * sizeof(uint32_t), st));
+    // a launch that is NOT persistent cannot zero other call sites' counters from inside the kernel: do it in front (same stream
+    // order as the in-kernel reset: before this layer's tiles, behind the previous launch)
+    if (reset_ptr && !persistent) V3D_CHECK_HIP(v3d_fill_async(reset_ptr, 0, (size_t)reset_words * 4, st));
+    dim3 lgrid(persistent ? std::min(tiles, n_cu) : tiles, p.CoutPad / DC_BN);
+    auto kern = mt == 9 ? (ksize == 3 ? conv2d_bf16x3_large_kernel<3, 9, PREC> : conv2d_bf16x3_large_kernel<1, 9, PREC>)
+                        : (ksize == 3 ? conv2d_bf16x3_large_kernel<3, 5, PREC> : conv2d_bf16x3_large_kernel<1, 5, PREC>);
+    const int smem = std::max(dl_smem(mt), 84 * 1024);
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    hipLaunchKernelGGL(kern, lgrid, dim3(DL_THREADS), smem, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+                       (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo, y_nchw);
+    V3D_CHECK_LAUNCH();
+    return V3D_OK;
+  }
+  if (tile_state && y_hi) V3D_CHECK_HIP(v3d_fill_async(tile_state, 0x01, (size_t)v3d_conv2d_bg_tiles(B, H, W) * sizeof(uint32_t), st));
+  if (reset_ptr) V3D_CHECK_HIP(v3d_fill_async(reset_ptr, 0, (size_t)reset_words * 4, st));
+  dim3 grid(v3d_ceil_div(p.M, DC_BM), p.CoutPad / DC_BN);
+  if (ksize == 3)
+    hipLaunchKernelGGL((conv2d_bf16x3_kernel<3, PREC>), grid, dim3(DC_THREADS), 0, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+                       (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo, y_nchw);
+  else
+    hipLaunchKernelGGL((conv2d_bf16x3_kernel<1, PREC>), grid, dim3(DC_THREADS), 0, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+                       (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo, y_nchw);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+// The convolution on split planes in either arithmetic (`pr` NULL or prec 0: bf16x3 -- the entry points above).  reset_ptr /
+// reset_words: this launch zeroes those counter words of OTHER call sites before its tiles run -- inside the kernel on the persistent
+// paths, by a fill in front of it otherwise, so a chain of layers may mix both kinds (a layer off the persistent paths used to drop
+// the request silently: ADVICE round 4).
+extern "C" int v3d_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
+                                     int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
+                                     float* y_nchw, const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo,
+                                     uint32_t* work, uint32_t* tile_state, uint32_t* reset_ptr, int reset_words,
+                                     const v3d_conv2d_prec* pr, v3d_stream_t stream) {
   if (reset_ptr && (reset_words < 0 || reset_words > 4096 || !work)) return V3D_EINVAL;
   if (!x_hi || !x_lo || !weight_image || B < 1 || H < 1 || W < 1 || Cout < 1) return V3D_EINVAL;
   if (occ && (!bg_hi || !bg_lo || reach < 0 || reach > 64)) return V3D_EINVAL;
   if (Cin < DC_KC || Cin % DC_KC || (ksize != 1 && ksize != 3)) return V3D_EUNSUPPORTED;
   if ((y_hi == nullptr) != (y_lo == nullptr) || (!y_hi && !y_nchw)) return V3D_EINVAL;
   if (y_hi && (Cout % 8)) return V3D_EUNSUPPORTED;
+  if (dc_check_prec(pr, y_hi != nullptr)) return V3D_EINVAL;
   DcParams p;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ks = ksize; p.relu = relu;
   p.CoutPad = (Cout + DC_BN - 1) / DC_BN * DC_BN;
@@ -1364,71 +1654,13 @@ extern "C" int v3d_conv2d_nhwc_bf16x3_bg2(const void* x_hi, const void* x_lo, co
   p.tile_state = nullptr;
   p.reset_ptr = nullptr;
   p.reset_words = 0;
+  const bool f16s = pr && pr->prec == V3D_PREC_F16S;
+  p.in_entry = f16s ? pr->in_entry : nullptr;
+  p.out_entry = (f16s && y_hi) ? pr->out_entry : nullptr;
+  p.range_flag = f16s ? pr->range_flag : nullptr;
+  p.w_trailer = reinterpret_cast<const float*>(reinterpret_cast<const char*>(weight_image) + dc_image_payload_bytes(Cin, Cout, ksize));
   hipStream_t st = (hipStream_t)stream;
-  if (ksize == 1 && !y_hi && Cout <= 16 && (Cin == 128 || Cin == 256)) {  // the head: stream kernel
-    const dim3 sgrid(v3d_ceil_div(v3d_ceil_div(p.M, 16), 4));
-    if (Cin == 128)
-      hipLaunchKernelGGL(conv1x1_bf16x3_small_cout_kernel<4>, sgrid, dim3(256), 0, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
-                         (const bf16_t*)weight_image, bias, p, y_nchw);
-    else
-      hipLaunchKernelGGL(conv1x1_bf16x3_small_cout_kernel<8>, sgrid, dim3(256), 0, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
-                         (const bf16_t*)weight_image, bias, p, y_nchw);
-    V3D_CHECK_LAUNCH();
-    return V3D_OK;
-  }
-  const bool large_ok = Cin >= 64 && H < 32768 && W < 65536 && W >= 16;  // (Cin % 32 == 0 checked above) else: the 64-pixel kernel
-  if (large_ok && Cout > 32) {
-    // With background skipping (and a work counter) the tiles are 80 pixels instead of 144 and the grid is persistent, one
-    // workgroup per CU drawing tiles from the counter: see the kernel.  The LDS request is padded past half a CU's LDS so that
-    // two workgroups never share a CU.
-    static int n_cu = 0;
-    if (!n_cu) {
-      int dev = 0;
-      V3D_CHECK_HIP(hipGetDevice(&dev));
-      V3D_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
-    const bool persistent = p.occ && work && p.CoutPad == DC_BN;
-    if (persistent && ksize == 3 && Cin == DL_KC) {  // 2-D tiles with an LDS-resident neighbourhood
-      p.work = work;
-      p.tile_state = tile_state;
-      p.reset_ptr = reset_ptr;
-      p.reset_words = reset_words;
-      const int tiles2 = B * v3d_ceil_div(H, D2_TH) * v3d_ceil_div(W, D2_TW);
-      const int smem2 = std::max(dl_smem(D2_TH), 84 * 1024);
-      V3D_CHECK_HIP(hipFuncSetAttribute((const void*)conv2d_bf16x3_tile2d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
-      // (persistent grid on fewer CUs, leaving the rest to other frames' kernels: 192 workgroups +1.8 % pipelined, +3.7 % latency;
-      //  128 neutral, +15 % latency -- profiles/r04_dense_grid.txt; not adopted)
-      hipLaunchKernelGGL(conv2d_bf16x3_tile2d_kernel, dim3(std::min(tiles2, n_cu)), dim3(DL_THREADS), smem2, st, (const bf16_t*)x_hi,
-                         (const bf16_t*)x_lo, (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo);
-      V3D_CHECK_LAUNCH();
-      return V3D_OK;
-    }
-    const int mt = persistent ? 5 : 9;  // (in launch order the small tiles only add rounds: 33 vs 27 us on a full map)
-    const int tiles = v3d_ceil_div(p.M, mt * 16);
-    p.work = persistent ? work : nullptr;
-    p.tile_state = persistent ? tile_state : nullptr;
-    p.reset_ptr = persistent ? reset_ptr : nullptr;
-    p.reset_words = persistent ? reset_words : 0;
-    if (tile_state && y_hi && !persistent)  // every pixel of the persistent buffer is about to be computed
-      V3D_CHECK_HIP(v3d_fill_async(tile_state, 0x01, (size_t)v3d_conv2d_bg_tiles(B, H, W) * sizeof(uint32_t), st));
-    dim3 lgrid(persistent ? std::min(tiles, n_cu) : tiles, p.CoutPad / DC_BN);
-    auto kern = mt == 9 ? (ksize == 3 ? conv2d_bf16x3_large_kernel<3, 9> : conv2d_bf16x3_large_kernel<1, 9>)
-                        : (ksize == 3 ? conv2d_bf16x3_large_kernel<3, 5> : conv2d_bf16x3_large_kernel<1, 5>);
-    const int smem = std::max(dl_smem(mt), 84 * 1024);
-    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    hipLaunchKernelGGL(kern, lgrid, dim3(DL_THREADS), smem, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
-                       (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo, y_nchw);
-    V3D_CHECK_LAUNCH();
-    return V3D_OK;
-  }
-  if (tile_state && y_hi) V3D_CHECK_HIP(v3d_fill_async(tile_state, 0x01, (size_t)v3d_conv2d_bg_tiles(B, H, W) * sizeof(uint32_t), st));
-  dim3 grid(v3d_ceil_div(p.M, DC_BM), p.CoutPad / DC_BN);
-  if (ksize == 3)
-    hipLaunchKernelGGL(conv2d_bf16x3_kernel<3>, grid, dim3(DC_THREADS), 0, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
-                       (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo, y_nchw);
-  else
-    hipLaunchKernelGGL(conv2d_bf16x3_kernel<1>, grid, dim3(DC_THREADS), 0, st, (const bf16_t*)x_hi, (const bf16_t*)x_lo,
-                       (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo, y_nchw);
-  V3D_CHECK_LAUNCH();
-  return V3D_OK;
+  if (f16s)
+    return dc_launch<1>(x_hi, x_lo, weight_image, bias, p, ksize, y_hi, y_lo, y_nchw, occ, work, tile_state, reset_ptr, reset_words, st);
+  return dc_launch<0>(x_hi, x_lo, weight_image, bias, p, ksize, y_hi, y_lo, y_nchw, occ, work, tile_state, reset_ptr, reset_words, st);
 }

@@ -72,6 +72,13 @@ struct v3d_backbone {
   void *bev_hi = nullptr, *bev_lo = nullptr;
   int32_t *bev_pix = nullptr, *bev_pix_n = nullptr;
   int ring_tiles_min = 2;  // v3d_backbone_set_throughput_mode: 4
+  // Arithmetic of the packed layers in the INFERENCE entry points (the training plan always runs bf16x3): v3d_backbone_set_precision.
+  // f16s reads one scale entry {s, 1/s, limit, max} per tensor from act_tab: entry l = the rows layer l gathers, entry n_layers =
+  // the BEV map (scale of the split planes the last layer / the densify kernel writes).  Entries start as {1, 1, 2^15}: valid
+  // for magnitudes below 2^15, full precision once v3d_backbone_calibrate has set them from a frame.
+  int prec = V3D_PREC_BF16X3;
+  bool calibrating = false;  // the next forwards run every layer on the exact-fp32 kernel (no scales involved): calibration pass
+  float* act_tab = nullptr;
   struct PlanTrain* train = nullptr;  // training buffers, allocated by the first v3d_backbone_train_forward
   // (Measured and removed in round 4: the rulebook chain on a second stream with one event per finished rulebook -- inside a
   // captured graph the fork / join costs more than the overlap returns, 3 209 -> 2 526 frames/s pipelined)
@@ -96,10 +103,8 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
   // ---- pass 1: geometry, capacities, rulebook sharing
   PlanStage s0{};
   s0.hash_items = (int)cap0;
-  if (true) {  // (same for stage 0's table)
-    cap0 = (cap0 + 63) / 64 * 64;
-    if ((cap0 / 64) % 2 == 0) cap0 += 64;
-  }
+  cap0 = (cap0 + 63) / 64 * 64;  // (an odd multiple of 64 rows: see the strided stages below)
+  if ((cap0 / 64) % 2 == 0) cap0 += 64;
   s0.cap = (int)cap0;
   for (int j = 0; j < 3; j++) s0.shape[j] = cfg->grid_shape[j];
   p->stages.push_back(s0);
@@ -145,10 +150,8 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       // The capacity is the row stride of the stage's neighbour tables (nbr[k][o], k-major): a power of two would put the K rows
       // a tile reads at the same offset of every 128 KB -- one memory channel, one cache set.  Make it an odd multiple of 64 rows.
       ns.hash_items = (int)cap;
-      if (true) {
-        cap = (cap + 63) / 64 * 64;
-        if ((cap / 64) % 2 == 0) cap += 64;
-      }
+      cap = (cap + 63) / 64 * 64;
+      if ((cap / 64) % 2 == 0) cap += 64;
       ns.cap = (int)cap;
       ns.hash_ready_by_sparse = true;
       const long long tickets = (long long)p->stages[cur].cap * conv_fan(L.d);  // tickets per input row: rulebook.hip rb_ticket
@@ -210,6 +213,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       p->bev_pix = ar.take<int32_t>(sl.cap);
       p->bev_pix_n = ar.take<int32_t>(1);
     }
+    p->act_tab = ar.take<float>(4 * (p->layers.size() + 1));
     p->cand_slot[0] = ar.take<int>((size_t)max_tickets);
     p->cand_slot[1] = ar.take<int>((size_t)max_tickets);
     for (auto& L : p->layers) {
@@ -233,6 +237,11 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
   e = hipMemset(p->ff_begin, 0xFF, p->ff_bytes);
   if (e == hipSuccess) e = hipMemset(p->bev_hi, 0, (size_t)((char*)p->bev_lo - (char*)p->bev_hi) * 2);  // the planes are adjacent
   if (e == hipSuccess) e = hipMemset(p->bev_pix_n, 0, sizeof(int32_t));
+  if (e == hipSuccess) {
+    std::vector<float> tab;
+    for (size_t i = 0; i <= p->layers.size(); i++) tab.insert(tab.end(), {1.f, 1.f, 32768.f, 0.f});
+    e = hipMemcpy(p->act_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) { (void)hipFree(p->arena); delete p; return (int)e; }
   *out = p;
   return V3D_OK;
@@ -258,7 +267,7 @@ extern "C" int v3d_backbone_set_layer(v3d_backbone* p, int layer, const float* w
   V3D_CHECK_HIP(hipMemcpyAsync(L.weight, weight, (size_t)L.K * L.d.cin * L.d.cout * 4, hipMemcpyDeviceToDevice, st));
   L.has_affine = scale != nullptr;
   if (L.d.cout % 16 == 0) {
-    int rc = v3d_sparse_conv_pack_weights(L.weight, L.K, L.d.cin, L.d.cout, L.wimg, stream);
+    int rc = v3d_sparse_conv_pack_weights2(L.weight, L.K, L.d.cin, L.d.cout, p->prec, L.wimg, stream);
     if (rc) return rc;
   }
   if (scale) {
@@ -308,7 +317,7 @@ static int plan_frame_start(v3d_backbone* p, void* dense_hi, void* dense_lo, hip
   bool own;
   int rc = plan_own_planes(p, dense_hi, dense_lo, own);
   if (rc) return rc;
-  if (!own || (p->ff_bytes & 15) || ((uintptr_t)p->ff_begin & 15)) {
+  if (!own || (p->ff_bytes & 15) || ((uintptr_t)p->ff_begin & 15) || (p->out_channels * p->stages.back().shape[0]) % 8) {
     V3D_CHECK_HIP(v3d_fill_async(p->ff_begin, 0xFF, p->ff_bytes, st));  // all hash tables, count slots, flags, the occupancy bitmap
     if (!own) return V3D_OK;
     const PlanStage& sl = p->stages.back();
@@ -344,6 +353,41 @@ extern "C" int v3d_backbone_bev_planes(v3d_backbone* p, void** hi, void** lo) {
   if (!p || !hi || !lo) return V3D_EINVAL;
   *hi = p->bev_hi;
   *lo = p->bev_lo;
+  return V3D_OK;
+}
+
+// Arithmetic of the inference entry points.  The weight images are packed per precision: call before v3d_backbone_set_layer
+// (runtime.BackbonePlan re-uploads the layers when it changes).
+extern "C" int v3d_backbone_set_precision(v3d_backbone* p, int prec) {
+  if (!p || (prec != V3D_PREC_BF16X3 && prec != V3D_PREC_F16S)) return V3D_EINVAL;
+  p->prec = prec;
+  return V3D_OK;
+}
+extern "C" int v3d_backbone_precision(const v3d_backbone* p) { return p ? p->prec : V3D_EINVAL; }
+
+// f16s: (n_layers + 1) x {s, 1/s, limit, max} in device memory, entry l = input rows of layer l, entry n_layers = the BEV map
+extern "C" float* v3d_backbone_act_scales(v3d_backbone* p) { return p ? p->act_tab : nullptr; }
+
+// on: the following forwards run every layer on the exact-fp32 kernel (whatever the magnitudes: nothing is scaled) -- the pass
+// v3d_backbone_calibrate reads.  Their split planes are written with the scale entry as it stands.
+extern "C" int v3d_backbone_set_calibrating(v3d_backbone* p, int on) {
+  if (!p) return V3D_EINVAL;
+  p->calibrating = on != 0;
+  return V3D_OK;
+}
+
+// Scale entries from the LAST forward's tensors (enqueued on `stream`, no host synchronisation): per tensor the power of two that
+// puts its largest magnitude `headroom_bits` binades below the top of the scaled range, i.e. later frames may exceed this frame's
+// maxima by 2^(headroom_bits + 1) before the range flag is raised.  Costs nothing in precision up to ~7 bits (spconv.hip).
+extern "C" int v3d_backbone_calibrate(v3d_backbone* p, int headroom_bits, v3d_stream_t stream) {
+  if (!p || headroom_bits < 0 || headroom_bits > 12) return V3D_EINVAL;
+  for (size_t l = 0; l <= p->layers.size(); l++) {
+    const float* rows = l == 0 ? p->mean : p->layers[l - 1].out;
+    const int C = l == 0 ? p->cfg.point_channels : p->layers[l - 1].d.cout;
+    const PlanStage& sg = p->stages[l == 0 ? 0 : p->layers[l - 1].stage_out];
+    int rc = v3d_act_scale_from_rows(rows, sg.n_dev, sg.cap, C, headroom_bits, p->act_tab + 4 * l, stream);
+    if (rc) return rc;
+  }
   return V3D_OK;
 }
 
@@ -455,23 +499,33 @@ static int plan_layer_rulebook(v3d_backbone* p, size_t l, std::vector<char>& rb_
   return rc;
 }
 
-// out = act((sum_k feat[nbr[k]] @ W[k]) * scale + shift) of layer l: the packed bf16x3 kernels where the reduction dim fills
-// an MFMA (Cin >= 16), the exact-fp32 wave kernel else
+// out = act((sum_k feat[nbr[k]] @ W[k]) * scale + shift) of layer l: the packed split-precision kernels where the reduction dim
+// fills an MFMA (Cin >= 16), the exact-fp32 wave kernel else.  `inference`: the plan's arithmetic (f16s reads the layer's scale
+// entries and checks its output against the next one); the training plan passes false (bf16x3 images, no scales).
 static int plan_layer_conv(v3d_backbone* p, PlanLayer& L, const float* feat, const void* wimg, const float* weight,
                            const float* scale, const float* shift, int relu, float* out, hipStream_t st,
-                           const V3dDensifyOut* densify = nullptr, bool* densified = nullptr) {
+                           const V3dDensifyOut* densify = nullptr, bool* densified = nullptr, bool inference = false) {
   const v3d_backbone_config& c = p->cfg;
   PlanStage& so = p->stages[L.stage_out];
   int rc = V3D_EUNSUPPORTED;
   if (densified) *densified = false;
-  if (c.conv_algo == 4 || (c.conv_algo == 0 && L.d.cin >= 16)) {
+  const bool exact_pass = inference && p->calibrating;
+  if (!exact_pass && (c.conv_algo == 4 || (c.conv_algo == 0 && L.d.cin >= 16))) {
+    const int prec = inference ? p->prec : V3D_PREC_BF16X3;
+    const size_t l = (size_t)(&L - p->layers.data());
+    const V3dActScale as{p->act_tab + 4 * l, p->act_tab + 4 * (l + 1), p->overflow + p->layers.size()};
     rc = v3d_i_sparse_conv_fwd_packed(feat, wimg, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout, scale, shift,
-                                      relu, out, L.rows_hint, st, densify, p->ring_tiles_min);
+                                      relu, out, L.rows_hint, st, densify, p->ring_tiles_min, prec, &as);
     if (rc == V3D_OK && densify && densified) *densified = true;
   }
-  if (rc == V3D_EUNSUPPORTED)
-    rc = v3d_sparse_conv_fwd(feat, weight, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout, scale, shift, relu,
-                             out, (c.conv_algo == 4 || c.conv_algo == 0) ? 3 : c.conv_algo, st);
+  if (rc == V3D_EUNSUPPORTED) {
+    // (an f16s plan outside its calibration pass: the exact layer's output feeds a scaled layer -- checked against that entry)
+    const bool check = inference && p->prec == V3D_PREC_F16S && !p->calibrating;
+    const size_t l = (size_t)(&L - p->layers.data());
+    rc = v3d_i_sparse_conv_fwd_exact(feat, weight, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout, scale, shift, relu,
+                                     out, exact_pass ? 0 : ((c.conv_algo == 4 || c.conv_algo == 0) ? 3 : c.conv_algo), st,
+                                     check ? p->act_tab + 4 * (l + 1) : nullptr, check ? p->overflow + p->layers.size() : nullptr);
+  }
   return rc;
 }
 
@@ -499,7 +553,7 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
       dn = V3dDensifyOut{sl.coords, sl.shape[0], sl.shape[1], sl.shape[2], p->bev_hi, p->bev_lo, p->bev_occ, p->bev_pix, p->bev_pix_n};
     }
     rc = plan_layer_conv(p, L, feat, L.wimg, L.weight, L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr,
-                         L.d.relu, L.out, st, want_dn ? &dn : nullptr, &densified);
+                         L.d.relu, L.out, st, want_dn ? &dn : nullptr, &densified, true);
     if (rc) return rc;
     feat = L.out;
   }
@@ -512,7 +566,8 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
     PlanStage& sl = p->stages.back();
     const bool own = dense_hi == p->bev_hi && dense_lo == p->bev_lo;  // (plan_clear_own_planes ran at the start of this frame)
     rc = v3d_i_densify_nhwc_split(feat, sl.coords, sl.n_dev, sl.cap, B, p->out_channels, sl.shape, dense_hi, dense_lo, p->bev_occ,
-                                  st, own ? p->bev_pix : nullptr, own ? p->bev_pix_n : nullptr);
+                                  st, own ? p->bev_pix : nullptr, own ? p->bev_pix_n : nullptr, p->prec,
+                                  p->act_tab + 4 * p->layers.size(), p->overflow + p->layers.size());
     if (rc) return rc;
   }
   return V3D_OK;
@@ -749,6 +804,7 @@ extern "C" int v3d_backbone_train_forward(v3d_backbone* p, const float* voxel_me
   for (size_t l = 0; l < p->layers.size(); l++)
     if (!io[l].weight || !io[l].gamma || !io[l].beta || (io[l].running_mean == nullptr) != (io[l].running_var == nullptr))
       return V3D_EINVAL;
+  if (p->prec != V3D_PREC_BF16X3) return V3D_EINVAL;  // the step re-packs the layers' images as bf16 pieces: a training plan is a bf16x3 plan
   int rc = plan_train_alloc(p);
   if (rc) return rc;
   PlanTrain* t = p->train;

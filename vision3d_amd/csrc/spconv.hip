@@ -71,7 +71,8 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
                                                                        const int* __restrict__ n_ptr, int cap, int K,
                                                                        const float* __restrict__ scale,
                                                                        const float* __restrict__ shift, int relu,
-                                                                       float* __restrict__ out) {
+                                                                       float* __restrict__ out, const float* __restrict__ next_entry,
+                                                                       int* __restrict__ range_flag) {
   constexpr int NB = COUT / 16;
   constexpr int G = SPW_WAVES / NB;
   constexpr int T = CIN / 4;  // MFMA steps; also floats of one row held per lane
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
   }
   __syncthreads();
 
+  float vmax = 0.f;  // (an f16s plan: this exact layer feeds a scaled one -- its output is checked against that tensor's limit)
   for (int idx = tid; idx < SPC_TM * (COUT / 4); idx += NT) {
     const int rw = idx / (COUT / 4), c4 = idx % (COUT / 4);
     if (row0 + rw >= n) continue;
@@ -238,18 +240,21 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
       v.z = fmaxf(v.z, 0.f);
       v.w = fmaxf(v.w, 0.f);
     }
+    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     *reinterpret_cast<float4*>(out + (size_t)(row0 + rw) * COUT + c4 * 4) = v;
   }
+  if (next_entry && range_flag && vmax > next_entry[2]) atomicMax(range_flag, V3D_FLAG_RANGE);
 }
 
 template <int CIN, int COUT>
 static int launch_wave(const float* in, const float* W, const int* nbr, const int* n_ptr, int cap, int K,
-                       const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
+                       const float* scale, const float* shift, int relu, float* out, hipStream_t st, const float* next_entry,
+                       int* range_flag) {
   constexpr int G = SPW_WAVES / (COUT / 16);
   const size_t lds = (size_t)G * SPC_TM * COUT * 4 + (size_t)K * SPC_TM * 4 + (size_t)K * 4 + (size_t)K * SPC_TM + 64;
   if (lds > 64 * 1024) return V3D_EUNSUPPORTED;
   hipLaunchKernelGGL((spconv_fwd_wave<CIN, COUT>), dim3(v3d_ceil_div(cap, SPC_TM)), dim3(SPW_WAVES * V3D_WAVE), lds, st,
-                     in, W, nbr, n_ptr, cap, K, scale, shift, relu, out);
+                     in, W, nbr, n_ptr, cap, K, scale, shift, relu, out, next_entry, range_flag);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -259,10 +264,9 @@ static int launch_wave(const float* in, const float* W, const int* nbr, const in
 // kernel (output-stationary in the strictest sense): no LDS accumulators, no compaction lists, no barriers
 // in the loop, no atomics -- the ablation of algo 3 showed that machinery, not the MFMAs, was the cost.
 // Rows without a neighbour under offset k simply contribute a zero A row; the ~3x redundant matrix work
-// that causes is affordable because the products run on v_mfma_f32_16x16x32_bf16 in split precision
-// (activations = hi + mid + lo, weights = hi + lo, 4 bf16 MFMAs per product tile, fp32 accumulate: fp32-class
-// accuracy at 1/4 of the fp32-MFMA cost -- the scheme of csrc/dense_conv.hip with one more activation term).  Weights are split and packed ONCE per layer
-// into the exact fragment order (v3d_sparse_conv_pack_weights), activations are split in registers.
+// that causes is affordable because the products run on the 16-bit matrix pipe in split precision (operands = hi + lo
+// 16-bit pieces, 3 MFMAs per product tile, fp32 accumulate: see "the split-precision product" below).  Weights are split and
+// packed ONCE per layer into the exact fragment order (v3d_sparse_conv_pack_weights), activations are split in registers.
 // Per offset a lane issues 2*KI float4 loads of its gathered row slice and KI*NB*2 16-byte loads of packed
 // weights; operands of offset k+1 are in flight while offset k multiplies (two register sets).
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -273,80 +277,140 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float f) {
   if ((u & 0x7F800000u) == 0x7F800000u) return u >> 16;
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
-// split 8 fp32 ACTIVATIONS into three packed bf16 fragments hi + mid + lo (24 significant bits: exact
-// up to fp32 rounding).  Weights carry two (hi + lo, 16 bits).  The product is evaluated as
-//   hi*Whi + hi*Wlo + mid*Whi + lo*Whi      (mid*Wlo ~ 2^-26 is dropped)
-// so the only representation error left is the weights' 2^-18 residual: half the error of a 2x2-term
-// split for one more MFMA, which the latency-bound sparse kernel does not notice.
-// hi is rounded to nearest even (so |mid| <= 2^-9 |x| and the dropped mid*Wlo term stays ~2^-26); mid and lo are
-// plain truncations of the exact remainders -- x - hi has <= 16 significant bits, so hi + mid + lo == x exactly
-// either way, and truncation is 2 VALU ops per element instead of 8 (the split, not the MFMA, was the issue-
-// slot limiter of this kernel).  The two bf16 halves of a dword are merged with one v_perm_b32.
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
-  u32x4_t h, m, l;
-#ifdef SPR_NOSPLIT  // experiment only (wrong results): what the kernels cost without the split's VALU work
-  h = u32x4_t{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
-  m = u32x4_t{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
-  l = h ^ m;
-  hi = __builtin_bit_cast(bf16x8_t, h); mid = __builtin_bit_cast(bf16x8_t, m); lo = __builtin_bit_cast(bf16x8_t, l);
-  return;
-#endif
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const unsigned u0 = __float_as_uint(x[2 * i]), u1 = __float_as_uint(x[2 * i + 1]);
-    const unsigned h0 = (u0 + 0x7FFFu + ((u0 >> 16) & 1u)) & 0xFFFF0000u, h1 = (u1 + 0x7FFFu + ((u1 >> 16) & 1u)) & 0xFFFF0000u;
-    const float r0 = x[2 * i] - __uint_as_float(h0), r1 = x[2 * i + 1] - __uint_as_float(h1);
-    const unsigned m0 = __float_as_uint(r0) & 0xFFFF0000u, m1 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float l0 = r0 - __uint_as_float(m0), l1 = r1 - __uint_as_float(m1);
-    h[i] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);  // (h1 & 0xFFFF0000) | (h0 >> 16)
-    m[i] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
-    l[i] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
-  }
-  hi = __builtin_bit_cast(bf16x8_t, h);
-  mid = __builtin_bit_cast(bf16x8_t, m);
-  lo = __builtin_bit_cast(bf16x8_t, l);
-}
-
-// two-way split (hi = RNE(x), lo = RNE(x - hi)) on the hardware converter: 16 significant bits, for the 3-term product
-// hi*Whi + hi*Wlo + lo*Whi (the scheme of csrc/dense_conv.hip)
+// ---- the split-precision product of the packed kernels, two arithmetics (template parameter PREC of every kernel below) ----
+// Both evaluate  a * w = al*Wh + ah*Wl + ah*Wh  (three MFMA terms, fp32 accumulation, smallest terms first) on operands split into
+// hi = rne(x), lo = rne(x - hi); they differ in the 16-bit format of the pieces:
+//   PREC 0 "bf16x3"  bf16 pieces: 8 + 8 significant bits, 2^-17 per product, any fp32 magnitude (no scale to choose): the arithmetic
+//                    of rounds 1-4, kept for the training plan (gradients span too many binades for a per-tensor scale) and as
+//                    the library's `fast` inference mode.  Strict elementwise error of a SECOND layer against float64 on entries
+//                    above 1e-3 of the layer maximum: 1.1e-3 ... 2.1e-3 (torch's fp32 conv3d: 2e-5 ... 1.1e-4).
+//   PREC 1 "f16s"    f16 pieces of x * s with a power-of-two scale s per tensor: 11 + 11 significant bits, 2^-22 per product --
+//                    the error of a 1 728-term dot product is then fp32's own accumulation noise (tools/mb_f16split.hip on MI355X:
+//                    strict relative error max 1.0e-4 / rms 2.2e-6 against 1.7e-4 / 2.5e-6 for the exact-fp32 MFMA and
+//                    2.1e-3 / 5.5e-5 for bf16x3), at the SAME three MFMAs.  v_mfma_f32_16x16x32_f16 keeps subnormal f16 inputs
+//                    (probed), so a piece below 2^-14 degrades to the 2^-24 quantum instead of vanishing: with the tensor's
+//                    maximum scaled to 2^8 ... 2^14 everything down to 2^-17 of the maximum keeps full precision.
+//                    The scales: activations -- V3dActScale: {s, 1/s, limit} in device memory, chosen by the caller from the
+//                    observed maximum of the tensor with headroom (runtime.py: calibration); an output beyond the CONSUMER's
+//                    limit raises a device flag (the frame is then re-run after recalibration, like a capacity overflow) --;
+//                    weights -- per layer from max|W| at pack time, its inverse in the image's trailer.  Scaling by powers of
+//                    two is exact, so the result does not depend on the scales as long as nothing leaves the f16 range.
+typedef _Float16 spr_f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 spr_f16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 spr_bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float spr_f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split8_2(const float (&x)[8], bf16x8_t& hi, bf16x8_t& lo) {
-  u32x4_t h, l;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const spr_bf16x2_t hh = __builtin_convertvector(spr_f32x2_t{x[2 * i], x[2 * i + 1]}, spr_bf16x2_t);
-    const unsigned hb = __builtin_bit_cast(unsigned, hh);
-    const float r0 = x[2 * i] - __uint_as_float(hb << 16), r1 = x[2 * i + 1] - __uint_as_float(hb & 0xFFFF0000u);
-    h[i] = hb;
-    l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(spr_f32x2_t{r0, r1}, spr_bf16x2_t));
-  }
-  hi = __builtin_bit_cast(bf16x8_t, h);
-  lo = __builtin_bit_cast(bf16x8_t, l);
+
+template <int PREC>
+__device__ __forceinline__ f32x4 sp_mfma(const u32x4_t a, const u32x4_t b, const f32x4 c) {
+  if constexpr (PREC == 0)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(spr_f16x8_t, a), __builtin_bit_cast(spr_f16x8_t, b), c, 0, 0, 0);
 }
 
-// Terms of the split-precision product in the packed kernels.  4: activations hi+mid+lo (24 bits) x weights hi+lo: al*Wh +
-// am*Wh + ah*Wl + ah*Wh, fp32-class (2^-18 from the weights' residual).  3 (default since the ring kernel made the matrix
-// pipe count again): activations hi+lo (16 bits, both RNE on the hardware converter): al*Wh + ah*Wl + ah*Wh, 2^-17 -- the
-// scheme of the dense kernels, 25 % fewer MFMAs and a third of the split's VALU work.  Measured against the 4-term result
-// per layer: max |diff| / max |out| = 2-4e-6 (4-term vs oracle: 4e-7), bar 1e-4; ring 64->64 13.1 -> 12.2 us.
-#ifndef SPC_TERMS
-#define SPC_TERMS 3
-#endif
-__device__ __forceinline__ void split_act(const float (&x)[8], bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
-  if constexpr (SPC_TERMS == 4) {
-    split8(x, hi, mid, lo);
-  } else {
-    split8_2(x, hi, lo);
-    mid = lo;  // unused
+// 8 fp32 activations -> packed hi / lo fragments (both RNE on the hardware converters: v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32).
+// PREC 1: of x * s (s: the tensor's power-of-two scale, exact).
+template <int PREC>
+__device__ __forceinline__ void split_act(const float (&x)[8], const float s, u32x4_t& hi, u32x4_t& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if constexpr (PREC == 0) {
+      const spr_bf16x2_t hh = __builtin_convertvector(spr_f32x2_t{x[2 * i], x[2 * i + 1]}, spr_bf16x2_t);
+      const unsigned hb = __builtin_bit_cast(unsigned, hh);
+      const float r0 = x[2 * i] - __uint_as_float(hb << 16), r1 = x[2 * i + 1] - __uint_as_float(hb & 0xFFFF0000u);
+      hi[i] = hb;
+      lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(spr_f32x2_t{r0, r1}, spr_bf16x2_t));
+    } else {
+      const float a = x[2 * i] * s, b = x[2 * i + 1] * s;
+      const spr_f16x2_t hh = __builtin_convertvector(spr_f32x2_t{a, b}, spr_f16x2_t);
+      const float r0 = a - (float)hh[0], r1 = b - (float)hh[1];
+      hi[i] = __builtin_bit_cast(unsigned, hh);
+      lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(spr_f32x2_t{r0, r1}, spr_f16x2_t));
+    }
   }
+}
+
+// one value -> (hi, lo) 16-bit patterns, PREC 1: of v * s
+template <int PREC>
+__device__ __forceinline__ void split_one(const float v, const float s, unsigned short& hi, unsigned short& lo) {
+  if constexpr (PREC == 0) {
+    const unsigned h = bf16_rne_bits(v);
+    hi = (unsigned short)h;
+    lo = (unsigned short)bf16_rne_bits(v - __uint_as_float(h << 16));
+  } else {
+    const float a = v * s;
+    const _Float16 h = (_Float16)a;
+    const _Float16 l = (_Float16)(a - (float)h);
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, l);
+  }
+}
+
+// PREC 1: scale of the input rows, the factor that undoes input and weight scales, and the consumer's limit on this launch's output
+struct SpScales {
+  float s_in, undo, limit;
+};
+// trailer of a packed weight image (all precisions allocate it; PREC 1 fills it): {max|W| bits, 1/s_w, s_w, precision}
+#define V3D_WIMG_TRAILER 256
+template <int PREC>
+__device__ __forceinline__ SpScales sp_scales(const V3dActScale& as, const unsigned short* wimg, size_t img_elems) {
+  SpScales r{1.f, 1.f, 3.0e38f};
+  if constexpr (PREC == 1) {
+    r.s_in = as.in[0];
+    r.undo = as.in[1] * reinterpret_cast<const float*>(wimg + img_elems)[1];
+    if (as.next) r.limit = as.next[2];
+  }
+  return r;
+}
+// an output beyond the consumer's limit: the frame's summary flag (<= 0: fine, 1: a capacity was hit, 2: out of f16s range)
+__device__ __forceinline__ void sp_range_check(const V3dActScale& as, const float vmax, const float limit) {
+  if (as.flag && vmax > limit) atomicMax(as.flag, V3D_FLAG_RANGE);
+}
+
+// power-of-two scale that puts a tensor whose largest magnitude has the fp32 bits `amax_bits` into [2^target, 2^(target + 1)):
+// only the exponent is used.  Zero / subnormal maxima give 1; the exponent is clamped so that the scale AND its inverse are normal.
+__host__ __device__ static inline float v3d_pow2_scale(unsigned amax_bits, int target) {
+  const int eb = (int)((amax_bits >> 23) & 0xFFu);
+  if (eb == 0 || eb == 255) return 1.f;
+  int sb = 127 + target - (eb - 127);
+  sb = sb < 2 ? 2 : (sb > 252 ? 252 : sb);
+  const unsigned bits = (unsigned)sb << 23;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __uint_as_float(bits);
+#else
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+#endif
+}
+#define V3D_F16S_WEIGHT_TARGET 13  // max|W| * s_w in [2^13, 2^14)
+
+// max |w| of a weight tensor into word 0 of the image's trailer (zeroed by the caller): non-negative floats order like their bits
+__global__ void spconv_wmax_kernel(const float* __restrict__ W, long long n, unsigned* __restrict__ trailer) {
+  unsigned m = 0u;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+    m = max(m, __float_as_uint(W[t]) & 0x7FFFFFFFu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(trailer, m);
 }
 
 // packed weights: img[k][ki][nb][plane][lane][8]: lane (j = lane&15, kg = lane>>4) holds
-// W[k][cin = ki*32 + kg*8 + e][cout = nb*16 + j], e < 8 (zero beyond Cin)
+// W[k][cin = ki*32 + kg*8 + e][cout = nb*16 + j], e < 8 (zero beyond Cin); PREC 1: of W * s_w, trailer = {max bits, 1/s_w, s_w, 1}
+template <int PREC>
 __global__ void spconv_pack_weights_kernel(const float* __restrict__ W, int K, int Cin, int Cout, unsigned short* __restrict__ img) {
   const int KI = (Cin + 31) / 32, NB = Cout / 16;
   const long long total = (long long)K * KI * NB * 64 * 8;
+  float sw = 1.f;
+  if constexpr (PREC == 1) {
+    unsigned* trailer = reinterpret_cast<unsigned*>(img + total * 2);
+    sw = v3d_pow2_scale(trailer[0], V3D_F16S_WEIGHT_TARGET);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      reinterpret_cast<float*>(trailer)[1] = 1.f / sw;
+      reinterpret_cast<float*>(trailer)[2] = sw;
+      trailer[3] = 1u;
+    }
+  }
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     long long r = t;
     const int e = (int)(r % 8); r /= 8;
@@ -356,11 +420,11 @@ __global__ void spconv_pack_weights_kernel(const float* __restrict__ W, int K, i
     const int k = (int)r;
     const int cin = ki * 32 + (lane >> 4) * 8 + e, cout = nb * 16 + (lane & 15);
     const float v = cin < Cin ? W[((size_t)k * Cin + cin) * Cout + cout] : 0.f;
-    const unsigned h = bf16_rne_bits(v);
-    const unsigned l = bf16_rne_bits(v - __uint_as_float(h << 16));
+    unsigned short h, l;
+    split_one<PREC>(v, sw, h, l);
     const size_t base = ((((size_t)k * KI + ki) * NB + nb) * 2) * 512 + (size_t)lane * 8 + e;
-    img[base] = (unsigned short)h;
-    img[base + 512] = (unsigned short)l;
+    img[base] = h;
+    img[base + 512] = l;
   }
 }
 
@@ -405,14 +469,64 @@ int v3d_i_sparse_conv_pack_batch(const V3dPackJobs& jobs, int n, hipStream_t str
   return V3D_OK;
 }
 
+// f16s: scale entry {s, 1/s, limit, max} of a tensor from its own rows -- the exact maximum, so the entry needs no range flag.
+// One workgroup (the per-op path and calibration passes: not on the frame's critical path).
+#define V3D_F16S_ACT_TARGET 13  // max|x| * s in [2^(13 - headroom), 2^(14 - headroom))
+__global__ __launch_bounds__(1024) void act_scale_from_rows_kernel(const float* __restrict__ rows, const int* __restrict__ n_ptr, int cap,
+                                                                    int C, int headroom, float* __restrict__ entry) {
+  __shared__ unsigned wmax[16];
+  const long long total = (long long)(n_ptr ? min(*n_ptr, cap) : cap) * C;
+  unsigned m = 0u;
+  const long long vec = (((uintptr_t)rows & 15) == 0) ? total / 4 : 0;  // (a misaligned view: scalar loads)
+  for (long long t = threadIdx.x; t < vec; t += 1024) {
+    const uint4 v = reinterpret_cast<const uint4*>(rows)[t];
+    m = max(max(m, v.x & 0x7FFFFFFFu), max(max(v.y & 0x7FFFFFFFu, v.z & 0x7FFFFFFFu), v.w & 0x7FFFFFFFu));
+  }
+  for (long long t = vec * 4 + threadIdx.x; t < total; t += 1024) m = max(m, __float_as_uint(rows[t]) & 0x7FFFFFFFu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; w++) m = max(m, wmax[w]);
+    const float s = v3d_pow2_scale(m, V3D_F16S_ACT_TARGET - headroom);
+    entry[0] = s;
+    entry[1] = 1.f / s;
+    entry[2] = 32768.f / s;
+    entry[3] = __uint_as_float(m);
+  }
+}
+
+extern "C" int v3d_act_scale_from_rows(const float* rows, const int32_t* n_rows, int cap, int C, int headroom_bits, float* entry,
+                                       v3d_stream_t stream) {
+  if (!rows || !entry || cap < 1 || C < 1 || headroom_bits < 0 || headroom_bits > 12) return V3D_EINVAL;
+  hipLaunchKernelGGL(act_scale_from_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rows, n_rows, cap, C, headroom_bits, entry);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 extern "C" size_t v3d_sparse_conv_weight_image_bytes(int K, int Cin, int Cout) {
-  return (size_t)K * ((Cin + 31) / 32) * (Cout / 16) * 2 * 512 * sizeof(unsigned short);
+  return (size_t)K * ((Cin + 31) / 32) * (Cout / 16) * 2 * 512 * sizeof(unsigned short) + V3D_WIMG_TRAILER;
 }
 
 extern "C" int v3d_sparse_conv_pack_weights(const float* weight, int K, int Cin, int Cout, void* image, v3d_stream_t stream) {
+  return v3d_sparse_conv_pack_weights2(weight, K, Cin, Cout, V3D_PREC_BF16X3, image, stream);
+}
+
+extern "C" int v3d_sparse_conv_pack_weights2(const float* weight, int K, int Cin, int Cout, int prec, void* image,
+                                             v3d_stream_t stream) {
   if (!weight || !image || K < 1 || Cin < 1 || Cout < 16 || Cout % 16) return V3D_EINVAL;
-  hipLaunchKernelGGL(spconv_pack_weights_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, weight, K, Cin, Cout,
-                     (unsigned short*)image);
+  if (prec != V3D_PREC_BF16X3 && prec != V3D_PREC_F16S) return V3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned short* img = (unsigned short*)image;
+  if (prec == V3D_PREC_F16S) {
+    unsigned* trailer = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(image) + v3d_sparse_conv_weight_image_bytes(K, Cin, Cout) - V3D_WIMG_TRAILER);
+    V3D_CHECK_HIP(v3d_fill_async(trailer, 0, V3D_WIMG_TRAILER, st));
+    hipLaunchKernelGGL(spconv_wmax_kernel, dim3(64), dim3(256), 0, st, weight, (long long)K * Cin * Cout, trailer);
+    hipLaunchKernelGGL(spconv_pack_weights_kernel<1>, dim3(256), dim3(256), 0, st, weight, K, Cin, Cout, img);
+  } else {
+    hipLaunchKernelGGL(spconv_pack_weights_kernel<0>, dim3(256), dim3(256), 0, st, weight, K, Cin, Cout, img);
+  }
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -430,21 +544,13 @@ extern "C" int v3d_debug_rows_timeline(unsigned long long* host_out) {
 #define SPR_STAMP(idx)
 #endif
 
-// fp32 -> bf16, round to nearest even (inf / nan truncated): the split of dense_conv.hip's planes, hi = rne(x), lo = rne(x - hi)
-__device__ __forceinline__ unsigned short spr_bf16_rne(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
-
-template <int CIN, int COUT>
+template <int CIN, int COUT, int PREC>
 __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __restrict__ in,
                                                              const unsigned short* __restrict__ wimg,
                                                              const int* __restrict__ nbr, const int* __restrict__ n_ptr,
                                                              int cap, int K, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, int relu,
-                                                             float* __restrict__ out, const V3dDensifyOut dn) {
+                                                             float* __restrict__ out, const V3dDensifyOut dn, const V3dActScale as) {
   // workgroup = 16 output rows; its 4 waves split the K kernel offsets (wave w takes k = w, w+4, ...), keep
   // private register accumulators and meet ONCE, in the epilogue, where the 4 partial tiles are summed in a
   // fixed order (deterministic).  4x more waves in flight and a 4x shorter dependent chain per wave than one
@@ -465,12 +571,14 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
     // its neighbours', which then sit in that XCD's L2 instead of being fetched by all eight (64->64 at 36 k rows:
     // 53 -> 48 us; neutral at 8 k).
     const int nwg = (n + 15) / 16;
+    if (dn.hi && blockIdx.x == 0 && tid == 0) *dn.pix_n = n;  // (before the early exit: an EMPTY frame lists no pixels)
     if (wg >= nwg) return;
     const int q = nwg / 8, rmd = nwg % 8, xcd = wg % 8, idx = wg / 8;
     wg = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;  // bijective on [0, nwg)
   }
   const int row0 = wg * 16;
   const int r = lane & 15, kg = lane >> 4;
+  const SpScales ss = sp_scales<PREC>(as, wimg, (size_t)K * NF * 512);
   SPR_STAMP(0);
   for (int k = tid >> 4; k < K; k += V3D_BLOCK / 16)
     nbr_s[k * 16 + r] = (row0 + r < n) ? nbr[(size_t)k * cap + row0 + r] : -1;
@@ -510,22 +618,14 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
   auto multiply = [&](const float (&a)[KI][8], const u32x4_t (&b)[NF]) {
 #pragma unroll
     for (int ki = 0; ki < KI; ki++) {
-      bf16x8_t ah, am, al;
-      split_act(a[ki], ah, am, al);
+      u32x4_t ah, al;
+      split_act<PREC>(a[ki], ss.s_in, ah, al);
 #pragma unroll
-      for (int j = 0; j < NB; j++)  // smallest terms first
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), acc[j], 0, 0, 0);
-      if constexpr (SPC_TERMS == 4) {
+      for (int j = 0; j < NB; j++) acc[j] = sp_mfma<PREC>(al, b[(ki * NB + j) * 2], acc[j]);  // smallest terms first
 #pragma unroll
-        for (int j = 0; j < NB; j++)
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), acc[j], 0, 0, 0);
-      }
+      for (int j = 0; j < NB; j++) acc[j] = sp_mfma<PREC>(ah, b[(ki * NB + j) * 2 + 1], acc[j]);
 #pragma unroll
-      for (int j = 0; j < NB; j++)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2 + 1]), acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < NB; j++)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, b[(ki * NB + j) * 2]), acc[j], 0, 0, 0);
+      for (int j = 0; j < NB; j++) acc[j] = sp_mfma<PREC>(ah, b[(ki * NB + j) * 2], acc[j]);
     }
   };
 
@@ -558,9 +658,12 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
   SPR_STAMP(13);
 
   // epilogue: wave w finishes column blocks j = w, w + NW, ...;  D[row = kg*4 + rr][col = r]
+  float vmax = 0.f;
+  const float s_next = (PREC == 1 && dn.hi) ? as.next[0] : 1.f;  // f16s: the planes hold the pieces of v * (the dense head's input scale)
   for (int j = wave; j < NB; j += NW) {
     const int col = j * 16 + r;
-    const float sc = scale ? scale[col] : 1.f, sh = scale ? shift[col] : 0.f;
+    // (f16s: the power-of-two factor that undoes the operand scales rides in the BatchNorm scale: exact)
+    const float sc = (scale ? scale[col] : 1.f) * ss.undo, sh = scale ? shift[col] : 0.f;
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
       float v = part[((0 * NB + j) * 4 + rr) * 64 + lane];
@@ -568,16 +671,18 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
       for (int w = 1; w < NW; w++) v += part[((w * NB + j) * 4 + rr) * 64 + lane];
       const int row = row0 + kg * 4 + rr;
       if (row < n) {
-        if (scale) v = v * sc + sh;
+        if (scale || PREC == 1) v = v * sc + sh;
         if (relu) v = fmaxf(v, 0.f);
+        if constexpr (PREC == 1) vmax = fmaxf(vmax, fabsf(v));
         out[(size_t)row * COUT + col] = v;
         if (dn.hi) {  // .dense() of the last layer: the row straight into the split BEV planes (see V3dDensifyOut)
           const int4 c = reinterpret_cast<const int4*>(dn.coords)[row];
           const int pixel = (c.x * dn.H + c.z) * dn.W + c.w;
           const size_t o = (size_t)pixel * ((size_t)COUT * dn.D) + (size_t)col * dn.D + c.y;
-          const unsigned short h = spr_bf16_rne(v);
+          unsigned short h, l;
+          split_one<PREC>(v, s_next, h, l);
           reinterpret_cast<unsigned short*>(dn.hi)[o] = h;
-          reinterpret_cast<unsigned short*>(dn.lo)[o] = spr_bf16_rne(v - __uint_as_float((unsigned)h << 16));
+          reinterpret_cast<unsigned short*>(dn.lo)[o] = l;
           if (col == 0) {
             if (dn.occ) atomicAnd(dn.occ + ((size_t)c.x * dn.H + c.z) * ((dn.W + 31) >> 5) + (c.w >> 5), ~(1u << (c.w & 31)));
             dn.pix[row] = pixel;
@@ -586,7 +691,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
       }
     }
   }
-  if (dn.hi && blockIdx.x == 0 && tid == 0) *dn.pix_n = n;
+  if constexpr (PREC == 1) sp_range_check(as, vmax, ss.limit);
   SPR_STAMP(14);
 }
 
@@ -596,13 +701,13 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
 // L2 -> CU weight stream (3 500 workgroups x 442 KB = 1.5 GB per launch at 56 k rows ~ the 34 TB/s of the L2s); here
 // that stream is 4x smaller and the kernel runs into the MFMA issue rate of the 4-term split instead.  Below that
 // size the 4x longer dependent chain per wave (27 instead of 7 offsets) loses: launch_rows picks by capacity.
-template <int CIN, int COUT>
+template <int CIN, int COUT, int PREC>
 __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __restrict__ in,
                                                                  const unsigned short* __restrict__ wimg,
                                                                  const int* __restrict__ nbr, const int* __restrict__ n_ptr,
                                                                  int cap, int K, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, int relu,
-                                                                 float* __restrict__ out) {
+                                                                 float* __restrict__ out, const V3dActScale as) {
   constexpr int KI = (CIN + 31) / 32, NB = COUT / 16;
   constexpr int NF = KI * NB * 2;          // 16-byte weight fragments per offset per lane
   constexpr int WBYTES = NF * 64 * 16;     // one W[k] image
@@ -617,6 +722,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __
   const int row0 = blockIdx.x * 64;
   if (row0 >= n) return;
   const int r = lane & 15, kg = lane >> 4;
+  const SpScales ss = sp_scales<PREC>(as, wimg, (size_t)K * NF * 512);
   for (int t = tid; t < K * 64; t += V3D_BLOCK) {
     const int k = t >> 6, rr = t & 63;
     nbr_s[t] = (row0 + rr < n) ? nbr[(size_t)k * cap + row0 + rr] : -1;
@@ -653,18 +759,17 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __
 #pragma unroll
   for (int j = 0; j < NB; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto multiply = [&](const float (&a)[KI][8], int buf) {
-    const bf16x8_t* bw = reinterpret_cast<const bf16x8_t*>(wbuf + buf * WBYTES) + lane;
+    const u32x4_t* bw = reinterpret_cast<const u32x4_t*>(wbuf + buf * WBYTES) + lane;
 #pragma unroll
     for (int ki = 0; ki < KI; ki++) {
-      bf16x8_t ah, am, al;
-      split_act(a[ki], ah, am, al);
+      u32x4_t ah, al;
+      split_act<PREC>(a[ki], ss.s_in, ah, al);
 #pragma unroll
       for (int j = 0; j < NB; j++) {
-        const bf16x8_t bh = bw[(size_t)((ki * NB + j) * 2) * 64], bl = bw[(size_t)((ki * NB + j) * 2 + 1) * 64];
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[j], 0, 0, 0);  // smallest terms first
-        if constexpr (SPC_TERMS == 4) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[j], 0, 0, 0);
+        const u32x4_t bh = bw[(size_t)((ki * NB + j) * 2) * 64], bl = bw[(size_t)((ki * NB + j) * 2 + 1) * 64];
+        acc[j] = sp_mfma<PREC>(al, bh, acc[j]);  // smallest terms first
+        acc[j] = sp_mfma<PREC>(ah, bl, acc[j]);
+        acc[j] = sp_mfma<PREC>(ah, bh, acc[j]);
       }
     }
   };
@@ -692,21 +797,24 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __
     }
   }
   // epilogue straight from the accumulators: D[row = kg*4 + rr][col = j*16 + r] of this wave's tile
+  float vmax = 0.f;
 #pragma unroll
   for (int j = 0; j < NB; j++) {
     const int col = j * 16 + r;
-    const float sc = scale ? scale[col] : 1.f, sh = scale ? shift[col] : 0.f;
+    const float sc = (scale ? scale[col] : 1.f) * ss.undo, sh = scale ? shift[col] : 0.f;
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
       const int row = row0 + wave * 16 + kg * 4 + rr;
       if (row < n) {
         float v = acc[j][rr];
-        if (scale) v = v * sc + sh;
+        if (scale || PREC == 1) v = v * sc + sh;
         if (relu) v = fmaxf(v, 0.f);
+        if constexpr (PREC == 1) vmax = fmaxf(vmax, fabsf(v));
         out[(size_t)row * COUT + col] = v;
       }
     }
   }
+  if constexpr (PREC == 1) sp_range_check(as, vmax, ss.limit);
 }
 
 __device__ __attribute__((aligned(256))) const float spr_zero_row[128] = {};
@@ -768,12 +876,13 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigne
 // enough: the fragments of offset k are in registers before the requests of k + 1 overwrite the slot piece by piece, each piece
 // behind the MFMA group that consumed it.
 // The pass of T tiles per wave as a device function: the kernel below picks T per LAUNCH from the live row count (device-side).
-template <int CIN, int COUT, int T, int K, int STAGE>
+template <int CIN, int COUT, int T, int K, int STAGE, int PREC>
 __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in, const unsigned short* __restrict__ wimg,
                                                    const int* __restrict__ nbr, const int n, int cap, const float* __restrict__ scale,
                                                    const float* __restrict__ shift, int relu, float* __restrict__ out,
                                                    unsigned char* wbuf0 /*LDS: 2 x one W[k] image*/,
-                                                   unsigned char* aslot /*LDS: [wave][tile][piece][16 rows][64 B]*/) {
+                                                   unsigned char* aslot /*LDS: [wave][tile][piece][16 rows][64 B]*/,
+                                                   const V3dActScale& as) {
   static_assert(CIN % 32 == 0 && CIN <= 64 && T >= 1 && T <= 3, "shape not covered by the offset-outer kernel");
   constexpr int KI = CIN / 32, NB = COUT / 16, NW = 8;
   constexpr int NF = KI * NB * 2;                 // 1 KB weight fragments per offset
@@ -786,6 +895,8 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
   const int r = lane & 15, kg = lane >> 4;
   const int rows_per_pass = 16 * T * NW;
   const int npass = (n + rows_per_pass - 1) / rows_per_pass;
+  const SpScales ss = sp_scales<PREC>(as, wimg, (size_t)K * NF * 512);
+  float vmax = 0.f;
 
   f32x4 wreg[WPT];
   auto issue_w = [&](int k) {  // (threads beyond a small image re-read its last piece: no branch)
@@ -865,8 +976,8 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
               araw[0][(t * KI + ki) * 2 + v] =
                   *reinterpret_cast<const f32x4*>(sl + t * (CIN * 64) + ki * 2048 + ((((kg & 1) * 2 + v) ^ sw) * 16));
       }
-      const bf16x8_t* bw = reinterpret_cast<const bf16x8_t*>(wbuf0 + cur * WBYTES) + lane;
-      bf16x8_t bh[KI][NB], bl[KI][NB];
+      const u32x4_t* bw = reinterpret_cast<const u32x4_t*>(wbuf0 + cur * WBYTES) + lane;
+      u32x4_t bh[KI][NB], bl[KI][NB];
 #pragma unroll
       for (int ki = 0; ki < KI; ki++)
 #pragma unroll
@@ -880,18 +991,14 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
         for (int ki = 0; ki < KI; ki++) {
           const f32x4 v0 = araw[STAGE ? 0 : cur][(t * KI + ki) * 2], v1 = araw[STAGE ? 0 : cur][(t * KI + ki) * 2 + 1];
           const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-          bf16x8_t ah, am, al;
-          split_act(x, ah, am, al);
+          u32x4_t ah, al;
+          split_act<PREC>(x, ss.s_in, ah, al);
 #pragma unroll
-          for (int j = 0; j < NB; j++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ki][j], acc[t][j], 0, 0, 0);  // smallest terms first
-          if constexpr (SPC_TERMS == 4) {
+          for (int j = 0; j < NB; j++) acc[t][j] = sp_mfma<PREC>(al, bh[ki][j], acc[t][j]);  // smallest terms first
 #pragma unroll
-            for (int j = 0; j < NB; j++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[ki][j], acc[t][j], 0, 0, 0);
-          }
+          for (int j = 0; j < NB; j++) acc[t][j] = sp_mfma<PREC>(ah, bl[ki][j], acc[t][j]);
 #pragma unroll
-          for (int j = 0; j < NB; j++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ki][j], acc[t][j], 0, 0, 0);
-#pragma unroll
-          for (int j = 0; j < NB; j++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ki][j], acc[t][j], 0, 0, 0);
+          for (int j = 0; j < NB; j++) acc[t][j] = sp_mfma<PREC>(ah, bh[ki][j], acc[t][j]);
           __builtin_amdgcn_sched_barrier(0);
           issue_chunk(t, ki, araw[STAGE ? 0 : cur ^ 1]);   // [2]  (STAGE: overwrites the slot piece this MFMA group consumed)
           __builtin_amdgcn_sched_barrier(0);
@@ -928,19 +1035,21 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
 #pragma unroll
       for (int j = 0; j < NB; j++) {
         const int col = j * 16 + r;
-        const float sc = scale ? scale[col] : 1.f, sh = scale ? shift[col] : 0.f;
+        const float sc = (scale ? scale[col] : 1.f) * ss.undo, sh = scale ? shift[col] : 0.f;
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
           const int row = row0 + t * 16 + kg * 4 + rr;
           if (row < n) {
             float vv = acc[t][j][rr];
-            if (scale) vv = vv * sc + sh;
+            if (scale || PREC == 1) vv = vv * sc + sh;
             if (relu) vv = fmaxf(vv, 0.f);
+            if constexpr (PREC == 1) vmax = fmaxf(vmax, fabsf(vv));
             out[(size_t)row * COUT + col] = vv;
           }
         }
       }
   }
+  if constexpr (PREC == 1) sp_range_check(as, vmax, ss.limit);
 }
 
 // T = tiles per wave and pass (rows per pass = 128 T).  TMAX = 3: the pass size is picked per LAUNCH from the live row count, which
@@ -948,24 +1057,24 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
 // round of 256 workgroups; beyond, 256-row passes would need a second, nearly empty round (49 -> 91 us in the frame, round 4
 // trace) -- three tiles per wave keep up to 98 304 rows in one round.  Both bodies live in the one kernel (registers and LDS of the
 // larger); every wave of the grid reads the same count, so the choice is uniform.
-template <int CIN, int COUT, int TMAX, int K, int STAGE = 1>
+template <int CIN, int COUT, int TMAX, int K, int STAGE, int PREC>
 __global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __restrict__ in,
                                                               const unsigned short* __restrict__ wimg,
                                                               const int* __restrict__ nbr, const int* __restrict__ n_ptr,
                                                               int cap, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, int relu,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, const V3dActScale as) {
   constexpr int WBYTES = (CIN / 32) * (COUT / 16) * 2 * 1024;
   __shared__ __attribute__((aligned(16))) unsigned char wbuf[2 * WBYTES];
   __shared__ __attribute__((aligned(16))) unsigned char aslot[STAGE ? 8 * TMAX * CIN * 64 : 16];
   const int n = min(*n_ptr, cap);
   if constexpr (TMAX == 3) {
     if (n > 2 * 128 * 256)
-      spconv_kouter_body<CIN, COUT, 3, K, STAGE>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot);
+      spconv_kouter_body<CIN, COUT, 3, K, STAGE, PREC>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot, as);
     else
-      spconv_kouter_body<CIN, COUT, 2, K, STAGE>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot);
+      spconv_kouter_body<CIN, COUT, 2, K, STAGE, PREC>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot, as);
   } else {
-    spconv_kouter_body<CIN, COUT, TMAX, K, STAGE>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot);
+    spconv_kouter_body<CIN, COUT, TMAX, K, STAGE, PREC>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot, as);
   }
 }
 
@@ -998,10 +1107,11 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __res
 // does not grow) and put up to 16 waves on the CU, whose matrix pipes idle half of a two-tile round: the caller picks the smallest
 // TILES that keeps the expected row count inside ONE round.
 // (the body of one workgroup's TILES tiles; the kernel behind it loops over the live tile groups)
-template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK, int STAGE, int TILES>
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK, int STAGE, int TILES, int PREC>
 __device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, const unsigned short* __restrict__ wimg,
                                                  const int* __restrict__ nbr, const int n, int cap, const float* __restrict__ scale,
-                                                 const float* __restrict__ shift, int relu, float* __restrict__ out, const int wg_in) {
+                                                 const float* __restrict__ shift, int relu, float* __restrict__ out, const int wg_in,
+                                                 const SpScales& ss, float& vmax) {
   // OG = offsets per round = multiplying waves per tile.  OG = 3: 9 rounds, 3 round buffers, 6 + 2 waves.
   // OG = 2: 14 rounds (the 28th offset is a zero row), 4 round buffers (three rounds of weights in flight), 4 + 2
   // waves -- one multiplying wave per SIMD.  Measured slower (64->64 at 8 160 rows: 12.3 vs 13.0 us): the cost of a round
@@ -1170,8 +1280,8 @@ __device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, c
         else vm_wait_tie<16>(ar);
       }
     }
-    const bf16x8_t* bw = reinterpret_cast<const bf16x8_t*>(SPR_RING(R) + g * WBYTES) + lane;
-    bf16x8_t ah[KI], am[KI], al[KI], bh[KI][NB], bl[KI][NB];
+    const u32x4_t* bw = reinterpret_cast<const u32x4_t*>(SPR_RING(R) + g * WBYTES) + lane;
+    u32x4_t ah[KI], al[KI], bh[KI][NB], bl[KI][NB];
 #pragma unroll
     for (int ki = 0; ki < KI; ki++)
 #pragma unroll
@@ -1183,20 +1293,16 @@ __device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, c
     for (int ki = 0; ki < KI; ki++) {
       const f32x4 v0 = araw[STAGE ? 0 : R % ABUF][ki * 2], v1 = araw[STAGE ? 0 : R % ABUF][ki * 2 + 1];
       const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      split_act(x, ah[ki], am[ki], al[ki]);
+      split_act<PREC>(x, ss.s_in, ah[ki], al[ki]);
     }
 #pragma unroll
     for (int ki = 0; ki < KI; ki++) {
 #pragma unroll
-      for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ki], bh[ki][j], acc[j], 0, 0, 0);  // smallest terms first
-      if constexpr (SPC_TERMS == 4) {
+      for (int j = 0; j < NB; j++) acc[j] = sp_mfma<PREC>(al[ki], bh[ki][j], acc[j]);  // smallest terms first
 #pragma unroll
-        for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[ki], bh[ki][j], acc[j], 0, 0, 0);
-      }
+      for (int j = 0; j < NB; j++) acc[j] = sp_mfma<PREC>(ah[ki], bl[ki][j], acc[j]);
 #pragma unroll
-      for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ki], bl[ki][j], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ki], bh[ki][j], acc[j], 0, 0, 0);
+      for (int j = 0; j < NB; j++) acc[j] = sp_mfma<PREC>(ah[ki], bh[ki][j], acc[j]);
       if (R + ALOOK < ROUNDS) {  // (STAGE: overwrites the slot piece this MFMA group consumed)
         __builtin_amdgcn_sched_barrier(0);
         issue_chunk(ki, R + ALOOK);
@@ -1226,8 +1332,10 @@ __device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, c
 #pragma unroll
     for (int w = 1; w < OG; w++) v += part[((w * NB + j) * 4 + rr) * 64 + lane];
     if (row < n) {
-      if (scale) v = v * scale[col] + shift[col];
+      if (scale) v = v * (scale[col] * ss.undo) + shift[col];
+      else if constexpr (PREC == 1) v = v * ss.undo;
       if (relu) v = fmaxf(v, 0.f);
+      if constexpr (PREC == 1) vmax = fmaxf(vmax, fabsf(v));
       out[(size_t)row * COUT + col] = v;
     }
   }
@@ -1240,61 +1348,71 @@ __device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, c
 // workgroups for a 32 k-row capacity, ~255 of them live) the dead tail cannot be PLACED until a live workgroup retires -- the
 // dispatcher sits on this kernel for its whole duration and, with several frames in flight, no other frame's kernel starts beside
 // it (round-4 overlap trace: the ring kernels ran alone 99.8 % of their time, the dense tile kernel 69 %).
-template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int TILES = 2>
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK, int STAGE, int TILES, int PREC>
 __global__ __launch_bounds__((TILES * OG + NMV) * 64) void spconv_fwd_rows_ring(const float* __restrict__ in,
                                                                           const unsigned short* __restrict__ wimg,
                                                                           const int* __restrict__ nbr,
                                                                           const int* __restrict__ n_ptr, int cap,
                                                                           const float* __restrict__ scale,
                                                                           const float* __restrict__ shift, int relu,
-                                                                          float* __restrict__ out) {
+                                                                          float* __restrict__ out, const V3dActScale as) {
   const int n = min(*n_ptr, cap);
   const int nwg = (n + 16 * TILES - 1) / (16 * TILES);
+  const SpScales ss = sp_scales<PREC>(as, wimg, (size_t)27 * (CIN / 32) * (COUT / 16) * 2 * 512);
+  float vmax = 0.f;
   // (the XCD-contiguous remap inside the body is a bijection of [0, nwg) for ANY set of indices below nwg)
   for (int g = blockIdx.x; g < nwg; g += gridDim.x) {
-    spconv_ring_body<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES>(in, wimg, nbr, n, cap, scale, shift, relu, out, g);
+    spconv_ring_body<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, PREC>(in, wimg, nbr, n, cap, scale, shift, relu, out, g, ss, vmax);
     __syncthreads();  // the next group's weight DMA and partial sums reuse this group's LDS
   }
+  if constexpr (PREC == 1) sp_range_check(as, vmax, ss.limit);
 }
 
-template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int TILES = 2>
-static int launch_rows_ring(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
-                            const float* scale, const float* shift, int relu, float* out, hipStream_t st, int rows_hint = 0) {
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK, int STAGE, int TILES, int PREC>
+static int launch_rows_ring_p(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
+                              const float* scale, const float* shift, int relu, float* out, hipStream_t st, const V3dActScale& as) {
   // grid: never more workgroups than the chip can hold AT ONCE (occupancy of this instantiation x CUs, a multiple of 8 for the XCD
   // map) -- every workgroup is placed the moment the kernel is dispatched -- and never more than the capacity needs
-  (void)rows_hint;
-  static int slots = 0;  // (same for every device of a node: one GPU type)
-  if (!slots) {
+  static V3dPerDeviceInt cache;
+  int* slots = cache.slot();
+  if (!*slots) {
     int dev = 0, n_cu = 0, per_cu = 0;
     V3D_CHECK_HIP(hipGetDevice(&dev));
     V3D_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    V3D_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES>,
+    V3D_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, PREC>,
                                                                (TILES * OG + NMV) * 64, 0));
-    slots = std::max(8, per_cu * n_cu / 8 * 8);
+    *slots = std::max(8, per_cu * n_cu / 8 * 8);
   }
-  const int grid = std::min(v3d_ceil_div(cap, 16 * TILES), slots);
-  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES>), dim3(grid),
-                     dim3((TILES * OG + NMV) * 64), 0, st, in, (const unsigned short*)wimg, nbr, n_ptr, cap, scale, shift, relu, out);
+  const int grid = std::min(v3d_ceil_div(cap, 16 * TILES), *slots);
+  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, PREC>), dim3(grid),
+                     dim3((TILES * OG + NMV) * 64), 0, st, in, (const unsigned short*)wimg, nbr, n_ptr, cap, scale, shift, relu, out, as);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
-
-template <int CIN, int COUT>
-static void launch_rows_big(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
-                            const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
-  constexpr int NF = ((CIN + 31) / 32) * (COUT / 16) * 2;
-  const size_t lds = (size_t)2 * NF * 64 * 16 + (size_t)K * 64 * 4;
-  hipLaunchKernelGGL((spconv_fwd_rows_big<CIN, COUT>), dim3(v3d_ceil_div(cap, 64)), dim3(V3D_BLOCK), lds, st, in,
-                       (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out);
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int TILES = 2>
+static int launch_rows_ring(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
+                            const float* scale, const float* shift, int relu, float* out, hipStream_t st, int prec, const V3dActScale& as) {
+  if (prec == V3D_PREC_F16S)
+    return launch_rows_ring_p<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, as);
+  return launch_rows_ring_p<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, 0>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, as);
 }
 
-template <int CIN, int COUT, int T, int STAGE = 1>
+template <int CIN, int COUT, int PREC>
+static void launch_rows_big(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
+                            const float* scale, const float* shift, int relu, float* out, hipStream_t st, const V3dActScale& as) {
+  constexpr int NF = ((CIN + 31) / 32) * (COUT / 16) * 2;
+  const size_t lds = (size_t)2 * NF * 64 * 16 + (size_t)K * 64 * 4;
+  hipLaunchKernelGGL((spconv_fwd_rows_big<CIN, COUT, PREC>), dim3(v3d_ceil_div(cap, 64)), dim3(V3D_BLOCK), lds, st, in,
+                       (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, as);
+}
+
+template <int CIN, int COUT, int T, int STAGE, int PREC>
 static void launch_rows_kouter(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
-                               const float* scale, const float* shift, int relu, float* out, hipStream_t st) {
+                               const float* scale, const float* shift, int relu, float* out, hipStream_t st, const V3dActScale& as) {
   const int passes = v3d_ceil_div(cap, 16 * (T == 3 ? 2 : T) * 8);  // (T = 3: the kernel may walk 256-row passes)
   const int grid = passes >= 256 ? 256 : ((passes + 7) / 8) * 8;  // a multiple of 8: the pass -> XCD map assumes it
-  hipLaunchKernelGGL((spconv_fwd_rows_kouter<CIN, COUT, T, 27, STAGE>), dim3(grid), dim3(512), 0, st, in, (const unsigned short*)wimg,
-                     nbr, n_ptr, cap, scale, shift, relu, out);
+  hipLaunchKernelGGL((spconv_fwd_rows_kouter<CIN, COUT, T, 27, STAGE, PREC>), dim3(grid), dim3(512), 0, st, in, (const unsigned short*)wimg,
+                     nbr, n_ptr, cap, scale, shift, relu, out, as);
 }
 
 // rows_hint > 0: expected number of LIVE rows (the live count itself is device-side): the caller's best knowledge -- the
@@ -1304,26 +1422,27 @@ static void launch_rows_kouter(const float* in, const void* wimg, const int* nbr
 // for the shape, -16 its register-gather form (each where the shape has it, else the 16-row kernel).
 #define V3D_BIG_ROWS 32768
 #define V3D_RING_ROWS 16384  // two full rounds of 32-row workgroups on 256 CUs; beyond, the 16-row kernel wins again (36 k rows: 47 vs 53 us)
-template <int CIN, int COUT>
+template <int CIN, int COUT, int PREC>
 static int launch_rows(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
                        const float* scale, const float* shift, int relu, float* out, int rows_hint, hipStream_t st,
-                       const V3dDensifyOut* densify, int tiles_min) {
+                       const V3dDensifyOut* densify, int tiles_min, const V3dActScale& as) {
+  constexpr int prec = PREC;
   const int force = densify ? 1 : (rows_hint < 0 ? -rows_hint : 0);  // .dense() rides in the 16-row kernel's epilogue only
   if constexpr (CIN >= 32 && CIN <= 64 && COUT >= 32 && COUT <= 64) {
     // the offset-outer persistent kernel (3x3x3 only; 6: rows staged through LDS, 7: rows gathered into registers): 64->64 at
     // 56 k rows 58 -> 47.5 us.  It needs a full round of 256-row passes to pay: the 32-channel shapes and the mid sizes stay on
     // the kernels below (32->32 at 81 k rows: 316 passes on 256 workgroups = 2 rounds, 43 vs 30 us)
     if (K == 27 && (force == 6 || force == 7 || force == 8 || (force == 0 && CIN == 64 && COUT == 64 && rows_hint >= V3D_BIG_ROWS))) {
-      if (force == 7) launch_rows_kouter<CIN, COUT, 2, 0>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);
-      else if (force == 8) launch_rows_kouter<CIN, COUT, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);  // 256-row passes only
-      else launch_rows_kouter<CIN, COUT, 3, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st);  // 256 / 384-row passes by live count
+      if (force == 7) launch_rows_kouter<CIN, COUT, 2, 0, PREC>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, as);
+      else if (force == 8) launch_rows_kouter<CIN, COUT, 2, 1, PREC>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, as);  // 256-row passes only
+      else launch_rows_kouter<CIN, COUT, 3, 1, PREC>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, as);  // 256 / 384-row passes by live count
       V3D_CHECK_LAUNCH();
       return V3D_OK;
     }
     // the 64-row LDS-shared-weights kernel: from ~32 k live rows on the 16-row kernel is bound by the L2 -> CU weight
     // stream (64->64 at 36 k rows 54 vs 53 us, at 56 k 82 vs 66 us, at 81 k 110 vs 85 us)
     if (force == 5 || (force == 0 && rows_hint >= V3D_BIG_ROWS)) {
-      launch_rows_big<CIN, COUT>(in, wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, st);
+      launch_rows_big<CIN, COUT, PREC>(in, wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, st, as);
       V3D_CHECK_LAUNCH();
       return V3D_OK;
     }
@@ -1346,23 +1465,23 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
           // another frame's kernels use (same box: 3 820 -> 3 875 / 3 970 frames/s pipelined, 0.451 -> 0.462 ms one frame at a time)
           int tiles = force == 12 ? 2 : force == 13 ? 3 : force == 14 ? 4 : (want <= 32 * 256 ? 2 : want <= 48 * 256 ? 3 : 4);
           if (!force && tiles < tiles_min) tiles = tiles_min > 4 ? 4 : tiles_min;
-          if (tiles == 2) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, rows_hint);
-          if (tiles == 3) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, rows_hint);
-          return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 4>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, rows_hint);
+          if (tiles == 2) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, prec, as);
+          if (tiles == 3) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, prec, as);
+          return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 4>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, prec, as);
         }
       }
-      if (force != 16 && CIN == 32 && COUT == 32) return launch_rows_ring<CIN, COUT, 3, 2, 2, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, rows_hint);
-      return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, rows_hint);
+      if (force != 16 && CIN == 32 && COUT == 32) return launch_rows_ring<CIN, COUT, 3, 2, 2, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, prec, as);
+      return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, prec, as);
     }
   }
   const size_t lds = (size_t)4 * (COUT / 16) * 4 * 64 * 4 + (size_t)K * 16 * 4;
-  hipLaunchKernelGGL((spconv_fwd_rows<CIN, COUT>), dim3(v3d_ceil_div(cap, 16)), dim3(V3D_BLOCK), lds, st, in,
-                     (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, densify ? *densify : V3dDensifyOut{});
+  hipLaunchKernelGGL((spconv_fwd_rows<CIN, COUT, PREC>), dim3(v3d_ceil_div(cap, 16)), dim3(V3D_BLOCK), lds, st, in,
+                     (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, densify ? *densify : V3dDensifyOut{}, as);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
 
-// Forward with PRE-PACKED split weights (v3d_sparse_conv_pack_weights): the bf16x3 row-owner kernel.
+// Forward with PRE-PACKED split weights (v3d_sparse_conv_pack_weights): the split-precision row-owner kernels.
 extern "C" int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr,
                                           const int32_t* n_out, int cap_out, int K, int Cin, int Cout, const float* scale,
                                           const float* shift, int relu, float* out, int rows_hint, v3d_stream_t stream) {
@@ -1370,14 +1489,32 @@ extern "C" int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_im
                                       (hipStream_t)stream);
 }
 
+extern "C" int v3d_sparse_conv_fwd_packed2(const float* in, const void* weight_image, const int32_t* nbr,
+                                           const int32_t* n_out, int cap_out, int K, int Cin, int Cout, const float* scale,
+                                           const float* shift, int relu, float* out, int rows_hint, int prec,
+                                           const float* act_in, const float* act_next, int32_t* range_flag, v3d_stream_t stream) {
+  const V3dActScale as{act_in, act_next, range_flag};
+  return v3d_i_sparse_conv_fwd_packed(in, weight_image, nbr, n_out, cap_out, K, Cin, Cout, scale, shift, relu, out, rows_hint,
+                                      (hipStream_t)stream, nullptr, 2, prec, &as);
+}
+
 int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                  int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
-                                 float* out, int rows_hint, hipStream_t st, const V3dDensifyOut* densify, int ring_tiles_min) {
+                                 float* out, int rows_hint, hipStream_t st, const V3dDensifyOut* densify, int ring_tiles_min,
+                                 int prec, const V3dActScale* act) {
   if (!in || !weight_image || !nbr || !n_out || !out || cap_out < 1 || K < 1) return V3D_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return V3D_EINVAL;
-#define V3D_TRY(ci, co) \
-  if (Cin == ci && Cout == co)  \
-    return launch_rows<ci, co>(in, weight_image, nbr, n_out, cap_out, K, scale, shift, relu, out, rows_hint, st, densify, ring_tiles_min);
+  if (prec != V3D_PREC_BF16X3 && prec != V3D_PREC_F16S) return V3D_EINVAL;
+  if (prec == V3D_PREC_F16S && (!act || !act->in || (densify && !act->next))) return V3D_EINVAL;  // no scale, no f16s
+  const V3dActScale as = (prec == V3D_PREC_F16S) ? *act : V3dActScale{nullptr, nullptr, nullptr};
+#define V3D_TRY(ci, co)                                                                                                        \
+  if (Cin == ci && Cout == co) {                                                                                               \
+    if (prec == V3D_PREC_F16S)                                                                                                 \
+      return launch_rows<ci, co, 1>(in, weight_image, nbr, n_out, cap_out, K, scale, shift, relu, out, rows_hint, st, densify, \
+                                    ring_tiles_min, as);                                                                       \
+    return launch_rows<ci, co, 0>(in, weight_image, nbr, n_out, cap_out, K, scale, shift, relu, out, rows_hint, st, densify,   \
+                                  ring_tiles_min, as);                                                                         \
+  }
   V3D_TRY(4, 16)
   V3D_TRY(16, 16)
   V3D_TRY(16, 32)
@@ -1396,14 +1533,20 @@ int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, cons
 extern "C" int v3d_sparse_conv_fwd(const float* in, const float* weight, const int32_t* nbr, const int32_t* n_out,
                                    int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift,
                                    int relu, float* out, int algo, v3d_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
+  return v3d_i_sparse_conv_fwd_exact(in, weight, nbr, n_out, cap_out, K, Cin, Cout, scale, shift, relu, out, algo, (hipStream_t)stream,
+                                     nullptr, nullptr);
+}
+
+int v3d_i_sparse_conv_fwd_exact(const float* in, const float* weight, const int32_t* nbr, const int32_t* n_out, int cap_out, int K,
+                                int Cin, int Cout, const float* scale, const float* shift, int relu, float* out, int algo,
+                                hipStream_t st, const float* next_entry, int32_t* range_flag) {
   if (!in || !weight || !nbr || !n_out || !out || cap_out < 1 || K < 1 || Cin < 1 || Cout < 1) return V3D_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return V3D_EINVAL;
   if (algo != 0 && algo != 1 && algo != 3) return V3D_EINVAL;  // (2 was an LDS-staged fp32 kernel: removed)
   if (algo == 0 || algo == 3) {
     int rc = V3D_EUNSUPPORTED;
 #define V3D_TRY(ci, co) \
-  if (Cin == ci && Cout == co) rc = launch_wave<ci, co>(in, weight, nbr, n_out, cap_out, K, scale, shift, relu, out, st);
+  if (Cin == ci && Cout == co) rc = launch_wave<ci, co>(in, weight, nbr, n_out, cap_out, K, scale, shift, relu, out, st, next_entry, range_flag);
     V3D_TRY(4, 16)
     V3D_TRY(16, 16)
     V3D_TRY(16, 32)

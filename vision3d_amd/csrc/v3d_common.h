@@ -65,6 +65,26 @@ static inline hipError_t v3d_set_max_lds(V3dPerDeviceFlag& f, const void* fn, in
   return e;
 }
 
+// per-device cache of an integer launch parameter (occupancy, CU count): a process may drive several GPUs
+struct V3dPerDeviceInt {
+  int v[V3D_MAX_DEVICES] = {};
+  int* slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= V3D_MAX_DEVICES) dev = 0;
+    return &v[dev];
+  }
+};
+// compute units of the current device (cached per device); 0 on error
+static inline int v3d_device_cu_count() {
+  static V3dPerDeviceInt cache;
+  int* c = cache.slot();
+  if (!*c) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) *c = n;
+  }
+  return *c;
+}
+
 // Bump allocator over a caller-provided workspace.
 struct V3dArena {
   char* base;

@@ -52,8 +52,22 @@ int v3d_i_nms_sorted(const void* prep_sorted, const int* order, int N, float iou
 
 int v3d_i_nms_mask_sorted(const void* prep_sorted, int N, float iou_threshold, unsigned long long* mask, hipStream_t st);
 
+// Arithmetic of the packed sparse kernels and of the dense head (spconv.hip, "the split-precision product"): bf16 pieces (2^-17 per
+// product, scale-free) or f16 pieces under per-tensor power-of-two scales (2^-22: fp32-class at the same three MFMAs).
+// (V3D_PREC_BF16X3 = 0 / V3D_PREC_F16S = 1: include/vision3d_hip.h)
+// values of a frame's summary flag word (reset to -1 by the plan's per-frame 0xFF fill; raised with atomicMax)
+#define V3D_FLAG_CAPACITY 1  // an active-site capacity was hit: rows were dropped
+#define V3D_FLAG_RANGE 2     // f16s arithmetic: a tensor exceeded the range its scale was calibrated for
+// f16s: one entry per tensor in device memory = {s, 1/s, limit, 0}: the tensor is split as f16(x * s) by its consumer, and its
+// producer raises V3D_FLAG_RANGE when |x| > limit (= 2^15 / s: a factor two inside f16's 65 504).  All null for bf16x3.
+struct V3dActScale {
+  const float* in;    // entry of the rows this launch gathers
+  const float* next;  // nullable: entry of this launch's OUTPUT (checked in the epilogue; the scale of planes written there)
+  int32_t* flag;      // nullable: where a range violation is recorded
+};
+
 // .dense() riding in the epilogue of the LAST sparse layer (the 16-row kernel): besides its rows the layer writes them, split into
-// bf16 hi / lo, into the plan's persistent BEV planes out[(b * H + y) * W + x][c * D + z], clears the pixel's bit in the inverted
+// 16-bit hi / lo pieces (of the launch's arithmetic; f16s: scaled by its `next` entry), into the plan's persistent BEV planes out[(b * H + y) * W + x][c * D + z], clears the pixel's bit in the inverted
 // occupancy bitmap and lists the pixel -- what densify_split_kernel (dense_conv.hip) does in a launch of its own.
 struct V3dDensifyOut {
   const int32_t* coords;  // (cap, 4) = (b, z, y, x) of the layer's OUTPUT rows
@@ -68,7 +82,15 @@ int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, cons
                                  float* out, int rows_hint, hipStream_t st, const V3dDensifyOut* densify = nullptr /*the 16-row
                                  kernel is used whatever the row count; V3D_EUNSUPPORTED if the shape has no packed kernel*/,
                                  int ring_tiles_min = 2 /*64 -> 64 ring kernel: at least this many 16-row tiles per workgroup
-                                 (throughput mode of a plan: fewer, fatter workgroups = less CU-time per launch)*/);
+                                 (throughput mode of a plan: fewer, fatter workgroups = less CU-time per launch)*/,
+                                 int prec = V3D_PREC_BF16X3 /*the arithmetic the image was packed for*/,
+                                 const V3dActScale* act = nullptr /*V3D_PREC_F16S: required*/);
+
+// spconv.hip: v3d_sparse_conv_fwd (exact fp32 kernels) whose output is additionally checked against the limit of the f16s scale
+// entry of the tensor it produces (wave kernel only; both nullable)
+int v3d_i_sparse_conv_fwd_exact(const float* in, const float* weight, const int32_t* nbr, const int32_t* n_out, int cap_out, int K,
+                                int Cin, int Cout, const float* scale, const float* shift, int relu, float* out, int algo,
+                                hipStream_t st, const float* next_entry, int32_t* range_flag);
 
 // spconv.hip: several packed weight images in one launch (mode 0: W (K, Cin, Cout); 1 / 2: the transposed layer of a source
 // (K, Cout, Cin), 2 with the offsets reversed)
@@ -95,6 +117,8 @@ int v3d_i_sparse_bn_relu_bwd(const float* x, const float* dy, int n, const int32
 int v3d_i_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
                              const int32_t* spatial_shape_host, void* out_hi, void* out_lo, uint32_t* occ_inv, hipStream_t st,
                              int32_t* written_pix = nullptr /*with written_n: PERSISTENT planes -- no fill, the written pixels are listed*/,
-                             int32_t* written_n = nullptr);
+                             int32_t* written_n = nullptr, int prec = V3D_PREC_BF16X3,
+                             const float* act_entry = nullptr /*f16s: {s, 1/s, limit, ..} of the planes (device)*/,
+                             int32_t* range_flag = nullptr /*f16s, nullable: raised to V3D_FLAG_RANGE by a value beyond the limit*/);
 // zero the listed pixels (channels bf16 values each) of both planes: start-of-frame job of persistent BEV planes
 int v3d_i_bev_clear_pixels(const int32_t* pix, const int32_t* n, int cap, int channels, void* hi, void* lo, hipStream_t st);

@@ -56,7 +56,7 @@ class GraphedSecond(object):
         hi, lo = self.plan.forward_split(self.static_points, self.offsets, persistent=True)
         head = self.model.head
         maps = self.dense.forward(hi, lo, occ=self.plan.bev_occupancy(len(self.offsets) - 1) if self.model.skip_background else None,
-                                  work=self.work)
+                                  work=self.work, in_entry=self.plan.bev_entry(), range_flag=self.plan.overflow_any())
         self.native = head.native_supported(len(self.frame_sizes), self.anchors.numel() // (7 * self.model.cfg.NUM_CLASSES))
         if self.native:
             return head.native_proposals(maps, self.anchors, self.plan.overflow_any())
@@ -80,15 +80,46 @@ class GraphedSecond(object):
         self.graph.replay()
         return self.outputs
 
+    def _finalize(self):
+        head = self.model.head
+        if self.native:
+            return head.finalize_native(*self.outputs, overflow_flag=self.plan.overflow_any())
+        out = head.finalize(*self.outputs)
+        if self.plan.f16s:
+            self.plan.check_overflow()
+        return out
+
+    def finalize(self, peers=()):
+        """The frame's host read.  f16s: a frame that left the calibrated range (runtime.RangeOverflow) is recalibrated ON and run
+        again -- the scale entries, the empty-map responses and the persistent planes' tile states are device memory the captured
+        graph reads, rewritten in place by one eager pass over the frame still sitting in the static buffer.  `peers`: the other
+        slots of a pipeline (they share the dense head's entries): the caller has drained them; their tile states are reset too."""
+        from ..runtime import RangeOverflow
+        try:
+            return self._finalize()
+        except RangeOverflow:
+            dev = self.static_points.device
+            torch.cuda.synchronize(dev)  # nothing else may be reading the entries while they are rewritten
+            self.plan.recalibrate()
+            self.dense.recalibrate()
+            with torch.no_grad():
+                self._body()  # eager: calibration passes of the plan, then of the dense head, on this frame
+            for g in (self,) + tuple(peers):
+                g.after_recalibration()
+            self.graph.replay()
+            return self._finalize()
+
+    def after_recalibration(self):
+        """The dense head's scale entries changed under this slot's captured graph: nothing in its persistent planes is in place."""
+        if self.work is not None and self.work.key is not None:
+            self.work.ensure(self.dense, *self.work.key[:3])
+
     def __call__(self, clouds):
         self.load(clouds)
         if self.graph is None:
             self._capture()
         self.graph.replay()
-        head = self.model.head
-        if self.native:
-            return head.finalize_native(*self.outputs, overflow_flag=self.plan.overflow_any())
-        return head.finalize(*self.outputs)
+        return self.finalize()
 
 
 def choose_streams(time_of, n_candidates, max_depth, min_gain=0.015):
@@ -163,9 +194,7 @@ class PipelinedSecond(object):
     def _finish(self, i, stream):
         g = self.slots[i]
         with torch.cuda.stream(stream):
-            if g.native:
-                return g.model.head.finalize_native(*g.outputs, overflow_flag=g.plan.overflow_any())
-            return g.model.head.finalize(*g.outputs)
+            return g.finalize(peers=[p for p in self.slots if p is not g])
 
     # ---- stream selection by measurement ---------------------------------------------------------------------
     def _time_streams(self, streams, clouds, frames):

@@ -27,6 +27,17 @@ def _pinned_pair(device):
     return _PINNED[key]
 
 
+def _raise_on_flag(word):
+    """The frame's summary word (csrc/v3d_internal.h): 1 = a capacity was hit, 2 = an f16s tensor left its calibrated range."""
+    if word == 2:
+        from ..runtime import RangeOverflow
+        raise RangeOverflow("f16s arithmetic: a tensor of this frame exceeded its calibrated range (results invalid); recalibrate "
+                            "on this frame and run it again (Second.inference and the graph runners do)")
+    if word > 0:
+        raise RuntimeError("sparse backbone: a stage exceeded its active-site capacity (rows were dropped); build the "
+                           "plan with a larger `growth` (Second.plan_growth / BackbonePlan(growth=...))")
+
+
 class ProposalLayer(nn.Module):
 
     def __init__(self, cfg):
@@ -151,17 +162,15 @@ class ProposalLayer(nn.Module):
                 host[1:2].copy_(overflow_flag, non_blocking=True)
             torch.cuda.current_stream(n_out.device).synchronize()
             n, ovf = int(host[0]), int(host[1])
-            if ovf > 0:
-                raise RuntimeError("sparse backbone: a stage exceeded its active-site capacity (rows were dropped); build the "
-                                   "plan with a larger `growth` (Second.plan_growth / BackbonePlan(growth=...))")
+            _raise_on_flag(ovf)
         return [boxes[:n], batch_idx[:n], class_idx[:n], scores[:n]]
 
     def inference_native(self, head_maps, anchors, overflow_flag=None):
         if not self.native_supported(head_maps.shape[0], anchors.numel() // (7 * self.cfg.NUM_CLASSES)):  # too large: op-by-op
             cls_map, reg_map = self.maps_from_fused(head_maps)
             out = self.inference_from_maps(cls_map, reg_map, anchors)
-            if overflow_flag is not None and int(overflow_flag.item()) > 0:
-                raise RuntimeError("sparse backbone: a stage exceeded its active-site capacity (rows were dropped)")
+            if overflow_flag is not None:
+                _raise_on_flag(int(overflow_flag.item()))
             return out
         return self.finalize_native(*self.native_proposals(head_maps, anchors, overflow_flag))
 
@@ -192,9 +201,10 @@ class ProposalLayer(nn.Module):
         return self.reshape_cls(self.conv_cls(feature_map)), self.reshape_reg(self.conv_reg(feature_map))
 
     def native_head(self, feature_map):
-        """fp32 (B, C_IN, H, W) cuda -> fused [cls | reg] maps (B, n_anchor * (1 + DOF), H, W) fp32 on the streaming bf16x3 MFMA
-        1x1 kernel (csrc/dense_conv.hip:conv1x1_bf16x3_small_cout_kernel); the packed weight image is cached until a head
-        tensor changes.  (Second's inference paths get the same maps from DenseHeadPlan, which feeds the kernel split planes
+        """fp32 (B, C_IN, H, W) cuda -> fused [cls | reg] maps (B, n_anchor * (1 + DOF), H, W) fp32 on the streaming split-precision
+        MFMA 1x1 kernel (csrc/dense_conv.hip:conv1x1_bf16x3_small_cout_kernel) in f16s arithmetic -- the input's scale entry is
+        taken from the tensor's own maximum per call, so nothing can leave the range --; the packed weight image is cached until a
+        head tensor changes.  (Second's inference paths get the same maps from DenseHeadPlan, which feeds the kernel split planes
         directly; this entry is for callers that hold an fp32 feature map: PV_RCNN.proposal, `model.head(features)`.)"""
         from ..runtime import conv2d_split, pack_conv_weight, to_split_nhwc
         tensors = (self.conv_cls.weight, self.conv_cls.bias, self.conv_reg.weight, self.conv_reg.bias)
@@ -204,11 +214,11 @@ class ProposalLayer(nn.Module):
             with torch.no_grad():
                 w = torch.cat((self.conv_cls.weight, self.conv_reg.weight), 0)
                 bias = torch.cat((self.conv_cls.bias, self.conv_reg.bias), 0).float().contiguous()
-                cache = (stamp, pack_conv_weight(w), bias, w.shape[1], w.shape[0])
+                cache = (stamp, pack_conv_weight(w, None, "fp32"), bias, w.shape[1], w.shape[0])
             self.__dict__["_native_head"] = cache
         _, img, bias, cin, cout = cache
-        hi, lo = to_split_nhwc(feature_map.float())
-        return conv2d_split(hi, lo, img, bias, False, cin, cout, 1, out_split=False, out_nchw=True)[1]
+        hi, lo = to_split_nhwc(feature_map.float(), "fp32")
+        return conv2d_split(hi, lo, img, bias, False, cin, cout, 1, out_split=False, out_nchw=True, pr=(hi.v3d_entry, None, None))[1]
 
 
 class FusedProposalLossFunction(torch.autograd.Function):

@@ -55,6 +55,8 @@ class RPN(nn.Module):
     """One-stage dense RPN: ZeroPad+Conv3x3, `blocks` x Conv3x3 (pad 1), then a `stride`x`stride` conv
     (1x1 at stride 1), every conv bias-free and followed by BatchNorm2d(eps 1e-3, mom 0.01) + ReLU."""
 
+    precision = os.environ.get("V3D_PRECISION", "fp32")  # arithmetic of native_forward (see Second.precision)
+
     def __init__(self, C_in=128, C_up=128, C_down=128, blocks=5):
         super().__init__()
         self.down_block, C_in = self._make_down_block(C_in, C_down, blocks)
@@ -123,8 +125,15 @@ class RPN(nn.Module):
         from ..runtime import DenseHeadPlan, to_split_nhwc
         plan = self.__dict__.get("_native_plan")
         if plan is None:
-            plan = self.__dict__["_native_plan"] = DenseHeadPlan(self, None)
-        hi, lo = to_split_nhwc(x.float())
+            plan = self.__dict__["_native_plan"] = DenseHeadPlan(self, None, precision=self.precision)
+        plan.set_precision(self.precision)
+        if not plan.f16s:
+            hi, lo = to_split_nhwc(x.float())
+            return plan.forward(hi, lo, want_features=True)[1]
+        # f16s: the input's scale entry comes from the tensor itself, the layers' entries from a calibration on EVERY call (a
+        # module-level call has no frame stream to amortise one over, and no flag reader): exact maxima, nothing can leave the range
+        hi, lo = to_split_nhwc(x.float(), plan.precision)
+        plan.calibrate(hi, lo, hi.v3d_entry, headroom_bits=0)
         return plan.forward(hi, lo, want_features=True)[1]
 
     def fused_forward(self, x):
@@ -143,6 +152,10 @@ class Second(nn.Module):
     # native inference paths: RPN tiles far from every occupied BEV pixel are copied from the empty-map response instead of
     # convolved (runtime.DenseHeadPlan.forward(occ=...)); the values are identical, False only for A/B measurements
     skip_background = os.environ.get("V3D_SKIP_BACKGROUND", "1") != "0"
+    # arithmetic of the native INFERENCE paths (sparse backbone plan + dense head): "fp32" = f16 hi / lo pieces under calibrated
+    # power-of-two scales -- the reference's fp32 modules up to summation noise, same MFMA count as "bf16x3" (bf16 pieces, 2^-17 per
+    # product, no calibration): csrc/spconv.hip "the split-precision product".  Set before the first inference call.
+    precision = os.environ.get("V3D_PRECISION", "fp32")
 
     def __init__(self, cfg):
         super().__init__()
@@ -156,6 +169,18 @@ class Second(nn.Module):
         self.rpn = RPN(C_in=64 * z)
         self.head = ProposalLayer(cfg)
         self.cfg = cfg
+
+    def set_precision(self, precision):
+        """Arithmetic of every native INFERENCE path of this model: the plans (Second.precision), RPN.native_forward and the
+        op-by-op sparse modules.  "fp32" (default) or "bf16x3"."""
+        from .. import _lib as L
+        if precision not in L.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(L.PRECISIONS)}")
+        self.precision = self.rpn.precision = precision
+        for m in self.modules():
+            if isinstance(m, spconv.conv._SparseConvBase):
+                m.precision = precision
+        return self
 
     def feature_extract(self, item):
         if "voxel_mean" in item:  # fused into the device voxelizer
@@ -181,7 +206,19 @@ class Second(nn.Module):
         cap_pts = 1 << max(14, (max(m, 1) - 1).bit_length())  # the plan's voxel capacity is min(points, B * MAX_VOXELS) >= M
         plan = self.backbone_plan(b, max(cap_pts, b * 16384))
         hi, lo = plan.forward_voxels_split(item["voxel_mean"], item["coordinates"], b)
-        return self.dense_plan().forward(hi, lo, occ=plan.bev_occupancy(b) if self.skip_background else None), plan
+        return self.dense_plan().forward(hi, lo, occ=plan.bev_occupancy(b) if self.skip_background else None,
+                                         in_entry=plan.bev_entry(), range_flag=plan.overflow_any()), plan
+
+    def _with_recalibration(self, run, plan_of):
+        """`run()` once; when the frame left the range the f16s scale entries were calibrated for (runtime.RangeOverflow: the
+        frame's summary word, read in the frame's one host synchronisation), recalibrate on THIS frame and run it again."""
+        from ..runtime import RangeOverflow
+        try:
+            return run()
+        except RangeOverflow:
+            plan_of().recalibrate()
+            self.dense_plan().recalibrate()
+            return run()
 
     # training: RPN + heads forward / backward on csrc/dense_train.hip (bf16 storage, fp32 accumulation) instead of torch / MIOpen.
     # The precision contract of those kernels is the one of `torch.autocast("cuda", torch.bfloat16)`, so they run
@@ -238,9 +275,13 @@ class Second(nn.Module):
         # the fused maps of an EARLIER training forward must never reach ProposalLoss through a re-used item dict
         item.pop("_head_maps", None)
         if self._native_item(item):
-            maps, plan = self._head_maps_from_item(item)
-            plan.check_overflow()  # no count is read on this path: one blocking word
-            scores, boxes = self.head.maps_from_fused(maps)
+            state = {}
+
+            def run():
+                maps, state["plan"] = self._head_maps_from_item(item)
+                state["plan"].check_overflow()  # no count is read on this path: one blocking word
+                return maps
+            scores, boxes = self.head.maps_from_fused(self._with_recalibration(run, lambda: state["plan"]))
         elif (maps := self._train_head_maps(item)) is not None:
             scores, boxes = maps if isinstance(maps, tuple) else self.head.maps_from_fused(maps)
             if not isinstance(maps, tuple):
@@ -254,8 +295,12 @@ class Second(nn.Module):
 
     def inference(self, item):
         if self._native_item(item):
-            maps, plan = self._head_maps_from_item(item)
-            return self.head.inference_native(maps, item["anchors"], overflow_flag=plan.overflow_any())
+            state = {}
+
+            def run():
+                maps, state["plan"] = self._head_maps_from_item(item)
+                return self.head.inference_native(maps, item["anchors"], overflow_flag=state["plan"].overflow_any())
+            return self._with_recalibration(run, lambda: state["plan"])
         return self.head.inference(self.feature_extract(item), item["anchors"])
 
     # ---- fused path: raw device points in, proposals out (voxelizer + sparse backbone in one native call)
@@ -268,7 +313,8 @@ class Second(nn.Module):
         key = (str(dev), int(max_batch), int(max_points)) + ((int(slot),) if slot else ())
         if key not in plans:
             plans[key] = BackbonePlan(self.cnn, self.cfg, max_batch=max_batch, max_points=max_points, device=dev,
-                                      growth=self.__dict__.get("plan_growth", 2.0))
+                                      growth=self.__dict__.get("plan_growth", 2.0), precision=self.precision)
+        plans[key].set_precision(self.precision)
         return plans[key]
 
     def bev_from_points(self, clouds):
@@ -292,7 +338,8 @@ class Second(nn.Module):
     def dense_plan(self):
         from ..runtime import DenseHeadPlan
         if "_dense_plan" not in self.__dict__:
-            self.__dict__["_dense_plan"] = DenseHeadPlan(self.rpn, self.head)
+            self.__dict__["_dense_plan"] = DenseHeadPlan(self.rpn, self.head, precision=self.precision)
+        self.__dict__["_dense_plan"].set_precision(self.precision)
         return self.__dict__["_dense_plan"]
 
     def head_maps_from_points(self, clouds):
@@ -303,8 +350,15 @@ class Second(nn.Module):
     def fused_head_from_points(self, clouds):
         """raw points -> (B, n_anchor*(1+DOF), H, W) fp32: the [cls | reg] output of the fused 1x1 head."""
         plan, flat, offsets = self._plan_for(clouds)
-        hi, lo = plan.forward_split(flat, offsets)
-        return self.dense_plan().forward(hi, lo, occ=plan.bev_occupancy(len(clouds)) if self.skip_background else None)
+
+        def run():
+            hi, lo = plan.forward_split(flat, offsets)
+            maps = self.dense_plan().forward(hi, lo, occ=plan.bev_occupancy(len(clouds)) if self.skip_background else None,
+                                             in_entry=plan.bev_entry(), range_flag=plan.overflow_any())
+            if plan.f16s:  # (this path reads nothing else back: one blocking word, as Second.forward does)
+                plan.check_overflow()
+            return maps
+        return self._with_recalibration(run, lambda: plan)
 
     def graphed_inference(self, anchors, frame_sizes):
         """Capture raw points -> candidates+NMS as ONE HIP graph for a fixed batch geometry (frame_sizes = points
@@ -330,9 +384,12 @@ class Second(nn.Module):
             raise ValueError("inference_points: the torch (MIOpen) dense path was removed; dense must be 'mfma'")
         if proposals == "native":
             plan, flat, offsets = self._plan_for(clouds)
-            hi, lo = plan.forward_split(flat, offsets)
-            occ = plan.bev_occupancy(len(clouds)) if self.skip_background else None
-            return self.head.inference_native(self.dense_plan().forward(hi, lo, occ=occ), anchors,
-                                              overflow_flag=plan.overflow_any())
+
+            def run():
+                hi, lo = plan.forward_split(flat, offsets)
+                occ = plan.bev_occupancy(len(clouds)) if self.skip_background else None
+                maps = self.dense_plan().forward(hi, lo, occ=occ, in_entry=plan.bev_entry(), range_flag=plan.overflow_any())
+                return self.head.inference_native(maps, anchors, overflow_flag=plan.overflow_any())
+            return self._with_recalibration(run, lambda: plan)
         cls_map, reg_map = self.head_maps_from_points(clouds)
         return self.head.inference_from_maps(cls_map, reg_map, anchors)

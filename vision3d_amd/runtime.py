@@ -15,6 +15,31 @@ from .spconv.conv import _SparseConvBase
 from .spconv.modules import fold_batchnorm
 
 
+class RangeOverflow(RuntimeError):
+    """f16s arithmetic: a tensor of the last frame exceeded the range its scale entry was calibrated for (the frame's results
+    are not valid).  Recalibrate on that frame (BackbonePlan.recalibrate / DenseHeadPlan.recalibrate) and run it again --
+    Second.inference and the captured-graph runners do."""
+
+
+CALIB_HEADROOM_BITS = 5  # a later frame may exceed the calibration frame's maxima by 2^6 before the range flag is raised
+
+
+def scale_entry_from_max(amax, headroom_bits, out=None):
+    """(4,) float32 device entry {s, 1/s, 2^15 / s, max} for a tensor whose largest magnitude is the 0-dim tensor `amax`: s = the
+    power of two that puts it into [2^(13 - h), 2^(14 - h)) -- csrc/spconv.hip v3d_pow2_scale, here as device-side torch ops (no
+    host synchronisation)."""
+    amax = amax.detach().to(torch.float32).reshape(())
+    _, e = torch.frexp(amax)  # amax = m * 2^e, m in [0.5, 1)
+    ok = torch.isfinite(amax) & (amax > 0)
+    expo = torch.where(ok, (14 - int(headroom_bits)) - e, torch.zeros_like(e)).clamp(-125, 125)
+    s = torch.ldexp(torch.ones((), dtype=torch.float32, device=amax.device), expo)
+    entry = torch.stack((s, 1.0 / s, 32768.0 / s, amax))
+    if out is not None:
+        out.copy_(entry)
+        return out
+    return entry
+
+
 class PlanCache(dict):
     """Per-module cache of native plans.  Plans own device arenas through a C handle: a deep copy of the module
     (copy.deepcopy(model), EMA / checkpoint helpers) starts with an empty cache instead of aliasing the handles."""
@@ -49,7 +74,10 @@ def flatten_sparse_layers(module):
 
 class BackbonePlan(object):
 
-    def __init__(self, cnn, cfg, max_batch=1, max_points=None, growth=2.0, device=None, conv_algo=0):
+    def __init__(self, cnn, cfg, max_batch=1, max_points=None, growth=2.0, device=None, conv_algo=0, precision="bf16x3"):
+        """precision: arithmetic of the packed layers in the inference entry points -- "fp32" (= "f16s": f16 hi / lo pieces under
+        calibrated power-of-two scales, the reference's fp32 results up to summation noise) or "bf16x3" (bf16 pieces, 2^-17 per
+        product, scale-free: the training plan and the fast mode).  csrc/spconv.hip "the split-precision product"."""
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.cfg = cfg
         self.layers = flatten_sparse_layers(cnn.blocks)
@@ -75,6 +103,8 @@ class BackbonePlan(object):
         self._handle = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(L.lib().v3d_backbone_create(C.byref(c), descs, C.byref(self._handle)), "backbone_create")
+        self.precision = None
+        self.set_precision(precision)
         self.out_channels = self.layers[-1][0].out_channels
         shape = list(self.grid_shape)
         for conv, _, _ in self.layers:
@@ -92,6 +122,41 @@ class BackbonePlan(object):
             except Exception:
                 pass
             self._handle = None
+
+    # ---- arithmetic and its scale entries (f16s)
+    def set_precision(self, precision):
+        if precision not in L.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(L.PRECISIONS)}")
+        if self.precision is not None and L.PRECISIONS[precision] == L.PRECISIONS[self.precision]:
+            return
+        L.check(L.lib().v3d_backbone_set_precision(self._handle, L.PRECISIONS[precision]), "backbone_set_precision")
+        self.precision = precision
+        self._stamp = None  # the weight images are packed per arithmetic
+        self._calib = "need" if self.f16s else "off"
+
+    @property
+    def f16s(self):
+        return L.PRECISIONS[self.precision] == L.PREC_F16S
+
+    def act_scales(self):
+        """(n_layers + 1, 4) float32 device view {s, 1/s, limit, max}: entry l = the rows layer l gathers, the last = the BEV map."""
+        ptr = L.lib().v3d_backbone_act_scales(self._handle)
+        return _view(ptr, (len(self.layers) + 1, 4), torch.float32, self.device)
+
+    def bev_entry(self):
+        """(4,) device entry of the split BEV planes (what DenseHeadPlan.forward takes as `in_entry`); None for bf16x3."""
+        return self.act_scales()[len(self.layers)] if self.f16s else None
+
+    def recalibrate(self):
+        """f16s: the next eager forward re-derives the scale entries from its own frame (after a RangeOverflow)."""
+        if self.f16s:
+            self._calib = "need"
+
+    def copy_calibration(self, other):
+        """Take another plan's scale entries (the plans of a pipeline's slots share one calibration)."""
+        if self.f16s and other.f16s and len(other.layers) == len(self.layers):
+            self.act_scales().copy_(other.act_scales())
+            self._calib = other._calib
 
     def _param_stamp(self):
         st = []
@@ -152,15 +217,32 @@ class BackbonePlan(object):
         self._tuned = True
 
     def _maybe_tune(self):
-        """True once, right after the first eager forward: the caller repeats that forward so that even the first
-        result it returns comes from the kernels every later frame will use (the variants differ in the last bits).
-        That first forward is synchronised anyway, so it also checks the capacities against the observed frame."""
-        if not self.__dict__.get("_tuned") and not torch.cuda.is_current_stream_capturing():
+        """True while the forward that has just been enqueued must be repeated by the caller (eager calls only, never during
+        stream capture):
+          * once after the first forward: the kernels are now picked from the observed sparsity (the variants differ in the last
+            bits), and -- that forward is synchronised anyway -- the capacities are checked against the observed frame;
+          * f16s, first forward or after `recalibrate()`: one pass with every layer on the exact-fp32 kernel, from whose tensors
+            the scale entries are derived (v3d_backbone_calibrate, device-side), then the frame itself."""
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        again = False
+        if not self.__dict__.get("_tuned"):
             self.tune()
             if not self.__dict__.get("allow_overflow"):
-                self.check_overflow()
+                self.check_overflow(ignore_range=True)
+            again = True
+        if self._calib == "need":
+            L.check(L.lib().v3d_backbone_set_calibrating(self._handle, 1), "backbone_set_calibrating")
+            self._calib = "exact"
             return True
-        return False
+        if self._calib == "exact":
+            L.check(L.lib().v3d_backbone_calibrate(self._handle, int(self.__dict__.get("calib_headroom", CALIB_HEADROOM_BITS)),
+                                                   L.stream_ptr()), "backbone_calibrate")
+            L.check(L.lib().v3d_backbone_set_calibrating(self._handle, 0), "backbone_set_calibrating")
+            self._calib = "done"
+            self.calibration_generation = self.__dict__.get("calibration_generation", 0) + 1
+            return True
+        return again
 
     def set_throughput_mode(self, on=True):
         """Kernels picked for frames that run BESIDE other frames on the GPU (v3d_backbone_set_throughput_mode): less CU-time per
@@ -176,8 +258,12 @@ class BackbonePlan(object):
         L.check(L.lib().v3d_backbone_bev_planes(self._handle, C.byref(hi), C.byref(lo)), "backbone_bev_planes")
         d, h, w = self.out_shape
         full = (self.max_batch, h, w, self.out_channels * d)
-        return (_view(hi.value, full, torch.int16, self.device)[:int(batch_size)],
-                _view(lo.value, full, torch.int16, self.device)[:int(batch_size)])
+        return self._tag(_view(hi.value, full, torch.int16, self.device)[:int(batch_size)],
+                         _view(lo.value, full, torch.int16, self.device)[:int(batch_size)])
+
+    def _tag(self, hi, lo):
+        tag_planes(hi, self.bev_entry(), self.overflow_any() if self.f16s else None)
+        return hi, lo
 
     def forward_split(self, points, frame_offsets, persistent=False):
         """Same as forward() but the BEV map comes out as the dense head's input format: two bf16 NHWC
@@ -187,7 +273,7 @@ class BackbonePlan(object):
         pts = L.as_f32("backbone", points)
         b = len(frame_offsets) - 1
         d, h, w = self.out_shape
-        hi, lo = self.own_planes(b) if persistent else split_planes_like(b, h, w, self.out_channels * d, pts.device)
+        hi, lo = self.own_planes(b) if persistent else self._tag(*split_planes_like(b, h, w, self.out_channels * d, pts.device))
         with torch.cuda.device(pts.device):
             L.check(L.lib().v3d_backbone_forward2(self._handle, L.ptr(pts), pts.shape[0], L.host_i32(frame_offsets), b, 0,
                                                   L.ptr(hi), L.ptr(lo), L.stream_ptr()), "backbone_forward2")
@@ -199,7 +285,7 @@ class BackbonePlan(object):
         """The convolutions of the frame forwarded last, on the rulebooks that call left in the plan (timing variant: no
         voxelizer, no rulebook build); same planes as forward_split returned."""
         d, h, w = self.out_shape
-        hi, lo = split_planes_like(int(batch_size), h, w, self.out_channels * d, device)
+        hi, lo = self._tag(*split_planes_like(int(batch_size), h, w, self.out_channels * d, device))
         with torch.cuda.device(device):
             L.check(L.lib().v3d_backbone_forward_reuse(self._handle, int(batch_size), 0, L.ptr(hi), L.ptr(lo), L.stream_ptr()),
                     "backbone_forward_reuse")
@@ -215,7 +301,7 @@ class BackbonePlan(object):
         if coords.shape != (m, 4) or mean.shape[1] != self.cfg.C_IN:
             raise RuntimeError("backbone: voxel_mean (M, C_IN) / coordinates (M, 4) expected")
         d, h, w = self.out_shape
-        hi, lo = split_planes_like(int(batch_size), h, w, self.out_channels * d, mean.device)
+        hi, lo = self._tag(*split_planes_like(int(batch_size), h, w, self.out_channels * d, mean.device))
         with torch.cuda.device(mean.device):
             L.check(L.lib().v3d_backbone_forward_voxels(self._handle, L.ptr(mean), L.ptr(coords), m, int(batch_size), 0,
                                                         L.ptr(hi), L.ptr(lo), L.stream_ptr()), "backbone_forward_voxels")
@@ -376,7 +462,7 @@ class BackbonePlan(object):
 
     def overflow(self):
         """(n_layers + 1,) int32 device flags of the last forward: [l] = 1 where layer l hit its active-site capacity
-        (rows were dropped), [n_layers] = 1 if any did."""
+        (rows were dropped), [n_layers] = 1 if any did (or an f16s tensor left its calibrated range: `overflow_any` reads 2)."""
         ptr = L.lib().v3d_backbone_overflow_flags(self._handle)
         return (_view(ptr, (len(self.layers) + 1,), torch.int32, self.device) > 0).to(torch.int32)
 
@@ -386,9 +472,13 @@ class BackbonePlan(object):
         ptr = L.lib().v3d_backbone_overflow_flags(self._handle)
         return _view(ptr + 4 * len(self.layers), (1,), torch.int32, self.device)
 
-    def check_overflow(self):
-        """Blocking check for callers that only take the BEV map (no per-frame host read of their own)."""
-        if int(self.overflow_any().item()) > 0:
+    def check_overflow(self, ignore_range=False):
+        """Blocking check for callers that only take the BEV map (no per-frame host read of their own).  The summary word is 1 when
+        a capacity was hit, 2 when an f16s tensor left its calibrated range (RangeOverflow: recalibrate and re-run)."""
+        word = int(self.overflow_any().item())
+        if word == 2 and not ignore_range:
+            raise RangeOverflow("sparse backbone (f16s): a tensor exceeded its calibrated range; recalibrate() and run the frame again")
+        if word == 1 or (word == 2 and any(self.overflow()[:-1].tolist())):
             hit = [i for i, f in enumerate(self.overflow()[:-1].tolist()) if f]
             raise RuntimeError(f"sparse backbone: layers {hit} exceeded their active-site capacity (rows were dropped); "
                                "build the plan with a larger `growth`")
@@ -437,17 +527,27 @@ def _view(ptr, shape, dtype, device):
 # dense BEV head on the matrix cores (csrc/dense_conv.hip)
 # ------------------------------------------------------------------------------------------------
 def split_planes_like(b, h, w, c, device):
-    """Two bf16 NHWC planes ("hi", "lo") stored as int16."""
+    """Two 16-bit NHWC planes ("hi", "lo") stored as int16 (bf16 or f16 pieces by the arithmetic of their producer)."""
     both = torch.empty((2, b, h, w, c), dtype=torch.int16, device=device)  # contiguous: one fill clears both planes
     return both[0], both[1]
 
 
+def _prec_struct(pr):
+    """pr = None (bf16x3) | (in_entry, out_entry | None, range_flag | None): device (4,) float32 entries of an f16s call."""
+    if pr is None:
+        return None, None
+    in_entry, out_entry, flag = pr
+    st = L.Conv2dPrec(L.PREC_F16S, L.ptr(in_entry), L.ptr(out_entry), L.ptr(flag))
+    return C.byref(st), st  # (the structure must outlive the call: the caller keeps the second value)
+
+
 def conv2d_split(x_hi, x_lo, image, bias, relu, cin, cout, ksize, out_split=True, out_nchw=False, occ=None, reach=0, bg=None, work=None,
-                 out=None, tile_state=None, reset=None):
-    """One bf16x3 convolution on split NHWC planes; returns (y_hi, y_lo) and/or fp32 (B,cout,H,W).
+                 out=None, tile_state=None, reset=None, pr=None):
+    """One split-precision convolution on split NHWC planes; returns (y_hi, y_lo) and/or fp32 (B,cout,H,W).
     occ / reach / bg = (bg_hi, bg_lo) [/ work: 2 zeroed int32 of the caller's, see the header]: background skipping
     (v3d_conv2d_nhwc_bf16x3_bg), same values.  out = (y_hi, y_lo): write into these planes; with tile_state (one int32 per
-    tile of a PERSISTENT `out`, see the header) background tiles that already hold the empty-map response are not written."""
+    tile of a PERSISTENT `out`, see the header) background tiles that already hold the empty-map response are not written.
+    pr: None = bf16x3 (image from pack_conv_weight(.., "bf16x3")); (in_entry, out_entry, range_flag) = f16s."""
     b, h, w, c = x_hi.shape
     assert c == cin
     dev = x_hi.device
@@ -458,51 +558,80 @@ def conv2d_split(x_hi, x_lo, image, bias, relu, cin, cout, ksize, out_split=True
             raise RuntimeError("conv2d_split: `out` planes do not match the output geometry")
     if out_nchw:
         y = torch.empty((b, cout, h, w), dtype=torch.float32, device=dev)
+    skipping = occ is not None and bg is not None
+    ref, keep = _prec_struct(pr)
     with torch.cuda.device(dev):
-        if occ is not None and bg is not None:
-            # reset = (int32 tensor, words): OTHER call sites' counters this launch zeroes at its start (words may be 0) instead of
-            # resetting its own pair at its end (v3d_conv2d_nhwc_bf16x3_bg2; DenseHeadPlan.forward chains the layers)
-            L.check(L.lib().v3d_conv2d_nhwc_bf16x3_bg2(L.ptr(x_hi), L.ptr(x_lo), L.ptr(image), L.ptr(bias), int(bool(relu)), b, h,
-                                                       w, cin, cout, ksize, L.ptr(y_hi), L.ptr(y_lo), L.ptr(y), L.ptr(occ),
-                                                       int(reach), L.ptr(bg[0]), L.ptr(bg[1]), L.ptr(work),
-                                                       L.ptr(tile_state) if (work is not None and out is not None) else None,
-                                                       (reset[0].data_ptr() if reset is not None else None),
-                                                       (int(reset[1]) if reset is not None else 0), L.stream_ptr()),
-                    "conv2d_nhwc_bf16x3_bg2")
-        else:
-            L.check(L.lib().v3d_conv2d_nhwc_bf16x3(L.ptr(x_hi), L.ptr(x_lo), L.ptr(image), L.ptr(bias), int(bool(relu)), b, h, w,
-                                                   cin, cout, ksize, L.ptr(y_hi), L.ptr(y_lo), L.ptr(y), L.stream_ptr()),
-                    "conv2d_nhwc_bf16x3")
+        # reset = (int32 tensor, words): OTHER call sites' counters this launch zeroes before its tiles run (words may be 0) instead
+        # of resetting its own pair at its end (v3d_conv2d_nhwc_split; DenseHeadPlan.forward chains the layers)
+        L.check(L.lib().v3d_conv2d_nhwc_split(L.ptr(x_hi), L.ptr(x_lo), L.ptr(image), L.ptr(bias), int(bool(relu)), b, h, w, cin, cout,
+                                              ksize, L.ptr(y_hi), L.ptr(y_lo), L.ptr(y), L.ptr(occ) if skipping else None,
+                                              int(reach) if skipping else 0, L.ptr(bg[0]) if skipping else None,
+                                              L.ptr(bg[1]) if skipping else None, L.ptr(work) if skipping else None,
+                                              L.ptr(tile_state) if (skipping and work is not None and out is not None) else None,
+                                              (reset[0].data_ptr() if (skipping and reset is not None) else None),
+                                              (int(reset[1]) if (skipping and reset is not None) else 0), ref, L.stream_ptr()),
+                "conv2d_nhwc_split")
+    del keep
     return (y_hi, y_lo), y
 
 
-def pack_conv_weight(weight, scale=None):
-    """(Cout,Cin,k,k) fp32 [* per-cout scale] -> packed split image (uint8 tensor)."""
+def pack_conv_weight(weight, scale=None, precision="bf16x3"):
+    """(Cout,Cin,k,k) fp32 [* per-cout scale] -> packed split image (uint8 tensor) for the given arithmetic."""
     w = weight.detach().to(torch.float32).contiguous()
     cout, cin, k, _ = w.shape
     lib = L.lib()
     img = torch.empty(int(lib.v3d_conv2d_weight_image_bytes(cin, cout, k)), dtype=torch.uint8, device=w.device)
     sc = None if scale is None else scale.detach().to(torch.float32).contiguous()
     with torch.cuda.device(w.device):
-        L.check(lib.v3d_conv2d_pack_weights(L.ptr(w), L.ptr(sc), cout, cin, k, L.ptr(img), L.stream_ptr()), "conv2d_pack_weights")
+        L.check(lib.v3d_conv2d_pack_weights2(L.ptr(w), L.ptr(sc), cout, cin, k, L.PRECISIONS[precision], L.ptr(img), L.stream_ptr()),
+                "conv2d_pack_weights")
     return img
 
 
-def to_split_nhwc(x):
-    """fp32 (B,C,H,W) -> split planes (entry point for tensors that come from torch)."""
+def act_entry_from_tensor(x, headroom_bits=0):
+    """(4,) device entry {s, 1/s, limit, max} from the EXACT maximum of a float32 tensor (v3d_act_scale_from_rows)."""
+    x = L.as_f32("act_entry_from_tensor", x)
+    entry = torch.empty(4, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().v3d_act_scale_from_rows(L.ptr(x), None, x.numel(), 1, int(headroom_bits), L.ptr(entry), L.stream_ptr()),
+                "act_scale_from_rows")
+    return entry
+
+
+def tag_planes(hi, entry, flag=None):
+    """f16s planes know their scale: the (4,) device entry they were written under (and the frame's range-flag word) ride on the
+    `hi` tensor object as attributes -- DenseHeadPlan.forward picks them up when the caller does not pass them."""
+    hi.v3d_entry, hi.v3d_flag = entry, flag
+    return hi
+
+
+def to_split_nhwc(x, precision="bf16x3"):
+    """fp32 (B,C,H,W) -> split planes (entry point for tensors that come from torch).  f16s: the planes' scale entry is taken
+    from the tensor's own maximum and attached to `hi` (tag_planes)."""
     x = L.as_f32("to_split_nhwc", x)
     b, c, h, w = x.shape
     hi, lo = split_planes_like(b, h, w, c, x.device)
+    f16s = L.PRECISIONS[precision] == L.PREC_F16S
+    entry = act_entry_from_tensor(x) if f16s else None
     with torch.cuda.device(x.device):
-        L.check(L.lib().v3d_nchw_to_split_nhwc(L.ptr(x), b, c, h, w, L.ptr(hi), L.ptr(lo), L.stream_ptr()), "nchw_to_split_nhwc")
+        L.check(L.lib().v3d_nchw_to_split_nhwc2(L.ptr(x), b, c, h, w, L.ptr(hi), L.ptr(lo), L.PRECISIONS[precision], L.ptr(entry),
+                                                L.stream_ptr()), "nchw_to_split_nhwc")
+    tag_planes(hi, entry)
     return hi, lo
+
+
+def planes_abs_max(hi, lo, entry):
+    """0-dim device tensor: largest magnitude held by f16s planes written under `entry` (calibration)."""
+    v = hi.view(torch.float16).float() + lo.view(torch.float16).float()
+    return v.abs().max() * entry[1]
 
 
 class DenseHeadState(object):
     """Per stream / captured graph state of a DenseHeadPlan: the tile counters of the persistent skipping kernels, one pair of
     output planes per RPN layer that stays put from frame to frame, and per layer one word per 80-pixel tile saying whether the
-    tile currently holds computed values (1) or the layer's empty-map response (0).  That response only depends on the weights:
-    a background tile that was background in the frame before needs no write (csrc/dense_conv.hip, DcParams::tile_state)."""
+    tile currently holds computed values (1) or the layer's empty-map response (0).  That response only depends on the weights
+    (and, f16s, on the layer's scale entry): a background tile that was background in the frame before needs no write
+    (csrc/dense_conv.hip, DcParams::tile_state)."""
 
     def __init__(self, plan, device):
         self.device = device
@@ -510,26 +639,49 @@ class DenseHeadState(object):
         self.key, self.out, self.tiles = None, None, None
 
     def ensure(self, plan, b, h, w):
-        key = (int(b), int(h), int(w), plan._stamp)
+        geom = (int(b), int(h), int(w), tuple(ly["cout"] for ly in plan.layers[:-1]))
+        key = geom + (plan._stamp, plan.calibration_generation)
         if key == self.key:
             return
-        self.out = [split_planes_like(b, h, w, ly["cout"], self.device) for ly in plan.layers[:-1]]
-        n = int(L.lib().v3d_conv2d_bg_tiles(int(b), int(h), int(w)))
-        self.tiles = [torch.ones(n, dtype=torch.int32, device=self.device) for _ in plan.layers[:-1]]  # nothing is in place yet
+        if self.out is None or self.key[:4] != geom:
+            self.out = [split_planes_like(b, h, w, ly["cout"], self.device) for ly in plan.layers[:-1]]
+            n = int(L.lib().v3d_conv2d_bg_tiles(int(b), int(h), int(w)))
+            self.tiles = [torch.ones(n, dtype=torch.int32, device=self.device) for _ in plan.layers[:-1]]
+        else:  # new weights or scales: the planes stay where they are (captured graphs hold their addresses), nothing is in place
+            for t in self.tiles:
+                t.fill_(1)
         self.key = key
 
 
 class DenseHeadPlan(object):
-    """RPN (conv+BN+ReLU stack, detector/second.py:58-94) + the two 1x1 heads (proposal.py:19-22) as 8
-    bf16x3 MFMA convolutions with folded BatchNorm; weights re-packed automatically when tensors change."""
+    """RPN (conv+BN+ReLU stack, detector/second.py:58-94) + the two 1x1 heads (proposal.py:19-22) as 8 split-precision MFMA
+    convolutions with folded BatchNorm; weights re-packed automatically when tensors change.
+    precision "fp32" (f16s): every RPN layer's output planes have a static scale entry in `self.tab`, set by `calibrate` from one
+    frame with headroom (automatic on the first eager forward); "bf16x3": scale-free."""
 
     fuse_tail = True  # False: the 1x1 up-conv and the head as two launches (cross-check of the fused kernel, tests)
 
-    def __init__(self, rpn, head):
+    def __init__(self, rpn, head, precision="bf16x3"):
+        if precision not in L.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(L.PRECISIONS)}")
         self.rpn, self.head = rpn, head
+        self.precision = precision
         self._stamp = None
         self.layers = []
         self._background = {}
+        self.tab = None                   # (RPN layers, 4) float32 device scale entries of the layers' output planes (f16s)
+        self.calibrated = False
+        self.calibration_generation = 0
+
+    @property
+    def f16s(self):
+        return L.PRECISIONS[self.precision] == L.PREC_F16S
+
+    def set_precision(self, precision):
+        if precision not in L.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(L.PRECISIONS)}")
+        if L.PRECISIONS[precision] != L.PRECISIONS[self.precision]:
+            self.precision, self._stamp, self.calibrated = precision, None, False
 
     def _pairs(self):
         mods = list(self.rpn.down_block) + list(self.rpn.up_block)
@@ -543,7 +695,7 @@ class DenseHeadPlan(object):
         tensors = [t for c, b in pairs for t in (c.weight, b.running_mean, b.running_var, b.weight, b.bias)]
         if self.head is not None:
             tensors += [self.head.conv_cls.weight, self.head.conv_cls.bias, self.head.conv_reg.weight, self.head.conv_reg.bias]
-        stamp = tuple((t.data_ptr(), t._version) for t in tensors)
+        stamp = tuple((t.data_ptr(), t._version) for t in tensors) + (self.precision,)
         if stamp == self._stamp:
             return
         layers = []
@@ -556,16 +708,34 @@ class DenseHeadPlan(object):
                     raise NotImplementedError("DenseHeadPlan: RPN convs must be 1x1/3x3, stride 1, bias-free")
                 scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
                 shift = (bn.bias - bn.running_mean * scale).float().contiguous()
-                layers.append(dict(img=pack_conv_weight(conv.weight, scale), bias=shift, relu=True, cin=conv.in_channels,
-                                   cout=conv.out_channels, k=k))
+                # (calibration bound |out| <= l1 * max|in| + bmax: largest L1 norm of a folded filter, largest |bias|)
+                l1 = (conv.weight.float() * scale.view(-1, 1, 1, 1)).abs().sum((1, 2, 3)).max()
+                layers.append(dict(img=pack_conv_weight(conv.weight, scale, self.precision), bias=shift, relu=True,
+                                   cin=conv.in_channels, cout=conv.out_channels, k=k, l1=l1, bmax=shift.abs().max()))
             if self.head is not None:
                 w = torch.cat((self.head.conv_cls.weight, self.head.conv_reg.weight), 0)
                 bias = torch.cat((self.head.conv_cls.bias, self.head.conv_reg.bias), 0).float().contiguous()
-                layers.append(dict(img=pack_conv_weight(w), bias=bias, relu=False, cin=w.shape[1], cout=w.shape[0], k=1))
+                layers.append(dict(img=pack_conv_weight(w, None, self.precision), bias=bias, relu=False, cin=w.shape[1], cout=w.shape[0], k=1))
             else:
                 layers.append(None)  # RPN only (RPN.native_forward): no head layer
         self.layers, self._stamp = layers, stamp
-        self._background = {}  # responses to an empty map belong to the old weights
+        self.calibrated = False  # the scale entries belong to the old weights' activations
+        self._invalidate_background()
+        if self.f16s:
+            dev = layers[0]["bias"].device
+            if self.tab is None or self.tab.shape[0] != len(layers) - 1 or self.tab.device != dev:
+                self.tab = torch.tensor([[1.0, 1.0, 32768.0, 0.0]] * (len(layers) - 1), dtype=torch.float32, device=dev)
+
+    def _invalidate_background(self):
+        """The empty-map responses belong to the old weights / scales: recomputed at the next use -- INTO the same tensors when
+        they exist (captured graphs hold their addresses)."""
+        for planes in self._background.values():
+            planes["valid"] = False
+        self.calibration_generation += 1  # (DenseHeadState: nothing is in place any more)
+
+    def recalibrate(self):
+        """f16s: the next eager forward re-derives the layers' scale entries from its own frame (after a RangeOverflow)."""
+        self.calibrated = False
 
     def new_work(self, device):
         """Zeroed tile-counter scratch for `forward(..., work=...)`: keep one per stream / captured graph."""
@@ -578,30 +748,78 @@ class DenseHeadPlan(object):
         self.sync_weights()
         return DenseHeadState(self, device)
 
+    def _pr(self, i, in_entry, flag, planes_out=True):
+        """f16s call description of layer i: input entry = the caller's for layer 0, the previous layer's else."""
+        if not self.f16s:
+            return None
+        src = in_entry if i == 0 else self.tab[i - 1]
+        return (src, self.tab[i] if planes_out else None, flag)
+
     def background(self, h, w, device):
         """Per RPN layer: its output on an EMPTY (all-zero) BEV map of one image, as split planes -- what every pixel far
         enough from all occupied pixels evaluates to, borders included (`forward(..., occ=...)`).  Computed once per weight
-        set and map size by the same kernels."""
+        set (f16s: and calibration), map size by the same kernels."""
         key = (int(h), int(w), str(device))
-        if key not in self._background:
+        rec = self._background.get(key)
+        if rec is None or not rec["valid"]:
             x_hi, x_lo = split_planes_like(1, h, w, self.layers[0]["cin"], device)
             x_hi.zero_()
             x_lo.zero_()
+            zero_entry = None
+            if self.f16s:  # (an all-zero map: any scale describes it)
+                zero_entry = torch.tensor([1.0, 1.0, 32768.0, 0.0], dtype=torch.float32, device=device)
             planes = []
-            for ly in self.layers[:-1]:
-                (x_hi, x_lo), _ = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"])
+            for i, ly in enumerate(self.layers[:-1]):
+                out = None if rec is None else rec["planes"][i]
+                (x_hi, x_lo), _ = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"], out=out,
+                                               pr=self._pr(i, zero_entry, None))
                 planes.append((x_hi, x_lo))
-            self._background[key] = planes
-        return self._background[key]
+            self._background[key] = dict(planes=planes, valid=True)
+        return self._background[key]["planes"]
 
-    def forward(self, x_hi, x_lo, want_features=False, occ=None, work=None):
+    def calibrate(self, x_hi, x_lo, in_entry, headroom_bits=CALIB_HEADROOM_BITS):
+        """f16s: set every layer's scale entry from THIS frame (device-side, no host synchronisation; never during capture).
+        The chain runs once with provisional entries from the rigorous bound |out| <= L1(filter) * max|in| + max|bias| (it cannot
+        overflow; it only wastes a few bits of the small values), reads each layer's true maximum off the planes it wrote and
+        stores the entry for that maximum with `headroom_bits` of margin."""
+        self.sync_weights()
+        if not self.f16s:
+            return
+        amax = planes_abs_max(x_hi, x_lo, in_entry)  # of THIS frame's planes (in_entry[3] is the calibration frame's)
+        src = in_entry
+        for i, ly in enumerate(self.layers[:-1]):
+            prov = scale_entry_from_max(ly["l1"] * amax + ly["bmax"], 0)
+            (x_hi, x_lo), _ = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"],
+                                           pr=(src, prov, None))
+            amax = planes_abs_max(x_hi, x_lo, prov)
+            scale_entry_from_max(amax, headroom_bits, out=self.tab[i])
+            src = prov
+        self.calibrated = True
+        self._invalidate_background()
+
+    def forward(self, x_hi, x_lo, want_features=False, occ=None, work=None, in_entry=None, range_flag=None):
         """split BEV planes -> fp32 head maps (B, n_cls*n_yaw*(1+DOF), H, W) [+ fp32 RPN features].
         occ: BackbonePlan.bev_occupancy() of the same frame -- tiles of the RPN layers whose receptive field holds no occupied
         BEV pixel are copied from the empty-map response instead of convolved (identical values; a sparse scene leaves more
         than half of the map in that state).
         work: (2 * RPN layers,) zeroed int32 scratch owned by the caller, one per stream in flight (`new_work()`): the tile
-        counters of the persistent skipping kernels, which leave them zeroed.  None: allocated (one fill) per call."""
+        counters of the persistent skipping kernels, which leave them zeroed for the next frame (a DenseHeadState's chain: the
+        layers zero each other's pairs; a layer off the persistent kernels zeroes them with a fill).  None: allocated per call.
+        f16s: in_entry = the (4,) device scale entry of the input planes (BackbonePlan.bev_entry(), to_split_nhwc),
+        range_flag = (1,) int32 device word raised to 2 when a layer's output leaves its calibrated range (the plan's
+        overflow_any()).  An uncalibrated plan calibrates itself on this frame first (eager calls only)."""
         self.sync_weights()
+        if self.f16s:
+            if in_entry is None:
+                in_entry = getattr(x_hi, "v3d_entry", None)
+                range_flag = getattr(x_hi, "v3d_flag", None) if range_flag is None else range_flag
+            if in_entry is None:
+                raise RuntimeError("DenseHeadPlan (f16s): the input planes carry no scale entry -- they must come from an f16s "
+                                   "BackbonePlan / to_split_nhwc(x, 'fp32') (runtime.tag_planes), or pass in_entry")
+        elif getattr(x_hi, "v3d_entry", None) is not None:
+            raise RuntimeError("DenseHeadPlan (bf16x3) was handed f16s planes: plan and dense head must use one arithmetic")
+            if not self.calibrated and not torch.cuda.is_current_stream_capturing():
+                self.calibrate(x_hi, x_lo, in_entry)
         if occ is not None and work is None:
             work = self.new_work(x_hi.device)
         state = work if isinstance(work, DenseHeadState) else None
@@ -627,11 +845,13 @@ class DenseHeadPlan(object):
             if last and fuse_tail:
                 b, h, w, _ = x_hi.shape
                 maps = torch.empty((b, head["cout"], h, w), dtype=torch.float32, device=x_hi.device)
+                ref, keep = _prec_struct(self._pr(i, in_entry, range_flag))
                 with torch.cuda.device(x_hi.device):
-                    L.check(L.lib().v3d_conv2d_1x1_head_fused(L.ptr(x_hi), L.ptr(x_lo), L.ptr(ly["img"]), L.ptr(ly["bias"]),
-                                                              int(bool(ly["relu"])), L.ptr(head["img"]), L.ptr(head["bias"]),
-                                                              int(bool(head["relu"])), b, h, w, 128, head["cout"], L.ptr(maps),
-                                                              L.stream_ptr()), "conv2d_1x1_head_fused")
+                    L.check(L.lib().v3d_conv2d_1x1_head_fused2(L.ptr(x_hi), L.ptr(x_lo), L.ptr(ly["img"]), L.ptr(ly["bias"]),
+                                                               int(bool(ly["relu"])), L.ptr(head["img"]), L.ptr(head["bias"]),
+                                                               int(bool(head["relu"])), b, h, w, 128, head["cout"], L.ptr(maps),
+                                                               ref, L.stream_ptr()), "conv2d_1x1_head_fused")
+                del keep
                 return maps
             reach += ly["k"] // 2
             (x_hi, x_lo), f = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"],
@@ -639,11 +859,13 @@ class DenseHeadPlan(object):
                                            bg=None if bg is None else bg[i], work=None if work is None else work[2 * i:2 * i + 2],
                                            out=None if state is None else state.out[i],
                                            tile_state=None if state is None else state.tiles[i],
-                                           reset=None if not chain else ((work[2:], work.numel() - 2) if i == 0 else (work, 2 if i == 1 else 0)))
+                                           reset=None if not chain else ((work[2:], work.numel() - 2) if i == 0 else (work, 2 if i == 1 else 0)),
+                                           pr=self._pr(i, in_entry, range_flag))
             feats = f if last else feats
         ly = self.layers[-1]
         if ly is None:
             return (None, feats)
+        n_rpn = len(self.layers) - 1
         _, maps = conv2d_split(x_hi, x_lo, ly["img"], ly["bias"], ly["relu"], ly["cin"], ly["cout"], ly["k"],
-                               out_split=False, out_nchw=True)
+                               out_split=False, out_nchw=True, pr=self._pr(n_rpn, in_entry, range_flag, planes_out=False))
         return (maps, feats) if want_features else maps

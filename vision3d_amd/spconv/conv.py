@@ -70,10 +70,13 @@ def build_sparse_rulebook(x, ksize, stride, padding):
     return Rulebook(nbr, cap_out, n_host, n_out, coords_out[:n_host], out_shape)
 
 
-def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False, algo=0, packed=None, variant=0):
+def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False, algo=0, packed=None, variant=0, precision="bf16x3"):
     """out (rb.n, Cout) = act((sum_k features[nbr[k]] @ weight[k]) * scale + shift).
     variant (algo 4 only; tests and benchmarks): 0 = the kernel is picked from the live row count; 1 / 5 / 10 force the 16-row,
-    the 64-row LDS-shared-weights or the LDS-ring kernel (passed to the C ABI as a negative rows_hint)."""
+    the 64-row LDS-shared-weights or the LDS-ring kernel (passed to the C ABI as a negative rows_hint).
+    precision (algo 4 only): "bf16x3" or "fp32" (f16s: the input's scale entry is taken from the rows' own maximum by a small
+    launch in front of the layer, so the op-by-op path needs no calibration and cannot leave the range); `packed` must be the
+    image of that arithmetic (pack_sparse_weight(.., precision))."""
     feat = L.as_f32("sparse_conv", features)
     cin, cout = weight.shape[-2], weight.shape[-1]
     w = L.as_f32("sparse_conv", weight).reshape(-1, cin, cout)
@@ -88,12 +91,18 @@ def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False
     if algo == 0:  # default: bf16x3 row-owner kernel once the reduction dim fills an MFMA, fp32 wave kernel below
         algo = 4 if (cin >= 16 and cout % 16 == 0) else 3
     if algo == 4:  # bf16x3 row-owner kernel on pre-packed split weights (packed image cached per weight version)
-        img = packed if packed is not None else pack_sparse_weight(w, k, cin, cout)
+        img = packed if packed is not None else pack_sparse_weight(w, k, cin, cout, precision)
+        prec = L.PRECISIONS[precision]
+        entry = None
         with torch.cuda.device(feat.device):
-            L.check(L.lib().v3d_sparse_conv_fwd_packed(L.ptr(feat), L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k,
-                                                       cin, cout, L.ptr(sc), L.ptr(sh), int(bool(relu)), L.ptr(out),
-                                                       -int(variant) if variant else int(rb.n), L.stream_ptr()),
-                    "sparse_conv_fwd_packed")
+            if prec == L.PREC_F16S:
+                entry = torch.empty(4, dtype=torch.float32, device=feat.device)
+                L.check(L.lib().v3d_act_scale_from_rows(L.ptr(feat), None, feat.shape[0], cin, 0, L.ptr(entry), L.stream_ptr()),
+                        "act_scale_from_rows")
+            L.check(L.lib().v3d_sparse_conv_fwd_packed2(L.ptr(feat), L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k,
+                                                        cin, cout, L.ptr(sc), L.ptr(sh), int(bool(relu)), L.ptr(out),
+                                                        -int(variant) if variant else int(rb.n), prec, L.ptr(entry), None, None,
+                                                        L.stream_ptr()), "sparse_conv_fwd_packed")
         return out
     with torch.cuda.device(feat.device):
         L.check(L.lib().v3d_sparse_conv_fwd(L.ptr(feat), L.ptr(w), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k, cin,
@@ -102,18 +111,22 @@ def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False
     return out
 
 
-def pack_sparse_weight(w_flat, k, cin, cout):
-    """(K,Cin,Cout) fp32 -> split bf16 fragments in MFMA order (csrc/spconv.hip spconv_pack_weights_kernel)."""
+def pack_sparse_weight(w_flat, k, cin, cout, precision="bf16x3"):
+    """(K,Cin,Cout) fp32 -> split 16-bit fragments in MFMA order (csrc/spconv.hip spconv_pack_weights_kernel) for the arithmetic."""
     lib = L.lib()
     img = torch.empty(int(lib.v3d_sparse_conv_weight_image_bytes(k, cin, cout)), dtype=torch.uint8, device=w_flat.device)
     with torch.cuda.device(w_flat.device):
-        L.check(lib.v3d_sparse_conv_pack_weights(L.ptr(w_flat), k, cin, cout, L.ptr(img), L.stream_ptr()),
+        L.check(lib.v3d_sparse_conv_pack_weights2(L.ptr(w_flat), k, cin, cout, L.PRECISIONS[precision], L.ptr(img), L.stream_ptr()),
                 "sparse_conv_pack_weights")
     return img
 
 
 class _SparseConvBase(nn.Module):
     subm = False
+    # arithmetic of the INFERENCE forward (no autograd) of the packed kernel: "fp32" = f16s, the reference's fp32 spconv layers up to
+    # summation noise; "bf16x3" = the scale-free 2^-17 product, which the autograd path always uses (gradients span too many binades
+    # for one scale per tensor).  csrc/spconv.hip "the split-precision product".
+    precision = "fp32"
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
                  indice_key=None):
@@ -139,15 +152,15 @@ class _SparseConvBase(nn.Module):
         if self.bias is not None:
             nn.init.uniform_(self.bias, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
 
-    def _packed_weight(self):
-        """Split/packed weight image, cached ON THE MODULE and refreshed when the parameter changes."""
+    def _packed_weight(self, precision="bf16x3"):
+        """Split/packed weight image, cached ON THE MODULE and refreshed when the parameter (or the arithmetic) changes."""
         w = self.weight
-        stamp = (w.data_ptr(), w._version, str(w.device))
+        stamp = (w.data_ptr(), w._version, str(w.device), precision)
         cache = self.__dict__.get("_pack_cache")
         if cache is None or cache[0] != stamp:
             k = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
             flat = w.detach().to(torch.float32).reshape(k, self.in_channels, self.out_channels).contiguous()
-            cache = (stamp, pack_sparse_weight(flat, k, self.in_channels, self.out_channels))
+            cache = (stamp, pack_sparse_weight(flat, k, self.in_channels, self.out_channels, precision))
             self.__dict__["_pack_cache"] = cache
         return cache[1]
 
@@ -189,8 +202,9 @@ class _SparseConvBase(nn.Module):
                 scale = torch.ones_like(b)
         packed = None
         if self.algo in (0, 4) and self.in_channels >= 16 and self.out_channels % 16 == 0:
-            packed = self._packed_weight()
-        feats = sparse_conv_forward(x.features.detach(), self.weight.detach(), rb, scale, shift, relu, self.algo, packed, self.variant)
+            packed = self._packed_weight(self.precision)
+        feats = sparse_conv_forward(x.features.detach(), self.weight.detach(), rb, scale, shift, relu, self.algo, packed, self.variant,
+                                    self.precision)
         out = SparseConvTensor(feats, rb.out_indices, rb.out_shape, x.batch_size)
         out.indice_dict = x.indice_dict
         out._n_dev = rb.n_dev
