@@ -78,7 +78,7 @@ def parse():
     ap.add_argument("--path", choices=["graph", "native", "eager"], default="graph",
                     help="graph: native path captured in one HIP graph; native: backbone plan + MFMA dense head, eager "
                          "launches; eager: per-op python -> C ABI (every path runs the hand-written kernels: there is no torch dense path)")
-    ap.add_argument("--mode", choices=["forward", "train", "pvrcnn"], default="forward",
+    ap.add_argument("--mode", choices=["forward", "train", "pvrcnn", "plumbing"], default="forward",
                     help="forward: the headline metric; train: BASELINE configs[2] (SECOND train step, bs=8/GPU, gradient "
                          "all-reduce over RCCL) -- a secondary line, same JSON contract")
     ap.add_argument("--no-channels-last", action="store_true", help="train mode: keep the dense RPN/head in NCHW")
@@ -452,6 +452,127 @@ def pvrcnn_main(args):
         dist.destroy_process_group()
 
 
+def plumbing_main(args):
+    """configs[0]: voxelize (+ fused VFE mean) + points_in_boxes on one 16 384-point synthetic KITTI cloud -- the reference's
+    CPU-runnable plumbing case (core/preprocess.py:26-33, core/geometry.py:27-65), here on the device beside the CPU port.
+    A step = one frame: the voxelizer's launches and the points-in-boxes launch, replayed as one captured HIP graph per distinct
+    frame of the stream (inputs resident in HBM, nothing read back inside the timed region).  Roofline: HBM, algorithmic bytes
+    16 N + 36 M (voxelizer: points read once; per voxel coords + occupancy + mean written, max_pts point slots not counted: the
+    detector consumes the mean) and 12 N + 28 n + N n (points-in-boxes: xyz read, boxes read, mask written), SURVEY.md 8(d)."""
+    from vision3d_amd import dist_util, synth
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.core.geometry import points_in_boxes_mask
+    from vision3d_amd.spconv.utils import voxelize_batch
+    import torch.distributed as dist
+    rank, local, world = dist_util.env_world()
+    torch.cuda.set_device(local % torch.cuda.device_count())
+    dist_util.init_from_env(BACKEND)
+    n_ranks_seen = ranks_seen(world, args.gpus)
+    cfg = second_car_cfg()
+    n_pts = args.points or 16384
+    n_stream = max(1, args.stream)
+    seeds = [j * world + rank for j in range(n_stream)]
+    clouds_np = [synth.make_cloud(s, n_pts) for s in seeds]
+    boxes_np = [synth.make_gt_boxes(s) for s in seeds]
+    clouds = [torch.from_numpy(c).cuda() for c in clouds_np]
+    boxes = [torch.from_numpy(b).cuda() for b in boxes_np]
+
+    def frame(j):
+        _, coords, occ, mean, n_vox = voxelize_batch(clouds[j], [0, n_pts], cfg.VOXEL_SIZE, cfg.GRID_BOUNDS, cfg.MAX_OCCUPANCY,
+                                                     cfg.MAX_VOXELS, want_voxels=False)
+        return coords, occ, mean, n_vox, points_in_boxes_mask(clouds[j], boxes[j], True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    graphs, outs = [], []
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        for j in range(n_stream):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                frame(j)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs.append(frame(j))
+            graphs.append(g)
+    for i in range(args.warmup):
+        graphs[i % n_stream].replay()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        graphs[i % n_stream].replay()
+    fence()
+    elapsed = dist_util.max_over_ranks(time.perf_counter() - t0, world, device=REDUCE_DEVICE)
+    m_vox = int(outs[0][3].item())
+    n_box = int(boxes[0].shape[0])
+    roofline = cpu_baseline = None
+    if rank == 0 and not args.no_roofline:
+        def graph_us(fn, rep=20):
+            g = torch.cuda.CUDAGraph()
+            fn()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                for _ in range(rep):
+                    fn()
+            ts = []
+            for trial in range(4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                g.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                if trial:
+                    ts.append(e0.elapsed_time(e1) * 1e3 / rep)
+            return float(np.mean(ts))
+        with torch.no_grad():
+            t_vox = graph_us(lambda: voxelize_batch(clouds[0], [0, n_pts], cfg.VOXEL_SIZE, cfg.GRID_BOUNDS, cfg.MAX_OCCUPANCY,
+                                                    cfg.MAX_VOXELS, want_voxels=False))
+            t_pib = graph_us(lambda: points_in_boxes_mask(clouds[0], boxes[0], True))
+        b_vox, b_pib = 16.0 * n_pts + 36.0 * m_vox, 12.0 * n_pts + 28.0 * n_box + float(n_pts) * n_box
+        roofline = dict(bound="hbm", kernel="vox_insert + vox_emit (voxelizer + VFE mean, 2 launches; 1 fill)", achieved=b_vox / (t_vox * 1e-6) / 1e9,
+                        peak=HBM_PEAK_GBS, unit="GB/s", frac=b_vox / (t_vox * 1e-6) / 1e9 / HBM_PEAK_GBS, bytes_per_launch=b_vox,
+                        avg_us=t_vox, traffic=None,
+                        points_in_boxes=dict(kernel="points_in_boxes_kernel", avg_us=t_pib, bytes_per_launch=b_pib,
+                                             achieved=b_pib / (t_pib * 1e-6) / 1e9, frac=b_pib / (t_pib * 1e-6) / 1e9 / HBM_PEAK_GBS),
+                        note="0.7 MB of algorithmic traffic per frame against launches of ~10 us: the stage is bound by launch latency "
+                             "and the dependent chain insert -> count/scan -> emit, not by HBM (SURVEY.md F9); durations are per "
+                             "frame (all launches of the stage), back to back inside one HIP graph")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import oracle as orc  # the CPU port: baseline only (never on the product path)
+            orc.build()
+            t0c, nfr = time.perf_counter(), 0
+            while time.perf_counter() - t0c < 10.0:
+                j = nfr % n_stream
+                vox, co, num = orc.voxelize(clouds_np[j], cfg.VOXEL_SIZE, cfg.GRID_BOUNDS, cfg.MAX_OCCUPANCY, cfg.MAX_VOXELS)
+                orc.vfe_mean(vox, num)
+                orc.points_in_boxes(clouds_np[j], boxes_np[j], True)
+                nfr += 1
+            dtc = time.perf_counter() - t0c
+            cpu_baseline = dict(value=nfr / dtc, unit="frames/s", cores=1, kind="port",
+                                sample=f"{nfr} frames of the same stream in {dtc:.1f} s: oracle/v3d_oracle.c voxelizer + VFE mean + "
+                                       "points-in-boxes, one thread")
+        except Exception as e:  # a reported extra
+            cpu_baseline = dict(value=None, unit="frames/s", error=f"{type(e).__name__}: {str(e)[:200]}")
+    if rank == 0:
+        print(json.dumps(dict(
+            metric="frames/sec voxelize + points_in_boxes, 16k-pt KITTI cloud", value=world * args.steps / elapsed, unit="frames/s",
+            n_gpus=world, n_ranks_seen=n_ranks_seen, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
+            higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32 / int32 (bit-exact voxel indices and masks)", data="synthetic",
+            config=dict(workload="voxelize (+ VFE mean) + points_in_boxes on one 16384-pt synthetic KITTI cloud (BASELINE configs[0])",
+                        points_per_frame=n_pts, voxels_per_frame=m_vox, boxes_per_frame=n_box, distinct_frames_in_timed_loop=n_stream,
+                        parallelism=f"frame-parallel replicas x{world}", path="one captured HIP graph per frame, one at a time"),
+            roofline=roofline, cpu_baseline=cpu_baseline)))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def fps_roofline(model, points):
     """The dominant kernel of PV-RCNN stage 2: farthest-point sampling 16 384 -> 2 048 (fps_slab_kernel, csrc/pointops.hip), ONE
     workgroup per frame.  HBM view per the contract: compulsory bytes N * 12 + K * 4 (points read once, indices written; points and
@@ -636,6 +757,8 @@ def main():
         return train_main(args)
     if args.mode == "pvrcnn":
         return pvrcnn_main(args)
+    if args.mode == "plumbing":
+        return plumbing_main(args)
     from vision3d_amd import dist_util
     rank, local, world = dist_util.env_world()
     assert torch.cuda.is_available(), "bench.py needs a GPU (vision3d_amd has no CPU path)"

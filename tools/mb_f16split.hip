@@ -50,6 +50,23 @@ __device__ __forceinline__ void split_f16(const float (&x)[8], float s, f16x8_t&
   lo = __builtin_bit_cast(f16x8_t, l);
 }
 
+// the four-instruction split of csrc/v3d_common.h against the plain expressions, bit for bit
+__global__ void mix_probe(const float* __restrict__ x, int n, float s, unsigned* __restrict__ mism) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (2 * i + 1 >= n) return;
+  const float x0 = x[2 * i], x1 = x[2 * i + 1];
+  unsigned h = 0u, l = 0u;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x0), "s"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x1), "s"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x0), "s"(s), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "s"(s), "v"(h));
+  const float a = x0 * s, b = x1 * s;
+  const f16x2_t hh = __builtin_convertvector(f32x2_t{a, b}, f16x2_t);
+  const float r0 = a - (float)hh[0], r1 = b - (float)hh[1];
+  const unsigned he = __builtin_bit_cast(unsigned, hh), le = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t));
+  if (h != he || l != le) atomicAdd(mism, 1u);
+}
+
 __global__ void denorm_probe(float* out) {
   const int lane = threadIdx.x;
   f16x8_t a = {}, b = {};
@@ -117,6 +134,26 @@ int main() {
   hipMemcpy(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost);
   printf("denorm probe: f16 subnormal 2^-20 x 1024 through v_mfma_f32_16x16x32_f16 = %g (2^-10 = %g kept, 0 = flushed)\n", h_out[0], 1.0 / 1024);
 
+  {
+    const int n = 1 << 22;
+    std::vector<float> hx(n);
+    srand(99);
+    for (int i = 0; i < n; i++) {  // magnitudes over 40 binades, both signs, some exact zeros and f16-subnormal products
+      const double m = (rand() / (double)RAND_MAX) * 2.0 - 1.0;
+      hx[i] = (i % 97 == 0) ? 0.f : (float)(m * pow(2.0, (rand() % 40) - 30));
+    }
+    float* dx; unsigned* dm;
+    hipMalloc(&dx, n * 4); hipMalloc(&dm, 4);
+    hipMemcpy(dx, hx.data(), n * 4, hipMemcpyHostToDevice);
+    for (float s : {1.f, 256.f, 1.f / 1024.f, 16384.f}) {
+      hipMemset(dm, 0, 4);
+      hipLaunchKernelGGL(mix_probe, dim3(n / 2 / 256), dim3(256), 0, 0, dx, n, s, dm);
+      unsigned mm = 0;
+      hipMemcpy(&mm, dm, 4, hipMemcpyDeviceToHost);
+      printf("v_fma_mix split vs expression split, scale %g: %u mismatching pairs of %d\n", s, mm, n / 2);
+    }
+    hipFree(dx); hipFree(dm);
+  }
   const int T = 512, K = 1728;
   srand(1234);
   for (int scen = 0; scen < 3; scen++) {

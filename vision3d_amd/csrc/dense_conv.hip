@@ -627,11 +627,7 @@ __device__ __forceinline__ void split_pair(float v0, float v1, float s, unsigned
     const float r0 = v0 - __uint_as_float(hi << 16), r1 = v1 - __uint_as_float(hi & 0xFFFF0000u);
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t));
   } else {
-    const float a0 = v0 * s, a1 = v1 * s;
-    const f16x2_t h = __builtin_convertvector(f32x2_t{a0, a1}, f16x2_t);
-    hi = __builtin_bit_cast(unsigned, h);
-    const float r0 = a0 - (float)h[0], r1 = a1 - (float)h[1];
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t));
+    v3d_split_f16_pair(v0, v1, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s))), hi, lo);
   }
 }
 

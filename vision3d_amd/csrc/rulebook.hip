@@ -21,6 +21,10 @@ struct RbGeom {
   int kc[3], Kc;     // strided layers: ceil(ks / stride) per axis and their product -- tickets per input row (see rb_ticket)
 };
 
+// A site table word is key << 24 | row (v3d_common.h): keys own 40 bits.  Grids are limited to 2^34 cells (fill_geom), which leaves
+// 6 bits for the batch index: a coordinate row with b outside [0, 64) has no key -- it is never inserted (its neighbours read -1;
+// the strided builder raises its overflow flag), instead of aliasing another site's key.
+#define RB_MAX_BATCH 64
 __device__ __forceinline__ v3d_key_t rb_key(int b, int z, int y, int x, const int* shape) {
   return (((v3d_key_t)b * shape[0] + z) * shape[1] + y) * shape[2] + x;
 }
@@ -33,6 +37,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_hash_build_kernel(const int4* __
   const int n = min(*n_ptr, cap);
   for (int i = blockIdx.x * V3D_BLOCK + threadIdx.x; i < n; i += gridDim.x * V3D_BLOCK) {
     const int4 c = coords[i];
+    if ((unsigned)c.x >= (unsigned)RB_MAX_BATCH) continue;  // no key (see rb_key)
     const int s = v3d_site_insert(h, rb_key(c.x, c.y, c.z, c.w, g.in_shape), (unsigned)i);
     if (s >= 0) vals[s] = i;
   }
@@ -50,7 +55,7 @@ __device__ __forceinline__ void rb_subm_entry(const int4* __restrict__ coords, i
   if (2 * k + 1 == g.K) {
     v = o;  // centre tap: the site itself
   } else if (z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2]) {
-    v = v3d_site_find_row(h, rb_key(c.x, z, y, x, g.in_shape));  // one access: the row rides in the key word
+    if ((unsigned)c.x < (unsigned)RB_MAX_BATCH) v = v3d_site_find_row(h, rb_key(c.x, z, y, x, g.in_shape));  // one access: the row rides in the key word
   }
   nbr[(size_t)k * cap + o] = v;
 }
@@ -117,7 +122,7 @@ __device__ __forceinline__ void rb_candidates_body(const int4* __restrict__ coor
     const int4 c = coords[i];
     int k, oz, oy, ox, s = -1;
     if (rb_ticket(c, j, g, k, oz, oy, ox)) {
-      s = v3d_site_insert(h, rb_key(c.x, oz, oy, ox, g.out_shape), V3D_SITE_NO_ROW);  // numbered by the emit pass
+      s = (unsigned)c.x < (unsigned)RB_MAX_BATCH ? v3d_site_insert(h, rb_key(c.x, oz, oy, ox, g.out_shape), V3D_SITE_NO_ROW) : -1;  // numbered by the emit pass
       if (s >= 0) {
         atomicMin(&first_ticket[s], (unsigned)t);
         s |= k << RB_SLOT_BITS;
@@ -337,7 +342,9 @@ static int fill_geom(RbGeom& g, const int32_t* shape, const int32_t* ks, const i
   }
   if (g.K > 62) return V3D_EUNSUPPORTED;  // the kernel offset rides in 6 bits of a candidate word beside the slot (-1 = dead)
   // linear cell keys (batch index in front: up to 64 frames) must fit the 40 key bits of a site table's words (v3d_common.h)
+  // -- input AND output grid, and the batch index itself is bounded where keys are made (RB_MAX_BATCH)
   if ((long long)g.in_shape[0] * g.in_shape[1] * g.in_shape[2] >= (1ll << 34)) return V3D_EUNSUPPORTED;
+  if ((long long)g.out_shape[0] * g.out_shape[1] * g.out_shape[2] >= (1ll << 34)) return V3D_EUNSUPPORTED;
   return V3D_OK;
 }
 

@@ -92,6 +92,7 @@ static int conv_fan(const v3d_layer_desc& d) {
 
 extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_layer_desc* descs, v3d_backbone** out) {
   if (!cfg || !descs || !out || cfg->n_layers < 1 || cfg->max_batch < 1 || cfg->max_points < 1) return V3D_EINVAL;
+  if (cfg->max_batch > 64) return V3D_EUNSUPPORTED;  // the batch index rides in 6 bits of a site key (rulebook.hip RB_MAX_BATCH)
   v3d_backbone* p = new (std::nothrow) v3d_backbone();
   if (!p) return V3D_EINVAL;
   p->cfg = *cfg;

@@ -321,11 +321,10 @@ __device__ __forceinline__ void split_act(const float (&x)[8], const float s, u3
       hi[i] = hb;
       lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(spr_f32x2_t{r0, r1}, spr_bf16x2_t));
     } else {
-      const float a = x[2 * i] * s, b = x[2 * i + 1] * s;
-      const spr_f16x2_t hh = __builtin_convertvector(spr_f32x2_t{a, b}, spr_f16x2_t);
-      const float r0 = a - (float)hh[0], r1 = b - (float)hh[1];
-      hi[i] = __builtin_bit_cast(unsigned, hh);
-      lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(spr_f32x2_t{r0, r1}, spr_f16x2_t));
+      unsigned h, l;  // (four mixed-precision fmas per pair: v3d_common.h)
+      v3d_split_f16_pair(x[2 * i], x[2 * i + 1], __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s))), h, l);
+      hi[i] = h;
+      lo[i] = l;
     }
   }
 }

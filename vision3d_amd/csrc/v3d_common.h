@@ -65,6 +65,24 @@ static inline hipError_t v3d_set_max_lds(V3dPerDeviceFlag& f, const void* fn, in
   return e;
 }
 
+// f16s arithmetic (csrc/spconv.hip "the split-precision product"): (x0, x1) -> packed f16 pairs hi = rne(x * s), lo = rne(x * s - hi)
+// in FOUR instructions.  v_fma_mix{lo,hi}_f16 evaluate fma(a, b, c) on f32 / f16 sources chosen per operand and round ONCE to f16
+// into one half of the destination: hi = fma(x, s, 0); lo = fma(x, s, -hi) with the f16 half of `hi` read in place -- x * s is exact
+// (s is a power of two) and x * s - hi fits 14 bits, so both are the values of the plain expressions (checked bit for bit by
+// tools/mb_f16split.hip), without the multiply, the two conversions back and the subtraction (8 VALU operations per pair; the
+// bf16 split takes 6: there is no bf16 mix instruction).  `s` must be wave-uniform (an SGPR operand).
+__device__ __forceinline__ void v3d_split_f16_pair(const float x0, const float x1, const float s, unsigned& hi, unsigned& lo) {
+  unsigned h = 0u, l = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only parses the declaration)
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x0), "s"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x1), "s"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x0), "s"(s), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "s"(s), "v"(h));
+#endif
+  hi = h;
+  lo = l;
+}
+
 // per-device cache of an integer launch parameter (occupancy, CU count): a process may drive several GPUs
 struct V3dPerDeviceInt {
   int v[V3D_MAX_DEVICES] = {};

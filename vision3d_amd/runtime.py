@@ -816,10 +816,10 @@ class DenseHeadPlan(object):
             if in_entry is None:
                 raise RuntimeError("DenseHeadPlan (f16s): the input planes carry no scale entry -- they must come from an f16s "
                                    "BackbonePlan / to_split_nhwc(x, 'fp32') (runtime.tag_planes), or pass in_entry")
-        elif getattr(x_hi, "v3d_entry", None) is not None:
-            raise RuntimeError("DenseHeadPlan (bf16x3) was handed f16s planes: plan and dense head must use one arithmetic")
             if not self.calibrated and not torch.cuda.is_current_stream_capturing():
                 self.calibrate(x_hi, x_lo, in_entry)
+        elif getattr(x_hi, "v3d_entry", None) is not None:
+            raise RuntimeError("DenseHeadPlan (bf16x3) was handed f16s planes: plan and dense head must use one arithmetic")
         if occ is not None and work is None:
             work = self.new_work(x_hi.device)
         state = work if isinstance(work, DenseHeadState) else None
