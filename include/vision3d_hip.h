@@ -389,6 +389,9 @@ typedef struct v3d_conv2d_prec {
   const float* in_entry;  /* f16s: device entry of the input planes */
   const float* out_entry; /* f16s: device entry of the output planes (NULL when only fp32 NCHW is written) */
   int32_t* range_flag;    /* f16s, nullable */
+  const float* w_inv;     /* f16s, nullable: device copy of the weight image's 1 / s_w (float 1 of its 256-byte trailer) in memory the
+                             caller keeps hot, e.g. beside its scale entries; NULL: read from the trailer (a cold line per launch) */
+  const float* w_inv2;    /* same for the second image of v3d_conv2d_1x1_head_fused2 */
 } v3d_conv2d_prec;
 int v3d_conv2d_pack_weights2(const float* weight, const float* scale, int Cout, int Cin, int ksize, int prec, void* image,
                              v3d_stream_t stream);

@@ -136,7 +136,7 @@ class BackboneConfig(C.Structure):
 
 class Conv2dPrec(C.Structure):
     """v3d_conv2d_prec: arithmetic of a dense-head call + the device scale entries of its planes (f16s)."""
-    _fields_ = [("prec", C.c_int32), ("in_entry", _vp), ("out_entry", _vp), ("range_flag", _vp)]
+    _fields_ = [("prec", C.c_int32), ("in_entry", _vp), ("out_entry", _vp), ("range_flag", _vp), ("w_inv", _vp), ("w_inv2", _vp)]
 
 
 PREC_BF16X3, PREC_F16S = 0, 1

@@ -335,7 +335,7 @@ struct DcParams {
   // range flag (nullable)
   const float* in_entry;
   const float* out_entry;
-  const float* w_trailer;
+  const float* w_inv;  // 1 / s_w: the caller's hot copy (v3d_conv2d_prec::w_inv) or the image's trailer (a cold line: ~1 us per launch)
   int* range_flag;
 };
 
@@ -347,7 +347,7 @@ template <int PREC>
 __device__ __forceinline__ DcScales dc_scales(const DcParams& p) {
   DcScales r{1.f, 1.f, 3.0e38f};
   if constexpr (PREC == 1) {
-    r.undo = p.in_entry[1] * p.w_trailer[1];
+    r.undo = p.in_entry[1] * p.w_inv[0];
     if (p.out_entry) {
       r.s_out = p.out_entry[0];
       r.limit = p.out_entry[2];
@@ -1324,8 +1324,8 @@ __global__ __launch_bounds__(256) void conv1x1_bf16x3_small_cout_kernel(const bf
 #define FH_SLAB (2 * 16 * FH_ROW)                   // hi + lo planes of one wave's 16 x 128 tile
 #define FH_W1_BYTES (4 * 2 * 128 * 32 * 2)          // 4 k-steps x (hi, lo) x 128 couts x 32 cins, bf16
 #define FH_SMEM (FH_W1_BYTES + FH_WAVES * FH_SLAB)
-struct FhScales {  // f16s (PREC 1): entries of the input planes and of the intermediate tensor, the two images' trailers, the flag
-  const float *in_entry, *mid_entry, *w1_trailer, *w2_trailer;
+struct FhScales {  // f16s (PREC 1): entries of the input planes and of the intermediate tensor, the two images' 1 / s_w, the flag
+  const float *in_entry, *mid_entry, *w1_inv, *w2_inv;
   int* range_flag;
 };
 template <int PREC>
@@ -1356,10 +1356,10 @@ __global__ __launch_bounds__(FH_WAVES * 64) void conv1x1_head_fused_kernel(const
   __syncthreads();
   DcScales sc1{1.f, 1.f, 3.0e38f}, sc2{1.f, 1.f, 3.0e38f};
   if constexpr (PREC == 1) {
-    sc1.undo = fs.in_entry[1] * fs.w1_trailer[1];
+    sc1.undo = fs.in_entry[1] * fs.w1_inv[0];
     sc1.s_out = fs.mid_entry[0];
     sc1.limit = fs.mid_entry[2];
-    sc2.undo = fs.mid_entry[1] * fs.w2_trailer[1];
+    sc2.undo = fs.mid_entry[1] * fs.w2_inv[0];
   }
   float vmax = 0.f;
   const unsigned char* w1s = fh_smem;
@@ -1472,8 +1472,8 @@ extern "C" int v3d_conv2d_1x1_head_fused2(const void* x_hi, const void* x_lo, co
   if (f16s) {
     fs.in_entry = pr->in_entry;
     fs.mid_entry = pr->out_entry;
-    fs.w1_trailer = reinterpret_cast<const float*>(reinterpret_cast<const char*>(w1_image) + dc_image_payload_bytes(128, 128, 1));
-    fs.w2_trailer = reinterpret_cast<const float*>(reinterpret_cast<const char*>(w2_image) + dc_image_payload_bytes(128, Cout2, 1));
+    fs.w1_inv = pr->w_inv ? pr->w_inv : reinterpret_cast<const float*>(reinterpret_cast<const char*>(w1_image) + dc_image_payload_bytes(128, 128, 1)) + 1;
+    fs.w2_inv = pr->w_inv2 ? pr->w_inv2 : reinterpret_cast<const float*>(reinterpret_cast<const char*>(w2_image) + dc_image_payload_bytes(128, Cout2, 1)) + 1;
     fs.range_flag = pr->range_flag;
   }
   auto kern = f16s ? conv1x1_head_fused_kernel<1> : conv1x1_head_fused_kernel<0>;
@@ -1654,7 +1654,8 @@ extern "C" int v3d_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const v
   p.in_entry = f16s ? pr->in_entry : nullptr;
   p.out_entry = (f16s && y_hi) ? pr->out_entry : nullptr;
   p.range_flag = f16s ? pr->range_flag : nullptr;
-  p.w_trailer = reinterpret_cast<const float*>(reinterpret_cast<const char*>(weight_image) + dc_image_payload_bytes(Cin, Cout, ksize));
+  p.w_inv = (f16s && pr->w_inv) ? pr->w_inv
+                                : reinterpret_cast<const float*>(reinterpret_cast<const char*>(weight_image) + dc_image_payload_bytes(Cin, Cout, ksize)) + 1;
   hipStream_t st = (hipStream_t)stream;
   if (f16s)
     return dc_launch<1>(x_hi, x_lo, weight_image, bias, p, ksize, y_hi, y_lo, y_nchw, occ, work, tile_state, reset_ptr, reset_words, st);

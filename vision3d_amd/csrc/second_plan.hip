@@ -79,6 +79,8 @@ struct v3d_backbone {
   int prec = V3D_PREC_BF16X3;
   bool calibrating = false;  // the next forwards run every layer on the exact-fp32 kernel (no scales involved): calibration pass
   float* act_tab = nullptr;
+  float* w_inv_tab = nullptr;  // [n_layers] 1 / s_w of the layers' f16s images, beside act_tab: what the kernels read instead of the
+                               // images' trailers (cold lines)
   struct PlanTrain* train = nullptr;  // training buffers, allocated by the first v3d_backbone_train_forward
   // (Measured and removed in round 4: the rulebook chain on a second stream with one event per finished rulebook -- inside a
   // captured graph the fork / join costs more than the overlap returns, 3 209 -> 2 526 frames/s pipelined)
@@ -214,7 +216,8 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       p->bev_pix = ar.take<int32_t>(sl.cap);
       p->bev_pix_n = ar.take<int32_t>(1);
     }
-    p->act_tab = ar.take<float>(4 * (p->layers.size() + 1));
+    p->act_tab = ar.take<float>(4 * (p->layers.size() + 1) + p->layers.size());
+    p->w_inv_tab = p->act_tab + 4 * (p->layers.size() + 1);
     p->cand_slot[0] = ar.take<int>((size_t)max_tickets);
     p->cand_slot[1] = ar.take<int>((size_t)max_tickets);
     for (auto& L : p->layers) {
@@ -241,6 +244,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
   if (e == hipSuccess) {
     std::vector<float> tab;
     for (size_t i = 0; i <= p->layers.size(); i++) tab.insert(tab.end(), {1.f, 1.f, 32768.f, 0.f});
+    for (size_t i = 0; i < p->layers.size(); i++) tab.push_back(1.f);
     e = hipMemcpy(p->act_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
   }
   if (e != hipSuccess) { (void)hipFree(p->arena); delete p; return (int)e; }
@@ -270,6 +274,10 @@ extern "C" int v3d_backbone_set_layer(v3d_backbone* p, int layer, const float* w
   if (L.d.cout % 16 == 0) {
     int rc = v3d_sparse_conv_pack_weights2(L.weight, L.K, L.d.cin, L.d.cout, p->prec, L.wimg, stream);
     if (rc) return rc;
+    if (p->prec == V3D_PREC_F16S) {  // the image's 1 / s_w (written by the pack kernel) into the plan's hot table
+      const char* trailer = (const char*)L.wimg + v3d_sparse_conv_weight_image_bytes(L.K, L.d.cin, L.d.cout) - 256;
+      V3D_CHECK_HIP(hipMemcpyAsync(p->w_inv_tab + layer, trailer + 4, sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
   }
   if (scale) {
     V3D_CHECK_HIP(hipMemcpyAsync(L.scale, scale, (size_t)L.d.cout * 4, hipMemcpyDeviceToDevice, st));
@@ -514,7 +522,7 @@ static int plan_layer_conv(v3d_backbone* p, PlanLayer& L, const float* feat, con
   if (!exact_pass && (c.conv_algo == 4 || (c.conv_algo == 0 && L.d.cin >= 16))) {
     const int prec = inference ? p->prec : V3D_PREC_BF16X3;
     const size_t l = (size_t)(&L - p->layers.data());
-    const V3dActScale as{p->act_tab + 4 * l, p->act_tab + 4 * (l + 1), p->overflow + p->layers.size()};
+    const V3dActScale as{p->act_tab + 4 * l, p->act_tab + 4 * (l + 1), p->overflow + p->layers.size(), p->w_inv_tab + l};
     rc = v3d_i_sparse_conv_fwd_packed(feat, wimg, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout, scale, shift,
                                       relu, out, L.rows_hint, st, densify, p->ring_tiles_min, prec, &as);
     if (rc == V3D_OK && densify && densified) *densified = true;

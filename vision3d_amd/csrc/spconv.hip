@@ -356,7 +356,7 @@ __device__ __forceinline__ SpScales sp_scales(const V3dActScale& as, const unsig
   SpScales r{1.f, 1.f, 3.0e38f};
   if constexpr (PREC == 1) {
     r.s_in = as.in[0];
-    r.undo = as.in[1] * reinterpret_cast<const float*>(wimg + img_elems)[1];
+    r.undo = as.in[1] * (as.w_inv ? *as.w_inv : reinterpret_cast<const float*>(wimg + img_elems)[1]);
     if (as.next) r.limit = as.next[2];
   }
   return r;
@@ -1492,7 +1492,7 @@ extern "C" int v3d_sparse_conv_fwd_packed2(const float* in, const void* weight_i
                                            const int32_t* n_out, int cap_out, int K, int Cin, int Cout, const float* scale,
                                            const float* shift, int relu, float* out, int rows_hint, int prec,
                                            const float* act_in, const float* act_next, int32_t* range_flag, v3d_stream_t stream) {
-  const V3dActScale as{act_in, act_next, range_flag};
+  const V3dActScale as{act_in, act_next, range_flag, nullptr};
   return v3d_i_sparse_conv_fwd_packed(in, weight_image, nbr, n_out, cap_out, K, Cin, Cout, scale, shift, relu, out, rows_hint,
                                       (hipStream_t)stream, nullptr, 2, prec, &as);
 }
@@ -1505,7 +1505,7 @@ int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, cons
   if ((scale == nullptr) != (shift == nullptr)) return V3D_EINVAL;
   if (prec != V3D_PREC_BF16X3 && prec != V3D_PREC_F16S) return V3D_EINVAL;
   if (prec == V3D_PREC_F16S && (!act || !act->in || (densify && !act->next))) return V3D_EINVAL;  // no scale, no f16s
-  const V3dActScale as = (prec == V3D_PREC_F16S) ? *act : V3dActScale{nullptr, nullptr, nullptr};
+  const V3dActScale as = (prec == V3D_PREC_F16S) ? *act : V3dActScale{nullptr, nullptr, nullptr, nullptr};
 #define V3D_TRY(ci, co)                                                                                                        \
   if (Cin == ci && Cout == co) {                                                                                               \
     if (prec == V3D_PREC_F16S)                                                                                                 \

@@ -64,6 +64,9 @@ struct V3dActScale {
   const float* in;    // entry of the rows this launch gathers
   const float* next;  // nullable: entry of this launch's OUTPUT (checked in the epilogue; the scale of planes written there)
   int32_t* flag;      // nullable: where a range violation is recorded
+  const float* w_inv; // nullable: 1 / s_w of the weight image in memory the caller keeps HOT (a plan's table: one line for all layers).
+                      // NULL: read from the image's trailer -- a line nothing else touches, i.e. a cold miss of ~1 us at the top of
+                      // every launch (measured: every packed layer +1 us against bf16x3 until the plan passed this)
 };
 
 // .dense() riding in the epilogue of the LAST sparse layer (the 16-row kernel): besides its rows the layer writes them, split into

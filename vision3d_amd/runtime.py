@@ -536,8 +536,10 @@ def _prec_struct(pr):
     """pr = None (bf16x3) | (in_entry, out_entry | None, range_flag | None): device (4,) float32 entries of an f16s call."""
     if pr is None:
         return None, None
-    in_entry, out_entry, flag = pr
-    st = L.Conv2dPrec(L.PREC_F16S, L.ptr(in_entry), L.ptr(out_entry), L.ptr(flag))
+    in_entry, out_entry, flag = pr[:3]
+    w_inv = pr[3] if len(pr) > 3 else None   # (1,) device float: hot copy of the image's 1 / s_w (DenseHeadPlan keeps them in one line)
+    w_inv2 = pr[4] if len(pr) > 4 else None
+    st = L.Conv2dPrec(L.PREC_F16S, L.ptr(in_entry), L.ptr(out_entry), L.ptr(flag), L.ptr(w_inv), L.ptr(w_inv2))
     return C.byref(st), st  # (the structure must outlive the call: the caller keeps the second value)
 
 
@@ -725,6 +727,12 @@ class DenseHeadPlan(object):
             dev = layers[0]["bias"].device
             if self.tab is None or self.tab.shape[0] != len(layers) - 1 or self.tab.device != dev:
                 self.tab = torch.tensor([[1.0, 1.0, 32768.0, 0.0]] * (len(layers) - 1), dtype=torch.float32, device=dev)
+                self.w_inv = torch.ones(len(layers), dtype=torch.float32, device=dev)
+            # the images' 1 / s_w (float 1 of each 256-byte trailer, written by the pack kernels) gathered into ONE hot line: the
+            # kernels would otherwise open every launch on a cold miss of a line nothing else reads
+            for i, ly in enumerate(layers):
+                if ly is not None:
+                    self.w_inv[i:i + 1].copy_(ly["img"][-256:].view(torch.float32)[1:2])
 
     def _invalidate_background(self):
         """The empty-map responses belong to the old weights / scales: recomputed at the next use -- INTO the same tensors when
@@ -753,7 +761,8 @@ class DenseHeadPlan(object):
         if not self.f16s:
             return None
         src = in_entry if i == 0 else self.tab[i - 1]
-        return (src, self.tab[i] if planes_out else None, flag)
+        nxt = self.w_inv[i + 1:i + 2] if i + 1 < self.w_inv.numel() else None  # (the fused tail's second image: the head)
+        return (src, self.tab[i] if planes_out else None, flag, self.w_inv[i:i + 1], nxt)
 
     def background(self, h, w, device):
         """Per RPN layer: its output on an EMPTY (all-zero) BEV map of one image, as split planes -- what every pixel far
