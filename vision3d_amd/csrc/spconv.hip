@@ -302,7 +302,11 @@ typedef float spr_f32x2_t __attribute__((ext_vector_type(2)));
 
 template <int PREC>
 __device__ __forceinline__ f32x4 sp_mfma(const u32x4_t a, const u32x4_t b, const f32x4 c) {
+#ifdef SP_EXP_F16S_BF16_MFMA  // experiment only (wrong results): the f16s kernels on the bf16 instruction -- is the f16 MFMA itself slower?
+  if constexpr (true)
+#else
   if constexpr (PREC == 0)
+#endif
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   else
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(spr_f16x8_t, a), __builtin_bit_cast(spr_f16x8_t, b), c, 0, 0, 0);
@@ -320,6 +324,14 @@ __device__ __forceinline__ void split_act(const float (&x)[8], const float s, u3
       const float r0 = x[2 * i] - __uint_as_float(hb << 16), r1 = x[2 * i + 1] - __uint_as_float(hb & 0xFFFF0000u);
       hi[i] = hb;
       lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(spr_f32x2_t{r0, r1}, spr_bf16x2_t));
+#ifdef SP_EXP_F16S_BF16_SPLIT  // experiment only (wrong results): the f16s kernels with the bf16 split's instructions
+    } else if constexpr (true) {
+      const spr_bf16x2_t hh = __builtin_convertvector(spr_f32x2_t{x[2 * i], x[2 * i + 1]}, spr_bf16x2_t);
+      const unsigned hb = __builtin_bit_cast(unsigned, hh);
+      const float r0 = x[2 * i] - __uint_as_float(hb << 16), r1 = x[2 * i + 1] - __uint_as_float(hb & 0xFFFF0000u);
+      hi[i] = hb;
+      lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(spr_f32x2_t{r0, r1}, spr_bf16x2_t));
+#endif
     } else {
       unsigned h, l;  // (four mixed-precision fmas per pair: v3d_common.h)
       v3d_split_f16_pair(x[2 * i], x[2 * i + 1], __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s))), h, l);
