@@ -1,6 +1,6 @@
 // ref_driver.cpp -- C-ABI driver around the REFERENCE's own rotated-IoU core.
 //
-// TEST INFRASTRUCTURE ONLY (see the header of oracle/oracle.py and DESIGN.md section 2).  This file contains no geometry: it #includes
+// TEST INFRASTRUCTURE ONLY (see the header of oracle/oracle.py and DESIGN.md section 3).  This file contains no geometry: it #includes
 // the reference header in place (-I/root/reference/vision3d/ops/csrc/box_iou_rotated, see
 // oracle/Makefile) and exposes detectron2::single_box_iou_rotated<float>
 // (box_iou_rotated_utils.h:313-340) through plain C symbols, so tests can pin oracle/v3d_oracle.c

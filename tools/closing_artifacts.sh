@@ -1,5 +1,5 @@
 # Round-closing measurements on one MI355X box: the four bench lines of BASELINE.json with their rocprofv3 kernel statistics, the
-# pipeline overlap trace and the microbenchmarks DESIGN.md section 5b quotes.  Output: gpurun_out/closing/ (copied to profiles/r03_*).
+# pipeline overlap trace and the microbenchmarks docs/rounds/design_rounds_1-4.md section 5b quotes.  Output: gpurun_out/closing/ (copied to profiles/r03_*).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/closing; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_k -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_prof.json 2> $O/prof_k.err

@@ -83,7 +83,7 @@ struct v3d_backbone {
                                // images' trailers (cold lines)
   struct PlanTrain* train = nullptr;  // training buffers, allocated by the first v3d_backbone_train_forward
   // (Measured and removed in round 4: the rulebook chain on a second stream with one event per finished rulebook -- inside a
-  // captured graph the fork / join costs more than the overlap returns, 3 209 -> 2 526 frames/s pipelined)
+  // captured graph the fork / join costs more than the overlap returns, 3 209 -> 2 526 frames/s pipelined; docs/rounds/design_rounds_1-4.md 5c.4.)
 };
 
 static int conv_fan(const v3d_layer_desc& d) {

@@ -40,7 +40,7 @@ def prebuild_rulebooks(root, x):
     in 17 ms).  In the pre-pass the reads only wait for the short rulebook kernels; afterwards the whole forward is
     enqueued without a single synchronisation."""
     from .conv import _SparseConvBase
-    if os.environ.get("V3D_PREBUILD_RULEBOOKS", "1") == "0":  # A/B switch (bench notes in DESIGN.md)
+    if os.environ.get("V3D_PREBUILD_RULEBOOKS", "1") == "0":  # A/B switch (bench notes in docs/rounds/design_rounds_1-4.md)
         return x
     cur = x
     for m in root.modules():  # registration order == execution order for (nested) Sequential trees
