@@ -93,6 +93,10 @@ def parse():
                     help="arithmetic of the native inference path: fp32 = f16 hi/lo pieces under calibrated power-of-two scales (the "
                          "reference's fp32 modules up to summation noise); bf16x3 = bf16 pieces, 2^-17 per product (fast mode)")
     ap.add_argument("--no-fast-mode", action="store_true", help="forward mode: skip the bf16x3 line measured beside the fp32-class one")
+    ap.add_argument("--order", choices=["shuffled", "scan"], default="shuffled",
+                    help="forward mode: point order of the synthetic sweeps -- shuffled (default: what the TRAINING dataset hands over, "
+                         "kitti_dataset.py:154; the gathers of the sparse convolutions are then random) or scan (firing order: what "
+                         "inference.py reads from a .bin file; neighbouring voxels are neighbouring rows)")
     ap.add_argument("--stream", type=int, default=8, help="different synthetic frames per rank the timed loop cycles through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch event timing pass (profiling runs)")
@@ -785,7 +789,8 @@ def main():
                             cfg.GRID_BOUNDS[4] + 0.02, cfg.GRID_BOUNDS[5]]
     anchors = AnchorGenerator(acfg).anchors.cuda()
     # frame-parallel sharding: rank r owns frames r*B .. r*B+B-1 of the synthetic stream
-    make = (lambda seed, n: synth.make_waymo_cloud(seed, n)) if waymo else (lambda seed, n: synth.make_cloud(seed, n))
+    make = ((lambda seed, n: synth.make_waymo_cloud(seed, n, order=args.order)) if waymo
+            else (lambda seed, n: synth.make_cloud(seed, n, order=args.order)))
     # A stream of N_STREAM different frames per rank (seeds differ per rank and per step), resident in HBM before the timed
     # region; step i runs frames stream[i % N_STREAM]: the timed loop is not a replay of one cache-resident cloud.
     N_STREAM = max(1, args.stream)
@@ -1188,7 +1193,7 @@ def main():
                     scaling="weak", vs_baseline=None, dtype=DTYPE_NOTE[args.precision], data="synthetic", precision=args.precision,
                     fast_mode=fast_mode,
                     config=dict(workload=wl,
-                                frames_per_gpu_per_step=args.batch, points_per_frame=args.points,
+                                frames_per_gpu_per_step=args.batch, points_per_frame=args.points, point_order=args.order,
                                 distinct_frames_in_timed_loop=N_STREAM,
                                 parallelism=f"frame-parallel replicas x{world}", pipeline_depth=(graphed.depth if pipelined else 1),
                                 pipeline_tuning=(graphed.tuned if pipelined else None),
