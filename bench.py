@@ -755,6 +755,9 @@ def run_cpu_baseline(model, cfg, anchors, make, args, workload="kitti"):
 
 
 def main():
+    import faulthandler
+    import signal
+    faulthandler.register(signal.SIGUSR1, all_threads=True)  # `kill -USR1 <pid>` (or timeout -s USR1) dumps the Python stacks of a stuck run
     args = parse()
     ensure_world(args)
     if args.mode == "train":

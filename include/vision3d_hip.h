@@ -331,8 +331,10 @@ uint32_t* v3d_backbone_bev_occupancy(v3d_backbone* plan);
 int v3d_backbone_bev_planes(v3d_backbone* plan, void** hi, void** lo);
 /* Kernel choice of the following forwards: on != 0 = THROUGHPUT mode, for plans whose frames run beside other frames on the same GPU
  * (one plan per frame in flight): the LDS-filling 64 -> 64 sparse kernel takes four 16-row tiles per workgroup whatever the row count --
- * fewer, fatter workgroups: ~39 % less CU-time per launch, ~20 % longer launches (results are bit-identical either way).  Default off:
- * the shortest launch (one frame at a time). */
+ * fewer, fatter workgroups: ~39 % less CU-time per launch, ~20 % longer launches (results are bit-identical either way) --, and a
+ * packed layer that is followed by a packed layer writes its output rows ONLY in the split form the next layer gathers
+ * (v3d_backbone_set_presplit), not as fp32 rows: v3d_backbone_layer_output's feature views of such layers are then stale.
+ * Default off: the shortest launch (one frame at a time), every layer's fp32 rows written. */
 int v3d_backbone_set_throughput_mode(v3d_backbone* plan, int on);
 /* Arithmetic of the plan's INFERENCE entry points (v3d_backbone_forward* ; the training plan is bf16x3): V3D_PREC_BF16X3 (default of
  * a new plan) or V3D_PREC_F16S.  Set it BEFORE v3d_backbone_set_layer: the weight images are packed per arithmetic.
@@ -344,6 +346,9 @@ int v3d_backbone_set_throughput_mode(v3d_backbone* plan, int on);
  * calibration frame's maximum) raises v3d_backbone_overflow_flags()[n_layers] to 2: recalibrate on it and run it again. */
 int v3d_backbone_set_precision(v3d_backbone* plan, int prec);
 int v3d_backbone_precision(const v3d_backbone* plan);
+/* on != 0 (default): a packed layer also writes its output rows split into the arithmetic's 16-bit pieces and the next packed layer
+ * gathers those (no conversion work in its main loop); 0: every layer splits the fp32 rows it gathers (A/B).  Same results. */
+int v3d_backbone_set_presplit(v3d_backbone* plan, int on);
 float* v3d_backbone_act_scales(v3d_backbone* plan);
 int v3d_backbone_set_calibrating(v3d_backbone* plan, int on);
 int v3d_backbone_calibrate(v3d_backbone* plan, int headroom_bits, v3d_stream_t stream);

@@ -267,3 +267,29 @@ def test_bf16x3_mode_still_available_and_close_to_fp32_class():
         assert plan.precision == "bf16x3" and plan.bev_entry() is None and model.dense_plan().precision == "bf16x3"
     assert not torch.equal(fp32, fast)
     assert_features_close(fast.cpu().numpy(), fp32.cpu().numpy(), "bf16x3 vs f16s head maps")
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("seeds", [(0,), (1, 2, 3, 4, 5, 6, 7)], ids=["kitti_bs1", "bs7_big_kernels"])
+def test_presplit_rows_are_bit_identical_to_in_register_splits(seeds, precision):
+    """A packed layer of a plan also writes its output rows split into the arithmetic's 16-bit pieces (under the next layer's scale
+    entry) and the next packed layer gathers those instead of splitting fp32 rows in its main loop: the same pieces either way, so
+    the BEV map must not change by a bit.  bs = 1 runs the 16-row and LDS-ring kernels (staged and register gathers), the 7-frame
+    batch the 64-row LDS-shared-weights kernel and the offset-outer kernel (>= 32 768 rows per stage)."""
+    model = build_model(9).set_precision(precision)
+    clouds = [torch.from_numpy(synth.make_cloud(s)).cuda() for s in seeds]
+    with torch.no_grad():
+        plan, flat, offsets = model._plan_for(clouds)
+        on = model.bev_from_points(clouds).clone()
+        rows = [int(plan.layer_output(l)[2].item()) for l in range(len(plan.layers))]
+        plan.set_presplit(False)
+        off = model.bev_from_points(clouds).clone()
+        plan.set_presplit(True)
+        again = model.bev_from_points(clouds).clone()
+        plan.set_throughput_mode(True)  # split rows ONLY (the fp32 rows of layers followed by a packed layer are not written), 4-tile ring
+        thr = model.bev_from_points(clouds).clone()
+        plan.set_throughput_mode(False)
+    if len(seeds) > 1:
+        assert max(rows) >= 32768, rows
+    assert torch.equal(on, off) and torch.equal(on, again) and torch.equal(on, thr)
+    assert float(on.abs().max()) > 0

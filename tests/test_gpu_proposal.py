@@ -139,18 +139,18 @@ def test_pipelined_frames_match_single_frame_graph(autotune):
         single = model.graphed_inference(anchors, [frames[0][0].shape[0]])
         want = [[t.clone() for t in single(f)] for f in frames]
         pipe = model.pipelined_inference(anchors, [frames[0][0].shape[0]], depth=3 if autotune else 2, autotune=autotune)
-        got, last = [], None
+        got = []
         for f in frames:
-            r = pipe(f)  # collects the oldest frame (views of its slot's buffers), then submits f to ANOTHER slot
-            if last is not None:  # contract: a result stays valid until the next collect(), i.e. across one more submit
-                for t, c in zip(last[0], last[1]):
-                    assert torch.equal(t, c), "collected tensors changed before the next collect()"
-                last = None
-            if r is not None:
-                torch.cuda.synchronize()  # let the frame just submitted run: it must not touch the collected slot
-                copy = [t.clone() for t in r]
-                got.append(copy)
-                last = (r, copy)
+            if len(pipe.pending) < pipe.depth:
+                pipe.submit(f)
+                continue
+            r = pipe.collect()  # the oldest frame: views of its slot's static buffers (collect synchronised that slot's stream)
+            copy = [t.clone() for t in r]
+            pipe.submit(f)  # goes to ANOTHER slot: the ring has one slot more than frames in flight
+            torch.cuda.synchronize()  # the frame just submitted has run to its end ...
+            for t, c in zip(r, copy):  # ... contract: a result stays valid until the NEXT collect(), i.e. across this submit
+                assert torch.equal(t, c), "collected tensors changed before the next collect()"
+            got.append(copy)
         got += [[t.clone() for t in r] for r in pipe.flush()]
     assert len(got) == len(want)
     if autotune:

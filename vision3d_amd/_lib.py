@@ -89,6 +89,7 @@ _SIGNATURES = {
     "v3d_nchw_to_split_nhwc2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "v3d_backbone_set_precision": (_i, [_vp, _i]),
     "v3d_backbone_precision": (_i, [_vp]),
+    "v3d_backbone_set_presplit": (_i, [_vp, _i]),
     "v3d_backbone_act_scales": (_vp, [_vp]),
     "v3d_backbone_set_calibrating": (_i, [_vp, _i]),
     "v3d_backbone_calibrate": (_i, [_vp, _i, _vp]),

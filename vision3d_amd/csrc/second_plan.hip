@@ -24,6 +24,8 @@ struct PlanLayer {
   int rulebook;             // index into nbr tables
   bool builds_rulebook;
   float *weight, *scale, *shift, *out;
+  void* out_s;  // the output rows once more, split into the arithmetic's 16-bit pieces under the next layer's scale entry: what the
+                // next packed layer gathers (its main loop then converts nothing); nullptr for the last layer
   void* wimg;  // split + packed weights for the bf16x3 kernel
   int has_affine;
   int* chunk_counts;  // strided layers: published per-chunk counts -> offsets (inside the per-frame 0xFF region)
@@ -78,6 +80,8 @@ struct v3d_backbone {
   // for magnitudes below 2^15, full precision once v3d_backbone_calibrate has set them from a frame.
   int prec = V3D_PREC_BF16X3;
   bool calibrating = false;  // the next forwards run every layer on the exact-fp32 kernel (no scales involved): calibration pass
+  bool presplit = true;      // packed layers also write their rows split for the next packed layer (v3d_backbone_set_presplit: A/B)
+  bool fp32_rows = true;     // ... beside the fp32 rows (v3d_backbone_layer_output); false in throughput mode: split rows only
   float* act_tab = nullptr;
   float* w_inv_tab = nullptr;  // [n_layers] 1 / s_w of the layers' f16s images, beside act_tab: what the kernels read instead of the
                                // images' trailers (cold lines)
@@ -226,6 +230,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
       L.scale = ar.take<float>(L.d.cout);
       L.shift = ar.take<float>(L.d.cout);
       L.out = ar.take<float>((size_t)p->stages[L.stage_out].cap * L.d.cout);
+      L.out_s = (&L != &p->layers.back() && L.d.cout % 8 == 0) ? (void*)ar.take<float>((size_t)p->stages[L.stage_out].cap * L.d.cout) : nullptr;
     }
   };
   {
@@ -355,6 +360,7 @@ static int plan_clear_own_planes(v3d_backbone* p, void* dense_hi, void* dense_lo
 extern "C" int v3d_backbone_set_throughput_mode(v3d_backbone* p, int on) {
   if (!p) return V3D_EINVAL;
   p->ring_tiles_min = on ? 4 : 2;
+  p->fp32_rows = !on;  // (v3d_backbone_layer_output: the feature rows of layers followed by a packed layer are then not written)
   return V3D_OK;
 }
 
@@ -373,6 +379,15 @@ extern "C" int v3d_backbone_set_precision(v3d_backbone* p, int prec) {
   return V3D_OK;
 }
 extern "C" int v3d_backbone_precision(const v3d_backbone* p) { return p ? p->prec : V3D_EINVAL; }
+
+// on (default): every packed layer of the inference entry points also writes its output rows split into the arithmetic's 16-bit
+// pieces (under the next layer's scale entry) and the next packed layer gathers those: no conversion work in its main loop.
+// off: every layer splits the fp32 rows it gathers in registers (rounds 1-4; A/B measurements).  Same results bit for bit.
+extern "C" int v3d_backbone_set_presplit(v3d_backbone* p, int on) {
+  if (!p) return V3D_EINVAL;
+  p->presplit = on != 0;
+  return V3D_OK;
+}
 
 // f16s: (n_layers + 1) x {s, 1/s, limit, max} in device memory, entry l = input rows of layer l, entry n_layers = the BEV map
 extern "C" float* v3d_backbone_act_scales(v3d_backbone* p) { return p ? p->act_tab : nullptr; }
@@ -513,7 +528,8 @@ static int plan_layer_rulebook(v3d_backbone* p, size_t l, std::vector<char>& rb_
 // entries and checks its output against the next one); the training plan passes false (bf16x3 images, no scales).
 static int plan_layer_conv(v3d_backbone* p, PlanLayer& L, const float* feat, const void* wimg, const float* weight,
                            const float* scale, const float* shift, int relu, float* out, hipStream_t st,
-                           const V3dDensifyOut* densify = nullptr, bool* densified = nullptr, bool inference = false) {
+                           const V3dDensifyOut* densify = nullptr, bool* densified = nullptr, bool inference = false,
+                           const void** feat_split = nullptr /*in: the input rows' split copy or null; out: this layer's or null*/) {
   const v3d_backbone_config& c = p->cfg;
   PlanStage& so = p->stages[L.stage_out];
   int rc = V3D_EUNSUPPORTED;
@@ -523,9 +539,20 @@ static int plan_layer_conv(v3d_backbone* p, PlanLayer& L, const float* feat, con
     const int prec = inference ? p->prec : V3D_PREC_BF16X3;
     const size_t l = (size_t)(&L - p->layers.data());
     const V3dActScale as{p->act_tab + 4 * l, p->act_tab + 4 * (l + 1), p->overflow + p->layers.size(), p->w_inv_tab + l};
+    const void* in_s = feat_split ? *feat_split : nullptr;
+    // (f16s only: its split is conversion instructions that issue slowly -- profiles/r05_f16s_split_ab.txt --; with bf16 pieces the
+    //  second copy of the rows costs the pipelined mode more than the plain split it saves: profiles/r05_presplit_ab.txt)
+    //  In THROUGHPUT mode the fp32 rows of such a layer are not written at all -- nobody reads them: the next layer gathers the
+    //  split copy, captured graphs expose no intermediate rows -- so the split copy replaces the fp32 stores instead of adding to
+    //  them, and pays in both arithmetics.
+    void* out_s = (feat_split && p->presplit && (prec == V3D_PREC_F16S || !p->fp32_rows)) ? L.out_s : nullptr;
+    if (out_s && !p->fp32_rows && !densify) out = nullptr;
     rc = v3d_i_sparse_conv_fwd_packed(feat, wimg, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout, scale, shift,
-                                      relu, out, L.rows_hint, st, densify, p->ring_tiles_min, prec, &as);
+                                      relu, out, L.rows_hint, st, densify, p->ring_tiles_min, prec, &as, in_s, out_s);
     if (rc == V3D_OK && densify && densified) *densified = true;
+    if (feat_split) *feat_split = rc == V3D_OK ? out_s : nullptr;
+  } else if (feat_split) {
+    *feat_split = nullptr;  // an exact-fp32 layer writes fp32 rows only
   }
   if (rc == V3D_EUNSUPPORTED) {
     // (an f16s plan outside its calibration pass: the exact layer's output feeds a scaled layer -- checked against that entry)
@@ -543,6 +570,7 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
   int rc = V3D_OK;
   std::vector<char> rb_done(p->layers.size(), 0);
   const float* feat = p->mean;
+  const void* feat_split = nullptr;  // the split copy of `feat` (written by the previous packed layer), or null
   // the candidate pass of a strided layer rides in the launch that produces its input sites' last table (rulebook.hip RbCandJob)
   std::vector<char> cand_done(p->layers.size(), 0);
   bool densified = false;
@@ -562,7 +590,7 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
       dn = V3dDensifyOut{sl.coords, sl.shape[0], sl.shape[1], sl.shape[2], p->bev_hi, p->bev_lo, p->bev_occ, p->bev_pix, p->bev_pix_n};
     }
     rc = plan_layer_conv(p, L, feat, L.wimg, L.weight, L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr,
-                         L.d.relu, L.out, st, want_dn ? &dn : nullptr, &densified, true);
+                         L.d.relu, L.out, st, want_dn ? &dn : nullptr, &densified, true, &feat_split);
     if (rc) return rc;
     feat = L.out;
   }

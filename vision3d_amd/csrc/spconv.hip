@@ -341,6 +341,47 @@ __device__ __forceinline__ void split_act(const float (&x)[8], const float s, u3
   }
 }
 
+// INS = 1: the gathered rows are ALREADY split (row = [hi: C x 16 bit | lo: C x 16 bit], the bytes of the fp32 row): the producing layer
+// wrote them that way under THIS layer's scale entry (sp_store_split below), so the lane's two 16-byte loads return its hi and lo
+// fragments directly and the main loop has no conversion work at all.  The 8 dwords travel in the same `float[8]` registers the
+// fp32 path uses: [0..3] = hi, [4..7] = lo.
+template <int PREC, int INS>
+__device__ __forceinline__ void split_in(const float (&x)[8], const float s, u32x4_t& hi, u32x4_t& lo) {
+  if constexpr (INS) {
+    hi = u32x4_t{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+    lo = u32x4_t{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
+  } else {
+    split_act<PREC>(x, s, hi, lo);
+  }
+}
+
+// (v0, v1) -> packed hi pair and lo pair, PREC 1: of v * s
+template <int PREC>
+__device__ __forceinline__ void sp_split_pair(const float v0, const float v1, const float s, unsigned& hi, unsigned& lo) {
+  if constexpr (PREC == 0) {
+    const spr_bf16x2_t hh = __builtin_convertvector(spr_f32x2_t{v0, v1}, spr_bf16x2_t);
+    hi = __builtin_bit_cast(unsigned, hh);
+    const float r0 = v0 - __uint_as_float(hi << 16), r1 = v1 - __uint_as_float(hi & 0xFFFF0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(spr_f32x2_t{r0, r1}, spr_bf16x2_t));
+  } else {
+    v3d_split_f16_pair(v0, v1, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s))), hi, lo);
+  }
+}
+
+// Epilogue, second copy of an output row for the NEXT packed layer: the row split into pieces (of v * s: the consumer's scale entry).
+// A lane holds D[row][col = j * 16 + r]; lanes r and r ^ 1 hold neighbouring columns of the same row: they exchange their values
+// (one DPP move), both split the pair, the even lane stores the hi pair and the odd lane the lo pair -- one 4-byte store per
+// value and lane, as many store instructions as the fp32 row takes.  Every lane of a pair must call this (rows are uniform
+// across the 16 lanes that share (kg, rr): the callers' `row < n` test keeps pairs together).
+template <int PREC, int COUT>
+__device__ __forceinline__ void sp_store_split(unsigned short* __restrict__ out_s, const int row, const int col, const int r, const float v,
+                                               const float s) {
+  const float pv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
+  unsigned h, l;
+  sp_split_pair<PREC>((r & 1) ? pv : v, (r & 1) ? v : pv, s, h, l);
+  *reinterpret_cast<unsigned*>(out_s + (size_t)row * (2 * COUT) + ((r & 1) ? COUT : 0) + (col & ~1)) = (r & 1) ? l : h;
+}
+
 // one value -> (hi, lo) 16-bit patterns, PREC 1: of v * s
 template <int PREC>
 __device__ __forceinline__ void split_one(const float v, const float s, unsigned short& hi, unsigned short& lo) {
@@ -555,13 +596,14 @@ extern "C" int v3d_debug_rows_timeline(unsigned long long* host_out) {
 #define SPR_STAMP(idx)
 #endif
 
-template <int CIN, int COUT, int PREC>
+template <int CIN, int COUT, int PREC, int INS>
 __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __restrict__ in,
                                                              const unsigned short* __restrict__ wimg,
                                                              const int* __restrict__ nbr, const int* __restrict__ n_ptr,
                                                              int cap, int K, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, int relu,
-                                                             float* __restrict__ out, const V3dDensifyOut dn, const V3dActScale as) {
+                                                             float* __restrict__ out, const V3dDensifyOut dn, const V3dActScale as,
+                                                             unsigned short* __restrict__ out_s) {
   // workgroup = 16 output rows; its 4 waves split the K kernel offsets (wave w takes k = w, w+4, ...), keep
   // private register accumulators and meet ONCE, in the epilogue, where the 4 partial tiles are summed in a
   // fixed order (deterministic).  4x more waves in flight and a 4x shorter dependent chain per wave than one
@@ -605,7 +647,13 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
       const int c0 = ki * 32 + kg * 8;
       if (src >= 0 && c0 < CIN) {
         const float* p = in + (size_t)src * CIN + c0;
-        if constexpr (CIN % 8 == 0) {
+        if constexpr (INS) {  // split rows: hi fragment at byte 2 c0, lo fragment CIN halfwords further
+          static_assert(!INS || CIN % 8 == 0, "split rows need whole 16-byte fragments");
+          const char* q = reinterpret_cast<const char*>(in) + (size_t)src * CIN * 4 + c0 * 2;
+          const float4 v0 = *reinterpret_cast<const float4*>(q), v1 = *reinterpret_cast<const float4*>(q + CIN * 2);
+          a[ki][0] = v0.x; a[ki][1] = v0.y; a[ki][2] = v0.z; a[ki][3] = v0.w;
+          a[ki][4] = v1.x; a[ki][5] = v1.y; a[ki][6] = v1.z; a[ki][7] = v1.w;
+        } else if constexpr (CIN % 8 == 0) {
           const float4 v0 = reinterpret_cast<const float4*>(p)[0], v1 = reinterpret_cast<const float4*>(p)[1];
           a[ki][0] = v0.x; a[ki][1] = v0.y; a[ki][2] = v0.z; a[ki][3] = v0.w;
           a[ki][4] = v1.x; a[ki][5] = v1.y; a[ki][6] = v1.z; a[ki][7] = v1.w;
@@ -630,7 +678,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
 #pragma unroll
     for (int ki = 0; ki < KI; ki++) {
       u32x4_t ah, al;
-      split_act<PREC>(a[ki], ss.s_in, ah, al);
+      split_in<PREC, INS>(a[ki], ss.s_in, ah, al);
 #pragma unroll
       for (int j = 0; j < NB; j++) acc[j] = sp_mfma<PREC>(al, b[(ki * NB + j) * 2], acc[j]);  // smallest terms first
 #pragma unroll
@@ -670,7 +718,8 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
 
   // epilogue: wave w finishes column blocks j = w, w + NW, ...;  D[row = kg*4 + rr][col = r]
   float vmax = 0.f;
-  const float s_next = (PREC == 1 && dn.hi) ? as.next[0] : 1.f;  // f16s: the planes hold the pieces of v * (the dense head's input scale)
+  // f16s: planes / split rows hold the pieces of v * (the consumer's scale)
+  const float s_next = (PREC == 1 && (dn.hi || out_s)) ? as.next[0] : 1.f;
   for (int j = wave; j < NB; j += NW) {
     const int col = j * 16 + r;
     // (f16s: the power-of-two factor that undoes the operand scales rides in the BatchNorm scale: exact)
@@ -685,7 +734,8 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
         if (scale || PREC == 1) v = v * sc + sh;
         if (relu) v = fmaxf(v, 0.f);
         if constexpr (PREC == 1) vmax = fmaxf(vmax, fabsf(v));
-        out[(size_t)row * COUT + col] = v;
+        if (out) out[(size_t)row * COUT + col] = v;
+        if (out_s) sp_store_split<PREC, COUT>(out_s, row, col, r, v, s_next);
         if (dn.hi) {  // .dense() of the last layer: the row straight into the split BEV planes (see V3dDensifyOut)
           const int4 c = reinterpret_cast<const int4*>(dn.coords)[row];
           const int pixel = (c.x * dn.H + c.z) * dn.W + c.w;
@@ -712,13 +762,14 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
 // L2 -> CU weight stream (3 500 workgroups x 442 KB = 1.5 GB per launch at 56 k rows ~ the 34 TB/s of the L2s); here
 // that stream is 4x smaller and the kernel runs into the MFMA issue rate of the 4-term split instead.  Below that
 // size the 4x longer dependent chain per wave (27 instead of 7 offsets) loses: launch_rows picks by capacity.
-template <int CIN, int COUT, int PREC>
+template <int CIN, int COUT, int PREC, int INS>
 __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __restrict__ in,
                                                                  const unsigned short* __restrict__ wimg,
                                                                  const int* __restrict__ nbr, const int* __restrict__ n_ptr,
                                                                  int cap, int K, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, int relu,
-                                                                 float* __restrict__ out, const V3dActScale as) {
+                                                                 float* __restrict__ out, const V3dActScale as,
+                                                                 unsigned short* __restrict__ out_s) {
   constexpr int KI = (CIN + 31) / 32, NB = COUT / 16;
   constexpr int NF = KI * NB * 2;          // 16-byte weight fragments per offset per lane
   constexpr int WBYTES = NF * 64 * 16;     // one W[k] image
@@ -756,8 +807,8 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __
     for (int ki = 0; ki < KI; ki++) {
       const int c0 = ki * 32 + kg * 8;
       if (src >= 0 && c0 < CIN) {
-        const float* p = in + (size_t)src * CIN + c0;
-        const float4 v0 = reinterpret_cast<const float4*>(p)[0], v1 = reinterpret_cast<const float4*>(p)[1];
+        const char* p = reinterpret_cast<const char*>(in) + (size_t)src * CIN * 4 + (INS ? c0 * 2 : c0 * 4);
+        const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + (INS ? CIN * 2 : 16));
         a[ki][0] = v0.x; a[ki][1] = v0.y; a[ki][2] = v0.z; a[ki][3] = v0.w;
         a[ki][4] = v1.x; a[ki][5] = v1.y; a[ki][6] = v1.z; a[ki][7] = v1.w;
       } else {
@@ -774,7 +825,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __
 #pragma unroll
     for (int ki = 0; ki < KI; ki++) {
       u32x4_t ah, al;
-      split_act<PREC>(a[ki], ss.s_in, ah, al);
+      split_in<PREC, INS>(a[ki], ss.s_in, ah, al);
 #pragma unroll
       for (int j = 0; j < NB; j++) {
         const u32x4_t bh = bw[(size_t)((ki * NB + j) * 2) * 64], bl = bw[(size_t)((ki * NB + j) * 2 + 1) * 64];
@@ -809,6 +860,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __
   }
   // epilogue straight from the accumulators: D[row = kg*4 + rr][col = j*16 + r] of this wave's tile
   float vmax = 0.f;
+  const float s_next = (PREC == 1 && out_s) ? as.next[0] : 1.f;
 #pragma unroll
   for (int j = 0; j < NB; j++) {
     const int col = j * 16 + r;
@@ -821,7 +873,8 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows_big(const float* __
         if (scale || PREC == 1) v = v * sc + sh;
         if (relu) v = fmaxf(v, 0.f);
         if constexpr (PREC == 1) vmax = fmaxf(vmax, fabsf(v));
-        out[(size_t)row * COUT + col] = v;
+        if (out) out[(size_t)row * COUT + col] = v;
+        if (out_s) sp_store_split<PREC, COUT>(out_s, row, col, r, v, s_next);
       }
     }
   }
@@ -887,13 +940,13 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigne
 // enough: the fragments of offset k are in registers before the requests of k + 1 overwrite the slot piece by piece, each piece
 // behind the MFMA group that consumed it.
 // The pass of T tiles per wave as a device function: the kernel below picks T per LAUNCH from the live row count (device-side).
-template <int CIN, int COUT, int T, int K, int STAGE, int PREC>
+template <int CIN, int COUT, int T, int K, int STAGE, int PREC, int INS>
 __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in, const unsigned short* __restrict__ wimg,
                                                    const int* __restrict__ nbr, const int n, int cap, const float* __restrict__ scale,
                                                    const float* __restrict__ shift, int relu, float* __restrict__ out,
                                                    unsigned char* wbuf0 /*LDS: 2 x one W[k] image*/,
                                                    unsigned char* aslot /*LDS: [wave][tile][piece][16 rows][64 B]*/,
-                                                   const V3dActScale& as) {
+                                                   const V3dActScale& as, unsigned short* __restrict__ out_s) {
   static_assert(CIN % 32 == 0 && CIN <= 64 && T >= 1 && T <= 3, "shape not covered by the offset-outer kernel");
   constexpr int KI = CIN / 32, NB = COUT / 16, NW = 8;
   constexpr int NF = KI * NB * 2;                 // 1 KB weight fragments per offset
@@ -907,6 +960,7 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
   const int rows_per_pass = 16 * T * NW;
   const int npass = (n + rows_per_pass - 1) / rows_per_pass;
   const SpScales ss = sp_scales<PREC>(as, wimg, (size_t)K * NF * 512);
+  const float s_next = (PREC == 1 && out_s) ? as.next[0] : 1.f;
   float vmax = 0.f;
 
   f32x4 wreg[WPT];
@@ -942,7 +996,7 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
       for (int t = 0; t < T; t++) {
         int sq = (k < K && row0 + t * 16 + (STAGE ? (lane >> 2) : r) < n) ? sidx[t] : -1;
         prow[t] = (sq >= 0 ? in + (size_t)sq * CIN : spr_zero_row) +
-                  (STAGE ? ((lane & 3) ^ ((lane >> 5) & 1)) * 4 : kg * 8);
+                  (STAGE ? ((lane & 3) ^ ((lane >> 5) & 1)) * 4 : (INS ? kg * 4 : kg * 8));  // (split rows: 16-byte hi fragment kg)
       }
     };
     const unsigned slot0 = STAGE ? __builtin_amdgcn_readfirstlane(lds_addr_of(aslot) + wave * (T * CIN * 64)) : 0u;
@@ -950,6 +1004,15 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
       if constexpr (STAGE) {
         asm_dma16(prow[t] + (ki * 2) * 16, slot0 + t * (CIN * 64) + (ki * 2) * 1024);
         asm_dma16(prow[t] + (ki * 2 + 1) * 16, slot0 + t * (CIN * 64) + (ki * 2 + 1) * 1024);
+      } else if constexpr (INS) {  // split rows: hi fragment at 64 ki (+ 16 kg, in prow), lo fragment 2 CIN bytes further
+        if (ki == 0) {
+          asm_gld16(a[t * KI * 2], prow[t]);
+          if constexpr (CIN == 64) asm_gld16_128(a[t * KI * 2 + 1], prow[t]);
+          else asm_gld16_64(a[t * KI * 2 + 1], prow[t]);
+        } else {
+          asm_gld16_64(a[t * KI * 2 + 2], prow[t]);
+          asm_gld16_192(a[t * KI * 2 + 3], prow[t]);
+        }
       } else if (ki == 0) {
         asm_gld16(a[t * KI * 2], prow[t]);
         asm_gld16_16(a[t * KI * 2 + 1], prow[t]);
@@ -976,8 +1039,10 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
       vm_wait_tie<T + WPT>(src[cur ^ 1]);
       row_ptrs(k + 1, src[cur ^ 1]);
       if constexpr (STAGE) {  // this wave's slots hold the rows of k: fragments into registers
-        const unsigned char* sl = aslot + wave * (T * CIN * 64) + ((kg >> 1) * 1024 + r * 64);
         const int sw = (r >> 3) & 1;
+        // (position q of a row's 64-byte piece holds source chunk q ^ sw: the DMA lane mapping above.  fp32 rows: the lane's 8
+        //  floats are chunks 2 (kg & 1) + v of piece 2 ki + (kg >> 1); split rows: hi = chunk kg of piece ki, lo = of piece KI + ki)
+        const unsigned char* sl = aslot + wave * (T * CIN * 64) + (INS ? r * 64 + ((kg ^ sw) * 16) : (kg >> 1) * 1024 + r * 64);
 #pragma unroll
         for (int t = 0; t < T; t++)
 #pragma unroll
@@ -985,7 +1050,8 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
 #pragma unroll
             for (int v = 0; v < 2; v++)
               araw[0][(t * KI + ki) * 2 + v] =
-                  *reinterpret_cast<const f32x4*>(sl + t * (CIN * 64) + ki * 2048 + ((((kg & 1) * 2 + v) ^ sw) * 16));
+                  INS ? *reinterpret_cast<const f32x4*>(sl + t * (CIN * 64) + (v * KI + ki) * 1024)
+                      : *reinterpret_cast<const f32x4*>(sl + t * (CIN * 64) + ki * 2048 + ((((kg & 1) * 2 + v) ^ sw) * 16));
       }
       const u32x4_t* bw = reinterpret_cast<const u32x4_t*>(wbuf0 + cur * WBYTES) + lane;
       u32x4_t bh[KI][NB], bl[KI][NB];
@@ -1003,7 +1069,7 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
           const f32x4 v0 = araw[STAGE ? 0 : cur][(t * KI + ki) * 2], v1 = araw[STAGE ? 0 : cur][(t * KI + ki) * 2 + 1];
           const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
           u32x4_t ah, al;
-          split_act<PREC>(x, ss.s_in, ah, al);
+          split_in<PREC, INS>(x, ss.s_in, ah, al);
 #pragma unroll
           for (int j = 0; j < NB; j++) acc[t][j] = sp_mfma<PREC>(al, bh[ki][j], acc[t][j]);  // smallest terms first
 #pragma unroll
@@ -1055,7 +1121,8 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
             if (scale || PREC == 1) vv = vv * sc + sh;
             if (relu) vv = fmaxf(vv, 0.f);
             if constexpr (PREC == 1) vmax = fmaxf(vmax, fabsf(vv));
-            out[(size_t)row * COUT + col] = vv;
+            if (out) out[(size_t)row * COUT + col] = vv;
+            if (out_s) sp_store_split<PREC, COUT>(out_s, row, col, r, vv, s_next);
           }
         }
       }
@@ -1068,24 +1135,25 @@ __device__ __forceinline__ void spconv_kouter_body(const float* __restrict__ in,
 // round of 256 workgroups; beyond, 256-row passes would need a second, nearly empty round (49 -> 91 us in the frame, round 4
 // trace) -- three tiles per wave keep up to 98 304 rows in one round.  Both bodies live in the one kernel (registers and LDS of the
 // larger); every wave of the grid reads the same count, so the choice is uniform.
-template <int CIN, int COUT, int TMAX, int K, int STAGE, int PREC>
+template <int CIN, int COUT, int TMAX, int K, int STAGE, int PREC, int INS>
 __global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __restrict__ in,
                                                               const unsigned short* __restrict__ wimg,
                                                               const int* __restrict__ nbr, const int* __restrict__ n_ptr,
                                                               int cap, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, int relu,
-                                                              float* __restrict__ out, const V3dActScale as) {
+                                                              float* __restrict__ out, const V3dActScale as,
+                                                              unsigned short* __restrict__ out_s) {
   constexpr int WBYTES = (CIN / 32) * (COUT / 16) * 2 * 1024;
   __shared__ __attribute__((aligned(16))) unsigned char wbuf[2 * WBYTES];
   __shared__ __attribute__((aligned(16))) unsigned char aslot[STAGE ? 8 * TMAX * CIN * 64 : 16];
   const int n = min(*n_ptr, cap);
   if constexpr (TMAX == 3) {
     if (n > 2 * 128 * 256)
-      spconv_kouter_body<CIN, COUT, 3, K, STAGE, PREC>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot, as);
+      spconv_kouter_body<CIN, COUT, 3, K, STAGE, PREC, INS>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot, as, out_s);
     else
-      spconv_kouter_body<CIN, COUT, 2, K, STAGE, PREC>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot, as);
+      spconv_kouter_body<CIN, COUT, 2, K, STAGE, PREC, INS>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot, as, out_s);
   } else {
-    spconv_kouter_body<CIN, COUT, TMAX, K, STAGE, PREC>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot, as);
+    spconv_kouter_body<CIN, COUT, TMAX, K, STAGE, PREC, INS>(in, wimg, nbr, n, cap, scale, shift, relu, out, wbuf, aslot, as, out_s);
   }
 }
 
@@ -1118,11 +1186,11 @@ __global__ __launch_bounds__(512) void spconv_fwd_rows_kouter(const float* __res
 // does not grow) and put up to 16 waves on the CU, whose matrix pipes idle half of a two-tile round: the caller picks the smallest
 // TILES that keeps the expected row count inside ONE round.
 // (the body of one workgroup's TILES tiles; the kernel behind it loops over the live tile groups)
-template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK, int STAGE, int TILES, int PREC>
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK, int STAGE, int TILES, int PREC, int INS>
 __device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, const unsigned short* __restrict__ wimg,
                                                  const int* __restrict__ nbr, const int n, int cap, const float* __restrict__ scale,
                                                  const float* __restrict__ shift, int relu, float* __restrict__ out, const int wg_in,
-                                                 const SpScales& ss, float& vmax) {
+                                                 const SpScales& ss, float& vmax, unsigned short* __restrict__ out_s, const float s_next) {
   // OG = offsets per round = multiplying waves per tile.  OG = 3: 9 rounds, 3 round buffers, 6 + 2 waves.
   // OG = 2: 14 rounds (the 28th offset is a zero row), 4 round buffers (three rounds of weights in flight), 4 + 2
   // waves -- one multiplying wave per SIMD.  Measured slower (64->64 at 8 160 rows: 12.3 vs 13.0 us): the cost of a round
@@ -1210,7 +1278,7 @@ __device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, c
   const float* prow = spr_zero_row;  // this lane's slice of the row being requested
   auto row_ptr = [&](int src_i) {
     const int src = src_i;
-    prow = (src >= 0 ? in + (size_t)src * CIN : spr_zero_row) + (STAGE ? ((lane & 3) ^ ((lane >> 5) & 1)) * 4 : kg * 8);
+    prow = (src >= 0 ? in + (size_t)src * CIN : spr_zero_row) + (STAGE ? ((lane & 3) ^ ((lane >> 5) & 1)) * 4 : (INS ? kg * 4 : kg * 8));
   };
   const unsigned slot0 = STAGE ? __builtin_amdgcn_readfirstlane(lds_addr_of(aslot) + wv * (ALOOK * CIN * 64)) : 0u;
   auto issue_chunk = [&](int ki, int Rr) {  // the two requests of channel block ki for round Rr
@@ -1219,7 +1287,16 @@ __device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, c
       asm_dma16(prow + (ki * 2 + 1) * 16, slot0 + (Rr % ALOOK) * (CIN * 64) + (ki * 2 + 1) * 1024);
     } else {
       f32x4 (&a)[KI * 2] = araw[Rr % ABUF];
-      if (ki == 0) {
+      if constexpr (INS) {  // split rows: hi fragment at 64 ki (+ 16 kg, in prow), lo fragment 2 CIN bytes further
+        if (ki == 0) {
+          asm_gld16(a[0], prow);
+          if constexpr (CIN == 64) asm_gld16_128(a[1], prow);
+          else asm_gld16_64(a[1], prow);
+        } else if constexpr (KI == 2) {
+          asm_gld16_64(a[2], prow);
+          asm_gld16_192(a[3], prow);
+        }
+      } else if (ki == 0) {
         asm_gld16(a[0], prow);
         asm_gld16_16(a[1], prow);
       } else if constexpr (KI == 2) {
@@ -1273,13 +1350,14 @@ __device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, c
         else if (younger == 8) vm_wait<8>();
         else vm_wait<12>();
         // this wave's slot holds the rows of round R: fragments into registers
-        const unsigned char* sl = aslot + (wv * ALOOK + R % ALOOK) * (CIN * 64) + ((kg >> 1) * 1024 + r * 64);
         const int sw = (r >> 3) & 1;
+        const unsigned char* sl = aslot + (wv * ALOOK + R % ALOOK) * (CIN * 64) + (INS ? r * 64 + ((kg ^ sw) * 16) : (kg >> 1) * 1024 + r * 64);
 #pragma unroll
         for (int ki = 0; ki < KI; ki++)
 #pragma unroll
-          for (int v = 0; v < 2; v++)
-            araw[0][ki * 2 + v] = *reinterpret_cast<const f32x4*>(sl + ki * 2048 + ((((kg & 1) * 2 + v) ^ sw) * 16));
+          for (int v = 0; v < 2; v++)  // (split rows: hi = chunk kg of piece ki, lo = of piece KI + ki; see spconv_kouter_body)
+            araw[0][ki * 2 + v] = INS ? *reinterpret_cast<const f32x4*>(sl + (v * KI + ki) * 1024)
+                                      : *reinterpret_cast<const f32x4*>(sl + ki * 2048 + ((((kg & 1) * 2 + v) ^ sw) * 16));
       } else {
         f32x4 (&ar)[KI * 2] = araw[R % ABUF];
         if (younger == 0) vm_wait_tie<0>(ar);
@@ -1304,7 +1382,7 @@ __device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, c
     for (int ki = 0; ki < KI; ki++) {
       const f32x4 v0 = araw[STAGE ? 0 : R % ABUF][ki * 2], v1 = araw[STAGE ? 0 : R % ABUF][ki * 2 + 1];
       const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      split_act<PREC>(x, ss.s_in, ah[ki], al[ki]);
+      split_in<PREC, INS>(x, ss.s_in, ah[ki], al[ki]);
     }
 #pragma unroll
     for (int ki = 0; ki < KI; ki++) {
@@ -1347,7 +1425,8 @@ __device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, c
       else if constexpr (PREC == 1) v = v * ss.undo;
       if (relu) v = fmaxf(v, 0.f);
       if constexpr (PREC == 1) vmax = fmaxf(vmax, fabsf(v));
-      out[(size_t)row * COUT + col] = v;
+      if (out) out[(size_t)row * COUT + col] = v;
+      if (out_s) sp_store_split<PREC, COUT>(out_s, row, col, r, v, s_next);
     }
   }
   SPR_STAMP(14);
@@ -1359,29 +1438,41 @@ __device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, c
 // workgroups for a 32 k-row capacity, ~255 of them live) the dead tail cannot be PLACED until a live workgroup retires -- the
 // dispatcher sits on this kernel for its whole duration and, with several frames in flight, no other frame's kernel starts beside
 // it (round-4 overlap trace: the ring kernels ran alone 99.8 % of their time, the dense tile kernel 69 %).
-template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK, int STAGE, int TILES, int PREC>
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK, int STAGE, int TILES, int PREC, int INS>
 __global__ __launch_bounds__((TILES * OG + NMV) * 64) void spconv_fwd_rows_ring(const float* __restrict__ in,
                                                                           const unsigned short* __restrict__ wimg,
                                                                           const int* __restrict__ nbr,
                                                                           const int* __restrict__ n_ptr, int cap,
                                                                           const float* __restrict__ scale,
                                                                           const float* __restrict__ shift, int relu,
-                                                                          float* __restrict__ out, const V3dActScale as) {
+                                                                          float* __restrict__ out, const V3dActScale as,
+                                                                          unsigned short* __restrict__ out_s) {
   const int n = min(*n_ptr, cap);
   const int nwg = (n + 16 * TILES - 1) / (16 * TILES);
   const SpScales ss = sp_scales<PREC>(as, wimg, (size_t)27 * (CIN / 32) * (COUT / 16) * 2 * 512);
+  const float s_next = (PREC == 1 && out_s) ? as.next[0] : 1.f;
   float vmax = 0.f;
   // (the XCD-contiguous remap inside the body is a bijection of [0, nwg) for ANY set of indices below nwg)
   for (int g = blockIdx.x; g < nwg; g += gridDim.x) {
-    spconv_ring_body<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, PREC>(in, wimg, nbr, n, cap, scale, shift, relu, out, g, ss, vmax);
+    spconv_ring_body<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, PREC, INS>(in, wimg, nbr, n, cap, scale, shift, relu, out, g, ss, vmax,
+                                                                              out_s, s_next);
     __syncthreads();  // the next group's weight DMA and partial sums reuse this group's LDS
   }
   if constexpr (PREC == 1) sp_range_check(as, vmax, ss.limit);
 }
 
-template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK, int STAGE, int TILES, int PREC>
+// how a launch is parameterised beyond the layer itself: arithmetic, its scale entries, and the split-row copies (INS: the gathered
+// rows are `in_split`; out_split: also write the output rows split for the next packed layer)
+struct SpLaunch {
+  int prec;
+  V3dActScale as;
+  const void* in_split;
+  unsigned short* out_split;
+};
+
+template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK, int STAGE, int TILES, int PREC, int INS>
 static int launch_rows_ring_p(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
-                              const float* scale, const float* shift, int relu, float* out, hipStream_t st, const V3dActScale& as) {
+                              const float* scale, const float* shift, int relu, float* out, hipStream_t st, const SpLaunch& sl) {
   // grid: never more workgroups than the chip can hold AT ONCE (occupancy of this instantiation x CUs, a multiple of 8 for the XCD
   // map) -- every workgroup is placed the moment the kernel is dispatched -- and never more than the capacity needs
   static V3dPerDeviceInt cache;
@@ -1390,40 +1481,44 @@ static int launch_rows_ring_p(const float* in, const void* wimg, const int* nbr,
     int dev = 0, n_cu = 0, per_cu = 0;
     V3D_CHECK_HIP(hipGetDevice(&dev));
     V3D_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    V3D_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, PREC>,
+    V3D_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, PREC, INS>,
                                                                (TILES * OG + NMV) * 64, 0));
     *slots = std::max(8, per_cu * n_cu / 8 * 8);
   }
   const int grid = std::min(v3d_ceil_div(cap, 16 * TILES), *slots);
-  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, PREC>), dim3(grid),
-                     dim3((TILES * OG + NMV) * 64), 0, st, in, (const unsigned short*)wimg, nbr, n_ptr, cap, scale, shift, relu, out, as);
+  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, PREC, INS>), dim3(grid),
+                     dim3((TILES * OG + NMV) * 64), 0, st, INS ? (const float*)sl.in_split : in, (const unsigned short*)wimg, nbr, n_ptr, cap,
+                     scale, shift, relu, out, sl.as, sl.out_split);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
 template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK = 2, int STAGE = 0, int TILES = 2>
 static int launch_rows_ring(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
-                            const float* scale, const float* shift, int relu, float* out, hipStream_t st, int prec, const V3dActScale& as) {
-  if (prec == V3D_PREC_F16S)
-    return launch_rows_ring_p<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, as);
-  return launch_rows_ring_p<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, 0>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, as);
+                            const float* scale, const float* shift, int relu, float* out, hipStream_t st, const SpLaunch& sl) {
+#define V3D_RING(P, I) launch_rows_ring_p<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, P, I>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, sl)
+  if (sl.prec == V3D_PREC_F16S) return sl.in_split ? V3D_RING(1, 1) : V3D_RING(1, 0);
+  return sl.in_split ? V3D_RING(0, 1) : V3D_RING(0, 0);
+#undef V3D_RING
 }
 
-template <int CIN, int COUT, int PREC>
+template <int CIN, int COUT, int PREC, int INS>
 static void launch_rows_big(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
-                            const float* scale, const float* shift, int relu, float* out, hipStream_t st, const V3dActScale& as) {
+                            const float* scale, const float* shift, int relu, float* out, hipStream_t st, const SpLaunch& sl) {
   constexpr int NF = ((CIN + 31) / 32) * (COUT / 16) * 2;
   const size_t lds = (size_t)2 * NF * 64 * 16 + (size_t)K * 64 * 4;
-  hipLaunchKernelGGL((spconv_fwd_rows_big<CIN, COUT, PREC>), dim3(v3d_ceil_div(cap, 64)), dim3(V3D_BLOCK), lds, st, in,
-                       (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, as);
+  hipLaunchKernelGGL((spconv_fwd_rows_big<CIN, COUT, PREC, INS>), dim3(v3d_ceil_div(cap, 64)), dim3(V3D_BLOCK), lds, st,
+                     INS ? (const float*)sl.in_split : in, (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, sl.as,
+                     sl.out_split);
 }
 
-template <int CIN, int COUT, int T, int STAGE, int PREC>
+template <int CIN, int COUT, int T, int STAGE, int PREC, int INS>
 static void launch_rows_kouter(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
-                               const float* scale, const float* shift, int relu, float* out, hipStream_t st, const V3dActScale& as) {
+                               const float* scale, const float* shift, int relu, float* out, hipStream_t st, const SpLaunch& sl) {
   const int passes = v3d_ceil_div(cap, 16 * (T == 3 ? 2 : T) * 8);  // (T = 3: the kernel may walk 256-row passes)
   const int grid = passes >= 256 ? 256 : ((passes + 7) / 8) * 8;  // a multiple of 8: the pass -> XCD map assumes it
-  hipLaunchKernelGGL((spconv_fwd_rows_kouter<CIN, COUT, T, 27, STAGE, PREC>), dim3(grid), dim3(512), 0, st, in, (const unsigned short*)wimg,
-                     nbr, n_ptr, cap, scale, shift, relu, out, as);
+  hipLaunchKernelGGL((spconv_fwd_rows_kouter<CIN, COUT, T, 27, STAGE, PREC, INS>), dim3(grid), dim3(512), 0, st,
+                     INS ? (const float*)sl.in_split : in, (const unsigned short*)wimg, nbr, n_ptr, cap, scale, shift, relu, out, sl.as,
+                     sl.out_split);
 }
 
 // rows_hint > 0: expected number of LIVE rows (the live count itself is device-side): the caller's best knowledge -- the
@@ -1433,27 +1528,26 @@ static void launch_rows_kouter(const float* in, const void* wimg, const int* nbr
 // for the shape, -16 its register-gather form (each where the shape has it, else the 16-row kernel).
 #define V3D_BIG_ROWS 32768
 #define V3D_RING_ROWS 16384  // two full rounds of 32-row workgroups on 256 CUs; beyond, the 16-row kernel wins again (36 k rows: 47 vs 53 us)
-template <int CIN, int COUT, int PREC>
+template <int CIN, int COUT, int PREC, int INS>
 static int launch_rows(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap, int K,
                        const float* scale, const float* shift, int relu, float* out, int rows_hint, hipStream_t st,
-                       const V3dDensifyOut* densify, int tiles_min, const V3dActScale& as) {
-  constexpr int prec = PREC;
+                       const V3dDensifyOut* densify, int tiles_min, const SpLaunch& sl) {
   const int force = densify ? 1 : (rows_hint < 0 ? -rows_hint : 0);  // .dense() rides in the 16-row kernel's epilogue only
   if constexpr (CIN >= 32 && CIN <= 64 && COUT >= 32 && COUT <= 64) {
     // the offset-outer persistent kernel (3x3x3 only; 6: rows staged through LDS, 7: rows gathered into registers): 64->64 at
     // 56 k rows 58 -> 47.5 us.  It needs a full round of 256-row passes to pay: the 32-channel shapes and the mid sizes stay on
     // the kernels below (32->32 at 81 k rows: 316 passes on 256 workgroups = 2 rounds, 43 vs 30 us)
     if (K == 27 && (force == 6 || force == 7 || force == 8 || (force == 0 && CIN == 64 && COUT == 64 && rows_hint >= V3D_BIG_ROWS))) {
-      if (force == 7) launch_rows_kouter<CIN, COUT, 2, 0, PREC>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, as);
-      else if (force == 8) launch_rows_kouter<CIN, COUT, 2, 1, PREC>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, as);  // 256-row passes only
-      else launch_rows_kouter<CIN, COUT, 3, 1, PREC>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, as);  // 256 / 384-row passes by live count
+      if (force == 7) launch_rows_kouter<CIN, COUT, 2, 0, PREC, INS>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, sl);
+      else if (force == 8) launch_rows_kouter<CIN, COUT, 2, 1, PREC, INS>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, sl);  // 256-row passes only
+      else launch_rows_kouter<CIN, COUT, 3, 1, PREC, INS>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, sl);  // 256 / 384-row passes by live count
       V3D_CHECK_LAUNCH();
       return V3D_OK;
     }
     // the 64-row LDS-shared-weights kernel: from ~32 k live rows on the 16-row kernel is bound by the L2 -> CU weight
     // stream (64->64 at 36 k rows 54 vs 53 us, at 56 k 82 vs 66 us, at 81 k 110 vs 85 us)
     if (force == 5 || (force == 0 && rows_hint >= V3D_BIG_ROWS)) {
-      launch_rows_big<CIN, COUT, PREC>(in, wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, st, as);
+      launch_rows_big<CIN, COUT, PREC, INS>(in, wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, st, sl);
       V3D_CHECK_LAUNCH();
       return V3D_OK;
     }
@@ -1476,18 +1570,19 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
           // another frame's kernels use (same box: 3 820 -> 3 875 / 3 970 frames/s pipelined, 0.451 -> 0.462 ms one frame at a time)
           int tiles = force == 12 ? 2 : force == 13 ? 3 : force == 14 ? 4 : (want <= 32 * 256 ? 2 : want <= 48 * 256 ? 3 : 4);
           if (!force && tiles < tiles_min) tiles = tiles_min > 4 ? 4 : tiles_min;
-          if (tiles == 2) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, prec, as);
-          if (tiles == 3) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, prec, as);
-          return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 4>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, prec, as);
+          if (tiles == 2) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, sl);
+          if (tiles == 3) return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 3>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, sl);
+          return launch_rows_ring<CIN, COUT, 3, 2, 4, 1, 1, 4>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, sl);
         }
       }
-      if (force != 16 && CIN == 32 && COUT == 32) return launch_rows_ring<CIN, COUT, 3, 2, 2, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, prec, as);
-      return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, prec, as);
+      if (force != 16 && CIN == 32 && COUT == 32) return launch_rows_ring<CIN, COUT, 3, 2, 2, 2, 1>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, sl);
+      return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, sl);
     }
   }
   const size_t lds = (size_t)4 * (COUT / 16) * 4 * 64 * 4 + (size_t)K * 16 * 4;
-  hipLaunchKernelGGL((spconv_fwd_rows<CIN, COUT, PREC>), dim3(v3d_ceil_div(cap, 16)), dim3(V3D_BLOCK), lds, st, in,
-                     (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out, densify ? *densify : V3dDensifyOut{}, as);
+  hipLaunchKernelGGL((spconv_fwd_rows<CIN, COUT, PREC, INS>), dim3(v3d_ceil_div(cap, 16)), dim3(V3D_BLOCK), lds, st,
+                     INS ? (const float*)sl.in_split : in, (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out,
+                     densify ? *densify : V3dDensifyOut{}, sl.as, sl.out_split);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -1512,19 +1607,29 @@ extern "C" int v3d_sparse_conv_fwd_packed2(const float* in, const void* weight_i
 int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                  int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
                                  float* out, int rows_hint, hipStream_t st, const V3dDensifyOut* densify, int ring_tiles_min,
-                                 int prec, const V3dActScale* act) {
-  if (!in || !weight_image || !nbr || !n_out || !out || cap_out < 1 || K < 1) return V3D_EINVAL;
+                                 int prec, const V3dActScale* act, const void* in_split, void* out_split) {
+  if (!in || !weight_image || !nbr || !n_out || (!out && !out_split) || cap_out < 1 || K < 1) return V3D_EINVAL;  // (out may be NULL
+  // when only the split copy of the rows is wanted: a plan in throughput mode, whose intermediate fp32 rows nobody reads)
   if ((scale == nullptr) != (shift == nullptr)) return V3D_EINVAL;
+  if (!out && densify) return V3D_EINVAL;
   if (prec != V3D_PREC_BF16X3 && prec != V3D_PREC_F16S) return V3D_EINVAL;
-  if (prec == V3D_PREC_F16S && (!act || !act->in || (densify && !act->next))) return V3D_EINVAL;  // no scale, no f16s
-  const V3dActScale as = (prec == V3D_PREC_F16S) ? *act : V3dActScale{nullptr, nullptr, nullptr, nullptr};
-#define V3D_TRY(ci, co)                                                                                                        \
-  if (Cin == ci && Cout == co) {                                                                                               \
-    if (prec == V3D_PREC_F16S)                                                                                                 \
-      return launch_rows<ci, co, 1>(in, weight_image, nbr, n_out, cap_out, K, scale, shift, relu, out, rows_hint, st, densify, \
-                                    ring_tiles_min, as);                                                                       \
-    return launch_rows<ci, co, 0>(in, weight_image, nbr, n_out, cap_out, K, scale, shift, relu, out, rows_hint, st, densify,   \
-                                  ring_tiles_min, as);                                                                         \
+  if (prec == V3D_PREC_F16S && (!act || !act->in || ((densify || out_split) && !act->next))) return V3D_EINVAL;  // no scale, no f16s
+  if (in_split && Cin % 8) return V3D_EINVAL;
+  SpLaunch sl;
+  sl.prec = prec;
+  sl.as = (prec == V3D_PREC_F16S) ? *act : V3dActScale{nullptr, nullptr, nullptr, nullptr};
+  sl.in_split = in_split;
+  sl.out_split = (unsigned short*)out_split;
+#define V3D_GO(ci, co, P, I) \
+  return launch_rows<ci, co, P, I>(in, weight_image, nbr, n_out, cap_out, K, scale, shift, relu, out, rows_hint, st, densify, ring_tiles_min, sl)
+#define V3D_TRY(ci, co)                                    \
+  if (Cin == ci && Cout == co) {                           \
+    if constexpr ((ci) % 8 == 0) {                         \
+      if (prec == V3D_PREC_F16S && in_split) V3D_GO(ci, co, 1, 1); \
+      if (prec == V3D_PREC_BF16X3 && in_split) V3D_GO(ci, co, 0, 1); \
+    }                                                      \
+    if (prec == V3D_PREC_F16S) V3D_GO(ci, co, 1, 0);       \
+    V3D_GO(ci, co, 0, 0);                                  \
   }
   V3D_TRY(4, 16)
   V3D_TRY(16, 16)
@@ -1538,6 +1643,7 @@ int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, cons
   V3D_TRY(64, 128)
   V3D_TRY(128, 128)
 #undef V3D_TRY
+#undef V3D_GO
   return V3D_EUNSUPPORTED;
 }
 

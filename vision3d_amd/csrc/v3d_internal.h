@@ -87,7 +87,12 @@ int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, cons
                                  int ring_tiles_min = 2 /*64 -> 64 ring kernel: at least this many 16-row tiles per workgroup
                                  (throughput mode of a plan: fewer, fatter workgroups = less CU-time per launch)*/,
                                  int prec = V3D_PREC_BF16X3 /*the arithmetic the image was packed for*/,
-                                 const V3dActScale* act = nullptr /*V3D_PREC_F16S: required*/);
+                                 const V3dActScale* act = nullptr /*V3D_PREC_F16S: required*/,
+                                 const void* in_split = nullptr /*the gathered rows ALREADY split into this arithmetic's pieces under
+                                 act->in (row = [hi: Cin x 16 bit | lo: Cin x 16 bit]): what an earlier call wrote through out_split;
+                                 the main loop then has no conversion work*/,
+                                 void* out_split = nullptr /*besides `out`: the output rows split under act->next (f16s) for the next
+                                 packed layer, (cap_out, 2 * Cout) 16-bit*/);
 
 // spconv.hip: v3d_sparse_conv_fwd (exact fp32 kernels) whose output is additionally checked against the limit of the f16s scale
 // entry of the tensor it produces (wave kernel only; both nullable)

@@ -38,6 +38,7 @@ class GraphedSecond(object):
         allocator pools and lets the backbone plan pick its kernels from the observed sparsity (BackbonePlan.tune;
         an all-zero buffer would tune for a one-voxel frame) -- then capture."""
         dev = self.static_points.device
+        self.model.share_calibration(self.plan)  # (f16s: a slot captured after a calibrated peer takes its scale entries)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():
@@ -104,6 +105,7 @@ class GraphedSecond(object):
             self.dense.recalibrate()
             with torch.no_grad():
                 self._body()  # eager: calibration passes of the plan, then of the dense head, on this frame
+            self.model.spread_calibration(self.plan)  # every plan of the model follows (device copies into the tables the graphs read)
             for g in (self,) + tuple(peers):
                 g.after_recalibration()
             self.graph.replay()

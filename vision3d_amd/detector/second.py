@@ -218,7 +218,9 @@ class Second(nn.Module):
         except RangeOverflow:
             plan_of().recalibrate()
             self.dense_plan().recalibrate()
-            return run()
+            out = run()
+            self.spread_calibration(plan_of())
+            return out
 
     # training: RPN + heads forward / backward on csrc/dense_train.hip (bf16 storage, fp32 accumulation) instead of torch / MIOpen.
     # The precision contract of those kernels is the one of `torch.autocast("cuda", torch.bfloat16)`, so they run
@@ -315,7 +317,25 @@ class Second(nn.Module):
             plans[key] = BackbonePlan(self.cnn, self.cfg, max_batch=max_batch, max_points=max_points, device=dev,
                                       growth=self.__dict__.get("plan_growth", 2.0), precision=self.precision)
         plans[key].set_precision(self.precision)
+        self.share_calibration(plans[key])
         return plans[key]
+
+    def share_calibration(self, plan):
+        """f16s: the plans of one model (the slots of a pipeline, different batch capacities) use ONE set of scale entries -- a plan
+        that has none yet takes them from a calibrated peer instead of calibrating on whatever frame it sees first, so every slot
+        computes the same bits for the same frame."""
+        if not plan.f16s or plan._calib == "done":
+            return
+        for other in self.__dict__.get("_plans", {}).values():
+            if other is not plan and other.f16s and other._calib == "done" and other.device == plan.device:
+                plan.copy_calibration(other)
+                return
+
+    def spread_calibration(self, plan):
+        """... and after `plan` was recalibrated (a frame left the range), its peers follow."""
+        for other in self.__dict__.get("_plans", {}).values():
+            if other is not plan and other.f16s and plan.f16s and other.device == plan.device:
+                other.copy_calibration(plan)
 
     def bev_from_points(self, clouds):
         """clouds: list of (N_b, C) float32 cuda tensors -> BEV map (B, 128, 200, 176); eval mode only."""

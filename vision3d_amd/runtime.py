@@ -5,6 +5,7 @@ libvision3d_hip.so: voxelizer + every sparse layer (BatchNorm folded, ReLU fused
 by ONE C call per forward with no host synchronisation.  Parameters are re-uploaded automatically when
 the module's tensors change (load_state_dict, optimizer step)."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -105,6 +106,8 @@ class BackbonePlan(object):
             L.check(L.lib().v3d_backbone_create(C.byref(c), descs, C.byref(self._handle)), "backbone_create")
         self.precision = None
         self.set_precision(precision)
+        if os.environ.get("V3D_PRESPLIT", "1") == "0":  # A/B measurements only (same results)
+            self.set_presplit(False)
         self.out_channels = self.layers[-1][0].out_channels
         shape = list(self.grid_shape)
         for conv, _, _ in self.layers:
@@ -138,6 +141,11 @@ class BackbonePlan(object):
     def f16s(self):
         return L.PRECISIONS[self.precision] == L.PREC_F16S
 
+    def set_presplit(self, on=True):
+        """Packed layers also write their rows split for the next packed layer (default on; off = every layer splits the fp32 rows it
+        gathers: A/B measurements).  Same results bit for bit."""
+        L.check(L.lib().v3d_backbone_set_presplit(self._handle, int(bool(on))), "backbone_set_presplit")
+
     def act_scales(self):
         """(n_layers + 1, 4) float32 device view {s, 1/s, limit, max}: entry l = the rows layer l gathers, the last = the BEV map."""
         ptr = L.lib().v3d_backbone_act_scales(self._handle)
@@ -157,6 +165,9 @@ class BackbonePlan(object):
         if self.f16s and other.f16s and len(other.layers) == len(self.layers):
             self.act_scales().copy_(other.act_scales())
             self._calib = other._calib
+            if other._calib == "done":
+                L.check(L.lib().v3d_backbone_set_calibrating(self._handle, 0), "backbone_set_calibrating")
+                self.calibration_generation = self.__dict__.get("calibration_generation", 0) + 1
 
     def _param_stamp(self):
         st = []
