@@ -97,6 +97,7 @@ def parse():
                     help="forward mode: point order of the synthetic sweeps -- shuffled (default: what the TRAINING dataset hands over, "
                          "kitti_dataset.py:154; the gathers of the sparse convolutions are then random) or scan (firing order: what "
                          "inference.py reads from a .bin file; neighbouring voxels are neighbouring rows)")
+    ap.add_argument("--watchdog", type=int, default=1500, help="seconds after which a run that has not finished dumps its stacks and exits 124 (0 = off)")
     ap.add_argument("--stream", type=int, default=8, help="different synthetic frames per rank the timed loop cycles through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch event timing pass (profiling runs)")
@@ -754,11 +755,30 @@ def run_cpu_baseline(model, cfg, anchors, make, args, workload="kitti"):
     return out
 
 
+def _arm_watchdog(limit_s):
+    """A run that stops making progress must end, not sit on the GPU box: a daemon thread dumps every Python stack and exits with
+    status 124 when the process is older than `limit_s` seconds (0 = off).  The default (1 500 s) is several times the longest mode."""
+    if limit_s <= 0:
+        return
+    import faulthandler
+    import threading
+
+    def bark():
+        sys.stderr.write(f"bench.py: no result after {limit_s} s -- dumping stacks and exiting\n")
+        faulthandler.dump_traceback(all_threads=True)
+        sys.stderr.flush()
+        os._exit(124)
+    t = threading.Timer(limit_s, bark)
+    t.daemon = True
+    t.start()
+
+
 def main():
     import faulthandler
     import signal
     faulthandler.register(signal.SIGUSR1, all_threads=True)  # `kill -USR1 <pid>` (or timeout -s USR1) dumps the Python stacks of a stuck run
     args = parse()
+    _arm_watchdog(args.watchdog)
     ensure_world(args)
     if args.mode == "train":
         return train_main(args)
