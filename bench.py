@@ -954,23 +954,39 @@ def main():
         REP, layers = 25, []
         side = torch.cuda.Stream()
         from vision3d_amd import _lib as L
-        from vision3d_amd.runtime import act_entry_from_tensor
-        for (features, weight, rb, scale, shift, relu, algo, packed) in captured:
+        from vision3d_amd.runtime import act_entry_from_tensor, rows_split
+        f16s = args.precision == "fp32"
+        n_packed = 0
+        last_packable = max(i for i, c in enumerate(captured) if c[0].shape[1] >= 16 and c[1].shape[-1] % 16 == 0)
+        for li, (features, weight, rb, scale, shift, relu, algo, packed) in enumerate(captured):
             cin_, cout_ = weight.shape[-2], weight.shape[-1]
             packable = features.shape[1] >= 16 and cout_ % 16 == 0
-            if packable:  # the layer's kernel ALONE, in the arithmetic of the run (f16s: the scale entry is computed once, outside
-                # the timed launches -- in the frame it is a calibrated table entry, not a launch)
+            if packable:
+                # The layer's kernel ALONE, in the arithmetic of the run and in the form the pipelined frames run it (a plan in
+                # throughput mode): from the second packed layer on the gathered rows are the producer's PRE-SPLIT copy, and a layer
+                # that feeds another packed layer writes its rows only in that form.  f16s scale entries are computed once, outside the
+                # timed launches (in the frame they are calibrated table entries, not launches).
                 packed = convmod.pack_sparse_weight(weight.reshape(-1, cin_, cout_).contiguous(), rb.nbr.shape[0], cin_, cout_, args.precision)
-                entry = act_entry_from_tensor(features) if args.precision == "fp32" else None
-                out_buf = torch.empty((rb.n, cout_), dtype=torch.float32, device=features.device)
+                entry = act_entry_from_tensor(features) if f16s else None
                 feat_c = features.contiguous()
+                out_buf = torch.empty((rb.n, cout_), dtype=torch.float32, device=features.device)
+                L.check(L.lib().v3d_sparse_conv_fwd_packed2(L.ptr(feat_c), L.ptr(packed), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap,
+                                                            rb.nbr.shape[0], cin_, cout_, L.ptr(scale), L.ptr(shift), int(bool(relu)),
+                                                            L.ptr(out_buf), int(rb.n), L.PRECISIONS[args.precision], L.ptr(entry),
+                                                            None, None, None, None, L.stream_ptr()), "sparse_conv_fwd_packed2")
+                in_s = rows_split(feat_c, args.precision, entry) if n_packed > 0 else None
+                feeds_packed = li != last_packable
+                out_s = torch.empty((rb.n, 2 * cout_), dtype=torch.int16, device=features.device) if feeds_packed else None
+                next_entry = act_entry_from_tensor(out_buf) if (f16s and feeds_packed) else None
+                n_packed += 1
 
                 def launch(feat_c=feat_c, packed=packed, rb=rb, scale=scale, shift=shift, relu=relu, out_buf=out_buf, entry=entry,
-                           cin_=cin_, cout_=cout_):
-                    L.check(L.lib().v3d_sparse_conv_fwd_packed2(L.ptr(feat_c), L.ptr(packed), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap,
-                                                                rb.nbr.shape[0], cin_, cout_, L.ptr(scale), L.ptr(shift), int(bool(relu)),
-                                                                L.ptr(out_buf), int(rb.n), L.PRECISIONS[args.precision], L.ptr(entry),
-                                                                None, None, L.stream_ptr()), "sparse_conv_fwd_packed2")
+                           cin_=cin_, cout_=cout_, in_s=in_s, out_s=out_s, next_entry=next_entry):
+                    L.check(L.lib().v3d_sparse_conv_fwd_packed2(None if in_s is not None else L.ptr(feat_c), L.ptr(packed), L.ptr(rb.nbr),
+                                                                L.ptr(rb.n_dev), rb.cap, rb.nbr.shape[0], cin_, cout_, L.ptr(scale),
+                                                                L.ptr(shift), int(bool(relu)), None if out_s is not None else L.ptr(out_buf),
+                                                                int(rb.n), L.PRECISIONS[args.precision], L.ptr(entry), L.ptr(next_entry),
+                                                                None, L.ptr(in_s), L.ptr(out_s), L.stream_ptr()), "sparse_conv_fwd_packed2")
             else:
                 def launch(features=features, weight=weight, rb=rb, scale=scale, shift=shift, relu=relu, algo=algo):
                     orig(features, weight, rb, scale, shift, relu, algo, None)

@@ -193,10 +193,17 @@ int v3d_act_scale_from_rows(const float* rows, const int32_t* n_rows, int cap, i
 int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
                                float* out, int rows_hint, v3d_stream_t stream);
+/* in_split / out_split (both nullable): rows ALREADY split into the arithmetic's 16-bit pieces -- a row = [hi: C x 16 bit |
+ * lo: C x 16 bit], the bytes of the fp32 row; f16s: pieces of x * s of the tensor's scale entry.  in_split (then `in` may be NULL):
+ * the layer gathers these and its main loop converts nothing; out_split (Cout % 8 == 0; f16s needs act_next; `out` may then be NULL):
+ * the output rows once more in that form, for the next layer's in_split.  A chain of layers this way computes the same bits as
+ * on fp32 rows (v3d_sparse_rows_split makes split rows from fp32 rows). */
 int v3d_sparse_conv_fwd_packed2(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                 int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
                                 float* out, int rows_hint, int prec, const float* act_in, const float* act_next,
-                                int32_t* range_flag, v3d_stream_t stream);
+                                int32_t* range_flag, const void* in_split, void* out_split, v3d_stream_t stream);
+int v3d_sparse_rows_split(const float* rows, const int32_t* n_rows, int cap, int C, int prec, const float* act_entry,
+                          void* out_split, v3d_stream_t stream);
 
 /* ---- T3 backward (spconv indice_conv backward; the reference trains through it at train.py:65).
  * Data gradient: dX[i] = sum_k dY[nbrT[k][i]] @ W[k]^T -- the forward entry points above on the TRANSPOSED

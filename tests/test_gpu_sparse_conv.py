@@ -263,3 +263,44 @@ def test_sparse_sequential_fuses_and_matches_unfused(oracle):
             ref = torch.relu(layer[1](raw.features))
         assert_features_close(fused.features.detach().cpu().numpy(), ref.cpu().numpy(), "fused vs unfused")
         np.testing.assert_array_equal(fused.indices.cpu().numpy(), raw.indices.cpu().numpy())
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("variant", [1, 5, 6, 7, 10, 16],
+                         ids=["16rows", "64rows_lds_weights", "offset_outer_staged", "offset_outer_regs", "lds_ring", "lds_ring_regs"])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 32), (64, 64)])
+def test_presplit_rows_every_kernel_variant(oracle, cin, cout, variant, precision):
+    """Rows that are ALREADY split into the arithmetic's 16-bit pieces (v3d_sparse_conv_fwd_packed2 in_split / out_split: what the
+    layers of a plan hand each other) through every kernel of the packed product: gathering the split copy gives the bits of
+    gathering the fp32 rows, and the split copy a layer writes is the split of the fp32 rows it writes -- ragged tail, fused affine +
+    ReLU, f16s scale entries from the tensors' own maxima."""
+    from vision3d_amd import _lib as L
+    from vision3d_amd.runtime import act_entry_from_tensor, rows_split
+    from vision3d_amd.spconv.conv import build_subm_rulebook, pack_sparse_weight
+    rng = np.random.default_rng(cin * 3 + cout + variant)
+    coords = kitti_coords(oracle, [5])[:5003]
+    feats = dev(rng.standard_normal((len(coords), cin)).astype(np.float32))
+    w = dev((rng.standard_normal((27, cin, cout)) / np.sqrt(cin * 9)).astype(np.float32))
+    sc, sh = dev(rng.uniform(0.5, 1.5, cout).astype(np.float32)), dev(rng.standard_normal(cout).astype(np.float32) * 0.1)
+    x = make_tensor(coords, feats.cpu().numpy(), [41, 1600, 1408], 1)
+    rb = build_subm_rulebook(x, [3, 3, 3])
+    f16s = precision == "fp32"
+    prec = L.PRECISIONS[precision]
+    img = pack_sparse_weight(w, 27, cin, cout, precision)
+    entry = act_entry_from_tensor(feats) if f16s else None
+
+    def run(in_rows, in_split, out, next_entry, out_split):
+        L.check(L.lib().v3d_sparse_conv_fwd_packed2(L.ptr(in_rows), L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, 27, cin, cout,
+                                                    L.ptr(sc), L.ptr(sh), 1, L.ptr(out), -variant, prec, L.ptr(entry), L.ptr(next_entry),
+                                                    None, L.ptr(in_split), L.ptr(out_split), L.stream_ptr()), "fwd_packed2")
+    ref = torch.empty((rb.n, cout), dtype=torch.float32, device="cuda")
+    run(feats, None, ref, None, None)
+    next_entry = act_entry_from_tensor(ref) if f16s else None
+    got = torch.empty_like(ref)
+    got_s = torch.zeros((rb.n, 2 * cout), dtype=torch.int16, device="cuda")
+    run(None, rows_split(feats, precision, entry), got, next_entry, got_s)     # split rows in, fp32 rows + split rows out
+    assert torch.equal(got, ref)
+    assert torch.equal(got_s, rows_split(ref, precision, next_entry))
+    only_s = torch.zeros_like(got_s)
+    run(feats, None, None, next_entry, only_s)                                 # fp32 rows in, split rows ONLY out
+    assert torch.equal(only_s, got_s)

@@ -44,7 +44,8 @@ _SIGNATURES = {
     "v3d_sparse_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "v3d_sparse_conv_fwd_packed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "v3d_sparse_conv_pack_weights2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
-    "v3d_sparse_conv_fwd_packed2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "v3d_sparse_conv_fwd_packed2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "v3d_sparse_rows_split": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "v3d_act_scale_from_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "v3d_rulebook_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "v3d_sparse_conv_bwd_weight_workspace": (_sz, [_i, _i, _i]),

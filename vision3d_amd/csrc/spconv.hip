@@ -1598,10 +1598,41 @@ extern "C" int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_im
 extern "C" int v3d_sparse_conv_fwd_packed2(const float* in, const void* weight_image, const int32_t* nbr,
                                            const int32_t* n_out, int cap_out, int K, int Cin, int Cout, const float* scale,
                                            const float* shift, int relu, float* out, int rows_hint, int prec,
-                                           const float* act_in, const float* act_next, int32_t* range_flag, v3d_stream_t stream) {
+                                           const float* act_in, const float* act_next, int32_t* range_flag,
+                                           const void* in_split, void* out_split, v3d_stream_t stream) {
   const V3dActScale as{act_in, act_next, range_flag, nullptr};
-  return v3d_i_sparse_conv_fwd_packed(in, weight_image, nbr, n_out, cap_out, K, Cin, Cout, scale, shift, relu, out, rows_hint,
-                                      (hipStream_t)stream, nullptr, 2, prec, &as);
+  return v3d_i_sparse_conv_fwd_packed(in ? in : (const float*)in_split, weight_image, nbr, n_out, cap_out, K, Cin, Cout, scale, shift,
+                                      relu, out, rows_hint, (hipStream_t)stream, nullptr, 2, prec, &as, in_split, out_split);
+}
+
+// fp32 rows -> split rows ([hi: C x 16 bit | lo: C x 16 bit] per row, the bytes of the fp32 row) in the pieces of `prec`, f16s: of
+// x * entry[0].  What a packed layer writes through out_split, as a launch of its own (callers that hold fp32 rows, tests).
+template <int PREC>
+__global__ __launch_bounds__(256) void rows_split_kernel(const float* __restrict__ rows, const int* __restrict__ n_ptr, int cap, int C,
+                                                         const float* __restrict__ entry, unsigned short* __restrict__ out) {
+  const long long total = (long long)(n_ptr ? min(*n_ptr, cap) : cap) * C;
+  const float s = PREC == 1 ? entry[0] : 1.f;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long row = t / C;
+    const int c = (int)(t - row * C);
+    unsigned short h, l;
+    split_one<PREC>(rows[t], s, h, l);
+    out[row * 2 * C + c] = h;
+    out[row * 2 * C + C + c] = l;
+  }
+}
+
+extern "C" int v3d_sparse_rows_split(const float* rows, const int32_t* n_rows, int cap, int C, int prec, const float* act_entry,
+                                     void* out_split, v3d_stream_t stream) {
+  if (!rows || !out_split || cap < 1 || C < 8 || C % 8) return V3D_EINVAL;
+  if (prec == V3D_PREC_F16S ? !act_entry : prec != V3D_PREC_BF16X3) return V3D_EINVAL;
+  const int blocks = (int)std::min<long long>(((long long)cap * C + 255) / 256, 4096);
+  if (prec == V3D_PREC_F16S)
+    hipLaunchKernelGGL(rows_split_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, n_rows, cap, C, act_entry, (unsigned short*)out_split);
+  else
+    hipLaunchKernelGGL(rows_split_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, n_rows, cap, C, nullptr, (unsigned short*)out_split);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
 }
 
 int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,

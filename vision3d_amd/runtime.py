@@ -611,6 +611,18 @@ def act_entry_from_tensor(x, headroom_bits=0):
     return entry
 
 
+def rows_split(rows, precision="fp32", entry=None):
+    """fp32 rows (n, C) -> the same rows split into the arithmetic's 16-bit pieces, (n, 2 C) int16 = [hi | lo] per row
+    (v3d_sparse_rows_split): what a packed sparse layer gathers through `in_split` (f16s: pieces of x * entry[0])."""
+    x = L.as_f32("rows_split", rows)
+    n, c = x.shape
+    out = torch.empty((n, 2 * c), dtype=torch.int16, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().v3d_sparse_rows_split(L.ptr(x), None, max(n, 1), c, L.PRECISIONS[precision], L.ptr(entry), L.ptr(out), L.stream_ptr()),
+                "sparse_rows_split")
+    return out
+
+
 def tag_planes(hi, entry, flag=None):
     """f16s planes know their scale: the (4,) device entry they were written under (and the frame's range-flag word) ride on the
     `hi` tensor object as attributes -- DenseHeadPlan.forward picks them up when the caller does not pass them."""

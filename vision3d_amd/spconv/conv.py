@@ -101,7 +101,7 @@ def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False
                         "act_scale_from_rows")
             L.check(L.lib().v3d_sparse_conv_fwd_packed2(L.ptr(feat), L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k,
                                                         cin, cout, L.ptr(sc), L.ptr(sh), int(bool(relu)), L.ptr(out),
-                                                        -int(variant) if variant else int(rb.n), prec, L.ptr(entry), None, None,
+                                                        -int(variant) if variant else int(rb.n), prec, L.ptr(entry), None, None, None, None,
                                                         L.stream_ptr()), "sparse_conv_fwd_packed")
         return out
     with torch.cuda.device(feat.device):
