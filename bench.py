@@ -157,6 +157,49 @@ def ensure_world(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def numa_cpus_of_gpu(device_index, sysfs="/sys"):
+    """CPUs of the NUMA node the GPU hangs off (sorted list), or None when the topology cannot be read: the device's PCI address
+    from torch -> /sys/bus/pci/devices/<bdf>/numa_node -> /sys/devices/system/node/node<N>/cpulist."""
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(os.path.join(sysfs, "bus/pci/devices", bdf, "numa_node")).read().strip())
+        if node < 0:
+            return None
+        return parse_cpulist(open(os.path.join(sysfs, "devices/system/node", f"node{node}", "cpulist")).read())
+    except Exception:
+        return None
+
+
+def parse_cpulist(text):
+    """'0-15,128-143' -> [0, ..., 15, 128, ..., 143]"""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return sorted(set(cpus))
+
+
+def pin_rank_to_gpu_numa(local_rank, world):
+    """One process per GPU: the frame is ~37 launches of ~10 us driven by ONE host thread, so where that thread runs matters once
+    eight ranks share the host -- each rank is pinned to the cores of its GPU's NUMA node (its share of them when several local
+    ranks hang off one node).  Multi-rank jobs only (V3D_BENCH_PIN=1 / 0 forces it on / off); returns what was done for the line."""
+    want = os.environ.get("V3D_BENCH_PIN")
+    if want == "0" or (want is None and world <= 1):
+        return None
+    cpus = numa_cpus_of_gpu(local_rank % max(torch.cuda.device_count(), 1))
+    if not cpus:
+        return dict(pinned=False, reason="GPU -> NUMA node not readable from sysfs")
+    try:
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0))) or cpus
+        os.sched_setaffinity(0, allowed)
+        return dict(pinned=True, cpus=len(allowed), first=allowed[0], last=allowed[-1])
+    except Exception as e:
+        return dict(pinned=False, reason=f"{type(e).__name__}: {str(e)[:80]}")
+
+
 def ranks_seen(world, expect=None):
     """An all-reduce of ones over the job: what the collective backend (RCCL) really spans.  `expect` (= --gpus): a job whose
     collective spans a different number of ranks fails here, before anything is timed."""
@@ -191,6 +234,7 @@ def train_main(args):
     import torch.distributed as dist
     rank, local, world = dist_util.env_world()
     torch.cuda.set_device(local % torch.cuda.device_count())
+    pin_rank_to_gpu_numa(local, world)
     dist_util.init_from_env(BACKEND)
     # (only matters with V3D_DENSE_TRAIN=torch, where the dense RPN / heads train through MIOpen: let it search its solvers during
     # the warm-up -- 811 -> 868 frames/s on the same box against the default heuristic pick; V3D_TRAIN_BENCHMARK=0 switches it off)
@@ -352,6 +396,7 @@ def pvrcnn_main(args):
     import torch.distributed as dist
     rank, local, world = dist_util.env_world()
     torch.cuda.set_device(local % torch.cuda.device_count())
+    pin_rank_to_gpu_numa(local, world)
     dist_util.init_from_env(BACKEND)
     cfg = second_car_cfg()
     torch.manual_seed(0)
@@ -471,6 +516,7 @@ def plumbing_main(args):
     import torch.distributed as dist
     rank, local, world = dist_util.env_world()
     torch.cuda.set_device(local % torch.cuda.device_count())
+    pin_rank_to_gpu_numa(local, world)
     dist_util.init_from_env(BACKEND)
     n_ranks_seen = ranks_seen(world, args.gpus)
     cfg = second_car_cfg()
@@ -790,6 +836,7 @@ def main():
     rank, local, world = dist_util.env_world()
     assert torch.cuda.is_available(), "bench.py needs a GPU (vision3d_amd has no CPU path)"
     torch.cuda.set_device(local % torch.cuda.device_count())
+    pinning = pin_rank_to_gpu_numa(local, world)
     dist_util.init_from_env(BACKEND)  # RCCL; used for the barrier and the max-reduce only (frames are independent)
     import torch.distributed as dist
 
@@ -1234,7 +1281,7 @@ def main():
                     config=dict(workload=wl,
                                 frames_per_gpu_per_step=args.batch, points_per_frame=args.points, point_order=args.order,
                                 distinct_frames_in_timed_loop=N_STREAM,
-                                parallelism=f"frame-parallel replicas x{world}", pipeline_depth=(graphed.depth if pipelined else 1),
+                                parallelism=f"frame-parallel replicas x{world}", host_pinning=pinning, pipeline_depth=(graphed.depth if pipelined else 1),
                                 pipeline_tuning=(graphed.tuned if pipelined else None),
                                 path={"graph": "native backbone plan + split-precision MFMA dense head + device proposal stage, one HIP graph per "
                                                "frame" + (f", {graphed.depth} frames in flight" if pipelined else ""),

@@ -42,3 +42,27 @@ def test_mismatches_fail_loudly(bench):
     with pytest.raises(SystemExit):
         bench.launch_plan(0, {}, [], 1, backend="nccl")
     assert bench.launch_plan(2, {}, [], 1, backend="gloo") is not None  # gloo: ranks may share a device (control-flow check)
+
+
+def test_numa_pinning_reads_the_topology_and_degrades_quietly(bench, tmp_path, monkeypatch):
+    """One rank per GPU is pinned to the cores of its GPU's NUMA node (bench.pin_rank_to_gpu_numa): the cpulist parser, the sysfs
+    walk on a fake tree, and the no-topology case (this container: no GPU, no such files) which must do nothing."""
+    assert bench.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert bench.parse_cpulist("") == []
+
+    class Props:
+        pci_domain_id, pci_bus_id, pci_device_id = 0, 0x65, 0
+    monkeypatch.setattr(bench.torch.cuda, "get_device_properties", lambda i: Props())
+    dev = tmp_path / "bus/pci/devices/0000:65:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices/system/node/node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text("16-31,144-159\n")
+    cpus = bench.numa_cpus_of_gpu(0, sysfs=str(tmp_path))
+    assert cpus == list(range(16, 32)) + list(range(144, 160))
+    (dev / "numa_node").write_text("-1\n")  # no affinity reported
+    assert bench.numa_cpus_of_gpu(0, sysfs=str(tmp_path)) is None
+    assert bench.numa_cpus_of_gpu(0, sysfs=str(tmp_path / "missing")) is None
+    monkeypatch.delenv("V3D_BENCH_PIN", raising=False)
+    assert bench.pin_rank_to_gpu_numa(0, 1) is None  # single-rank jobs are left alone
