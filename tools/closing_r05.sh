@@ -13,10 +13,10 @@ stats() {  # stats <name> <bench args...>: rocprofv3 kernel statistics of one be
   rm -rf /tmp/prof_$name
 }
 # 1. one frame at a time: per-kernel statistics + the in-frame sequence timeline (KITTI, Waymo range)
-stats one_frame --pipeline 1 --steps 300 --warmup 20 --no-cpu-baseline --no-roofline --no-h2d --windows 1
+stats one_frame --pipeline 1 --steps 300 --warmup 20 --no-cpu-baseline --no-roofline --no-h2d --no-fast-mode --windows 1
 python tools/trace_sequence.py /tmp/one_frame_kernel_trace.csv 200 > $O/trace_sequence.txt 2>&1
 cp $O/one_frame_kernel_stats.csv profiles/in_frame_kernel_stats.csv
-stats waymo_one_frame --workload waymo --pipeline 1 --steps 60 --warmup 10 --no-cpu-baseline --no-roofline --no-h2d --windows 1
+stats waymo_one_frame --workload waymo --pipeline 1 --steps 60 --warmup 10 --no-cpu-baseline --no-roofline --no-h2d --no-fast-mode --windows 1
 python tools/trace_sequence.py /tmp/waymo_one_frame_kernel_trace.csv 40 > $O/waymo_trace_sequence.txt 2>&1
 cp $O/waymo_one_frame_kernel_stats.csv profiles/in_frame_kernel_stats_waymo.csv
 # 2. the bench lines (the first two exactly as the driver runs them / as bench.py defaults)
