@@ -28,7 +28,7 @@ def timed(fn, reps=50):
 def main():
     cfg = second_car_cfg()
     torch.manual_seed(0)
-    model = Second(cfg).cuda().eval()
+    model = Second(cfg).cuda().eval().set_precision("bf16x3")  # (the layer-by-layer calls below pass no scale entries: the scale-free arithmetic)
     clouds = [torch.from_numpy(synth.make_cloud(0, 16384)).cuda()]
     with torch.no_grad():
         plan, flat, offsets = model._plan_for(clouds)

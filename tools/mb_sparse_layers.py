@@ -27,17 +27,26 @@ with torch.no_grad():
     model.cnn(it["voxel_mean"], it["coordinates"], it["batch_size"])
 convmod.sparse_conv_forward = orig
 REP = 25
+PREC = os.environ.get("MB_PRECISION", "bf16x3")  # arithmetic of the timed calls ("fp32" = f16s: each call then also launches the
+# small scale-entry reduction of the op-by-op path -- tools/mb_prec_ab.py times the kernels alone in both arithmetics)
 VARIANTS = [int(v) for v in os.environ.get("MB_VARIANTS", "0,1,10,5").split(",")]  # forced kernels (negative rows_hint codes)
+
+
+def packed_for(a):
+    w = a[1]
+    cin, cout = w.shape[-2], w.shape[-1]
+    return convmod.pack_sparse_weight(w.reshape(-1, cin, cout).contiguous(), a[2].nbr.shape[0], cin, cout, PREC)
 
 
 def timed(a, variant):
     g = torch.cuda.CUDAGraph()
+    img = packed_for(a)
     with torch.no_grad():
-        orig(a[0], a[1], a[2], a[3], a[4], a[5], 4, a[7], variant)
+        orig(a[0], a[1], a[2], a[3], a[4], a[5], 4, img, variant, PREC)
         torch.cuda.synchronize()
         with torch.cuda.graph(g):
             for _ in range(REP):
-                o = orig(a[0], a[1], a[2], a[3], a[4], a[5], 4, a[7], variant)
+                o = orig(a[0], a[1], a[2], a[3], a[4], a[5], 4, img, variant, PREC)
     ts = []
     for trial in range(4):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -66,13 +75,14 @@ if os.environ.get("MB_SEQUENCE", "1") != "0":
     layers = [a for a in cap if a[1].shape[-2] >= 16]
     g = torch.cuda.CUDAGraph()
     with torch.no_grad():
-        for a in layers:
-            orig(a[0], a[1], a[2], a[3], a[4], a[5], 4, a[7], 0)
+        imgs = [packed_for(a) for a in layers]
+        for a, img in zip(layers, imgs):
+            orig(a[0], a[1], a[2], a[3], a[4], a[5], 4, img, 0, PREC)
         torch.cuda.synchronize()
         with torch.cuda.graph(g):
             for _ in range(REP):
-                for a in layers:
-                    orig(a[0], a[1], a[2], a[3], a[4], a[5], 4, a[7], 0)
+                for a, img in zip(layers, imgs):
+                    orig(a[0], a[1], a[2], a[3], a[4], a[5], 4, img, 0, PREC)
     ts = []
     for trial in range(4):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
