@@ -112,6 +112,23 @@ int v3d_assign_targets(const float* gt_boxes, const int64_t* gt_class, int n_gt,
                        float* G_reg, uint8_t* M_reg, int64_t* matches, void* workspace, size_t workspace_bytes,
                        v3d_stream_t stream);
 
+/* ---- f2: GT-sampling + global augmentation of one training frame, fused (two launches with sampling, one without).
+ * Replaces the chain vision3d/dataset/augmentation.py:31-48 -- SampleAugmentation :117-198 (paste at float64 positions :162-166,
+ * collision filter IoU > 1e-2 :140-149, scene points under the pasted rectangles removed :195), FlipAugmentation :78-95,
+ * ScaleAugmentation :98-114, RotateAugmentation :51-75 -- which the reference runs in numpy.  The random draws are the caller's
+ * (made on the host with the reference's numpy calls in the reference's order): k samples {int32 box_row, pt_start, pt_len, cls;
+ * float64 px, py} (32 bytes each, device memory) indexing the flat database tensors db_points (P, 4) / db_boxes (K, 7), flip,
+ * the scale factor, cos / sin / value of the float32 rotation angle.  Arithmetic: float64 with sampling (numpy's promotion at the
+ * paste), float32 without (k == 0: out_class_idx and work are not touched; any C >= 3).  With sampling C must be 4.
+ * Outputs at capacity: out_points (N + sample_points, 4), out_boxes (n + k, 7), out_class_idx (n + k); the ragged sizes are the
+ * first int32 words of `work`: {kept samples, kept sample points, kept scene points}, followed by keep[k] (0 / 1 per sample).
+ * Result rows: kept scene points in order, then the kept samples' points in draw order; scene boxes, then kept samples' boxes. */
+size_t v3d_augment_work_bytes(int N, int n, int k);
+int v3d_augment_frame(const float* points, int N, int C, const float* boxes, const int64_t* class_idx, int n,
+                      const float* db_points, const float* db_boxes, const void* samples, int k, int sample_points, int flip,
+                      double factor, double cos_theta, double sin_theta, double theta, float* out_points, float* out_boxes,
+                      int64_t* out_class_idx, void* work, size_t work_bytes, v3d_stream_t stream);
+
 /* ---- A11: points in cuboids / rectangles.
  * Replaces core/geometry.py:27-65 (PointsInCuboids._get_mask when use_z != 0,
  * PointsNotInRectangles._get_mask otherwise).  points (N,C>=3) f32, boxes (n,7) f32

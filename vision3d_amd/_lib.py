@@ -34,6 +34,9 @@ _SIGNATURES = {
     "v3d_assign_targets_workspace": (_sz, [_i, _i, _i]),
     "v3d_assign_targets": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "v3d_points_in_boxes": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "v3d_augment_work_bytes": (_sz, [_i, _i, _i]),
+    "v3d_augment_frame": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, C.c_double, C.c_double, C.c_double, C.c_double,
+                               _vp, _vp, _vp, _vp, _sz, _vp]),
     "v3d_voxelize_workspace": (_sz, [_i]),
     "v3d_voxelize": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "v3d_rulebook_workspace": (_sz, [_i, _i, _i]),

@@ -14,6 +14,7 @@
 #include "v3d_common.h"
 #include "nms_device.h"
 #include "rotated_iou.h"
+#include "pib_device.h"
 
 using v3d::BoxPrep;
 
@@ -340,10 +341,6 @@ extern "C" int v3d_nms_rotated(const float* boxes, const float* scores, int N, f
 // points in boxes (core/geometry.py:4-65).  Corner arithmetic in fp64 exactly where numpy promotes
 // (geometry.py:21); cos/sin evaluated on the float32 yaw.  One thread per point, boxes staged in LDS.
 // ------------------------------------------------------------------------------------------------
-struct PibBox {
-  double cx[4], cy[4];
-  float zlo, zhi;
-};
 #define PIB_BOXES 64
 
 __global__ __launch_bounds__(V3D_BLOCK) void points_in_boxes_kernel(const float* __restrict__ pts, int N, int C,
@@ -361,33 +358,13 @@ __global__ __launch_bounds__(V3D_BLOCK) void points_in_boxes_kernel(const float*
     const int nb = min(PIB_BOXES, n - b0);
     __syncthreads();
     if ((int)threadIdx.x < nb) {
-      const float* bx = boxes + 7 * (size_t)(b0 + threadIdx.x);
-      const float cf = cosf(bx[6]), sf = sinf(bx[6]);
-      const double ux[4] = {-0.5, 0.5, 0.5, -0.5}, uy[4] = {-0.5, -0.5, 0.5, 0.5};
-      PibBox pb;
-#pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const double lx = (double)bx[3] * ux[v], ly = (double)bx[4] * uy[v];
-        pb.cx[v] = ((double)cf * lx + (double)(-sf) * ly) + (double)bx[0];
-        pb.cy[v] = ((double)sf * lx + (double)cf * ly) + (double)bx[1];
-      }
-      pb.zlo = bx[2] - bx[5] / 2;
-      pb.zhi = bx[2] + bx[5] / 2;
+      const PibBox pb = pib_prep(boxes + 7 * (size_t)(b0 + threadIdx.x));
       sb[threadIdx.x] = pb;
     }
     __syncthreads();
     if (i < N) {
       for (int b = 0; b < nb; b++) {
-        const PibBox& pb = sb[b];
-        bool in = true;
-        if (use_z) in = (pz > pb.zlo) && (pz < pb.zhi);
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-          const int pv = (v + 3) & 3;
-          const double sx = -(pb.cx[v] - pb.cx[pv]), sy = -(pb.cy[v] - pb.cy[pv]);
-          const double vx = pb.cx[v] - (double)px, vy = pb.cy[v] - (double)py;
-          in = in && (sx * vy - sy * vx > 0);
-        }
+        const bool in = pib_inside(sb[b], px, py, pz, use_z != 0);
         mask[(size_t)i * n + b0 + b] = in ? 1 : 0;
       }
     }

@@ -44,20 +44,70 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_hash_build_kernel(const int4* __
 }
 
 // ---------------------------------------------------------------------------------- submanifold table
-// nbr[k][o] of offset k for output row o (the kernels that call this are further down: they can carry a candidate job)
-__device__ __forceinline__ void rb_subm_entry(const int4* __restrict__ coords, int n, int cap, const RbGeom& g, const V3dHash& h,
-                                              const int* __restrict__ vals, int* __restrict__ nbr, int k, int o) {
+// nbr[k][o] of offset k for output row o (the kernels that call this are further down: they can carry a candidate job),
+// KPT consecutive offsets per thread.  One look-up per thread leaves a wave with a single dependent chain
+// (coordinate row -> table word -> store) and the launch latency-bound: ~45 G look-ups/s at Waymo range, where 2.8 - 4 M look-ups
+// per table cost 60 - 85 us.  Here a thread reads its coordinate row ONCE and issues the first probes of its KPT offsets as
+// straight-line, unconditional loads (an offset with nothing to look up -- centre tap, outside the grid, past K -- probes slot 0 and
+// ignores the word), so KPT table reads are in flight per lane before the first is consumed; only a probe that lands on ANOTHER
+// site's word walks on (linear probing, load factor < 0.5 of the capacity: rare).  Stores stay coalesced along o for every offset.
+template <int KPT>
+__device__ __forceinline__ void rb_subm_entries(const int4* __restrict__ coords, int n, int cap, const RbGeom& g, const V3dHash& h,
+                                                int* __restrict__ nbr, int kgroup, int o) {
   if (o >= n) return;
-  const int kx = k % g.ks[2], ky = (k / g.ks[2]) % g.ks[1], kz = k / (g.ks[2] * g.ks[1]);
   const int4 c = coords[o];
-  const int z = c.y + kz - g.ks[0] / 2, y = c.z + ky - g.ks[1] / 2, x = c.w + kx - g.ks[2] / 2;
-  int v = -1;
-  if (2 * k + 1 == g.K) {
-    v = o;  // centre tap: the site itself
-  } else if (z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2]) {
-    if ((unsigned)c.x < (unsigned)RB_MAX_BATCH) v = v3d_site_find_row(h, rb_key(c.x, z, y, x, g.in_shape));  // one access: the row rides in the key word
+  const bool keyed = (unsigned)c.x < (unsigned)RB_MAX_BATCH;
+  v3d_key_t key[KPT], w[KPT];
+  unsigned s[KPT];
+  bool look[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const int k = kgroup * KPT + j;
+    const int kx = k % g.ks[2], ky = (k / g.ks[2]) % g.ks[1], kz = k / (g.ks[2] * g.ks[1]);
+    const int z = c.y + kz - g.ks[0] / 2, y = c.z + ky - g.ks[1] / 2, x = c.w + kx - g.ks[2] / 2;
+    look[j] = keyed && k < g.K && 2 * k + 1 != g.K && z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 &&
+              x < g.in_shape[2];
+    key[j] = look[j] ? rb_key(c.x, z, y, x, g.in_shape) : 0;
+    s[j] = look[j] ? v3d_hash_start(key[j], h) : 0u;
+    w[j] = h.keys[s[j]];
   }
-  nbr[(size_t)k * cap + o] = v;
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const int k = kgroup * KPT + j;
+    int v = -1;
+    if (2 * k + 1 == g.K) {
+      v = o;
+    } else if (look[j]) {
+      const v3d_key_t word = w[j];
+      if ((word >> V3D_SITE_ROW_BITS) == key[j]) {
+        const unsigned row = (unsigned)word & V3D_SITE_NO_ROW;
+        if (row != V3D_SITE_NO_ROW) v = (int)row;
+      } else if (word != V3D_EMPTY_KEY) {
+        v = v3d_site_find_row_from(h, key[j], (s[j] + 1) & h.mask);  // another site's word: walk on
+      }
+    }
+    if (k < g.K) nbr[(size_t)k * cap + o] = v;
+  }
+}
+// Offsets per thread: 9 (one kz plane of a 3x3x3 kernel) for the long site lists, 1 for the short ones.  Measured in the frame
+// (profiles/r05_rb_subm_kpt.txt): at Waymo range (104 k - 180 k rows) 9 per thread takes the four tables from 62 / 85 / 50 / 25 us to
+// 45 / 64 / 39 / 16 us; on a KITTI frame (16 k - 30 k rows, a few hundred workgroups) the same form is SLOWER (9.8 -> 22.6 us, 11.2 ->
+// 15.7 us): too few threads are left and each walks nine address computations in a row.  The switch is on the capacity, which
+// host and device both know.
+#define RB_SUBM_KPT 9
+#define RB_SUBM_KPT_MIN_ROWS 40960
+__host__ __device__ inline int rb_subm_kpt(int cap, int K) { return (K == 27 && cap >= RB_SUBM_KPT_MIN_ROWS) ? RB_SUBM_KPT : 1; }
+__host__ __device__ inline int rb_subm_blocks(int cap, int K) {
+  const int kpt = rb_subm_kpt(cap, K);
+  return ((cap + V3D_BLOCK - 1) / V3D_BLOCK) * ((K + kpt - 1) / kpt);
+}
+__device__ __forceinline__ void rb_subm_block(const int4* __restrict__ coords, int n, int cap, const RbGeom& g, const V3dHash& h,
+                                              int* __restrict__ nbr, int idx) {
+  const int nbx = (cap + V3D_BLOCK - 1) / V3D_BLOCK, o = (idx % nbx) * V3D_BLOCK + threadIdx.x;
+  if (rb_subm_kpt(cap, g.K) == RB_SUBM_KPT)
+    rb_subm_entries<RB_SUBM_KPT>(coords, n, cap, g, h, nbr, idx / nbx, o);
+  else
+    rb_subm_entries<1>(coords, n, cap, g, h, nbr, idx / nbx, o);
 }
 
 // ---------------------------------------------------------------------------------- strided conv
@@ -144,7 +194,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_candidates_kernel(const int4* __
   rb_candidates_body(coords, n_ptr, cap_in, g, h, first_ticket, cand_slot, overflow, overflow_any, blockIdx.x, gridDim.x);
 }
 
-// grid = ceil(cap/256) * K blocks (block -> (kernel offset, 256 output rows)) + the blocks of a candidate job riding along
+// grid = rb_subm_blocks(cap, K) blocks (block -> (group of kernel offsets, 256 output rows)) + the blocks of a candidate job riding along
 __global__ __launch_bounds__(V3D_BLOCK) void rb_subm_nbr_kernel(const int4* __restrict__ coords,
                                                                 const int* __restrict__ n_ptr, int cap,
                                                                 const RbGeom g, const V3dHash h,
@@ -155,8 +205,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_subm_nbr_kernel(const int4* __re
                        job.overflow_any, blockIdx.x - subm_blocks, job.blocks);
     return;
   }
-  const int nbx = (cap + V3D_BLOCK - 1) / V3D_BLOCK;
-  rb_subm_entry(coords, min(*n_ptr, cap), cap, g, h, vals, nbr, blockIdx.x / nbx, (blockIdx.x % nbx) * V3D_BLOCK + threadIdx.x);
+  rb_subm_block(coords, min(*n_ptr, cap), cap, g, h, nbr, blockIdx.x);
 }
 
 __device__ __forceinline__ bool rb_is_first(const int* cand_slot, const unsigned* first_ticket, long long t,
@@ -318,8 +367,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void rb_fill_nbr_kernel(const int* __res
   }
   // ---- submanifold table of the output sites
   const int idx = blockIdx.x - fill_blocks;
-  const int nbx = (cap_out + V3D_BLOCK - 1) / V3D_BLOCK;
-  rb_subm_entry(coords_out, min(*n_out_ptr, cap_out), cap_out, sg, sh, vals, subm_nbr, idx / nbx, (idx % nbx) * V3D_BLOCK + threadIdx.x);
+  rb_subm_block(coords_out, min(*n_out_ptr, cap_out), cap_out, sg, sh, subm_nbr, idx);
 }
 
 // ---------------------------------------------------------------------------------- host side
@@ -401,7 +449,7 @@ int v3d_i_subm_nbr(const int32_t* coords, const int32_t* n, int cap, const int32
   RbCandJob job;
   rc = make_cand_job(next, job);
   if (rc) return rc;
-  const int subm_blocks = v3d_ceil_div(cap, V3D_BLOCK) * g.K;
+  const int subm_blocks = rb_subm_blocks(cap, g.K);
   hipLaunchKernelGGL(rb_subm_nbr_kernel, dim3(subm_blocks + job.blocks), dim3(V3D_BLOCK), 0, st,
                      (const int4*)coords, n, cap, g, hh, h.vals, nbr, subm_blocks, job);
   V3D_CHECK_LAUNCH();
@@ -447,7 +495,7 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
     if (rc) return rc;
     for (int j = 0; j < 3; j++)
       if (!(sg.ks[j] & 1)) return V3D_EINVAL;
-    subm_blocks = v3d_ceil_div(cap_out, V3D_BLOCK) * sg.K;
+    subm_blocks = rb_subm_blocks(cap_out, sg.K);
   }
   RbCandJob job;
   rc = make_cand_job(next, job);

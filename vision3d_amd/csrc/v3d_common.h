@@ -202,8 +202,7 @@ __device__ __forceinline__ int v3d_site_insert(const V3dHash h, v3d_key_t key, u
 }
 
 // the row of a site in a table completed by an EARLIER kernel (or numbered by v3d_site_set_row), -1 if absent / not numbered
-__device__ __forceinline__ int v3d_site_find_row(const V3dHash h, v3d_key_t key) {
-  unsigned s = v3d_hash_start(key, h);
+__device__ __forceinline__ int v3d_site_find_row_from(const V3dHash h, v3d_key_t key, unsigned s) {
   for (unsigned probes = 0; probes <= h.mask; probes++) {
     const v3d_key_t w = h.keys[s];
     if ((w >> V3D_SITE_ROW_BITS) == key) {
@@ -214,6 +213,10 @@ __device__ __forceinline__ int v3d_site_find_row(const V3dHash h, v3d_key_t key)
     s = (s + 1) & h.mask;
   }
   return -1;
+}
+
+__device__ __forceinline__ int v3d_site_find_row(const V3dHash h, v3d_key_t key) {
+  return v3d_site_find_row_from(h, key, v3d_hash_start(key, h));
 }
 
 // number the site in slot `s` (its only writer at this point: no insert runs concurrently)

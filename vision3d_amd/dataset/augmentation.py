@@ -15,6 +15,13 @@ reproduces the reference draw for draw -- the golden test relies on that.
 Arithmetic follows numpy's promotions, because they decide the values: pasted boxes and points are float32 + float64
 positions (augmentation.py:162-166), so from there on the reference computes in float64 and casts to float32 at the very
 end (kitti_dataset.py:119-120); without sampling everything stays float32.  The same dtypes are used on the device.
+
+Two forms of the same computation.  The classes `SampleAugmentation` / `FlipAugmentation` / `ScaleAugmentation` /
+`RotateAugmentation` mirror the reference's classes one to one on torch device tensors (about 60 small launches per frame).
+`ChainedAugmentation` runs the whole chain through `v3d_augment_frame` (csrc/augment.hip): none of the draws depends on a device
+result, so all of them are made first -- same calls, same order -- and the frame is two launches (collision filter + boxes; point
+filter + ordered compaction + paste + transform) and one host read (the ragged sizes).  `ChainedAugmentation(fused=False)` keeps
+the class-by-class chain; the two are compared bit for bit in tests/test_gpu_augmentation.py.
 """
 import os
 import pickle
@@ -22,6 +29,7 @@ import pickle
 import numpy as np
 import torch
 
+from .. import _lib as L
 from ..core.geometry import PointsNotInRectangles
 from ..ops import box_iou_rotated
 
@@ -55,6 +63,18 @@ class SampleDatabase:
 
     def count(self, class_idx):
         return len(self.sizes[class_idx])
+
+    def flat(self):
+        """-> (all points (sum P, 4), all boxes (sum K, 7), first point row per class, first box row per class): the per-class
+        tensors behind each other, what `v3d_augment_frame` indexes.  Built on first use."""
+        if getattr(self, "_flat", None) is None:
+            dev = self.points[0].device if self.points else torch.device("cuda")
+            pts = torch.cat(self.points) if self.points else torch.zeros((0, 4), device=dev)
+            box = torch.cat(self.boxes) if self.boxes else torch.zeros((0, 7), device=dev)
+            pt_base = np.concatenate([[0], np.cumsum([p.shape[0] for p in self.points])]).astype(np.int64)
+            box_base = np.concatenate([[0], np.cumsum([b.shape[0] for b in self.boxes])]).astype(np.int64)
+            self._flat = (pts.contiguous(), box.contiguous(), pt_base, box_base)
+        return self._flat
 
 
 class Augmentation:
@@ -173,12 +193,17 @@ class SampleAugmentation(Augmentation):
         return points, boxes, class_idx
 
 
+SAMPLE_RECORD = np.dtype([("box_row", np.int32), ("pt_start", np.int32), ("pt_len", np.int32), ("cls", np.int32),
+                          ("px", np.float64), ("py", np.float64)])  # AugSample of csrc/augment.hip
+
+
 class ChainedAugmentation(Augmentation):
     """sample -> flip -> scale -> rotate (augmentation.py:31-48).  numpy in -> numpy out (float32, the dtype the reference's
-    dataset casts to); cuda tensors in -> cuda tensors out."""
+    dataset casts to); cuda tensors in -> cuda tensors out.  fused (default): the frame through `v3d_augment_frame`."""
 
-    def __init__(self, cfg, database=None, rng=None):
+    def __init__(self, cfg, database=None, rng=None, fused=True):
         super().__init__(cfg, rng)
+        self.fused = fused
         self.sample = SampleAugmentation(cfg, database, self.rng) if cfg.AUG.DATABASE_SAMPLE else None
         self.augmentations = [FlipAugmentation(cfg, self.rng), ScaleAugmentation(cfg, self.rng), RotateAugmentation(cfg, self.rng)]
 
@@ -186,11 +211,69 @@ class ChainedAugmentation(Augmentation):
         as_numpy = isinstance(points, np.ndarray)
         points, boxes = _to_device(points, torch.float32), _to_device(boxes, torch.float32)
         class_idx = _to_device(np.asarray(class_idx, np.int64) if as_numpy else class_idx, torch.int64)
-        if self.sample is not None:
-            points, boxes, class_idx = self.sample(points, boxes, class_idx)
-        for aug in self.augmentations:
-            points, boxes = aug(points, boxes)
-        points, boxes = points.float(), boxes.float()
+        if self.fused:
+            points, boxes, class_idx = self.fused_frame(points, boxes, class_idx)
+        else:
+            if self.sample is not None:
+                points, boxes, class_idx = self.sample(points, boxes, class_idx)
+            for aug in self.augmentations:
+                points, boxes = aug(points, boxes)
+            points, boxes = points.float(), boxes.float()
         if as_numpy:
             return points.cpu().numpy(), boxes.cpu().numpy(), class_idx.cpu().numpy()
         return points, boxes, class_idx
+
+    def draw(self):
+        """Every random draw of one frame, through the calls the chained classes make, in their order: the samples class by
+        class (augmentation.py:132), their positions (:164), the flip coin (:90), the scale (:110), the angle (:71)."""
+        cfg, picks, position = self.cfg, [], None
+        if self.sample is not None:
+            picks = self.sample.draw_samples()
+            if picks:
+                lower, upper = np.r_[cfg.GRID_BOUNDS].reshape(2, 3)[:, :2]
+                position = self.rng.rand(len(picks), 2) * (upper - lower) + lower  # float64
+        flip = not (self.rng.rand() < 0.5 or not cfg.AUG.FLIP_HORIZONTAL)
+        factor = float(self.uniform(*cfg.AUG.GLOBAL_SCALE))
+        theta = self.uniform(*cfg.AUG.GLOBAL_ROTATION)
+        return picks, position, flip, factor, theta
+
+    def sample_records(self, picks, position):
+        db = self.sample.database
+        _, _, pt_base, box_base = db.flat()
+        rec = np.zeros(len(picks), SAMPLE_RECORD)
+        for j, (c, i) in enumerate(picks):
+            rec[j] = (box_base[c] + i, pt_base[c] + db.offsets[c][i], db.sizes[c][i], c, position[j, 0], position[j, 1])
+        return rec
+
+    def fused_frame(self, points, boxes, class_idx):
+        L.require_gpu("augment_frame", points, boxes, class_idx)
+        picks, position, flip, factor, theta = self.draw()
+        points, boxes, class_idx = points.contiguous(), boxes.contiguous(), class_idx.contiguous()
+        N, C = points.shape
+        n, k = boxes.shape[0], len(picks)
+        cos_t, sin_t = float(np.cos(theta)), float(np.sin(theta))  # float32 cos / sin of the float32 angle, as the reference's matrix
+        dev = points.device
+        with torch.cuda.device(dev):
+            if k == 0:
+                out_p, out_b = torch.empty_like(points), torch.empty_like(boxes)
+                L.check(L.lib().v3d_augment_frame(L.ptr(points), N, C, L.ptr(boxes), 0, n, 0, 0, 0, 0, 0, int(flip), factor, cos_t, sin_t,
+                                                  float(theta), L.ptr(out_p), L.ptr(out_b), 0, 0, 0, L.stream_ptr()), "augment_frame")
+                return out_p, out_b, class_idx
+            if C != 4:
+                raise RuntimeError(f"augment_frame: the sample database holds 4-column points, the scene has {C}")
+            db_points, db_boxes, _, _ = self.sample.database.flat()
+            rec = self.sample_records(picks, position)
+            sample_points = int(rec["pt_len"].sum())
+            samples = torch.from_numpy(rec.view(np.uint8).reshape(-1)).to(dev)
+            work_bytes = int(L.lib().v3d_augment_work_bytes(N, n, k))
+            work = torch.empty((work_bytes + 7) // 8, dtype=torch.int64, device=dev)
+            out_p = torch.empty((N + sample_points, 4), dtype=torch.float32, device=dev)
+            out_b = torch.empty((n + k, 7), dtype=torch.float32, device=dev)
+            out_c = torch.empty(n + k, dtype=torch.int64, device=dev)
+            L.check(L.lib().v3d_augment_frame(L.ptr(points), N, C, L.ptr(boxes), L.ptr(class_idx), n, L.ptr(db_points), L.ptr(db_boxes),
+                                              L.ptr(samples), k, sample_points, int(flip), factor, cos_t, sin_t, float(theta),
+                                              L.ptr(out_p), L.ptr(out_b), L.ptr(out_c), L.ptr(work), work_bytes, L.stream_ptr()),
+                    "augment_frame")
+            head = work[:2].view(torch.int32).cpu().numpy()  # the one host read: {kept samples, their points, kept scene points}
+        kept, kept_points, scene_points = int(head[0]), int(head[1]), int(head[2])
+        return out_p[:scene_points + kept_points], out_b[:n + kept], out_c[:n + kept]
