@@ -200,6 +200,11 @@ int v3d_sparse_conv_pack_weights2(const float* weight, int K, int Cin, int Cout,
  * no host synchronisation.  headroom_bits in [0, 12]. */
 int v3d_act_scale_from_rows(const float* rows, const int32_t* n_rows, int cap, int C, int headroom_bits, float* entry,
                             v3d_stream_t stream);
+/* The same entry computed by a grid of workgroups: `scratch` = two uint32 words in device memory that are ZERO when the launch
+ * starts (running maximum, arrival ticket); the last workgroup to arrive writes the entry and zeroes them again, so one zeroed
+ * scratch serves every later call on the same stream.  scratch NULL: the one-workgroup form above. */
+int v3d_act_scale_from_rows2(const float* rows, const int32_t* n_rows, int cap, int C, int headroom_bits, float* entry,
+                             uint32_t* scratch, v3d_stream_t stream);
 /* rows_hint > 0: the caller's estimate of the LIVE row count (*n_out is device-side), used only to choose the kernel: 3x3x3 with
  * Cin, Cout in {32, 64}: LDS-ring kernel up to 16 384 rows, 64-row LDS-shared-weights kernel from 32 768, else the 16-row kernel;
  * 0 = unknown (ring / 16-row).  The 64 -> 64 ring kernel owns a CU per workgroup: it takes 2, 3 or 4 sixteen-row tiles per workgroup,

@@ -250,6 +250,43 @@ def test_pv_rcnn_forward_and_inference():
     assert (scores[:-1] >= scores[1:]).all() and set(bidx.tolist()) <= {0, 1}
 
 
+def test_pv_rcnn_prefetched_keypoints_change_nothing():
+    """PV_RCNN.prefetch_keypoints (the next frame's farthest-point sampling started on the side stream before the current frame is
+    issued) against the plain call: same keypoints, same detections, over a few frames in flight."""
+    from vision3d_amd.core import AnchorGenerator, Preprocessor
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.detector import PV_RCNN
+    cfg = second_car_cfg()
+    torch.manual_seed(4)
+    model = PV_RCNN(cfg).cuda().eval()
+    anchors = AnchorGenerator(cfg).anchors.cuda()
+    n = cfg.NUM_CLASSES * cfg.PROPOSAL.TOPK
+    samples = torch.rand((1, n, cfg.GRIDPOOL.NUM_GRIDPOINTS, 3), generator=torch.Generator().manual_seed(5)).cuda()
+    clouds = [synth.make_cloud(10 + i) for i in range(4)]
+    make = lambda i: Preprocessor(cfg, seed=0)(dict(points=[clouds[i]], anchors=anchors))
+
+    def seeded():
+        model.cnn.pad_generator = torch.Generator(device="cuda").manual_seed(6)
+    with torch.no_grad():
+        plain = []
+        for i in range(4):
+            seeded()
+            item = make(i)
+            plain.append((model.inference(item, samples), item["keypoints"].clone()))
+        item = model.prefetch_keypoints(make(0))
+        assert "_keypoints_ready" in item
+        for i in range(4):
+            nxt = model.prefetch_keypoints(make(i + 1)) if i < 3 else None
+            seeded()
+            dets = model.inference(item, samples)
+            assert "_keypoints_ready" not in item
+            assert torch.equal(item["keypoints"], plain[i][1])
+            for x, y in zip(dets, plain[i][0]):
+                assert torch.equal(x, y)
+            item = nxt
+    torch.cuda.synchronize()
+
+
 def test_pv_rcnn_stage_pieces_run():
     """configs[3] shapes: FPS keypoints + 5-level VSA + BEV gather -> (B, 512, 2048); RoI-grid pool -> (B, n, 256)."""
     from vision3d_amd.core import Preprocessor

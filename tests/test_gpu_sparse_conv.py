@@ -304,3 +304,34 @@ def test_presplit_rows_every_kernel_variant(oracle, cin, cout, variant, precisio
     only_s = torch.zeros_like(got_s)
     run(feats, None, None, next_entry, only_s)                                 # fp32 rows in, split rows ONLY out
     assert torch.equal(only_s, got_s)
+
+
+def test_scale_entry_grid_form_equals_the_single_workgroup_form():
+    """v3d_act_scale_from_rows2 (grid of workgroups, self-resetting scratch) against v3d_act_scale_from_rows on the same rows:
+    identical entries; a device-side row count, a misaligned view, a one-element tensor; the scratch reads zero again after
+    every launch (so back-to-back launches on one stream need no fill)."""
+    from vision3d_amd import _lib as L
+    torch.manual_seed(3)
+    lib = L.lib()
+    scratch = L.scale_scratch(torch.device("cuda", torch.cuda.current_device()))
+    big = torch.randn(70001, 64, device="cuda") * 3.0
+    big[41234, 17] = -913.25  # the maximum sits in one place
+    cases = [(big, None, 64), (big[:1], None, 64), (big.reshape(-1)[1:64 * 1000 + 1].reshape(1000, 64), None, 64),
+             (big, torch.tensor([12345], dtype=torch.int32, device="cuda"), 64), (torch.zeros(100, 16, device="cuda"), None, 16),
+             (torch.full((1, 1), 2.0 ** -130, device="cuda"), None, 1)]
+    for ci, (rows, n_dev, c) in enumerate(cases):
+        for headroom in (0, 5):
+            a = torch.empty(4, device="cuda")
+            b = torch.empty(4, device="cuda")
+            L.check(lib.v3d_act_scale_from_rows(L.ptr(rows), L.ptr(n_dev), rows.shape[0], c, headroom, L.ptr(a), L.stream_ptr()), "one")
+            for _ in range(2):  # twice: the second launch runs on the scratch the first left behind
+                b.fill_(-1)
+                L.check(lib.v3d_act_scale_from_rows2(L.ptr(rows), L.ptr(n_dev), rows.shape[0], c, headroom, L.ptr(b), L.ptr(scratch),
+                                                     L.stream_ptr()), "grid")
+                assert torch.equal(a, b), (ci, headroom, a.tolist(), b.tolist())
+                assert scratch.tolist() == [0, 0]
+            n = rows.shape[0] if n_dev is None else int(n_dev.item())
+            amax = float(rows[:n].abs().max())
+            assert float(a[3]) == amax
+            if amax > 1e-30:
+                assert 2.0 ** (13 - headroom) <= amax * float(a[0]) < 2.0 ** (14 - headroom), (ci, amax, a.tolist())

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "v3d_sparse_conv_fwd_packed2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "v3d_sparse_rows_split": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "v3d_act_scale_from_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "v3d_act_scale_from_rows2": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "v3d_rulebook_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "v3d_sparse_conv_bwd_weight_workspace": (_sz, [_i, _i, _i]),
     "v3d_sparse_conv_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
@@ -229,6 +230,20 @@ def host_i32(values):
 
 def host_f32(values):
     return (C.c_float * len(values))(*[float(v) for v in values])
+
+
+_scale_scratch = {}
+
+
+def scale_scratch(device):
+    """The two zeroed uint32 words v3d_act_scale_from_rows2 works in, one pair per (device, stream): the kernel leaves them zero,
+    so launches on one stream reuse them; two streams never share a pair."""
+    index = torch.device(device).index
+    key = (torch.cuda.current_device() if index is None else index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _scale_scratch.get(key)
+    if buf is None:
+        buf = _scale_scratch[key] = torch.zeros(2, dtype=torch.int32, device=device)
+    return buf
 
 
 def workspace(nbytes, device):

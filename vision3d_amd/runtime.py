@@ -606,8 +606,8 @@ def act_entry_from_tensor(x, headroom_bits=0):
     x = L.as_f32("act_entry_from_tensor", x)
     entry = torch.empty(4, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        L.check(L.lib().v3d_act_scale_from_rows(L.ptr(x), None, x.numel(), 1, int(headroom_bits), L.ptr(entry), L.stream_ptr()),
-                "act_scale_from_rows")
+        L.check(L.lib().v3d_act_scale_from_rows2(L.ptr(x), None, x.numel(), 1, int(headroom_bits), L.ptr(entry),
+                                                 L.ptr(L.scale_scratch(x.device)), L.stream_ptr()), "act_scale_from_rows")
     return entry
 
 
