@@ -287,6 +287,39 @@ def test_pv_rcnn_prefetched_keypoints_change_nothing():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("batch", [1, 2])
+def test_pv_rcnn_native_cnn_equals_the_module_path(batch):
+    """Stage 1 of an inference frame through the backbone plan (PV_RCNN._native_cnn) against the module-by-module sparse CNN: the
+    same sites in the same order at every level (exact), features and BEV map equal up to the f16s rounding of a calibrated instead
+    of a per-call activation scale, and detections that agree."""
+    from gpu_util import FP32_CLASS_FLOOR, assert_features_close
+    from vision3d_amd.core import AnchorGenerator, Preprocessor
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.detector import PV_RCNN
+    cfg = second_car_cfg()
+    torch.manual_seed(7)
+    model = PV_RCNN(cfg).cuda().eval()
+    anchors = AnchorGenerator(cfg).anchors.cuda()
+    clouds = [synth.make_cloud(20 + i)[: 16384 - 900 * i] for i in range(batch)]
+    make = lambda: Preprocessor(cfg, seed=0)(dict(points=clouds, anchors=anchors))
+    results = {}
+    with torch.no_grad():
+        for native in (False, True, True):  # twice natively: the second frame runs on the calibrated plan without its set-up passes
+            model.native_cnn = native
+            model.cnn.pad_generator = torch.Generator(device="cuda").manual_seed(8)
+            item = model.proposal(make())
+            results[native] = ([(x.clone(), f.clone()) for x, f in item["_cnn_features"]], item["_bev_map"].clone(), item["P_cls"].clone())
+    (lv_a, bev_a, cls_a), (lv_b, bev_b, cls_b) = results[False], results[True]
+    assert len(lv_a) == len(lv_b) == 4
+    for level, ((xa, fa), (xb, fb)) in enumerate(zip(lv_a, lv_b)):
+        assert xa.shape == xb.shape and fa.shape == fb.shape, (level, xa.shape, xb.shape)
+        assert torch.equal(xa, xb), f"level {level}: the sites differ"
+        assert_features_close(fb.cpu().numpy().reshape(-1, fb.shape[-1]), fa.cpu().numpy().reshape(-1, fa.shape[-1]),
+                              f"level {level} features", floor=FP32_CLASS_FLOOR)
+    assert_features_close(bev_b.cpu().numpy().reshape(batch, -1), bev_a.cpu().numpy().reshape(batch, -1), "BEV map", floor=FP32_CLASS_FLOOR)
+    assert float((cls_a - cls_b).abs().max()) < 1e-4 * max(1.0, float(cls_a.abs().max()))
+
+
 def test_pv_rcnn_stage_pieces_run():
     """configs[3] shapes: FPS keypoints + 5-level VSA + BEV gather -> (B, 512, 2048); RoI-grid pool -> (B, n, 256)."""
     from vision3d_amd.core import Preprocessor

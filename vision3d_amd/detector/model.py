@@ -80,11 +80,14 @@ class PV_RCNN(nn.Module):
         main = torch.cuda.current_stream(item["points"].device)
         if "keypoints" not in item:
             self.prefetch_keypoints(item)
-        if "voxel_mean" in item:      # device voxelizer output
-            voxel_features = item["voxel_mean"]
-        else:                         # reference-style (M, K, C) slots + occupancy
-            voxel_features = self.vfe(item["features"], item["occupancy"])
-        cnn_features, bev_map = self.cnn(voxel_features, item["coordinates"], item["batch_size"])
+        if self._native_item(item):   # eval, no autograd, voxels of the device Preprocessor: the sparse CNN as one native plan
+            cnn_features, bev_map = self._native_cnn(item)
+        else:
+            if "voxel_mean" in item:      # device voxelizer output
+                voxel_features = item["voxel_mean"]
+            else:                         # reference-style (M, K, C) slots + occupancy
+                voxel_features = self.vfe(item["features"], item["occupancy"])
+            cnn_features, bev_map = self.cnn(voxel_features, item["coordinates"], item["batch_size"])
         item["P_cls"], item["P_reg"] = self.proposal_layer(bev_map)
         item["_cnn_features"], item["_bev_map"] = cnn_features, bev_map
         ready = item.pop("_keypoints_ready", None)
@@ -92,6 +95,60 @@ class PV_RCNN(nn.Module):
             main.wait_event(ready)
             item["keypoints"].record_stream(main)
         return item
+
+    # ---- the sparse CNN of an inference frame through the backbone plan (csrc/second_plan.hip): voxels in, the four sparse levels
+    #      and the BEV map out of ONE native call (rulebooks + 14 layers, ~35 launches issued from C++) instead of the module-by-module
+    #      path (a rulebook + a row-count read per stage, a scale entry + a launch per layer).  The levels are views of the plan's
+    #      stage buffers: rows [0, n) of the stage's last layer, n read in the frame's one host synchronisation together with the
+    #      plan's summary word (capacity / f16s range).  Same sites in the same order as the modules (one rulebook builder); features
+    #      equal up to the f16s rounding of a calibrated instead of a per-call scale.
+    native_cnn = True
+
+    def _native_item(self, item):
+        if not self.native_cnn or self.training or torch.is_grad_enabled() or "voxel_mean" not in item:
+            return False
+        vm, co = item["voxel_mean"], item["coordinates"]
+        return vm.is_cuda and co.is_cuda and co.dtype == torch.int32 and vm.dtype == torch.float32 and vm.shape[0] > 0
+
+    def _backbone_plan(self, batch_size, max_points):
+        from ..runtime import BackbonePlan, PlanCache
+        from ..spconv.conv import _SparseConvBase
+        plans = self.__dict__.setdefault("_plans", PlanCache())
+        dev = next(self.parameters()).device
+        key = (str(dev), int(batch_size), int(max_points))
+        if key not in plans:
+            plans[key] = BackbonePlan(self.cnn, self.cfg, max_batch=batch_size, max_points=max_points, device=dev,
+                                      growth=self.__dict__.get("plan_growth", 2.0), precision=_SparseConvBase.precision)
+            for other in plans.values():  # one calibration per model (see Second.share_calibration)
+                if other is not plans[key] and other.f16s and other._calib == "done":
+                    plans[key].copy_calibration(other)
+                    break
+        plans[key].set_precision(_SparseConvBase.precision)
+        return plans[key]
+
+    def _native_cnn(self, item):
+        from .. import spconv
+        vm, co, b = item["voxel_mean"], item["coordinates"], int(item["batch_size"])
+        cap_pts = 1 << max(14, (max(vm.shape[0], 1) - 1).bit_length())
+        plan = self._backbone_plan(b, max(cap_pts, b * 16384))
+        ends, k = [], 0  # index of the last layer of every stage in the plan's flat layer list
+        for stage in self.cnn.blocks:
+            k += sum(1 for m in stage.modules() if isinstance(m, spconv.conv._SparseConvBase))
+            ends.append(k - 1)
+        for attempt in range(2):
+            bev_map = plan.forward_voxels(vm, co, b)
+            outs = [plan.layer_output(e) for e in ends[:-1]]
+            host = torch.cat([n for _, _, n, _ in outs] + [plan.overflow_any()]).tolist()  # the one host read of stage 1
+            if host[-1] == 2 and attempt == 0:  # an f16s tensor left its calibrated range: recalibrate on this frame, run it again
+                plan.recalibrate()
+                continue
+            if host[-1]:
+                plan.check_overflow()  # raises with the layers that hit their capacity
+            break
+        volumes = [spconv.SparseConvTensor(vm, co, self.cnn.grid_shape, b)]
+        volumes += [spconv.SparseConvTensor(f[:n], c[:n], shape, b) for (f, c, _, shape), n in zip(outs, host)]
+        points = [self.cnn.to_global(stride, vol) for stride, vol in zip(self.cfg.STRIDES, volumes)]
+        return points, bev_map
 
     def prefetch_keypoints(self, item):
         """Start the keypoint sampling of `item` (needs item["points"]) on the side stream and return at once: item["keypoints"] is

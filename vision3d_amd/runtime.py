@@ -320,6 +320,25 @@ class BackbonePlan(object):
             return self.forward_voxels_split(voxel_mean, coordinates, batch_size)
         return hi, lo
 
+    def forward_voxels(self, voxel_mean, coordinates, batch_size, out=None):
+        """The plan fed with existing voxels, BEV map as the reference's `.dense()` + fold returns it: (B, C_out * D, H, W) float32.
+        The callers that also want the sparse levels (`layer_output`): PV_RCNN's stage 1."""
+        self.sync_weights()
+        mean = L.as_f32("backbone", voxel_mean)
+        coords = L.as_i32("backbone", coordinates)
+        m = mean.shape[0]
+        if coords.shape != (m, 4) or mean.shape[1] != self.cfg.C_IN:
+            raise RuntimeError("backbone: voxel_mean (M, C_IN) / coordinates (M, 4) expected")
+        d, h, w = self.out_shape
+        if out is None:
+            out = torch.empty((int(batch_size), self.out_channels * d, h, w), dtype=torch.float32, device=mean.device)
+        with torch.cuda.device(mean.device):
+            L.check(L.lib().v3d_backbone_forward_voxels(self._handle, L.ptr(mean), L.ptr(coords), m, int(batch_size), L.ptr(out),
+                                                        None, None, L.stream_ptr()), "backbone_forward_voxels")
+        if self._maybe_tune():
+            return self.forward_voxels(voxel_mean, coordinates, batch_size, out)
+        return out
+
     def bev_occupancy(self, batch_size):
         """(B * H, ceil(W / 32)) int32 device view of the plan's BEV occupancy bitmap for the LAST forward_split /
         forward_voxels_split: one bit per BEV pixel, inverted (0 = occupied).  Reset by the plan's per-frame fill and written
