@@ -82,7 +82,10 @@ def parse():
                     help="forward: the headline metric; train: BASELINE configs[2] (SECOND train step, bs=8/GPU, gradient "
                          "all-reduce over RCCL) -- a secondary line, same JSON contract")
     ap.add_argument("--no-channels-last", action="store_true", help="train mode: keep the dense RPN/head in NCHW")
-    ap.add_argument("--no-amp", action="store_true", help="train mode: keep the dense RPN/head in fp32 (default bf16 autocast)")
+    ap.add_argument("--train-arith", choices=["fp32", "bf16"], default="fp32",
+                    help="train mode, arithmetic of `value`: fp32 = the reference's script as written (no autocast; dense half on the "
+                         "fp32-class split kernels), bf16 = the step under bf16 autocast.  The other one is printed under `fast_mode` / not at all")
+    ap.add_argument("--no-amp", action="store_true", help="train mode: same as --train-arith fp32 (kept for older command lines)")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="frames in flight per GPU (graph path).  Throughput mode: independent bs=1 frames overlap on separate "
                          "streams / HIP graphs / plan arenas; every step still submits ONE frame and the timed region completes "
@@ -243,17 +246,8 @@ def train_main(args):
     if args.points is None:
         args.points = 16384
     bs = args.batch if args.batch > 1 else 8
-    torch.manual_seed(0)
-    model = Second(cfg).cuda().train()
-    native_dense = os.environ.get("V3D_DENSE_TRAIN", "native") == "native" and not args.no_amp
-    if not args.no_channels_last and not native_dense:  # torch dense path only: MIOpen's bf16 igemm kernels are NHWC-native
-        model.rpn = model.rpn.to(memory_format=torch.channels_last)
-        model.head = model.head.to(memory_format=torch.channels_last)
-        model.rpn.register_forward_pre_hook(lambda m, a: (a[0].contiguous(memory_format=torch.channels_last),))
+    native_env = os.environ.get("V3D_DENSE_TRAIN", "native") == "native"
     loss_fn = ProposalLoss(cfg)
-    # fused = one kernel per parameter-group chunk instead of ~15 multi-tensor launches (0.23 ms of a 7.4 ms step); same update rule
-    opt = torch.optim.Adam(model.parameters(), lr=0.01, betas=(0.9, 0.99), weight_decay=0.01,
-                           fused=os.environ.get("V3D_FUSED_ADAM", "1") != "0")
     pre, assigner = Preprocessor(cfg, seed=0), ProposalTargetAssigner(cfg)
     fids = [rank * bs + i for i in range(bs)]
     clouds = [torch.from_numpy(synth.make_cloud(f, args.points)).cuda() for f in fids]
@@ -263,31 +257,7 @@ def train_main(args):
         targets.append(assigner(dict(boxes=gt, class_idx=torch.zeros(len(gt), dtype=torch.long),
                                      box_ignore=torch.zeros(len(gt), dtype=torch.bool))))
     tgt = {k: torch.stack([t[k] for t in targets]).cuda() for k in ("G_cls", "G_reg", "M_cls", "M_reg")}
-    params = [p for p in model.parameters() if p.requires_grad]
-    sparse_ids = {id(p) for p in model.cnn.parameters()}
-    reducer = dist_util.TwoPhaseGradReducer([p for p in params if id(p) not in sparse_ids],
-                                            [p for p in params if id(p) in sparse_ids], world)
-    amp = not args.no_amp
     fused_loss = os.environ.get("V3D_FUSED_LOSS", "1") != "0"  # csrc/proposal_loss.hip (needs the native dense path's fused maps)
-
-    def step():
-        item = pre(dict(points=clouds))
-        item.update(tgt)
-        opt.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            out = model(item)
-            if not fused_loss:
-                out.pop("_head_maps", None)  # A/B: ProposalLoss through the torch expressions
-            losses = loss_fn(out)
-        if world > 1:  # the dense half's bucket is reduced while the native sparse backward runs
-            for plan in model.cnn.__dict__.get("_train_plans", {}).values():
-                plan.pre_backward_hook = reducer.start_early
-        losses["loss"].backward()
-        reducer.finish()
-        torch.nn.utils.clip_grad_norm_(params, max_norm=35)
-        model.check_train_overflow()  # this step's capacity word (copied behind the forward): before the weights are touched
-        opt.step()
-        return losses["loss"].detach()
 
     def fence():
         torch.cuda.synchronize()
@@ -295,19 +265,78 @@ def train_main(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        loss = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = dist_util.max_over_ranks(time.perf_counter() - t0, world, device=REDUCE_DEVICE)
-    model.check_train_overflow()  # the last step's capacity word
+    def run_arith(amp):
+        """K timed optimiser steps of a fresh model in one arithmetic: amp = the step under bf16 autocast (dense half: bf16 storage,
+        one MFMA term); not amp = the reference's fp32 script as written (dense half: split hi + lo storage, three MFMA terms --
+        Second.dense_train_precision "bf16x3"; "torch" = MIOpen fp32)."""
+        torch.manual_seed(0)
+        model = Second(cfg).cuda().train()
+        native_dense = native_env and (amp or model.dense_train_precision != "torch")
+        if not args.no_channels_last and not native_dense:  # torch dense path only: MIOpen's bf16 igemm kernels are NHWC-native
+            model.rpn = model.rpn.to(memory_format=torch.channels_last)
+            model.head = model.head.to(memory_format=torch.channels_last)
+            model.rpn.register_forward_pre_hook(lambda m, a: (a[0].contiguous(memory_format=torch.channels_last),))
+        # fused = one kernel per parameter-group chunk instead of ~15 multi-tensor launches (0.23 ms of a 7.4 ms step); same update rule
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, betas=(0.9, 0.99), weight_decay=0.01,
+                               fused=os.environ.get("V3D_FUSED_ADAM", "1") != "0")
+        params = [p for p in model.parameters() if p.requires_grad]
+        sparse_ids = {id(p) for p in model.cnn.parameters()}
+        reducer = dist_util.TwoPhaseGradReducer([p for p in params if id(p) not in sparse_ids],
+                                                [p for p in params if id(p) in sparse_ids], world)
+
+        def step():
+            item = pre(dict(points=clouds))
+            item.update(tgt)
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                out = model(item)
+                if not fused_loss:
+                    out.pop("_head_maps", None)  # A/B: ProposalLoss through the torch expressions
+                losses = loss_fn(out)
+            if world > 1:  # the dense half's bucket is reduced while the native sparse backward runs
+                for plan in model.cnn.__dict__.get("_train_plans", {}).values():
+                    plan.pre_backward_hook = reducer.start_early
+            losses["loss"].backward()
+            reducer.finish()
+            torch.nn.utils.clip_grad_norm_(params, max_norm=35)
+            model.check_train_overflow()  # this step's capacity word (copied behind the forward): before the weights are touched
+            opt.step()
+            return losses["loss"].detach()
+
+        for _ in range(args.warmup):
+            loss = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        fence()
+        elapsed = dist_util.max_over_ranks(time.perf_counter() - t0, world, device=REDUCE_DEVICE)
+        model.check_train_overflow()  # the last step's capacity word
+        if amp:
+            dense = ("bf16 dense RPN/head on hand-written MFMA kernels (csrc/dense_train.hip), fp32 accumulate; " if native_dense else
+                     "bf16 autocast dense RPN/head (torch / MIOpen); ")
+        else:
+            dense = ("fp32-class dense RPN/head on hand-written kernels: split bf16 hi + lo storage, three MFMA terms per product, fp32 "
+                     "accumulate (csrc/dense_train.hip split path + csrc/dense_conv.hip), no autocast -- the reference's train.py as "
+                     "written; " if native_dense else "fp32 dense RPN/head (torch / MIOpen); ")
+        return dict(elapsed=elapsed, loss=float(loss), model=model, native_dense=native_dense, fallbacks=int(model.torch_dense_fallbacks),
+                    dtype=dense + "sparse convs bf16-split MFMA fwd/dX, fp32 MFMA dW")
+
+    amp = args.train_arith == "bf16" and not args.no_amp
+    main = run_arith(amp)
+    elapsed, loss, model, native_dense = main["elapsed"], main["loss"], main["model"], main["native_dense"]
+    fast = None
+    if not amp and not args.no_fast_mode:
+        del model
+        other = run_arith(True)
+        fast = dict(value=world * bs * args.steps / other["elapsed"], unit="frames/s", ms_per_step=1e3 * other["elapsed"] / args.steps,
+                    dtype=other["dtype"], final_loss=other["loss"], torch_dense_fallbacks=other["fallbacks"],
+                    note="the same step under torch.autocast(bfloat16): reduced-precision dense half, not the reference's arithmetic")
+        model = other["model"]  # (any trained model of the architecture serves the CPU baseline's state_dict)
     seen = ranks_seen(world, args.gpus)
     roofline = cpu_baseline = None
     if rank == 0 and not args.no_roofline:
-        roofline = train_roofline(bs)
+        roofline = train_roofline(bs) if amp else train_roofline_split(bs)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cpu_baseline = train_cpu_baseline(model, cfg, clouds[0], {k: v[:1] for k, v in tgt.items()}, args)
@@ -318,15 +347,11 @@ def train_main(args):
             metric="frames/sec SECOND train step, 16k-pt KITTI cloud", value=world * bs * args.steps / elapsed, unit="frames/s",
             n_gpus=world, n_ranks_seen=seen, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
             scaling="weak", vs_baseline=None,
-            dtype=(("bf16 dense RPN/head on hand-written MFMA kernels (csrc/dense_train.hip), fp32 accumulate; " if native_dense else
-                    "bf16 autocast dense RPN/head (torch / MIOpen); ") if amp else "fp32 dense RPN/head (torch / MIOpen); ")
-            + "sparse convs bf16-split MFMA fwd/dX, fp32 MFMA dW",
-            data="synthetic",
+            dtype=main["dtype"], data="synthetic", fast_mode=fast,
             config=dict(workload="SECOND train step (BASELINE configs[2]): fwd + ProposalLoss + bwd + grad all-reduce + clip + Adam",
                         proposal_loss=("native fused pass (csrc/proposal_loss.hip)" if (fused_loss and native_dense) else "torch expressions"),
                         frames_per_gpu_per_step=bs, points_per_frame=args.points, parallelism=f"data-parallel x{world}, two-bucket all-reduce (dense bucket overlapped with the sparse backward)"),
-            roofline=roofline, cpu_baseline=cpu_baseline, torch_dense_fallbacks=int(model.torch_dense_fallbacks),
-            final_loss=float(loss))))
+            roofline=roofline, cpu_baseline=cpu_baseline, torch_dense_fallbacks=main["fallbacks"], final_loss=float(loss))))
     if world > 1:
         dist.destroy_process_group()
 
@@ -362,6 +387,38 @@ def train_roofline(bs, h=200, w=176):
                 traffic=None, traffic_note="PMC passes of this kernel: profiles/r03_a_pmc_dense_train.txt (2 x 58.8 MB fetched, 81.7 MB "
                                            "written per launch at bs = 8)",
                 note="bf16 operands, fp32 accumulate, one MFMA term per product (the autocast contract); dense bf16 peak 2.5 PFLOP/s")
+
+
+def train_roofline_split(bs, h=200, w=176):
+    """The dominant kernel of the fp32-class train step -- the 3x3 128 -> 128 bf16x3 convolution of csrc/dense_conv.hip on split
+    planes (12 launches per step: 6 forward + 6 data gradients) -- against the dense bf16 MFMA peak.  Algorithmic flops
+    2 * M * 128 * 128 * 9 per launch (the three terms of the split product are the arithmetic's price, not useful work) over the
+    average of 20 back-to-back launches between two HIP events on the launch stream."""
+    from vision3d_amd import _lib as L
+    from vision3d_amd.runtime import pack_conv_weight, split_planes_like, to_split_nhwc
+    lib = L.lib()
+    hi, lo = to_split_nhwc(torch.randn(bs, 128, h, w, device="cuda"))
+    img = pack_conv_weight(torch.randn(128, 128, 3, 3, device="cuda") / 34.0, None, "bf16x3")
+    y_hi, y_lo = split_planes_like(bs, h, w, 128, hi.device)
+    run = lambda: L.check(lib.v3d_conv2d_nhwc_bf16x3(L.ptr(hi), L.ptr(lo), L.ptr(img), None, 0, bs, h, w, 128, 128, 3, L.ptr(y_hi), L.ptr(y_lo),
+                                                     None, L.stream_ptr()), "conv")
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / 20
+    fl = 2.0 * bs * h * w * 128 * 128 * 9
+    io = 2 * 2 * 2.0 * bs * h * w * 128  # two planes in, two planes out, bf16
+    return dict(bound="mfma", kernel="conv2d_bf16x3_large_kernel<3>", launches_per_step=12, flops_per_launch=fl, avg_us=t * 1e6,
+                achieved=fl / t / 1e12, peak=2500.0, unit="TFLOP/s", frac=fl / t / 1e12 / 2500.0, issued_over_useful=3.0,
+                algorithmic_bytes_per_launch=io + 2 * 2.0 * 9 * 128 * 128,
+                hbm_view=dict(achieved_gbs=io / t / 1e9, frac=io / t / 1e9 / HBM_PEAK_GBS), traffic=None,
+                note="useful flops (one product per weight x activation pair) against the dense bf16 peak; the kernel issues three MFMA "
+                     "terms per product (hi*hi + hi*lo + lo*hi)")
 
 
 def train_cpu_baseline(model, cfg, cloud, tgt1, args):

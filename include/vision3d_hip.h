@@ -567,6 +567,19 @@ int v3d_dense_train_forward(const void* bev, int B, int H, int W, const v3d_dens
 int v3d_dense_train_backward(const void* bev, const float* dmaps, int B, int H, int W, const v3d_dense_train_layer* layers,
                              int n_layers, const float* head_weight, int O, void* arena, float* dhead_weight, float* dhead_bias,
                              void* dbev, v3d_stream_t stream);
+/* The same step in fp32-class arithmetic ("bf16x3"): what the reference's fp32 train.py:58-66 (no autocast) needs from the dense half.
+ * Every tensor is a split pair of bf16 NHWC planes (value = hi + lo: 16 significant bits), every product three MFMA terms with fp32
+ * accumulation (2^-17 per product; scale-free, so gradients need no calibration): convolutions and data gradients on
+ * v3d_conv2d_nhwc_bf16x3, the weight gradient as three passes of the bf16 kernel over (hi, hi), (hi, lo), (lo, hi), statistics /
+ * normalisation / head gradients in fp32 on hi + lo.  Same layer descriptors, same reductions (fixed order, bit-repeatable); O <= 16.
+ * bev_hi / bev_lo, dbev_hi / dbev_lo: (B, H, W, 128) bf16 planes; the backward reads the SAME bev planes and arena as the forward. */
+size_t v3d_dense_train_arena_bytes_split(int B, int H, int W, int n_layers, int O);
+int v3d_dense_train_forward_split(const void* bev_hi, const void* bev_lo, int B, int H, int W, const v3d_dense_train_layer* layers,
+                                  int n_layers, const float* head_weight, const float* head_bias, int O, void* arena, float* maps,
+                                  v3d_stream_t stream);
+int v3d_dense_train_backward_split(const void* bev_hi, const void* bev_lo, const float* dmaps, int B, int H, int W,
+                                   const v3d_dense_train_layer* layers, int n_layers, const float* head_weight, int O, void* arena,
+                                   float* dhead_weight, float* dhead_bias, void* dbev_hi, void* dbev_lo, v3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -115,8 +115,8 @@ def test_second_train_forward_hands_its_fused_maps_to_the_loss():
 def test_reference_fp32_script_reaches_the_native_dense_kernels_when_opted_in():
     """The reference's train.py:58-66 runs fp32 with no autocast.  With `model.dense_train_precision = "bf16"` the training forward
     enters bf16 autocast itself for the dense half: the step takes the native kernels (fused maps present, no torch fallback) and
-    loss / gradients equal those of the same step wrapped in autocast by the caller.  The default ("fp32") keeps the torch modules
-    and hands no fused maps over; a re-used item never carries maps of an earlier forward."""
+    loss / gradients equal those of the same step wrapped in autocast by the caller.  "torch" keeps the torch modules and hands no
+    fused maps over (the default, "bf16x3", is the native fp32-class step: tests/test_gpu_dense_train.py); a re-used item never carries maps of an earlier forward."""
     from vision3d_amd import synth
     from vision3d_amd.core import Preprocessor, ProposalTargetAssigner
     from vision3d_amd.detector import ProposalLoss, Second
@@ -139,7 +139,7 @@ def test_reference_fp32_script_reaches_the_native_dense_kernels_when_opted_in():
                 out = model(item)
                 losses = ProposalLoss(cfg)(out)
         else:
-            model.dense_train_precision = "bf16" if mode == "opt_in" else "fp32"
+            model.dense_train_precision = "bf16" if mode == "opt_in" else "torch"
             out = model(item)  # train.py:63 -- no autocast anywhere
             losses = ProposalLoss(cfg)(out)
         fused = "_head_maps" in out

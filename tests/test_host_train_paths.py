@@ -43,7 +43,7 @@ def test_plan_cache_evicts_the_oldest_geometry(monkeypatch):
     built = []
 
     class StubPlan(object):
-        def __init__(self, rpn, head, B, H, W, device):
+        def __init__(self, rpn, head, B, H, W, device, precision="bf16"):
             built.append((B, H, W))
 
         def parameters(self):
@@ -64,7 +64,7 @@ def test_plan_cache_evicts_the_oldest_geometry(monkeypatch):
     assert len(built) == n + 2
     assert [k[1][0] for k in cache] == list(range(3, n + 3))  # the two oldest geometries were dropped
     first = dense_train.train_head_maps(None, None, torch.zeros(n + 2, 128, 4, 4), cache)
-    assert len(built) == n + 2 and first is cache[("cpu", (n + 2, 128, 4, 4))]  # a cached geometry is reused
+    assert len(built) == n + 2 and first is cache[("cpu", (n + 2, 128, 4, 4), "bf16")]  # a cached geometry is reused
 
 
 def test_supported_refuses_frozen_batchnorm_and_cumulative_momentum():

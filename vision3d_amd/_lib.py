@@ -123,6 +123,9 @@ _SIGNATURES = {
     "v3d_dense_train_arena_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "v3d_dense_train_arena_init": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "v3d_dense_train_forward": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "v3d_dense_train_arena_bytes_split": (_sz, [_i, _i, _i, _i, _i]),
+    "v3d_dense_train_forward_split": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "v3d_dense_train_backward_split": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "v3d_dense_train_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -39,6 +39,29 @@ __device__ __forceinline__ void dt_unpack8(const dt_u32x4 v, float (&x)[8]) {
   }
 }
 
+// Split storage (the fp32-class training path, "bf16x3"): a tensor is TWO bf16 planes, value = hi + lo (hi = RNE(v), lo = RNE(v - hi):
+// 16 significant bits, the operand format of the 3-term products of csrc/dense_conv.hip).  The elementwise / reduction kernels below
+// take a nullable `lo` plane beside every bf16 tensor: null = the bf16-storage path, unchanged.
+__device__ __forceinline__ void dt_load8(const dt_bf16* __restrict__ hi, const dt_bf16* __restrict__ lo, long long off, float (&v)[8]) {
+  dt_unpack8(*reinterpret_cast<const dt_u32x4*>(hi + off), v);
+  if (lo) {
+    float w[8];
+    dt_unpack8(*reinterpret_cast<const dt_u32x4*>(lo + off), w);
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] += w[e];
+  }
+}
+__device__ __forceinline__ void dt_store8(dt_bf16* __restrict__ hi, dt_bf16* __restrict__ lo, long long off, const float (&v)[8]) {
+  const dt_u32x4 h = dt_u32x4{dt_pack2(v[0], v[1]), dt_pack2(v[2], v[3]), dt_pack2(v[4], v[5]), dt_pack2(v[6], v[7])};
+  *reinterpret_cast<dt_u32x4*>(hi + off) = h;
+  if (lo) {
+    float hv[8];
+    dt_unpack8(h, hv);
+    *reinterpret_cast<dt_u32x4*>(lo + off) = dt_u32x4{dt_pack2(v[0] - hv[0], v[1] - hv[1]), dt_pack2(v[2] - hv[2], v[3] - hv[3]),
+                                                      dt_pack2(v[4] - hv[4], v[5] - hv[5]), dt_pack2(v[6] - hv[6], v[7] - hv[7])};
+  }
+}
+
 #define DT_C 128          // channels of every RPN convolution (Cin = Cout)
 #define DT_BM 128         // pixels per tile
 #define DT_THREADS 512    // 4 matrix waves + 4 loader waves
@@ -695,9 +718,10 @@ extern "C" int v3d_dense_train_bn_finalize(const float* partial, int tiles, long
 }
 
 // y = relu((x - mean) * invstd * gamma + beta), bf16 NHWC -> bf16 NHWC.  thread = 8 channels of one pixel (16-byte load / store).
-__global__ __launch_bounds__(256) void dt_bn_relu_apply_kernel(const dt_bf16* __restrict__ x, long long M, const float* __restrict__ mean,
-                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, int relu, dt_bf16* __restrict__ y) {
+__global__ __launch_bounds__(256) void dt_bn_relu_apply_kernel(const dt_bf16* __restrict__ x, const dt_bf16* __restrict__ x_lo, long long M,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                                               dt_bf16* __restrict__ y, dt_bf16* __restrict__ y_lo) {
   const int c8 = threadIdx.x & 15;
   float sc[8], sh[8];
 #pragma unroll
@@ -708,13 +732,13 @@ __global__ __launch_bounds__(256) void dt_bn_relu_apply_kernel(const dt_bf16* __
   }
   for (long long m = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); m < M; m += (long long)gridDim.x * 16) {
     float v[8];
-    dt_unpack8(*reinterpret_cast<const dt_u32x4*>(x + m * DT_C + c8 * 8), v);
+    dt_load8(x, x_lo, m * DT_C + c8 * 8, v);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       v[e] = fmaf(v[e], sc[e], sh[e]);
       if (relu) v[e] = fmaxf(v[e], 0.f);
     }
-    *reinterpret_cast<dt_u32x4*>(y + m * DT_C + c8 * 8) = dt_u32x4{dt_pack2(v[0], v[1]), dt_pack2(v[2], v[3]), dt_pack2(v[4], v[5]), dt_pack2(v[6], v[7])};
+    dt_store8(y, y_lo, m * DT_C + c8 * 8, v);
   }
 }
 
@@ -723,7 +747,7 @@ extern "C" int v3d_dense_train_bn_relu_apply(const void* x, long long M, const f
   if (!x || !y || M < 1 || !mean || !invstd || !gamma || !beta) return V3D_EINVAL;
   const long long blocks = (M + 15) / 16;
   hipLaunchKernelGGL(dt_bn_relu_apply_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream,
-                     (const dt_bf16*)x, M, mean, invstd, gamma, beta, relu, (dt_bf16*)y);
+                     (const dt_bf16*)x, (const dt_bf16*)nullptr, M, mean, invstd, gamma, beta, relu, (dt_bf16*)y, (dt_bf16*)nullptr);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -733,7 +757,8 @@ extern "C" int v3d_dense_train_bn_relu_apply(const void* x, long long M, const f
 // Pass 1 (this kernel): per-block partial (sum g, sum g * x_hat) per channel, blocks in a fixed grid, thread = 8 channels of a pixel,
 // the 16 pixel rows of a block reduced through LDS in row order.
 #define DT_RED_BLOCKS 512
-__global__ __launch_bounds__(256) void dt_bn_bwd_reduce_kernel(const dt_bf16* __restrict__ x, const dt_bf16* __restrict__ dy, long long M,
+__global__ __launch_bounds__(256) void dt_bn_bwd_reduce_kernel(const dt_bf16* __restrict__ x, const dt_bf16* __restrict__ x_lo,
+                                                               const dt_bf16* __restrict__ dy, const dt_bf16* __restrict__ dy_lo, long long M,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                int relu, float* __restrict__ partial /*[blocks][2][128]*/) {
@@ -748,8 +773,8 @@ __global__ __launch_bounds__(256) void dt_bn_bwd_reduce_kernel(const dt_bf16* __
   }
   for (long long m = (long long)blockIdx.x * 16 + rg; m < M; m += (long long)gridDim.x * 16) {
     float xv[8], gv[8];
-    dt_unpack8(*reinterpret_cast<const dt_u32x4*>(x + m * DT_C + c8 * 8), xv);
-    dt_unpack8(*reinterpret_cast<const dt_u32x4*>(dy + m * DT_C + c8 * 8), gv);
+    dt_load8(x, x_lo, m * DT_C + c8 * 8, xv);
+    dt_load8(dy, dy_lo, m * DT_C + c8 * 8, gv);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const float xh = (xv[e] - mu[e]) * is[e];
@@ -781,11 +806,12 @@ __global__ __launch_bounds__(DT_COLSUM_THREADS) void dt_bn_bwd_finalize_kernel(c
   }
 }
 
-__global__ __launch_bounds__(256) void dt_bn_bwd_apply_kernel(const dt_bf16* __restrict__ x, const dt_bf16* __restrict__ dy, long long M,
+__global__ __launch_bounds__(256) void dt_bn_bwd_apply_kernel(const dt_bf16* __restrict__ x, const dt_bf16* __restrict__ x_lo,
+                                                              const dt_bf16* dy, const dt_bf16* dy_lo, long long M,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ dbeta, const float* __restrict__ dgamma, int relu,
-                                                              dt_bf16* __restrict__ dx) {
+                                                              dt_bf16* dx, dt_bf16* dx_lo) {
   const int c8 = threadIdx.x & 15;
   float mu[8], is[8], ga[8], be[8], k0[8], k1[8];
   const float inv_m = 1.f / (float)M;
@@ -798,15 +824,15 @@ __global__ __launch_bounds__(256) void dt_bn_bwd_apply_kernel(const dt_bf16* __r
   }
   for (long long m = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); m < M; m += (long long)gridDim.x * 16) {
     float xv[8], gv[8], o[8];
-    dt_unpack8(*reinterpret_cast<const dt_u32x4*>(x + m * DT_C + c8 * 8), xv);
-    dt_unpack8(*reinterpret_cast<const dt_u32x4*>(dy + m * DT_C + c8 * 8), gv);
+    dt_load8(x, x_lo, m * DT_C + c8 * 8, xv);
+    dt_load8(dy, dy_lo, m * DT_C + c8 * 8, gv);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const float xh = (xv[e] - mu[e]) * is[e];
       const float g = (!relu || fmaf(xh, ga[e], be[e]) > 0.f) ? gv[e] : 0.f;
       o[e] = ga[e] * is[e] * (g - k0[e] - xh * k1[e]);
     }
-    *reinterpret_cast<dt_u32x4*>(dx + m * DT_C + c8 * 8) = dt_u32x4{dt_pack2(o[0], o[1]), dt_pack2(o[2], o[3]), dt_pack2(o[4], o[5]), dt_pack2(o[6], o[7])};
+    dt_store8(dx, dx_lo, m * DT_C + c8 * 8, o);
   }
 }
 
@@ -814,22 +840,60 @@ extern "C" size_t v3d_dense_train_bn_bwd_workspace(void) { return (size_t)DT_RED
 
 // x: the layer's raw convolution output (bf16 NHWC), dy: gradient w.r.t. the post-ReLU output -> dx (gradient w.r.t. x, bf16 NHWC;
 // may alias dy), dgamma, dbeta (fp32).
-extern "C" int v3d_dense_train_bn_relu_bwd(const void* x, const void* dy, long long M, const float* mean, const float* invstd,
-                                           const float* gamma, const float* beta, int relu, void* dx, float* dgamma, float* dbeta,
-                                           void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
+// (x_lo / dy_lo / dx_lo: the lo planes of split storage, all three or none)
+static int dt_bn_relu_bwd(const void* x, const void* x_lo, const void* dy, const void* dy_lo, long long M, const float* mean,
+                          const float* invstd, const float* gamma, const float* beta, int relu, void* dx, void* dx_lo, float* dgamma,
+                          float* dbeta, void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
   if (!x || !dy || !dx || M < 1 || !mean || !invstd || !gamma || !beta || !dgamma || !dbeta || !workspace) return V3D_EINVAL;
   if (workspace_bytes < v3d_dense_train_bn_bwd_workspace()) return V3D_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const long long want = (M + 15) / 16;
   const int blocks = (int)(want < DT_RED_BLOCKS ? want : DT_RED_BLOCKS);
   float* partial = (float*)workspace;
-  hipLaunchKernelGGL(dt_bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const dt_bf16*)x, (const dt_bf16*)dy, M, mean, invstd, gamma,
-                     beta, relu, partial);
+  hipLaunchKernelGGL(dt_bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const dt_bf16*)x, (const dt_bf16*)x_lo, (const dt_bf16*)dy,
+                     (const dt_bf16*)dy_lo, M, mean, invstd, gamma, beta, relu, partial);
   hipLaunchKernelGGL(dt_bn_bwd_finalize_kernel, dim3(2 * DT_C / 32), dim3(DT_COLSUM_THREADS), 0, st, partial, blocks, dbeta, dgamma);
-  hipLaunchKernelGGL(dt_bn_bwd_apply_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, st, (const dt_bf16*)x, (const dt_bf16*)dy, M,
-                     mean, invstd, gamma, beta, dbeta, dgamma, relu, (dt_bf16*)dx);
+  hipLaunchKernelGGL(dt_bn_bwd_apply_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, st, (const dt_bf16*)x, (const dt_bf16*)x_lo,
+                     (const dt_bf16*)dy, (const dt_bf16*)dy_lo, M, mean, invstd, gamma, beta, dbeta, dgamma, relu, (dt_bf16*)dx, (dt_bf16*)dx_lo);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
+}
+
+extern "C" int v3d_dense_train_bn_relu_bwd(const void* x, const void* dy, long long M, const float* mean, const float* invstd,
+                                           const float* gamma, const float* beta, int relu, void* dx, float* dgamma, float* dbeta,
+                                           void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
+  return dt_bn_relu_bwd(x, nullptr, dy, nullptr, M, mean, invstd, gamma, beta, relu, dx, nullptr, dgamma, dbeta, workspace, workspace_bytes,
+                        stream);
+}
+
+// Batch statistics of a split tensor: per-block partial (sum x, sum x^2) per channel in the layout dt_bn_finalize_kernel reduces
+// (the bf16-storage path gets them from the convolution's epilogue; the split path's convolutions are csrc/dense_conv.hip's).
+__global__ __launch_bounds__(256) void dt_bn_stats_kernel(const dt_bf16* __restrict__ x, const dt_bf16* __restrict__ x_lo, long long M,
+                                                          float* __restrict__ partial /*[blocks][2][128]*/) {
+  __shared__ float red[16][2][DT_C];
+  const int c8 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) s1[e] = s2[e] = 0.f;
+  for (long long m = (long long)blockIdx.x * 16 + rg; m < M; m += (long long)gridDim.x * 16) {
+    float xv[8];
+    dt_load8(x, x_lo, m * DT_C + c8 * 8, xv);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      s1[e] += xv[e];
+      s2[e] = fmaf(xv[e], xv[e], s2[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    red[rg][0][c8 * 8 + e] = s1[e];
+    red[rg][1][c8 * 8 + e] = s2[e];
+  }
+  __syncthreads();
+  const int which = threadIdx.x / DT_C, c = threadIdx.x % DT_C;
+  float a = 0.f;
+  for (int g = 0; g < 16; g++) a += red[g][which][c];
+  partial[((size_t)blockIdx.x * 2 + which) * DT_C + c] = a;
 }
 
 #define DT_WG_SLABS 64
@@ -1054,7 +1118,7 @@ __global__ __launch_bounds__(256) void dt_head_fwd_kernel(const dt_bf16* __restr
 // dFeat[m][c] = sum_o dP[b][o][pix] * W[o][c]  (bf16 NHWC out)
 template <int O>  // compile-time: the per-pixel gradient vector stays in registers
 __global__ __launch_bounds__(256) void dt_head_bwd_data_kernel(const float* __restrict__ dmaps, long long M, int HW, const float* __restrict__ w,
-                                                               dt_bf16* __restrict__ dfeat) {
+                                                               dt_bf16* __restrict__ dfeat, dt_bf16* __restrict__ dfeat_lo) {
   __shared__ float ws[O * DT_C];
   for (int i = threadIdx.x; i < O * DT_C; i += 256) ws[i] = w[i];
   __syncthreads();
@@ -1070,7 +1134,7 @@ __global__ __launch_bounds__(256) void dt_head_bwd_data_kernel(const float* __re
       for (int o = 0; o < O; o++)
 #pragma unroll
         for (int e = 0; e < 8; e++) a[e] = fmaf(g[o], ws[o * DT_C + p * 8 + e], a[e]);
-      *reinterpret_cast<dt_u32x4*>(dfeat + m * DT_C + p * 8) = dt_u32x4{dt_pack2(a[0], a[1]), dt_pack2(a[2], a[3]), dt_pack2(a[4], a[5]), dt_pack2(a[6], a[7])};
+      dt_store8(dfeat, dfeat_lo, m * DT_C + p * 8, a);
     }
   }
 }
@@ -1079,8 +1143,9 @@ __global__ __launch_bounds__(256) void dt_head_bwd_data_kernel(const float* __re
 #define DT_HEAD_PX 512
 #define DT_HEAD_BLOCKS 1024
 template <int O>  // even
-__global__ __launch_bounds__(256) void dt_head_bwd_weight_kernel(const dt_bf16* __restrict__ feat, const float* __restrict__ dmaps, long long M,
-                                                                 int HW, float* __restrict__ partial /*[blocks][O + 1][128]*/) {
+__global__ __launch_bounds__(256) void dt_head_bwd_weight_kernel(const dt_bf16* __restrict__ feat, const dt_bf16* __restrict__ feat_lo,
+                                                                 const float* __restrict__ dmaps, long long M, int HW,
+                                                                 float* __restrict__ partial /*[blocks][O + 1][128]*/) {
   __shared__ float gs[64][O + 1];
   const int c = threadIdx.x & 127, oh = threadIdx.x >> 7;
   const int o_lo = oh * (O / 2);
@@ -1103,7 +1168,7 @@ __global__ __launch_bounds__(256) void dt_head_bwd_weight_kernel(const dt_bf16* 
     __syncthreads();
     const int npx = (int)min((long long)64, M - m0);
     for (int px = 0; px < npx; px++) {
-      const float fv = dt_to_f32(feat[(m0 + px) * DT_C + c]);
+      const float fv = dt_to_f32(feat[(m0 + px) * DT_C + c]) + (feat_lo ? dt_to_f32(feat_lo[(m0 + px) * DT_C + c]) : 0.f);
 #pragma unroll
       for (int i = 0; i < O / 2; i++) acc[i] = fmaf(gs[px][o_lo + i], fv, acc[i]);
       if (oh == 0 && c < O) db += gs[px][c];
@@ -1146,8 +1211,14 @@ extern "C" int v3d_dense_train_head_fwd(const void* feat, int B, int H, int W, c
 }
 
 // dmaps fp32 (B, O, H, W) -> dfeat bf16 NHWC, dweight (O, 128), dbias (O)
+static int dt_head_bwd(const void* feat, const void* feat_lo, const float* dmaps, int B, int H, int W, const float* weight, int O, void* dfeat,
+                       void* dfeat_lo, float* dweight, float* dbias, void* workspace, size_t workspace_bytes, v3d_stream_t stream);
 extern "C" int v3d_dense_train_head_bwd(const void* feat, const float* dmaps, int B, int H, int W, const float* weight, int O, void* dfeat,
                                         float* dweight, float* dbias, void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
+  return dt_head_bwd(feat, nullptr, dmaps, B, H, W, weight, O, dfeat, nullptr, dweight, dbias, workspace, workspace_bytes, stream);
+}
+static int dt_head_bwd(const void* feat, const void* feat_lo, const float* dmaps, int B, int H, int W, const float* weight, int O, void* dfeat,
+                       void* dfeat_lo, float* dweight, float* dbias, void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
   if (!feat || !dmaps || !weight || !dfeat || !dweight || !dbias || !workspace || B < 1 || H < 1 || W < 1 || O < 1 || O > DT_HEAD_MAX)
     return V3D_EINVAL;
   if (workspace_bytes < v3d_dense_train_head_workspace(O)) return V3D_EWORKSPACE;
@@ -1159,8 +1230,8 @@ extern "C" int v3d_dense_train_head_bwd(const void* feat, const float* dmaps, in
   const unsigned db_ = (unsigned)(blocks < 2048 ? blocks : 2048);
 #define DT_HEAD_CASE(OV)                                                                                                              \
   if (O == OV) {                                                                                                                      \
-    hipLaunchKernelGGL(dt_head_bwd_data_kernel<OV>, dim3(db_), dim3(256), 0, st, dmaps, M, H * W, weight, (dt_bf16*)dfeat);            \
-    hipLaunchKernelGGL(dt_head_bwd_weight_kernel<OV>, dim3(wb), dim3(256), 0, st, (const dt_bf16*)feat, dmaps, M, H * W, (float*)workspace); \
+    hipLaunchKernelGGL(dt_head_bwd_data_kernel<OV>, dim3(db_), dim3(256), 0, st, dmaps, M, H * W, weight, (dt_bf16*)dfeat, (dt_bf16*)dfeat_lo); \
+    hipLaunchKernelGGL(dt_head_bwd_weight_kernel<OV>, dim3(wb), dim3(256), 0, st, (const dt_bf16*)feat, (const dt_bf16*)feat_lo, dmaps, M, H * W, (float*)workspace); \
   } else
   DT_HEAD_CASE(8) DT_HEAD_CASE(16) DT_HEAD_CASE(24) DT_HEAD_CASE(32) DT_HEAD_CASE(48) DT_HEAD_CASE(64) return V3D_EUNSUPPORTED;
 #undef DT_HEAD_CASE
@@ -1279,6 +1350,183 @@ extern "C" int v3d_dense_train_backward(const void* bev, const float* dmaps, int
     void* img = base + a.off_img + (size_t)(2 * l + 1) * img_stride;  // packed by the forward call
     void* out = l == 0 ? dbev : g[cur ^ 1];
     DT_TRY(v3d_dense_train_conv(g[cur], img, B, H, W, L.ksize, out, nullptr, stream));
+    cur ^= 1;
+  }
+  return V3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the same step, fp32-class ("bf16x3")
+// The reference's train.py:58-66 runs the dense half in fp32 (no autocast).  This variant keeps EVERY tensor of the step as a
+// split pair (hi + lo bf16 planes: 16 significant bits) and evaluates every product with three MFMA terms (hi*hi + hi*lo + lo*hi,
+// fp32 accumulation: 2^-17 per product, scale-free -- gradients need no calibration):
+//   convolutions, forward and data gradient   csrc/dense_conv.hip's bf16x3 kernels (the inference RPN's), raw output, no epilogue;
+//                                             the data gradient is the same convolution on the channel-swapped, tap-flipped weights
+//   weight gradient                           dt_wgrad_kernel three times -- (x_hi, dy_hi), (x_hi, dy_lo), (x_lo, dy_hi) -- into three
+//                                             sets of slab partials, summed by one fixed-order reduction
+//   batch statistics, BN + ReLU, their        the kernels above on hi + lo (fp32 arithmetic; statistics from the stored values,
+//   backward, the head's gradients            fixed-order two-level reductions as before)
+//   head forward                              dense_conv.hip's 1x1 stream kernel (bias, fp32 NCHW maps)
+// About 2.4x the traffic and 3x the matrix work of the bf16-storage step; no tensor of it ever exists in reduced precision.
+__global__ __launch_bounds__(256) void dt_wt_flip_kernel(const float* __restrict__ w, int taps, float* __restrict__ wt) {
+  const int total = DT_C * DT_C * taps;  // wt[ci][co][t] = w[co][ci][taps - 1 - t]
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int t = i % taps, co = (i / taps) % DT_C, ci = i / (taps * DT_C);
+    wt[i] = w[((size_t)co * DT_C + ci) * taps + (taps - 1 - t)];
+  }
+}
+
+// dt_wgrad_reduce_kernel for any number of slab partials: thread (co, g) sums slabs g, g + 8, ... in that order, the eight group
+// sums are combined in the same fixed tree.
+__global__ __launch_bounds__(1024) void dt_wgrad_reduce_any_kernel(const float* __restrict__ partial, int slabs, int taps, float* __restrict__ dw) {
+  __shared__ float grp[8][3][DT_C];
+  const int ci = blockIdx.x, a0 = blockIdx.y * 3, na = taps - a0 < 3 ? taps - a0 : 3;
+  const int co = threadIdx.x & (DT_C - 1), g = threadIdx.x >> 7;
+  const size_t total = (size_t)taps * DT_C * DT_C;
+  for (int a = 0; a < na; a++) {
+    float v = 0.f;
+    for (int s = g; s < slabs; s += 8) v += partial[(size_t)s * total + ((size_t)(a0 + a) * DT_C + ci) * DT_C + co];
+    grp[g][a][co] = v;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < DT_C * na; idx += 1024) {
+    const int c = idx / na, a = idx - c * na;
+    const float v = ((grp[0][a][c] + grp[1][a][c]) + (grp[2][a][c] + grp[3][a][c])) + ((grp[4][a][c] + grp[5][a][c]) + (grp[6][a][c] + grp[7][a][c]));
+    dw[((size_t)c * DT_C + ci) * taps + a0 + a] = v;
+  }
+}
+
+static int dt_wgrad_split(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, int B, int H, int W, int ksize, float* dw,
+                          void* workspace, size_t workspace_bytes, hipStream_t st) {
+  if (workspace_bytes < 3 * v3d_dense_train_wgrad_workspace(ksize)) return V3D_EWORKSPACE;
+  const long long tiles = (long long)B * ((H + DT3_TH - 1) / DT3_TH) * ((W + DT3_TW - 1) / DT3_TW);
+  const int slabs = (int)(tiles < DT_WG_SLABS ? tiles : DT_WG_SLABS), taps = ksize * ksize;
+  float* partial = (float*)workspace;
+  const size_t term = (size_t)slabs * taps * DT_C * DT_C;
+  static V3dPerDeviceFlag attr9, attr1;
+  V3D_CHECK_HIP(v3d_set_max_lds(attr9, (const void*)dt_wgrad_kernel<9>, DT_W2_SMEM));
+  V3D_CHECK_HIP(v3d_set_max_lds(attr1, (const void*)dt_wgrad_kernel<1>, DT_W2_SMEM));
+  const void* xs[3] = {x_hi, x_hi, x_lo};
+  const void* ys[3] = {dy_hi, dy_lo, dy_hi};
+  for (int t = 0; t < 3; t++) {
+    if (ksize == 3)
+      hipLaunchKernelGGL(dt_wgrad_kernel<9>, dim3(4 * slabs), dim3(768), DT_W2_SMEM, st, (const dt_bf16*)xs[t], (const dt_bf16*)ys[t], B, H, W,
+                         slabs, partial + t * term);
+    else
+      hipLaunchKernelGGL(dt_wgrad_kernel<1>, dim3(4 * slabs), dim3(768), DT_W2_SMEM, st, (const dt_bf16*)xs[t], (const dt_bf16*)ys[t], B, H, W,
+                         slabs, partial + t * term);
+  }
+  hipLaunchKernelGGL(dt_wgrad_reduce_any_kernel, dim3(DT_C, (taps + 2) / 3), dim3(1024), 0, st, partial, 3 * slabs, taps, dw);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+struct DtArenaS {
+  size_t plane;  // one bf16 plane of an activation
+  size_t off_raw, off_act, off_stat, off_partial, off_img, off_himg, off_wt, off_g0, off_g1, off_ws, img, total;
+};
+static DtArenaS dt_arena_layout_split(int B, int H, int W, int n_layers, int O) {
+  DtArenaS a;
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  a.plane = up((size_t)B * H * W * DT_C * 2);
+  a.img = up(v3d_conv2d_weight_image_bytes(DT_C, DT_C, 3));
+  size_t o = 0;
+  a.off_raw = o; o += (size_t)n_layers * 2 * a.plane;
+  a.off_act = o; o += (size_t)n_layers * 2 * a.plane;
+  a.off_stat = o; o += up((size_t)n_layers * 2 * DT_C * 4);
+  a.off_partial = o; o += up((size_t)DT_RED_BLOCKS * 2 * DT_C * 4);
+  a.off_img = o; o += (size_t)n_layers * 2 * a.img;
+  a.off_himg = o; o += up(v3d_conv2d_weight_image_bytes(DT_C, O, 1));
+  a.off_wt = o; o += up((size_t)9 * DT_C * DT_C * 4);
+  a.off_g0 = o; o += 2 * a.plane;
+  a.off_g1 = o; o += 2 * a.plane;
+  size_t ws = 3 * v3d_dense_train_wgrad_workspace(3);
+  if (v3d_dense_train_head_workspace(O) > ws) ws = v3d_dense_train_head_workspace(O);
+  if (v3d_dense_train_bn_bwd_workspace() > ws) ws = v3d_dense_train_bn_bwd_workspace();
+  a.off_ws = o; o += up(ws);
+  a.total = o;
+  return a;
+}
+
+extern "C" size_t v3d_dense_train_arena_bytes_split(int B, int H, int W, int n_layers, int O) {
+  if (B < 1 || H < 1 || W < 1 || n_layers < 1 || O < 1) return 0;
+  return dt_arena_layout_split(B, H, W, n_layers, O).total;
+}
+
+// bev: split NHWC planes (B, H, W, 128) -> maps fp32 (B, O, H, W)
+extern "C" int v3d_dense_train_forward_split(const void* bev_hi, const void* bev_lo, int B, int H, int W, const v3d_dense_train_layer* layers,
+                                             int n_layers, const float* head_weight, const float* head_bias, int O, void* arena, float* maps,
+                                             v3d_stream_t stream) {
+  if (!bev_hi || !bev_lo || !layers || !arena || !maps || !head_weight || n_layers < 1 || n_layers > 16 || O < 1 || O > 16) return V3D_EINVAL;
+  if ((long long)B * H * W > 0x7FFFFFF0ll / DT_C) return V3D_EINVAL;
+  const DtArenaS a = dt_arena_layout_split(B, H, W, n_layers, O);
+  unsigned char* base = (unsigned char*)arena;
+  const long long M = (long long)B * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  float* wt = (float*)(base + a.off_wt);
+  for (int l = 0; l < n_layers; l++) {  // image 2 l: forward, 2 l + 1: the data gradient's (read by the backward call of this step)
+    const v3d_dense_train_layer& L = layers[l];
+    if (!L.weight || !L.gamma || !L.beta || (L.ksize != 1 && L.ksize != 3)) return V3D_EINVAL;
+    DT_TRY(v3d_conv2d_pack_weights(L.weight, nullptr, DT_C, DT_C, L.ksize, base + a.off_img + (size_t)(2 * l) * a.img, stream));
+    hipLaunchKernelGGL(dt_wt_flip_kernel, dim3(64), dim3(256), 0, st, L.weight, L.ksize * L.ksize, wt);
+    DT_TRY(v3d_conv2d_pack_weights(wt, nullptr, DT_C, DT_C, L.ksize, base + a.off_img + (size_t)(2 * l + 1) * a.img, stream));
+  }
+  DT_TRY(v3d_conv2d_pack_weights(head_weight, nullptr, O, DT_C, 1, base + a.off_himg, stream));
+  const long long want = (M + 15) / 16;
+  const int blocks = (int)(want < DT_RED_BLOCKS ? want : DT_RED_BLOCKS);
+  float* partial = (float*)(base + a.off_partial);
+  const void *x_hi = bev_hi, *x_lo = bev_lo;
+  for (int l = 0; l < n_layers; l++) {
+    const v3d_dense_train_layer& L = layers[l];
+    unsigned char* raw = base + a.off_raw + (size_t)l * 2 * a.plane;
+    unsigned char* act = base + a.off_act + (size_t)l * 2 * a.plane;
+    float* mean = (float*)(base + a.off_stat) + (size_t)l * 2 * DT_C;
+    DT_TRY(v3d_conv2d_nhwc_bf16x3(x_hi, x_lo, base + a.off_img + (size_t)(2 * l) * a.img, nullptr, 0, B, H, W, DT_C, DT_C, L.ksize, raw,
+                                  raw + a.plane, nullptr, stream));
+    hipLaunchKernelGGL(dt_bn_stats_kernel, dim3(blocks), dim3(256), 0, st, (const dt_bf16*)raw, (const dt_bf16*)(raw + a.plane), M, partial);
+    DT_TRY(v3d_dense_train_bn_finalize(partial, blocks, M, L.eps, L.momentum, mean, mean + DT_C, L.running_mean, L.running_var,
+                                       L.num_batches_tracked, stream));
+    const long long ab = (M + 15) / 16;
+    hipLaunchKernelGGL(dt_bn_relu_apply_kernel, dim3((unsigned)(ab < 4096 ? ab : 4096)), dim3(256), 0, st, (const dt_bf16*)raw,
+                       (const dt_bf16*)(raw + a.plane), M, mean, mean + DT_C, L.gamma, L.beta, 1, (dt_bf16*)act, (dt_bf16*)(act + a.plane));
+    x_hi = act;
+    x_lo = act + a.plane;
+  }
+  V3D_CHECK_LAUNCH();
+  return v3d_conv2d_nhwc_bf16x3(x_hi, x_lo, base + a.off_himg, head_bias, 0, B, H, W, DT_C, O, 1, nullptr, nullptr, maps, stream);
+}
+
+// dmaps fp32 (B, O, H, W) -> gradients of every layer, of the head, and of the input (dbev: split NHWC planes)
+extern "C" int v3d_dense_train_backward_split(const void* bev_hi, const void* bev_lo, const float* dmaps, int B, int H, int W,
+                                              const v3d_dense_train_layer* layers, int n_layers, const float* head_weight, int O, void* arena,
+                                              float* dhead_weight, float* dhead_bias, void* dbev_hi, void* dbev_lo, v3d_stream_t stream) {
+  if (!bev_hi || !bev_lo || !dmaps || !layers || !arena || !head_weight || !dhead_weight || !dhead_bias || !dbev_hi || !dbev_lo || n_layers < 1 ||
+      n_layers > 16 || O < 1 || O > 16)
+    return V3D_EINVAL;
+  const DtArenaS a = dt_arena_layout_split(B, H, W, n_layers, O);
+  unsigned char* base = (unsigned char*)arena;
+  const long long M = (long long)B * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  void* ws = base + a.off_ws;
+  const size_t ws_bytes = a.total - a.off_ws;
+  unsigned char* g[2] = {base + a.off_g0, base + a.off_g1};
+  const unsigned char* feat = base + a.off_act + (size_t)(n_layers - 1) * 2 * a.plane;
+  DT_TRY(dt_head_bwd(feat, feat + a.plane, dmaps, B, H, W, head_weight, O, g[0], g[0] + a.plane, dhead_weight, dhead_bias, ws, ws_bytes, stream));
+  int cur = 0;  // g[cur] = gradient w.r.t. the post-ReLU output of layer l
+  for (int l = n_layers - 1; l >= 0; l--) {
+    const v3d_dense_train_layer& L = layers[l];
+    if (!L.grad_weight || !L.grad_gamma || !L.grad_beta) return V3D_EINVAL;
+    const unsigned char* raw = base + a.off_raw + (size_t)l * 2 * a.plane;
+    const void* xin_hi = l == 0 ? bev_hi : (const void*)(base + a.off_act + (size_t)(l - 1) * 2 * a.plane);
+    const void* xin_lo = l == 0 ? bev_lo : (const void*)(base + a.off_act + (size_t)(l - 1) * 2 * a.plane + a.plane);
+    const float* mean = (const float*)(base + a.off_stat) + (size_t)l * 2 * DT_C;
+    // gradient w.r.t. the raw convolution output, in place
+    DT_TRY(dt_bn_relu_bwd(raw, raw + a.plane, g[cur], g[cur] + a.plane, M, mean, mean + DT_C, L.gamma, L.beta, 1, g[cur], g[cur] + a.plane,
+                          L.grad_gamma, L.grad_beta, ws, ws_bytes, stream));
+    DT_TRY(dt_wgrad_split(xin_hi, xin_lo, g[cur], g[cur] + a.plane, B, H, W, L.ksize, L.grad_weight, ws, ws_bytes, st));
+    void* out_hi = l == 0 ? dbev_hi : (void*)g[cur ^ 1];
+    void* out_lo = l == 0 ? dbev_lo : (void*)(g[cur ^ 1] + a.plane);
+    DT_TRY(v3d_conv2d_nhwc_bf16x3(g[cur], g[cur] + a.plane, base + a.off_img + (size_t)(2 * l + 1) * a.img, nullptr, 0, B, H, W, DT_C, DT_C,
+                                  L.ksize, out_hi, out_lo, nullptr, stream));
     cur ^= 1;
   }
   return V3D_OK;

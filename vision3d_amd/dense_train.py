@@ -6,6 +6,14 @@ The RPN (7 x [Conv2d 128 -> 128 + BatchNorm2d(batch statistics) + ReLU], vision3
 `torch.autocast(bfloat16)` -- which is how rounds 1-2 ran it, through MIOpen.  `DenseTrainFunction` is the autograd node;
 `Second.forward` takes this path in training mode under bf16 autocast when the shapes are the ones the kernels are built for
 (`supported()`), otherwise the torch modules run as before.
+
+Two arithmetics (`precision`):
+  "bf16"    bf16 storage, one MFMA term per product: the contract of `torch.autocast(bfloat16)`; input = bf16 channels_last map.
+  "bf16x3"  the fp32 step of the reference's train.py:58-66 (no autocast anywhere): every tensor of the step is a split pair of bf16
+            planes (hi + lo, 16 significant bits), every product three MFMA terms with fp32 accumulation (2^-17 per product, no
+            scales to calibrate), statistics / normalisation / head gradients in fp32 on hi + lo
+            (`v3d_dense_train_forward_split / _backward_split`); input = the fp32 BEV map, gradient returned in fp32.
+            What `Second.forward` runs for a training step OUTSIDE autocast: no MIOpen convolution in the step.
 """
 import ctypes as C
 
@@ -25,18 +33,21 @@ def rpn_pairs(rpn):
     return convs, bns, len(convs) + len(bns) == len(mods)
 
 
-def supported(rpn, head, bev):
-    return why_unsupported(rpn, head, bev) is None
+def supported(rpn, head, bev, precision="bf16"):
+    return why_unsupported(rpn, head, bev, precision) is None
 
 
-def why_unsupported(rpn, head, bev):
+def why_unsupported(rpn, head, bev, precision="bf16"):
     """None when the kernels cover the stack, else the reason.  Covered: bf16 channels_last CUDA input with 128 channels; every
     RPN conv 128 -> 128, 3x3 (pad 1 / ZeroPad2d + pad 0) or 1x1, stride 1, bias-free, fp32 weights, each followed by a
     BatchNorm2d (affine, in TRAINING mode with a numeric momentum: the kernels always normalise with batch statistics and update
     the running statistics by `momentum`; fp32 running statistics on the input's device) + ReLU; head = two biased fp32 1x1
     convs with 8 * n <= 64 fused outputs."""
-    if not (bev.is_cuda and bev.dtype == torch.bfloat16 and bev.dim() == 4 and bev.shape[1] == 128 and bev.shape[3] >= 4
-            and bev.is_contiguous(memory_format=torch.channels_last)):
+    if precision == "bf16x3":
+        if not (bev.is_cuda and bev.dtype == torch.float32 and bev.dim() == 4 and bev.shape[1] == 128 and bev.shape[3] >= 4):
+            return "input is not an fp32 CUDA map with 128 channels"
+    elif not (bev.is_cuda and bev.dtype == torch.bfloat16 and bev.dim() == 4 and bev.shape[1] == 128 and bev.shape[3] >= 4
+              and bev.is_contiguous(memory_format=torch.channels_last)):
         return "input is not a bf16 channels_last CUDA map with 128 channels"
     convs, bns, clean = rpn_pairs(rpn)
     if not clean or len(convs) != len(bns) or not convs or len(convs) > 16:
@@ -77,23 +88,30 @@ def why_unsupported(rpn, head, bev):
             return "head parameters are not fp32 tensors on the input's device"
     if (head.conv_cls.out_channels + head.conv_reg.out_channels) not in (8, 16, 24, 32, 48, 64):
         return "fused head width is not one of 8, 16, 24, 32, 48, 64"
+    if precision == "bf16x3" and head.conv_cls.out_channels + head.conv_reg.out_channels > 16:
+        return "fused head wider than 16 channels (the split path's head kernel)"
     return None
 
 
 class DenseTrainPlan(object):
     """Arena + parameter plumbing for one (B, H, W) geometry.  The arena carries the activations of ONE forward to its backward."""
 
-    def __init__(self, rpn, head, B, H, W, device):
+    def __init__(self, rpn, head, B, H, W, device, precision="bf16"):
         self.rpn, self.head = rpn, head
         self.convs, self.bns, _ = rpn_pairs(rpn)
         self.B, self.H, self.W, self.device = int(B), int(H), int(W), device
         self.O = head.conv_cls.out_channels + head.conv_reg.out_channels
+        self.split = precision == "bf16x3"
         lib = L.lib()
-        n = int(lib.v3d_dense_train_arena_bytes(self.B, self.H, self.W, len(self.convs), self.O))
-        self.arena = torch.empty(n, dtype=torch.uint8, device=device)
-        with torch.cuda.device(device):
-            L.check(lib.v3d_dense_train_arena_init(L.ptr(self.arena), self.B, self.H, self.W, len(self.convs), self.O, L.stream_ptr()),
-                    "dense_train_arena_init")
+        if self.split:
+            n = int(lib.v3d_dense_train_arena_bytes_split(self.B, self.H, self.W, len(self.convs), self.O))
+            self.arena = torch.empty(n, dtype=torch.uint8, device=device)
+        else:
+            n = int(lib.v3d_dense_train_arena_bytes(self.B, self.H, self.W, len(self.convs), self.O))
+            self.arena = torch.empty(n, dtype=torch.uint8, device=device)
+            with torch.cuda.device(device):
+                L.check(lib.v3d_dense_train_arena_init(L.ptr(self.arena), self.B, self.H, self.W, len(self.convs), self.O, L.stream_ptr()),
+                        "dense_train_arena_init")
         self.generation = 0
 
     def parameters(self):
@@ -132,13 +150,21 @@ class DenseTrainPlan(object):
         return w.float().contiguous(), b.float().contiguous()
 
     def forward(self, bev):
-        """bev bf16 (B, 128, H, W) channels_last -> fused head maps fp32 (B, O, H, W)."""
+        """bev bf16 (B, 128, H, W) channels_last [split plan: fp32 (B, 128, H, W)] -> fused head maps fp32 (B, O, H, W)."""
         maps = torch.empty((self.B, self.O, self.H, self.W), dtype=torch.float32, device=self.device)
         self._hw, self._hb = self._head()
         io = self._io()
         with torch.cuda.device(self.device):
-            L.check(L.lib().v3d_dense_train_forward(L.ptr(bev), self.B, self.H, self.W, io, len(self.convs), L.ptr(self._hw), L.ptr(self._hb),
-                                                    self.O, L.ptr(self.arena), L.ptr(maps), L.stream_ptr()), "dense_train_forward")
+            if self.split:
+                from .runtime import to_split_nhwc
+                bev = to_split_nhwc(bev.float().contiguous())  # (hi, lo) bf16 NHWC planes, kept for the backward (weight gradient)
+                L.check(L.lib().v3d_dense_train_forward_split(L.ptr(bev[0]), L.ptr(bev[1]), self.B, self.H, self.W, io, len(self.convs),
+                                                              L.ptr(self._hw), L.ptr(self._hb), self.O, L.ptr(self.arena), L.ptr(maps),
+                                                              L.stream_ptr()), "dense_train_forward_split")
+            else:
+                L.check(L.lib().v3d_dense_train_forward(L.ptr(bev), self.B, self.H, self.W, io, len(self.convs), L.ptr(self._hw),
+                                                        L.ptr(self._hb), self.O, L.ptr(self.arena), L.ptr(maps), L.stream_ptr()),
+                        "dense_train_forward")
         stats = [t for b in self.bns if b.track_running_stats and b.running_mean is not None
                  for t in (b.running_mean, b.running_var, b.num_batches_tracked)]
         if stats:  # updated through raw pointers: bump the version counters (host side only)
@@ -158,12 +184,20 @@ class DenseTrainPlan(object):
             grads.append(flat[off:off + p.numel()].view(p.shape))
             off += p.numel()
         dhw, dhb = flat[off:off + self.O * 128].view(self.O, 128), flat[off + self.O * 128:off + self.O * 129]
-        dbev = torch.empty((self.B, 128, self.H, self.W), dtype=torch.bfloat16, device=self.device, memory_format=torch.channels_last)
         io = self._io(grads)
         with torch.cuda.device(self.device):
-            L.check(L.lib().v3d_dense_train_backward(L.ptr(self._bev), L.ptr(dmaps), self.B, self.H, self.W, io, len(self.convs),
-                                                     L.ptr(self._hw), self.O, L.ptr(self.arena), L.ptr(dhw), L.ptr(dhb), L.ptr(dbev),
-                                                     L.stream_ptr()), "dense_train_backward")
+            if self.split:
+                planes = torch.empty((2, self.B, self.H, self.W, 128), dtype=torch.bfloat16, device=self.device)
+                L.check(L.lib().v3d_dense_train_backward_split(L.ptr(self._bev[0]), L.ptr(self._bev[1]), L.ptr(dmaps), self.B, self.H, self.W,
+                                                               io, len(self.convs), L.ptr(self._hw), self.O, L.ptr(self.arena), L.ptr(dhw),
+                                                               L.ptr(dhb), L.ptr(planes[0]), L.ptr(planes[1]), L.stream_ptr()),
+                        "dense_train_backward_split")
+                dbev = (planes[0].float() + planes[1].float()).permute(0, 3, 1, 2)  # fp32 (B, 128, H, W), channels_last strides
+            else:
+                dbev = torch.empty((self.B, 128, self.H, self.W), dtype=torch.bfloat16, device=self.device, memory_format=torch.channels_last)
+                L.check(L.lib().v3d_dense_train_backward(L.ptr(self._bev), L.ptr(dmaps), self.B, self.H, self.W, io, len(self.convs),
+                                                         L.ptr(self._hw), self.O, L.ptr(self.arena), L.ptr(dhw), L.ptr(dhb), L.ptr(dbev),
+                                                         L.stream_ptr()), "dense_train_backward")
         nc = self.head.conv_cls.out_channels
         grads += [dhw[:nc].reshape(self.head.conv_cls.weight.shape), dhb[:nc], dhw[nc:].reshape(self.head.conv_reg.weight.shape), dhb[nc:]]
         return dbev, grads
@@ -193,12 +227,13 @@ class DenseTrainFunction(torch.autograd.Function):
         return (None, dbev if ctx.needs_bev_grad else None) + tuple(grads)
 
 
-def train_head_maps(rpn, head, bev, cache):
-    """bev (bf16 channels_last) -> fused fp32 head maps through the native plan; `cache`: dict owned by the caller (plans by geometry)."""
-    key = (str(bev.device), tuple(bev.shape))
+def train_head_maps(rpn, head, bev, cache, precision="bf16"):
+    """bev (bf16 channels_last | fp32 for "bf16x3") -> fused fp32 head maps through the native plan; `cache`: dict owned by the caller
+    (plans by geometry and arithmetic)."""
+    key = (str(bev.device), tuple(bev.shape), precision)
     plan = cache.get(key)
     if plan is None:
-        while len(cache) >= MAX_CACHED_PLANS:  # an arena is ~150 MB per image of the batch: keep the most recent geometries only
+        while len(cache) >= MAX_CACHED_PLANS:  # an arena is ~150 MB (split: ~300 MB) per image of the batch: keep the most recent only
             cache.pop(next(iter(cache)))
-        plan = cache[key] = DenseTrainPlan(rpn, head, bev.shape[0], bev.shape[2], bev.shape[3], bev.device)
+        plan = cache[key] = DenseTrainPlan(rpn, head, bev.shape[0], bev.shape[2], bev.shape[3], bev.device, precision)
     return DenseTrainFunction.apply(plan, bev, *plan.parameters())

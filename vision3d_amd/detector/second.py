@@ -222,29 +222,43 @@ class Second(nn.Module):
             self.spread_calibration(plan_of())
             return out
 
-    # training: RPN + heads forward / backward on csrc/dense_train.hip (bf16 storage, fp32 accumulation) instead of torch / MIOpen.
-    # The precision contract of those kernels is the one of `torch.autocast("cuda", torch.bfloat16)`, so they run
-    #   * when the caller's step is under bf16 autocast (what bench.py --mode train does, BASELINE configs[2]), or
-    #   * when the model is told to: `model.dense_train_precision = "bf16"` (or V3D_DENSE_TRAIN_PRECISION=bf16) makes the
-    #     training forward enter bf16 autocast ITSELF for the dense half, so the reference's fp32 script (train.py:58-66, no
-    #     autocast anywhere) reaches the native kernels unchanged.
-    # The default, "fp32", keeps the reference's arithmetic for a step outside autocast: the dense half then runs the torch
-    # modules (MIOpen) -- there is no fp32-class native dense TRAINING kernel (INTEGRATION.md section A says so).
+    # training: RPN + heads forward / backward on csrc/dense_train.hip instead of torch / MIOpen, in the arithmetic of the caller's step:
+    #   * under bf16 autocast (what bench.py --mode train does, BASELINE configs[2]): bf16 storage, fp32 accumulation -- the contract
+    #     of `torch.autocast("cuda", torch.bfloat16)`;
+    #   * outside autocast -- the reference's fp32 script, train.py:58-66 -- `dense_train_precision` (V3D_DENSE_TRAIN_PRECISION):
+    #       "bf16x3" (default)  the fp32-class step: split hi + lo storage, three-term products (dense_train.py): no MIOpen
+    #                           convolution anywhere in the step, nothing to opt into;
+    #       "bf16"              the model enters bf16 autocast ITSELF for the dense half (the faster, reduced-precision step);
+    #       "torch"             the torch modules (MIOpen fp32 convolutions), as the reference runs them.
     native_dense_train = os.environ.get("V3D_DENSE_TRAIN", "native") == "native"
-    dense_train_precision = os.environ.get("V3D_DENSE_TRAIN_PRECISION", "fp32")
+    dense_train_precision = os.environ.get("V3D_DENSE_TRAIN_PRECISION", "bf16x3")
 
     def _train_head_maps(self, item):
         """-> fused fp32 head maps of a TRAINING forward through the native dense plan [or the (scores, boxes) pair of the torch
-        modules where the plan does not apply], or None when the step is not a bf16 training step (see above)."""
+        modules where the plan does not apply], or None when the torch modules are asked for (see above)."""
         if not (self.native_dense_train and self.training and torch.is_grad_enabled()):
             return None
         autocast = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
-        if not autocast:
-            if self.dense_train_precision != "bf16" or torch.is_autocast_enabled("cuda"):
-                return None
+        if autocast:
+            return self._train_head_maps_autocast(item)
+        if torch.is_autocast_enabled("cuda"):  # (another autocast dtype: the torch modules know what to do with it)
+            return None
+        if self.dense_train_precision == "bf16":
             with torch.autocast("cuda", dtype=torch.bfloat16):  # opted in: the model enters the contract itself
                 return self._train_head_maps_autocast(item)
-        return self._train_head_maps_autocast(item)
+        if self.dense_train_precision == "bf16x3":
+            return self._train_head_maps_split(item)
+        if self.dense_train_precision != "torch":
+            raise ValueError(f"dense_train_precision must be 'bf16x3', 'bf16' or 'torch', not {self.dense_train_precision!r}")
+        return None
+
+    def _train_head_maps_split(self, item):
+        from .. import dense_train
+        features = item["voxel_mean"] if "voxel_mean" in item else self.vfe(item["features"], item["occupancy"])
+        bev = self.cnn(features, item["coordinates"], item["batch_size"])
+        if not dense_train.supported(self.rpn, self.head, bev, "bf16x3"):
+            return self._torch_dense_fallback(bev, dense_train.why_unsupported(self.rpn, self.head, bev, "bf16x3"))
+        return dense_train.train_head_maps(self.rpn, self.head, bev, self.__dict__.setdefault("_dense_train_plans", {}), "bf16x3")
 
     def _train_head_maps_autocast(self, item):
         from .. import dense_train
