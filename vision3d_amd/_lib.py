@@ -241,6 +241,10 @@ _scale_scratch = {}
 def scale_scratch(device):
     """The two zeroed uint32 words v3d_act_scale_from_rows2 works in, one pair per (device, stream): the kernel leaves them zero,
     so launches on one stream reuse them; two streams never share a pair."""
+    if torch.cuda.is_current_stream_capturing():
+        # a captured graph may replay beside other replays of graphs captured on this same stream: a pair of its own, zeroed by a
+        # fill node of the graph itself
+        return torch.zeros(2, dtype=torch.int32, device=device)
     index = torch.device(device).index
     key = (torch.cuda.current_device() if index is None else index, torch.cuda.current_stream(device).cuda_stream)
     buf = _scale_scratch.get(key)
