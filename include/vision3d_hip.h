@@ -443,6 +443,9 @@ int v3d_nchw_to_split_nhwc2(const float* x, int B, int C, int H, int W, void* ou
 int v3d_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
                            const int32_t* spatial_shape_host, void* out_hi, void* out_lo, v3d_stream_t stream);
 int v3d_nchw_to_split_nhwc(const float* x, int B, int C, int H, int W, void* out_hi, void* out_lo, v3d_stream_t stream);
+/* ... and back: bf16 split planes (B,H,W,C) -> fp32 (B,C,H,W) = hi + lo (C even).  The gradient of the BEV map leaving
+ * v3d_dense_train_backward_split for the sparse training plan, which takes fp32 NCHW. */
+int v3d_split_nhwc_to_nchw(const void* x_hi, const void* x_lo, int B, int C, int H, int W, float* out, v3d_stream_t stream);
 /* v3d_backbone_forward with a choice of output formats (any may be NULL): fp32 (B,C*D,H,W) and/or split planes. */
 int v3d_backbone_forward2(v3d_backbone* plan, const float* points, int n_points, const int32_t* frame_offsets_host,
                           int B, float* dense_nchw, void* dense_hi, void* dense_lo, v3d_stream_t stream);

@@ -397,3 +397,29 @@ def test_dense_head_plan_with_and_without_the_fused_tail():
         dense.fuse_tail = True
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
     assert torch.equal(outs[True][0], outs[True][1])
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 13, 37), (1, 6, 5, 7), (3, 192, 9, 70), (1, 5, 4, 6)])
+def test_nchw_split_conversions_are_exact_and_round_trip(shape):
+    """v3d_nchw_to_split_nhwc2 (tiled form for even C, plain form for odd C) against the definition -- hi = RNE(x) as bf16, lo = RNE(x - hi),
+    per pixel and channel -- and v3d_split_nhwc_to_nchw back: hi + lo in fp32, exactly; f16s planes hold the pieces of x * s."""
+    from vision3d_amd import _lib as L
+    from vision3d_amd.runtime import to_split_nhwc
+    b, c, h, w = shape
+    torch.manual_seed(9)
+    x = torch.randn(shape, device="cuda") * 5.0
+    x[0, 0, 0, 0] = 0.0
+    hi, lo = to_split_nhwc(x)
+    ref_hi = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    ref_lo = (x.permute(0, 2, 3, 1) - ref_hi.float()).to(torch.bfloat16)
+    assert torch.equal(hi.view(torch.bfloat16), ref_hi) and torch.equal(lo.view(torch.bfloat16), ref_lo)
+    if c % 2 == 0:
+        back = torch.full(shape, float("nan"), device="cuda")
+        L.check(L.lib().v3d_split_nhwc_to_nchw(L.ptr(hi), L.ptr(lo), b, c, h, w, L.ptr(back), L.stream_ptr()), "split_nhwc_to_nchw")
+        assert torch.equal(back, (ref_hi.float() + ref_lo.float()).permute(0, 3, 1, 2))
+        assert float((back - x).abs().max()) <= 2.0 ** -16 * float(x.abs().max())
+    hi16, lo16 = to_split_nhwc(x, "fp32")
+    s = float(hi16.v3d_entry[0])
+    r_hi = (x.permute(0, 2, 3, 1) * s).to(torch.float16)
+    r_lo = (x.permute(0, 2, 3, 1) * s - r_hi.float()).to(torch.float16)
+    assert torch.equal(hi16.view(torch.float16), r_hi) and torch.equal(lo16.view(torch.float16), r_lo)

@@ -107,6 +107,7 @@ _SIGNATURES = {
     "v3d_conv2d_nhwc_bf16x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "v3d_densify_nhwc_split": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "v3d_nchw_to_split_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "v3d_split_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "v3d_dense_train_weight_image_bytes": (_sz, [_i]),
     "v3d_dense_train_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
     "v3d_dense_train_conv_tiles": (_i, [_i, _i, _i]),

@@ -290,6 +290,76 @@ __global__ void nchw_to_split_nhwc_kernel(const float* __restrict__ x, int B, in
   }
 }
 
+// The same through an LDS tile (even C <= 128 per pass): 64 pixels of one image x all channels -- rows of 64 consecutive pixels read
+// per channel (256-byte runs), packed channel pairs written per pixel (256-byte rows of each plane).  The plain kernel above reads
+// with a stride of H * W floats between lanes: 0.9 TB/s on an 8-image map, 323 us of every fp32-class train step.
+#define NS_PX 64
+template <int PREC>
+__global__ __launch_bounds__(256) void nchw_to_split_nhwc_tiled_kernel(const float* __restrict__ x, int B, int C, int HW, bf16_t* __restrict__ hi,
+                                                                       bf16_t* __restrict__ lo, const float* __restrict__ entry) {
+  __shared__ float tile[NS_PX][129];
+  const float s = PREC == 1 ? entry[0] : 1.f;
+  const int tpi = (HW + NS_PX - 1) / NS_PX, tid = threadIdx.x;
+  for (long long idx = blockIdx.x; idx < (long long)B * tpi; idx += gridDim.x) {
+    const int b = (int)(idx / tpi), p0 = (int)(idx % tpi) * NS_PX;
+    for (int c0 = 0; c0 < C; c0 += 128) {
+      const int cn = min(128, C - c0);
+      __syncthreads();
+      {
+        const int p = tid & 63;
+        if (p0 + p < HW)
+          for (int c = tid >> 6; c < cn; c += 4) tile[p][c] = x[((size_t)b * C + c0 + c) * HW + p0 + p];
+      }
+      __syncthreads();
+      const int cp = tid & 63;  // channels 2 cp, 2 cp + 1
+      if (2 * cp < cn)
+        for (int p = tid >> 6; p < NS_PX && p0 + p < HW; p += 4) {
+          bf16_t h0, l0, h1, l1;
+          split_val<PREC>(tile[p][2 * cp], s, h0, l0);
+          split_val<PREC>(tile[p][2 * cp + 1], s, h1, l1);
+          const size_t o = ((size_t)b * HW + p0 + p) * C + c0 + 2 * cp;
+          *reinterpret_cast<unsigned*>(hi + o) = (unsigned)h0 | ((unsigned)h1 << 16);
+          *reinterpret_cast<unsigned*>(lo + o) = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+    }
+  }
+}
+
+// bf16 split NHWC planes -> fp32 NCHW (hi + lo): the way back (the gradient of the BEV map leaving the fp32-class dense train step)
+__global__ __launch_bounds__(256) void split_nhwc_to_nchw_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo, int B, int C, int HW,
+                                                                 float* __restrict__ x) {
+  __shared__ float tile[NS_PX][129];
+  const int tpi = (HW + NS_PX - 1) / NS_PX, tid = threadIdx.x;
+  for (long long idx = blockIdx.x; idx < (long long)B * tpi; idx += gridDim.x) {
+    const int b = (int)(idx / tpi), p0 = (int)(idx % tpi) * NS_PX;
+    for (int c0 = 0; c0 < C; c0 += 128) {
+      const int cn = min(128, C - c0);
+      __syncthreads();
+      const int cp = tid & 63;
+      if (2 * cp < cn)
+        for (int p = tid >> 6; p < NS_PX && p0 + p < HW; p += 4) {
+          const size_t o = ((size_t)b * HW + p0 + p) * C + c0 + 2 * cp;
+          const unsigned h = *reinterpret_cast<const unsigned*>(hi + o), l = *reinterpret_cast<const unsigned*>(lo + o);
+          tile[p][2 * cp] = __uint_as_float(h << 16) + __uint_as_float(l << 16);
+          tile[p][2 * cp + 1] = __uint_as_float(h & 0xFFFF0000u) + __uint_as_float(l & 0xFFFF0000u);
+        }
+      __syncthreads();
+      const int p = tid & 63;
+      if (p0 + p < HW)
+        for (int c = tid >> 6; c < cn; c += 4) x[((size_t)b * C + c0 + c) * HW + p0 + p] = tile[p][c];
+    }
+  }
+}
+
+extern "C" int v3d_split_nhwc_to_nchw(const void* x_hi, const void* x_lo, int B, int C, int H, int W, float* out, v3d_stream_t stream) {
+  if (!x_hi || !x_lo || !out || B < 1 || C < 2 || (C & 1) || H < 1 || W < 1) return V3D_EINVAL;
+  const long long tiles = (long long)B * ((H * W + NS_PX - 1) / NS_PX);
+  hipLaunchKernelGGL(split_nhwc_to_nchw_kernel, dim3((unsigned)std::min<long long>(tiles, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x_hi, (const bf16_t*)x_lo, B, C, H * W, out);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 extern "C" int v3d_nchw_to_split_nhwc(const float* x, int B, int C, int H, int W, void* out_hi, void* out_lo,
                                       v3d_stream_t stream) {
   return v3d_nchw_to_split_nhwc2(x, B, C, H, W, out_hi, out_lo, V3D_PREC_BF16X3, nullptr, stream);
@@ -299,6 +369,18 @@ extern "C" int v3d_nchw_to_split_nhwc2(const float* x, int B, int C, int H, int 
                                        const float* act_entry, v3d_stream_t stream) {
   if (!x || !out_hi || !out_lo || B < 1 || C < 1 || H < 1 || W < 1) return V3D_EINVAL;
   if (prec == V3D_PREC_F16S ? !act_entry : prec != V3D_PREC_BF16X3) return V3D_EINVAL;
+  if (!(C & 1)) {
+    const long long tiles = (long long)B * ((H * W + NS_PX - 1) / NS_PX);
+    const dim3 grid((unsigned)std::min<long long>(tiles, 8192));
+    if (prec == V3D_PREC_F16S)
+      hipLaunchKernelGGL(nchw_to_split_nhwc_tiled_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, B, C, H * W, (bf16_t*)out_hi,
+                         (bf16_t*)out_lo, act_entry);
+    else
+      hipLaunchKernelGGL(nchw_to_split_nhwc_tiled_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, x, B, C, H * W, (bf16_t*)out_hi,
+                         (bf16_t*)out_lo, nullptr);
+    V3D_CHECK_LAUNCH();
+    return V3D_OK;
+  }
   if (prec == V3D_PREC_F16S)
     hipLaunchKernelGGL(nchw_to_split_nhwc_kernel<1>, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, B, C, H * W, (bf16_t*)out_hi,
                        (bf16_t*)out_lo, act_entry);

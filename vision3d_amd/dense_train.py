@@ -192,7 +192,9 @@ class DenseTrainPlan(object):
                                                                io, len(self.convs), L.ptr(self._hw), self.O, L.ptr(self.arena), L.ptr(dhw),
                                                                L.ptr(dhb), L.ptr(planes[0]), L.ptr(planes[1]), L.stream_ptr()),
                         "dense_train_backward_split")
-                dbev = (planes[0].float() + planes[1].float()).permute(0, 3, 1, 2)  # fp32 (B, 128, H, W), channels_last strides
+                dbev = torch.empty((self.B, 128, self.H, self.W), dtype=torch.float32, device=self.device)  # what the sparse plan takes
+                L.check(L.lib().v3d_split_nhwc_to_nchw(L.ptr(planes[0]), L.ptr(planes[1]), self.B, 128, self.H, self.W, L.ptr(dbev),
+                                                       L.stream_ptr()), "split_nhwc_to_nchw")
             else:
                 dbev = torch.empty((self.B, 128, self.H, self.W), dtype=torch.bfloat16, device=self.device, memory_format=torch.channels_last)
                 L.check(L.lib().v3d_dense_train_backward(L.ptr(self._bev), L.ptr(dmaps), self.B, self.H, self.W, io, len(self.convs),
