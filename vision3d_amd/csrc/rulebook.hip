@@ -89,23 +89,70 @@ __device__ __forceinline__ void rb_subm_entries(const int4* __restrict__ coords,
     if (k < g.K) nbr[(size_t)k * cap + o] = v;
   }
 }
+// The 3x3x3 form of the same: offsets decoded at compile time (KPT = 9: one kz plane per thread, kgroup = kz; KPT = 27: the whole
+// kernel), keys as the centre's key plus a per-offset delta ((dz * H + dy) * W + dx: one 64-bit add instead of three multiply-adds).
+template <int KPT>
+__device__ __forceinline__ void rb_subm_entries_333(const int4* __restrict__ coords, int n, int cap, const RbGeom& g, const V3dHash& h,
+                                                    int* __restrict__ nbr, int kgroup, int o) {
+  static_assert(KPT == 9 || KPT == 27, "one kz plane or the whole kernel");
+  if (o >= n) return;
+  const int4 c = coords[o];
+  const bool keyed = (unsigned)c.x < (unsigned)RB_MAX_BATCH;
+  const int D = g.in_shape[0], H = g.in_shape[1], W = g.in_shape[2];
+  const v3d_key_t key0 = rb_key(c.x, c.y, c.z, c.w, g.in_shape);
+  v3d_key_t key[KPT], w[KPT];
+  unsigned s[KPT];
+  bool look[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const int dz = (KPT == 27 ? j / 9 : kgroup) - 1, dy = (j / 3) % 3 - 1, dx = j % 3 - 1;
+    const int z = c.y + dz, y = c.z + dy, x = c.w + dx;
+    look[j] = keyed && (dz | dy | dx) != 0 && z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W;
+    const long long delta = ((long long)dz * H + dy) * W + dx;
+    key[j] = look[j] ? key0 + (v3d_key_t)delta : 0;
+    s[j] = look[j] ? v3d_hash_start(key[j], h) : 0u;
+    w[j] = h.keys[s[j]];
+  }
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const int k = kgroup * KPT + j;
+    const int dz = (KPT == 27 ? j / 9 : kgroup) - 1, dy = (j / 3) % 3 - 1, dx = j % 3 - 1;
+    int v = -1;
+    if ((dz | dy | dx) == 0) {
+      v = o;  // centre tap: the site itself
+    } else if (look[j]) {
+      const v3d_key_t word = w[j];
+      if ((word >> V3D_SITE_ROW_BITS) == key[j]) {
+        const unsigned row = (unsigned)word & V3D_SITE_NO_ROW;
+        if (row != V3D_SITE_NO_ROW) v = (int)row;
+      } else if (word != V3D_EMPTY_KEY) {
+        v = v3d_site_find_row_from(h, key[j], (s[j] + 1) & h.mask);  // another site's word: walk on
+      }
+    }
+    nbr[(size_t)k * cap + o] = v;
+  }
+}
 // Offsets per thread: 9 (one kz plane of a 3x3x3 kernel) for the long site lists, 1 for the short ones.  Measured in the frame
 // (profiles/r05_rb_subm_kpt.txt): at Waymo range (104 k - 180 k rows) 9 per thread takes the four tables from 62 / 85 / 50 / 25 us to
 // 45 / 64 / 39 / 16 us; on a KITTI frame (16 k - 30 k rows, a few hundred workgroups) the same form is SLOWER (9.8 -> 22.6 us, 11.2 ->
 // 15.7 us): too few threads are left and each walks nine address computations in a row.  The switch is on the capacity, which
 // host and device both know.
+#ifndef RB_SUBM_KPT
 #define RB_SUBM_KPT 9
+#endif
 #define RB_SUBM_KPT_MIN_ROWS 40960
-__host__ __device__ inline int rb_subm_kpt(int cap, int K) { return (K == 27 && cap >= RB_SUBM_KPT_MIN_ROWS) ? RB_SUBM_KPT : 1; }
-__host__ __device__ inline int rb_subm_blocks(int cap, int K) {
-  const int kpt = rb_subm_kpt(cap, K);
-  return ((cap + V3D_BLOCK - 1) / V3D_BLOCK) * ((K + kpt - 1) / kpt);
+__host__ __device__ inline int rb_subm_kpt(int cap, const RbGeom& g) {
+  return (g.K == 27 && g.ks[0] == 3 && g.ks[1] == 3 && g.ks[2] == 3 && cap >= RB_SUBM_KPT_MIN_ROWS) ? RB_SUBM_KPT : 1;
+}
+__host__ __device__ inline int rb_subm_blocks(int cap, const RbGeom& g) {
+  const int kpt = rb_subm_kpt(cap, g);
+  return ((cap + V3D_BLOCK - 1) / V3D_BLOCK) * ((g.K + kpt - 1) / kpt);
 }
 __device__ __forceinline__ void rb_subm_block(const int4* __restrict__ coords, int n, int cap, const RbGeom& g, const V3dHash& h,
                                               int* __restrict__ nbr, int idx) {
   const int nbx = (cap + V3D_BLOCK - 1) / V3D_BLOCK, o = (idx % nbx) * V3D_BLOCK + threadIdx.x;
-  if (rb_subm_kpt(cap, g.K) == RB_SUBM_KPT)
-    rb_subm_entries<RB_SUBM_KPT>(coords, n, cap, g, h, nbr, idx / nbx, o);
+  if (rb_subm_kpt(cap, g) == RB_SUBM_KPT)
+    rb_subm_entries_333<RB_SUBM_KPT>(coords, n, cap, g, h, nbr, idx / nbx, o);
   else
     rb_subm_entries<1>(coords, n, cap, g, h, nbr, idx / nbx, o);
 }
@@ -449,7 +496,7 @@ int v3d_i_subm_nbr(const int32_t* coords, const int32_t* n, int cap, const int32
   RbCandJob job;
   rc = make_cand_job(next, job);
   if (rc) return rc;
-  const int subm_blocks = rb_subm_blocks(cap, g.K);
+  const int subm_blocks = rb_subm_blocks(cap, g);
   hipLaunchKernelGGL(rb_subm_nbr_kernel, dim3(subm_blocks + job.blocks), dim3(V3D_BLOCK), 0, st,
                      (const int4*)coords, n, cap, g, hh, h.vals, nbr, subm_blocks, job);
   V3D_CHECK_LAUNCH();
@@ -495,7 +542,7 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
     if (rc) return rc;
     for (int j = 0; j < 3; j++)
       if (!(sg.ks[j] & 1)) return V3D_EINVAL;
-    subm_blocks = rb_subm_blocks(cap_out, sg.K);
+    subm_blocks = rb_subm_blocks(cap_out, sg);
   }
   RbCandJob job;
   rc = make_cand_job(next, job);
