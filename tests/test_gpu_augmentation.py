@@ -128,7 +128,8 @@ def test_fused_frame_edge_cases(golden_aug):
         for y in np.arange(lower[1], upper[1] + 4, 4.0):
             wall.append([x, y, 0.0, 3.9, 3.9, 2.0, 0.0])
     wall = torch.tensor(wall, dtype=torch.float32).cuda()
-    cases = [(pts, boxes[:0], cls[:0]), (pts[:0], boxes, cls), (pts[:1], boxes[:1], cls[:1]),
+    big = torch.rand((181003, 4), generator=torch.Generator().manual_seed(11)) * torch.tensor([70.0, 80.0, 4.0, 1.0]) + torch.tensor([0.0, -40.0, -3.0, 0.0])
+    cases = [(pts, boxes[:0], cls[:0]), (pts[:0], boxes, cls), (pts[:1], boxes[:1], cls[:1]), (big.cuda(), boxes, cls),  # 708 scan chunks
              (pts, wall, torch.zeros(len(wall), dtype=torch.int64).cuda())]
     for ci, (p, b, c) in enumerate(cases):
         np.random.seed(100 + ci)
