@@ -320,6 +320,45 @@ def test_pv_rcnn_native_cnn_equals_the_module_path(batch):
     assert float((cls_a - cls_b).abs().max()) < 1e-4 * max(1.0, float(cls_a.abs().max()))
 
 
+@pytest.mark.parametrize("batch", [1, 2])
+def test_pv_rcnn_native_proposal_tail_equals_the_torch_statements(batch):
+    """PV_RCNN.native_tail: stage-1 top-k + decode (v3d_proposals_topk) and the stage-2 tail -- refined-box decode, sigmoid, batched
+    rotated NMS, score cut (v3d_refine_nms) -- against the torch statements of the same steps on the same frame: same proposals in
+    the same order, same survivors in the same order, boxes and scores within float rounding (device expf vs torch's)."""
+    from vision3d_amd.core import AnchorGenerator, Preprocessor
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.detector import PV_RCNN
+    cfg = second_car_cfg()
+    torch.manual_seed(21)
+    model = PV_RCNN(cfg).cuda().eval()
+    with torch.no_grad():  # scores that straddle the class threshold and overlapping boxes: both cuts must have work to do
+        model.proposal_layer.conv_cls.bias.fill_(0.3)
+        model.refinement_layer.mlp[-1].bias[7] = 0.2
+        model.refinement_layer.mlp[-1].weight.mul_(30.0)
+    anchors = AnchorGenerator(cfg).anchors.cuda()
+    clouds = [synth.make_cloud(30 + i) for i in range(batch)]
+    n = cfg.NUM_CLASSES * cfg.PROPOSAL.TOPK
+    samples = torch.rand((batch, n, cfg.GRIDPOOL.NUM_GRIDPOINTS, 3), generator=torch.Generator().manual_seed(22)).cuda()
+    outs = {}
+    with torch.no_grad():
+        for native in (True, False):
+            model.native_tail = native
+            model.cnn.pad_generator = torch.Generator(device="cuda").manual_seed(23)
+            item = Preprocessor(cfg, seed=0)(dict(points=clouds, anchors=anchors))
+            dets = model.inference(item, samples)
+            outs[native] = (dets, item["proposals"].clone(), item["proposal_scores"].clone(), item["boxes_refined"].clone())
+    (da, pa, sa, ra), (db, pb, sb, rb) = outs[True], outs[False]
+    assert pa.shape == pb.shape == (batch, n, 7)
+    torch.testing.assert_close(sa, sb, rtol=0, atol=0)
+    torch.testing.assert_close(pa, pb, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ra, rb, rtol=1e-5, atol=1e-5)
+    assert len(da[0]) == len(db[0]) and 0 < len(da[0]) < batch * n, (len(da[0]), len(db[0]))
+    assert torch.equal(da[1], db[1]) and torch.equal(da[2], db[2])
+    torch.testing.assert_close(da[3], db[3], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(da[0], db[0], rtol=1e-5, atol=1e-5)
+    assert (da[3][:-1] >= da[3][1:]).all()
+
+
 def test_pv_rcnn_stage_pieces_run():
     """configs[3] shapes: FPS keypoints + 5-level VSA + BEV gather -> (B, 512, 2048); RoI-grid pool -> (B, n, 256)."""
     from vision3d_amd.core import Preprocessor

@@ -28,6 +28,9 @@ _SIGNATURES = {
     "v3d_proposals_workspace": (_sz, [_i, _i, _i]),
     "v3d_proposals": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "v3d_proposals_flag": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "v3d_proposals_topk": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "v3d_refine_nms_workspace": (_sz, [_i, _i, _i]),
+    "v3d_refine_nms": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "v3d_sparse_bn_workspace": (_sz, [_i, _i]),
     "v3d_sparse_bn_relu_fwd": (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _sz, _vp]),
     "v3d_sparse_bn_relu_bwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

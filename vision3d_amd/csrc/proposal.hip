@@ -264,11 +264,16 @@ __global__ __launch_bounds__(SEL_THREADS) void prop_topk_merge_kernel(const floa
 // shift the BEV boxes by group (ops/iou_nms.py:127-133: offset = group * (max_coord - min_coord + 1), added to x and
 // y), sort (score descending, index ascending) in LDS and emit the NMS inputs in sorted order -- what were four
 // launches (decode, keys, bitonic sort, gather + box prep).  N <= 1024.
+// REFINE: the same stage for stage-2 boxes (PV-RCNN: detector/model.py inference tail) -- residuals and the boxes they refine come
+// from arrays in candidate order instead of the head maps / anchor grid, the score is the sigmoid of a confidence logit.
+template <bool REFINE>
 __device__ __forceinline__ void prop_decode_sort_body(const float* __restrict__ maps, const float* __restrict__ anchors,
                                                       const PropGeom& g, const int* cand_anchor, const float* cand_score,
                                                       float* __restrict__ boxes /*(N,7)*/, long long* __restrict__ batch_idx,
                                                       long long* __restrict__ class_idx, int* __restrict__ order,
-                                                      v3d::BoxPrep* __restrict__ prep) {
+                                                      v3d::BoxPrep* __restrict__ prep, const float* __restrict__ ref_deltas = nullptr,
+                                                      const float* __restrict__ ref_boxes = nullptr,
+                                                      const float* __restrict__ ref_conf = nullptr, float* __restrict__ ref_score = nullptr) {
   __shared__ float red_hi[PROP_WAVES], red_lo[PROP_WAVES];
   __shared__ unsigned long long keys[PROP_THREADS];
   __shared__ float sbev[PROP_THREADS][5];
@@ -281,12 +286,20 @@ __device__ __forceinline__ void prop_decode_sort_body(const float* __restrict__ 
   if (t < N) {
     grp = t / g.topk;
     const int b = grp / g.n_cls, c = grp % g.n_cls;
-    const int a = cand_anchor[t], yaw_i = a / g.HW, pix = a % g.HW;
     float d[7], an[7];
+    if constexpr (REFINE) {
 #pragma unroll
-    for (int q = 0; q < 7; q++) {
-      d[q] = maps[((size_t)b * g.ctot + n_anchor + (size_t)(c * 7 + q) * g.n_yaw + yaw_i) * g.HW + pix];
-      an[q] = anchors[((size_t)c * g.n_yaw * g.HW + a) * 7 + q];
+      for (int q = 0; q < 7; q++) {
+        d[q] = ref_deltas[(size_t)t * 7 + q];
+        an[q] = ref_boxes[(size_t)t * 7 + q];
+      }
+    } else {
+      const int a = cand_anchor[t], yaw_i = a / g.HW, pix = a % g.HW;
+#pragma unroll
+      for (int q = 0; q < 7; q++) {
+        d[q] = maps[((size_t)b * g.ctot + n_anchor + (size_t)(c * 7 + q) * g.n_yaw + yaw_i) * g.HW + pix];
+        an[q] = anchors[((size_t)c * g.n_yaw * g.HW + a) * 7 + q];
+      }
     }
     const float diag = sqrtf(an[3] * an[3] + an[4] * an[4]);
     o[0] = d[0] * diag + an[0];
@@ -321,7 +334,14 @@ __device__ __forceinline__ void prop_decode_sort_body(const float* __restrict__ 
   // key = (~orderable(score) << 32) | index, ascending == the order v3d_nms_rotated sorts in; padding sorts last
   unsigned long long key = ~0ull;
   if (t < N) {
-    const unsigned u = __float_as_uint(cand_score[t]);
+    float sc;
+    if constexpr (REFINE) {
+      sc = prop_sigmoid(ref_conf[t]);
+      ref_score[t] = sc;
+    } else {
+      sc = cand_score[t];
+    }
+    const unsigned u = __float_as_uint(sc);
     const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     key = ((unsigned long long)(~ord) << 32) | (unsigned)t;
   }
@@ -375,7 +395,7 @@ __global__ __launch_bounds__(PROP_THREADS) void prop_decode_sort_kernel(const fl
                                                                         float* __restrict__ boxes, long long* __restrict__ batch_idx,
                                                                         long long* __restrict__ class_idx, int* __restrict__ order,
                                                                         v3d::BoxPrep* __restrict__ prep) {
-  prop_decode_sort_body(maps, anchors, g, cand_anchor, cand_score, boxes, batch_idx, class_idx, order, prep);
+  prop_decode_sort_body<false>(maps, anchors, g, cand_anchor, cand_score, boxes, batch_idx, class_idx, order, prep);
 }
 
 // Level-2 merge of every group AND the decode / sort / box prep in ONE workgroup (at most PROP_FUSE_GROUPS groups: the bs = 1
@@ -398,7 +418,15 @@ __global__ __launch_bounds__(PROP_THREADS) void prop_merge_decode_sort_kernel(co
                       cand_anchor + (size_t)grp * g.topk);
     __syncthreads();  // (also: the next group reuses the selection's LDS)
   }
-  prop_decode_sort_body(maps, anchors, g, cand_anchor, cand_score, boxes, batch_idx, class_idx, order, prep);
+  prop_decode_sort_body<false>(maps, anchors, g, cand_anchor, cand_score, boxes, batch_idx, class_idx, order, prep);
+}
+
+__global__ __launch_bounds__(PROP_THREADS) void prop_refine_sort_kernel(const float* __restrict__ deltas, const float* __restrict__ props,
+                                                                        const float* __restrict__ conf, PropGeom g, float* __restrict__ scores,
+                                                                        float* __restrict__ boxes, long long* __restrict__ batch_idx,
+                                                                        long long* __restrict__ class_idx, int* __restrict__ order,
+                                                                        v3d::BoxPrep* __restrict__ prep) {
+  prop_decode_sort_body<true>(nullptr, nullptr, g, nullptr, nullptr, boxes, batch_idx, class_idx, order, prep, deltas, props, conf, scores);
 }
 
 // keep (sorted by score, from the NMS) -> ordered compaction of the rows that pass their class threshold (one workgroup)
@@ -495,14 +523,35 @@ extern "C" int v3d_proposals(const float* head_maps, const float* anchors, int B
                             out_batch_idx, out_class_idx, out_scores, n_out, nullptr, workspace, workspace_bytes, stream);
 }
 
+// topk_boxes / topk_scores != NULL: stop behind the decode -- the (N, 7) decoded candidates and their scores in candidate order
+// (group-major, score descending inside a group) are the result (v3d_proposals_topk); the NMS half does not run.
+static int prop_run(const float* head_maps, const float* anchors, int B, int n_cls, int n_yaw, int H, int W, int topk,
+                    const float* score_thresh_host, float iou_threshold, float* out_boxes, int64_t* out_batch_idx, int64_t* out_class_idx,
+                    float* out_scores, int32_t* n_out, const int32_t* aux_flag, void* workspace, size_t workspace_bytes, v3d_stream_t stream,
+                    float* topk_boxes, float* topk_scores);
+
 extern "C" int v3d_proposals_flag(const float* head_maps, const float* anchors, int B, int n_cls, int n_yaw, int H, int W,
                                   int topk, const float* score_thresh_host, float iou_threshold, float* out_boxes,
                                   int64_t* out_batch_idx, int64_t* out_class_idx, float* out_scores, int32_t* n_out,
                                   const int32_t* aux_flag, void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
+  if (!score_thresh_host || !out_boxes || !out_batch_idx || !out_class_idx || !out_scores || !n_out) return V3D_EINVAL;
+  return prop_run(head_maps, anchors, B, n_cls, n_yaw, H, W, topk, score_thresh_host, iou_threshold, out_boxes, out_batch_idx, out_class_idx,
+                  out_scores, n_out, aux_flag, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int v3d_proposals_topk(const float* head_maps, const float* anchors, int B, int n_cls, int n_yaw, int H, int W, int topk,
+                                  float* boxes, float* scores, void* workspace, size_t workspace_bytes, v3d_stream_t stream) {
+  if (!boxes || !scores) return V3D_EINVAL;
+  return prop_run(head_maps, anchors, B, n_cls, n_yaw, H, W, topk, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
+                  workspace_bytes, stream, boxes, scores);
+}
+
+static int prop_run(const float* head_maps, const float* anchors, int B, int n_cls, int n_yaw, int H, int W, int topk,
+                    const float* score_thresh_host, float iou_threshold, float* out_boxes, int64_t* out_batch_idx, int64_t* out_class_idx,
+                    float* out_scores, int32_t* n_out, const int32_t* aux_flag, void* workspace, size_t workspace_bytes, v3d_stream_t stream,
+                    float* topk_boxes, float* topk_scores) {
   hipStream_t st = (hipStream_t)stream;
-  if (!head_maps || !anchors || !score_thresh_host || !out_boxes || !out_batch_idx || !out_class_idx || !out_scores ||
-      !n_out || !workspace)
-    return V3D_EINVAL;
+  if (!head_maps || !anchors || !workspace) return V3D_EINVAL;
   if (B < 1 || n_cls < 1 || n_cls > PROP_MAX_CLS || n_yaw < 1 || H < 1 || W < 1 || topk < 1 || topk > PROP_MAX_TOPK)
     return V3D_EINVAL;
   if ((long long)B * n_cls * topk > PROP_THREADS) return V3D_EUNSUPPORTED;  // candidates of ALL groups are sorted by one block
@@ -510,15 +559,17 @@ extern "C" int v3d_proposals_flag(const float* head_maps, const float* anchors, 
   if (workspace_bytes < v3d_proposals_workspace(B, n_cls, topk)) return V3D_EWORKSPACE;
   PropGeom g;
   g.B = B; g.n_cls = n_cls; g.n_yaw = n_yaw; g.HW = H * W; g.topk = topk; g.ctot = n_cls * n_yaw * 8;
-  for (int c = 0; c < PROP_MAX_CLS; c++) g.thresh[c] = c < n_cls ? score_thresh_host[c] : 0.f;
+  for (int c = 0; c < PROP_MAX_CLS; c++) g.thresh[c] = (c < n_cls && score_thresh_host) ? score_thresh_host[c] : 0.f;
   const size_t N = (size_t)B * n_cls * topk;
   char* p = (char*)workspace;
   auto take = [&](size_t bytes) { char* q = p; p += prop_align(bytes); return (void*)q; };
   float* cand_score = (float*)take(N * 4);
+  if (topk_scores) cand_score = topk_scores;
   int* cand_anchor = (int*)take(N * 4);
   float* part_score = (float*)take(N * PROP_CHUNKS * 4);
   int* part_idx = (int*)take(N * PROP_CHUNKS * 4);
   float* boxes = (float*)take(N * 7 * 4);
+  if (topk_boxes) boxes = topk_boxes;
   long long* bidx = (long long*)take(N * 8);
   long long* cidx = (long long*)take(N * 8);
   long long* keep = (long long*)take(N * 8);
@@ -551,7 +602,7 @@ extern "C" int v3d_proposals_flag(const float* head_maps, const float* anchors, 
     hipLaunchKernelGGL(prop_decode_sort_kernel, dim3(1), dim3(PROP_THREADS), 0, st, head_maps, anchors, g, cand_anchor,
                        cand_score, boxes, bidx, cidx, order, prep);
   }
-  {
+  if (!topk_boxes) {
     const size_t nwords = (N + 63) / 64;
     unsigned long long* mask = (unsigned long long*)nms_ws;  // N*nwords + nwords words <= v3d_nms_rotated_workspace(N)
     const int rc = v3d_i_nms_mask_sorted(prep, (int)N, iou_threshold, mask, st);
@@ -562,6 +613,49 @@ extern "C" int v3d_proposals_flag(const float* head_maps, const float* anchors, 
   }
   (void)bev;
   (void)n_keep;
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+// Stage-2 tail (PV-RCNN: vision3d_amd/detector/model.py inference; the reference's refinement.py:32-33 raises, SURVEY.md 8(f) rank 3
+// defines it): refined box = core/box_encode.py:13-21 decode of the residuals against the proposals, score = sigmoid of the
+// confidence logit, coordinate-offset batched rotated NMS per (frame, class) group (ops/iou_nms.py:90-134), per-class score cut --
+// the candidates arrive in the layout v3d_proposals_topk produces ((B, n_cls, topk) group-major).  3 launches, no host sync.
+extern "C" size_t v3d_refine_nms_workspace(int B, int n_cls, int topk) { return v3d_proposals_workspace(B, n_cls, topk); }
+
+extern "C" int v3d_refine_nms(const float* deltas, const float* proposals, const float* conf, int B, int n_cls, int topk,
+                              const float* score_thresh_host, float iou_threshold, float* refined, float* out_boxes, int64_t* out_batch_idx,
+                              int64_t* out_class_idx, float* out_scores, int32_t* n_out, void* workspace, size_t workspace_bytes,
+                              v3d_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!deltas || !proposals || !conf || !score_thresh_host || !out_boxes || !out_batch_idx || !out_class_idx || !out_scores || !n_out ||
+      !workspace)
+    return V3D_EINVAL;
+  if (B < 1 || n_cls < 1 || n_cls > PROP_MAX_CLS || topk < 1 || topk > PROP_MAX_TOPK) return V3D_EINVAL;
+  if ((long long)B * n_cls * topk > PROP_THREADS) return V3D_EUNSUPPORTED;  // one workgroup decodes and sorts all candidates
+  if (workspace_bytes < v3d_refine_nms_workspace(B, n_cls, topk)) return V3D_EWORKSPACE;
+  PropGeom g;
+  g.B = B; g.n_cls = n_cls; g.n_yaw = 1; g.HW = 1; g.topk = topk; g.ctot = 0;
+  for (int c = 0; c < PROP_MAX_CLS; c++) g.thresh[c] = c < n_cls ? score_thresh_host[c] : 0.f;
+  const size_t N = (size_t)B * n_cls * topk;
+  char* p = (char*)workspace;
+  auto take = [&](size_t bytes) { char* q = p; p += prop_align(bytes); return (void*)q; };
+  float* scores = (float*)take(N * 4);
+  float* boxes = refined ? refined : (float*)take(N * 7 * 4);
+  long long* bidx = (long long*)take(N * 8);
+  long long* cidx = (long long*)take(N * 8);
+  long long* keep = (long long*)take(N * 8);
+  int* order = (int*)take(N * 4);
+  v3d::BoxPrep* prep = (v3d::BoxPrep*)take(N * sizeof(v3d::BoxPrep));
+  unsigned long long* mask = (unsigned long long*)take(v3d_nms_rotated_workspace((int)N));
+  hipLaunchKernelGGL(prop_refine_sort_kernel, dim3(1), dim3(PROP_THREADS), 0, st, deltas, proposals, conf, g, scores, boxes, bidx, cidx, order,
+                     prep);
+  const size_t nwords = (N + 63) / 64;
+  const int rc = v3d_i_nms_mask_sorted(prep, (int)N, iou_threshold, mask, st);
+  if (rc != V3D_OK) return rc;
+  hipLaunchKernelGGL(prop_nms_reduce_finalize_kernel, dim3(1), dim3(PROP_NMS_THREADS), 0, st, mask, order, (int)N, mask + N * nwords, keep, g,
+                     boxes, bidx, cidx, scores, out_boxes, (long long*)out_batch_idx, (long long*)out_class_idx, out_scores, n_out,
+                     (const int*)nullptr);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }

@@ -80,7 +80,8 @@ class PV_RCNN(nn.Module):
         main = torch.cuda.current_stream(item["points"].device)
         if "keypoints" not in item:
             self.prefetch_keypoints(item)
-        if self._native_item(item):   # eval, no autograd, voxels of the device Preprocessor: the sparse CNN as one native plan
+        native = self._native_item(item)
+        if native:                    # eval, no autograd, voxels of the device Preprocessor: the sparse CNN as one native plan
             cnn_features, bev_map = self._native_cnn(item)
         else:
             if "voxel_mean" in item:      # device voxelizer output
@@ -88,7 +89,12 @@ class PV_RCNN(nn.Module):
             else:                         # reference-style (M, K, C) slots + occupancy
                 voxel_features = self.vfe(item["features"], item["occupancy"])
             cnn_features, bev_map = self.cnn(voxel_features, item["coordinates"], item["batch_size"])
-        item["P_cls"], item["P_reg"] = self.proposal_layer(bev_map)
+        if native and self.native_tail:  # the fused [cls | reg] maps are what the native top-k of stage1_proposals reads
+            item["_head_maps"] = self.proposal_layer.native_head(bev_map)
+            item["P_cls"], item["P_reg"] = self.proposal_layer.maps_from_fused(item["_head_maps"])
+        else:
+            item.pop("_head_maps", None)
+            item["P_cls"], item["P_reg"] = self.proposal_layer(bev_map)
         item["_cnn_features"], item["_bev_map"] = cnn_features, bev_map
         ready = item.pop("_keypoints_ready", None)
         if ready is not None:
@@ -176,9 +182,23 @@ class PV_RCNN(nn.Module):
     #   refined box = box_encode.decode(residuals, proposal)  (RefinementLayer.apply_refinements);
     #   inference   = refined boxes scored by sigmoid(confidence), rotated NMS per (frame, class) at the stage-1 IoU threshold,
     #                 the per-class score threshold of the config.
+    # the proposal stage either side of stage 2 on csrc/proposal.hip (inference frames of the device Preprocessor): top-k + decode in 2
+    # launches instead of ~26, refined-box decode + sigmoid + batched rotated NMS + score cut in 3 instead of ~60 -- the main stream of
+    # an eager PV-RCNN frame is bound by its launch count.  False: the torch statements below (the cross-check of the tests).
+    native_tail = True
+
+    def _native_tail_ok(self, item):
+        head = self.proposal_layer
+        return (self.native_tail and "_head_maps" in item and not torch.is_grad_enabled()
+                and head.native_supported(item["_head_maps"].shape[0], item["anchors"].numel() // (7 * self.cfg.NUM_CLASSES)))
+
     def stage1_proposals(self, item):
         """-> boxes (B, n_cls * TOPK, 7), scores (B, n_cls * TOPK), class_idx (n_cls * TOPK,) from P_cls / P_reg / anchors."""
         head = self.proposal_layer
+        if self._native_tail_ok(item):
+            boxes, scores = head.native_topk(item["_head_maps"], item["anchors"])
+            class_idx = torch.arange(self.cfg.NUM_CLASSES, device=scores.device).repeat_interleave(head.TOPK)
+            return boxes, scores, class_idx
         score_map = item["P_cls"].sigmoid()
         b, n_cls = score_map.shape[:2]
         scores, anchor_idx = score_map.reshape(b, n_cls, -1).topk(head.TOPK, -1)
@@ -186,26 +206,35 @@ class PV_RCNN(nn.Module):
         class_idx = torch.arange(n_cls, device=scores.device).repeat_interleave(head.TOPK)
         return boxes.reshape(b, -1, head.DOF), scores.reshape(b, -1), class_idx
 
-    def forward(self, item, samples=None):
+    def forward(self, item, samples=None, decode=True):
         """Stage 1 + stage 2.  Adds to `item`: keypoints, P_cls, P_reg, keypoint_features (B, 512, K), proposals (B, n, 7),
         proposal_scores (B, n), proposal_class (n,), pooled_features (B, n, 256), R_reg (B, n, 7), R_cls (B, n, 1) and
-        boxes_refined (B, n, 7).  `samples` (B, n, NUM_GRIDPOINTS, 3) in [0, 1) fixes the RoI grid points (the reference draws
-        them with an unseeded torch.rand, roi_grid_pool.py:59)."""
+        boxes_refined (B, n, 7) [decode=False: left to the caller -- `inference` gets them from the native tail].  `samples`
+        (B, n, NUM_GRIDPOINTS, 3) in [0, 1) fixes the RoI grid points (the reference draws them with an unseeded torch.rand,
+        roi_grid_pool.py:59)."""
         item = self.proposal(item)
         features = self.point_feature_extract(item, item["_cnn_features"], item["_bev_map"])
         boxes, scores, class_idx = self.stage1_proposals(item)
         pooled = self.roi_grid_pool(boxes, item["keypoints"], features, samples)
         deltas, conf = self.refinement_layer(item["points"], pooled, boxes)
         item.update(keypoint_features=features, proposals=boxes, proposal_scores=scores, proposal_class=class_idx,
-                    pooled_features=pooled, R_reg=deltas, R_cls=conf,
-                    boxes_refined=self.refinement_layer.apply_refinements(deltas, boxes))
+                    pooled_features=pooled, R_reg=deltas, R_cls=conf)
+        if decode:
+            item["boxes_refined"] = self.refinement_layer.apply_refinements(deltas, boxes)
         return item
 
     def inference(self, item, samples=None):
         """-> (boxes (K, 7), batch_idx (K,), class_idx (K,), scores (K,)) by decreasing score, the return contract of
         Second.inference / ProposalLayer.inference."""
         from ..ops import batched_nms_rotated
-        item = self.forward(item, samples)
+        if "voxel_mean" in item and self.native_tail and not self.training and not torch.is_grad_enabled():
+            item = self.forward(item, samples, decode=False)
+            if self._native_tail_ok(item):
+                item["boxes_refined"], out = self.proposal_layer.native_refine_nms(item["R_reg"], item["proposals"], item["R_cls"])
+                return out
+            item["boxes_refined"] = self.refinement_layer.apply_refinements(item["R_reg"], item["proposals"])
+        else:
+            item = self.forward(item, samples)
         boxes = item["boxes_refined"]
         b, n = boxes.shape[:2]
         scores = item["R_cls"].sigmoid().reshape(-1)

@@ -146,6 +146,54 @@ class ProposalLayer(nn.Module):
                                            L.ptr(ws), ws.numel(), L.stream_ptr()), "proposals")
         return boxes, batch_idx, class_idx, scores, n_out
 
+    def native_topk(self, head_maps, anchors):
+        """The decoded top-k candidates BEFORE NMS (v3d_proposals_topk): boxes (B, n_cls * TOPK, 7), scores (B, n_cls * TOPK), in the
+        order of `scores.topk` + `_decode` of the torch statement (ties: anchor index ascending).  No host synchronisation."""
+        cfg = self.cfg
+        L.require_gpu("proposals_topk", head_maps, anchors)
+        maps, anc = L.as_f32("proposals_topk", head_maps), L.as_f32("proposals_topk", anchors)
+        B, ctot, H, W = maps.shape
+        n_cls, n_yaw = cfg.NUM_CLASSES, cfg.NUM_YAW
+        if ctot != n_cls * n_yaw * (1 + self.DOF) or self.DOF != 7 or anc.numel() != n_cls * n_yaw * H * W * 7:
+            raise RuntimeError("proposals_topk: head map / anchor grid shapes disagree")
+        N = B * n_cls * self.TOPK
+        boxes = torch.empty((B, n_cls * self.TOPK, 7), dtype=torch.float32, device=maps.device)
+        scores = torch.empty((B, n_cls * self.TOPK), dtype=torch.float32, device=maps.device)
+        lib = L.lib()
+        ws = L.workspace(lib.v3d_proposals_workspace(B, n_cls, self.TOPK), maps.device)
+        with torch.cuda.device(maps.device):
+            L.check(lib.v3d_proposals_topk(L.ptr(maps), L.ptr(anc), B, n_cls, n_yaw, H, W, self.TOPK, L.ptr(boxes), L.ptr(scores), L.ptr(ws),
+                                           ws.numel(), L.stream_ptr()), "proposals_topk")
+        assert N == boxes.shape[0] * boxes.shape[1]
+        return boxes, scores
+
+    def native_refine_nms(self, deltas, proposals, conf, iou_threshold=0.01):
+        """Stage-2 tail (v3d_refine_nms): deltas / proposals (B, n_cls * TOPK, 7) and conf (B, n_cls * TOPK[, 1]) in the layout of
+        `native_topk` -> (refined boxes (B, n, 7), [boxes, batch_idx, class_idx, scores] of the survivors by decreasing score).  One
+        host read (the count)."""
+        cfg = self.cfg
+        d, p, c = (L.as_f32("refine_nms", t) for t in (deltas, proposals, conf))
+        L.require_gpu("refine_nms", d, p, c)
+        B, n = p.shape[:2]
+        n_cls = cfg.NUM_CLASSES
+        if n != n_cls * self.TOPK or d.shape != p.shape or c.numel() != B * n or p.shape[-1] != 7:
+            raise RuntimeError("refine_nms: candidates are not in the (B, n_cls * TOPK) layout of native_topk")
+        N, dev = B * n, p.device
+        refined = torch.empty((B, n, 7), dtype=torch.float32, device=dev)
+        boxes = torch.empty((N, 7), dtype=torch.float32, device=dev)
+        batch_idx = torch.empty((N,), dtype=torch.int64, device=dev)
+        class_idx = torch.empty((N,), dtype=torch.int64, device=dev)
+        scores = torch.empty((N,), dtype=torch.float32, device=dev)
+        n_out = torch.empty((1,), dtype=torch.int32, device=dev)
+        lib = L.lib()
+        ws = L.workspace(lib.v3d_refine_nms_workspace(B, n_cls, self.TOPK), dev)
+        thresh = L.host_f32([a["score_thresh"] for a in cfg.ANCHORS[:n_cls]])
+        with torch.cuda.device(dev):
+            L.check(lib.v3d_refine_nms(L.ptr(d), L.ptr(p), L.ptr(c), B, n_cls, self.TOPK, thresh, float(iou_threshold), L.ptr(refined),
+                                       L.ptr(boxes), L.ptr(batch_idx), L.ptr(class_idx), L.ptr(scores), L.ptr(n_out), L.ptr(ws), ws.numel(),
+                                       L.stream_ptr()), "refine_nms")
+        return refined, self.finalize_native(boxes, batch_idx, class_idx, scores, n_out)
+
     @staticmethod
     def finalize_native(boxes, batch_idx, class_idx, scores, n_out, overflow_flag=None):
         """The one host read of the frame (the reference synchronises inside its NMS): the number of proposals and, when
