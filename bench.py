@@ -97,7 +97,7 @@ def parse():
                     help="arithmetic of the native inference path: fp32 = f16 hi/lo pieces under calibrated power-of-two scales (the "
                          "reference's fp32 modules up to summation noise); bf16x3 = bf16 pieces, 2^-17 per product (fast mode)")
     ap.add_argument("--no-fast-mode", action="store_true", help="forward mode: skip the bf16x3 line measured beside the fp32-class one")
-    ap.add_argument("--order", choices=["shuffled", "scan"], default="shuffled",
+    ap.add_argument("--order", choices=["shuffled", "scan", "morton"], default="shuffled",
                     help="forward mode: point order of the synthetic sweeps -- shuffled (default: what the TRAINING dataset hands over, "
                          "kitti_dataset.py:154; the gathers of the sparse convolutions are then random) or scan (firing order: what "
                          "inference.py reads from a .bin file; neighbouring voxels are neighbouring rows)")

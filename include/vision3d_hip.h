@@ -241,6 +241,24 @@ int v3d_sparse_conv_fwd_packed2(const float* in, const void* weight_image, const
                                 int32_t* range_flag, const void* in_split, void* out_split, v3d_stream_t stream);
 int v3d_sparse_rows_split(const float* rows, const int32_t* n_rows, int cap, int C, int prec, const float* act_entry,
                           void* out_split, v3d_stream_t stream);
+/* ---- T3 over SPATIALLY ORDERED rows (csrc/brick.hip; same interface the reference reaches through spconv.SubMConv3d,
+ * detector/sparse_cnn.py:15-30).  When the rows of a stage are numbered in a spatial (brick / Morton) order, the 27 x 256
+ * neighbours of 256 consecutive rows are ~1.2-1.7 x 256 distinct rows: v3d_sparse_brick_plan derives, once per submanifold
+ * table `nbr` (K = 27), per 256-row pass the list of those rows (`ulist`, 480 per pass; `ucnt` their number), every table entry
+ * as a slot of its pass's list (`lidx`, 0xFFFF = no neighbour) and per 16-row tile the mask of offsets any of its rows has
+ * (`tmask`); v3d_sparse_conv_fwd_brick (Cin -> Cout = 64 -> 64, 32 -> 32; split rows in, rows and / or split rows out) keeps a pass's
+ * rows in LDS and walks the offsets without any global gather.  Correct for ANY row order (a pass with more than 480 distinct
+ * neighbours gathers directly); same bits as v3d_sparse_conv_fwd_packed2 with rows_hint = -6.
+ * v3d_sparse_brick_table_bytes: byte sizes of the four tables for a capacity (each a multiple of 256), returns their sum. */
+size_t v3d_sparse_brick_table_bytes(int cap, int K, size_t* lidx_bytes, size_t* ulist_bytes, size_t* ucnt_bytes,
+                                    size_t* tmask_bytes);
+int v3d_sparse_brick_plan(const int32_t* nbr, const int32_t* n_rows, int cap, int K, uint16_t* lidx, int32_t* ulist,
+                          int32_t* ucnt, uint32_t* tmask, v3d_stream_t stream);
+int v3d_sparse_conv_fwd_brick(const void* in_split, const void* weight_image, const int32_t* nbr, const uint16_t* lidx,
+                              const int32_t* ulist, const int32_t* ucnt, const uint32_t* tmask, const int32_t* n_out,
+                              int cap, int K, int Cin, int Cout, const float* scale, const float* shift, int relu, float* out,
+                              int prec, const float* act_in, const float* act_next, int32_t* range_flag, void* out_split,
+                              v3d_stream_t stream);
 
 /* ---- T3 backward (spconv indice_conv backward; the reference trains through it at train.py:65).
  * Data gradient: dX[i] = sum_k dY[nbrT[k][i]] @ W[k]^T -- the forward entry points above on the TRANSPOSED

@@ -52,6 +52,9 @@ _SIGNATURES = {
     "v3d_sparse_conv_pack_weights2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "v3d_sparse_conv_fwd_packed2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "v3d_sparse_rows_split": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "v3d_sparse_brick_table_bytes": (_sz, [_i, _i, _vp, _vp, _vp, _vp]),
+    "v3d_sparse_brick_plan": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "v3d_sparse_conv_fwd_brick": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "v3d_act_scale_from_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "v3d_act_scale_from_rows2": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "v3d_rulebook_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -94,6 +94,20 @@ int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, cons
                                  void* out_split = nullptr /*besides `out`: the output rows split under act->next (f16s) for the next
                                  packed layer, (cap_out, 2 * Cout) 16-bit*/);
 
+// brick.hip: tables of a submanifold rulebook over spatially ordered rows (a plan in brick order), per pass of 256 output rows:
+// the distinct input rows it touches, the neighbour table translated into slots of that list, per-tile offset masks.
+struct V3dBrickTables {
+  uint16_t* lidx;   // (K, cap) slot of nbr[k][o] in its pass's list, 0xFFFF = no neighbour
+  int32_t* ulist;   // (passes, 480) distinct input rows of a pass, ascending
+  int32_t* ucnt;    // (passes) their number (beyond 480: the pass runs the direct-gather body)
+  uint32_t* tmask;  // (ceil(cap / 16)) bit k = some row of the 16-row tile has a neighbour under offset k
+};
+int v3d_i_sparse_brick_plan(const int32_t* nbr, const int32_t* n_in, int cap_in, const int32_t* n_out, int cap_out, int K,
+                            const V3dBrickTables& t, hipStream_t st);
+int v3d_i_sparse_conv_fwd_brick(const void* in_split, const void* weight_image, const int32_t* nbr, const V3dBrickTables& bt,
+                                const int32_t* n_out, int cap, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
+                                float* out, int prec, const V3dActScale* act, void* out_split, hipStream_t st);
+
 // spconv.hip: v3d_sparse_conv_fwd (exact fp32 kernels) whose output is additionally checked against the limit of the f16s scale
 // entry of the tensor it produces (wave kernel only; both nullable)
 int v3d_i_sparse_conv_fwd_exact(const float* in, const float* weight, const int32_t* nbr, const int32_t* n_out, int cap_out, int K,

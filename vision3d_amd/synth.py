@@ -55,6 +55,16 @@ def _ray_scene(rng, az, el, n_cars, x_rng, y_rng, wall_rng):
     return d * t[:, None], hit, boxes
 
 
+def _morton_key(pts, bounds, vs=(0.05, 0.05, 0.1)):
+    c = np.floor((pts[:, :3].astype(np.float32) - np.asarray(bounds[:3], np.float32)) / np.asarray(vs, np.float32)).astype(np.int64)
+    key = np.zeros(pts.shape[0], np.uint64)
+    for j in range(3):
+        x = c[:, j].astype(np.uint64)
+        for i in range(13):
+            key |= ((x >> np.uint64(i)) & np.uint64(1)) << np.uint64(3 * i + j)
+    return key
+
+
 def make_cloud(seed=0, n_points=16384, bounds=KITTI_BOUNDS, fov_deg=45.0, az_steps=1000, n_beams=64,
                n_cars=12, return_boxes=False, order="shuffled"):
     """One synthetic sweep, float32 (n_points, 4).  Deterministic in `seed`.
@@ -80,10 +90,12 @@ def make_cloud(seed=0, n_points=16384, bounds=KITTI_BOUNDS, fov_deg=45.0, az_ste
         if pts.shape[0] >= n_points:
             break
         steps *= 2  # denser azimuth sampling until the crop holds enough returns
-    if order == "scan":  # the same subset as the shuffled sweep (same generator draws), restored to firing order
+    if order in ("scan", "morton"):  # the same subset as the shuffled sweep (same generator draws), restored to firing order
         sel = np.arange(pts.shape[0])
         sub.shuffle(sel)
         pts = pts[np.sort(sel[:n_points])]
+        if order == "morton":  # (experiments: the returns sorted by the 3-D Morton key of their 0.05 x 0.05 x 0.1 m cell, stable)
+            pts = pts[np.argsort(_morton_key(pts, bounds), kind="stable")]
     else:
         sub.shuffle(pts)
         pts = pts[:n_points]
