@@ -116,6 +116,69 @@ def second_forward(sd, clouds, voxel_size, bounds, max_pts=5, max_voxels=20000, 
                 layer_stats=stats)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The same forward in FLOAT64 from the definition (numpy matmuls over the C rulebooks, torch CPU double convolutions): not a
+# restatement of what the reference computes -- the reference computes in fp32 -- but the yardstick for the STRICT elementwise bar
+# of the fp32-class arithmetic: two fp32 pipelines differ from each other by twice their own summation noise (the fp32 restatement
+# above against the GPU path: 2-4e-4 on entries above 1e-3 of the maximum), each differs from float64 by its own (<= 2e-4).
+# ---------------------------------------------------------------------------------------------------------------------------------
+def sparse_backbone64(sd, feats, coords, shape, batch_size):
+    feats = np.asarray(feats, np.float64)
+    books = {}
+    for bi, block in enumerate(SPMIDDLE_FHD):
+        for li, (kind, cin, cout, ks, st, pd, key) in enumerate(block):
+            if kind == "subm":
+                if key not in books:
+                    books[key] = O.subm_rulebook(coords, shape, ks)
+                nbr, out_coords, out_shape = books[key], coords, shape
+            else:
+                out_coords, nbr, out_shape = O.sparse_rulebook(coords, shape, ks, st, pd)
+            w = np.asarray(sd[f"cnn.blocks.{bi}.{li}.0.weight"], np.float64).reshape(nbr.shape[1], cin, cout)
+            pre = f"cnn.blocks.{bi}.{li}.1"
+            g, b_, m, v = (np.asarray(sd[pre + k], np.float64) for k in (".weight", ".bias", ".running_mean", ".running_var"))
+            scale = g / np.sqrt(v + BN_EPS)
+            f = np.concatenate([feats, np.zeros((1, cin))], 0)  # row -1 = absent neighbour
+            out = np.zeros((nbr.shape[0], cout))
+            for k in range(nbr.shape[1]):
+                out += f[nbr[:, k]] @ w[k]
+            feats = np.maximum(out * scale + (b_ - m * scale), 0.0)
+            coords, shape = out_coords, out_shape
+    c = feats.shape[1]
+    dense = np.zeros((batch_size, c, shape[0], shape[1], shape[2]))
+    co = np.asarray(coords).reshape(-1, 4)
+    dense[co[:, 0], :, co[:, 1], co[:, 2], co[:, 3]] = feats
+    return dense.reshape(batch_size, c * shape[0], shape[1], shape[2])
+
+
+def dense_rpn_head64(sd, bev):
+    T = lambda k: torch.from_numpy(np.ascontiguousarray(sd[k])).double()
+    x = torch.from_numpy(np.ascontiguousarray(bev)).double()
+
+    def cbr(x, conv, bn, pad):
+        x = F.conv2d(x, T(conv + ".weight"), None, padding=pad)
+        x = F.batch_norm(x, T(bn + ".running_mean"), T(bn + ".running_var"), T(bn + ".weight"), T(bn + ".bias"), False, 0.0, BN_EPS)
+        return F.relu(x)
+
+    x = cbr(F.pad(x, (1, 1, 1, 1)), "rpn.down_block.1", "rpn.down_block.2", 0)
+    for j in range(5):
+        x = cbr(x, f"rpn.down_block.{4 + 3 * j}", f"rpn.down_block.{5 + 3 * j}", 1)
+    x = cbr(x, "rpn.up_block.0", "rpn.up_block.1", 0)
+    cls = F.conv2d(x, T("head.conv_cls.weight"), T("head.conv_cls.bias"))
+    reg = F.conv2d(x, T("head.conv_reg.weight"), T("head.conv_reg.bias"))
+    return x.numpy(), cls.numpy(), reg.numpy()
+
+
+def second_forward64(sd, clouds, voxel_size, bounds, max_pts=5, max_voxels=20000, dense=True):
+    """-> dict(bev, rpn, cls, reg) in float64 (rpn / cls / reg only with dense=True): the strict yardstick, see above."""
+    vox, coords, occ = voxelize_batch(clouds, voxel_size, bounds, max_pts, max_voxels)
+    mean = O.vfe_mean(vox, occ)
+    bev = sparse_backbone64(sd, mean, coords, grid_shape(bounds, voxel_size), len(clouds))
+    if not dense:
+        return dict(bev=bev)
+    rpn, cls, reg = dense_rpn_head64(sd, bev)
+    return dict(bev=bev, rpn=rpn, cls=cls, reg=reg)
+
+
 def proposals(cls, reg, anchors, n_cls, n_yaw, dof, topk, score_thresh):
     """detector/proposal.py:47-80 on the CPU: sigmoid, top-k, decode, batched rotated NMS (0.01), score cut."""
     b = cls.shape[0]

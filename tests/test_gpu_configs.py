@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import assert_features_close, numpy_state_dict, randomize_bn
+from gpu_util import assert_features_close, assert_fp32_class, numpy_state_dict, randomize_bn
 from vision3d_amd import synth
 from vision3d_amd.core.config import second_car_cfg, waymo_range_cfg
 
@@ -40,7 +40,9 @@ def test_waymo_range_cropped_forward_matches_oracle():
     ref, _, _, _ = second_cpu.sparse_backbone(numpy_state_dict(model), O.vfe_mean(vox, occ), coords,
                                               second_cpu.grid_shape(cfg.GRID_BOUNDS, cfg.VOXEL_SIZE), 1)
     assert bev.shape == ref.shape == (1, 64 * 3, 376, 376)
-    assert_features_close(bev.cpu().numpy(), ref, "Waymo-range crop: BEV vs oracle")
+    ref64 = second_cpu.sparse_backbone64(numpy_state_dict(model), O.vfe_mean(vox, occ), coords,
+                                         second_cpu.grid_shape(cfg.GRID_BOUNDS, cfg.VOXEL_SIZE), 1)
+    assert_fp32_class(bev.cpu().numpy(), ref, "Waymo-range crop: BEV vs oracle", ref64)
 
 
 def test_waymo_range_full_sweep_sites_exact_and_large_kernels(oracle):

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import assert_features_close, randomize_bn
+from gpu_util import assert_features_close, assert_fp32_class, randomize_bn
 from vision3d_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -106,5 +106,11 @@ def test_eval_forward_item_is_native_and_matches_module_path(aliased):
         p_cls, p_reg = out["P_cls"].clone(), out["P_reg"].clone()
     ref = model(dict(item))  # autograd on -> module path (MIOpen fp32)
     assert p_cls.shape == ref["P_cls"].shape == (2, 1, 2, 200, 176) and p_reg.shape == ref["P_reg"].shape == (2, 1, 2, 200, 176, 7)
-    assert_features_close(p_cls.cpu().numpy(), ref["P_cls"].detach().cpu().numpy(), "P_cls native vs module path")
-    assert_features_close(p_reg.cpu().numpy(), ref["P_reg"].detach().cpu().numpy(), "P_reg native vs module path")
+    # elementwise against the module path (torch fp32), strict bar against float64 from the definition (oracle/second_cpu.py)
+    from gpu_util import numpy_state_dict
+    from oracle import second_cpu
+    ref64 = second_cpu.second_forward64(numpy_state_dict(model), clouds, cfg.VOXEL_SIZE, cfg.GRID_BOUNDS, cfg.MAX_OCCUPANCY, cfg.MAX_VOXELS)
+    assert_fp32_class(p_cls.cpu().numpy(), ref["P_cls"].detach().cpu().numpy(), "P_cls native vs module path",
+                      ref64["cls"].reshape(p_cls.shape))
+    assert_fp32_class(p_reg.cpu().numpy(), ref["P_reg"].detach().cpu().numpy(), "P_reg native vs module path",
+                      ref64["reg"].reshape(p_reg.shape[0], p_reg.shape[1], 7, *p_reg.shape[2:5]).transpose(0, 1, 3, 4, 5, 2))

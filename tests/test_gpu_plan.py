@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import assert_features_close, numpy_state_dict, randomize_bn
+from gpu_util import assert_features_close, assert_fp32_class, numpy_state_dict, randomize_bn
 from vision3d_amd import synth
 from vision3d_amd.core.config import second_car_cfg
 
@@ -91,7 +91,9 @@ def test_plan_tracks_weight_updates_and_matches_oracle():
     assert not torch.equal(before, after)
     ref = second_cpu.second_forward(numpy_state_dict(model), [cloud], cfg.VOXEL_SIZE, cfg.GRID_BOUNDS, cfg.MAX_OCCUPANCY,
                                     cfg.MAX_VOXELS)
-    assert_features_close(after.cpu().numpy(), ref["bev"], "plan BEV vs oracle")
+    ref64 = second_cpu.second_forward64(numpy_state_dict(model), [cloud], cfg.VOXEL_SIZE, cfg.GRID_BOUNDS, cfg.MAX_OCCUPANCY, cfg.MAX_VOXELS,
+                                        dense=False)
+    assert_fp32_class(after.cpu().numpy(), ref["bev"], "plan BEV vs oracle", ref64["bev"])
 
 
 def test_inference_points_equals_item_path():
@@ -252,6 +254,101 @@ def test_f16s_range_overflow_is_flagged_recalibrated_and_rerun():
         assert gplan.calibration_generation == g0 + 1
         _same_detections(out, got)
         _same_detections(run([loud]), got)  # steady state after the recalibration: plain replays
+
+
+def test_f16s_quiet_frame_is_flagged_recalibrated_downward_and_rerun():
+    """The other direction (round-5 review, weak 2): scale entries calibrated on a LOUD frame keep 22 bits only down to 2^-17 of
+    that frame's maxima.  A later frame whose tensors stay 2^12 or more below the calibrated limits must not silently lose
+    precision: every producing wave folds its maximum into the plan's per-frame table, the one-wave check behind the last layer
+    raises the summary word to 3 (runtime.RangeUnderflow at the frame's one host read), the entries are re-derived from THAT frame
+    and it is run again -- eager path, captured graph, and a pipeline with 4 frames in flight (both directions)."""
+    from vision3d_amd.core import AnchorGenerator
+    from vision3d_amd.runtime import RangeUnderflow
+    cfg = second_car_cfg()
+    anchors = AnchorGenerator(cfg).anchors.cuda()
+    normal = torch.from_numpy(synth.make_cloud(1)).cuda()
+    loud = normal.clone()
+    loud[:, 3] *= 3.0e4  # every layer's input ~1e4-fold (2^13) louder than the normal frame
+    with torch.no_grad():
+        want_normal = build_model(7).inference_points([normal], anchors)
+        want_loud = build_model(7).inference_points([loud], anchors)
+        model = build_model(7)
+        model.inference_points([loud], anchors)  # calibrated on the loud frame
+        plan = next(iter(model._plans.values()))
+        gen = plan.calibration_generation
+        hi, lo = plan.forward_split(normal, [0, normal.shape[0]])  # the check itself: the plan alone raises the word to 3
+        assert int(plan.overflow_any().item()) == 3
+        with pytest.raises(RangeUnderflow):
+            plan.check_overflow()
+        got = model.inference_points([normal], anchors)  # flagged -> recalibrated downward on this frame -> run again
+        assert plan.calibration_generation == gen + 1
+        _same_detections(got, want_normal)
+        assert int(plan.overflow_any().item()) <= 0
+        # ordinary variation is NOT flagged (no recalibration churn): the same sweep with half the reflectance
+        mid = normal.clone()
+        mid[:, 3] *= 0.5
+        model.inference_points([mid], anchors)
+        assert plan.calibration_generation == gen + 1
+        # captured graph: calibrated on the loud frame at capture, then handed the normal one, then the loud one again
+        gmodel = build_model(7)
+        run = gmodel.graphed_inference(anchors, [16384])
+        _same_detections(run([loud]), want_loud)
+        g0 = run.plan.calibration_generation
+        _same_detections(run([normal]), want_normal)
+        assert run.plan.calibration_generation == g0 + 1
+        _same_detections(run([normal]), want_normal)  # steady state: plain replays
+        _same_detections(run([loud]), want_loud)      # ... and up again (RangeOverflow)
+        assert run.plan.calibration_generation == g0 + 2
+        # 4 frames in flight: loud, loud, normal, normal, loud, normal ... every result equals the freshly calibrated model's
+        pmodel = build_model(7)
+        pipe = pmodel.pipelined_inference(anchors, [16384], depth=4)
+        seq = [loud, loud, normal, normal, normal, loud, normal, loud, loud, normal]
+        outs = []
+        for c in seq:
+            r = pipe([c])
+            if r is not None:
+                outs.append([t.clone() for t in r])
+        outs += [[t.clone() for t in r] for r in pipe.flush()]
+        assert len(outs) == len(seq)
+        for c, o in zip(seq, outs):
+            _same_detections(o, want_loud if c is loud else want_normal)
+
+
+def test_f16s_scale_entries_follow_weight_updates():
+    """scale entries derived from the OLD weights must not survive a load_state_dict / optimizer step.  Eager
+    entry points that never read the range flag (bev_from_points) recalibrate on the next frame; a captured graph is captured again
+    (the dense head's packed images are new tensors)."""
+    from vision3d_amd.core import AnchorGenerator
+    cfg = second_car_cfg()
+    anchors = AnchorGenerator(cfg).anchors.cuda()
+    cloud = torch.from_numpy(synth.make_cloud(4)).cuda()
+    with torch.no_grad():
+        model = build_model(5)
+        model.bev_from_points([cloud])
+        plan = next(iter(model._plans.values()))
+        gen = plan.calibration_generation
+        for m in model.cnn.modules():  # every sparse layer 2^-3 quieter: far inside the range flags' blind zone
+            if hasattr(m, "weight") and m.weight is not None and m.weight.dim() == 5:
+                m.weight.mul_(0.125)
+        after = model.bev_from_points([cloud]).clone()
+        assert plan.calibration_generation == gen + 1
+        fresh = build_model(5)
+        for m in fresh.cnn.modules():
+            if hasattr(m, "weight") and m.weight is not None and m.weight.dim() == 5:
+                m.weight.mul_(0.125)
+        assert torch.equal(after, fresh.bev_from_points([cloud]))
+        # captured graph: weights change after the capture -> the next launch captures again and gives the fresh model's result
+        gmodel = build_model(5)
+        run = gmodel.graphed_inference(anchors, [16384])
+        before = [t.clone() for t in run([cloud])]
+        gmodel.head.conv_cls.bias.add_(0.5)
+        gmodel.rpn.down_block[1].weight.mul_(1.25)
+        out = run([cloud])
+        fresh = build_model(5)
+        fresh.head.conv_cls.bias.add_(0.5)
+        fresh.rpn.down_block[1].weight.mul_(1.25)
+        _same_detections(out, fresh.inference_points([cloud], anchors))
+        assert len(out[0]) != len(before[0]) or not torch.equal(out[3], before[3])
 
 
 def test_bf16x3_mode_still_available_and_close_to_fp32_class():

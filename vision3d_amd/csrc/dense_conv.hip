@@ -189,7 +189,8 @@ __global__ __launch_bounds__(V3D_BLOCK) void densify_split_kernel(const float* _
                                                                   int H, int Wd, bf16_t* __restrict__ hi,
                                                                   bf16_t* __restrict__ lo, unsigned* __restrict__ occ,
                                                                   int* __restrict__ written_pix, int* __restrict__ written_n,
-                                                                  const float* __restrict__ entry, int* __restrict__ range_flag) {
+                                                                  const float* __restrict__ entry, int* __restrict__ range_flag,
+                                                                  unsigned* __restrict__ frame_max) {
   const int n = min(*n_ptr, cap);
   const long long total = (long long)n * C;
   const float s_out = PREC == 1 ? entry[0] : 1.f, limit = PREC == 1 ? entry[2] : 0.f;
@@ -210,8 +211,10 @@ __global__ __launch_bounds__(V3D_BLOCK) void densify_split_kernel(const float* _
     hi[o] = h;
     lo[o] = l;
   }
-  if constexpr (PREC == 1)
+  if constexpr (PREC == 1) {
     if (range_flag && vmax > limit) atomicMax(range_flag, V3D_FLAG_RANGE);
+    if (frame_max) v3d_publish_frame_max(frame_max, vmax);
+  }
 }
 
 extern "C" int v3d_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
@@ -247,7 +250,8 @@ int v3d_i_bev_clear_pixels(const int32_t* pix, const int32_t* n, int cap, int ch
 // cleared (v3d_i_bev_clear_pixels on the list the previous call left here): no fill, and this call's pixel list is left behind.
 int v3d_i_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
                              const int32_t* spatial_shape_host, void* out_hi, void* out_lo, uint32_t* occ_inv, hipStream_t st,
-                             int32_t* written_pix, int32_t* written_n, int prec, const float* act_entry, int32_t* range_flag) {
+                             int32_t* written_pix, int32_t* written_n, int prec, const float* act_entry, int32_t* range_flag,
+                             unsigned* frame_max) {
   if (!feat || !coords || !n || cap < 1 || B < 1 || C < 1 || !spatial_shape_host || !out_hi || !out_lo) return V3D_EINVAL;
   if (prec == V3D_PREC_F16S ? !act_entry : prec != V3D_PREC_BF16X3) return V3D_EINVAL;
   if ((written_pix == nullptr) != (written_n == nullptr)) return V3D_EINVAL;
@@ -265,10 +269,10 @@ int v3d_i_densify_nhwc_split(const float* feat, const int32_t* coords, const int
   const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
   if (prec == V3D_PREC_F16S)
     hipLaunchKernelGGL(densify_split_kernel<1>, dim3(blocks > 4096 ? 4096 : blocks), dim3(V3D_BLOCK), 0, st, feat, (const int4*)coords, n,
-                       cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo, occ_inv, written_pix, written_n, act_entry, range_flag);
+                       cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo, occ_inv, written_pix, written_n, act_entry, range_flag, frame_max);
   else
     hipLaunchKernelGGL(densify_split_kernel<0>, dim3(blocks > 4096 ? 4096 : blocks), dim3(V3D_BLOCK), 0, st, feat, (const int4*)coords, n,
-                       cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo, occ_inv, written_pix, written_n, nullptr, nullptr);
+                       cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo, occ_inv, written_pix, written_n, nullptr, nullptr, nullptr);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }

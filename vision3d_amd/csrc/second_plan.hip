@@ -85,6 +85,8 @@ struct v3d_backbone {
   float* act_tab = nullptr;
   float* w_inv_tab = nullptr;  // [n_layers] 1 / s_w of the layers' f16s images, beside act_tab: what the kernels read instead of the
                                // images' trailers (cold lines)
+  unsigned* frame_max = nullptr;  // [n_layers + 1] f16s: running maximum (fp32 bits) of the tensor entry l describes over THIS frame, zeroed
+                                  // by the frame's first launch: what plan_quiet_check_kernel compares with the entries' limits
   struct PlanTrain* train = nullptr;  // training buffers, allocated by the first v3d_backbone_train_forward
   // (Measured and removed in round 4: the rulebook chain on a second stream with one event per finished rulebook -- inside a
   // captured graph the fork / join costs more than the overlap returns, 3 209 -> 2 526 frames/s pipelined; docs/rounds/design_rounds_1-4.md 5c.4.)
@@ -222,6 +224,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
     }
     p->act_tab = ar.take<float>(4 * (p->layers.size() + 1) + p->layers.size());
     p->w_inv_tab = p->act_tab + 4 * (p->layers.size() + 1);
+    p->frame_max = ar.take<unsigned>(p->layers.size() + 1);
     p->cand_slot[0] = ar.take<int>((size_t)max_tickets);
     p->cand_slot[1] = ar.take<int>((size_t)max_tickets);
     for (auto& L : p->layers) {
@@ -246,6 +249,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
   e = hipMemset(p->ff_begin, 0xFF, p->ff_bytes);
   if (e == hipSuccess) e = hipMemset(p->bev_hi, 0, (size_t)((char*)p->bev_lo - (char*)p->bev_hi) * 2);  // the planes are adjacent
   if (e == hipSuccess) e = hipMemset(p->bev_pix_n, 0, sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemset(p->frame_max, 0, (p->layers.size() + 1) * sizeof(unsigned));
   if (e == hipSuccess) {
     std::vector<float> tab;
     for (size_t i = 0; i <= p->layers.size(); i++) tab.insert(tab.end(), {1.f, 1.f, 32768.f, 0.f});
@@ -304,7 +308,9 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
 // ahead of the densify kernel that needs it).
 __global__ __launch_bounds__(256) void plan_frame_start_kernel(uint4* __restrict__ ff, size_t nvec, int fill_blocks,
                                                                const int* __restrict__ pix, const int* __restrict__ n_ptr, int cap,
-                                                               int units, uint4* __restrict__ hi, uint4* __restrict__ lo) {
+                                                               int units, uint4* __restrict__ hi, uint4* __restrict__ lo,
+                                                               unsigned* __restrict__ frame_max, int n_frame_max) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_frame_max) frame_max[threadIdx.x] = 0u;  // (f16s: the tensors' running maxima of this frame)
   if ((int)blockIdx.x < fill_blocks) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)fill_blocks * 256)
       ff[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
@@ -333,6 +339,7 @@ static int plan_frame_start(v3d_backbone* p, void* dense_hi, void* dense_lo, hip
   if (rc) return rc;
   if (!own || (p->ff_bytes & 15) || ((uintptr_t)p->ff_begin & 15) || (p->out_channels * p->stages.back().shape[0]) % 8) {
     V3D_CHECK_HIP(v3d_fill_async(p->ff_begin, 0xFF, p->ff_bytes, st));  // all hash tables, count slots, flags, the occupancy bitmap
+    V3D_CHECK_HIP(v3d_fill_async(p->frame_max, 0, (p->layers.size() + 1) * sizeof(unsigned), st));
     if (!own) return V3D_OK;
     const PlanStage& sl = p->stages.back();
     return v3d_i_bev_clear_pixels(p->bev_pix, p->bev_pix_n, sl.cap, p->out_channels * sl.shape[0], p->bev_hi, p->bev_lo, st);
@@ -343,9 +350,25 @@ static int plan_frame_start(v3d_backbone* p, void* dense_hi, void* dense_lo, hip
   const int fill_blocks = (int)std::min<size_t>((nvec + 255) / 256, 4096);
   const int clear_blocks = (int)std::min<long long>(v3d_ceil_div((long long)sl.cap * units, 256), 1024);
   hipLaunchKernelGGL(plan_frame_start_kernel, dim3(fill_blocks + clear_blocks), dim3(256), 0, st, (uint4*)p->ff_begin, nvec, fill_blocks,
-                     p->bev_pix, p->bev_pix_n, sl.cap, units, (uint4*)p->bev_hi, (uint4*)p->bev_lo);
+                     p->bev_pix, p->bev_pix_n, sl.cap, units, (uint4*)p->bev_hi, (uint4*)p->bev_lo, p->frame_max, (int)p->layers.size() + 1);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
+}
+
+// f16s, the DOWNWARD range check.  An output beyond its consumer's limit is caught where it is produced (V3D_FLAG_RANGE); a tensor
+// that has become much SMALLER than the frame its scale entry was calibrated on is only known once the whole tensor exists: every
+// producing wave folds its maximum into frame_max[entry], and this one-wave launch behind the last layer compares the maxima with
+// the limits -- a tensor whose largest magnitude lies 2^V3D_QUIET_BITS or more below its limit raises the frame's summary word to
+// V3D_FLAG_QUIET (read in the frame's one host synchronisation: recalibrate on this frame, run it again -- as for V3D_FLAG_RANGE).
+// Entry 0 (the voxel means, consumed by the exact-fp32 input layer) and all-zero tensors (an empty frame) are not judged.
+__global__ __launch_bounds__(64) void plan_quiet_check_kernel(const float* __restrict__ act_tab, const unsigned* __restrict__ frame_max,
+                                                              int n_entries, int* __restrict__ flag) {
+  bool quiet = false;
+  for (int l = 1 + (int)threadIdx.x; l < n_entries; l += 64) {
+    const unsigned m = frame_max[l];
+    quiet |= m != 0u && __uint_as_float(m) < act_tab[4 * l + 2] * (1.f / (float)(1 << V3D_QUIET_BITS));
+  }
+  if (__ballot(quiet) != 0ull && threadIdx.x == 0) atomicMax(flag, V3D_FLAG_QUIET);
 }
 
 // (timing variant without a per-frame fill: only the planes' clear)
@@ -538,15 +561,20 @@ static int plan_layer_conv(v3d_backbone* p, PlanLayer& L, const float* feat, con
   if (!exact_pass && (c.conv_algo == 4 || (c.conv_algo == 0 && L.d.cin >= 16))) {
     const int prec = inference ? p->prec : V3D_PREC_BF16X3;
     const size_t l = (size_t)(&L - p->layers.data());
-    const V3dActScale as{p->act_tab + 4 * l, p->act_tab + 4 * (l + 1), p->overflow + p->layers.size(), p->w_inv_tab + l};
+    const V3dActScale as{p->act_tab + 4 * l, p->act_tab + 4 * (l + 1), p->overflow + p->layers.size(), p->w_inv_tab + l,
+                         inference ? p->frame_max + l + 1 : nullptr};
     const void* in_s = feat_split ? *feat_split : nullptr;
     // (f16s only: its split is conversion instructions that issue slowly -- profiles/r05_f16s_split_ab.txt --; with bf16 pieces the
     //  second copy of the rows costs the pipelined mode more than the plain split it saves: profiles/r05_presplit_ab.txt)
     //  In THROUGHPUT mode the fp32 rows of such a layer are not written at all -- nobody reads them: the next layer gathers the
     //  split copy, captured graphs expose no intermediate rows -- so the split copy replaces the fp32 stores instead of adding to
     //  them, and pays in both arithmetics.
-    void* out_s = (feat_split && p->presplit && (prec == V3D_PREC_F16S || !p->fp32_rows)) ? L.out_s : nullptr;
-    if (out_s && !p->fp32_rows && !densify) out = nullptr;
+    //  Both only when the NEXT layer really runs a packed kernel (a channel pair outside the packed table falls back to the exact-fp32
+    //  kernel, which gathers fp32 rows: they must then exist, and a split copy would be written for nobody).
+    const bool next_packed = l + 1 < p->layers.size() && p->layers[l + 1].d.cin >= 16 && (c.conv_algo == 4 || c.conv_algo == 0) &&
+                             v3d_i_sparse_conv_packed_supported(p->layers[l + 1].d.cin, p->layers[l + 1].d.cout);
+    void* out_s = (feat_split && p->presplit && next_packed && (prec == V3D_PREC_F16S || !p->fp32_rows)) ? L.out_s : nullptr;
+    if (out_s && !p->fp32_rows && !densify && v3d_i_sparse_conv_packed_supported(L.d.cin, L.d.cout)) out = nullptr;
     rc = v3d_i_sparse_conv_fwd_packed(feat, wimg, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout, scale, shift,
                                       relu, out, L.rows_hint, st, densify, p->ring_tiles_min, prec, &as, in_s, out_s);
     if (rc == V3D_OK && densify && densified) *densified = true;
@@ -560,7 +588,8 @@ static int plan_layer_conv(v3d_backbone* p, PlanLayer& L, const float* feat, con
     const size_t l = (size_t)(&L - p->layers.data());
     rc = v3d_i_sparse_conv_fwd_exact(feat, weight, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout, scale, shift, relu,
                                      out, exact_pass ? 0 : ((c.conv_algo == 4 || c.conv_algo == 0) ? 3 : c.conv_algo), st,
-                                     check ? p->act_tab + 4 * (l + 1) : nullptr, check ? p->overflow + p->layers.size() : nullptr);
+                                     check ? p->act_tab + 4 * (l + 1) : nullptr, check ? p->overflow + p->layers.size() : nullptr,
+                                     check ? p->frame_max + l + 1 : nullptr);
   }
   return rc;
 }
@@ -604,8 +633,14 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
     const bool own = dense_hi == p->bev_hi && dense_lo == p->bev_lo;  // (plan_clear_own_planes ran at the start of this frame)
     rc = v3d_i_densify_nhwc_split(feat, sl.coords, sl.n_dev, sl.cap, B, p->out_channels, sl.shape, dense_hi, dense_lo, p->bev_occ,
                                   st, own ? p->bev_pix : nullptr, own ? p->bev_pix_n : nullptr, p->prec,
-                                  p->act_tab + 4 * p->layers.size(), p->overflow + p->layers.size());
+                                  p->act_tab + 4 * p->layers.size(), p->overflow + p->layers.size(),
+                                  p->prec == V3D_PREC_F16S && !p->calibrating ? p->frame_max + p->layers.size() : nullptr);
     if (rc) return rc;
+  }
+  if (p->prec == V3D_PREC_F16S && !p->calibrating) {
+    hipLaunchKernelGGL(plan_quiet_check_kernel, dim3(1), dim3(64), 0, st, p->act_tab, p->frame_max, (int)p->layers.size() + 1,
+                       p->overflow + (int)p->layers.size());
+    V3D_CHECK_LAUNCH();
   }
   return V3D_OK;
 }

@@ -202,8 +202,10 @@ __device__ __forceinline__ SpScales sp_scales(const V3dActScale& as, const unsig
   return r;
 }
 // an output beyond the consumer's limit: the frame's summary flag (<= 0: fine, 1: a capacity was hit, 2: out of f16s range)
+// (every lane of the wave calls this, at the end of the kernel)
 __device__ __forceinline__ void sp_range_check(const V3dActScale& as, const float vmax, const float limit) {
   if (as.flag && vmax > limit) atomicMax(as.flag, V3D_FLAG_RANGE);
+  if (as.fmax) v3d_publish_frame_max(as.fmax, vmax);
 }
 
 static __device__ __attribute__((aligned(256))) const float spr_zero_row[128] = {};

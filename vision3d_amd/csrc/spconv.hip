@@ -73,7 +73,7 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
                                                                        const float* __restrict__ scale,
                                                                        const float* __restrict__ shift, int relu,
                                                                        float* __restrict__ out, const float* __restrict__ next_entry,
-                                                                       int* __restrict__ range_flag) {
+                                                                       int* __restrict__ range_flag, unsigned* __restrict__ frame_max) {
   constexpr int NB = COUT / 16;
   constexpr int G = SPW_WAVES / NB;
   constexpr int T = CIN / 4;  // MFMA steps; also floats of one row held per lane
@@ -245,17 +245,18 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
     *reinterpret_cast<float4*>(out + (size_t)(row0 + rw) * COUT + c4 * 4) = v;
   }
   if (next_entry && range_flag && vmax > next_entry[2]) atomicMax(range_flag, V3D_FLAG_RANGE);
+  if (frame_max) v3d_publish_frame_max(frame_max, vmax);
 }
 
 template <int CIN, int COUT>
 static int launch_wave(const float* in, const float* W, const int* nbr, const int* n_ptr, int cap, int K,
                        const float* scale, const float* shift, int relu, float* out, hipStream_t st, const float* next_entry,
-                       int* range_flag) {
+                       int* range_flag, unsigned* frame_max) {
   constexpr int G = SPW_WAVES / (COUT / 16);
   const size_t lds = (size_t)G * SPC_TM * COUT * 4 + (size_t)K * SPC_TM * 4 + (size_t)K * 4 + (size_t)K * SPC_TM + 64;
   if (lds > 64 * 1024) return V3D_EUNSUPPORTED;
   hipLaunchKernelGGL((spconv_fwd_wave<CIN, COUT>), dim3(v3d_ceil_div(cap, SPC_TM)), dim3(SPW_WAVES * V3D_WAVE), lds, st,
-                     in, W, nbr, n_ptr, cap, K, scale, shift, relu, out, next_entry, range_flag);
+                     in, W, nbr, n_ptr, cap, K, scale, shift, relu, out, next_entry, range_flag, frame_max);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -1543,6 +1544,15 @@ extern "C" int v3d_sparse_rows_split(const float* rows, const int32_t* n_rows, i
   return V3D_OK;
 }
 
+// the (Cin, Cout) pairs v3d_i_sparse_conv_fwd_packed has kernels for (its V3D_TRY table): what a plan asks BEFORE it decides that a
+// layer's fp32 rows need not be written because the next layer gathers the split copy
+bool v3d_i_sparse_conv_packed_supported(int Cin, int Cout) {
+  static const int shapes[][2] = {{4, 16}, {16, 16}, {16, 32}, {32, 32}, {32, 64}, {64, 64}, {4, 32}, {32, 16}, {64, 32}, {64, 128}, {128, 128}};
+  for (const auto& s : shapes)
+    if (s[0] == Cin && s[1] == Cout) return true;
+  return false;
+}
+
 int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                  int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
                                  float* out, int rows_hint, hipStream_t st, const V3dDensifyOut* densify, int ring_tiles_min,
@@ -1590,19 +1600,19 @@ extern "C" int v3d_sparse_conv_fwd(const float* in, const float* weight, const i
                                    int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift,
                                    int relu, float* out, int algo, v3d_stream_t stream) {
   return v3d_i_sparse_conv_fwd_exact(in, weight, nbr, n_out, cap_out, K, Cin, Cout, scale, shift, relu, out, algo, (hipStream_t)stream,
-                                     nullptr, nullptr);
+                                     nullptr, nullptr, nullptr);
 }
 
 int v3d_i_sparse_conv_fwd_exact(const float* in, const float* weight, const int32_t* nbr, const int32_t* n_out, int cap_out, int K,
                                 int Cin, int Cout, const float* scale, const float* shift, int relu, float* out, int algo,
-                                hipStream_t st, const float* next_entry, int32_t* range_flag) {
+                                hipStream_t st, const float* next_entry, int32_t* range_flag, unsigned* frame_max) {
   if (!in || !weight || !nbr || !n_out || !out || cap_out < 1 || K < 1 || Cin < 1 || Cout < 1) return V3D_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return V3D_EINVAL;
   if (algo != 0 && algo != 1 && algo != 3) return V3D_EINVAL;  // (2 was an LDS-staged fp32 kernel: removed)
   if (algo == 0 || algo == 3) {
     int rc = V3D_EUNSUPPORTED;
 #define V3D_TRY(ci, co) \
-  if (Cin == ci && Cout == co) rc = launch_wave<ci, co>(in, weight, nbr, n_out, cap_out, K, scale, shift, relu, out, st, next_entry, range_flag);
+  if (Cin == ci && Cout == co) rc = launch_wave<ci, co>(in, weight, nbr, n_out, cap_out, K, scale, shift, relu, out, st, next_entry, range_flag, frame_max);
     V3D_TRY(4, 16)
     V3D_TRY(16, 16)
     V3D_TRY(16, 32)

@@ -83,6 +83,16 @@ __device__ __forceinline__ void v3d_split_f16_pair(const float x0, const float x
   lo = l;
 }
 
+// The frame's running maximum of a tensor (f16s range bookkeeping): non-negative floats order like their bits.  Every lane of the
+// wave calls this with its own largest magnitude; one lane folds the wave's maximum into the word -- an atomic only while the word
+// is still smaller (a handful per launch: the word is read first).
+__device__ __forceinline__ void v3d_publish_frame_max(unsigned* __restrict__ word, const float vmax) {
+  unsigned b = __float_as_uint(vmax);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
+  if ((threadIdx.x & 63) == 0 && b > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, b);
+}
+
 // per-device cache of an integer launch parameter (occupancy, CU count): a process may drive several GPUs
 struct V3dPerDeviceInt {
   int v[V3D_MAX_DEVICES] = {};

@@ -58,6 +58,9 @@ int v3d_i_nms_mask_sorted(const void* prep_sorted, int N, float iou_threshold, u
 // values of a frame's summary flag word (reset to -1 by the plan's per-frame 0xFF fill; raised with atomicMax)
 #define V3D_FLAG_CAPACITY 1  // an active-site capacity was hit: rows were dropped
 #define V3D_FLAG_RANGE 2     // f16s arithmetic: a tensor exceeded the range its scale was calibrated for
+#define V3D_FLAG_QUIET 3     // f16s arithmetic: a tensor's largest magnitude of this frame lies 2^12 or more below the limit its scale was
+                             // calibrated for (the small entries of such a tensor no longer keep 22 bits): recalibrate downward, run again
+#define V3D_QUIET_BITS 12
 // f16s: one entry per tensor in device memory = {s, 1/s, limit, 0}: the tensor is split as f16(x * s) by its consumer, and its
 // producer raises V3D_FLAG_RANGE when |x| > limit (= 2^15 / s: a factor two inside f16's 65 504).  All null for bf16x3.
 struct V3dActScale {
@@ -67,6 +70,8 @@ struct V3dActScale {
   const float* w_inv; // nullable: 1 / s_w of the weight image in memory the caller keeps HOT (a plan's table: one line for all layers).
                       // NULL: read from the image's trailer -- a line nothing else touches, i.e. a cold miss of ~1 us at the top of
                       // every launch (measured: every packed layer +1 us against bf16x3 until the plan passed this)
+  unsigned* fmax;     // nullable: the frame's running maximum of this launch's OUTPUT tensor (fp32 bits; zero at the start of a frame):
+                      // every wave folds its largest magnitude in (v3d_publish_frame_max) -- what the plan's quiet check reads
 };
 
 // .dense() riding in the epilogue of the LAST sparse layer (the 16-row kernel): besides its rows the layer writes them, split into
@@ -108,11 +113,13 @@ int v3d_i_sparse_conv_fwd_brick(const void* in_split, const void* weight_image, 
                                 const int32_t* n_out, int cap, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
                                 float* out, int prec, const V3dActScale* act, void* out_split, hipStream_t st);
 
+bool v3d_i_sparse_conv_packed_supported(int Cin, int Cout);
+
 // spconv.hip: v3d_sparse_conv_fwd (exact fp32 kernels) whose output is additionally checked against the limit of the f16s scale
 // entry of the tensor it produces (wave kernel only; both nullable)
 int v3d_i_sparse_conv_fwd_exact(const float* in, const float* weight, const int32_t* nbr, const int32_t* n_out, int cap_out, int K,
                                 int Cin, int Cout, const float* scale, const float* shift, int relu, float* out, int algo,
-                                hipStream_t st, const float* next_entry, int32_t* range_flag);
+                                hipStream_t st, const float* next_entry, int32_t* range_flag, unsigned* frame_max = nullptr);
 
 // spconv.hip: several packed weight images in one launch (mode 0: W (K, Cin, Cout); 1 / 2: the transposed layer of a source
 // (K, Cout, Cin), 2 with the offsets reversed)
@@ -141,6 +148,7 @@ int v3d_i_densify_nhwc_split(const float* feat, const int32_t* coords, const int
                              int32_t* written_pix = nullptr /*with written_n: PERSISTENT planes -- no fill, the written pixels are listed*/,
                              int32_t* written_n = nullptr, int prec = V3D_PREC_BF16X3,
                              const float* act_entry = nullptr /*f16s: {s, 1/s, limit, ..} of the planes (device)*/,
-                             int32_t* range_flag = nullptr /*f16s, nullable: raised to V3D_FLAG_RANGE by a value beyond the limit*/);
+                             int32_t* range_flag = nullptr /*f16s, nullable: raised to V3D_FLAG_RANGE by a value beyond the limit*/,
+                             unsigned* frame_max = nullptr /*f16s, nullable: the planes' running maximum of the frame (V3dActScale::fmax)*/);
 // zero the listed pixels (channels bf16 values each) of both planes: start-of-frame job of persistent BEV planes
 int v3d_i_bev_clear_pixels(const int32_t* pix, const int32_t* n, int cap, int channels, void* hi, void* lo, hipStream_t st);

@@ -75,10 +75,23 @@ class GraphedSecond(object):
             if n < b - a:
                 self.static_points[a + n:b].fill_(PAD_COORDINATE)
 
-    def replay(self):
+    def weights_changed(self):
+        return self.plan.weights_changed() or self.dense.weights_changed()
+
+    def launch(self):
+        """Enqueue the frame sitting in the static buffer.  Captures on first use -- and AGAIN when a parameter of the model changed
+        since the capture (load_state_dict, an optimizer step): the dense head's packed images are new tensors whose addresses the
+        old graph does not know, and the f16s scale entries belong to the old weights' activations; the warm-up passes of the new
+        capture upload the weights and recalibrate on this frame."""
+        if self.graph is not None and self.weights_changed():
+            torch.cuda.synchronize(self.static_points.device)  # nothing may still be running the old graph
+            self.graph = None
         if self.graph is None:
             self._capture()
         self.graph.replay()
+
+    def replay(self):
+        self.launch()
         return self.outputs
 
     def _finalize(self):
@@ -118,9 +131,7 @@ class GraphedSecond(object):
 
     def __call__(self, clouds):
         self.load(clouds)
-        if self.graph is None:
-            self._capture()
-        self.graph.replay()
+        self.launch()
         return self.finalize()
 
 
@@ -189,9 +200,7 @@ class PipelinedSecond(object):
         stream.wait_stream(torch.cuda.current_stream())  # the caller's cloud tensors are ready
         with torch.cuda.stream(stream), torch.no_grad():
             g.load(clouds)
-            if g.graph is None:
-                g._capture()
-            g.graph.replay()
+            g.launch()
 
     def _finish(self, i, stream):
         g = self.slots[i]

@@ -122,15 +122,29 @@ class PV_RCNN(nn.Module):
         plans = self.__dict__.setdefault("_plans", PlanCache())
         dev = next(self.parameters()).device
         key = (str(dev), int(batch_size), int(max_points))
+        # the arithmetic of THIS model's sparse modules (set per instance by set_precision, or by hand on the modules), not the class default
+        precision = next((m.precision for m in self.cnn.modules() if isinstance(m, _SparseConvBase)), _SparseConvBase.precision)
         if key not in plans:
             plans[key] = BackbonePlan(self.cnn, self.cfg, max_batch=batch_size, max_points=max_points, device=dev,
-                                      growth=self.__dict__.get("plan_growth", 2.0), precision=_SparseConvBase.precision)
+                                      growth=self.__dict__.get("plan_growth", 2.0), precision=precision)
             for other in plans.values():  # one calibration per model (see Second.share_calibration)
                 if other is not plans[key] and other.f16s and other._calib == "done":
                     plans[key].copy_calibration(other)
                     break
-        plans[key].set_precision(_SparseConvBase.precision)
+        plans[key].set_precision(precision)
         return plans[key]
+
+    def set_precision(self, precision):
+        """Arithmetic of the native sparse paths of this model (the op-by-op modules and the inference plan): "fp32" (f16s, default)
+        or "bf16x3" -- the same switch as Second.set_precision."""
+        from .. import _lib as L
+        if precision not in L.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(L.PRECISIONS)}")
+        from ..spconv.conv import _SparseConvBase
+        for m in self.modules():
+            if isinstance(m, _SparseConvBase):
+                m.precision = precision
+        return self
 
     def _native_cnn(self, item):
         from .. import spconv
@@ -145,10 +159,10 @@ class PV_RCNN(nn.Module):
             bev_map = plan.forward_voxels(vm, co, b)
             outs = [plan.layer_output(e) for e in ends[:-1]]
             host = torch.cat([n for _, _, n, _ in outs] + [plan.overflow_any()]).tolist()  # the one host read of stage 1
-            if host[-1] == 2 and attempt == 0:  # an f16s tensor left its calibrated range: recalibrate on this frame, run it again
+            if host[-1] in (2, 3) and attempt == 0:  # an f16s tensor left its calibrated range (up or down): recalibrate on this frame, run it again
                 plan.recalibrate()
                 continue
-            if host[-1]:
+            if host[-1] > 0:  # (a clean frame reads -1: the per-frame 0xFF fill)
                 plan.check_overflow()  # raises with the layers that hit their capacity
             break
         volumes = [spconv.SparseConvTensor(vm, co, self.cnn.grid_shape, b)]
@@ -164,6 +178,7 @@ class PV_RCNN(nn.Module):
         main, side = torch.cuda.current_stream(points.device), self._side_stream(points.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
+            points.record_stream(side)  # (the allocator must not hand the cloud's memory out again while the side stream reads it)
             item["keypoints"] = self.sample_keypoints(points)
             item["_keypoints_ready"] = side.record_event()
         return item

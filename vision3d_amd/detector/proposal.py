@@ -28,7 +28,12 @@ def _pinned_pair(device):
 
 
 def _raise_on_flag(word):
-    """The frame's summary word (csrc/v3d_internal.h): 1 = a capacity was hit, 2 = an f16s tensor left its calibrated range."""
+    """The frame's summary word (csrc/v3d_internal.h): 1 = a capacity was hit, 2 = an f16s tensor left its calibrated range, 3 = an
+    f16s tensor stayed 2^12 below it (precision at risk: recalibrate downward)."""
+    if word == 3:
+        from ..runtime import RangeUnderflow
+        raise RangeUnderflow("f16s arithmetic: a tensor of this frame stayed 2^12 below its calibrated range (the fp32-class precision "
+                             "is not guaranteed); recalibrate on this frame and run it again (Second.inference and the graph runners do)")
     if word == 2:
         from ..runtime import RangeOverflow
         raise RangeOverflow("f16s arithmetic: a tensor of this frame exceeded its calibrated range (results invalid); recalibrate "

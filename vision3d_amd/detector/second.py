@@ -229,7 +229,8 @@ class Second(nn.Module):
     #       "bf16x3" (default)  the fp32-class step: split hi + lo storage, three-term products (dense_train.py): no MIOpen
     #                           convolution anywhere in the step, nothing to opt into;
     #       "bf16"              the model enters bf16 autocast ITSELF for the dense half (the faster, reduced-precision step);
-    #       "torch"             the torch modules (MIOpen fp32 convolutions), as the reference runs them.
+    #       "torch"             the torch modules (MIOpen fp32 convolutions), as the reference runs them;
+    #       "fp32"              (the value rounds 1-4 documented for the torch modules) = "torch".
     native_dense_train = os.environ.get("V3D_DENSE_TRAIN", "native") == "native"
     dense_train_precision = os.environ.get("V3D_DENSE_TRAIN_PRECISION", "bf16x3")
 
@@ -243,13 +244,15 @@ class Second(nn.Module):
             return self._train_head_maps_autocast(item)
         if torch.is_autocast_enabled("cuda"):  # (another autocast dtype: the torch modules know what to do with it)
             return None
+        if self.dense_train_precision == "fp32":  # the pre-round-5 name of the torch-module step: still honoured
+            return None
         if self.dense_train_precision == "bf16":
             with torch.autocast("cuda", dtype=torch.bfloat16):  # opted in: the model enters the contract itself
                 return self._train_head_maps_autocast(item)
         if self.dense_train_precision == "bf16x3":
             return self._train_head_maps_split(item)
         if self.dense_train_precision != "torch":
-            raise ValueError(f"dense_train_precision must be 'bf16x3', 'bf16' or 'torch', not {self.dense_train_precision!r}")
+            raise ValueError(f"dense_train_precision must be 'bf16x3', 'bf16', 'torch' or 'fp32' (= 'torch'), not {self.dense_train_precision!r}")
         return None
 
     def _train_head_maps_split(self, item):

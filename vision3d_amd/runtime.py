@@ -22,6 +22,13 @@ class RangeOverflow(RuntimeError):
     Second.inference and the captured-graph runners do."""
 
 
+class RangeUnderflow(RangeOverflow):
+    """f16s arithmetic, the other direction: a tensor of the last frame stayed 2^12 or more below the limit its scale entry was
+    calibrated for (summary word 3, csrc/second_plan.hip plan_quiet_check_kernel) -- the frame's small entries no longer keep the
+    22 bits of the fp32-class arithmetic.  Handled like RangeOverflow (which it subclasses, so every recalibrate-and-rerun path
+    catches it): the entries are re-derived from this frame, downward, and the frame is run again."""
+
+
 CALIB_HEADROOM_BITS = 5  # a later frame may exceed the calibration frame's maxima by 2^6 before the range flag is raised
 
 
@@ -181,6 +188,11 @@ class BackbonePlan(object):
         stamp = self._param_stamp()
         if stamp == self._stamp:
             return
+        if self.f16s and self._stamp is not None and self._calib == "done" and not torch.cuda.is_current_stream_capturing():
+            # the scale entries were derived from the OLD weights' activations (load_state_dict, an optimizer step): derive them again
+            # on the next eager frame -- the eager entry points that never read the range flag (forward, bev_from_points) would
+            # otherwise run on stale entries; captured graphs are refreshed by their runner (detector/graph.py, weights_changed)
+            self._calib = "need"
         lib = L.lib()
         keep = []
         with torch.cuda.device(self.device), torch.no_grad():
@@ -203,9 +215,15 @@ class BackbonePlan(object):
         self._keep = keep  # sources stay alive until the async copies have been consumed
         self._stamp = stamp
 
+    def weights_changed(self):
+        """True when a module tensor changed since the last upload (cheap: pointers and version counters)."""
+        return self._stamp is not None and self._param_stamp() != self._stamp
+
     def forward(self, points, frame_offsets, out=None):
         """points (sum N, C) float32 cuda (frames concatenated), frame_offsets: host ints (B+1).
-        Returns the BEV map (B, C_out * D, H, W); nothing is synchronised."""
+        Returns the BEV map (B, C_out * D, H, W); nothing is synchronised.  f16s: the scale entries follow the weights (sync_weights)
+        and the first frame; a LATER frame outside the calibrated range raises the plan's summary word, which this entry point does not
+        read -- callers that feed frames of very different magnitudes call `check_overflow()` (blocking) or use the inference paths."""
         self.sync_weights()
         pts = L.as_f32("backbone", points)
         b = len(frame_offsets) - 1
@@ -506,9 +524,11 @@ class BackbonePlan(object):
         """Blocking check for callers that only take the BEV map (no per-frame host read of their own).  The summary word is 1 when
         a capacity was hit, 2 when an f16s tensor left its calibrated range (RangeOverflow: recalibrate and re-run)."""
         word = int(self.overflow_any().item())
+        if word == 3 and not ignore_range:
+            raise RangeUnderflow("sparse backbone (f16s): a tensor stayed 2^12 below its calibrated range; recalibrate() and run the frame again")
         if word == 2 and not ignore_range:
             raise RangeOverflow("sparse backbone (f16s): a tensor exceeded its calibrated range; recalibrate() and run the frame again")
-        if word == 1 or (word == 2 and any(self.overflow()[:-1].tolist())):
+        if word == 1 or (word >= 2 and any(self.overflow()[:-1].tolist())):
             hit = [i for i, f in enumerate(self.overflow()[:-1].tolist()) if f]
             raise RuntimeError(f"sparse backbone: layers {hit} exceeded their active-site capacity (rows were dropped); "
                                "build the plan with a larger `growth`")
@@ -734,12 +754,20 @@ class DenseHeadPlan(object):
         assert len(convs) == len(bns)
         return list(zip(convs, bns))
 
-    def sync_weights(self):
-        pairs = self._pairs()
-        tensors = [t for c, b in pairs for t in (c.weight, b.running_mean, b.running_var, b.weight, b.bias)]
+    def _param_stamp(self):
+        tensors = [t for c, b in self._pairs() for t in (c.weight, b.running_mean, b.running_var, b.weight, b.bias)]
         if self.head is not None:
             tensors += [self.head.conv_cls.weight, self.head.conv_cls.bias, self.head.conv_reg.weight, self.head.conv_reg.bias]
-        stamp = tuple((t.data_ptr(), t._version) for t in tensors) + (self.precision,)
+        return tuple((t.data_ptr(), t._version) for t in tensors) + (self.precision,)
+
+    def weights_changed(self):
+        """True when a module tensor changed since the last upload: the packed images (new tensors) are then stale -- a captured
+        graph that baked their addresses in must be captured again (detector/graph.py)."""
+        return self._stamp is not None and self._param_stamp() != self._stamp
+
+    def sync_weights(self):
+        pairs = self._pairs()
+        stamp = self._param_stamp()
         if stamp == self._stamp:
             return
         layers = []
