@@ -63,7 +63,7 @@ DTYPE_NOTE = {
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1,
                     help="ranks of the job = GPUs of this node, one process per GPU.  Under torch.distributed.run (WORLD_SIZE set) it "
@@ -105,7 +105,7 @@ def parse():
     ap.add_argument("--stream", type=int, default=8, help="different synthetic frames per rank the timed loop cycles through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch event timing pass (profiling runs)")
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (about 1.4 s each on one core: ~11 s)")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU baseline sample (about 1.4 s each on one core: ~6 s)")
     ap.add_argument("--windows", type=int, default=31,
                     help="forward mode: back-to-back timed windows of --steps steps each (barrier + synchronize on both sides of every "
                          "window, pipeline empty at its start, max over ranks per window); `value` is the MEDIAN window, "
@@ -115,7 +115,10 @@ def parse():
                          "stage 2 + refinement NMS), one frame at a time, instead of stage 2 on resident stage-1 outputs")
     ap.add_argument("--no-h2d", action="store_true", help="skip the with_h2d line (pinned host cloud copied in every step)")
     ap.add_argument("--single-frames", type=int, default=200, help="frames timed one at a time for single_frame_ms (median, p10, p90)")
-    return ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true",
+                    help="default forward run on one GPU: skip the compact sub-lines of the OTHER BASELINE configurations (`extra`: Waymo-range "
+                         "sweep, bs = 8 KITTI batch, plumbing, PV-RCNN stage 2, train step), each a short in-process run of its own mode")
+    return ap.parse_args(argv)
 
 
 def launch_plan(gpus, environ, argv, n_devices, backend=BACKEND, port=None):
@@ -403,8 +406,8 @@ def train_roofline_split(bs, h=200, w=176):
     hi, lo = to_split_nhwc(torch.randn(bs, 128, h, w, device="cuda"))
     img = pack_conv_weight(torch.randn(128, 128, 3, 3, device="cuda") / 34.0, None, "bf16x3")
     y_hi, y_lo = split_planes_like(bs, h, w, 128, hi.device)
-    run = lambda: L.check(lib.v3d_conv2d_nhwc_bf16x3(L.ptr(hi), L.ptr(lo), L.ptr(img), None, 0, bs, h, w, 128, 128, 3, L.ptr(y_hi), L.ptr(y_lo),
-                                                     None, L.stream_ptr()), "conv")
+    run = lambda: L.check(lib.v3d_conv2d_nhwc_split(L.ptr(hi), L.ptr(lo), L.ptr(img), None, 0, bs, h, w, 128, 128, 3, L.ptr(y_hi), L.ptr(y_lo),
+                                                    None, None, 0, None, None, None, None, None, 0, None, L.stream_ptr()), "conv")
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -898,6 +901,47 @@ def _arm_watchdog(limit_s):
     t.start()
 
 
+# ---- the other BASELINE configurations on the driver's clock: compact sub-lines of the default run --------------------------------
+EXTRA_RUNS = [  # (key, what, argv of a short run of that mode)
+    ("waymo", "BASELINE configs[4]: SECOND forward, 180 k-pt Waymo-range sweep, 3 frames in flight",
+     ["--workload", "waymo", "--pipeline", "3", "--windows", "5", "--steps", "60", "--warmup", "10", "--single-frames", "40", "--stream", "4"]),
+    ("kitti_bs8", "SECOND forward, batch of 8 KITTI clouds per step (65-110 k rows per sparse stage: the large-layer kernels), 2 batches in flight",
+     ["--batch", "8", "--pipeline", "2", "--windows", "5", "--steps", "30", "--warmup", "5", "--single-frames", "20", "--stream", "2"]),
+    ("plumbing", "BASELINE configs[0]: voxelize + points_in_boxes, one 16 k-pt cloud", ["--mode", "plumbing", "--windows", "5", "--steps", "100"]),
+    ("pvrcnn_stage2", "BASELINE configs[3]: PV-RCNN stage 2 on SECOND proposals", ["--mode", "pvrcnn", "--windows", "5", "--steps", "20", "--warmup", "5"]),
+    ("train", "BASELINE configs[2]: SECOND train step bf16, 8 frames per GPU", ["--mode", "train", "--steps", "6", "--warmup", "2"]),
+]
+
+
+def run_extras():
+    """-> {key: compact line} -- every entry a short IN-PROCESS run of bench.py's own mode (same code path as the full line of that
+    mode, fewer windows, no CPU baseline, no bf16x3 / H2D side lines); never raises."""
+    import contextlib
+    import io
+    out = {}
+    for key, what, argv in EXTRA_RUNS:
+        t0 = time.perf_counter()
+        try:
+            a = parse(argv + ["--no-cpu-baseline", "--no-fast-mode", "--no-h2d", "--no-extra", "--watchdog", "0"])
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                {"forward": forward_main, "train": train_main, "pvrcnn": pvrcnn_main, "plumbing": plumbing_main}[a.mode](a)
+            d = json.loads([ln for ln in buf.getvalue().strip().splitlines() if ln.startswith("{")][-1])
+            r = d.get("roofline") or {}
+            out[key] = dict(what=what, metric=d.get("metric"), value=d.get("value"), unit=d.get("unit"), ms_per_step=d.get("ms_per_step"),
+                            single_frame_ms=d.get("single_frame_ms"), steps=d.get("steps"), windows=d.get("windows"),
+                            workload=(d.get("config") or {}).get("workload"),
+                            roofline=dict(kernel=r.get("kernel"), bound=r.get("bound"), frac=r.get("frac"), achieved=r.get("achieved"), unit=r.get("unit"),
+                                          avg_us=r.get("avg_us"), avg_us_in_frame=r.get("avg_us_in_frame"), frac_in_frame=r.get("frac_in_frame"),
+                                          hbm_frac=(r.get("hbm_view") or {}).get("frac"), traffic=r.get("traffic")) if r else None,
+                            seconds=round(time.perf_counter() - t0, 1))
+        except BaseException as e:  # (SystemExit of an argument check included): a reported extra, never the bench line's fate
+            out[key] = dict(what=what, value=None, error=f"{type(e).__name__}: {str(e)[:200]}", seconds=round(time.perf_counter() - t0, 1))
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     import faulthandler
     import signal
@@ -911,6 +955,10 @@ def main():
         return pvrcnn_main(args)
     if args.mode == "plumbing":
         return plumbing_main(args)
+    return forward_main(args)
+
+
+def forward_main(args):
     from vision3d_amd import dist_util
     rank, local, world = dist_util.env_world()
     assert torch.cuda.is_available(), "bench.py needs a GPU (vision3d_amd has no CPU path)"
@@ -1096,7 +1144,7 @@ def main():
                 entry = act_entry_from_tensor(features) if f16s else None
                 feat_c = features.contiguous()
                 out_buf = torch.empty((rb.n, cout_), dtype=torch.float32, device=features.device)
-                L.check(L.lib().v3d_sparse_conv_fwd_packed2(L.ptr(feat_c), L.ptr(packed), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap,
+                L.check(L.lib().v3d_sparse_conv_fwd_packed(L.ptr(feat_c), L.ptr(packed), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap,
                                                             rb.nbr.shape[0], cin_, cout_, L.ptr(scale), L.ptr(shift), int(bool(relu)),
                                                             L.ptr(out_buf), int(rb.n), L.PRECISIONS[args.precision], L.ptr(entry),
                                                             None, None, None, None, L.stream_ptr()), "sparse_conv_fwd_packed2")
@@ -1108,7 +1156,7 @@ def main():
 
                 def launch(feat_c=feat_c, packed=packed, rb=rb, scale=scale, shift=shift, relu=relu, out_buf=out_buf, entry=entry,
                            cin_=cin_, cout_=cout_, in_s=in_s, out_s=out_s, next_entry=next_entry):
-                    L.check(L.lib().v3d_sparse_conv_fwd_packed2(None if in_s is not None else L.ptr(feat_c), L.ptr(packed), L.ptr(rb.nbr),
+                    L.check(L.lib().v3d_sparse_conv_fwd_packed(None if in_s is not None else L.ptr(feat_c), L.ptr(packed), L.ptr(rb.nbr),
                                                                 L.ptr(rb.n_dev), rb.cap, rb.nbr.shape[0], cin_, cout_, L.ptr(scale),
                                                                 L.ptr(shift), int(bool(relu)), None if out_s is not None else L.ptr(out_buf),
                                                                 int(rb.n), L.PRECISIONS[args.precision], L.ptr(entry), L.ptr(next_entry),
@@ -1247,14 +1295,67 @@ def main():
         torch.cuda.synchronize()
         t_dense = e0.elapsed_time(e1) * 1e-3 / 20
         fl = 2.0 * args.batch * ny * nx * cdim * cdim * 9
-        roofline_dense = dict(bound="mfma", kernel="conv2d_bf16x3_large_kernel<3,9>", launches_per_frame=6, flops_per_launch=fl,
-                              avg_us=t_dense * 1e6, achieved=fl / t_dense / 1e12, issued=3 * fl / t_dense / 1e12, peak=2500.0,
-                              unit="TFLOP/s", frac=fl / t_dense / 1e12 / 2500.0, frac_issued=3 * fl / t_dense / 1e12 / 2500.0,
-                              note="every tile convolved, random dense input (the frame itself runs the background-skipping "
-                                   "2-D tile form, conv2d_bf16x3_tile2d_kernel, on a sparse map: fewer MFMAs and one LDS-resident "
-                                   "neighbourhood per tile instead of a gather per tap); peak = dense 16-bit MFMA at the "
-                                   "data-sheet 2.4 GHz, 3 terms per split-precision product; matrix instructions are spaced out by "
-                                   "power management, 16 busy cycles each (profiles/r02_e_dense_tile_timeline.txt)")
+        full_map = dict(kernel="conv2d_bf16x3_large_kernel<3,9>", flops_per_launch=fl, avg_us=t_dense * 1e6, achieved=fl / t_dense / 1e12,
+                        issued=3 * fl / t_dense / 1e12, frac=fl / t_dense / 1e12 / 2500.0, frac_issued=3 * fl / t_dense / 1e12 / 2500.0,
+                        note="every tile convolved, random dense input (NOT what the frame runs: the upper bound of the matrix work)")
+        # ... and the kernel the FRAME runs: the background-skipping 2-D tile form on this frame's sparse map.  Live tiles per layer from
+        # the plan's own occupancy bitmap (a 5 x 16-pixel tile of layer i is live when an occupied BEV pixel lies within i + 1 pixels of
+        # it: csrc/dense_conv.hip dl_tile2d), matrix work of a live tile = 5 row blocks x 8 column blocks x 9 taps x 4 k-steps x 3 terms
+        # = 4 320 MFMAs of 16 384 flop; duration = the in-frame rocprofv3 average (committed csv) and, beside it, the whole dense head of
+        # this frame timed with events (7 launches in a captured graph).
+        roofline_dense = dict(bound="mfma", kernel="conv2d_bf16x3_tile2d_kernel", full_map=full_map)
+        try:
+            with torch.no_grad():
+                plan_d, flat_d, offs_d = model._plan_for(clouds)
+                hi_d, lo_d = plan_d.forward_split(flat_d, offs_d)
+                occ_w = plan_d.bev_occupancy(len(clouds)).clone()
+                bits = ((occ_w.view(len(clouds), ny, -1, 1) >> torch.arange(32, device="cuda", dtype=torch.int32)) & 1).reshape(len(clouds), ny, -1)[:, :, :nx]
+                occ_map = (bits == 0).float().unsqueeze(1)  # inverted bitmap: 0 = occupied
+                live, tiles_total = [], len(clouds) * ((ny + 4) // 5) * ((nx + 15) // 16)
+                for reach in range(1, 7):
+                    near = torch.nn.functional.max_pool2d(occ_map, 2 * reach + 1, 1, reach)
+                    pad = torch.nn.functional.pad(near, (0, (-nx) % 16, 0, (-ny) % 5))
+                    live.append(int((torch.nn.functional.max_pool2d(pad, (5, 16), (5, 16)) > 0).sum().item()))
+                dense, st_d = model.dense_plan(), model.dense_plan().new_state(hi_d.device) if model.skip_background else None
+                run_head = lambda: dense.forward(hi_d, lo_d, occ=plan_d.bev_occupancy(len(clouds)) if model.skip_background else None, work=st_d,
+                                                 in_entry=plan_d.bev_entry(), range_flag=plan_d.overflow_any())
+                for _ in range(3):
+                    run_head()
+                torch.cuda.synchronize()
+                gd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gd):
+                    for _ in range(10):
+                        run_head()
+                tsd = []
+                for trial in range(4):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); gd.replay(); e1.record(); torch.cuda.synchronize()
+                    if trial:
+                        tsd.append(e0.elapsed_time(e1) * 1e3 / 10)
+            head_us = float(np.mean(tsd))
+            in_frame_us, calls_d = None, 0
+            csv_d = os.path.join(REPO, "profiles", "in_frame_kernel_stats_waymo.csv" if waymo else "in_frame_kernel_stats.csv")
+            if os.path.exists(csv_d) and args.batch == 1:
+                import csv as _csv
+                rows_d = [r for r in _csv.DictReader(open(csv_d)) if "conv2d_bf16x3_tile2d_kernel" in r["Name"]]
+                calls_d = sum(int(r["Calls"]) for r in rows_d)
+                if calls_d:
+                    in_frame_us = sum(float(r["TotalDurationNs"]) for r in rows_d) / calls_d / 1e3
+            mf_tile = 5 * 8 * 9 * 4 * 3
+            issued_fl = float(np.mean(live)) * mf_tile * 16384.0
+            t_launch = (in_frame_us or head_us / 7.0) * 1e-6
+            roofline_dense.update(
+                launches_per_frame=6, tiles_total=tiles_total, live_tiles_per_layer=live, live_tiles_mean=float(np.mean(live)),
+                compute_units=256, mfma_per_live_tile=mf_tile, flops_issued_per_launch=issued_fl, flops_useful_per_launch=issued_fl / 3.0,
+                avg_us=t_launch * 1e6, avg_us_source=("profiles/" + os.path.basename(csv_d) + " (in the frame)") if in_frame_us else "dense head of this frame / 7 launches",
+                dense_head_us_this_frame=head_us, issued=issued_fl / t_launch / 1e12, achieved=issued_fl / 3.0 / t_launch / 1e12, peak=2500.0, unit="TFLOP/s",
+                frac_issued=issued_fl / t_launch / 1e12 / 2500.0, frac=issued_fl / 3.0 / t_launch / 1e12 / 2500.0,
+                sustained_peak_measured=dict(zero_operands=2200.0, random_operands=1650.0, source="profiles/r06_mfma_chain.txt (tools/mb_mfma_chain.hip: "
+                                             "nothing but v_mfma_f32_16x16x32_f16 on all 256 CUs: 7.5 / 9.4-10.3 ns per instruction and SIMD)"),
+                note="one live tile per CU and launch: the launch lasts one tile's chain (occupancy test, 64-request neighbourhood load, "
+                     "1 080 MFMAs per SIMD ~ 9-10 us at the sustained rate, epilogue); CUs without a live tile idle -- live_tiles_mean of 256")
+        except Exception as e:  # a reported extra
+            roofline_dense["error"] = f"{type(e).__name__}: {str(e)[:200]}"
         tot_bytes = sum(l["bytes"] for l in layers)
         tot_t = sum(l["t_avg_us"] for l in layers) * 1e-6
         stages = dict(sparse_conv_launches=len(layers), sparse_conv_us=tot_t * 1e6, sparse_conv_algorithmic_MB=tot_bytes / 1e6,
@@ -1371,6 +1472,9 @@ def main():
                     frames_per_s_one_at_a_time=(world * args.batch * 1e3 / single_ms) if single_ms else None,
                     roofline=roofline, cpu_baseline=cpu_baseline, roofline_dense=roofline_dense, stages=stages,
                     n_proposals=int(out[0].shape[0]))
+        if world == 1 and not waymo and args.batch == 1 and not args.no_extra:
+            del graphed
+            line["extra"] = run_extras()
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

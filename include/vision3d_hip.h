@@ -208,37 +208,33 @@ int v3d_sparse_conv_fwd(const float* in, const float* weight, const int32_t* nbr
 #define V3D_PREC_BF16X3 0
 #define V3D_PREC_F16S 1
 size_t v3d_sparse_conv_weight_image_bytes(int K, int Cin, int Cout);
-int v3d_sparse_conv_pack_weights(const float* weight, int K, int Cin, int Cout, void* image, v3d_stream_t stream);
-int v3d_sparse_conv_pack_weights2(const float* weight, int K, int Cin, int Cout, int prec, void* image, v3d_stream_t stream);
+/* image of `prec` (V3D_PREC_*) for the packed kernels: weight (K, Cin, Cout) fp32 -> split 16-bit fragments in MFMA order */
+int v3d_sparse_conv_pack_weights(const float* weight, int K, int Cin, int Cout, int prec, void* image, v3d_stream_t stream);
 /* entry[0..3] = {s, 1/s, 2^15 / s, max} for the n = min(*n_rows, cap) rows of `rows` (cap, C) [n_rows NULL: all cap rows]:
- * s = the power of two that puts the largest magnitude into [2^(13 - headroom_bits), 2^(14 - headroom_bits)).  One workgroup;
- * no host synchronisation.  headroom_bits in [0, 12]. */
+ * s = the power of two that puts the largest magnitude into [2^(13 - headroom_bits), 2^(14 - headroom_bits)).  No host
+ * synchronisation.  headroom_bits in [0, 12].  scratch NULL: one workgroup.  scratch != NULL: a grid of workgroups -- two uint32
+ * words in device memory that are ZERO when the launch starts (running maximum, arrival ticket); the last workgroup to arrive
+ * writes the entry and zeroes them again, so one zeroed scratch serves every later call on the same stream. */
 int v3d_act_scale_from_rows(const float* rows, const int32_t* n_rows, int cap, int C, int headroom_bits, float* entry,
-                            v3d_stream_t stream);
-/* The same entry computed by a grid of workgroups: `scratch` = two uint32 words in device memory that are ZERO when the launch
- * starts (running maximum, arrival ticket); the last workgroup to arrive writes the entry and zeroes them again, so one zeroed
- * scratch serves every later call on the same stream.  scratch NULL: the one-workgroup form above. */
-int v3d_act_scale_from_rows2(const float* rows, const int32_t* n_rows, int cap, int C, int headroom_bits, float* entry,
-                             uint32_t* scratch, v3d_stream_t stream);
+                            uint32_t* scratch, v3d_stream_t stream);
 /* rows_hint > 0: the caller's estimate of the LIVE row count (*n_out is device-side), used only to choose the kernel: 3x3x3 with
  * Cin, Cout in {32, 64}: LDS-ring kernel up to 16 384 rows, 64-row LDS-shared-weights kernel from 32 768, else the 16-row kernel;
  * 0 = unknown (ring / 16-row).  The 64 -> 64 ring kernel owns a CU per workgroup: it takes 2, 3 or 4 sixteen-row tiles per workgroup,
  * the smallest count that keeps rows_hint + 10 % inside one round of 256 workgroups (8 192 / 12 288 / 16 384 rows).
  * rows_hint < 0 FORCES a kernel (tests, benchmarks): -1 = 16-row, -5 = 64-row, -6 / -7 = offset-outer (staged / register gathers),
  * -10 = LDS ring, -16 = its register-gather form, -12 / -13 / -14 = the 64 -> 64 ring with 2 / 3 / 4 tiles per workgroup.
- * There is no process-global switch. */
-int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
-                               int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
-                               float* out, int rows_hint, v3d_stream_t stream);
-/* in_split / out_split (both nullable): rows ALREADY split into the arithmetic's 16-bit pieces -- a row = [hi: C x 16 bit |
+ * There is no process-global switch.
+ * prec = the arithmetic the image was packed for; V3D_PREC_F16S needs act_in (and act_next where split rows are written); act_in /
+ * act_next / range_flag are ignored (may be NULL) for V3D_PREC_BF16X3.
+ * in_split / out_split (both nullable): rows ALREADY split into the arithmetic's 16-bit pieces -- a row = [hi: C x 16 bit |
  * lo: C x 16 bit], the bytes of the fp32 row; f16s: pieces of x * s of the tensor's scale entry.  in_split (then `in` may be NULL):
  * the layer gathers these and its main loop converts nothing; out_split (Cout % 8 == 0; f16s needs act_next; `out` may then be NULL):
  * the output rows once more in that form, for the next layer's in_split.  A chain of layers this way computes the same bits as
  * on fp32 rows (v3d_sparse_rows_split makes split rows from fp32 rows). */
-int v3d_sparse_conv_fwd_packed2(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
-                                int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
-                                float* out, int rows_hint, int prec, const float* act_in, const float* act_next,
-                                int32_t* range_flag, const void* in_split, void* out_split, v3d_stream_t stream);
+int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
+                               int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
+                               float* out, int rows_hint, int prec, const float* act_in, const float* act_next,
+                               int32_t* range_flag, const void* in_split, void* out_split, v3d_stream_t stream);
 int v3d_sparse_rows_split(const float* rows, const int32_t* n_rows, int cap, int C, int prec, const float* act_entry,
                           void* out_split, v3d_stream_t stream);
 /* ---- T3 over SPATIALLY ORDERED rows (csrc/brick.hip; same interface the reference reaches through spconv.SubMConv3d,
@@ -283,12 +279,10 @@ int v3d_furthest_point_sample(const float* xyz, int B, int N, int K, int32_t* id
                               size_t workspace_bytes, v3d_stream_t stream);
 int v3d_gather_points(const float* feat, const int32_t* idx, int B, int C, int N, int K, float* out,
                       v3d_stream_t stream);
-int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M, float radius, int nsample,
-                   int32_t* idx, v3d_stream_t stream);
-/* Two radii around the same queries in one scan of the database (what PointnetSAModuleMSG asks for per feature source): per
- * (query, radius) the same result as v3d_ball_query. */
-int v3d_ball_query2(const float* xyz, const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a, int32_t* idx_a,
-                    float radius_b, int nsample_b, int32_t* idx_b, v3d_stream_t stream);
+/* idx_b == NULL: one radius (radius_b / nsample_b ignored).  idx_b != NULL: two radii around the same queries in ONE scan of the
+ * database (what PointnetSAModuleMSG asks for per feature source): per (query, radius) the same result as the one-radius call. */
+int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a, int32_t* idx_a,
+                   float radius_b, int nsample_b, int32_t* idx_b, v3d_stream_t stream);
 int v3d_group_points(const float* feat, const int32_t* idx, int B, int C, int N, int M, int nsample, float* out,
                      v3d_stream_t stream);
 /* Bilinear lookup of BEV features at keypoints: F.grid_sample(feature_map, grid, bilinear, zeros, align_corners=True) for a
@@ -342,9 +336,10 @@ int v3d_backbone_num_layers(const v3d_backbone* plan);
 /* weight (K,Cin,Cout) f32; scale/shift (Cout) or both NULL (no affine). */
 int v3d_backbone_set_layer(v3d_backbone* plan, int layer, const float* weight, const float* scale, const float* shift,
                            v3d_stream_t stream);
-/* points (n_points,C) f32 = frames concatenated; dense_out (B, Cout_last*D, H, W) f32 or NULL. */
+/* points (n_points,C) f32 = frames concatenated.  Outputs, any may be NULL: dense_nchw (B, Cout_last*D, H, W) f32 and / or the
+ * split planes dense_hi / dense_lo ((B, H, W, Cout_last*D) 16-bit pieces of the plan's arithmetic: the dense head's input). */
 int v3d_backbone_forward(v3d_backbone* plan, const float* points, int n_points, const int32_t* frame_offsets_host,
-                         int B, float* dense_out, v3d_stream_t stream);
+                         int B, float* dense_nchw, void* dense_hi, void* dense_lo, v3d_stream_t stream);
 /* Device-resident results of the last forward: layer = -1 -> voxelizer output (mean features, coords);
  * layer >= 0 -> that layer's output rows.  *n_rows_dev is a device int32; cap = row capacity. */
 int v3d_backbone_layer_output(v3d_backbone* plan, int layer, float** features, int32_t** coords,
@@ -364,19 +359,15 @@ int32_t* v3d_backbone_overflow_flags(v3d_backbone* plan);  /* (n_layers+1) i32 d
  * Cin % 32 == 0, ksize in {1,3} (stride 1, "same" zero padding).  Outputs: split NHWC planes (Cout % 8 == 0)
  * and/or fp32 NCHW (B,Cout,H,W). */
 size_t v3d_conv2d_weight_image_bytes(int Cin, int Cout, int ksize);
-/* weight (Cout,Cin,k,k) f32; optional per-output-channel scale (folded BatchNorm) multiplied in. */
-int v3d_conv2d_pack_weights(const float* weight, const float* scale, int Cout, int Cin, int ksize, void* image,
-                            v3d_stream_t stream);
-int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias, int relu,
-                           int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo, float* y_nchw,
-                           v3d_stream_t stream);
+/* (v3d_conv2d_pack_weights: weight (Cout,Cin,k,k) f32; optional per-output-channel scale (folded BatchNorm) multiplied in;
+ *  v3d_conv2d_nhwc_split: the convolution -- both declared below, with the arithmetic's scale entries) */
 /* Background skipping for the BEV head.  The BEV map of a sparse scene is mostly empty: an output pixel of layer L whose
  * receptive field through layers 1..L (`reach` pixels: +1 per 3x3 layer) contains no occupied BEV pixel sees exactly the inputs it
  * sees in an EMPTY map, so its value is the empty map's response at that position -- bit for bit, borders included.  The caller
  * computes that response once per weight set (the same convolutions on an all-zero map, occ = NULL) and passes it as bg_hi / bg_lo
  * ((H, W, Cout) split planes of ONE image); tiles whose pixels are all further than `reach` (Chebyshev) from every occupied pixel
  * become a copy of that response instead of a convolution.  Results are identical
- * to v3d_conv2d_nhwc_bf16x3 (which is this call with occ = NULL).  Applies to the large-tile kernel with split-plane output;
+ * to the call with occ = NULL.  Applies to the large-tile kernel with split-plane output;
  * any other configuration computes every pixel.
  * occ: BEV occupancy, one bit per pixel, INVERTED (bit cleared = occupied; a 0xFF fill = empty map), rows (b, y) of ceil(W / 32)
  * words.  A plan keeps one for its last forward (v3d_backbone_bev_occupancy: cleared by the per-frame 0xFF fill, set by the
@@ -386,7 +377,7 @@ int v3d_bev_occupancy_bits(const int32_t* coords /*(cap,4) b,z,y,x*/, const int3
                            uint32_t* occ, v3d_stream_t stream);
 uint32_t* v3d_backbone_bev_occupancy(v3d_backbone* plan);
 /* The plan's PERSISTENT split BEV planes ((max_batch, H, W, C_out * D) bf16 each, hi then lo, adjacent).  Passing exactly these two
- * pointers as dense_hi / dense_lo to v3d_backbone_forward2 / _forward_voxels / _forward_reuse makes the plan keep them zero outside
+ * pointers as dense_hi / dense_lo to v3d_backbone_forward / _forward_voxels / _forward_reuse makes the plan keep them zero outside
  * the occupied pixels itself: each frame clears the few thousand pixels the previous one wrote (in the launch of its per-frame fill)
  * instead of filling 2 x 9 MB per KITTI frame -- what .dense() (detector/sparse_cnn.py:128-133: zeros + scatter) costs.  Valid until the
  * next forward into them; nobody else may write them. */
@@ -414,43 +405,28 @@ int v3d_backbone_set_presplit(v3d_backbone* plan, int on);
 float* v3d_backbone_act_scales(v3d_backbone* plan);
 int v3d_backbone_set_calibrating(v3d_backbone* plan, int on);
 int v3d_backbone_calibrate(v3d_backbone* plan, int headroom_bits, v3d_stream_t stream);
-/* The tail of the SECOND dense head in ONE launch: RPN up-conv 1x1 128 -> 128 (+ folded BatchNorm bias + ReLU, detector/second.py:73-79)
- * followed by the fused [cls | reg] 1x1 head 128 -> Cout2 <= 16 (detector/proposal.py:19-22), split planes (B, H, W, 128) in, fp32
- * NCHW (B, Cout2, H, W) out; w1_image / w2_image from v3d_conv2d_pack_weights(.., ksize 1).  Bit-identical to v3d_conv2d_nhwc_bf16x3
- * applied twice; the intermediate planes never exist.  V3D_EUNSUPPORTED for other widths. */
-int v3d_conv2d_1x1_head_fused(const void* x_hi, const void* x_lo, const void* w1_image, const float* b1, int relu1,
-                              const void* w2_image, const float* b2, int relu2, int B, int H, int W, int Cmid, int Cout2,
-                              float* y_nchw, v3d_stream_t stream);
-int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias, int relu, int B,
-                              int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo, float* y_nchw,
-                              const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo,
-                              uint32_t* work /*nullable: two zeroed words owned by the caller for THIS call site (one pair per
-                              layer and stream in flight).  With it the skipping kernel runs as a persistent grid that draws
-                              80-pixel tiles from work[0]; the pair resets itself to zero when the kernel ends*/,
-                              uint32_t* tile_state /*nullable; with `work`, when y_hi / y_lo are PERSISTENT buffers of this call
-                              site (the same pair every frame): v3d_conv2d_bg_tiles words, nonzero = the tile holds computed
-                              values (initialise to nonzero).  A layer's empty-map response does not depend on the frame, so a
-                              background tile whose word is 0 already holds it and is not written at all; the kernel keeps the
-                              words up to date.  Reset them to nonzero when the weights (hence bg_hi / bg_lo) change*/,
-                              v3d_stream_t stream);
-/* The same call with the counter pair reset by ANOTHER launch: reset_ptr != NULL makes this launch zero reset_words words at
- * reset_ptr when it starts (the pairs of call sites whose launches lie behind it in stream order) and leave its own `work` pair as it
- * ends -- some later launch of the caller's zeroes it.  Saves the atomic round trip every workgroup of a self-resetting launch ends
- * on.  A chain of layers resets like this: the first layer zeroes the pairs of all the others (the previous frame's), the second
- * the first layer's.  `work` must read zero at launch. */
-int v3d_conv2d_nhwc_bf16x3_bg2(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias, int relu, int B,
-                               int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo, float* y_nchw,
-                               const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo, uint32_t* work,
-                               uint32_t* tile_state, uint32_t* reset_ptr, int reset_words, v3d_stream_t stream);
+/* v3d_conv2d_nhwc_split arguments of the background-skipping path (all nullable / zero = every tile convolved):
+ *   occ, reach, bg_hi, bg_lo  inverted BEV occupancy bitmap (v3d_backbone_bev_occupancy), the layer's reach in pixels and its
+ *                             response to the empty map (planes): tiles with no occupied pixel within reach ARE that response;
+ *   work        two zeroed words owned by the caller for THIS call site (one pair per layer and stream in flight).  With it the
+ *               skipping kernel runs as a persistent grid that draws tiles from work[0]; the pair resets itself when the kernel ends;
+ *   tile_state  with `work`, when y_hi / y_lo are PERSISTENT buffers of this call site (the same pair every frame):
+ *               v3d_conv2d_bg_tiles words, nonzero = the tile holds computed values (initialise to nonzero).  A layer's empty-map
+ *               response does not depend on the frame, so a background tile whose word is 0 already holds it and is not written
+ *               at all; the kernel keeps the words up to date.  Reset them to nonzero when the weights (bg_hi / bg_lo) change;
+ *   reset_ptr, reset_words    the counter pair reset by ANOTHER launch: reset_ptr != NULL makes this launch zero reset_words words
+ *               at reset_ptr when it starts (the pairs of call sites whose launches lie behind it in stream order) and leave its
+ *               own `work` pair as it ends -- some later launch of the caller's zeroes it (saves the atomic round trip every
+ *               workgroup of a self-resetting launch ends on); `work` must read zero at launch;
+ *   pr          NULL = bf16x3 images and planes; else the arithmetic and its scale entries (v3d_conv2d_prec below). */
 int v3d_conv2d_bg_tiles(int B, int H, int W);
 /* ---- the same dense head in fp32-class arithmetic (V3D_PREC_F16S; see the sparse section above for the two arithmetics).
  * The reference's RPN / heads are fp32 nn.Conv2d modules (detector/second.py:58-79, detector/proposal.py:19-22): f16s reproduces
  * them up to fp32 summation noise at the cost of bf16x3.  Planes then hold f16 pieces of x * s: every plane pair has a device entry
  * {s, 1/s, limit = 2^15 / s, ..} (set by the caller's calibration: vision3d_amd.runtime.DenseHeadPlan.calibrate; the BEV planes of
- * a plan use v3d_backbone_act_scales()[n_layers]), the weight image carries its own scale (v3d_conv2d_pack_weights2), and an output
+ * a plan use v3d_backbone_act_scales()[n_layers]), the weight image carries its own scale (v3d_conv2d_pack_weights), and an output
  * magnitude beyond its entry's limit raises *range_flag to 2 (atomicMax, nullable).  fp32 NCHW outputs are unscaled.
- * v3d_conv2d_nhwc_split(.., pr = NULL) is v3d_conv2d_nhwc_bf16x3_bg2; for v3d_conv2d_1x1_head_fused2 `out_entry` is the entry of
- * the intermediate 128-channel tensor. */
+ * For v3d_conv2d_1x1_head_fused `out_entry` is the entry of the intermediate 128-channel tensor. */
 typedef struct v3d_conv2d_prec {
   int32_t prec;           /* V3D_PREC_*: the arithmetic the weight image(s) were packed for */
   const float* in_entry;  /* f16s: device entry of the input planes */
@@ -458,31 +434,31 @@ typedef struct v3d_conv2d_prec {
   int32_t* range_flag;    /* f16s, nullable */
   const float* w_inv;     /* f16s, nullable: device copy of the weight image's 1 / s_w (float 1 of its 256-byte trailer) in memory the
                              caller keeps hot, e.g. beside its scale entries; NULL: read from the trailer (a cold line per launch) */
-  const float* w_inv2;    /* same for the second image of v3d_conv2d_1x1_head_fused2 */
+  const float* w_inv2;    /* same for the second image of v3d_conv2d_1x1_head_fused */
 } v3d_conv2d_prec;
-int v3d_conv2d_pack_weights2(const float* weight, const float* scale, int Cout, int Cin, int ksize, int prec, void* image,
-                             v3d_stream_t stream);
+int v3d_conv2d_pack_weights(const float* weight, const float* scale, int Cout, int Cin, int ksize, int prec, void* image,
+                            v3d_stream_t stream);
 int v3d_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias, int relu, int B,
                           int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo, float* y_nchw,
                           const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo, uint32_t* work,
                           uint32_t* tile_state, uint32_t* reset_ptr, int reset_words, const v3d_conv2d_prec* pr,
                           v3d_stream_t stream);
-int v3d_conv2d_1x1_head_fused2(const void* x_hi, const void* x_lo, const void* w1_image, const float* b1, int relu1,
-                               const void* w2_image, const float* b2, int relu2, int B, int H, int W, int Cmid, int Cout2,
-                               float* y_nchw, const v3d_conv2d_prec* pr, v3d_stream_t stream);
-int v3d_nchw_to_split_nhwc2(const float* x, int B, int C, int H, int W, void* out_hi, void* out_lo, int prec,
-                            const float* act_entry, v3d_stream_t stream);
+/* The tail of the SECOND dense head in ONE launch: RPN up-conv 1x1 128 -> 128 (+ folded BatchNorm bias + ReLU, detector/second.py:73-79)
+ * followed by the fused [cls | reg] 1x1 head 128 -> Cout2 <= 16 (detector/proposal.py:19-22), split planes (B, H, W, 128) in, fp32
+ * NCHW (B, Cout2, H, W) out; w1_image / w2_image from v3d_conv2d_pack_weights(.., ksize 1).  Bit-identical to v3d_conv2d_nhwc_split
+ * applied twice; the intermediate planes never exist.  V3D_EUNSUPPORTED for other widths.  pr NULL = bf16x3. */
+int v3d_conv2d_1x1_head_fused(const void* x_hi, const void* x_lo, const void* w1_image, const float* b1, int relu1,
+                              const void* w2_image, const float* b2, int relu2, int B, int H, int W, int Cmid, int Cout2,
+                              float* y_nchw, const v3d_conv2d_prec* pr, v3d_stream_t stream);
+/* fp32 (B, C, H, W) -> split planes (B, H, W, C) of `prec` (f16s: pieces of x * act_entry[0]; act_entry NULL for bf16x3) */
+int v3d_nchw_to_split_nhwc(const float* x, int B, int C, int H, int W, void* out_hi, void* out_lo, int prec,
+                           const float* act_entry, v3d_stream_t stream);
 /* .dense() of the last sparse stage straight into that input format: planes (B,H,W,C*D), channel = c*D + z. */
 int v3d_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
                            const int32_t* spatial_shape_host, void* out_hi, void* out_lo, v3d_stream_t stream);
-int v3d_nchw_to_split_nhwc(const float* x, int B, int C, int H, int W, void* out_hi, void* out_lo, v3d_stream_t stream);
 /* ... and back: bf16 split planes (B,H,W,C) -> fp32 (B,C,H,W) = hi + lo (C even).  The gradient of the BEV map leaving
  * v3d_dense_train_backward_split for the sparse training plan, which takes fp32 NCHW. */
 int v3d_split_nhwc_to_nchw(const void* x_hi, const void* x_lo, int B, int C, int H, int W, float* out, v3d_stream_t stream);
-/* v3d_backbone_forward with a choice of output formats (any may be NULL): fp32 (B,C*D,H,W) and/or split planes. */
-int v3d_backbone_forward2(v3d_backbone* plan, const float* points, int n_points, const int32_t* frame_offsets_host,
-                          int B, float* dense_nchw, void* dense_hi, void* dense_lo, v3d_stream_t stream);
-
 /* The convolutions (+ .dense()) of the frame the plan forwarded LAST, on the site lists and neighbour tables that call left
  * behind: no voxelizer, no rulebook build -- the "rulebooks prebuilt" timing variant.  Same outputs. */
 int v3d_backbone_forward_reuse(v3d_backbone* plan, int B, float* dense_nchw, void* dense_hi, void* dense_lo, v3d_stream_t stream);
@@ -490,7 +466,7 @@ int v3d_backbone_forward_reuse(v3d_backbone* plan, int B, float* dense_nchw, voi
 /* The same plan fed with EXISTING voxels -- voxel_mean (M, C) f32 and coords (M, 4) i32 (b, z, y, x), M <= the plan's voxel
  * capacity, rows frame-sorted as core/preprocess.py:26-33 produces them -- instead of raw points: what Second.forward(item) /
  * Second.inference(item) (detector/second.py:26-35, called by train.py:63 and inference.py:38) hold.  Two device copies replace
- * the voxelizer; everything after is v3d_backbone_forward2. */
+ * the voxelizer; everything after is v3d_backbone_forward. */
 int v3d_backbone_forward_voxels(v3d_backbone* plan, const float* voxel_mean, const int32_t* coords, int n_voxels, int B,
                                 float* dense_nchw, void* dense_hi, void* dense_lo, v3d_stream_t stream);
 
@@ -606,7 +582,7 @@ int v3d_dense_train_backward(const void* bev, const float* dmaps, int B, int H, 
 /* The same step in fp32-class arithmetic ("bf16x3"): what the reference's fp32 train.py:58-66 (no autocast) needs from the dense half.
  * Every tensor is a split pair of bf16 NHWC planes (value = hi + lo: 16 significant bits), every product three MFMA terms with fp32
  * accumulation (2^-17 per product; scale-free, so gradients need no calibration): convolutions and data gradients on
- * v3d_conv2d_nhwc_bf16x3, the weight gradient as three passes of the bf16 kernel over (hi, hi), (hi, lo), (lo, hi), statistics /
+ * v3d_conv2d_nhwc_split, the weight gradient as three passes of the bf16 kernel over (hi, hi), (hi, lo), (lo, hi), statistics /
  * normalisation / head gradients in fp32 on hi + lo.  Same layer descriptors, same reductions (fixed order, bit-repeatable); O <= 16.
  * bev_hi / bev_lo, dbev_hi / dbev_lo: (B, H, W, 128) bf16 planes; the backward reads the SAME bev planes and arena as the forward. */
 size_t v3d_dense_train_arena_bytes_split(int B, int H, int W, int n_layers, int O);

@@ -96,7 +96,7 @@ def test_brick_conv_same_bits_as_the_offset_outer_kernel(oracle, order, precisio
     ent_in = torch.empty(4, device="cuda")
     ent_next = torch.tensor([1.0, 1.0, 32768.0, 0.0], device="cuda")
     flag = torch.full((1,), -1, dtype=torch.int32, device="cuda")
-    L.check(lib.v3d_act_scale_from_rows(L.ptr(f_dev), None, n, cin, 0, L.ptr(ent_in), L.stream_ptr()), "scale")
+    L.check(lib.v3d_act_scale_from_rows(L.ptr(f_dev), None, n, cin, 0, L.ptr(ent_in), None, L.stream_ptr()), "scale")
     fsplit = torch.empty((n, 2 * cin), dtype=torch.int16, device="cuda")
     L.check(lib.v3d_sparse_rows_split(L.ptr(f_dev), L.ptr(n_dev), n, cin, prec, L.ptr(ent_in), L.ptr(fsplit), L.stream_ptr()), "split")
     tabs = _tables(L, nbr_dev, n_dev, n)
@@ -104,7 +104,7 @@ def test_brick_conv_same_bits_as_the_offset_outer_kernel(oracle, order, precisio
     os_a = torch.zeros((n, 2 * cin), dtype=torch.int16, device="cuda")
     os_b = torch.zeros_like(os_a)
     variant = 6 if cin == 64 else 5  # offset-outer / 64-row kernel: every wave walks the 27 offsets in order
-    L.check(lib.v3d_sparse_conv_fwd_packed2(None, L.ptr(img), L.ptr(nbr_dev), L.ptr(n_dev), n, K, cin, cin, L.ptr(sc), L.ptr(sh), 1, L.ptr(out_a),
+    L.check(lib.v3d_sparse_conv_fwd_packed(None, L.ptr(img), L.ptr(nbr_dev), L.ptr(n_dev), n, K, cin, cin, L.ptr(sc), L.ptr(sh), 1, L.ptr(out_a),
                                             -variant, prec, L.ptr(ent_in), L.ptr(ent_next), L.ptr(flag), L.ptr(fsplit), L.ptr(os_a), L.stream_ptr()), "packed2")
     L.check(lib.v3d_sparse_conv_fwd_brick(L.ptr(fsplit), L.ptr(img), L.ptr(nbr_dev), *[L.ptr(t) for t in tabs], L.ptr(n_dev), n, K, cin, cin,
                                           L.ptr(sc), L.ptr(sh), 1, L.ptr(out_b), prec, L.ptr(ent_in), L.ptr(ent_next), L.ptr(flag), L.ptr(os_b),

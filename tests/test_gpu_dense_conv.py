@@ -367,7 +367,7 @@ def test_fused_1x1_and_head_equal_the_two_launches_bit_for_bit(b, h, w, cout2, p
                           pr=(mid_entry, None, None) if f16s else None)
     fused = torch.empty_like(two)
     ref_struct, keep = _prec_struct((hi.v3d_entry, mid_entry, None) if f16s else None)
-    L.check(L.lib().v3d_conv2d_1x1_head_fused2(L.ptr(hi), L.ptr(lo), L.ptr(img1), L.ptr(b1), 1, L.ptr(img2), L.ptr(b2), 0, b, h, w, 128,
+    L.check(L.lib().v3d_conv2d_1x1_head_fused(L.ptr(hi), L.ptr(lo), L.ptr(img1), L.ptr(b1), 1, L.ptr(img2), L.ptr(b2), 0, b, h, w, 128,
                                                cout2, L.ptr(fused), ref_struct, L.stream_ptr()), "fused")
     torch.cuda.synchronize()
     assert torch.equal(fused, two)
@@ -402,7 +402,7 @@ def test_dense_head_plan_with_and_without_the_fused_tail():
 
 @pytest.mark.parametrize("shape", [(2, 128, 13, 37), (1, 6, 5, 7), (3, 192, 9, 70), (1, 5, 4, 6)])
 def test_nchw_split_conversions_are_exact_and_round_trip(shape):
-    """v3d_nchw_to_split_nhwc2 (tiled form for even C, plain form for odd C) against the definition -- hi = RNE(x) as bf16, lo = RNE(x - hi),
+    """v3d_nchw_to_split_nhwc (tiled form for even C, plain form for odd C) against the definition -- hi = RNE(x) as bf16, lo = RNE(x - hi),
     per pixel and channel -- and v3d_split_nhwc_to_nchw back: hi + lo in fp32, exactly; f16s planes hold the pieces of x * s."""
     from vision3d_amd import _lib as L
     from vision3d_amd.runtime import to_split_nhwc

@@ -343,6 +343,8 @@ def test_f16s_scale_entries_follow_weight_updates():
         before = [t.clone() for t in run([cloud])]
         gmodel.head.conv_cls.bias.add_(0.5)
         gmodel.rpn.down_block[1].weight.mul_(1.25)
+        assert [torch.equal(a, b) for a, b in zip(run([cloud]), before)] == [True] * 4  # (in-place edits of an eval-mode model: not noticed ...)
+        gmodel.notify_weights_changed()                                                    # ... until the runners are told
         out = run([cloud])
         fresh = build_model(5)
         fresh.head.conv_cls.bias.add_(0.5)

@@ -384,7 +384,7 @@ def test_pv_rcnn_stage_pieces_run():
 @pytest.mark.parametrize("n,m,ra,nsa,rb,nsb", [(16384, 2048, 0.4, 16, 0.8, 16), (4204, 2048, 2.4, 16, 4.8, 32), (777, 130, 1.0, 5, 3.0, 64),
                                                (2500, 37, 0.01, 16, 100.0, 32)])
 def test_ball_query_pair_equals_two_single_queries(n, m, ra, nsa, rb, nsb):
-    """v3d_ball_query2 (two radii in one scan) == v3d_ball_query per radius (itself exact against the oracle above): ragged
+    """v3d_ball_query (two radii in one scan) == v3d_ball_query per radius (itself exact against the oracle above): ragged
     sizes, a radius that finds nothing, one that finds everything."""
     from vision3d_amd.pointnet2 import pointnet2_utils as PU
     g = torch.Generator().manual_seed(n + m)

@@ -270,7 +270,7 @@ def test_sparse_sequential_fuses_and_matches_unfused(oracle):
                          ids=["16rows", "64rows_lds_weights", "offset_outer_staged", "offset_outer_regs", "lds_ring", "lds_ring_regs"])
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 32), (64, 64)])
 def test_presplit_rows_every_kernel_variant(oracle, cin, cout, variant, precision):
-    """Rows that are ALREADY split into the arithmetic's 16-bit pieces (v3d_sparse_conv_fwd_packed2 in_split / out_split: what the
+    """Rows that are ALREADY split into the arithmetic's 16-bit pieces (v3d_sparse_conv_fwd_packed in_split / out_split: what the
     layers of a plan hand each other) through every kernel of the packed product: gathering the split copy gives the bits of
     gathering the fp32 rows, and the split copy a layer writes is the split of the fp32 rows it writes -- ragged tail, fused affine +
     ReLU, f16s scale entries from the tensors' own maxima."""
@@ -290,7 +290,7 @@ def test_presplit_rows_every_kernel_variant(oracle, cin, cout, variant, precisio
     entry = act_entry_from_tensor(feats) if f16s else None
 
     def run(in_rows, in_split, out, next_entry, out_split):
-        L.check(L.lib().v3d_sparse_conv_fwd_packed2(L.ptr(in_rows), L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, 27, cin, cout,
+        L.check(L.lib().v3d_sparse_conv_fwd_packed(L.ptr(in_rows), L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, 27, cin, cout,
                                                     L.ptr(sc), L.ptr(sh), 1, L.ptr(out), -variant, prec, L.ptr(entry), L.ptr(next_entry),
                                                     None, L.ptr(in_split), L.ptr(out_split), L.stream_ptr()), "fwd_packed2")
     ref = torch.empty((rb.n, cout), dtype=torch.float32, device="cuda")
@@ -307,7 +307,7 @@ def test_presplit_rows_every_kernel_variant(oracle, cin, cout, variant, precisio
 
 
 def test_scale_entry_grid_form_equals_the_single_workgroup_form():
-    """v3d_act_scale_from_rows2 (grid of workgroups, self-resetting scratch) against v3d_act_scale_from_rows on the same rows:
+    """v3d_act_scale_from_rows with a scratch pair (grid of workgroups, self-resetting) against its one-workgroup form (scratch NULL) on the same rows:
     identical entries; a device-side row count, a misaligned view, a one-element tensor; the scratch reads zero again after
     every launch (so back-to-back launches on one stream need no fill)."""
     from vision3d_amd import _lib as L
@@ -323,10 +323,10 @@ def test_scale_entry_grid_form_equals_the_single_workgroup_form():
         for headroom in (0, 5):
             a = torch.empty(4, device="cuda")
             b = torch.empty(4, device="cuda")
-            L.check(lib.v3d_act_scale_from_rows(L.ptr(rows), L.ptr(n_dev), rows.shape[0], c, headroom, L.ptr(a), L.stream_ptr()), "one")
+            L.check(lib.v3d_act_scale_from_rows(L.ptr(rows), L.ptr(n_dev), rows.shape[0], c, headroom, L.ptr(a), None, L.stream_ptr()), "one")
             for _ in range(2):  # twice: the second launch runs on the scratch the first left behind
                 b.fill_(-1)
-                L.check(lib.v3d_act_scale_from_rows2(L.ptr(rows), L.ptr(n_dev), rows.shape[0], c, headroom, L.ptr(b), L.ptr(scratch),
+                L.check(lib.v3d_act_scale_from_rows(L.ptr(rows), L.ptr(n_dev), rows.shape[0], c, headroom, L.ptr(b), L.ptr(scratch),
                                                      L.stream_ptr()), "grid")
                 assert torch.equal(a, b), (ci, headroom, a.tolist(), b.tolist())
                 assert scratch.tolist() == [0, 0]

@@ -75,7 +75,7 @@ def run_layers(order):
         sh = torch.randn(cout, device="cuda") * 0.1
         ent_in = torch.empty(4, device="cuda"); ent_next = torch.tensor([1.0, 1.0, 32768.0, 0.0], device="cuda")
         flag = torch.full((1,), -1, dtype=torch.int32, device="cuda")
-        L.check(lib.v3d_act_scale_from_rows(L.ptr(feat), None, feat.shape[0], cin, 0, L.ptr(ent_in), L.stream_ptr()), "scale")
+        L.check(lib.v3d_act_scale_from_rows(L.ptr(feat), None, feat.shape[0], cin, 0, L.ptr(ent_in), None, L.stream_ptr()), "scale")
         fsplit = torch.empty((capr, 2 * cin), dtype=torch.int16, device="cuda")
         L.check(lib.v3d_sparse_rows_split(L.ptr(feat), L.ptr(rb.n_dev), feat.shape[0], cin, prec, L.ptr(ent_in), L.ptr(fsplit), L.stream_ptr()), "split")
         tabs = brick_tables(rb, K)
@@ -88,7 +88,7 @@ def run_layers(order):
         os_a = torch.zeros((capr, 2 * cout), dtype=torch.int16, device="cuda"); os_b = torch.zeros_like(os_a)
 
         def old(variant, out=out_a, osp=os_a):
-            L.check(lib.v3d_sparse_conv_fwd_packed2(None, L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), capr, K, cin, cout, L.ptr(sc), L.ptr(sh), 1,
+            L.check(lib.v3d_sparse_conv_fwd_packed(None, L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), capr, K, cin, cout, L.ptr(sc), L.ptr(sh), 1,
                                                     L.ptr(out), -variant if variant else n, prec, L.ptr(ent_in), L.ptr(ent_next), L.ptr(flag),
                                                     L.ptr(fsplit), L.ptr(osp), L.stream_ptr()), "packed2")
 

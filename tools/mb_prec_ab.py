@@ -1,5 +1,5 @@
 """A/B of the two arithmetics of the packed sparse kernels on the layers of one real KITTI frame (same process, same box): every
-layer's kernel ALONE through the C ABI (v3d_sparse_conv_fwd_packed2), REP launches inside one captured HIP graph between two
+layer's kernel ALONE through the C ABI (v3d_sparse_conv_fwd_packed), REP launches inside one captured HIP graph between two
 events.  f16s: the scale entry is computed once outside the timed launches (in the frame it is a table entry, not a launch).
 usage: [V3D_HIP_LIB=...] python tools/mb_prec_ab.py"""
 import os
@@ -65,7 +65,7 @@ for a in cap:
         out = torch.empty((rb.n, cout), dtype=torch.float32, device="cuda")
 
         def launch(img=img, entry=entry, out=out, prec=prec):
-            L.check(L.lib().v3d_sparse_conv_fwd_packed2(L.ptr(feat), L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k, cin, cout,
+            L.check(L.lib().v3d_sparse_conv_fwd_packed(L.ptr(feat), L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k, cin, cout,
                                                         L.ptr(sc), L.ptr(sh), int(bool(relu)), L.ptr(out), int(rb.n), prec,
                                                         L.ptr(entry), None, None, None, None, L.stream_ptr()), "fwd")
         t = timed(launch)
@@ -76,7 +76,7 @@ for a in cap:
         nxt = act_entry_from_tensor(out) if prec else None
 
         def launch_pre(img=img, entry=entry, prec=prec, in_s=in_s, out_s=out_s, nxt=nxt):
-            L.check(L.lib().v3d_sparse_conv_fwd_packed2(None, L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k, cin, cout,
+            L.check(L.lib().v3d_sparse_conv_fwd_packed(None, L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k, cin, cout,
                                                         L.ptr(sc), L.ptr(sh), int(bool(relu)), None, int(rb.n), prec,
                                                         L.ptr(entry), L.ptr(nxt), None, L.ptr(in_s), L.ptr(out_s), L.stream_ptr()), "fwd")
         t = timed(launch_pre)

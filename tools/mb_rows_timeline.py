@@ -18,13 +18,13 @@ w = torch.randn(K, C, C, device="cuda") / 40
 nbr = torch.randint(0, n, (K, n), device="cuda", dtype=torch.int32)
 nbr[torch.rand(K, n, device="cuda") > 0.31] = -1
 img = torch.empty(int(L.lib().v3d_sparse_conv_weight_image_bytes(K, C, C)), dtype=torch.uint8, device="cuda")
-L.check(L.lib().v3d_sparse_conv_pack_weights(L.ptr(w), K, C, C, L.ptr(img), L.stream_ptr()), "pack")
+L.check(L.lib().v3d_sparse_conv_pack_weights(L.ptr(w), K, C, C, 0, L.ptr(img), L.stream_ptr()), "pack")
 n_dev = torch.tensor([n], dtype=torch.int32, device="cuda")
 out = torch.empty(n, C, device="cuda")
 for variant in (10,):
     for _ in range(5):
         L.check(L.lib().v3d_sparse_conv_fwd_packed(L.ptr(x), L.ptr(img), L.ptr(nbr), L.ptr(n_dev), n, K, C, C, None, None, 0,
-                                                   L.ptr(out), -variant, L.stream_ptr()), "fwd")  # negative rows_hint = forced kernel
+                                                   L.ptr(out), -variant, 0, None, None, None, None, None, L.stream_ptr()), "fwd")  # negative rows_hint = forced kernel
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 256)()
     raw.v3d_debug_rows_timeline(buf)

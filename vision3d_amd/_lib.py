@@ -47,16 +47,13 @@ _SIGNATURES = {
     "v3d_rulebook_sparse": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "v3d_sparse_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "v3d_sparse_conv_weight_image_bytes": (_sz, [_i, _i, _i]),
-    "v3d_sparse_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "v3d_sparse_conv_fwd_packed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
-    "v3d_sparse_conv_pack_weights2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
-    "v3d_sparse_conv_fwd_packed2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "v3d_sparse_conv_pack_weights": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "v3d_sparse_conv_fwd_packed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "v3d_sparse_rows_split": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "v3d_sparse_brick_table_bytes": (_sz, [_i, _i, _vp, _vp, _vp, _vp]),
     "v3d_sparse_brick_plan": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "v3d_sparse_conv_fwd_brick": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
-    "v3d_act_scale_from_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
-    "v3d_act_scale_from_rows2": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "v3d_act_scale_from_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "v3d_rulebook_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "v3d_sparse_conv_bwd_weight_workspace": (_sz, [_i, _i, _i]),
     "v3d_sparse_conv_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
@@ -64,8 +61,7 @@ _SIGNATURES = {
     "v3d_fps_workspace": (_sz, [_i, _i]),
     "v3d_furthest_point_sample": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "v3d_gather_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "v3d_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
-    "v3d_ball_query2": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _f, _i, _vp, _vp]),
+    "v3d_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _f, _i, _vp, _vp]),
     "v3d_group_points": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "v3d_bev_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "v3d_sa_mlp_layer": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -75,11 +71,10 @@ _SIGNATURES = {
     "v3d_backbone_tune": (_i, [_vp]),
     "v3d_backbone_num_layers": (_i, [_vp]),
     "v3d_backbone_set_layer": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
-    "v3d_backbone_forward": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "v3d_backbone_layer_output": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "v3d_backbone_occupancy": (_vp, [_vp]),
     "v3d_backbone_overflow_flags": (_vp, [_vp]),
-    "v3d_backbone_forward2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "v3d_backbone_forward": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "v3d_backbone_forward_reuse": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "v3d_backbone_forward_voxels": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "v3d_backbone_train_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
@@ -91,28 +86,22 @@ _SIGNATURES = {
     "v3d_backbone_bev_occupancy": (_vp, [_vp]),
     "v3d_backbone_bev_planes": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "v3d_backbone_set_throughput_mode": (_i, [_vp, _i]),
-    "v3d_conv2d_nhwc_bf16x3_bg": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
-    "v3d_conv2d_nhwc_bf16x3_bg2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "v3d_conv2d_bg_tiles": (_i, [_i, _i, _i]),
-    "v3d_conv2d_pack_weights2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "v3d_conv2d_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "v3d_conv2d_nhwc_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
-    "v3d_conv2d_1x1_head_fused2": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "v3d_nchw_to_split_nhwc2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "v3d_conv2d_1x1_head_fused": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "v3d_nchw_to_split_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "v3d_backbone_set_precision": (_i, [_vp, _i]),
     "v3d_backbone_precision": (_i, [_vp]),
     "v3d_backbone_set_presplit": (_i, [_vp, _i]),
     "v3d_backbone_act_scales": (_vp, [_vp]),
     "v3d_backbone_set_calibrating": (_i, [_vp, _i]),
     "v3d_backbone_calibrate": (_i, [_vp, _i, _vp]),
-    "v3d_conv2d_1x1_head_fused": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "v3d_proposal_loss_workspace": (_sz, []),
     "v3d_proposal_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "v3d_proposal_loss_scale": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "v3d_conv2d_weight_image_bytes": (_sz, [_i, _i, _i]),
-    "v3d_conv2d_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
-    "v3d_conv2d_nhwc_bf16x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "v3d_densify_nhwc_split": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "v3d_nchw_to_split_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "v3d_split_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "v3d_dense_train_weight_image_bytes": (_sz, [_i]),
     "v3d_dense_train_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
@@ -246,7 +235,7 @@ _scale_scratch = {}
 
 
 def scale_scratch(device):
-    """The two zeroed uint32 words v3d_act_scale_from_rows2 works in, one pair per (device, stream): the kernel leaves them zero,
+    """The two zeroed uint32 words v3d_act_scale_from_rows works in, one pair per (device, stream): the kernel leaves them zero,
     so launches on one stream reuse them; two streams never share a pair."""
     if torch.cuda.is_current_stream_capturing():
         # a captured graph may replay beside other replays of graphs captured on this same stream: a pair of its own, zeroed by a

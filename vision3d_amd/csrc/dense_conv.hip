@@ -155,12 +155,7 @@ extern "C" size_t v3d_conv2d_weight_image_bytes(int Cin, int Cout, int ksize) {
   return dc_image_payload_bytes(Cin, Cout, ksize) + DC_WIMG_TRAILER;
 }
 
-extern "C" int v3d_conv2d_pack_weights(const float* weight, const float* scale, int Cout, int Cin, int ksize,
-                                       void* image, v3d_stream_t stream) {
-  return v3d_conv2d_pack_weights2(weight, scale, Cout, Cin, ksize, V3D_PREC_BF16X3, image, stream);
-}
-
-extern "C" int v3d_conv2d_pack_weights2(const float* weight, const float* scale, int Cout, int Cin, int ksize, int prec,
+extern "C" int v3d_conv2d_pack_weights(const float* weight, const float* scale, int Cout, int Cin, int ksize, int prec,
                                         void* image, v3d_stream_t stream) {
   if (!weight || !image || Cout < 1 || Cin < DC_KC || Cin % DC_KC || (ksize != 1 && ksize != 3)) return V3D_EINVAL;
   if (prec != V3D_PREC_BF16X3 && prec != V3D_PREC_F16S) return V3D_EINVAL;
@@ -190,7 +185,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void densify_split_kernel(const float* _
                                                                   bf16_t* __restrict__ lo, unsigned* __restrict__ occ,
                                                                   int* __restrict__ written_pix, int* __restrict__ written_n,
                                                                   const float* __restrict__ entry, int* __restrict__ range_flag,
-                                                                  unsigned* __restrict__ frame_max) {
+                                                                  unsigned* __restrict__ seen) {
   const int n = min(*n_ptr, cap);
   const long long total = (long long)n * C;
   const float s_out = PREC == 1 ? entry[0] : 1.f, limit = PREC == 1 ? entry[2] : 0.f;
@@ -213,7 +208,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void densify_split_kernel(const float* _
   }
   if constexpr (PREC == 1) {
     if (range_flag && vmax > limit) atomicMax(range_flag, V3D_FLAG_RANGE);
-    if (frame_max) v3d_publish_frame_max(frame_max, vmax);
+    if (seen) v3d_mark_seen(seen, vmax, limit * (1.f / (float)(1 << V3D_QUIET_BITS)));
   }
 }
 
@@ -251,7 +246,7 @@ int v3d_i_bev_clear_pixels(const int32_t* pix, const int32_t* n, int cap, int ch
 int v3d_i_densify_nhwc_split(const float* feat, const int32_t* coords, const int32_t* n, int cap, int B, int C,
                              const int32_t* spatial_shape_host, void* out_hi, void* out_lo, uint32_t* occ_inv, hipStream_t st,
                              int32_t* written_pix, int32_t* written_n, int prec, const float* act_entry, int32_t* range_flag,
-                             unsigned* frame_max) {
+                             unsigned* seen) {
   if (!feat || !coords || !n || cap < 1 || B < 1 || C < 1 || !spatial_shape_host || !out_hi || !out_lo) return V3D_EINVAL;
   if (prec == V3D_PREC_F16S ? !act_entry : prec != V3D_PREC_BF16X3) return V3D_EINVAL;
   if ((written_pix == nullptr) != (written_n == nullptr)) return V3D_EINVAL;
@@ -269,7 +264,7 @@ int v3d_i_densify_nhwc_split(const float* feat, const int32_t* coords, const int
   const int blocks = (int)((total + V3D_BLOCK - 1) / V3D_BLOCK);
   if (prec == V3D_PREC_F16S)
     hipLaunchKernelGGL(densify_split_kernel<1>, dim3(blocks > 4096 ? 4096 : blocks), dim3(V3D_BLOCK), 0, st, feat, (const int4*)coords, n,
-                       cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo, occ_inv, written_pix, written_n, act_entry, range_flag, frame_max);
+                       cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo, occ_inv, written_pix, written_n, act_entry, range_flag, seen);
   else
     hipLaunchKernelGGL(densify_split_kernel<0>, dim3(blocks > 4096 ? 4096 : blocks), dim3(V3D_BLOCK), 0, st, feat, (const int4*)coords, n,
                        cap, C, D, H, Wd, (bf16_t*)out_hi, (bf16_t*)out_lo, occ_inv, written_pix, written_n, nullptr, nullptr, nullptr);
@@ -364,12 +359,7 @@ extern "C" int v3d_split_nhwc_to_nchw(const void* x_hi, const void* x_lo, int B,
   return V3D_OK;
 }
 
-extern "C" int v3d_nchw_to_split_nhwc(const float* x, int B, int C, int H, int W, void* out_hi, void* out_lo,
-                                      v3d_stream_t stream) {
-  return v3d_nchw_to_split_nhwc2(x, B, C, H, W, out_hi, out_lo, V3D_PREC_BF16X3, nullptr, stream);
-}
-
-extern "C" int v3d_nchw_to_split_nhwc2(const float* x, int B, int C, int H, int W, void* out_hi, void* out_lo, int prec,
+extern "C" int v3d_nchw_to_split_nhwc(const float* x, int B, int C, int H, int W, void* out_hi, void* out_lo, int prec,
                                        const float* act_entry, v3d_stream_t stream) {
   if (!x || !out_hi || !out_lo || B < 1 || C < 1 || H < 1 || W < 1) return V3D_EINVAL;
   if (prec == V3D_PREC_F16S ? !act_entry : prec != V3D_PREC_BF16X3) return V3D_EINVAL;
@@ -402,7 +392,7 @@ struct DcParams {
   int B, H, W, Cin, Cout, CoutPad, ks, relu;
   int M;          // B*H*W
   int cout_store; // channels actually written
-  // background skipping (large-tile kernel, split-plane output only; see v3d_conv2d_nhwc_bf16x3_bg)
+  // background skipping (large-tile kernel, split-plane output only; see v3d_conv2d_nhwc_split: occ)
   const unsigned* occ;   // BEV occupancy, one bit per pixel, INVERTED (0 = occupied), rows of ceil(W / 32) words (nullptr:
                          // compute every tile)
   int reach;             // output pixels further than this (Chebyshev) from every occupied pixel equal the empty-map response
@@ -1537,12 +1527,6 @@ static int dc_check_prec(const v3d_conv2d_prec* pr, bool planes_out) {
 }
 
 extern "C" int v3d_conv2d_1x1_head_fused(const void* x_hi, const void* x_lo, const void* w1_image, const float* b1, int relu1,
-                                         const void* w2_image, const float* b2, int relu2, int B, int H, int W, int Cmid, int Cout2,
-                                         float* y_nchw, v3d_stream_t stream) {
-  return v3d_conv2d_1x1_head_fused2(x_hi, x_lo, w1_image, b1, relu1, w2_image, b2, relu2, B, H, W, Cmid, Cout2, y_nchw, nullptr, stream);
-}
-
-extern "C" int v3d_conv2d_1x1_head_fused2(const void* x_hi, const void* x_lo, const void* w1_image, const float* b1, int relu1,
                                           const void* w2_image, const float* b2, int relu2, int B, int H, int W, int Cmid, int Cout2,
                                           float* y_nchw, const v3d_conv2d_prec* pr, v3d_stream_t stream) {
   if (!x_hi || !x_lo || !w1_image || !w2_image || !y_nchw || B < 1 || H < 1 || W < 1) return V3D_EINVAL;
@@ -1572,13 +1556,6 @@ extern "C" int v3d_conv2d_1x1_head_fused2(const void* x_hi, const void* x_lo, co
 }
 
 extern "C" int v3d_conv2d_bg_tiles(int B, int H, int W);
-extern "C" int v3d_conv2d_nhwc_bf16x3(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
-                                      int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
-                                      float* y_nchw, v3d_stream_t stream) {
-  return v3d_conv2d_nhwc_split(x_hi, x_lo, weight_image, bias, relu, B, H, W, Cin, Cout, ksize, y_hi, y_lo, y_nchw, nullptr, 0,
-                               nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, stream);
-}
-
 // BEV occupancy bitmap, INVERTED (bit cleared = occupied) so that the 0xFF fill that resets the rest of a plan's per-frame
 // state also resets it: row (b, y) = ceil(W / 32) words, bit x % 32 of word x / 32.  From the site list of the last sparse
 // stage (rows (b, z, y, x); z is folded into the channels).
@@ -1610,23 +1587,6 @@ extern "C" int v3d_conv2d_bg_tiles(int B, int H, int W) {
   const long long flat = ((long long)B * H * W + 5 * 16 - 1) / (5 * 16);
   const long long blocks = (long long)B * ((H + D2_TH - 1) / D2_TH) * ((W + D2_TW - 1) / D2_TW);
   return (int)(flat > blocks ? flat : blocks);
-}
-
-extern "C" int v3d_conv2d_nhwc_bf16x3_bg(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
-                                         int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
-                                         float* y_nchw, const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo,
-                                         uint32_t* work, uint32_t* tile_state, v3d_stream_t stream) {
-  return v3d_conv2d_nhwc_split(x_hi, x_lo, weight_image, bias, relu, B, H, W, Cin, Cout, ksize, y_hi, y_lo, y_nchw, occ, reach, bg_hi,
-                               bg_lo, work, tile_state, nullptr, 0, nullptr, stream);
-}
-
-extern "C" int v3d_conv2d_nhwc_bf16x3_bg2(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias,
-                                          int relu, int B, int H, int W, int Cin, int Cout, int ksize, void* y_hi, void* y_lo,
-                                          float* y_nchw, const uint32_t* occ, int reach, const void* bg_hi, const void* bg_lo,
-                                          uint32_t* work, uint32_t* tile_state, uint32_t* reset_ptr, int reset_words,
-                                          v3d_stream_t stream) {
-  return v3d_conv2d_nhwc_split(x_hi, x_lo, weight_image, bias, relu, B, H, W, Cin, Cout, ksize, y_hi, y_lo, y_nchw, occ, reach, bg_hi,
-                               bg_lo, work, tile_state, reset_ptr, reset_words, nullptr, stream);
 }
 
 template <int PREC>

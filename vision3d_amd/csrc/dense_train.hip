@@ -19,6 +19,13 @@
 // bit-repeatable, no atomics.
 #include "v3d_internal.h"
 
+// the inference head's convolution (dense_conv.hip v3d_conv2d_nhwc_split) on bf16x3 images, every tile convolved
+static inline int dt_conv2d_plain(const void* x_hi, const void* x_lo, const void* weight_image, const float* bias, int relu, int B, int H, int W,
+                                  int Cin, int Cout, int ksize, void* y_hi, void* y_lo, float* y_nchw, v3d_stream_t stream) {
+  return v3d_conv2d_nhwc_split(x_hi, x_lo, weight_image, bias, relu, B, H, W, Cin, Cout, ksize, y_hi, y_lo, y_nchw, nullptr, 0, nullptr, nullptr,
+                               nullptr, nullptr, nullptr, 0, nullptr, stream);
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 dt_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float dt_f32x4;
 typedef unsigned dt_u32x4 __attribute__((ext_vector_type(4)));
@@ -1466,11 +1473,11 @@ extern "C" int v3d_dense_train_forward_split(const void* bev_hi, const void* bev
   for (int l = 0; l < n_layers; l++) {  // image 2 l: forward, 2 l + 1: the data gradient's (read by the backward call of this step)
     const v3d_dense_train_layer& L = layers[l];
     if (!L.weight || !L.gamma || !L.beta || (L.ksize != 1 && L.ksize != 3)) return V3D_EINVAL;
-    DT_TRY(v3d_conv2d_pack_weights(L.weight, nullptr, DT_C, DT_C, L.ksize, base + a.off_img + (size_t)(2 * l) * a.img, stream));
+    DT_TRY(v3d_conv2d_pack_weights(L.weight, nullptr, DT_C, DT_C, L.ksize, V3D_PREC_BF16X3, base + a.off_img + (size_t)(2 * l) * a.img, stream));
     hipLaunchKernelGGL(dt_wt_flip_kernel, dim3(64), dim3(256), 0, st, L.weight, L.ksize * L.ksize, wt);
-    DT_TRY(v3d_conv2d_pack_weights(wt, nullptr, DT_C, DT_C, L.ksize, base + a.off_img + (size_t)(2 * l + 1) * a.img, stream));
+    DT_TRY(v3d_conv2d_pack_weights(wt, nullptr, DT_C, DT_C, L.ksize, V3D_PREC_BF16X3, base + a.off_img + (size_t)(2 * l + 1) * a.img, stream));
   }
-  DT_TRY(v3d_conv2d_pack_weights(head_weight, nullptr, O, DT_C, 1, base + a.off_himg, stream));
+  DT_TRY(v3d_conv2d_pack_weights(head_weight, nullptr, O, DT_C, 1, V3D_PREC_BF16X3, base + a.off_himg, stream));
   const long long want = (M + 15) / 16;
   const int blocks = (int)(want < DT_RED_BLOCKS ? want : DT_RED_BLOCKS);
   float* partial = (float*)(base + a.off_partial);
@@ -1480,7 +1487,7 @@ extern "C" int v3d_dense_train_forward_split(const void* bev_hi, const void* bev
     unsigned char* raw = base + a.off_raw + (size_t)l * 2 * a.plane;
     unsigned char* act = base + a.off_act + (size_t)l * 2 * a.plane;
     float* mean = (float*)(base + a.off_stat) + (size_t)l * 2 * DT_C;
-    DT_TRY(v3d_conv2d_nhwc_bf16x3(x_hi, x_lo, base + a.off_img + (size_t)(2 * l) * a.img, nullptr, 0, B, H, W, DT_C, DT_C, L.ksize, raw,
+    DT_TRY(dt_conv2d_plain(x_hi, x_lo, base + a.off_img + (size_t)(2 * l) * a.img, nullptr, 0, B, H, W, DT_C, DT_C, L.ksize, raw,
                                   raw + a.plane, nullptr, stream));
     hipLaunchKernelGGL(dt_bn_stats_kernel, dim3(blocks), dim3(256), 0, st, (const dt_bf16*)raw, (const dt_bf16*)(raw + a.plane), M, partial);
     DT_TRY(v3d_dense_train_bn_finalize(partial, blocks, M, L.eps, L.momentum, mean, mean + DT_C, L.running_mean, L.running_var,
@@ -1492,7 +1499,7 @@ extern "C" int v3d_dense_train_forward_split(const void* bev_hi, const void* bev
     x_lo = act + a.plane;
   }
   V3D_CHECK_LAUNCH();
-  return v3d_conv2d_nhwc_bf16x3(x_hi, x_lo, base + a.off_himg, head_bias, 0, B, H, W, DT_C, O, 1, nullptr, nullptr, maps, stream);
+  return dt_conv2d_plain(x_hi, x_lo, base + a.off_himg, head_bias, 0, B, H, W, DT_C, O, 1, nullptr, nullptr, maps, stream);
 }
 
 // dmaps fp32 (B, O, H, W) -> gradients of every layer, of the head, and of the input (dbev: split NHWC planes)
@@ -1525,7 +1532,7 @@ extern "C" int v3d_dense_train_backward_split(const void* bev_hi, const void* be
     DT_TRY(dt_wgrad_split(xin_hi, xin_lo, g[cur], g[cur] + a.plane, B, H, W, L.ksize, L.grad_weight, ws, ws_bytes, st));
     void* out_hi = l == 0 ? dbev_hi : (void*)g[cur ^ 1];
     void* out_lo = l == 0 ? dbev_lo : (void*)(g[cur ^ 1] + a.plane);
-    DT_TRY(v3d_conv2d_nhwc_bf16x3(g[cur], g[cur] + a.plane, base + a.off_img + (size_t)(2 * l + 1) * a.img, nullptr, 0, B, H, W, DT_C, DT_C,
+    DT_TRY(dt_conv2d_plain(g[cur], g[cur] + a.plane, base + a.off_img + (size_t)(2 * l + 1) * a.img, nullptr, 0, B, H, W, DT_C, DT_C,
                                   L.ksize, out_hi, out_lo, nullptr, stream));
     cur ^= 1;
   }

@@ -503,25 +503,20 @@ __global__ __launch_bounds__(V3D_BLOCK) void ball_query2_kernel(const float* __r
   }
 }
 
-extern "C" int v3d_ball_query2(const float* xyz, const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a,
-                               int32_t* idx_a, float radius_b, int nsample_b, int32_t* idx_b, v3d_stream_t stream) {
-  if (B < 0 || N < 1 || M < 0 || nsample_a < 1 || nsample_b < 1) return V3D_EINVAL;
+// One entry point for one or two radii: idx_b == NULL -> the single-radius kernel (radius_b / nsample_b ignored); else both index
+// sets from ONE scan of the database (PointnetSAModuleMSG's two scales, detector/model.py:46-66).
+extern "C" int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a,
+                              int32_t* idx_a, float radius_b, int nsample_b, int32_t* idx_b, v3d_stream_t stream) {
+  if (B < 0 || N < 1 || M < 0 || nsample_a < 1 || (idx_b && nsample_b < 1)) return V3D_EINVAL;
   if (B == 0 || M == 0) return V3D_OK;
-  if (!xyz || !new_xyz || !idx_a || !idx_b) return V3D_EINVAL;
-  hipLaunchKernelGGL(ball_query2_kernel, dim3(v3d_ceil_div(M, (V3D_BLOCK / V3D_WAVE) * BQ2_QPW), B), dim3(V3D_BLOCK), 0,
-                     (hipStream_t)stream, xyz, new_xyz, N, M, radius_a * radius_a, nsample_a, idx_a, radius_b * radius_b, nsample_b,
-                     idx_b);
-  V3D_CHECK_LAUNCH();
-  return V3D_OK;
-}
-
-extern "C" int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M, float radius, int nsample,
-                              int32_t* idx, v3d_stream_t stream) {
-  if (B < 0 || N < 1 || M < 0 || nsample < 1) return V3D_EINVAL;
-  if (B == 0 || M == 0) return V3D_OK;
-  if (!xyz || !new_xyz || !idx) return V3D_EINVAL;
-  hipLaunchKernelGGL(ball_query_kernel, dim3(v3d_ceil_div(M, (V3D_BLOCK / V3D_WAVE) * BQ_QPW), B), dim3(V3D_BLOCK), 0, (hipStream_t)stream,
-                     xyz, new_xyz, N, M, radius * radius, nsample, idx);
+  if (!xyz || !new_xyz || !idx_a) return V3D_EINVAL;
+  if (!idx_b)
+    hipLaunchKernelGGL(ball_query_kernel, dim3(v3d_ceil_div(M, (V3D_BLOCK / V3D_WAVE) * BQ_QPW), B), dim3(V3D_BLOCK), 0, (hipStream_t)stream,
+                       xyz, new_xyz, N, M, radius_a * radius_a, nsample_a, idx_a);
+  else
+    hipLaunchKernelGGL(ball_query2_kernel, dim3(v3d_ceil_div(M, (V3D_BLOCK / V3D_WAVE) * BQ2_QPW), B), dim3(V3D_BLOCK), 0,
+                       (hipStream_t)stream, xyz, new_xyz, N, M, radius_a * radius_a, nsample_a, idx_a, radius_b * radius_b, nsample_b,
+                       idx_b);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }

@@ -85,8 +85,9 @@ struct v3d_backbone {
   float* act_tab = nullptr;
   float* w_inv_tab = nullptr;  // [n_layers] 1 / s_w of the layers' f16s images, beside act_tab: what the kernels read instead of the
                                // images' trailers (cold lines)
-  unsigned* frame_max = nullptr;  // [n_layers + 1] f16s: running maximum (fp32 bits) of the tensor entry l describes over THIS frame, zeroed
-                                  // by the frame's first launch: what plan_quiet_check_kernel compares with the entries' limits
+  unsigned* frame_max = nullptr;  // [n_layers + 1] f16s: "the tensor entry l describes held a value >= limit * 2^-12 in THIS frame" (0 / 1), zeroed
+                                  // by the frame's first launch and set by the producing waves: what plan_quiet_check_kernel reads
+  const int32_t** entry_rows = nullptr;  // [n_layers + 1] device: the live-row count of the stage each entry's tensor lives on
   struct PlanTrain* train = nullptr;  // training buffers, allocated by the first v3d_backbone_train_forward
   // (Measured and removed in round 4: the rulebook chain on a second stream with one event per finished rulebook -- inside a
   // captured graph the fork / join costs more than the overlap returns, 3 209 -> 2 526 frames/s pipelined; docs/rounds/design_rounds_1-4.md 5c.4.)
@@ -225,6 +226,7 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
     p->act_tab = ar.take<float>(4 * (p->layers.size() + 1) + p->layers.size());
     p->w_inv_tab = p->act_tab + 4 * (p->layers.size() + 1);
     p->frame_max = ar.take<unsigned>(p->layers.size() + 1);
+    p->entry_rows = ar.take<const int32_t*>(p->layers.size() + 1);
     p->cand_slot[0] = ar.take<int>((size_t)max_tickets);
     p->cand_slot[1] = ar.take<int>((size_t)max_tickets);
     for (auto& L : p->layers) {
@@ -250,6 +252,12 @@ extern "C" int v3d_backbone_create(const v3d_backbone_config* cfg, const v3d_lay
   if (e == hipSuccess) e = hipMemset(p->bev_hi, 0, (size_t)((char*)p->bev_lo - (char*)p->bev_hi) * 2);  // the planes are adjacent
   if (e == hipSuccess) e = hipMemset(p->bev_pix_n, 0, sizeof(int32_t));
   if (e == hipSuccess) e = hipMemset(p->frame_max, 0, (p->layers.size() + 1) * sizeof(unsigned));
+  if (e == hipSuccess) {
+    std::vector<const int32_t*> rows(p->layers.size() + 1);
+    rows[0] = p->stages[0].n_dev;
+    for (size_t l = 0; l < p->layers.size(); l++) rows[l + 1] = p->stages[p->layers[l].stage_out].n_dev;
+    e = hipMemcpy(p->entry_rows, rows.data(), rows.size() * sizeof(const int32_t*), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) {
     std::vector<float> tab;
     for (size_t i = 0; i <= p->layers.size(); i++) tab.insert(tab.end(), {1.f, 1.f, 32768.f, 0.f});
@@ -281,7 +289,7 @@ extern "C" int v3d_backbone_set_layer(v3d_backbone* p, int layer, const float* w
   V3D_CHECK_HIP(hipMemcpyAsync(L.weight, weight, (size_t)L.K * L.d.cin * L.d.cout * 4, hipMemcpyDeviceToDevice, st));
   L.has_affine = scale != nullptr;
   if (L.d.cout % 16 == 0) {
-    int rc = v3d_sparse_conv_pack_weights2(L.weight, L.K, L.d.cin, L.d.cout, p->prec, L.wimg, stream);
+    int rc = v3d_sparse_conv_pack_weights(L.weight, L.K, L.d.cin, L.d.cout, p->prec, L.wimg, stream);
     if (rc) return rc;
     if (p->prec == V3D_PREC_F16S) {  // the image's 1 / s_w (written by the pack kernel) into the plan's hot table
       const char* trailer = (const char*)L.wimg + v3d_sparse_conv_weight_image_bytes(L.K, L.d.cin, L.d.cout) - 256;
@@ -293,11 +301,6 @@ extern "C" int v3d_backbone_set_layer(v3d_backbone* p, int layer, const float* w
     V3D_CHECK_HIP(hipMemcpyAsync(L.shift, shift, (size_t)L.d.cout * 4, hipMemcpyDeviceToDevice, st));
   }
   return V3D_OK;
-}
-
-extern "C" int v3d_backbone_forward(v3d_backbone* p, const float* points, int n_points,
-                                    const int32_t* frame_offsets_host, int B, float* dense_out, v3d_stream_t stream) {
-  return v3d_backbone_forward2(p, points, n_points, frame_offsets_host, B, dense_out, nullptr, nullptr, stream);
 }
 
 static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense_out, void* dense_hi, void* dense_lo,
@@ -357,17 +360,16 @@ static int plan_frame_start(v3d_backbone* p, void* dense_hi, void* dense_lo, hip
 
 // f16s, the DOWNWARD range check.  An output beyond its consumer's limit is caught where it is produced (V3D_FLAG_RANGE); a tensor
 // that has become much SMALLER than the frame its scale entry was calibrated on is only known once the whole tensor exists: every
-// producing wave folds its maximum into frame_max[entry], and this one-wave launch behind the last layer compares the maxima with
-// the limits -- a tensor whose largest magnitude lies 2^V3D_QUIET_BITS or more below its limit raises the frame's summary word to
-// V3D_FLAG_QUIET (read in the frame's one host synchronisation: recalibrate on this frame, run it again -- as for V3D_FLAG_RANGE).
-// Entry 0 (the voxel means, consumed by the exact-fp32 input layer) and all-zero tensors (an empty frame) are not judged.
-__global__ __launch_bounds__(64) void plan_quiet_check_kernel(const float* __restrict__ act_tab, const unsigned* __restrict__ frame_max,
-                                                              int n_entries, int* __restrict__ flag) {
+// producing wave that sees a value of at least limit * 2^-V3D_QUIET_BITS sets the tensor's word (v3d_mark_seen), and this one-wave
+// launch behind the last layer raises the frame's summary word to V3D_FLAG_QUIET when a tensor WITH rows, whose calibration frame
+// was not all zeros, set nothing (read in the frame's one host synchronisation: recalibrate on this frame, run it again -- as
+// for V3D_FLAG_RANGE).  Entry 0 (the voxel means, consumed by the exact-fp32 input layer) is not judged.
+__global__ __launch_bounds__(64) void plan_quiet_check_kernel(const float* __restrict__ act_tab, const unsigned* __restrict__ seen,
+                                                              const int32_t* const* __restrict__ entry_rows, int n_entries,
+                                                              int* __restrict__ flag) {
   bool quiet = false;
-  for (int l = 1 + (int)threadIdx.x; l < n_entries; l += 64) {
-    const unsigned m = frame_max[l];
-    quiet |= m != 0u && __uint_as_float(m) < act_tab[4 * l + 2] * (1.f / (float)(1 << V3D_QUIET_BITS));
-  }
+  for (int l = 1 + (int)threadIdx.x; l < n_entries; l += 64)
+    quiet |= seen[l] == 0u && *entry_rows[l] > 0 && act_tab[4 * l + 3] != 0.f;
   if (__ballot(quiet) != 0ull && threadIdx.x == 0) atomicMax(flag, V3D_FLAG_QUIET);
 }
 
@@ -432,13 +434,13 @@ extern "C" int v3d_backbone_calibrate(v3d_backbone* p, int headroom_bits, v3d_st
     const float* rows = l == 0 ? p->mean : p->layers[l - 1].out;
     const int C = l == 0 ? p->cfg.point_channels : p->layers[l - 1].d.cout;
     const PlanStage& sg = p->stages[l == 0 ? 0 : p->layers[l - 1].stage_out];
-    int rc = v3d_act_scale_from_rows(rows, sg.n_dev, sg.cap, C, headroom_bits, p->act_tab + 4 * l, stream);
+    int rc = v3d_act_scale_from_rows(rows, sg.n_dev, sg.cap, C, headroom_bits, p->act_tab + 4 * l, nullptr, stream);
     if (rc) return rc;
   }
   return V3D_OK;
 }
 
-extern "C" int v3d_backbone_forward2(v3d_backbone* p, const float* points, int n_points,
+extern "C" int v3d_backbone_forward(v3d_backbone* p, const float* points, int n_points,
                                      const int32_t* frame_offsets_host, int B, float* dense_out, void* dense_hi,
                                      void* dense_lo, v3d_stream_t stream) {
   if (!p || !frame_offsets_host || B < 1 || B > p->cfg.max_batch || n_points < 0 || n_points > p->cfg.max_points)
@@ -562,7 +564,11 @@ static int plan_layer_conv(v3d_backbone* p, PlanLayer& L, const float* feat, con
     const int prec = inference ? p->prec : V3D_PREC_BF16X3;
     const size_t l = (size_t)(&L - p->layers.data());
     const V3dActScale as{p->act_tab + 4 * l, p->act_tab + 4 * (l + 1), p->overflow + p->layers.size(), p->w_inv_tab + l,
+#ifdef V3D_EXP_NO_SEEN
+                         nullptr};
+#else
                          inference ? p->frame_max + l + 1 : nullptr};
+#endif
     const void* in_s = feat_split ? *feat_split : nullptr;
     // (f16s only: its split is conversion instructions that issue slowly -- profiles/r05_f16s_split_ab.txt --; with bf16 pieces the
     //  second copy of the rows costs the pipelined mode more than the plain split it saves: profiles/r05_presplit_ab.txt)
@@ -637,11 +643,13 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
                                   p->prec == V3D_PREC_F16S && !p->calibrating ? p->frame_max + p->layers.size() : nullptr);
     if (rc) return rc;
   }
+#ifndef V3D_EXP_NO_SEEN
   if (p->prec == V3D_PREC_F16S && !p->calibrating) {
-    hipLaunchKernelGGL(plan_quiet_check_kernel, dim3(1), dim3(64), 0, st, p->act_tab, p->frame_max, (int)p->layers.size() + 1,
+    hipLaunchKernelGGL(plan_quiet_check_kernel, dim3(1), dim3(64), 0, st, p->act_tab, p->frame_max, p->entry_rows, (int)p->layers.size() + 1,
                        p->overflow + (int)p->layers.size());
     V3D_CHECK_LAUNCH();
   }
+#endif
   return V3D_OK;
 }
 
@@ -710,8 +718,8 @@ extern "C" int v3d_backbone_tune_from_voxels(v3d_backbone* p, const int32_t* coo
   return v3d_backbone_tune(p);
 }
 
-// Inverted BEV occupancy bitmap of the LAST forward that produced split planes (v3d_backbone_forward2 / _forward_voxels): device
-// pointer into the plan's arena, (B * H, ceil(W / 32)) words; what v3d_conv2d_nhwc_bf16x3_bg takes as `occ`.
+// Inverted BEV occupancy bitmap of the LAST forward that produced split planes (v3d_backbone_forward / _forward_voxels): device
+// pointer into the plan's arena, (B * H, ceil(W / 32)) words; what v3d_conv2d_nhwc_split takes as `occ`.
 extern "C" uint32_t* v3d_backbone_bev_occupancy(v3d_backbone* p) { return p ? p->bev_occ : nullptr; }
 
 extern "C" int32_t* v3d_backbone_occupancy(v3d_backbone* p) { return p ? p->occupancy : nullptr; }

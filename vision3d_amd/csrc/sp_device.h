@@ -205,7 +205,7 @@ __device__ __forceinline__ SpScales sp_scales(const V3dActScale& as, const unsig
 // (every lane of the wave calls this, at the end of the kernel)
 __device__ __forceinline__ void sp_range_check(const V3dActScale& as, const float vmax, const float limit) {
   if (as.flag && vmax > limit) atomicMax(as.flag, V3D_FLAG_RANGE);
-  if (as.fmax) v3d_publish_frame_max(as.fmax, vmax);
+  if (as.seen) v3d_mark_seen(as.seen, vmax, limit * (1.f / (float)(1 << V3D_QUIET_BITS)));
 }
 
 static __device__ __attribute__((aligned(256))) const float spr_zero_row[128] = {};

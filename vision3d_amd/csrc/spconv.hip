@@ -73,7 +73,7 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
                                                                        const float* __restrict__ scale,
                                                                        const float* __restrict__ shift, int relu,
                                                                        float* __restrict__ out, const float* __restrict__ next_entry,
-                                                                       int* __restrict__ range_flag, unsigned* __restrict__ frame_max) {
+                                                                       int* __restrict__ range_flag, unsigned* __restrict__ seen) {
   constexpr int NB = COUT / 16;
   constexpr int G = SPW_WAVES / NB;
   constexpr int T = CIN / 4;  // MFMA steps; also floats of one row held per lane
@@ -245,18 +245,18 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
     *reinterpret_cast<float4*>(out + (size_t)(row0 + rw) * COUT + c4 * 4) = v;
   }
   if (next_entry && range_flag && vmax > next_entry[2]) atomicMax(range_flag, V3D_FLAG_RANGE);
-  if (frame_max) v3d_publish_frame_max(frame_max, vmax);
+  if (seen && next_entry) v3d_mark_seen(seen, vmax, next_entry[2] * (1.f / (float)(1 << V3D_QUIET_BITS)));
 }
 
 template <int CIN, int COUT>
 static int launch_wave(const float* in, const float* W, const int* nbr, const int* n_ptr, int cap, int K,
                        const float* scale, const float* shift, int relu, float* out, hipStream_t st, const float* next_entry,
-                       int* range_flag, unsigned* frame_max) {
+                       int* range_flag, unsigned* seen) {
   constexpr int G = SPW_WAVES / (COUT / 16);
   const size_t lds = (size_t)G * SPC_TM * COUT * 4 + (size_t)K * SPC_TM * 4 + (size_t)K * 4 + (size_t)K * SPC_TM + 64;
   if (lds > 64 * 1024) return V3D_EUNSUPPORTED;
   hipLaunchKernelGGL((spconv_fwd_wave<CIN, COUT>), dim3(v3d_ceil_div(cap, SPC_TM)), dim3(SPW_WAVES * V3D_WAVE), lds, st,
-                     in, W, nbr, n_ptr, cap, K, scale, shift, relu, out, next_entry, range_flag, frame_max);
+                     in, W, nbr, n_ptr, cap, K, scale, shift, relu, out, next_entry, range_flag, seen);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void act_scale_from_rows_grid_kernel(con
   }
 }
 
-extern "C" int v3d_act_scale_from_rows2(const float* rows, const int32_t* n_rows, int cap, int C, int headroom_bits, float* entry,
+extern "C" int v3d_act_scale_from_rows(const float* rows, const int32_t* n_rows, int cap, int C, int headroom_bits, float* entry,
                                         uint32_t* scratch, v3d_stream_t stream) {
   if (!rows || !entry || cap < 1 || C < 1 || headroom_bits < 0 || headroom_bits > 12) return V3D_EINVAL;
   if (!scratch) {
@@ -456,20 +456,11 @@ extern "C" int v3d_act_scale_from_rows2(const float* rows, const int32_t* n_rows
   return V3D_OK;
 }
 
-extern "C" int v3d_act_scale_from_rows(const float* rows, const int32_t* n_rows, int cap, int C, int headroom_bits, float* entry,
-                                       v3d_stream_t stream) {
-  return v3d_act_scale_from_rows2(rows, n_rows, cap, C, headroom_bits, entry, nullptr, stream);
-}
-
 extern "C" size_t v3d_sparse_conv_weight_image_bytes(int K, int Cin, int Cout) {
   return (size_t)K * ((Cin + 31) / 32) * (Cout / 16) * 2 * 512 * sizeof(unsigned short) + V3D_WIMG_TRAILER;
 }
 
-extern "C" int v3d_sparse_conv_pack_weights(const float* weight, int K, int Cin, int Cout, void* image, v3d_stream_t stream) {
-  return v3d_sparse_conv_pack_weights2(weight, K, Cin, Cout, V3D_PREC_BF16X3, image, stream);
-}
-
-extern "C" int v3d_sparse_conv_pack_weights2(const float* weight, int K, int Cin, int Cout, int prec, void* image,
+extern "C" int v3d_sparse_conv_pack_weights(const float* weight, int K, int Cin, int Cout, int prec, void* image,
                                              v3d_stream_t stream) {
   if (!weight || !image || K < 1 || Cin < 1 || Cout < 16 || Cout % 16) return V3D_EINVAL;
   if (prec != V3D_PREC_BF16X3 && prec != V3D_PREC_F16S) return V3D_EINVAL;
@@ -1498,13 +1489,6 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
 
 // Forward with PRE-PACKED split weights (v3d_sparse_conv_pack_weights): the split-precision row-owner kernels.
 extern "C" int v3d_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr,
-                                          const int32_t* n_out, int cap_out, int K, int Cin, int Cout, const float* scale,
-                                          const float* shift, int relu, float* out, int rows_hint, v3d_stream_t stream) {
-  return v3d_i_sparse_conv_fwd_packed(in, weight_image, nbr, n_out, cap_out, K, Cin, Cout, scale, shift, relu, out, rows_hint,
-                                      (hipStream_t)stream);
-}
-
-extern "C" int v3d_sparse_conv_fwd_packed2(const float* in, const void* weight_image, const int32_t* nbr,
                                            const int32_t* n_out, int cap_out, int K, int Cin, int Cout, const float* scale,
                                            const float* shift, int relu, float* out, int rows_hint, int prec,
                                            const float* act_in, const float* act_next, int32_t* range_flag,
@@ -1605,14 +1589,14 @@ extern "C" int v3d_sparse_conv_fwd(const float* in, const float* weight, const i
 
 int v3d_i_sparse_conv_fwd_exact(const float* in, const float* weight, const int32_t* nbr, const int32_t* n_out, int cap_out, int K,
                                 int Cin, int Cout, const float* scale, const float* shift, int relu, float* out, int algo,
-                                hipStream_t st, const float* next_entry, int32_t* range_flag, unsigned* frame_max) {
+                                hipStream_t st, const float* next_entry, int32_t* range_flag, unsigned* seen) {
   if (!in || !weight || !nbr || !n_out || !out || cap_out < 1 || K < 1 || Cin < 1 || Cout < 1) return V3D_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return V3D_EINVAL;
   if (algo != 0 && algo != 1 && algo != 3) return V3D_EINVAL;  // (2 was an LDS-staged fp32 kernel: removed)
   if (algo == 0 || algo == 3) {
     int rc = V3D_EUNSUPPORTED;
 #define V3D_TRY(ci, co) \
-  if (Cin == ci && Cout == co) rc = launch_wave<ci, co>(in, weight, nbr, n_out, cap_out, K, scale, shift, relu, out, st, next_entry, range_flag, frame_max);
+  if (Cin == ci && Cout == co) rc = launch_wave<ci, co>(in, weight, nbr, n_out, cap_out, K, scale, shift, relu, out, st, next_entry, range_flag, seen);
     V3D_TRY(4, 16)
     V3D_TRY(16, 16)
     V3D_TRY(16, 32)

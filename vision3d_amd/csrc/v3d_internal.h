@@ -70,8 +70,8 @@ struct V3dActScale {
   const float* w_inv; // nullable: 1 / s_w of the weight image in memory the caller keeps HOT (a plan's table: one line for all layers).
                       // NULL: read from the image's trailer -- a line nothing else touches, i.e. a cold miss of ~1 us at the top of
                       // every launch (measured: every packed layer +1 us against bf16x3 until the plan passed this)
-  unsigned* fmax;     // nullable: the frame's running maximum of this launch's OUTPUT tensor (fp32 bits; zero at the start of a frame):
-                      // every wave folds its largest magnitude in (v3d_publish_frame_max) -- what the plan's quiet check reads
+  unsigned* seen;     // nullable (needs `next`): word of this launch's OUTPUT tensor, zero at the start of a frame, set to 1 by a wave whose
+                      // outputs reach next[2] * 2^-V3D_QUIET_BITS (v3d_mark_seen) -- what the plan's quiet check reads
 };
 
 // .dense() riding in the epilogue of the LAST sparse layer (the 16-row kernel): besides its rows the layer writes them, split into
@@ -119,7 +119,7 @@ bool v3d_i_sparse_conv_packed_supported(int Cin, int Cout);
 // entry of the tensor it produces (wave kernel only; both nullable)
 int v3d_i_sparse_conv_fwd_exact(const float* in, const float* weight, const int32_t* nbr, const int32_t* n_out, int cap_out, int K,
                                 int Cin, int Cout, const float* scale, const float* shift, int relu, float* out, int algo,
-                                hipStream_t st, const float* next_entry, int32_t* range_flag, unsigned* frame_max = nullptr);
+                                hipStream_t st, const float* next_entry, int32_t* range_flag, unsigned* seen = nullptr);
 
 // spconv.hip: several packed weight images in one launch (mode 0: W (K, Cin, Cout); 1 / 2: the transposed layer of a source
 // (K, Cout, Cin), 2 with the offsets reversed)
@@ -149,6 +149,6 @@ int v3d_i_densify_nhwc_split(const float* feat, const int32_t* coords, const int
                              int32_t* written_n = nullptr, int prec = V3D_PREC_BF16X3,
                              const float* act_entry = nullptr /*f16s: {s, 1/s, limit, ..} of the planes (device)*/,
                              int32_t* range_flag = nullptr /*f16s, nullable: raised to V3D_FLAG_RANGE by a value beyond the limit*/,
-                             unsigned* frame_max = nullptr /*f16s, nullable: the planes' running maximum of the frame (V3dActScale::fmax)*/);
+                             unsigned* seen = nullptr /*f16s, nullable: the planes' word of the downward range check (V3dActScale::seen)*/);
 // zero the listed pixels (channels bf16 values each) of both planes: start-of-frame job of persistent BEV planes
 int v3d_i_bev_clear_pixels(const int32_t* pix, const int32_t* n, int cap, int channels, void* hi, void* lo, hipStream_t st);

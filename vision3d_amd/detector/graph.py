@@ -76,6 +76,11 @@ class GraphedSecond(object):
                 self.static_points[a + n:b].fill_(PAD_COORDINATE)
 
     def weights_changed(self):
+        """One integer comparison per launch (Second.notify_weights_changed); the tensors are looked at only when it moved."""
+        epoch = self.model.__dict__.get("_weights_epoch", 0)
+        if epoch == self.__dict__.get("_seen_epoch"):
+            return False
+        self._seen_epoch = epoch
         return self.plan.weights_changed() or self.dense.weights_changed()
 
     def launch(self):
@@ -88,6 +93,7 @@ class GraphedSecond(object):
             self.graph = None
         if self.graph is None:
             self._capture()
+            self._seen_epoch = self.model.__dict__.get("_weights_epoch", 0)
         self.graph.replay()
 
     def replay(self):

@@ -169,6 +169,23 @@ class Second(nn.Module):
         self.rpn = RPN(C_in=64 * z)
         self.head = ProposalLayer(cfg)
         self.cfg = cfg
+        # "the parameters may have changed" counter for the captured-graph runners (detector/graph.py): bumped by load_state_dict, by
+        # every train() / eval() switch (an optimizer step happens in training mode) and by notify_weights_changed() (in-place edits
+        # in eval mode).  A runner compares this ONE integer per launch -- comparing the ~120 parameter version counters per frame
+        # cost 0.25 ms of host time per frame (profiles/r06_b_*: 3 800 -> 2 900 frames/s) -- and looks at the tensors only when it moved.
+        self.__dict__["_weights_epoch"] = 0
+        self.register_load_state_dict_post_hook(lambda module, incompatible: (module.notify_weights_changed(), None)[1])
+
+    def notify_weights_changed(self):
+        """Tell the captured-graph runners that parameters / buffers were edited (they check the tensors themselves on their next
+        launch).  Called automatically by load_state_dict and train() / eval(); call it after in-place edits of an eval-mode model.
+        The eager entry points need no notice: they compare the tensors' version counters on every call."""
+        self.__dict__["_weights_epoch"] = self.__dict__.get("_weights_epoch", 0) + 1
+        return self
+
+    def train(self, mode=True):
+        self.notify_weights_changed()
+        return super().train(mode)
 
     def set_precision(self, precision):
         """Arithmetic of every native INFERENCE path of this model: the plans (Second.precision), RPN.native_forward and the

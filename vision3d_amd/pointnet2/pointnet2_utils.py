@@ -82,7 +82,7 @@ def ball_query(radius, nsample, xyz, new_xyz):
     m = q.shape[1]
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=p.device)
     with torch.cuda.device(p.device):
-        L.check(L.lib().v3d_ball_query(L.ptr(p), L.ptr(q), b, n, m, float(radius), int(nsample), L.ptr(idx),
+        L.check(L.lib().v3d_ball_query(L.ptr(p), L.ptr(q), b, n, m, float(radius), int(nsample), L.ptr(idx), 0.0, 0, None,
                                        L.stream_ptr()), "ball_query")
     return idx
 
@@ -97,7 +97,7 @@ def ball_query_pair(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz):
     idx_a = torch.empty((b, m, nsample_a), dtype=torch.int32, device=p.device)
     idx_b = torch.empty((b, m, nsample_b), dtype=torch.int32, device=p.device)
     with torch.cuda.device(p.device):
-        L.check(L.lib().v3d_ball_query2(L.ptr(p), L.ptr(q), b, n, m, float(radius_a), int(nsample_a), L.ptr(idx_a),
+        L.check(L.lib().v3d_ball_query(L.ptr(p), L.ptr(q), b, n, m, float(radius_a), int(nsample_a), L.ptr(idx_a),
                                         float(radius_b), int(nsample_b), L.ptr(idx_b), L.stream_ptr()), "ball_query2")
     return idx_a, idx_b
 

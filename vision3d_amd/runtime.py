@@ -232,7 +232,7 @@ class BackbonePlan(object):
             out = torch.empty((b, self.out_channels * d, h, w), dtype=torch.float32, device=pts.device)
         with torch.cuda.device(pts.device):
             L.check(L.lib().v3d_backbone_forward(self._handle, L.ptr(pts), pts.shape[0], L.host_i32(frame_offsets), b,
-                                                 L.ptr(out), L.stream_ptr()), "backbone_forward")
+                                                 L.ptr(out), None, None, L.stream_ptr()), "backbone_forward")
         if self._maybe_tune():
             return self.forward(points, frame_offsets, out)
         return out
@@ -304,7 +304,7 @@ class BackbonePlan(object):
         d, h, w = self.out_shape
         hi, lo = self.own_planes(b) if persistent else self._tag(*split_planes_like(b, h, w, self.out_channels * d, pts.device))
         with torch.cuda.device(pts.device):
-            L.check(L.lib().v3d_backbone_forward2(self._handle, L.ptr(pts), pts.shape[0], L.host_i32(frame_offsets), b, 0,
+            L.check(L.lib().v3d_backbone_forward(self._handle, L.ptr(pts), pts.shape[0], L.host_i32(frame_offsets), b, 0,
                                                   L.ptr(hi), L.ptr(lo), L.stream_ptr()), "backbone_forward2")
         if self._maybe_tune():  # once: kernels are now picked by the observed sparsity
             return self.forward_split(points, frame_offsets, persistent)
@@ -597,7 +597,7 @@ def conv2d_split(x_hi, x_lo, image, bias, relu, cin, cout, ksize, out_split=True
                  out=None, tile_state=None, reset=None, pr=None):
     """One split-precision convolution on split NHWC planes; returns (y_hi, y_lo) and/or fp32 (B,cout,H,W).
     occ / reach / bg = (bg_hi, bg_lo) [/ work: 2 zeroed int32 of the caller's, see the header]: background skipping
-    (v3d_conv2d_nhwc_bf16x3_bg), same values.  out = (y_hi, y_lo): write into these planes; with tile_state (one int32 per
+    (v3d_conv2d_nhwc_split with occ), same values.  out = (y_hi, y_lo): write into these planes; with tile_state (one int32 per
     tile of a PERSISTENT `out`, see the header) background tiles that already hold the empty-map response are not written.
     pr: None = bf16x3 (image from pack_conv_weight(.., "bf16x3")); (in_entry, out_entry, range_flag) = f16s."""
     b, h, w, c = x_hi.shape
@@ -635,7 +635,7 @@ def pack_conv_weight(weight, scale=None, precision="bf16x3"):
     img = torch.empty(int(lib.v3d_conv2d_weight_image_bytes(cin, cout, k)), dtype=torch.uint8, device=w.device)
     sc = None if scale is None else scale.detach().to(torch.float32).contiguous()
     with torch.cuda.device(w.device):
-        L.check(lib.v3d_conv2d_pack_weights2(L.ptr(w), L.ptr(sc), cout, cin, k, L.PRECISIONS[precision], L.ptr(img), L.stream_ptr()),
+        L.check(lib.v3d_conv2d_pack_weights(L.ptr(w), L.ptr(sc), cout, cin, k, L.PRECISIONS[precision], L.ptr(img), L.stream_ptr()),
                 "conv2d_pack_weights")
     return img
 
@@ -645,7 +645,7 @@ def act_entry_from_tensor(x, headroom_bits=0):
     x = L.as_f32("act_entry_from_tensor", x)
     entry = torch.empty(4, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        L.check(L.lib().v3d_act_scale_from_rows2(L.ptr(x), None, x.numel(), 1, int(headroom_bits), L.ptr(entry),
+        L.check(L.lib().v3d_act_scale_from_rows(L.ptr(x), None, x.numel(), 1, int(headroom_bits), L.ptr(entry),
                                                  L.ptr(L.scale_scratch(x.device)), L.stream_ptr()), "act_scale_from_rows")
     return entry
 
@@ -678,7 +678,7 @@ def to_split_nhwc(x, precision="bf16x3"):
     f16s = L.PRECISIONS[precision] == L.PREC_F16S
     entry = act_entry_from_tensor(x) if f16s else None
     with torch.cuda.device(x.device):
-        L.check(L.lib().v3d_nchw_to_split_nhwc2(L.ptr(x), b, c, h, w, L.ptr(hi), L.ptr(lo), L.PRECISIONS[precision], L.ptr(entry),
+        L.check(L.lib().v3d_nchw_to_split_nhwc(L.ptr(x), b, c, h, w, L.ptr(hi), L.ptr(lo), L.PRECISIONS[precision], L.ptr(entry),
                                                 L.stream_ptr()), "nchw_to_split_nhwc")
     tag_planes(hi, entry)
     return hi, lo
@@ -926,7 +926,7 @@ class DenseHeadPlan(object):
                 maps = torch.empty((b, head["cout"], h, w), dtype=torch.float32, device=x_hi.device)
                 ref, keep = _prec_struct(self._pr(i, in_entry, range_flag))
                 with torch.cuda.device(x_hi.device):
-                    L.check(L.lib().v3d_conv2d_1x1_head_fused2(L.ptr(x_hi), L.ptr(x_lo), L.ptr(ly["img"]), L.ptr(ly["bias"]),
+                    L.check(L.lib().v3d_conv2d_1x1_head_fused(L.ptr(x_hi), L.ptr(x_lo), L.ptr(ly["img"]), L.ptr(ly["bias"]),
                                                                int(bool(ly["relu"])), L.ptr(head["img"]), L.ptr(head["bias"]),
                                                                int(bool(head["relu"])), b, h, w, 128, head["cout"], L.ptr(maps),
                                                                ref, L.stream_ptr()), "conv2d_1x1_head_fused")

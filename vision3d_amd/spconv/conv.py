@@ -97,9 +97,9 @@ def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False
         with torch.cuda.device(feat.device):
             if prec == L.PREC_F16S:
                 entry = torch.empty(4, dtype=torch.float32, device=feat.device)
-                L.check(L.lib().v3d_act_scale_from_rows2(L.ptr(feat), None, feat.shape[0], cin, 0, L.ptr(entry),
+                L.check(L.lib().v3d_act_scale_from_rows(L.ptr(feat), None, feat.shape[0], cin, 0, L.ptr(entry),
                                                          L.ptr(L.scale_scratch(feat.device)), L.stream_ptr()), "act_scale_from_rows")
-            L.check(L.lib().v3d_sparse_conv_fwd_packed2(L.ptr(feat), L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k,
+            L.check(L.lib().v3d_sparse_conv_fwd_packed(L.ptr(feat), L.ptr(img), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k,
                                                         cin, cout, L.ptr(sc), L.ptr(sh), int(bool(relu)), L.ptr(out),
                                                         -int(variant) if variant else int(rb.n), prec, L.ptr(entry), None, None, None, None,
                                                         L.stream_ptr()), "sparse_conv_fwd_packed")
@@ -116,7 +116,7 @@ def pack_sparse_weight(w_flat, k, cin, cout, precision="bf16x3"):
     lib = L.lib()
     img = torch.empty(int(lib.v3d_sparse_conv_weight_image_bytes(k, cin, cout)), dtype=torch.uint8, device=w_flat.device)
     with torch.cuda.device(w_flat.device):
-        L.check(lib.v3d_sparse_conv_pack_weights2(L.ptr(w_flat), k, cin, cout, L.PRECISIONS[precision], L.ptr(img), L.stream_ptr()),
+        L.check(lib.v3d_sparse_conv_pack_weights(L.ptr(w_flat), k, cin, cout, L.PRECISIONS[precision], L.ptr(img), L.stream_ptr()),
                 "sparse_conv_pack_weights")
     return img
 
