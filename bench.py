@@ -227,6 +227,26 @@ def layer_algorithmic_bytes(stats):
         + 8 * stats["pairs"]
 
 
+def mfma_busy_from_profiles(run, kernel_substr, avg_us):
+    """Matrix-pipe occupancy of a kernel from the committed counter passes (profiles/pmc_mfma.json, tools/pmc_mfma.sh):
+    SQ_VALU_MFMA_BUSY_CYCLES per launch / (1 024 SIMDs x THIS run's launch duration x 2.4 GHz) -- counters cannot be read from inside
+    this process, and the durations under counter collection are inflated.  None when no counter record matches."""
+    path = os.path.join(REPO, "profiles", "pmc_mfma.json")
+    if not os.path.exists(path) or not avg_us:
+        return None
+    rec = json.load(open(path))
+    hits = [(k, v) for k, v in rec.get(run, {}).items() if kernel_substr in k]
+    if not hits:
+        return None
+    n = sum(v["launches"] for _, v in hits)
+    busy = sum(v["mfma_busy_cycles"] * v["launches"] for _, v in hits) / n
+    instr = sum((v.get("mfma_instructions") or 0.0) * v["launches"] for _, v in hits) / n
+    return dict(mfma_busy_cycles_per_launch=busy, mfma_instructions_per_launch=instr, launches_in_record=n,
+                mfma_busy_frac=busy / (1024.0 * avg_us * 1e-6 * 2.4e9), clock_assumed_ghz=2.4,
+                sustained_floor_us=instr / 1024.0 * 10e-3,  # 10 ns per instruction and SIMD on random operands (profiles/r06_mfma_chain.txt)
+                source=rec.get("source"))
+
+
 def train_main(args):
     """configs[2]: one optimiser step of SECOND per GPU batch; gradients all-reduced over RCCL in two buckets, the dense half's
     while the native sparse backward runs (dist_util.TwoPhaseGradReducer).
@@ -343,6 +363,13 @@ def train_main(args):
     roofline = cpu_baseline = None
     if rank == 0 and not args.no_roofline:
         roofline = train_roofline(bs) if amp else train_roofline_split(bs)
+        if roofline and bs == 8:  # (the counter passes were taken on the 8-frame step)
+            mc = mfma_busy_from_profiles("train", "dt_conv3_kernel" if amp else "conv2d_bf16x3_large_kernel<3, 9, 0>", roofline.get("avg_us"))
+            roofline["mfma_busy_frac"], roofline["mfma_counters"] = (mc or {}).get("mfma_busy_frac"), mc
+            if mc and amp and "dt_conv3_kernel" in "".join(json.load(open(os.path.join(REPO, "profiles", "pmc_mfma.json"))).get("train", {}).keys()):
+                rec = [v for k, v in json.load(open(os.path.join(REPO, "profiles", "pmc_mfma.json")))["train"].items() if "dt_conv3_kernel" in k][0]
+                roofline["traffic"] = (rec.get("fetch_bytes_x2") or 0.0) + (rec.get("write_bytes") or 0.0)
+                roofline["traffic_source"] = "profiles/r06_pmc_mfma.txt (FETCH_SIZE x2 + WRITE_SIZE per launch)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cpu_baseline = train_cpu_baseline(model, cfg, clouds[0], {k: v[:1] for k, v in tgt.items()}, args)
@@ -1259,6 +1286,8 @@ def forward_main(args):
                 in_frame = dict(avg_us=us, hbm_frac=dom_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                 mfma_frac_algorithmic=mfma_alg / (us * 1e-6) / 2500e12, calls=calls,
                                 source="profiles/" + os.path.basename(csv_path))
+        mfma_pmc = mfma_busy_from_profiles("waymo" if waymo else "kitti", "spconv_fwd_rows_kouter<64, 64" if kouter else "spconv_fwd_rows_ring<64, 64", dom_t * 1e6) \
+            if args.batch == 1 else None
         if t_mfma >= t_hbm:
             roofline = dict(bound="mfma", achieved=mfma_alg / dom_t / 1e12, peak=2500.0, unit="TFLOP/s", frac=mfma_alg / dom_t / 2500e12,
                             floor_us=t_mfma * 1e6)
@@ -1272,6 +1301,7 @@ def forward_main(args):
                         avg_us=dom_t * 1e6, avg_us_in_frame=in_frame["avg_us"] if in_frame else None,
                         frac_in_frame=(in_frame["mfma_frac_algorithmic" if t_mfma >= t_hbm else "hbm_frac"] if in_frame else None),
                         in_frame=in_frame, traffic=traffic, traffic_source=traffic_src, hbm_view=hbm_view, mfma_view=mfma_view,
+                        mfma_busy_frac=(mfma_pmc or {}).get("mfma_busy_frac"), mfma_counters=mfma_pmc,
                         bound_note=f"floor at 100 % of each roof: HBM {t_hbm * 1e6:.2f} us (A_min at 8 TB/s), matrix pipe {t_mfma * 1e6:.2f} us "
                                    "(3 bf16 terms x useful flops at 2.5 PFLOP/s); avg_us = isolated back-to-back launches of each layer, "
                                    "avg_us_in_frame = rocprofv3 average inside the one-frame-at-a-time graph")
@@ -1350,6 +1380,7 @@ def forward_main(args):
                 avg_us=t_launch * 1e6, avg_us_source=("profiles/" + os.path.basename(csv_d) + " (in the frame)") if in_frame_us else "dense head of this frame / 7 launches",
                 dense_head_us_this_frame=head_us, issued=issued_fl / t_launch / 1e12, achieved=issued_fl / 3.0 / t_launch / 1e12, peak=2500.0, unit="TFLOP/s",
                 frac_issued=issued_fl / t_launch / 1e12 / 2500.0, frac=issued_fl / 3.0 / t_launch / 1e12 / 2500.0,
+                mfma_counters=mfma_busy_from_profiles("waymo" if waymo else "kitti", "conv2d_bf16x3_tile2d_kernel", t_launch * 1e6) if args.batch == 1 else None,
                 sustained_peak_measured=dict(zero_operands=2200.0, random_operands=1650.0, source="profiles/r06_mfma_chain.txt (tools/mb_mfma_chain.hip: "
                                              "nothing but v_mfma_f32_16x16x32_f16 on all 256 CUs: 7.5 / 9.4-10.3 ns per instruction and SIMD)"),
                 note="one live tile per CU and launch: the launch lasts one tile's chain (occupancy test, 64-request neighbourhood load, "

@@ -15,7 +15,7 @@ cd "$R"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf "$R/gpurun_out/pmc_$c"
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_$c" -o p -- \
-    python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-fast-mode --no-h2d --windows 1 $EXTRA > "$R/gpurun_out/pmc_$c.log" 2>&1
+    python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-fast-mode --no-h2d --no-extra --windows 1 $EXTRA > "$R/gpurun_out/pmc_$c.log" 2>&1
   echo "pmc $c rc=$?"
 done
 SUF=""

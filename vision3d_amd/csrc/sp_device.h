@@ -130,15 +130,29 @@ __device__ __forceinline__ void sp_store_split(unsigned short* __restrict__ out_
 //          execute in order); v[j][rr]: the finished values; nv: rows of the tile that exist (rows >= nv are not stored).
 #define SP_STAGE_STRIDE(COUT) ((COUT) * 4 + 16)
 #define SP_STAGE_BYTES(COUT) (16 * SP_STAGE_STRIDE(COUT))
-template <int COUT>
-__device__ __forceinline__ void sp_stage_flush(const unsigned char* stage, unsigned char* __restrict__ dst_tile, const int nv, const int lane) {
+// NT = threads that flush together (64: a wave's private block; a workgroup's size: a block shared behind a barrier), t = the caller's index in them
+template <int COUT, int NT = 64>
+__device__ __forceinline__ void sp_stage_flush(const unsigned char* stage, unsigned char* __restrict__ dst_tile, const int nv, const int t) {
   constexpr int ROWB = COUT * 4, CPR = ROWB / 16;  // bytes and 16-byte chunks per row
 #pragma unroll
-  for (int i = 0; i < (16 * CPR + 63) / 64; i++) {
-    const int ch = i * 64 + lane, row = ch / CPR, wc = ch % CPR;
+  for (int i = 0; i < (16 * CPR + NT - 1) / NT; i++) {
+    const int ch = i * NT + t, row = ch / CPR, wc = ch % CPR;
     if (ch < 16 * CPR && row < nv)
       *reinterpret_cast<uint4*>(dst_tile + (size_t)row * ROWB + wc * 16) = *reinterpret_cast<const uint4*>(stage + row * SP_STAGE_STRIDE(COUT) + wc * 16);
   }
+}
+// one value D[rowi][col] into a staging block: as fp32 / as its half of a split pair (lanes r, r ^ 1 hold neighbouring columns of the
+// same row: every lane of the pair must call this)
+template <int COUT>
+__device__ __forceinline__ void sp_stage_put_f32(unsigned char* stage, const int rowi, const int col, const float v) {
+  *reinterpret_cast<float*>(stage + rowi * SP_STAGE_STRIDE(COUT) + col * 4) = v;
+}
+template <int PREC, int COUT>
+__device__ __forceinline__ void sp_stage_put_split(unsigned char* stage, const int rowi, const int col, const int r, const float v, const float s) {
+  const float pv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
+  unsigned h, l;
+  sp_split_pair<PREC>((r & 1) ? pv : v, (r & 1) ? v : pv, s, h, l);
+  *reinterpret_cast<unsigned*>(stage + rowi * SP_STAGE_STRIDE(COUT) + ((r & 1) ? COUT * 2 : 0) + (col & ~1) * 2) = (r & 1) ? l : h;
 }
 // fp32 rows (cap, COUT): out_tile = first row of the tile
 template <int COUT, int NB>
@@ -148,8 +162,7 @@ __device__ __forceinline__ void sp_tile_store_f32(unsigned char* stage, float* _
 #pragma unroll
   for (int j = 0; j < NB; j++)
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++)
-      *reinterpret_cast<float*>(stage + (kg * 4 + rr) * SP_STAGE_STRIDE(COUT) + (j * 16 + r) * 4) = v[j][rr];
+    for (int rr = 0; rr < 4; rr++) sp_stage_put_f32<COUT>(stage, kg * 4 + rr, j * 16 + r, v[j][rr]);
   sp_stage_flush<COUT>(stage, reinterpret_cast<unsigned char*>(out_tile), nv, lane);
 }
 // split rows (cap, 2 * COUT) 16-bit = [hi: COUT | lo: COUT] under the consumer's scale `s` (sp_store_split's bytes)
@@ -160,12 +173,7 @@ __device__ __forceinline__ void sp_tile_store_split(unsigned char* stage, unsign
 #pragma unroll
   for (int j = 0; j < NB; j++)
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-      const float pv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[j][rr]), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
-      unsigned h, l;
-      sp_split_pair<PREC>((r & 1) ? pv : v[j][rr], (r & 1) ? v[j][rr] : pv, s, h, l);
-      *reinterpret_cast<unsigned*>(stage + (kg * 4 + rr) * SP_STAGE_STRIDE(COUT) + ((r & 1) ? COUT * 2 : 0) + ((j * 16 + r) & ~1) * 2) = (r & 1) ? l : h;
-    }
+    for (int rr = 0; rr < 4; rr++) sp_stage_put_split<PREC, COUT>(stage, kg * 4 + rr, j * 16 + r, r, v[j][rr], s);
   sp_stage_flush<COUT>(stage, reinterpret_cast<unsigned char*>(out_s_tile), nv, lane);
 }
 

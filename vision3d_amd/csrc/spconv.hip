@@ -611,10 +611,14 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
   __syncthreads();
   SPR_STAMP(13);
 
-  // epilogue: wave w finishes column blocks j = w, w + NW, ...;  D[row = kg*4 + rr][col = r]
+  // epilogue: wave w finishes column blocks j = w, w + NW, ...;  D[row = kg*4 + rr][col = r].  The 16 rows of the tile are one
+  // contiguous block of the output arrays: the finished values meet in two staging blocks behind the partial sums (fp32 rows,
+  // split rows) and leave as whole 16-byte pieces of consecutive rows (sp_device.h "epilogue stores ... COALESCED through LDS").
   float vmax = 0.f;
   // f16s: planes / split rows hold the pieces of v * (the consumer's scale)
   const float s_next = (PREC == 1 && (dn.hi || out_s)) ? as.next[0] : 1.f;
+  unsigned char* stg_f = reinterpret_cast<unsigned char*>(nbr_s + K * 16);
+  unsigned char* stg_s = stg_f + SP_STAGE_BYTES(COUT);
   for (int j = wave; j < NB; j += NW) {
     const int col = j * 16 + r;
     // (f16s: the power-of-two factor that undoes the operand scales rides in the BatchNorm scale: exact)
@@ -625,12 +629,12 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
 #pragma unroll
       for (int w = 1; w < NW; w++) v += part[((w * NB + j) * 4 + rr) * 64 + lane];
       const int row = row0 + kg * 4 + rr;
+      if (scale || PREC == 1) v = v * sc + sh;
+      if (relu) v = fmaxf(v, 0.f);
+      if (out) sp_stage_put_f32<COUT>(stg_f, kg * 4 + rr, col, v);
+      if (out_s) sp_stage_put_split<PREC, COUT>(stg_s, kg * 4 + rr, col, r, v, s_next);
       if (row < n) {
-        if (scale || PREC == 1) v = v * sc + sh;
-        if (relu) v = fmaxf(v, 0.f);
         if constexpr (PREC == 1) vmax = fmaxf(vmax, fabsf(v));
-        if (out) out[(size_t)row * COUT + col] = v;
-        if (out_s) sp_store_split<PREC, COUT>(out_s, row, col, r, v, s_next);
         if (dn.hi) {  // .dense() of the last layer: the row straight into the split BEV planes (see V3dDensifyOut)
           const int4 c = reinterpret_cast<const int4*>(dn.coords)[row];
           const int pixel = (c.x * dn.H + c.z) * dn.W + c.w;
@@ -646,6 +650,12 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
         }
       }
     }
+  }
+  if (out || out_s) {  // (workgroup-uniform)
+    __syncthreads();
+    const int nv = min(16, n - row0);
+    if (out) sp_stage_flush<COUT, V3D_BLOCK>(stg_f, reinterpret_cast<unsigned char*>(out + (size_t)row0 * COUT), nv, tid);
+    if (out_s) sp_stage_flush<COUT, V3D_BLOCK>(stg_s, reinterpret_cast<unsigned char*>(out_s + (size_t)row0 * (2 * COUT)), nv, tid);
   }
   if constexpr (PREC == 1) sp_range_check(as, vmax, ss.limit);
   SPR_STAMP(14);
@@ -1479,7 +1489,7 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
       return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, sl);
     }
   }
-  const size_t lds = (size_t)4 * (COUT / 16) * 4 * 64 * 4 + (size_t)K * 16 * 4;
+  const size_t lds = (size_t)4 * (COUT / 16) * 4 * 64 * 4 + (size_t)K * 16 * 4 + 2 * SP_STAGE_BYTES(COUT);  // partial sums | indices | staging
   hipLaunchKernelGGL((spconv_fwd_rows<CIN, COUT, PREC, INS>), dim3(v3d_ceil_div(cap, 16)), dim3(V3D_BLOCK), lds, st,
                      INS ? (const float*)sl.in_split : in, (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out,
                      densify ? *densify : V3dDensifyOut{}, sl.as, sl.out_split);
