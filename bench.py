@@ -930,42 +930,44 @@ def _arm_watchdog(limit_s):
 
 # ---- the other BASELINE configurations on the driver's clock: compact sub-lines of the default run --------------------------------
 EXTRA_RUNS = [  # (key, what, argv of a short run of that mode)
+    ("pvrcnn_stage2", "BASELINE configs[3]: PV-RCNN stage 2 on SECOND proposals", ["--mode", "pvrcnn", "--windows", "5", "--steps", "20", "--warmup", "5"]),
     ("waymo", "BASELINE configs[4]: SECOND forward, 180 k-pt Waymo-range sweep, 3 frames in flight",
      ["--workload", "waymo", "--pipeline", "3", "--windows", "5", "--steps", "60", "--warmup", "10", "--single-frames", "40", "--stream", "4"]),
     ("kitti_bs8", "SECOND forward, batch of 8 KITTI clouds per step (65-110 k rows per sparse stage: the large-layer kernels), 2 batches in flight",
      ["--batch", "8", "--pipeline", "2", "--windows", "5", "--steps", "30", "--warmup", "5", "--single-frames", "20", "--stream", "2"]),
     ("plumbing", "BASELINE configs[0]: voxelize + points_in_boxes, one 16 k-pt cloud", ["--mode", "plumbing", "--windows", "5", "--steps", "100"]),
-    ("pvrcnn_stage2", "BASELINE configs[3]: PV-RCNN stage 2 on SECOND proposals", ["--mode", "pvrcnn", "--windows", "5", "--steps", "20", "--warmup", "5"]),
     ("train", "BASELINE configs[2]: SECOND train step bf16, 8 frames per GPU", ["--mode", "train", "--steps", "6", "--warmup", "2"]),
 ]
 
 
 def run_extras():
-    """-> {key: compact line} -- every entry a short IN-PROCESS run of bench.py's own mode (same code path as the full line of that
-    mode, fewer windows, no CPU baseline, no bf16x3 / H2D side lines); never raises."""
-    import contextlib
-    import io
+    """-> {key: compact line} -- every entry a short run of bench.py's own mode in a FRESH process (same code path as the full line of
+    that mode, fewer windows, no CPU baseline, no bf16x3 / H2D side lines); never raises.  A fresh process because the in-process
+    form measured the process's history, not the configuration: which hardware queues a new HIP stream lands on depends on the
+    streams created before it (the Waymo-range line read 1 168 frames/s as the first extra and 972 behind the PV-RCNN one), and the
+    host-bound PV-RCNN line halves behind a run that left the interpreter a large heap."""
+    import subprocess
     out = {}
     for key, what, argv in EXTRA_RUNS:
         t0 = time.perf_counter()
         try:
-            a = parse(argv + ["--no-cpu-baseline", "--no-fast-mode", "--no-h2d", "--no-extra", "--watchdog", "0"])
-            buf = io.StringIO()
-            with contextlib.redirect_stdout(buf):
-                {"forward": forward_main, "train": train_main, "pvrcnn": pvrcnn_main, "plumbing": plumbing_main}[a.mode](a)
-            d = json.loads([ln for ln in buf.getvalue().strip().splitlines() if ln.startswith("{")][-1])
+            cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--no-cpu-baseline", "--no-fast-mode", "--no-h2d", "--no-extra", "--watchdog", "240"]
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            lines = [ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")]
+            if res.returncode != 0 or not lines:
+                raise RuntimeError(f"rc {res.returncode}: {res.stderr.strip()[-200:]}")
+            d = json.loads(lines[-1])
             r = d.get("roofline") or {}
             out[key] = dict(what=what, metric=d.get("metric"), value=d.get("value"), unit=d.get("unit"), ms_per_step=d.get("ms_per_step"),
                             single_frame_ms=d.get("single_frame_ms"), steps=d.get("steps"), windows=d.get("windows"),
                             workload=(d.get("config") or {}).get("workload"),
                             roofline=dict(kernel=r.get("kernel"), bound=r.get("bound"), frac=r.get("frac"), achieved=r.get("achieved"), unit=r.get("unit"),
                                           avg_us=r.get("avg_us"), avg_us_in_frame=r.get("avg_us_in_frame"), frac_in_frame=r.get("frac_in_frame"),
-                                          hbm_frac=(r.get("hbm_view") or {}).get("frac"), traffic=r.get("traffic")) if r else None,
+                                          hbm_frac=(r.get("hbm_view") or {}).get("frac"), traffic=r.get("traffic"),
+                                          mfma_busy_frac=r.get("mfma_busy_frac")) if r else None,
                             seconds=round(time.perf_counter() - t0, 1))
-        except BaseException as e:  # (SystemExit of an argument check included): a reported extra, never the bench line's fate
+        except BaseException as e:  # a reported extra, never the bench line's fate
             out[key] = dict(what=what, value=None, error=f"{type(e).__name__}: {str(e)[:200]}", seconds=round(time.perf_counter() - t0, 1))
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
     return out
 
 
@@ -1505,6 +1507,8 @@ def forward_main(args):
                     n_proposals=int(out[0].shape[0]))
         if world == 1 and not waymo and args.batch == 1 and not args.no_extra:
             del graphed
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
             line["extra"] = run_extras()
         print(json.dumps(line))
     if world > 1:
