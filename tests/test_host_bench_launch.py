@@ -66,3 +66,27 @@ def test_numa_pinning_reads_the_topology_and_degrades_quietly(bench, tmp_path, m
     assert bench.numa_cpus_of_gpu(0, sysfs=str(tmp_path / "missing")) is None
     monkeypatch.delenv("V3D_BENCH_PIN", raising=False)
     assert bench.pin_rank_to_gpu_numa(0, 1) is None  # single-rank jobs are left alone
+
+
+def test_extra_sub_lines_are_valid_short_runs_of_the_other_configurations(bench):
+    """The default run's `extra` object (round 6: the other BASELINE configurations on the driver's clock): every entry's argv parses,
+    names a mode bench.py has, and stays a SHORT run; the keys are the ones the round's review asked for."""
+    keys = [k for k, _, _ in bench.EXTRA_RUNS]
+    assert {"waymo", "plumbing", "pvrcnn_stage2"} <= set(keys) and len(keys) == len(set(keys))
+    for key, what, argv in bench.EXTRA_RUNS:
+        a = bench.parse(argv + ["--no-cpu-baseline", "--no-fast-mode", "--no-h2d", "--no-extra", "--watchdog", "240"])
+        assert a.mode in ("forward", "train", "pvrcnn", "plumbing") and a.no_extra and a.no_cpu_baseline
+        assert a.steps <= 100 and a.gpus == 1, key
+        assert "configs[" in what or "batch of 8" in what
+
+
+def test_counter_summaries_attach_to_the_roofline_objects(bench):
+    """bench.mfma_busy_from_profiles reads the committed counter passes (profiles/pmc_mfma.json) and divides the busy cycles by the
+    CALLER's launch duration; unknown kernels / runs give None."""
+    m = bench.mfma_busy_from_profiles("kitti", "conv2d_bf16x3_tile2d_kernel", 20.4)
+    assert m is not None and 0.1 < m["mfma_busy_frac"] < 0.5 and m["mfma_instructions_per_launch"] > 1e5
+    assert abs(m["mfma_busy_cycles_per_launch"] / m["mfma_instructions_per_launch"] - 16.0) < 0.01  # the 4-pass 16x16x32 instruction
+    assert bench.mfma_busy_from_profiles("kitti", "no_such_kernel", 10.0) is None
+    assert bench.mfma_busy_from_profiles("kitti", "conv2d_bf16x3_tile2d_kernel", None) is None
+    k = bench.mfma_busy_from_profiles("waymo", "spconv_fwd_rows_kouter<64, 64", 47.0)
+    assert k is not None and 20.0 < k["sustained_floor_us"] < 30.0  # 2 600 MFMAs per SIMD at 10 ns

@@ -45,3 +45,22 @@ def test_degenerate_sizes():
     assert choose_streams(lambda ids: 1.0, 1, 4) == ([0], {})
     chosen, log = choose_streams(lambda ids: 1.0 / len(ids), 2, 4)
     assert chosen == [0, 1] and set(log) == {2}
+
+
+def test_weight_change_epoch_is_one_integer_the_graph_runners_compare():
+    """Second.notify_weights_changed (round 6): bumped by load_state_dict and by every train() / eval() switch, so that a
+    captured-graph runner compares ONE integer per launch instead of ~120 parameter version counters."""
+    import torch
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.detector import Second
+    m = Second(second_car_cfg())
+    e0 = m._weights_epoch
+    m.eval()
+    e1 = m._weights_epoch
+    m.load_state_dict(m.state_dict())
+    e2 = m._weights_epoch
+    m.notify_weights_changed()
+    assert e0 < e1 < e2 < m._weights_epoch
+    with torch.no_grad():
+        m.head.conv_cls.bias.add_(1.0)  # an in-place edit alone is NOT noticed by the counter (documented): the caller notifies
+    assert m._weights_epoch == e2 + 1
