@@ -1023,6 +1023,14 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
 // 64-channel halves of 126 pixel rows x 128 B, chunk p of pixel row hp at chunk p ^ (hp & 7) (every ds_read_b128 lane group
 // covers the bank row once, for every tap alignment); the nine taps read their fragments from it at immediate offsets of eight
 // per-lane bases, the weights come straight from L2 as before, and there is no barrier between the taps.
+// FOUR waves (round 6; rounds 4-5: 4 matrix + 4 loader waves, 84 KB): every wave requests a quarter of the image (16 LDS-DMA
+// instructions), then multiplies its 32 output channels -- the loaders' only job was those 16 requests, yet as waves of the
+// same kernel they held 256 VGPRs each and, with the LDS padded past half a CU, the workgroup owned the CU: one live tile per
+// CU and launch at 0.23 matrix-pipe occupancy, and no other frame's tile beside it.  At 256 threads x 256 VGPRs and 64 KB (the
+// image; the epilogue tile reuses it) TWO workgroups share a CU -- with frames in flight the tiles of two frames' launches: one's
+// occupancy test, image load and epilogue under the other's matrix phase.  Same bits (the summation order of an output is
+// unchanged).  Same box: 3 750 -> 4 090 frames/s pipelined (bs = 1), one frame at a time 0.478 -> 0.483 ms (the epilogue's
+// stores on half the threads); Waymo-range 1 148 -> 1 218, bs = 8 5 870 -> 6 580 frames/s.
 // ------------------------------------------------------------------------------------------------
 #define D2_TH 5
 #define D2_TW 16
@@ -1032,18 +1040,19 @@ __device__ __forceinline__ void dl_tile(unsigned char* smem_l, const bf16_t* __r
 #define D2_HALF (D2_PIECES * 1024)
 #define D2_PLANE (2 * D2_HALF)
 static_assert(2 * D2_PLANE <= dl_smem(D2_TH), "the neighbourhood image lives in the tile kernel's LDS request");
+static_assert(D2_TH * 16 * DL_TS * 4 <= 2 * D2_PLANE, "the epilogue tile reuses the image's LDS");
+#define D2_THREADS 256
 // Returns true (workgroup-uniform) when the tile was LIVE and the workgroup's next tile has already been drawn into *s_next: the
-// draw -- an atomic round trip of ~1.5 us -- is issued behind the matrix phase by one thread of a loader wave and travels while the
+// draw -- an atomic round trip of ~1.5 us -- is issued behind the matrix phase by one thread and travels while the
 // epilogue stores, instead of standing between this tile's last store and the next tile.  (Asking at the START of a live tile hands
 // tiles to workgroups that stay busy for 15 us: 21 -> 32 us; at this point the workgroup is one epilogue away from being free.)
 template <int PREC>
 __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* __restrict__ x_hi, const bf16_t* __restrict__ x_lo,
                                           const bf16_t* __restrict__ w_img, const float* __restrict__ bias, const DcParams& p,
                                           bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo, const int mtile, int* s_next) {
-  constexpr int MT = D2_TH, BM = MT * 16;
+  constexpr int MT = D2_TH, BM = MT * 16, NT = D2_THREADS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = wave >= 4;
   const int tx_n = (p.W + D2_TW - 1) / D2_TW, ty_n = (p.H + D2_TH - 1) / D2_TH;
   const int b = mtile / (ty_n * tx_n), rt = mtile - b * ty_n * tx_n;
   const int y0 = (rt / tx_n) * D2_TH, x0 = (rt % tx_n) * D2_TW;
@@ -1069,7 +1078,7 @@ __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* _
         if (tid == 0) p.tile_state[mtile] = 0u;
       }
       const int parts = p.cout_store >> 3;
-      for (int q = tid; q < BM * parts; q += DL_THREADS) {
+      for (int q = tid; q < BM * parts; q += NT) {
         const int row = q / parts, part = q - row * parts;
         const int yy = y0 + (row >> 4), xx = x0 + (row & 15);
         if (yy >= p.H || xx >= p.W) continue;
@@ -1088,9 +1097,9 @@ __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* _
     acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  if (loader) {
-    // loader lw brings (plane lw & 1, half lw >> 1): 16 requests of 8 pixel rows x 128 B, zero rows outside the image
-    const int lw = wave - 4, plane = lw & 1, half = lw >> 1;
+  {
+    // wave w brings (plane w & 1, half w >> 1) of the image: 16 requests of 8 pixel rows x 128 B, zero rows outside the image
+    const int plane = wave & 1, half = wave >> 1;
     const int sub = lane >> 3, slot = lane & 7;
     const bf16_t* xp = plane ? x_lo : x_hi;
     typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -1106,8 +1115,8 @@ __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* _
       const bf16_t* src = ok ? xp + (((size_t)b * p.H + yy) * p.W + xx) * p.Cin + part * 8 : reinterpret_cast<const bf16_t*>(dl_zero16);
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dstb + j * 1024), 16, 0, 0);
     }
-    __syncthreads();  // image complete (the compiler waits for the requests in front of the barrier)
-  } else {
+  }
+  {
     // ---- matrix role: as dl_tile (4 waves side by side along Cout, B fragments straight from L2), A fragments from the image
     const size_t plane_elems = (size_t)(p.CoutPad / 16) * 4 * 16 * 8;
     u32x4 cb[DL_SS][4];
@@ -1183,9 +1192,9 @@ __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* _
       static_assert(NSTEP == 10, "the steps are written out");
     };
 #pragma unroll
-    for (int ss = 0; ss < DL_SS; ss++) load_b(ss);
+    for (int ss = 0; ss < DL_SS; ss++) load_b(ss);  // (behind the image requests: the barrier waits for both)
     tapn = 1;
-    __syncthreads();  // image complete
+    __syncthreads();  // image complete (the compiler waits for the requests in front of the barrier)
     multiply(D2_IC(0)); tapn = 2;
     multiply(D2_IC(1)); tapn = 3;
     multiply(D2_IC(2)); tapn = 4;
@@ -1200,7 +1209,7 @@ __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* _
   __syncthreads();  // every fragment read is behind us: the image's LDS becomes the epilogue tile
   const bool draws = s_next != nullptr && p.work != nullptr;
   unsigned drawn = 0u;
-  if (draws && tid == 4 * 64) drawn = gridDim.x + atomicAdd(p.work, 1u);  // the next tile, requested now (see the header)
+  if (draws && tid == 0) drawn = gridDim.x + atomicAdd(p.work, 1u);  // the next tile, requested now (see the header)
   // ---- epilogue (all 8 waves): accumulators -> LDS tile [80 px][128 + 4] fp32 -> bias + ReLU -> split planes
   const DcScales sc = dc_scales<PREC>(p);
   float vmax = 0.f;
@@ -1213,20 +1222,18 @@ __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* _
       eb1 = *reinterpret_cast<const f32x4*>(bias + co + 4);
     }
   }
-  if (!loader) {
 #pragma unroll
-    for (int i = 0; i < MT; i++)
+  for (int i = 0; i < MT; i++)
 #pragma unroll
-      for (int j = 0; j < 2; j++)
+    for (int j = 0; j < 2; j++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) tile[(i * 16 + (lane >> 4) * 4 + r) * DL_TS + wave * 32 + j * 16 + (lane & 15)] = acc[i][j][r];
-  }
+      for (int r = 0; r < 4; r++) tile[(i * 16 + (lane >> 4) * 4 + r) * DL_TS + wave * 32 + j * 16 + (lane & 15)] = acc[i][j][r];
   __syncthreads();
   const int c8 = tid & 15, co = c8 * 8;
   if (co < p.cout_store) {
 #pragma unroll
-    for (int k = 0; k < (BM + 31) / 32; k++) {
-      const int row = (tid >> 4) + 32 * k;
+    for (int k = 0; k < (BM + NT / 16 - 1) / (NT / 16); k++) {
+      const int row = (tid >> 4) + (NT / 16) * k;
       const int yy = y0 + (row >> 4), xx = x0 + (row & 15);
       if (row < BM && yy < p.H && xx < p.W) {
         const size_t m = ((size_t)b * p.H + yy) * p.W + xx;
@@ -1255,13 +1262,13 @@ __device__ __forceinline__ bool dl_tile2d(unsigned char* smem_l, const bf16_t* _
     }
   }
   if constexpr (PREC == 1) dc_range_check(p, vmax, sc.limit);
-  if (draws && tid == 4 * 64) *s_next = (int)drawn;
+  if (draws && tid == 0) *s_next = (int)drawn;
   return draws;
 }
 
 // persistent grid drawing 2-D tiles from the counter pair (see conv2d_bf16x3_large_kernel)
 template <int PREC>
-__global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_tile2d_kernel(const bf16_t* __restrict__ x_hi, const bf16_t* __restrict__ x_lo,
+__global__ __launch_bounds__(D2_THREADS, 2) void conv2d_bf16x3_tile2d_kernel(const bf16_t* __restrict__ x_hi, const bf16_t* __restrict__ x_lo,
                                                                           const bf16_t* __restrict__ w_img, const float* __restrict__ bias,
                                                                           const DcParams p, bf16_t* __restrict__ y_hi,
                                                                           bf16_t* __restrict__ y_lo) {
@@ -1273,7 +1280,7 @@ __global__ __launch_bounds__(DL_THREADS) void conv2d_bf16x3_tile2d_kernel(const 
   // (requesting the NEXT draw before the current tile starts hides the counter's round trip but hands tiles to workgroups
   // that are busy with a live one: 21.0 -> 32.4 us on the real frame)
   if (p.reset_ptr && blockIdx.x == 0)
-    for (int i = threadIdx.x; i < p.reset_words; i += DL_THREADS) p.reset_ptr[i] = 0u;
+    for (int i = threadIdx.x; i < p.reset_words; i += D2_THREADS) p.reset_ptr[i] = 0u;
   for (int mtile = blockIdx.x; mtile < ntiles;) {  // workgroup-uniform
     const bool drew = dl_tile2d<PREC>(smem_l, x_hi, x_lo, w_img, bias, p, y_hi, y_lo, mtile, &s_next);
     if (!drew && threadIdx.x == 0) s_next = (int)(gridDim.x + atomicAdd(p.work, 1u));
@@ -1609,8 +1616,8 @@ static int dc_launch(const void* x_hi, const void* x_lo, const void* weight_imag
   const bool large_ok = Cin >= 64 && H < 32768 && W < 65536 && W >= 16;  // (Cin % 32 == 0 checked by the caller) else: the 64-pixel kernel
   if (large_ok && Cout > 32) {
     // With background skipping (and a work counter) the tiles are 80 pixels instead of 144 and the grid is persistent, one
-    // workgroup per CU drawing tiles from the counter: see the kernel.  The LDS request is padded past half a CU's LDS so that
-    // two workgroups never share a CU.
+    // workgroup per CU drawing tiles from the counter: see the kernel.  The 80-pixel kernel's LDS request is padded past half a
+    // CU's LDS so that two of ITS workgroups never share a CU (the 2-D tile kernel below shares on purpose).
     const int n_cu = v3d_device_cu_count();
     if (n_cu < 1) return V3D_EINVAL;
     const bool persistent = p.occ && work && p.CoutPad == DC_BN;
@@ -1620,12 +1627,16 @@ static int dc_launch(const void* x_hi, const void* x_lo, const void* weight_imag
       p.reset_ptr = reset_ptr;
       p.reset_words = reset_words;
       const int tiles2 = B * v3d_ceil_div(H, D2_TH) * v3d_ceil_div(W, D2_TW);
-      const int smem2 = std::max(dl_smem(D2_TH), 84 * 1024);
+      // Four waves per workgroup, 64 KB of LDS and <= 256 VGPRs: TWO workgroups fit a CU (see the kernel's header).  The grid stays one
+      // workgroup per CU while the live tiles are fewer than the CUs (KITTI bs = 1: 146-201 of 440 tiles -- a second resident
+      // workgroup would only pair live tiles on one CU; the co-resident is another FRAME's launch); from 4 tiles per CU on (a batch,
+      // the Waymo-range map) two per CU: one tile's test / image load / epilogue runs under the other's matrix phase (bs = 8:
+      // 1.84 -> 1.68 ms per batch, 6 420 -> 6 580 frames/s pipelined)
+      const int smem2 = 2 * D2_PLANE;
       static V3dPerDeviceFlag attr2;
       V3D_CHECK_HIP(v3d_set_max_lds(attr2, (const void*)conv2d_bf16x3_tile2d_kernel<PREC>, smem2));
-      // (persistent grid on fewer CUs, leaving the rest to other frames' kernels: 192 workgroups +1.8 % pipelined, +3.7 % latency;
-      //  128 neutral, +15 % latency -- profiles/r04_dense_grid.txt; not adopted)
-      hipLaunchKernelGGL(conv2d_bf16x3_tile2d_kernel<PREC>, dim3(std::min(tiles2, n_cu)), dim3(DL_THREADS), smem2, st, (const bf16_t*)x_hi,
+      const int per_cu = tiles2 >= 4 * n_cu ? 2 : 1;
+      hipLaunchKernelGGL(conv2d_bf16x3_tile2d_kernel<PREC>, dim3(std::min(tiles2, n_cu * per_cu)), dim3(D2_THREADS), smem2, st, (const bf16_t*)x_hi,
                          (const bf16_t*)x_lo, (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo);
       V3D_CHECK_LAUNCH();
       return V3D_OK;

@@ -1468,7 +1468,9 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
     if (K == 27 && (force == 10 || force == 16 || (force >= 12 && force <= 14) || (force == 0 && rows_hint <= V3D_RING_ROWS))) {
       // (measured and not kept: two offsets per round + two weight buffers + register gathers = 69 KB of LDS at 64 -> 64, so that
       // two such workgroups -- the same layer of another frame in flight -- or one and an 80-pixel dense tile could share a CU:
-      // 12.9 vs 10.0 us in isolation and 3 121 vs 3 306 frames/s pipelined)
+      // 12.9 vs 10.0 us in isolation and 3 121 vs 3 306 frames/s pipelined; measured again in round 6 beside the four-wave dense tile
+      // kernel, which DOES leave it half a CU -- <64, 64, 2, 2, 4, 1, 1, 2>: 85 KB, 8 waves x 106 VGPRs -- 3 710-3 730 vs 4 075-4 120
+      // frames/s, and another summation order (two partial sums per output instead of three))
       if constexpr (CIN == 64 && COUT == 64) {
         if (force != 16) {
           // one LDS-filling workgroup per CU: keep the layer inside ONE round of 256 workgroups.  The live count is device-side and
