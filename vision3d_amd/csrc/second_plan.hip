@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "v3d_internal.h"
+#include "rb_device.h"
 
 struct PlanLayer {
   v3d_layer_desc d;
@@ -74,6 +75,11 @@ struct v3d_backbone {
   void *bev_hi = nullptr, *bev_lo = nullptr;
   int32_t *bev_pix = nullptr, *bev_pix_n = nullptr;
   int ring_tiles_min = 2;  // v3d_backbone_set_throughput_mode: 4
+#ifdef V3D_EXP_NO_RIDERS  // (A/B builds: tools/build_variant.sh)
+  bool rb_riders = false;
+#else
+  bool rb_riders = true;   // inference forwards: rulebook steps ride in the sparse layers' launches (PlanRbQueue)
+#endif
   // Arithmetic of the packed layers in the INFERENCE entry points (the training plan always runs bf16x3): v3d_backbone_set_precision.
   // f16s reads one scale entry {s, 1/s, limit, max} per tensor from act_tab: entry l = the rows layer l gathers, entry n_layers =
   // the BEV map (scale of the split planes the last layer / the densify kernel writes).  Entries start as {1, 1, 2^15}: valid
@@ -517,8 +523,27 @@ static bool plan_next_strided(v3d_backbone* p, size_t l, int stage, std::vector<
   return false;
 }
 
+// The rulebook chain of a frame as a QUEUE of steps (rb_device.h RbStep) instead of launches: it depends on coordinates only, so
+// the inference forward builds the whole queue first and lets a sparse layer's launch carry the next pending SCAN as its first
+// workgroups -- the chain runs ahead of the convolutions and the scans (4 of a KITTI frame's 38 launches, ~9 us of dependent round
+// trips each) disappear under them.  rb_step[rulebook] = the step whose completion the table needs (-1: launched directly).  A fill,
+// a scan no launch carried in time, and whatever must precede a direct launch are launched on their own -- the order of the
+// steps never changes.
+struct PlanRbQueue {
+  std::vector<RbStep> steps;
+  std::vector<int> rb_step;
+  size_t launched = 0;
+};
+static int plan_rb_flush(PlanRbQueue& q, int upto /*last step index that must have been launched; -1: none*/, hipStream_t st) {
+  while ((int)q.launched <= upto && q.launched < q.steps.size()) {
+    const int rc = v3d_i_rb_step_launch(q.steps[q.launched++], st);
+    if (rc) return rc;
+  }
+  return V3D_OK;
+}
+
 static int plan_layer_rulebook(v3d_backbone* p, size_t l, std::vector<char>& rb_done, bool& hash0_done, hipStream_t st,
-                               std::vector<char>* cand_done = nullptr) {
+                               std::vector<char>* cand_done = nullptr, PlanRbQueue* defer = nullptr) {
   PlanLayer& L = p->layers[l];
   if (!L.builds_rulebook || rb_done[l]) return V3D_OK;
   PlanStage& si = p->stages[L.stage_in];
@@ -526,6 +551,10 @@ static int plan_layer_rulebook(v3d_backbone* p, size_t l, std::vector<char>& rb_
   int rc;
   V3dRbCandNext nx;
   if (L.d.subm) {
+    if (defer) {  // a direct launch: everything queued so far comes first
+      rc = plan_rb_flush(*defer, (int)defer->steps.size() - 1, st);
+      if (rc) return rc;
+    }
     if (!si.hash_ready_by_sparse && !(L.stage_in == 0 && hash0_done)) {
       rc = v3d_i_hash_build(si.coords, si.n_dev, si.cap, si.shape, si.hash, 0, st);
       if (rc) return rc;
@@ -538,6 +567,26 @@ static int plan_layer_rulebook(v3d_backbone* p, size_t l, std::vector<char>& rb_
                     p->layers[l + 1].stage_in == L.stage_out;
   const int mine_done = cand_done && (*cand_done)[l];
   const bool carry = plan_next_strided(p, l, L.stage_out, cand_done, nx);
+  if (defer && mine_done) {
+    RbStep scan, fill;
+    rc = v3d_i_sparse_rulebook_steps(si.coords, si.n_dev, si.cap, si.shape, L.d.ksize, L.d.stride, L.d.padding, so.coords, so.n_dev, so.cap,
+                                     p->nbr[L.rulebook], p->overflow + l, so.hash, so.first_ticket, p->cand_slot[L.cand_buf], L.chunk_counts,
+                                     fuse ? p->layers[l + 1].d.ksize : nullptr, fuse ? p->nbr[p->layers[l + 1].rulebook] : nullptr,
+                                     p->overflow + p->layers.size(), carry ? &nx : nullptr, 1, &scan, &fill);
+    if (rc) return rc;
+    defer->steps.push_back(scan);
+    defer->steps.push_back(fill);
+    defer->rb_step[L.rulebook] = (int)defer->steps.size() - 1;
+    if (fuse) {
+      rb_done[l + 1] = 1;
+      defer->rb_step[p->layers[l + 1].rulebook] = (int)defer->steps.size() - 1;
+    }
+    return V3D_OK;
+  }
+  if (defer) {  // (its candidate pass is a launch of its own: direct, behind everything queued)
+    rc = plan_rb_flush(*defer, (int)defer->steps.size() - 1, st);
+    if (rc) return rc;
+  }
   rc = v3d_i_sparse_rulebook(si.coords, si.n_dev, si.cap, si.shape, L.d.ksize, L.d.stride, L.d.padding, so.coords, so.n_dev,
                              so.cap, p->nbr[L.rulebook], p->overflow + l, so.hash, so.first_ticket, p->cand_slot[L.cand_buf],
                              L.chunk_counts, nullptr, 0, fuse ? p->layers[l + 1].d.ksize : nullptr,
@@ -554,11 +603,13 @@ static int plan_layer_rulebook(v3d_backbone* p, size_t l, std::vector<char>& rb_
 static int plan_layer_conv(v3d_backbone* p, PlanLayer& L, const float* feat, const void* wimg, const float* weight,
                            const float* scale, const float* shift, int relu, float* out, hipStream_t st,
                            const V3dDensifyOut* densify = nullptr, bool* densified = nullptr, bool inference = false,
-                           const void** feat_split = nullptr /*in: the input rows' split copy or null; out: this layer's or null*/) {
+                           const void** feat_split = nullptr /*in: the input rows' split copy or null; out: this layer's or null*/,
+                           const RbScanJob* rider = nullptr, bool* rider_taken = nullptr /*a rulebook scan the launch may carry*/) {
   const v3d_backbone_config& c = p->cfg;
   PlanStage& so = p->stages[L.stage_out];
   int rc = V3D_EUNSUPPORTED;
   if (densified) *densified = false;
+  if (rider_taken) *rider_taken = false;
   const bool exact_pass = inference && p->calibrating;
   if (!exact_pass && (c.conv_algo == 4 || (c.conv_algo == 0 && L.d.cin >= 16))) {
     const int prec = inference ? p->prec : V3D_PREC_BF16X3;
@@ -582,7 +633,7 @@ static int plan_layer_conv(v3d_backbone* p, PlanLayer& L, const float* feat, con
     void* out_s = (feat_split && p->presplit && next_packed && (prec == V3D_PREC_F16S || !p->fp32_rows)) ? L.out_s : nullptr;
     if (out_s && !p->fp32_rows && !densify && v3d_i_sparse_conv_packed_supported(L.d.cin, L.d.cout)) out = nullptr;
     rc = v3d_i_sparse_conv_fwd_packed(feat, wimg, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout, scale, shift,
-                                      relu, out, L.rows_hint, st, densify, p->ring_tiles_min, prec, &as, in_s, out_s);
+                                      relu, out, L.rows_hint, st, densify, p->ring_tiles_min, prec, &as, in_s, out_s, rider, rider_taken);
     if (rc == V3D_OK && densify && densified) *densified = true;
     if (feat_split) *feat_split = rc == V3D_OK ? out_s : nullptr;
   } else if (feat_split) {
@@ -595,7 +646,7 @@ static int plan_layer_conv(v3d_backbone* p, PlanLayer& L, const float* feat, con
     rc = v3d_i_sparse_conv_fwd_exact(feat, weight, p->nbr[L.rulebook], so.n_dev, so.cap, L.K, L.d.cin, L.d.cout, scale, shift, relu,
                                      out, exact_pass ? 0 : ((c.conv_algo == 4 || c.conv_algo == 0) ? 3 : c.conv_algo), st,
                                      check ? p->act_tab + 4 * (l + 1) : nullptr, check ? p->overflow + p->layers.size() : nullptr,
-                                     check ? p->frame_max + l + 1 : nullptr);
+                                     check ? p->frame_max + l + 1 : nullptr, rider, rider_taken);
   }
   return rc;
 }
@@ -609,11 +660,32 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
   // the candidate pass of a strided layer rides in the launch that produces its input sites' last table (rulebook.hip RbCandJob)
   std::vector<char> cand_done(p->layers.size(), 0);
   bool densified = false;
+  // the whole rulebook chain as a queue of steps (see PlanRbQueue); what must be a launch of its own is launched here
+  PlanRbQueue rbq;
+  const bool riders = !reuse_rulebooks && p->rb_riders;
+  if (riders) {
+    rbq.rb_step.assign(p->nbr.size(), -1);
+    for (size_t l = 0; l < p->layers.size(); l++) {
+      rc = plan_layer_rulebook(p, l, rb_done, hash0_done, st, &cand_done, &rbq);
+      if (rc) return rc;
+    }
+  }
   for (size_t l = 0; l < p->layers.size(); l++) {
     PlanLayer& L = p->layers[l];
-    if (!reuse_rulebooks) {
+    if (!reuse_rulebooks && !riders) {
       rc = plan_layer_rulebook(p, l, rb_done, hash0_done, st, &cand_done);
       if (rc) return rc;
+    }
+    const RbScanJob* rider = nullptr;
+    bool rider_taken = false;
+    if (riders) {  // this layer's table first, and a pending fill (a launch of its own); then the next scan rides in this layer's launch
+      rc = plan_rb_flush(rbq, rbq.rb_step[L.rulebook], st);
+      if (rc) return rc;
+      if (rbq.launched < rbq.steps.size() && rbq.steps[rbq.launched].kind == 2) {
+        rc = plan_rb_flush(rbq, (int)rbq.launched, st);
+        if (rc) return rc;
+      }
+      if (rbq.launched < rbq.steps.size() && rbq.steps[rbq.launched].kind == 1) rider = &rbq.steps[rbq.launched].scan;
     }
     // the LAST layer writes the plan's own BEV planes from its epilogue (.dense() without a launch of its own) where it runs the
     // 16-row kernel anyway: not 3x3x3 (the SECOND backbone ends in a (3, 1, 1) layer) and below the 64-row kernel's row counts
@@ -625,9 +697,14 @@ static int plan_run_layers(v3d_backbone* p, int B, bool hash0_done, float* dense
       dn = V3dDensifyOut{sl.coords, sl.shape[0], sl.shape[1], sl.shape[2], p->bev_hi, p->bev_lo, p->bev_occ, p->bev_pix, p->bev_pix_n};
     }
     rc = plan_layer_conv(p, L, feat, L.wimg, L.weight, L.has_affine ? L.scale : nullptr, L.has_affine ? L.shift : nullptr,
-                         L.d.relu, L.out, st, want_dn ? &dn : nullptr, &densified, true, &feat_split);
+                         L.d.relu, L.out, st, want_dn ? &dn : nullptr, &densified, true, &feat_split, rider, &rider_taken);
     if (rc) return rc;
+    if (rider_taken) rbq.launched++;
     feat = L.out;
+  }
+  if (riders) {
+    rc = plan_rb_flush(rbq, (int)rbq.steps.size() - 1, st);
+    if (rc) return rc;
   }
   if (dense_out) {
     PlanStage& sl = p->stages.back();

@@ -14,6 +14,17 @@
 #include "v3d_internal.h"
 
 #include "sp_device.h"
+#include "rb_device.h"
+
+// A rulebook scan riding at the front of a sparse layer's grid (rb_device.h RbScanJob): the first rider.blocks workgroups run it on
+// their first V3D_BLOCK threads and `lds` (>= RB_SCAN_LDS bytes of the kernel's LDS), the others are the layer's own, renumbered.
+#define SP_RIDER_PROLOGUE(lds)                                                                        \
+  if (rider.blocks && (int)blockIdx.x < rider.blocks) {                                               \
+    if (threadIdx.x < V3D_BLOCK) rb_rider_run(rider, (int)blockIdx.x, (unsigned char*)(lds));         \
+    return;                                                                                           \
+  }                                                                                                   \
+  const int bid = (int)blockIdx.x - rider.blocks;                                                     \
+  [[maybe_unused]] const int nblk = (int)gridDim.x - rider.blocks;
 
 
 // The library has no process-global state: kernel variants are chosen from the arguments of each call (rows_hint; a
@@ -73,7 +84,8 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
                                                                        const float* __restrict__ scale,
                                                                        const float* __restrict__ shift, int relu,
                                                                        float* __restrict__ out, const float* __restrict__ next_entry,
-                                                                       int* __restrict__ range_flag, unsigned* __restrict__ seen) {
+                                                                       int* __restrict__ range_flag, unsigned* __restrict__ seen,
+                                                                       const RbScanJob rider) {
   constexpr int NB = COUT / 16;
   constexpr int G = SPW_WAVES / NB;
   constexpr int T = CIN / 4;  // MFMA steps; also floats of one row held per lane
@@ -83,9 +95,10 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
   int* list_in = (int*)(acc + G * SPC_TM * COUT);         // [K][64]
   int* cnt_pad = list_in + K * SPC_TM;                    // [K]
   unsigned char* list_row = (unsigned char*)(cnt_pad + K);  // [K][64]
+  SP_RIDER_PROLOGUE(smem)
 
   const int n = min(*n_ptr, cap);
-  const int row0 = blockIdx.x * SPC_TM;
+  const int row0 = bid * SPC_TM;
   if (row0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -251,12 +264,14 @@ __global__ __launch_bounds__(SPW_WAVES* V3D_WAVE) void spconv_fwd_wave(const flo
 template <int CIN, int COUT>
 static int launch_wave(const float* in, const float* W, const int* nbr, const int* n_ptr, int cap, int K,
                        const float* scale, const float* shift, int relu, float* out, hipStream_t st, const float* next_entry,
-                       int* range_flag, unsigned* seen) {
+                       int* range_flag, unsigned* seen, const RbScanJob* rider, bool* rider_taken) {
   constexpr int G = SPW_WAVES / (COUT / 16);
-  const size_t lds = (size_t)G * SPC_TM * COUT * 4 + (size_t)K * SPC_TM * 4 + (size_t)K * 4 + (size_t)K * SPC_TM + 64;
+  const size_t lds = std::max((size_t)G * SPC_TM * COUT * 4 + (size_t)K * SPC_TM * 4 + (size_t)K * 4 + (size_t)K * SPC_TM + 64, (size_t)RB_SCAN_LDS);
   if (lds > 64 * 1024) return V3D_EUNSUPPORTED;
-  hipLaunchKernelGGL((spconv_fwd_wave<CIN, COUT>), dim3(v3d_ceil_div(cap, SPC_TM)), dim3(SPW_WAVES * V3D_WAVE), lds, st,
-                     in, W, nbr, n_ptr, cap, K, scale, shift, relu, out, next_entry, range_flag, seen);
+  const RbScanJob r = rider ? *rider : RbScanJob{};
+  hipLaunchKernelGGL((spconv_fwd_wave<CIN, COUT>), dim3(v3d_ceil_div(cap, SPC_TM) + r.blocks), dim3(SPW_WAVES * V3D_WAVE), lds, st,
+                     in, W, nbr, n_ptr, cap, K, scale, shift, relu, out, next_entry, range_flag, seen, r);
+  if (rider_taken) *rider_taken = r.blocks > 0;
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -498,7 +513,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
                                                              int cap, int K, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, int relu,
                                                              float* __restrict__ out, const V3dDensifyOut dn, const V3dActScale as,
-                                                             unsigned short* __restrict__ out_s) {
+                                                             unsigned short* __restrict__ out_s, const RbScanJob rider) {
   // workgroup = 16 output rows; its 4 waves split the K kernel offsets (wave w takes k = w, w+4, ...), keep
   // private register accumulators and meet ONCE, in the epilogue, where the 4 partial tiles are summed in a
   // fixed order (deterministic).  4x more waves in flight and a 4x shorter dependent chain per wave than one
@@ -509,17 +524,18 @@ __global__ __launch_bounds__(V3D_BLOCK) void spconv_fwd_rows(const float* __rest
   extern __shared__ __attribute__((aligned(16))) float smem_rows[];
   float* part = smem_rows;                                  // [NW][NB][4][64] partial accumulators
   int* nbr_s = (int*)(part + NW * NB * 4 * 64);             // [K][16]
+  SP_RIDER_PROLOGUE(smem_rows)
   const int n = min(*n_ptr, cap);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int wg = blockIdx.x;
+  int wg = bid;
   {
     // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (private L2s);
     // remap the LIVE tiles so that each XCD walks one contiguous run of rows -- the rows a tile gathers are mostly
     // its neighbours', which then sit in that XCD's L2 instead of being fetched by all eight (64->64 at 36 k rows:
     // 53 -> 48 us; neutral at 8 k).
     const int nwg = (n + 15) / 16;
-    if (dn.hi && blockIdx.x == 0 && tid == 0) *dn.pix_n = n;  // (before the early exit: an EMPTY frame lists no pixels)
+    if (dn.hi && bid == 0 && tid == 0) *dn.pix_n = n;  // (before the early exit: an EMPTY frame lists no pixels)
     if (wg >= nwg) return;
     const int q = nwg / 8, rmd = nwg % 8, xcd = wg % 8, idx = wg / 8;
     wg = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;  // bijective on [0, nwg)
@@ -1100,7 +1116,8 @@ template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK, int STAGE, in
 __device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, const unsigned short* __restrict__ wimg,
                                                  const int* __restrict__ nbr, const int n, int cap, const float* __restrict__ scale,
                                                  const float* __restrict__ shift, int relu, float* __restrict__ out, const int wg_in,
-                                                 const SpScales& ss, float& vmax, unsigned short* __restrict__ out_s, const float s_next) {
+                                                 const SpScales& ss, float& vmax, unsigned short* __restrict__ out_s, const float s_next,
+                                                 unsigned char* __restrict__ wb0 /*round buffer 0: the kernel's (a rider block's scratch)*/) {
   // OG = offsets per round = multiplying waves per tile.  OG = 3: 9 rounds, 3 round buffers, 6 + 2 waves.
   // OG = 2: 14 rounds (the 28th offset is a zero row), 4 round buffers (three rounds of weights in flight), 4 + 2
   // waves -- one multiplying wave per SIMD.  Measured slower (64->64 at 8 160 rows: 12.3 vs 13.0 us): the cost of a round
@@ -1119,7 +1136,6 @@ __device__ __forceinline__ void spconv_ring_body(const float* __restrict__ in, c
   static_assert(CIN % 32 == 0 && CIN <= 128 && (OG * NF) % NMV == 0 && (LOOK - 1) * FPM < 64, "shape not covered by the ring kernel");
   static_assert(RB >= TILES * OG * NB * 4 * 64 * 4, "partials must fit one round buffer");
   static_assert(ALOOK >= 1 && ALOOK <= 4 && (ALOOK * KI * 2 <= 8 || ALOOK * KI * 2 == 12 || ALOOK * KI * 2 == 16), "gather look-ahead");
-  __shared__ __attribute__((aligned(16))) unsigned char wb0[RB];
   __shared__ __attribute__((aligned(16))) unsigned char wb1[RB];
   __shared__ __attribute__((aligned(16))) unsigned char wb2[NBUF >= 3 ? RB : 16];
   __shared__ __attribute__((aligned(16))) unsigned char wb3[NBUF == 4 ? RB : 16];
@@ -1356,16 +1372,22 @@ __global__ __launch_bounds__((TILES * OG + NMV) * 64) void spconv_fwd_rows_ring(
                                                                           const float* __restrict__ scale,
                                                                           const float* __restrict__ shift, int relu,
                                                                           float* __restrict__ out, const V3dActScale as,
-                                                                          unsigned short* __restrict__ out_s) {
+                                                                          unsigned short* __restrict__ out_s, const RbScanJob rider) {
+  // round buffer 0 of the body lives here: a rider block uses it as its scratch (a buffer of its own would take the 32 -> 32 shape
+  // from three workgroups per CU to two)
+  constexpr int RB0 = OG * (CIN / 32) * (COUT / 16) * 2 * 1024;
+  static_assert(RB0 >= RB_SCAN_LDS, "a rider's scratch fits round buffer 0");
+  __shared__ __attribute__((aligned(16))) unsigned char wb0[RB0];
+  SP_RIDER_PROLOGUE(wb0)
   const int n = min(*n_ptr, cap);
   const int nwg = (n + 16 * TILES - 1) / (16 * TILES);
   const SpScales ss = sp_scales<PREC>(as, wimg, (size_t)27 * (CIN / 32) * (COUT / 16) * 2 * 512);
   const float s_next = (PREC == 1 && out_s) ? as.next[0] : 1.f;
   float vmax = 0.f;
   // (the XCD-contiguous remap inside the body is a bijection of [0, nwg) for ANY set of indices below nwg)
-  for (int g = blockIdx.x; g < nwg; g += gridDim.x) {
+  for (int g = bid; g < nwg; g += nblk) {
     spconv_ring_body<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, PREC, INS>(in, wimg, nbr, n, cap, scale, shift, relu, out, g, ss, vmax,
-                                                                              out_s, s_next);
+                                                                              out_s, s_next, wb0);
     __syncthreads();  // the next group's weight DMA and partial sums reuse this group's LDS
   }
   if constexpr (PREC == 1) sp_range_check(as, vmax, ss.limit);
@@ -1378,7 +1400,16 @@ struct SpLaunch {
   V3dActScale as;
   const void* in_split;
   unsigned short* out_split;
+  const RbScanJob* rider;  // nullable: a rulebook scan the launch may carry (kernels that can: *rider_taken = true)
+  bool* rider_taken;
 };
+
+// What a ring launch carries: its rider blocks take a workgroup slot each (up to 16 waves, 50-154 KB of LDS), most of them leave
+// at once (one block per chunk of the CAPACITY; the live chunks are a fraction) -- a 64 -> 64 workgroup owns a CU: few blocks only.
+static RbScanJob sp_ring_rider(const SpLaunch& sl, int max_blocks) {
+  if (!sl.rider || sl.rider->blocks > max_blocks) return RbScanJob{};
+  return *sl.rider;
+}
 
 template <int CIN, int COUT, int OG, int NBUF, int NMV, int ALOOK, int STAGE, int TILES, int PREC, int INS>
 static int launch_rows_ring_p(const float* in, const void* wimg, const int* nbr, const int* n_ptr, int cap,
@@ -1395,10 +1426,13 @@ static int launch_rows_ring_p(const float* in, const void* wimg, const int* nbr,
                                                                (TILES * OG + NMV) * 64, 0));
     *slots = std::max(8, per_cu * n_cu / 8 * 8);
   }
-  const int grid = std::min(v3d_ceil_div(cap, 16 * TILES), *slots);
-  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, PREC, INS>), dim3(grid),
+  // (rider blocks take a workgroup slot each: a 64 -> 64 workgroup owns a CU, so few of them; the lighter shapes hold 2-3 per CU)
+  const RbScanJob r = sp_ring_rider(sl, CIN == 64 && COUT == 64 ? 32 : 512);
+  const int grid = std::min(v3d_ceil_div(cap, 16 * TILES), std::max(*slots - r.blocks, 8));
+  hipLaunchKernelGGL((spconv_fwd_rows_ring<CIN, COUT, OG, NBUF, NMV, ALOOK, STAGE, TILES, PREC, INS>), dim3(grid + r.blocks),
                      dim3((TILES * OG + NMV) * 64), 0, st, INS ? (const float*)sl.in_split : in, (const unsigned short*)wimg, nbr, n_ptr, cap,
-                     scale, shift, relu, out, sl.as, sl.out_split);
+                     scale, shift, relu, out, sl.as, sl.out_split, r);
+  if (sl.rider_taken) *sl.rider_taken = r.blocks > 0;
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -1491,10 +1525,13 @@ static int launch_rows(const float* in, const void* wimg, const int* nbr, const 
       return launch_rows_ring<CIN, COUT, 3, 3, 2>(in, wimg, nbr, n_ptr, cap, scale, shift, relu, out, st, sl);
     }
   }
-  const size_t lds = (size_t)4 * (COUT / 16) * 4 * 64 * 4 + (size_t)K * 16 * 4 + 2 * SP_STAGE_BYTES(COUT);  // partial sums | indices | staging
-  hipLaunchKernelGGL((spconv_fwd_rows<CIN, COUT, PREC, INS>), dim3(v3d_ceil_div(cap, 16)), dim3(V3D_BLOCK), lds, st,
+  const size_t lds = std::max((size_t)4 * (COUT / 16) * 4 * 64 * 4 + (size_t)K * 16 * 4 + 2 * SP_STAGE_BYTES(COUT),  // partial sums | indices | staging
+                              (size_t)RB_SCAN_LDS);
+  const RbScanJob r = sl.rider ? *sl.rider : RbScanJob{};
+  hipLaunchKernelGGL((spconv_fwd_rows<CIN, COUT, PREC, INS>), dim3(v3d_ceil_div(cap, 16) + r.blocks), dim3(V3D_BLOCK), lds, st,
                      INS ? (const float*)sl.in_split : in, (const unsigned short*)wimg, nbr, n_ptr, cap, K, scale, shift, relu, out,
-                     densify ? *densify : V3dDensifyOut{}, sl.as, sl.out_split);
+                     densify ? *densify : V3dDensifyOut{}, sl.as, sl.out_split, r);
+  if (sl.rider_taken) *sl.rider_taken = r.blocks > 0;
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }
@@ -1552,7 +1589,9 @@ bool v3d_i_sparse_conv_packed_supported(int Cin, int Cout) {
 int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, const int32_t* nbr, const int32_t* n_out,
                                  int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift, int relu,
                                  float* out, int rows_hint, hipStream_t st, const V3dDensifyOut* densify, int ring_tiles_min,
-                                 int prec, const V3dActScale* act, const void* in_split, void* out_split) {
+                                 int prec, const V3dActScale* act, const void* in_split, void* out_split, const RbScanJob* rider,
+                                 bool* rider_taken) {
+  if (rider_taken) *rider_taken = false;
   if (!in || !weight_image || !nbr || !n_out || (!out && !out_split) || cap_out < 1 || K < 1) return V3D_EINVAL;  // (out may be NULL
   // when only the split copy of the rows is wanted: a plan in throughput mode, whose intermediate fp32 rows nobody reads)
   if ((scale == nullptr) != (shift == nullptr)) return V3D_EINVAL;
@@ -1565,6 +1604,8 @@ int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, cons
   sl.as = (prec == V3D_PREC_F16S) ? *act : V3dActScale{nullptr, nullptr, nullptr, nullptr};
   sl.in_split = in_split;
   sl.out_split = (unsigned short*)out_split;
+  sl.rider = rider;
+  sl.rider_taken = rider_taken;
 #define V3D_GO(ci, co, P, I) \
   return launch_rows<ci, co, P, I>(in, weight_image, nbr, n_out, cap_out, K, scale, shift, relu, out, rows_hint, st, densify, ring_tiles_min, sl)
 #define V3D_TRY(ci, co)                                    \
@@ -1596,19 +1637,21 @@ extern "C" int v3d_sparse_conv_fwd(const float* in, const float* weight, const i
                                    int cap_out, int K, int Cin, int Cout, const float* scale, const float* shift,
                                    int relu, float* out, int algo, v3d_stream_t stream) {
   return v3d_i_sparse_conv_fwd_exact(in, weight, nbr, n_out, cap_out, K, Cin, Cout, scale, shift, relu, out, algo, (hipStream_t)stream,
-                                     nullptr, nullptr, nullptr);
+                                     nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 int v3d_i_sparse_conv_fwd_exact(const float* in, const float* weight, const int32_t* nbr, const int32_t* n_out, int cap_out, int K,
                                 int Cin, int Cout, const float* scale, const float* shift, int relu, float* out, int algo,
-                                hipStream_t st, const float* next_entry, int32_t* range_flag, unsigned* seen) {
+                                hipStream_t st, const float* next_entry, int32_t* range_flag, unsigned* seen, const RbScanJob* rider,
+                                bool* rider_taken) {
+  if (rider_taken) *rider_taken = false;
   if (!in || !weight || !nbr || !n_out || !out || cap_out < 1 || K < 1 || Cin < 1 || Cout < 1) return V3D_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return V3D_EINVAL;
   if (algo != 0 && algo != 1 && algo != 3) return V3D_EINVAL;  // (2 was an LDS-staged fp32 kernel: removed)
   if (algo == 0 || algo == 3) {
     int rc = V3D_EUNSUPPORTED;
 #define V3D_TRY(ci, co) \
-  if (Cin == ci && Cout == co) rc = launch_wave<ci, co>(in, weight, nbr, n_out, cap_out, K, scale, shift, relu, out, st, next_entry, range_flag, seen);
+  if (Cin == ci && Cout == co) rc = launch_wave<ci, co>(in, weight, nbr, n_out, cap_out, K, scale, shift, relu, out, st, next_entry, range_flag, seen, rider, rider_taken);
     V3D_TRY(4, 16)
     V3D_TRY(16, 16)
     V3D_TRY(16, 32)

@@ -2,6 +2,8 @@
 #pragma once
 #include "v3d_common.h"
 
+struct RbScanJob;  // rb_device.h
+struct RbStep;
 struct V3dRbHash {
   v3d_key_t* keys;
   int* vals;
@@ -45,6 +47,17 @@ int v3d_i_sparse_rulebook(const int32_t* coords_in, const int32_t* n_in, int cap
                           const V3dRbCandNext* next = nullptr /*carry the NEXT strided layer's candidate pass in the last launch*/,
                           int init_columns = 0 /*the emit pass writes -1 into the table columns of the sites it creates: the table then
                           needs no -1 fill (clear = 0 callers that do not pre-fill it)*/);
+
+// The same two steps as descriptors (rb_device.h RbStep) instead of launches: a plan hands the scans to the sparse layers' launches,
+// which run them as their first workgroups (the rulebook chain depends on coordinates only and runs ahead of the convolutions), and
+// launches the others with v3d_i_rb_step_launch.
+int v3d_i_sparse_rulebook_steps(const int32_t* coords_in, const int32_t* n_in, int cap_in, const int32_t* shape,
+                                const int32_t* ksize, const int32_t* stride, const int32_t* padding, int32_t* coords_out,
+                                int32_t* n_out, int cap_out, int32_t* nbr, int32_t* overflow, V3dRbHash out,
+                                unsigned* first_ticket, int* cand_slot, int* chunk_counts, const int32_t* next_subm_ksize,
+                                int32_t* next_subm_nbr, int32_t* overflow_any, const V3dRbCandNext* next, int init_columns,
+                                RbStep* scan, RbStep* fill);
+int v3d_i_rb_step_launch(const RbStep& s, hipStream_t st);
 
 // iou_nms.hip: mask + greedy reduction on boxes already sorted by (score desc, index asc) and prepped (BoxPrep rows)
 int v3d_i_nms_sorted(const void* prep_sorted, const int* order, int N, float iou_threshold, int64_t* keep, int32_t* n_keep,
@@ -97,7 +110,9 @@ int v3d_i_sparse_conv_fwd_packed(const float* in, const void* weight_image, cons
                                  act->in (row = [hi: Cin x 16 bit | lo: Cin x 16 bit]): what an earlier call wrote through out_split;
                                  the main loop then has no conversion work*/,
                                  void* out_split = nullptr /*besides `out`: the output rows split under act->next (f16s) for the next
-                                 packed layer, (cap_out, 2 * Cout) 16-bit*/);
+                                 packed layer, (cap_out, 2 * Cout) 16-bit*/,
+                                 const RbScanJob* rider = nullptr /*a rulebook scan the launch may carry as its first workgroups*/,
+                                 bool* rider_taken = nullptr /*set when it did (the 16-row and the ring kernels)*/);
 
 // brick.hip: tables of a submanifold rulebook over spatially ordered rows (a plan in brick order), per pass of 256 output rows:
 // the distinct input rows it touches, the neighbour table translated into slots of that list, per-tile offset masks.
@@ -119,7 +134,8 @@ bool v3d_i_sparse_conv_packed_supported(int Cin, int Cout);
 // entry of the tensor it produces (wave kernel only; both nullable)
 int v3d_i_sparse_conv_fwd_exact(const float* in, const float* weight, const int32_t* nbr, const int32_t* n_out, int cap_out, int K,
                                 int Cin, int Cout, const float* scale, const float* shift, int relu, float* out, int algo,
-                                hipStream_t st, const float* next_entry, int32_t* range_flag, unsigned* seen = nullptr);
+                                hipStream_t st, const float* next_entry, int32_t* range_flag, unsigned* seen = nullptr,
+                                const RbScanJob* rider = nullptr, bool* rider_taken = nullptr /*as above (the wave kernel)*/);
 
 // spconv.hip: several packed weight images in one launch (mode 0: W (K, Cin, Cout); 1 / 2: the transposed layer of a source
 // (K, Cout, Cin), 2 with the offsets reversed)

@@ -190,7 +190,7 @@ class PipelinedSecond(object):
         dev = next(model.parameters()).device
         self.slots = [GraphedSecond(model, anchors, frame_sizes, slot=i) for i in range(depth + 1)]
         for g in self.slots:  # frames of different slots share the GPU: kernels chosen for CU-time, not for the shortest launch
-            g.plan.set_throughput_mode(True)
+            g.plan.set_throughput_mode(__import__('os').environ.get('V3D_EXP_NO_TPUT') != '1')
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
         self.autotune, self.tuned = bool(autotune), None
         self.pending = []  # (slot, stream index) in submission order
