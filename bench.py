@@ -935,10 +935,10 @@ def _arm_watchdog(limit_s):
 # ---- the other BASELINE configurations on the driver's clock: compact sub-lines of the default run --------------------------------
 EXTRA_RUNS = [  # (key, what, argv of a short run of that mode)
     ("pvrcnn_stage2", "BASELINE configs[3]: PV-RCNN stage 2 on SECOND proposals", ["--mode", "pvrcnn", "--windows", "5", "--steps", "20", "--warmup", "5"]),
-    ("waymo", "BASELINE configs[4]: SECOND forward, 180 k-pt Waymo-range sweep, 3 frames in flight",
-     ["--workload", "waymo", "--pipeline", "3", "--windows", "5", "--steps", "60", "--warmup", "10", "--single-frames", "40", "--stream", "4"]),
-    ("kitti_bs8", "SECOND forward, batch of 8 KITTI clouds per step (65-110 k rows per sparse stage: the large-layer kernels), 2 batches in flight",
-     ["--batch", "8", "--pipeline", "2", "--windows", "5", "--steps", "30", "--warmup", "5", "--single-frames", "20", "--stream", "2"]),
+    ("waymo", "BASELINE configs[4]: SECOND forward, 180 k-pt Waymo-range sweep, frames in flight as the headline (streams and depth by measurement)",
+     ["--workload", "waymo", "--windows", "5", "--steps", "60", "--warmup", "10", "--single-frames", "40", "--stream", "4"]),
+    ("kitti_bs8", "SECOND forward, batch of 8 KITTI clouds per step (65-110 k rows per sparse stage: the large-layer kernels), batches in flight as the headline",
+     ["--batch", "8", "--windows", "5", "--steps", "30", "--warmup", "5", "--single-frames", "20", "--stream", "2"]),
     ("plumbing", "BASELINE configs[0]: voxelize + points_in_boxes, one 16 k-pt cloud", ["--mode", "plumbing", "--windows", "5", "--steps", "100"]),
     ("train", "BASELINE configs[2]: SECOND train step bf16, 8 frames per GPU", ["--mode", "train", "--steps", "6", "--warmup", "2"]),
 ]
@@ -1389,8 +1389,10 @@ def forward_main(args):
                 mfma_counters=mfma_busy_from_profiles("waymo" if waymo else "kitti", "conv2d_bf16x3_tile2d_kernel", t_launch * 1e6) if args.batch == 1 else None,
                 sustained_peak_measured=dict(zero_operands=2200.0, random_operands=1650.0, source="profiles/r06_mfma_chain.txt (tools/mb_mfma_chain.hip: "
                                              "nothing but v_mfma_f32_16x16x32_f16 on all 256 CUs: 7.5 / 9.4-10.3 ns per instruction and SIMD)"),
-                note="one live tile per CU and launch: the launch lasts one tile's chain (occupancy test, 64-request neighbourhood load, "
-                     "1 080 MFMAs per SIMD ~ 9-10 us at the sustained rate, epilogue); CUs without a live tile idle -- live_tiles_mean of 256")
+                note="one frame at a time: one live tile per CU and launch, the launch lasts one tile's chain (occupancy test, 64-request "
+                     "neighbourhood load, 1 080 MFMAs per SIMD ~ 9-10 us at the sustained rate, epilogue) and CUs without a live tile idle "
+                     "-- live_tiles_mean of 256.  The workgroup is 4 waves x 256 VGPRs + 64 KB of LDS (round 6), so with frames in flight "
+                     "the tiles of two frames' launches share a CU (`value`: 3 750 -> 4 090 frames/s on one box)")
         except Exception as e:  # a reported extra
             roofline_dense["error"] = f"{type(e).__name__}: {str(e)[:200]}"
         tot_bytes = sum(l["bytes"] for l in layers)

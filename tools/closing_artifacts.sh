@@ -2,14 +2,14 @@
 # every BASELINE.json configuration with their rocprofv3 kernel statistics, the one-frame kernel sequences, the pipeline overlap
 # trace and the HBM-traffic counter passes of the dominant sparse kernels.  Output: gpurun_out/closing_$ROUND/ ; afterwards, in the
 # build container:  ROUND=r06 bash tools/closing_artifacts.sh copy   puts the summaries under profiles/ (tracked).
-ROUND=${ROUND:-r06}
+ROUND=${ROUND:-r06}; SET=${SET:-c}  # SET: letter of the closing set under profiles/ (r06_c_*: mid-round, r06_d_*: final tree)
 if [ "${1:-}" = "copy" ]; then
   O=gpurun_out/closing_$ROUND
-  for f in bench bench_driver_form waymo train train_fp32_script pvrcnn pvrcnn_e2e plumbing; do [ -s $O/$f.json ] && cp $O/$f.json profiles/${ROUND}_c_${f}.json; done
+  for f in bench bench_driver_form waymo train train_fp32_script pvrcnn pvrcnn_e2e plumbing; do [ -s $O/$f.json ] && cp $O/$f.json profiles/${ROUND}_${SET}_${f}.json; done
   for f in kernel_stats one_frame_at_a_time_kernel_stats waymo_kernel_stats waymo_one_frame_at_a_time_kernel_stats train_kernel_stats pvrcnn_stage2_kernel_stats pvrcnn_e2e_kernel_stats; do
-    [ -s $O/$f.csv ] && cp $O/$f.csv profiles/${ROUND}_c_${f}.csv
+    [ -s $O/$f.csv ] && cp $O/$f.csv profiles/${ROUND}_${SET}_${f}.csv
   done
-  for f in trace_overlap trace_sequence waymo_trace_sequence; do [ -s $O/$f.txt ] && cp $O/$f.txt profiles/${ROUND}_c_${f}.txt; done
+  for f in trace_overlap trace_sequence waymo_trace_sequence; do [ -s $O/$f.txt ] && cp $O/$f.txt profiles/${ROUND}_${SET}_${f}.txt; done
   [ -s $O/one_frame_at_a_time_kernel_stats.csv ] && cp $O/one_frame_at_a_time_kernel_stats.csv profiles/in_frame_kernel_stats.csv
   [ -s $O/waymo_one_frame_at_a_time_kernel_stats.csv ] && cp $O/waymo_one_frame_at_a_time_kernel_stats.csv profiles/in_frame_kernel_stats_waymo.csv
   [ -s gpurun_out/pmc_traffic.txt ] && cp gpurun_out/pmc_traffic.txt profiles/${ROUND}_pmc_traffic.txt && cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
