@@ -1502,8 +1502,10 @@ def forward_main(args):
                                 distinct_frames_in_timed_loop=N_STREAM,
                                 parallelism=f"frame-parallel replicas x{world}", host_pinning=pinning, pipeline_depth=(graphed.depth if pipelined else 1),
                                 pipeline_tuning=(graphed.tuned if pipelined else None),
+                                frames_queued_per_stream=(graphed.QUEUE if pipelined else 1),
                                 path={"graph": "native backbone plan + split-precision MFMA dense head + device proposal stage, one HIP graph per "
-                                               "frame" + (f", {graphed.depth} frames in flight" if pipelined else ""),
+                                               "frame" + (f", {graphed.depth} frames executing on {graphed.depth} streams, the next frame of each stream "
+                                                          f"queued behind it ({graphed.capacity} submitted, results collected in order)" if pipelined else ""),
                                       "native": "native backbone plan + split-precision MFMA dense head",
                                       "eager": "eager python -> C ABI"}[args.path]),
                     **spread, with_h2d=with_h2d, n_ranks_seen=n_ranks_seen,

@@ -31,6 +31,10 @@ class GraphedSecond(object):
         self.dense = model.dense_plan()
         # this slot's tile counters (self-resetting), persistent RPN planes and tile states
         self.work = self.dense.new_state(dev) if model.skip_background else None
+        # the frame's two result words (proposal count, summary flag): pinned host memory the LAST kernel of the graph writes itself
+        self.host_out = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self.done = torch.cuda.Event()  # recorded behind every launch: the frame is waited for through it, not through its stream
+                                        # (PipelinedSecond queues the next frame of a stream behind it)
         self.graph = None  # captured on the first call, after a warm-up on THAT frame (see _capture)
 
     def _capture(self):
@@ -60,7 +64,7 @@ class GraphedSecond(object):
                                   work=self.work, in_entry=self.plan.bev_entry(), range_flag=self.plan.overflow_any())
         self.native = head.native_supported(len(self.frame_sizes), self.anchors.numel() // (7 * self.model.cfg.NUM_CLASSES))
         if self.native:
-            return head.native_proposals(maps, self.anchors, self.plan.overflow_any())
+            return head.native_proposals(maps, self.anchors, self.plan.overflow_any(), host_out=self.host_out)
         return head.proposals_padded(*head.maps_from_fused(maps), self.anchors)
 
     def load(self, clouds):
@@ -95,6 +99,7 @@ class GraphedSecond(object):
             self._capture()
             self._seen_epoch = self.model.__dict__.get("_weights_epoch", 0)
         self.graph.replay()
+        self.done.record()
 
     def replay(self):
         self.launch()
@@ -103,7 +108,7 @@ class GraphedSecond(object):
     def _finalize(self):
         head = self.model.head
         if self.native:
-            return head.finalize_native(*self.outputs, overflow_flag=self.plan.overflow_any())
+            return head.finalize_native(*self.outputs, overflow_flag=self.plan.overflow_any(), done=self.done)
         out = head.finalize(*self.outputs)
         if self.plan.f16s:
             self.plan.check_overflow()
@@ -128,6 +133,7 @@ class GraphedSecond(object):
             for g in (self,) + tuple(peers):
                 g.after_recalibration()
             self.graph.replay()
+            self.done.record()
             return self._finalize()
 
     def after_recalibration(self):
@@ -185,10 +191,12 @@ class PipelinedSecond(object):
 
     CANDIDATE_STREAMS = 8
     TUNE_FRAMES = 8
+    QUEUE = 2  # frames queued per stream (see `capacity`; 3 measured slower: 4 390 vs 4 770 frames/s, 1: 4 180)
 
     def __init__(self, model, anchors, frame_sizes, depth=2, autotune=False):
         dev = next(model.parameters()).device
-        self.slots = [GraphedSecond(model, anchors, frame_sizes, slot=i) for i in range(depth + 1)]
+        self.max_depth = depth
+        self.slots = [GraphedSecond(model, anchors, frame_sizes, slot=i) for i in range(depth * self.QUEUE + 1)]
         for g in self.slots:  # frames of different slots share the GPU: kernels chosen for CU-time, not for the shortest launch
             g.plan.set_throughput_mode(__import__('os').environ.get('V3D_EXP_NO_TPUT') != '1')
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
@@ -199,6 +207,15 @@ class PipelinedSecond(object):
     @property
     def depth(self):
         return len(self.streams)
+
+    @property
+    def capacity(self):
+        """Frames submitted and not yet collected: QUEUE per stream.  Only `depth` of them EXECUTE at a time (more streams than that
+        lose: the hardware runs four queues side by side, a fifth stream is time-sliced -- tune() measures it); the second frame of a
+        stream is already enqueued when the first finishes, so the host's share of a frame -- the wake-up from the wait, the
+        finalize, the next load and graph launch, ~60-90 us -- no longer stands between two frames of a stream.  Each frame is waited
+        for through its own event, not through its stream."""
+        return self.depth * self.QUEUE
 
     # ---- one frame on one slot -------------------------------------------------------------------------------
     def _launch(self, i, stream, clouds):
@@ -249,7 +266,7 @@ class PipelinedSecond(object):
         for i in range(len(self.slots)):  # capture every slot (tunes the plans on the real frame), one at a time
             self._launch(i, cands[0], clouds)
             self._finish(i, cands[0])
-        chosen, log = choose_streams(lambda ids: self._time_streams([cands[x] for x in ids], clouds, frames), len(cands), len(self.slots) - 1)
+        chosen, log = choose_streams(lambda ids: self._time_streams([cands[x] for x in ids], clouds, frames), len(cands), self.max_depth)
         self.streams = [cands[x] for x in chosen]
         self.tuned = dict(depth=len(chosen), window_frames=frames, us_per_frame={k: round(v * 1e6, 1) for k, v in log.items()})
         self.pending, self.next_slot, self.next_stream = [], 0, 0
@@ -259,11 +276,11 @@ class PipelinedSecond(object):
     def submit(self, clouds):
         if self.autotune and self.tuned is None:
             self.tune(clouds)
-        assert len(self.pending) < self.depth, "collect() the oldest frame before submitting another one"
+        assert len(self.pending) < self.capacity, "collect() the oldest frame before submitting another one"
         i, j = self.next_slot, self.next_stream
         self._launch(i, self.streams[j], clouds)
         self.pending.append((i, j))
-        self.next_slot = (i + 1) % (self.depth + 1)  # depth + 1 slots in the ring (tuning may have shortened the stream list)
+        self.next_slot = (i + 1) % (self.capacity + 1)  # capacity + 1 slots in the ring (tuning may have shortened the stream list)
         self.next_stream = (j + 1) % self.depth
 
     def collect(self, copy=False):
@@ -285,7 +302,7 @@ class PipelinedSecond(object):
         """submit this frame, return the oldest finished one once the pipeline is full (None while it fills)."""
         if self.autotune and self.tuned is None:
             self.tune(clouds)
-        if len(self.pending) == self.depth:
+        if len(self.pending) == self.capacity:
             out = self.collect()
             self.submit(clouds)
             return out

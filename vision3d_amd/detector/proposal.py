@@ -122,12 +122,15 @@ class ProposalLayer(nn.Module):
             ok = ok and anchors_per_class <= 8192 * min(40, 4096 // self.TOPK)
         return ok
 
-    def native_proposals(self, head_maps, anchors, overflow_flag=None):
+    def native_proposals(self, head_maps, anchors, overflow_flag=None, host_out=None):
         """The whole stage after the 1x1 heads in libvision3d_hip.so (csrc/proposal.hip: 8 launches, no host
         sync): head_maps (B, n_anchor*(1+DOF), H, W) = [cls | reg] channels of the fused head.  Returns padded
         (boxes (N,7), batch_idx, class_idx, scores, n_out int32 on the device); capturable in a HIP graph.
         overflow_flag (a plan's (1,) device word): copied into n_out[1] by the last kernel, so that `finalize_native` reads
-        the count and the plan's capacity verdict with ONE 8-byte copy."""
+        the count and the plan's capacity verdict with ONE 8-byte copy.
+        host_out (a PINNED int32 host tensor of two words, kept by the caller): the last kernel stores the pair straight into it
+        (pinned memory is device-accessible) -- no copy is enqueued behind the frame at all; `finalize_native` synchronises the
+        stream and reads it."""
         cfg = self.cfg
         L.require_gpu("proposals", head_maps, anchors)
         maps, anc = L.as_f32("proposals", head_maps), L.as_f32("proposals", anchors)
@@ -141,7 +144,12 @@ class ProposalLayer(nn.Module):
         batch_idx = torch.empty((N,), dtype=torch.int64, device=dev)
         class_idx = torch.empty((N,), dtype=torch.int64, device=dev)
         scores = torch.empty((N,), dtype=torch.float32, device=dev)
-        n_out = torch.empty((1 if overflow_flag is None else 2,), dtype=torch.int32, device=dev)  # written by the last kernel
+        if host_out is not None:
+            if not (host_out.is_pinned() and host_out.dtype == torch.int32 and host_out.numel() == 2 and overflow_flag is not None):
+                raise RuntimeError("proposals: host_out is a pinned int32 pair, and needs the plan's flag word beside the count")
+            n_out = host_out
+        else:
+            n_out = torch.empty((1 if overflow_flag is None else 2,), dtype=torch.int32, device=dev)  # written by the last kernel
         lib = L.lib()
         ws = L.workspace(lib.v3d_proposals_workspace(B, n_cls, self.TOPK), dev)
         thresh = L.host_f32([a["score_thresh"] for a in cfg.ANCHORS[:n_cls]])
@@ -200,11 +208,19 @@ class ProposalLayer(nn.Module):
         return refined, self.finalize_native(boxes, batch_idx, class_idx, scores, n_out)
 
     @staticmethod
-    def finalize_native(boxes, batch_idx, class_idx, scores, n_out, overflow_flag=None):
+    def finalize_native(boxes, batch_idx, class_idx, scores, n_out, overflow_flag=None, done=None):
         """The one host read of the frame (the reference synchronises inside its NMS): the number of proposals and, when
         the frame came through a BackbonePlan, that plan's capacity-overflow word in the same synchronisation -- a stage
-        that hit its active-site capacity has dropped rows, so the BEV map is wrong and the frame must not be returned."""
-        if overflow_flag is None and n_out.numel() == 1:
+        that hit its active-site capacity has dropped rows, so the BEV map is wrong and the frame must not be returned.
+        done (an event recorded behind the frame): waited for instead of the whole stream -- a later frame may already be queued there."""
+        if not n_out.is_cuda:  # the pinned pair the last kernel wrote itself (native_proposals host_out): wait for the frame, read
+            if done is not None:
+                done.synchronize()
+            else:
+                torch.cuda.current_stream(boxes.device).synchronize()
+            n, ovf = int(n_out[0]), int(n_out[1])
+            _raise_on_flag(ovf)
+        elif overflow_flag is None and n_out.numel() == 1:
             n = int(n_out.item())
         else:
             host = _pinned_pair(n_out.device)
