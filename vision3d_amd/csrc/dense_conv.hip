@@ -1622,6 +1622,7 @@ static int dc_launch(const void* x_hi, const void* x_lo, const void* weight_imag
     if (n_cu < 1) return V3D_EINVAL;
     const bool persistent = p.occ && work && p.CoutPad == DC_BN;
     if (persistent && ksize == 3 && Cin == DL_KC) {  // 2-D tiles with an LDS-resident neighbourhood
+      if (v3d_ablate('d')) return V3D_OK;
       p.work = work;
       p.tile_state = tile_state;
       p.reset_ptr = reset_ptr;
@@ -1636,6 +1637,7 @@ static int dc_launch(const void* x_hi, const void* x_lo, const void* weight_imag
       static V3dPerDeviceFlag attr2;
       V3D_CHECK_HIP(v3d_set_max_lds(attr2, (const void*)conv2d_bf16x3_tile2d_kernel<PREC>, smem2));
       const int per_cu = tiles2 >= 4 * n_cu ? 2 : 1;
+      // (192 / 384 workgroups at bs = 1 measured again under the round-6 pipeline: 4 770 / 4 730 vs 4 757 frames/s, 192 costs 20 us of latency)
       hipLaunchKernelGGL(conv2d_bf16x3_tile2d_kernel<PREC>, dim3(std::min(tiles2, n_cu * per_cu)), dim3(D2_THREADS), smem2, st, (const bf16_t*)x_hi,
                          (const bf16_t*)x_lo, (const bf16_t*)weight_image, bias, p, (bf16_t*)y_hi, (bf16_t*)y_lo);
       V3D_CHECK_LAUNCH();

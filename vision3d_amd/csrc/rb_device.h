@@ -117,8 +117,13 @@ __device__ __forceinline__ void rb_subm_entries_333(const int4* __restrict__ coo
 #define RB_SUBM_KPT 9
 #endif
 #define RB_SUBM_KPT_MIN_ROWS 40960
+#ifndef RB_SUBM_KPT_SMALL
+#define RB_SUBM_KPT_SMALL 1  // offsets per thread below RB_SUBM_KPT_MIN_ROWS (3x3x3: 1, or 3 -- measured on the KITTI frame in round 6:
+                             // 4 787 vs 4 760 frames/s pipelined, 453 vs 449 us one frame at a time: not adopted)
+#endif
 __host__ __device__ inline int rb_subm_kpt(int cap, const RbGeom& g) {
-  return (g.K == 27 && g.ks[0] == 3 && g.ks[1] == 3 && g.ks[2] == 3 && cap >= RB_SUBM_KPT_MIN_ROWS) ? RB_SUBM_KPT : 1;
+  const bool k333 = g.K == 27 && g.ks[0] == 3 && g.ks[1] == 3 && g.ks[2] == 3;
+  return (k333 && cap >= RB_SUBM_KPT_MIN_ROWS) ? RB_SUBM_KPT : (k333 ? RB_SUBM_KPT_SMALL : 1);
 }
 __host__ __device__ inline int rb_subm_blocks(int cap, const RbGeom& g) {
   const int kpt = rb_subm_kpt(cap, g);
@@ -127,8 +132,11 @@ __host__ __device__ inline int rb_subm_blocks(int cap, const RbGeom& g) {
 __device__ __forceinline__ void rb_subm_block(const int4* __restrict__ coords, int n, int cap, const RbGeom& g, const V3dHash& h,
                                               int* __restrict__ nbr, int idx) {
   const int nbx = (cap + V3D_BLOCK - 1) / V3D_BLOCK, o = (idx % nbx) * V3D_BLOCK + threadIdx.x;
-  if (rb_subm_kpt(cap, g) == RB_SUBM_KPT)
+  const int kpt = rb_subm_kpt(cap, g);
+  if (kpt == RB_SUBM_KPT)
     rb_subm_entries_333<RB_SUBM_KPT>(coords, n, cap, g, h, nbr, idx / nbx, o);
+  else if (RB_SUBM_KPT_SMALL > 1 && kpt == RB_SUBM_KPT_SMALL)
+    rb_subm_entries<RB_SUBM_KPT_SMALL>(coords, n, cap, g, h, nbr, idx / nbx, o);
   else
     rb_subm_entries<1>(coords, n, cap, g, h, nbr, idx / nbx, o);
 }

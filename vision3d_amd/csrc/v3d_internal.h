@@ -1,6 +1,16 @@
 // v3d_internal.h -- C++ entry points shared inside libvision3d_hip (not part of the C ABI).
 #pragma once
 #include "v3d_common.h"
+// Ablation builds only (bash tools/build_variant.sh abl "-DV3D_ABLATE" second_plan.hip dense_conv.hip proposal.hip): launches of a
+// class named in $V3D_ABL are skipped -- c: sparse convolutions, r: the 64 -> 64 3x3x3 ones only, d: dense 3x3 tile launches,
+// p: the proposal stage.  Results are garbage; the frame period with a class removed is its marginal cost (docs/rounds/round6.md).
+#ifdef V3D_ABLATE
+#include <cstdlib>
+#include <cstring>
+static inline bool v3d_ablate(char c) { const char* e = getenv("V3D_ABL"); return e && strchr(e, c); }
+#else
+static inline bool v3d_ablate(char) { return false; }
+#endif
 
 struct RbScanJob;  // rb_device.h
 struct RbStep;
