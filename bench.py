@@ -793,20 +793,25 @@ def pvrcnn_end_to_end(args, model, cfg, rank, world):
             dist.barrier()
         torch.cuda.synchronize()
 
+    AHEAD = 1  # frames whose keypoint sampling is in flight ahead of the frame being issued (a side stream / compute unit each).  Two ahead
+               # measured in round 6: 358 vs 375 frames/s -- the main stream's ~190 eager launches per frame (2.7 ms of host time) bound
+               # the line, not the 2.48 ms sampling
+
     def run(n, prefetch):
-        """n frames; prefetch: frame i + 1 is preprocessed and its keypoint sampling (one compute unit, 2.5 ms) started on the side
-        stream before frame i's inference is issued, so the sampling overlaps a whole frame of other work instead of stage 1 only."""
+        """n frames; prefetch: frames i + 1 .. i + AHEAD are preprocessed and their keypoint samplings (one compute unit and 2.5 ms
+        each, on side streams of their own) started before frame i's inference is issued, so a sampling overlaps whole frames of
+        other work instead of its own stage 1 only."""
         out = None
         with torch.no_grad():
-            item = model.prefetch_keypoints(make_item(0)) if prefetch else None
+            ahead = [model.prefetch_keypoints(make_item(j)) for j in range(min(AHEAD, n))] if prefetch else []
             for i in range(n):
                 if prefetch:
-                    nxt = model.prefetch_keypoints(make_item(i + 1))
+                    item = ahead.pop(0)
+                    if i + AHEAD < n:
+                        ahead.append(model.prefetch_keypoints(make_item(i + AHEAD)))
                 else:
                     item = make_item(i)
                 out = model.inference(item)
-                if prefetch:
-                    item = nxt
         return out
 
     timings = {}
@@ -827,8 +832,9 @@ def pvrcnn_end_to_end(args, model, cfg, rank, world):
             one_frame_at_a_time=dict(value=world * bs * args.steps / timings[False], ms_per_step=1e3 * timings[False] / args.steps,
                                      note="no prefetch: the keypoint sampling of a frame overlaps that frame's stage 1 only"),
             config=dict(workload="PV_RCNN.inference from raw points (stage 1 + BASELINE configs[3] stage 2 + refinement NMS), eager "
-                                 "launches; the next frame's keypoint sampling (farthest-point sampling, one compute unit) is started "
-                                 "on a side stream before the current frame is issued (PV_RCNN.prefetch_keypoints)",
+                                 "launches; the next frame's keypoint sampling (farthest-point sampling: 2 048 dependent steps on one "
+                                 "compute unit) is started on a side stream before the current frame is issued (PV_RCNN.prefetch_keypoints)",
+                        frames_sampled_ahead=AHEAD,
                         frames_per_gpu_per_step=bs,
                         points_per_frame=args.points or 16384, parallelism=f"frame-parallel replicas x{world}"),
             n_detections=int(out[0].shape[0]), roofline=None, cpu_baseline=None)))
