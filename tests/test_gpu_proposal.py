@@ -160,3 +160,35 @@ def test_pipelined_frames_match_single_frame_graph(autotune):
     for g, w in zip(got, want):
         for a, b in zip(g, w):
             assert torch.equal(a, b)
+
+
+def test_pipeline_filled_to_capacity_keeps_order_and_results():
+    """Round 6: two frames are queued per stream (`capacity` = 2 x depth submitted and not yet collected; the next frame of a stream
+    is enqueued before the current one is collected, each frame waited for through its own event, its result words written by the
+    last kernel into pinned host memory).  Through `run(clouds)` -- what bench.py calls -- and `collect(copy=True)`: every result
+    equals the one-frame-at-a-time graph's, in submission order, for a stream of different clouds longer than the slot ring."""
+    from test_gpu_dense_conv import build_model
+    from vision3d_amd import synth
+    cfg = second_car_cfg()
+    model = build_model(3)
+    anchors = AnchorGenerator(cfg).anchors.cuda()
+    frames = [[torch.from_numpy(synth.make_cloud(s)).cuda()] for s in range(1, 14)]  # 13 frames > capacity + 1 slots
+    with torch.no_grad():
+        single = model.graphed_inference(anchors, [frames[0][0].shape[0]])
+        want = [[t.clone() for t in single(f)] for f in frames]
+        pipe = model.pipelined_inference(anchors, [frames[0][0].shape[0]], depth=2)
+        assert pipe.capacity == 2 * pipe.depth == 4 and len(pipe.slots) == pipe.capacity + 1
+        got, in_flight_max = [], 0
+        for f in frames:
+            r = pipe(f)  # collects the oldest frame once `capacity` are submitted, then submits
+            in_flight_max = max(in_flight_max, len(pipe.pending))
+            if r is not None:
+                got.append([t.clone() for t in r])
+        assert in_flight_max == pipe.capacity
+        while pipe.pending:
+            got.append(pipe.collect(copy=True))
+        torch.cuda.synchronize()
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        for a, b in zip(g, w):
+            assert torch.equal(a, b)
