@@ -1248,6 +1248,35 @@ def forward_main(args):
         c1.record()
         torch.cuda.synchronize()
         copy_gbs = 10 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        # ... and the same copy AT THE KERNEL'S SIZE: A_min bytes moved (half read, half written) by back-to-back device copies -- the HBM
+        # roof a launch of this size can reach at all (a 4 MB launch is over before the memory system is up to speed: the roof as a
+        # function of size)
+        n_small = max(1024, int(dom_bytes / 2 / 4))
+        copy_at_size_us = None
+        try:  # 50 copies captured in ONE graph: dependent launches like the layers of a frame, no host time between them
+            gcopy = torch.cuda.CUDAGraph()
+            side_c = torch.cuda.Stream()
+            side_c.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side_c):
+                for _ in range(3):
+                    dst[:n_small].copy_(src[:n_small])
+            torch.cuda.current_stream().wait_stream(side_c)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gcopy):
+                for _ in range(50):
+                    dst[:n_small].copy_(src[:n_small])
+            gcopy.replay()
+            torch.cuda.synchronize()
+            c0.record()
+            for _ in range(4):
+                gcopy.replay()
+            c1.record()
+            torch.cuda.synchronize()
+            copy_at_size_us = c0.elapsed_time(c1) * 1e3 / 200
+            del gcopy
+        except Exception:  # (a reported extra)
+            copy_at_size_us = None
+        copy_at_size_gbs = (2 * n_small * 4 / (copy_at_size_us * 1e-6) / 1e9) if copy_at_size_us else None
         del src, dst
         # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed summary of the
         # two rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_h_pmc_traffic.txt) is
@@ -1283,7 +1312,12 @@ def forward_main(args):
         # frac follow it; the HBM view (the figure BASELINE.json's metric quotes) stays beside it.
         t_hbm, t_mfma = dom_bytes / (HBM_PEAK_GBS * 1e9), mfma_alg / 2500e12
         hbm_view = dict(achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, floor_us=t_hbm * 1e6,
-                        peak_measured_copy=copy_gbs, frac_of_measured=achieved / copy_gbs)
+                        peak_measured_copy=copy_gbs, frac_of_measured=achieved / copy_gbs,
+                        copy_at_size=(dict(bytes=2 * n_small * 4, us_per_copy=copy_at_size_us, gbs=copy_at_size_gbs, frac_of_it=achieved / copy_at_size_gbs,
+                                           note="device copies moving the same A_min bytes (half read, half written), 50 dependent launches in one "
+                                                "captured graph like the layers of a frame: the rate ANY launch of this size gets out of the memory "
+                                                "system (at KITTI size it is over before the memory system is up to speed; at Waymo-range size source "
+                                                "and destination sit in the 256 MB last-level cache -- not an HBM figure there)") if copy_at_size_us else None))
         # the same kernel INSIDE the frame (every launch follows a different kernel; row counts of the other frames of the stream):
         # rocprofv3 --kernel-trace --stats of the one-frame-at-a-time run, committed under profiles/ (tools/closing_artifacts.sh)
         in_frame = None
