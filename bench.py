@@ -552,9 +552,36 @@ def pvrcnn_main(args):
                 graphs = None
                 torch.cuda.synchronize()
 
+        # Which streams: two HIP streams overlap only if their hardware queues sit on different command-processor pipes (the line read
+        # 505 or 915 frames/s from one fresh process to the next with streams taken in creation order), so the replay streams of the
+        # slots are picked by measurement like the forward pipeline's (detector/graph.py choose_streams): every pair out of 8
+        # candidates, then greedily deeper while it pays.  A captured graph replays on whatever stream is current.
+        run_streams = [sl[2] for sl in slots]
+        tuned = None
+        if graphs is not None and depth >= 2 and args.pipeline < 1:
+            from vision3d_amd.detector.graph import choose_streams
+            cands = [torch.cuda.Stream() for _ in range(8)]
+
+            def time_of(ids, frames=12):
+                best = None
+                for _ in range(2):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for f in range(frames):
+                        with torch.cuda.stream(cands[ids[f % len(ids)]]):
+                            graphs[f % len(ids)].replay()
+                    torch.cuda.synchronize()
+                    t = (time.perf_counter() - t0) / frames
+                    best = t if best is None else min(best, t)
+                return best
+            chosen, log = choose_streams(time_of, len(cands), depth)
+            run_streams = [cands[c] for c in chosen]
+            tuned = dict(depth=len(chosen), us_per_frame={k: round(v * 1e6, 1) for k, v in log.items()})
+        n_run = len(run_streams)
+
         def submit(i):
-            sl = i % depth
-            with torch.cuda.stream(slots[sl][2]):
+            sl = i % n_run
+            with torch.cuda.stream(run_streams[sl]):
                 if graphs is not None:
                     graphs[sl].replay()
                 else:
@@ -587,7 +614,7 @@ def pvrcnn_main(args):
             config=dict(workload="PV-RCNN stage 2 (BASELINE configs[3]): FPS 2048 keypoints + 5-level VSA + BEV gather + "
                                  "RoI-grid pool (100 proposals) + refinement MLP", frames_per_gpu_per_step=bs,
                         points_per_frame=args.points or 16384, parallelism=f"frame-parallel replicas x{world}",
-                        frames_in_flight=depth,
+                        frames_in_flight=n_run, pipeline_tuning=tuned,
                         path=("one captured HIP graph per frame in flight" if graphs is not None else "eager launches") +
                              ", one host thread, one stream per frame in flight"),
             single_frame_ms=single_ms, frames_per_s_one_at_a_time=bs * 1e3 / single_ms,
