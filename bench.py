@@ -841,15 +841,40 @@ def pvrcnn_end_to_end(args, model, cfg, rank, world):
                 out = model.inference(item)
         return out
 
+    def run_in_flight(n):
+        """Two frames in flight from this one host thread (PV_RCNN.inference_begin / _end / _collect): stage 1 of frame i + 1 is queued
+        before frame i's row counts are read, frame i's result is read after frame i + 1's stage 2 is queued; keypoint samplings
+        for AHEAD_IN_FLIGHT frames at a time in ONE launch (a workgroup per cloud) on a side stream."""
+        out = None
+        with torch.no_grad():
+            items = model.prefetch_keypoints_many([make_item(j) for j in range(min(AHEAD_IN_FLIGHT, n))])
+            nxt_j = len(items)
+            st = model.inference_begin(items.pop(0), 0)
+            prev = None
+            for i in range(n):
+                if len(items) < AHEAD_IN_FLIGHT // 2 + 1 and nxt_j < n:  # the samplings of the next AHEAD_IN_FLIGHT frames in ONE launch
+                    batch = [make_item(j) for j in range(nxt_j, min(nxt_j + AHEAD_IN_FLIGHT, n))]
+                    items += model.prefetch_keypoints_many(batch)
+                    nxt_j += len(batch)
+                nxt = model.inference_begin(items.pop(0), (i + 1) % 2) if i + 1 < n else None
+                h = model.inference_end(st)
+                if prev is not None:
+                    out = model.inference_collect(prev)
+                prev, st = h, nxt
+            out = model.inference_collect(prev)
+        return out
+
+    AHEAD_IN_FLIGHT = 4
     timings = {}
-    for prefetch in (False, True):
-        run(max(args.warmup, 2), prefetch)
+    for prefetch in (False, True, "in_flight"):
+        fn = (lambda n: run_in_flight(n)) if prefetch == "in_flight" else (lambda n, p=prefetch: run(n, p))
+        fn(max(args.warmup, 2))
         fence()
         t0 = time.perf_counter()
-        out = run(args.steps, prefetch)
+        out = fn(args.steps)
         fence()
         timings[prefetch] = dist_util.max_over_ranks(time.perf_counter() - t0, world, device=REDUCE_DEVICE)
-    elapsed = timings[True]
+    elapsed = timings["in_flight"]
     if rank == 0:
         print(json.dumps(dict(
             metric="frames/sec PV-RCNN inference end to end, 16k-pt KITTI cloud", value=world * bs * args.steps / elapsed,
@@ -858,9 +883,14 @@ def pvrcnn_end_to_end(args, model, cfg, rank, world):
             data="synthetic",
             one_frame_at_a_time=dict(value=world * bs * args.steps / timings[False], ms_per_step=1e3 * timings[False] / args.steps,
                                      note="no prefetch: the keypoint sampling of a frame overlaps that frame's stage 1 only"),
-            config=dict(workload="PV_RCNN.inference from raw points (stage 1 + BASELINE configs[3] stage 2 + refinement NMS), eager "
-                                 "launches; the next frame's keypoint sampling (farthest-point sampling: 2 048 dependent steps on one "
-                                 "compute unit) is started on a side stream before the current frame is issued (PV_RCNN.prefetch_keypoints)",
+            prefetch_only=dict(value=world * bs * args.steps / timings[True], ms_per_step=1e3 * timings[True] / args.steps,
+                               note="PV_RCNN.inference frame by frame, the next frame's keypoint sampling started before it (rounds 4-5's `value`)"),
+            config=dict(workload="PV_RCNN inference from raw points (stage 1 + BASELINE configs[3] stage 2 + refinement NMS), eager "
+                                 "launches from one host thread, two frames in flight (PV_RCNN.inference_begin / _end / _collect: stage 1 "
+                                 "of frame i + 1 is queued before frame i's row counts are read, every wait is on the frame's own event); "
+                                 "keypoint samplings (farthest-point sampling: 2 048 dependent steps on one compute unit per cloud) of the "
+                                 "next frames batched into one launch on a side stream (PV_RCNN.prefetch_keypoints_many)",
+                        frames_in_flight=2, keypoint_samplings_ahead=AHEAD_IN_FLIGHT,
                         frames_sampled_ahead=AHEAD,
                         frames_per_gpu_per_step=bs,
                         points_per_frame=args.points or 16384, parallelism=f"frame-parallel replicas x{world}"),

@@ -422,3 +422,43 @@ def test_bev_bilinear_equals_grid_sample():
         fast = gat(bev, kp)
     slow = gat(bev.requires_grad_(True), kp)
     torch.testing.assert_close(fast, slow.detach(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_pv_rcnn_two_frames_in_flight_equal_frame_by_frame_inference():
+    """PV_RCNN.inference_begin / _end / _collect (stage 1 of the next frame queued before this frame's row counts are read; frames
+    alternate between two plan arenas; every wait on the frame's own event), with the keypoints of all frames sampled by one
+    batched launch (prefetch_keypoints_many), return what PV_RCNN.inference returns frame by frame, in order, for a stream of
+    different clouds."""
+    import torch
+    from vision3d_amd import synth
+    from vision3d_amd.core import AnchorGenerator, Preprocessor
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.detector import PV_RCNN
+    cfg = second_car_cfg()
+    torch.manual_seed(0)
+    model = PV_RCNN(cfg).cuda().eval()
+    anchors = AnchorGenerator(cfg).anchors.cuda()
+    pre = Preprocessor(cfg, seed=0)
+    clouds = [[torch.from_numpy(synth.make_cloud(s, 16384)).cuda()] for s in range(5)]
+    samples = torch.rand(1, cfg.NUM_CLASSES * model.proposal_layer.TOPK, cfg.GRIDPOOL.NUM_GRIDPOINTS, 3, device="cuda")
+
+    def item(i):
+        return pre(dict(points=clouds[i], anchors=anchors))
+    with torch.no_grad():
+        want = [[t.clone() for t in model.inference(item(i), samples)] for i in range(len(clouds))]
+        got, prev = [], None
+        ahead = model.prefetch_keypoints_many([item(j) for j in range(len(clouds))])  # all samplings in ONE launch (a workgroup per cloud)
+        st = model.inference_begin(ahead[0], 0)
+        for i in range(len(clouds)):
+            nxt = model.inference_begin(ahead[i + 1], (i + 1) % 2) if i + 1 < len(clouds) else None
+            h = model.inference_end(st, samples)
+            if prev is not None:
+                got.append([t.clone() for t in model.inference_collect(prev)])
+            prev, st = h, nxt
+        got.append([t.clone() for t in model.inference_collect(prev)])
+    assert len(got) == len(want)
+    assert len({w[0].shape[0] for w in want}) >= 1
+    for g, w in zip(got, want):
+        for a, b in zip(g, w):
+            assert torch.equal(a, b)

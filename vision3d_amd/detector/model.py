@@ -116,12 +116,12 @@ class PV_RCNN(nn.Module):
         vm, co = item["voxel_mean"], item["coordinates"]
         return vm.is_cuda and co.is_cuda and co.dtype == torch.int32 and vm.dtype == torch.float32 and vm.shape[0] > 0
 
-    def _backbone_plan(self, batch_size, max_points):
+    def _backbone_plan(self, batch_size, max_points, slot=0):
         from ..runtime import BackbonePlan, PlanCache
         from ..spconv.conv import _SparseConvBase
         plans = self.__dict__.setdefault("_plans", PlanCache())
         dev = next(self.parameters()).device
-        key = (str(dev), int(batch_size), int(max_points))
+        key = (str(dev), int(batch_size), int(max_points), int(slot))  # slot: frames in flight keep their levels in arenas of their own
         # the arithmetic of THIS model's sparse modules (set per instance by set_precision, or by hand on the modules), not the class default
         precision = next((m.precision for m in self.cnn.modules() if isinstance(m, _SparseConvBase)), _SparseConvBase.precision)
         if key not in plans:
@@ -147,28 +147,62 @@ class PV_RCNN(nn.Module):
         return self
 
     def _native_cnn(self, item):
+        return self._native_cnn_finish(item, self._native_cnn_launch(item))
+
+    def _native_cnn_launch(self, item, slot=0):
+        """Enqueue the plan's forward and the copy of its host words (row counts of the levels + summary flag) into pinned memory;
+        nothing is waited for.  -> state for `_native_cnn_finish`."""
         from .. import spconv
         vm, co, b = item["voxel_mean"], item["coordinates"], int(item["batch_size"])
         cap_pts = 1 << max(14, (max(vm.shape[0], 1) - 1).bit_length())
-        plan = self._backbone_plan(b, max(cap_pts, b * 16384))
+        plan = self._backbone_plan(b, max(cap_pts, b * 16384), slot)
+        if not plan.__dict__.get("_tuned"):
+            # a plan picks its kernels from the sparsity of the FIRST frame it sees, and the variants differ in the last bits: every
+            # slot's plan is tuned on the frame the first one saw, so that a frame's result does not depend on the slot it ran in
+            seen = self.__dict__.setdefault("_tune_frames", {})
+            tkey = (b, max(cap_pts, b * 16384))
+            if tkey not in seen:
+                seen[tkey] = (vm.clone(), co.clone())
+            elif slot != 0:
+                plan.forward_voxels(seen[tkey][0], seen[tkey][1], b)
         ends, k = [], 0  # index of the last layer of every stage in the plan's flat layer list
         for stage in self.cnn.blocks:
             k += sum(1 for m in stage.modules() if isinstance(m, spconv.conv._SparseConvBase))
             ends.append(k - 1)
+        bev_map = plan.forward_voxels(vm, co, b)
+        outs = [plan.layer_output(e) for e in ends[:-1]]
+        words = torch.cat([n for _, _, n, _ in outs] + [plan.overflow_any()])
+        pinned = self.__dict__.setdefault("_host_words", {})
+        key = (slot, words.numel())
+        if key not in pinned:
+            pinned[key] = (torch.empty(words.numel(), dtype=words.dtype).pin_memory(), torch.cuda.Event())
+        host, ready = pinned[key]
+        host.copy_(words, non_blocking=True)
+        ready.record()
+        return dict(plan=plan, ends=ends, outs=outs, bev_map=bev_map, host=host, ready=ready, slot=slot)
+
+    def _native_cnn_finish(self, item, st):
+        """The one host read of stage 1 (through ITS event: later work may already be queued on the stream), the level views."""
+        from .. import spconv
+        vm, co, b = item["voxel_mean"], item["coordinates"], int(item["batch_size"])
+        plan = st["plan"]
         for attempt in range(2):
-            bev_map = plan.forward_voxels(vm, co, b)
-            outs = [plan.layer_output(e) for e in ends[:-1]]
-            host = torch.cat([n for _, _, n, _ in outs] + [plan.overflow_any()]).tolist()  # the one host read of stage 1
+            st["ready"].synchronize()
+            host = st["host"].tolist()
             if host[-1] in (2, 3) and attempt == 0:  # an f16s tensor left its calibrated range (up or down): recalibrate on this frame, run it again
+                torch.cuda.synchronize(vm.device)  # (frames queued behind this one ran on the old entries: their own flags judge them)
                 plan.recalibrate()
+                st = self._native_cnn_launch(item, st["slot"])
+                item["_stage1_rerun"] = True  # (whoever computed the head from the first pass's BEV map does it again)
                 continue
             if host[-1] > 0:  # (a clean frame reads -1: the per-frame 0xFF fill)
                 plan.check_overflow()  # raises with the layers that hit their capacity
             break
+        outs = st["outs"]
         volumes = [spconv.SparseConvTensor(vm, co, self.cnn.grid_shape, b)]
         volumes += [spconv.SparseConvTensor(f[:n], c[:n], shape, b) for (f, c, _, shape), n in zip(outs, host)]
         points = [self.cnn.to_global(stride, vol) for stride, vol in zip(self.cfg.STRIDES, volumes)]
-        return points, bev_map
+        return points, st["bev_map"]
 
     PREFETCH_LANES = 4  # side streams the keypoint sampling of successive frames rotates over
 
@@ -190,6 +224,29 @@ class PV_RCNN(nn.Module):
             item["keypoints"] = self.sample_keypoints(points)
             item["_keypoints_ready"] = side.record_event()
         return item
+
+    def prefetch_keypoints_many(self, items):
+        """The same for SEVERAL frames at once: farthest-point sampling takes a batch -- one workgroup (one compute unit) per cloud in
+        ONE launch, 2.48 ms for all of them instead of 2.48 ms each (side streams of their own do not buy that: five streams are
+        more than the four hardware queues).  Frames of one size only; else frame by frame."""
+        pts = [it["points"] for it in items]
+        if len(items) < 2 or any(p.shape[1:] != pts[0].shape[1:] for p in pts):
+            return [self.prefetch_keypoints(it) for it in items]
+        lane = self.__dict__.get("_prefetch_lane", 0)
+        self.__dict__["_prefetch_lane"] = (lane + 1) % self.PREFETCH_LANES
+        main, side = torch.cuda.current_stream(pts[0].device), self._side_stream(pts[0].device, lane)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for p in pts:
+                p.record_stream(side)
+            kp = self.sample_keypoints(torch.cat(pts, dim=0))
+            ready = side.record_event()
+            k = 0
+            for it, p in zip(items, pts):
+                it["keypoints"] = kp[k:k + p.shape[0]]
+                it["_keypoints_ready"] = ready
+                k += p.shape[0]
+        return items
 
     @staticmethod
     def _side_stream(device, lane=0):
@@ -245,6 +302,60 @@ class PV_RCNN(nn.Module):
         if decode:
             item["boxes_refined"] = self.refinement_layer.apply_refinements(deltas, boxes)
         return item
+
+    # ---- two frames in flight from ONE host thread (round 6).  `inference` enqueues stage 1, WAITS for its row counts (the level views
+    # are sized by them), enqueues stage 2 and waits again for the result: the GPU idles while the host enqueues, the host while the
+    # GPU drains.  Split in three, stage 1 of frame i + 1 is queued BEFORE frame i's counts are read, and frame i's result is read
+    # only after frame i + 1's stage 2 is queued -- the stream never runs dry; every wait is on the frame's own event.  Frames
+    # alternate between two plan arenas (`slot`): stage 2 of one reads its levels while stage 1 of the other writes its own.
+    #     st = m.inference_begin(item0, 0)
+    #     for i ...:  nxt = m.inference_begin(item[i + 1], (i + 1) % 2); h = m.inference_end(st); out = m.inference_collect(prev); prev, st = h, nxt
+    def inference_begin(self, item, slot=0):
+        """Stage 1 of `item` enqueued (sparse CNN plan + fused head; the keypoint sampling on its side stream if not prefetched);
+        nothing is waited for."""
+        if not (self._native_item(item) and self.native_tail):
+            raise RuntimeError("inference_begin: frames of the device Preprocessor in eval mode without autograd")
+        if "keypoints" not in item:
+            self.prefetch_keypoints(item)
+        st = self._native_cnn_launch(item, slot)
+        item["_head_maps"] = self.proposal_layer.native_head(st["bev_map"])
+        item["P_cls"], item["P_reg"] = self.proposal_layer.maps_from_fused(item["_head_maps"])
+        return dict(item=item, cnn=st)
+
+    def inference_end(self, st, samples=None):
+        """Frame `st`: the host read of its stage 1 (its own event), stage 2 and the refinement tail enqueued, the result count on its
+        way to pinned memory.  -> handle for `inference_collect`."""
+        item = st["item"]
+        main = torch.cuda.current_stream(item["points"].device)
+        item["_cnn_features"], item["_bev_map"] = self._native_cnn_finish(item, st["cnn"])
+        if item.pop("_stage1_rerun", False):
+            item["_head_maps"] = self.proposal_layer.native_head(item["_bev_map"])
+            item["P_cls"], item["P_reg"] = self.proposal_layer.maps_from_fused(item["_head_maps"])
+        ready = item.pop("_keypoints_ready", None)
+        if ready is not None:
+            main.wait_event(ready)
+            item["keypoints"].record_stream(main)
+        features = self.point_feature_extract(item, item["_cnn_features"], item["_bev_map"])
+        boxes, scores, class_idx = self.stage1_proposals(item)
+        pooled = self.roi_grid_pool(boxes, item["keypoints"], features, samples)
+        deltas, conf = self.refinement_layer(item["points"], pooled, boxes)
+        item.update(keypoint_features=features, proposals=boxes, proposal_scores=scores, proposal_class=class_idx,
+                    pooled_features=pooled, R_reg=deltas, R_cls=conf)
+        item["boxes_refined"], raw = self.proposal_layer.native_refine_nms(deltas, boxes, conf, finalize=False)
+        slot = st["cnn"]["slot"]
+        pinned = self.__dict__.setdefault("_host_count", {})
+        if slot not in pinned:
+            pinned[slot] = (torch.empty(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        host, done = pinned[slot]
+        host.copy_(raw[4], non_blocking=True)
+        done.record()
+        return dict(raw=raw, host=host, done=done)
+
+    def inference_collect(self, h):
+        """-> (boxes, batch_idx, class_idx, scores) of the frame behind handle `h` (waits for ITS event only)."""
+        h["done"].synchronize()
+        n = int(h["host"][0])
+        return [t[:n] for t in h["raw"][:4]]
 
     def inference(self, item, samples=None):
         """-> (boxes (K, 7), batch_idx (K,), class_idx (K,), scores (K,)) by decreasing score, the return contract of

@@ -180,10 +180,11 @@ class ProposalLayer(nn.Module):
         assert N == boxes.shape[0] * boxes.shape[1]
         return boxes, scores
 
-    def native_refine_nms(self, deltas, proposals, conf, iou_threshold=0.01):
+    def native_refine_nms(self, deltas, proposals, conf, iou_threshold=0.01, finalize=True):
         """Stage-2 tail (v3d_refine_nms): deltas / proposals (B, n_cls * TOPK, 7) and conf (B, n_cls * TOPK[, 1]) in the layout of
         `native_topk` -> (refined boxes (B, n, 7), [boxes, batch_idx, class_idx, scores] of the survivors by decreasing score).  One
-        host read (the count)."""
+        host read (the count); finalize=False: no host read -- the second value is (boxes, batch_idx, class_idx, scores, n_out) padded,
+        n_out the device word (PV_RCNN.inference_end reads it through an event)."""
         cfg = self.cfg
         d, p, c = (L.as_f32("refine_nms", t) for t in (deltas, proposals, conf))
         L.require_gpu("refine_nms", d, p, c)
@@ -205,6 +206,8 @@ class ProposalLayer(nn.Module):
             L.check(lib.v3d_refine_nms(L.ptr(d), L.ptr(p), L.ptr(c), B, n_cls, self.TOPK, thresh, float(iou_threshold), L.ptr(refined),
                                        L.ptr(boxes), L.ptr(batch_idx), L.ptr(class_idx), L.ptr(scores), L.ptr(n_out), L.ptr(ws), ws.numel(),
                                        L.stream_ptr()), "refine_nms")
+        if not finalize:
+            return refined, (boxes, batch_idx, class_idx, scores, n_out)
         return refined, self.finalize_native(boxes, batch_idx, class_idx, scores, n_out)
 
     @staticmethod
