@@ -22,6 +22,8 @@ from ..pointnet2.pointnet2_modules import PointnetSAModuleMSG
 from . import layers, proposal, refinement, roi_grid_pool, sparse_cnn
 
 
+from ..runtime import PlanCache as _PlanCache  # (a dict a deep copy of the model starts empty: events, pinned words, device clones)
+
 _SIDE_STREAMS = {}  # device index -> the stream the keypoint sampling runs on (PV_RCNN.proposal)
 
 
@@ -159,7 +161,7 @@ class PV_RCNN(nn.Module):
         if not plan.__dict__.get("_tuned"):
             # a plan picks its kernels from the sparsity of the FIRST frame it sees, and the variants differ in the last bits: every
             # slot's plan is tuned on the frame the first one saw, so that a frame's result does not depend on the slot it ran in
-            seen = self.__dict__.setdefault("_tune_frames", {})
+            seen = self.__dict__.setdefault("_tune_frames", _PlanCache())
             tkey = (b, max(cap_pts, b * 16384))
             if tkey not in seen:
                 seen[tkey] = (vm.clone(), co.clone())
@@ -172,7 +174,7 @@ class PV_RCNN(nn.Module):
         bev_map = plan.forward_voxels(vm, co, b)
         outs = [plan.layer_output(e) for e in ends[:-1]]
         words = torch.cat([n for _, _, n, _ in outs] + [plan.overflow_any()])
-        pinned = self.__dict__.setdefault("_host_words", {})
+        pinned = self.__dict__.setdefault("_host_words", _PlanCache())
         key = (slot, words.numel())
         if key not in pinned:
             pinned[key] = (torch.empty(words.numel(), dtype=words.dtype).pin_memory(), torch.cuda.Event())
@@ -343,7 +345,7 @@ class PV_RCNN(nn.Module):
                     pooled_features=pooled, R_reg=deltas, R_cls=conf)
         item["boxes_refined"], raw = self.proposal_layer.native_refine_nms(deltas, boxes, conf, finalize=False)
         slot = st["cnn"]["slot"]
-        pinned = self.__dict__.setdefault("_host_count", {})
+        pinned = self.__dict__.setdefault("_host_count", _PlanCache())
         if slot not in pinned:
             pinned[slot] = (torch.empty(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
         host, done = pinned[slot]
