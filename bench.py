@@ -1097,7 +1097,8 @@ def _arm_watchdog(limit_s):
 
 # ---- the other BASELINE configurations on the driver's clock: compact sub-lines of the default run --------------------------------
 EXTRA_RUNS = [  # (key, what, argv of a short run of that mode)
-    ("pvrcnn_stage2", "BASELINE configs[3]: PV-RCNN stage 2 on SECOND proposals", ["--mode", "pvrcnn", "--windows", "5", "--steps", "20", "--warmup", "5"]),
+    ("pvrcnn_stage2", "BASELINE configs[3]: PV-RCNN stage 2 on SECOND proposals (keypoint samplings of a round's 16 frames in one launch; per-frame form beside it)",
+     ["--mode", "pvrcnn", "--windows", "5", "--steps", "64", "--warmup", "5"]),
     ("waymo", "BASELINE configs[4]: SECOND forward, 180 k-pt Waymo-range sweep, frames in flight as the headline (streams and depth by measurement)",
      ["--workload", "waymo", "--windows", "5", "--steps", "60", "--warmup", "10", "--single-frames", "40", "--stream", "4"]),
     ("kitti_bs8", "SECOND forward, batch of 8 KITTI clouds per step (65-110 k rows per sparse stage: the large-layer kernels), batches in flight as the headline",
