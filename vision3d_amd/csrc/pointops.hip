@@ -456,52 +456,37 @@ __global__ __launch_bounds__(V3D_BLOCK) void ball_query2_kernel(const float* __r
     bool wave_open = false;
 #pragma unroll
     for (int u = 0; u < BQ2_QPW; u++) wave_open = wave_open || cnta[u] < nsa || cntb[u] < nsb;
-    // Four 64-point steps per trip: their twelve LDS reads are issued together and the four test / ballot rounds follow in index
-    // order.  With 2 048 queries the chip holds ONE wave per SIMD, so nothing else hides a step's LDS round trip: one step per trip
-    // took ~400 clocks of which the arithmetic is ~60 (round 6: 75 -> see docs/rounds/round6.md for the measured effect).
-    for (int t0 = 0; t0 < tn && wave_open; t0 += 4 * 64) {
-      float px[4], py[4], pz[4];
+    for (int t0 = 0; t0 < tn && wave_open; t0 += 64) {
+      const int t = t0 + lane;
+      const bool in = t < tn;
+      const float px = in ? tile[3 * t] : 0.f, py = in ? tile[3 * t + 1] : 0.f, pz = in ? tile[3 * t + 2] : 0.f;
+      wave_open = false;
 #pragma unroll
-      for (int s4 = 0; s4 < 4; s4++) {
-        const int t = t0 + s4 * 64 + lane;
-        const bool in = t < tn;
-        px[s4] = in ? tile[3 * t] : 0.f;
-        py[s4] = in ? tile[3 * t + 1] : 0.f;
-        pz[s4] = in ? tile[3 * t + 2] : 0.f;
-      }
-#pragma unroll
-      for (int s4 = 0; s4 < 4; s4++) {
-        const int t = t0 + s4 * 64 + lane;
-        const bool in = t < tn;
-        if (!wave_open) break;  // (wave-uniform: every (query, radius) of this wave is full)
-        wave_open = false;
-#pragma unroll
-        for (int u = 0; u < BQ2_QPW; u++) {
-          const float dx = qx[u] - px[s4], dy = qy[u] - py[s4], dz = qz[u] - pz[s4];
-          const float d2 = dx * dx + dy * dy + dz * dz;
-          const size_t row = (size_t)b * M + (q0 + u < M ? q0 + u : 0);
-          if (cnta[u] < nsa) {
-            const bool hit = in && d2 < r2a;
-            const unsigned long long m = __ballot(hit);
-            if (m) {
-              if (cnta[u] == 0) firsta[u] = n0 + t0 + s4 * 64 + __ffsll((long long)m) - 1;
-              const int pos = cnta[u] + __popcll(m & ((1ull << lane) - 1ull));
-              if (hit && pos < nsa) idxa[row * nsa + pos] = n0 + t;
-              cnta[u] = min(nsa, cnta[u] + __popcll(m));
-            }
+      for (int u = 0; u < BQ2_QPW; u++) {
+        const float dx = qx[u] - px, dy = qy[u] - py, dz = qz[u] - pz;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        const size_t row = (size_t)b * M + (q0 + u < M ? q0 + u : 0);
+        if (cnta[u] < nsa) {
+          const bool hit = in && d2 < r2a;
+          const unsigned long long m = __ballot(hit);
+          if (m) {
+            if (cnta[u] == 0) firsta[u] = n0 + t0 + __ffsll((long long)m) - 1;
+            const int pos = cnta[u] + __popcll(m & ((1ull << lane) - 1ull));
+            if (hit && pos < nsa) idxa[row * nsa + pos] = n0 + t;
+            cnta[u] = min(nsa, cnta[u] + __popcll(m));
           }
-          if (cntb[u] < nsb) {
-            const bool hit = in && d2 < r2b;
-            const unsigned long long m = __ballot(hit);
-            if (m) {
-              if (cntb[u] == 0) firstb[u] = n0 + t0 + s4 * 64 + __ffsll((long long)m) - 1;
-              const int pos = cntb[u] + __popcll(m & ((1ull << lane) - 1ull));
-              if (hit && pos < nsb) idxb[row * nsb + pos] = n0 + t;
-              cntb[u] = min(nsb, cntb[u] + __popcll(m));
-            }
-          }
-          wave_open = wave_open || cnta[u] < nsa || cntb[u] < nsb;
         }
+        if (cntb[u] < nsb) {
+          const bool hit = in && d2 < r2b;
+          const unsigned long long m = __ballot(hit);
+          if (m) {
+            if (cntb[u] == 0) firstb[u] = n0 + t0 + __ffsll((long long)m) - 1;
+            const int pos = cntb[u] + __popcll(m & ((1ull << lane) - 1ull));
+            if (hit && pos < nsb) idxb[row * nsb + pos] = n0 + t;
+            cntb[u] = min(nsb, cntb[u] + __popcll(m));
+          }
+        }
+        wave_open = wave_open || cnta[u] < nsa || cntb[u] < nsb;
       }
     }
     if (lane == 0 && wave_open) atomicOr(&open_queries, 1);
