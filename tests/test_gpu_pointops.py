@@ -395,6 +395,89 @@ def test_ball_query_pair_equals_two_single_queries(n, m, ra, nsa, rb, nsb):
     assert torch.equal(ib, PU.ball_query(rb, nsb, xyz, new_xyz))
 
 
+def _both_algos(fn):
+    from vision3d_amd.pointnet2 import pointnet2_utils as PU
+    out = {}
+    for algo in ("scan", "grid"):
+        old, PU.BALL_QUERY_ALGO = PU.BALL_QUERY_ALGO, algo
+        try:
+            out[algo] = fn(PU)
+        finally:
+            PU.BALL_QUERY_ALGO = old
+    return out["scan"], out["grid"]
+
+
+@pytest.mark.parametrize("order", ["shuffled", "scan"])
+def test_ball_query_grid_equals_scan_at_pvrcnn_sizes(order):
+    """v3d_ball_query_grid == v3d_ball_query bit for bit on the six calls of a PV-RCNN frame's shapes: raw cloud and voxel-centre
+    databases around 2 048 keypoints (radii of config.py PSA.RADII), the keypoints around RoI grid points."""
+    from vision3d_amd.pointnet2 import pointnet2_utils as PU
+    cloud = torch.from_numpy(synth.make_cloud(5, order=order)[:, :3]).cuda()[None].contiguous()
+    kp = cloud[:, PU.furthest_point_sample(cloud, 2048)[0].long()].contiguous()
+    vs = torch.tensor([0.05, 0.05, 0.1], device="cuda")
+    databases = [(cloud, (0.4, 0.8))]
+    for stride, radii in zip((1, 2, 4, 8), ((0.4, 0.8), (0.8, 1.2), (1.2, 2.4), (2.4, 4.8))):
+        cells = torch.unique(torch.floor(cloud[0] / (vs * stride)), dim=0)
+        cells = cells[torch.randperm(cells.shape[0], generator=torch.Generator().manual_seed(stride)).cuda()]
+        databases.append(((cells * (vs * stride))[None].contiguous(), radii))
+    for db, (ra, rb) in databases:
+        (sa, sb), (ga, gb) = _both_algos(lambda PU: PU.ball_query_pair(ra, 16, rb, 32, db, kp))
+        assert torch.equal(sa, ga) and torch.equal(sb, gb), (db.shape, ra, rb)
+        assert (ga != 0).any() and (gb != 0).any()
+    grid_pts = (kp[:, :1600] + 0.3 * torch.randn(1, 1600, 3, generator=torch.Generator().manual_seed(3)).cuda()).contiguous()
+    (sa, sb), (ga, gb) = _both_algos(lambda PU: PU.ball_query_pair(0.8, 16, 1.6, 32, kp, grid_pts))
+    assert torch.equal(sa, ga) and torch.equal(sb, gb)
+
+
+@pytest.mark.parametrize("n,m,ra,nsa,rb,nsb", [(16384, 2048, 0.4, 16, 0.8, 16), (4204, 2048, 2.4, 16, 4.8, 32), (777, 130, 1.0, 5, 3.0, 64),
+                                               (2500, 37, 0.01, 16, 100.0, 32), (1, 9, 1.0, 4, 2.0, 4), (65, 3, 0.5, 100, 0.6, 70),
+                                               (40000, 500, 0.3, 16, 0.2, 32)])
+def test_ball_query_grid_equals_scan_ragged_and_degenerate(n, m, ra, nsa, rb, nsb):
+    """Ragged sizes, a radius that finds nothing / everything, nsample beyond a wave, the larger radius given first, two frames; then
+    the corner cases of the binning: non-finite database points and queries, queries far outside the database, a database of
+    coincident points, a database spread so wide that the cells must grow past the radius."""
+    g = torch.Generator().manual_seed(n * 7 + m)
+    xyz = (torch.rand(2, n, 3, generator=g) * torch.tensor([70.0, 80.0, 4.0])).cuda()
+    new_xyz = xyz[:, torch.randint(0, n, (m,), generator=g)].contiguous() + 0.05
+    (sa, sb), (ga, gb) = _both_algos(lambda PU: PU.ball_query_pair(ra, nsa, rb, nsb, xyz, new_xyz))
+    assert torch.equal(sa, ga) and torch.equal(sb, gb)
+    s1, g1 = _both_algos(lambda PU: PU.ball_query(rb, nsb, xyz, new_xyz))
+    assert torch.equal(s1, g1) and torch.equal(g1, gb)
+    # non-finite coordinates, far-away queries
+    bad = xyz.clone()
+    k = max(n // 10, 1)
+    bad[0, :k, 0] = float("nan")
+    bad[1, :k, 1] = float("inf")
+    bad[0, -k:, 2] = float("nan")
+    q = new_xyz.clone()
+    q[0, 0] = float("nan")
+    q[1, 0, 1] = float("-inf")
+    q[0, 1 % m] = 1e6
+    q[1, 2 % m, 0] = -3.0  # just outside the database's bounds
+    (sa, sb), (ga, gb) = _both_algos(lambda PU: PU.ball_query_pair(ra, nsa, rb, nsb, bad, q))
+    assert torch.equal(sa, ga) and torch.equal(sb, gb)
+    # coincident points; a very wide database (cells grown beyond the radius)
+    same = torch.full_like(xyz, 2.5)
+    (sa, sb), (ga, gb) = _both_algos(lambda PU: PU.ball_query_pair(ra, nsa, rb, nsb, same, new_xyz))
+    assert torch.equal(sa, ga) and torch.equal(sb, gb)
+    wide = xyz * torch.tensor([300.0, 300.0, 1.0], device="cuda")
+    qw = wide[:, torch.randint(0, n, (m,), generator=g)].contiguous() + 0.01
+    (sa, sb), (ga, gb) = _both_algos(lambda PU: PU.ball_query_pair(ra, nsa, rb, nsb, wide, qw))
+    assert torch.equal(sa, ga) and torch.equal(sb, gb)
+
+
+def test_ball_query_grid_workspace_is_checked():
+    from vision3d_amd import _lib as L
+    xyz = torch.rand(1, 100, 3).cuda()
+    idx = torch.empty((1, 100, 4), dtype=torch.int32, device="cuda")
+    need = L.lib().v3d_ball_query_grid_workspace(1, 100)
+    assert need >= 100 * 16
+    small = torch.empty(need - 16, dtype=torch.uint8, device="cuda")
+    rc = L.lib().v3d_ball_query_grid(L.ptr(xyz), L.ptr(xyz), 1, 100, 100, 1.0, 4, L.ptr(idx), 0.0, 0, None, L.ptr(small), small.numel(),
+                                     L.stream_ptr())
+    assert rc != 0
+
+
 def test_bev_bilinear_equals_grid_sample():
     """v3d_bev_bilinear == F.grid_sample(bilinear, zeros, align_corners=True) on a (B, 1, K, 2) grid, including points on and
     beyond the border (the gatherer clamps, the kernel must still zero-pad like torch)."""

@@ -11,6 +11,7 @@
 //   * ball query: one WAVE per query (ballot = hit mask, popcount prefix = slot), database points streamed through
 //     LDS tiles shared by the workgroup; first-nsample-in-index-order semantics with first-hit prefill.
 #include <algorithm>
+#include <cmath>
 
 #include "v3d_common.h"
 
@@ -517,6 +518,276 @@ extern "C" int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int
     hipLaunchKernelGGL(ball_query2_kernel, dim3(v3d_ceil_div(M, (V3D_BLOCK / V3D_WAVE) * BQ2_QPW), B), dim3(V3D_BLOCK), 0,
                        (hipStream_t)stream, xyz, new_xyz, N, M, radius_a * radius_a, nsample_a, idx_a, radius_b * radius_b, nsample_b,
                        idx_b);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------ ball query over a cell grid
+// The scan kernels above test EVERY database point against every query (2 048 x 16 384 distances per call, ~290 clocks per
+// 64-point step on one wave per SIMD: 75 us per call, six calls per PV-RCNN frame = a third of stage 2's kernel time), and a
+// cloud in training order (`kitti_dataset.py:154` shuffles the points) offers no index locality to prune by.  Here the database
+// is first binned into square (x, y) cells no smaller than the larger radius (one 1 024-thread workgroup per frame: bounds,
+// LDS histogram, scan, scatter of (x, y, z, index) records), and a query looks at the 3 x 3 cells around its own only:
+//   * which points are inside the ball is decided by the scan kernels' own expression on the same operands (-ffp-contract=off),
+//     so the hit SET is theirs bit for bit -- the cells only have to be a superset, which the 1 % margin on the cell edge
+//     guarantees against the rounding of the two cell computations (see bq_cell);
+//   * "the first nsample hits in INDEX order" does not depend on the order the candidates are met in: every hit sets bit
+//     `index` of a per-wave LDS bitmap (N bits per radius), and the answer is read off the bitmap in ascending order --
+//     popcount prefix over the lanes' word runs, the lanes below nsample emit their bits.
+// Same results as v3d_ball_query for every input (tests/test_gpu_pointops.py: equality with the scan kernel at full size, with the
+// CPU oracle at small sizes, non-finite coordinates, queries far outside the database).
+#define BQG_MAX_CELLS 8192
+#define BQG_BUILD_THREADS 1024
+#define BQG_HEADER_BYTES 32
+#define BQG_WAVES 4
+
+struct BqGrid {  // first words of a frame's workspace, written by the build kernel
+  float x0, y0, inv_c;
+  int nx, ny;
+};
+
+__host__ __device__ static inline size_t bqg_sorted_offset() { return (BQG_HEADER_BYTES + (BQG_MAX_CELLS + 1) * 4 + 15) / 16 * 16; }
+__host__ __device__ static inline size_t bqg_frame_bytes(int N) { return bqg_sorted_offset() + (size_t)N * 16; }
+
+// Cell coordinate of x along an axis that starts at x0: the SAME expression for database points and queries.  Two values less
+// than r apart differ by less than r * inv_c <= 1 / 1.01 before rounding and by at most 2 * 8192 * 2^-23 ~ 0.002 more after it
+// (two roundings each, at most BQG_MAX_CELLS cells along an axis): their floors differ by at most one.
+__device__ __forceinline__ float bq_cell(float x, float x0, float inv_c) { return floorf((x - x0) * inv_c); }
+
+// PPT > 0: N <= PPT * BQG_BUILD_THREADS and every thread keeps its points in registers (ONE trip to memory instead of three: a
+// workgroup alone on its compute unit has nothing to hide a trip behind -- 15 -> ~6 us at 16 384 points); PPT == 0: any N, the
+// points are read again in every pass.
+template <int PPT>
+__global__ __launch_bounds__(BQG_BUILD_THREADS) void bq_grid_build_kernel(const float* __restrict__ xyz, int N, float cell_min,
+                                                                          unsigned char* __restrict__ ws, size_t ws_stride) {
+  __shared__ float red[4][BQG_BUILD_THREADS / V3D_WAVE];
+  __shared__ int cnt[BQG_MAX_CELLS];
+  __shared__ int wsum[BQG_BUILD_THREADS / V3D_WAVE];
+  __shared__ BqGrid g;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* p = xyz + (size_t)b * N * 3;
+  unsigned char* w = ws + (size_t)b * ws_stride;
+  int* cell_start = reinterpret_cast<int*>(w + BQG_HEADER_BYTES);
+  float4* sorted = reinterpret_cast<float4*>(w + bqg_sorted_offset());
+  const float inf = __builtin_huge_valf();
+  [[maybe_unused]] float px[PPT ? PPT : 1], py[PPT ? PPT : 1], pz[PPT ? PPT : 1];
+  if constexpr (PPT > 0) {
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+      const int i = tid + k * BQG_BUILD_THREADS;
+      px[k] = i < N ? p[3 * (size_t)i] : inf;  // (a slot beyond N reads as a non-finite point: left out like one)
+      py[k] = i < N ? p[3 * (size_t)i + 1] : inf;
+      pz[k] = i < N ? p[3 * (size_t)i + 2] : inf;
+    }
+  }
+  // body(i, x, y, z) for every point with finite x and y (a point with a non-finite x or y can be in no ball: it is left out of the grid)
+  auto for_points = [&](auto body) {
+    if constexpr (PPT > 0) {
+#pragma unroll
+      for (int k = 0; k < PPT; k++)
+        if (fabsf(px[k]) < inf && fabsf(py[k]) < inf) body(tid + k * BQG_BUILD_THREADS, px[k], py[k], pz[k]);
+    } else {
+      for (int i = tid; i < N; i += BQG_BUILD_THREADS) {
+        const float x = p[3 * (size_t)i], y = p[3 * (size_t)i + 1], z = p[3 * (size_t)i + 2];
+        if (fabsf(x) < inf && fabsf(y) < inf) body(i, x, y, z);
+      }
+    }
+  };
+  // (a) bounds
+  float xlo = inf, xhi = -inf, ylo = inf, yhi = -inf;
+  for_points([&](int, float x, float y, float) {
+    xlo = fminf(xlo, x), xhi = fmaxf(xhi, x);
+    ylo = fminf(ylo, y), yhi = fmaxf(yhi, y);
+  });
+  xlo = -v3d_dpp_max_f32<true>(-xlo), xhi = v3d_dpp_max_f32<true>(xhi);
+  ylo = -v3d_dpp_max_f32<true>(-ylo), yhi = v3d_dpp_max_f32<true>(yhi);
+  if (lane == 0) red[0][wave] = xlo, red[1][wave] = xhi, red[2][wave] = ylo, red[3][wave] = yhi;
+  for (int i = tid; i < BQG_MAX_CELLS; i += BQG_BUILD_THREADS) cnt[i] = 0;
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < BQG_BUILD_THREADS / V3D_WAVE; i++) {
+      xlo = fminf(xlo, red[0][i]), xhi = fmaxf(xhi, red[1][i]);
+      ylo = fminf(ylo, red[2][i]), yhi = fmaxf(yhi, red[3][i]);
+    }
+    BqGrid t;
+    t.x0 = xlo, t.y0 = ylo, t.inv_c = 0.f, t.nx = 0, t.ny = 0;
+    if (xlo <= xhi) {  // at least one finite point
+      float c = cell_min;
+      for (;;) {  // cells no smaller than asked for, grown until the grid fits the LDS histogram
+        t.inv_c = 1.f / c;
+        const float fx = bq_cell(xhi, xlo, t.inv_c), fy = bq_cell(yhi, ylo, t.inv_c);  // (the largest cell along each axis)
+        if (fx < (float)BQG_MAX_CELLS && fy < (float)BQG_MAX_CELLS && ((long long)fx + 1) * ((long long)fy + 1) <= BQG_MAX_CELLS) {
+          t.nx = (int)fx + 1, t.ny = (int)fy + 1;
+          break;
+        }
+        c *= 1.5f;
+      }
+    }
+    g = t;
+    *reinterpret_cast<BqGrid*>(w) = t;
+  }
+  __syncthreads();
+  const BqGrid gg = g;
+  const int ncell = gg.nx * gg.ny;
+  auto cell_of = [&](float x, float y) { return (int)bq_cell(y, gg.y0, gg.inv_c) * gg.nx + (int)bq_cell(x, gg.x0, gg.inv_c); };
+  // (b) histogram
+  for_points([&](int, float x, float y, float) { atomicAdd(&cnt[cell_of(x, y)], 1); });
+  __syncthreads();
+  // (c) exclusive scan: BQG_MAX_CELLS / BQG_BUILD_THREADS consecutive cells per thread
+  constexpr int CPT = BQG_MAX_CELLS / BQG_BUILD_THREADS;
+  int own[CPT], sum = 0;
+#pragma unroll
+  for (int k = 0; k < CPT; k++) own[k] = cnt[tid * CPT + k], sum += own[k];
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < wave; i++) base += wsum[i];
+  int run = base + incl - sum;
+#pragma unroll
+  for (int k = 0; k < CPT; k++) {
+    const int c = tid * CPT + k;
+    cnt[c] = run;  // from here on: the cell's write cursor
+    if (c <= ncell) cell_start[c] = run;  // (entry ncell = the number of binned points)
+    run += own[k];
+  }
+  if (tid == BQG_BUILD_THREADS - 1 && ncell == BQG_MAX_CELLS) cell_start[ncell] = run;
+  __syncthreads();
+  // (d) scatter (the order inside a cell is whatever the atomics give: the queries do not depend on it)
+  for_points([&](int i, float x, float y, float z) { sorted[atomicAdd(&cnt[cell_of(x, y)], 1)] = make_float4(x, y, z, __int_as_float(i)); });
+}
+
+// the first `ns` set bits of a wave's bitmap in ascending order -> o[0, ns) (empty slots repeat the first hit; no hit: 0), the
+// bitmap left all zero.  Lane l owns the words [l * wpl, (l + 1) * wpl) (wpl odd: conflict-free).
+__device__ __forceinline__ void bq_bitmap_emit(unsigned* __restrict__ bm, int wpl, int ns, int* __restrict__ o, int lane) {
+  unsigned* mine = bm + lane * wpl;
+  int cnt = 0;
+  for (int k = 0; k < wpl; k++) cnt += __popc(mine[k]);
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  const int total = __shfl(incl, 63);
+  int pos = incl - cnt, first = 0;
+  const unsigned long long holders = __ballot(cnt > 0);
+  if (cnt > 0 && pos < ns) {
+    for (int k = 0; k < wpl && pos < ns; k++) {
+      unsigned wd = mine[k];
+      while (wd && pos < ns) {
+        const int bit = __ffs((int)wd) - 1;
+        const int id = (lane * wpl + k) * 32 + bit;
+        if (pos == 0) first = id;
+        o[pos++] = id;
+        wd &= wd - 1;
+      }
+    }
+  }
+  for (int k = 0; k < wpl; k++) mine[k] = 0u;
+  if (total < ns) {
+    first = holders ? __shfl(first, __ffsll((long long)holders) - 1) : 0;
+    for (int s = total + lane; s < ns; s += 64) o[s] = first;
+  }
+}
+
+__global__ __launch_bounds__(BQG_WAVES * 64) void bq_grid_query_kernel(const float* __restrict__ new_xyz, int M, float r2a, int nsa,
+                                                                       int* __restrict__ idxa, float r2b, int nsb,
+                                                                       int* __restrict__ idxb, const unsigned char* __restrict__ ws,
+                                                                       size_t ws_stride, int wpl) {
+  extern __shared__ unsigned bq_bits[];  // [waves][2][64 * wpl]
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  unsigned* ba = bq_bits + (size_t)wave * 2 * 64 * wpl;
+  unsigned* bb = ba + 64 * wpl;
+  for (int k = lane; k < 2 * 64 * wpl; k += 64) ba[k] = 0u;
+  const unsigned char* w = ws + (size_t)b * ws_stride;
+  const BqGrid g = *reinterpret_cast<const BqGrid*>(w);
+  const int* cell_start = reinterpret_cast<const int*>(w + BQG_HEADER_BYTES);
+  const float4* sorted = reinterpret_cast<const float4*>(w + bqg_sorted_offset());
+  for (int q = blockIdx.x * waves + wave; q < M; q += gridDim.x * waves) {
+    const float* qp = new_xyz + ((size_t)b * M + q) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const float tx = bq_cell(qx, g.x0, g.inv_c), ty = bq_cell(qy, g.y0, g.inv_c);
+    // (a query more than a cell outside the grid, or with a non-finite coordinate, has no candidates; the comparisons are
+    //  false for NaN)
+    if (tx >= -1.f && tx <= (float)g.nx && ty >= -1.f && ty <= (float)g.ny) {
+      const int cx = (int)tx, cy = (int)ty;
+      const int c0 = max(cx - 1, 0), c1 = min(cx + 1, g.nx - 1);
+      int s[3], e[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {  // the three cells of a row are one run of records
+        const int row = cy - 1 + d;
+        const bool ok = row >= 0 && row < g.ny && c0 <= c1;
+        s[d] = ok ? cell_start[row * g.nx + c0] : 0;
+        e[d] = ok ? cell_start[row * g.nx + c1 + 1] : 0;
+      }
+      // the three runs as ONE index space, four records per lane requested before the first is looked at (a wave alone on its
+      // query has one trip to the L2 per loop pass: 576 candidates were nine trips)
+      const int l0 = e[0] - s[0], l01 = l0 + e[1] - s[1], total = l01 + e[2] - s[2];
+      const float nanf_ = __builtin_nanf("");
+      for (int t0 = 0; t0 < total; t0 += 256) {
+        float4 pt[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int t = t0 + u * 64 + lane;
+          const int i = t < l0 ? s[0] + t : (t < l01 ? s[1] + (t - l0) : s[2] + (t - l01));
+          pt[u] = t < total ? sorted[i] : make_float4(nanf_, nanf_, nanf_, 0.f);  // (NaN: inside no ball)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const float dx = qx - pt[u].x, dy = qy - pt[u].y, dz = qz - pt[u].z;
+          const float d2 = dx * dx + dy * dy + dz * dz;
+          const int id = __float_as_int(pt[u].w);
+          if (d2 < r2a) atomicOr(&ba[id >> 5], 1u << (id & 31));
+          if (idxb && d2 < r2b) atomicOr(&bb[id >> 5], 1u << (id & 31));
+        }
+      }
+    }
+    __threadfence_block();  // (the wave's own LDS atomics before its reads)
+    bq_bitmap_emit(ba, wpl, nsa, idxa + ((size_t)b * M + q) * nsa, lane);
+    if (idxb) bq_bitmap_emit(bb, wpl, nsb, idxb + ((size_t)b * M + q) * nsb, lane);
+  }
+}
+
+extern "C" size_t v3d_ball_query_grid_workspace(int B, int N) {
+  if (B < 1 || N < 1) return 0;
+  return (size_t)B * bqg_frame_bytes(N);
+}
+
+// v3d_ball_query through a cell grid of the database (same arguments, same results; `workspace` = v3d_ball_query_grid_workspace(B, N)
+// bytes, 16-byte aligned, contents need not be kept).  Databases too large for the per-wave LDS bitmaps (N > ~250 000) take the scan.
+extern "C" int v3d_ball_query_grid(const float* xyz, const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a,
+                                   int32_t* idx_a, float radius_b, int nsample_b, int32_t* idx_b, void* workspace,
+                                   size_t workspace_bytes, v3d_stream_t stream) {
+  if (B < 0 || N < 1 || M < 0 || nsample_a < 1 || (idx_b && nsample_b < 1)) return V3D_EINVAL;
+  if (B == 0 || M == 0) return V3D_OK;
+  if (!xyz || !new_xyz || !idx_a) return V3D_EINVAL;
+  const int words = v3d_ceil_div(N, 32);
+  const int wpl = v3d_ceil_div(words, 64) | 1;  // odd
+  const size_t per_wave = (size_t)2 * 64 * wpl * sizeof(unsigned);
+  const int waves = (int)std::min<size_t>(BQG_WAVES, (size_t)64 * 1024 / per_wave);
+  const float rmax = idx_b ? std::max(fabsf(radius_a), fabsf(radius_b)) : fabsf(radius_a);
+  if (waves < 1 || !(rmax > 0.f) || !(rmax < 1e30f))
+    return v3d_ball_query(xyz, new_xyz, B, N, M, radius_a, nsample_a, idx_a, radius_b, nsample_b, idx_b, stream);
+  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < v3d_ball_query_grid_workspace(B, N)) return V3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t stride = bqg_frame_bytes(N);
+#define BQG_BUILD(PPT) \
+  hipLaunchKernelGGL(bq_grid_build_kernel<PPT>, dim3(B), dim3(BQG_BUILD_THREADS), 0, st, xyz, N, rmax * 1.01f, (unsigned char*)workspace, stride)
+  if (N <= 4 * BQG_BUILD_THREADS) BQG_BUILD(4);
+  else if (N <= 12 * BQG_BUILD_THREADS) BQG_BUILD(12);
+  else if (N <= 20 * BQG_BUILD_THREADS) BQG_BUILD(20);
+  else BQG_BUILD(0);
+#undef BQG_BUILD
+  V3D_CHECK_LAUNCH();
+  const int blocks = std::min(v3d_ceil_div(M, waves), 4096);
+  hipLaunchKernelGGL(bq_grid_query_kernel, dim3(blocks, B), dim3(waves * 64), waves * per_wave, st, new_xyz, M, radius_a * radius_a, nsample_a,
+                     idx_a, radius_b * radius_b, nsample_b, idx_b, (const unsigned char*)workspace, stride, wpl);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }

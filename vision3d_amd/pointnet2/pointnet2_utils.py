@@ -73,32 +73,47 @@ def _gather_forward(features, idx):
     return out
 
 
+# "grid" (default): csrc/pointops.hip v3d_ball_query_grid -- the database binned into (x, y) cells, a query tests the 3 x 3 cells
+# around its own; "scan": v3d_ball_query -- every database point against every query.  Same results bit for bit (the tests compare
+# them); the switch exists for A/B measurements.
+BALL_QUERY_ALGO = "grid"
+
+
+def _ball_query_call(p, q, radius_a, nsample_a, idx_a, radius_b, nsample_b, idx_b, what):
+    b, n, _ = p.shape
+    m = q.shape[1]
+    with torch.cuda.device(p.device):
+        if BALL_QUERY_ALGO == "grid":
+            nbytes = L.lib().v3d_ball_query_grid_workspace(b, n)
+            ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=p.device)
+            L.check(L.lib().v3d_ball_query_grid(L.ptr(p), L.ptr(q), b, n, m, float(radius_a), int(nsample_a), L.ptr(idx_a),
+                                                float(radius_b), int(nsample_b), L.ptr(idx_b), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                    what)
+        elif BALL_QUERY_ALGO == "scan":
+            L.check(L.lib().v3d_ball_query(L.ptr(p), L.ptr(q), b, n, m, float(radius_a), int(nsample_a), L.ptr(idx_a), float(radius_b),
+                                           int(nsample_b), L.ptr(idx_b), L.stream_ptr()), what)
+        else:
+            raise ValueError(f"BALL_QUERY_ALGO must be 'grid' or 'scan', not {BALL_QUERY_ALGO!r}")
+
+
 def ball_query(radius, nsample, xyz, new_xyz):
     """xyz (B, N, 3), new_xyz (B, M, 3) -> idx (B, M, nsample) int32: the first `nsample` points (index
     order) with d^2 < r^2, empty slots filled with the first hit, no hit -> 0."""
     L.require_gpu("ball_query", xyz, new_xyz)
     p, q = L.as_f32("ball_query", xyz), L.as_f32("ball_query", new_xyz)
-    b, n, _ = p.shape
-    m = q.shape[1]
-    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=p.device)
-    with torch.cuda.device(p.device):
-        L.check(L.lib().v3d_ball_query(L.ptr(p), L.ptr(q), b, n, m, float(radius), int(nsample), L.ptr(idx), 0.0, 0, None,
-                                       L.stream_ptr()), "ball_query")
+    idx = torch.empty((p.shape[0], q.shape[1], nsample), dtype=torch.int32, device=p.device)
+    _ball_query_call(p, q, radius, nsample, idx, 0.0, 0, None, "ball_query")
     return idx
 
 
 def ball_query_pair(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz):
-    """Two ball queries around the same `new_xyz` in one scan of `xyz` (the two scales of a multi-scale set-abstraction module):
+    """Two ball queries around the same `new_xyz` in one pass over `xyz` (the two scales of a multi-scale set-abstraction module):
     -> (idx_a (B, M, nsample_a), idx_b (B, M, nsample_b)), each exactly what `ball_query` returns for its radius."""
     L.require_gpu("ball_query", xyz, new_xyz)
     p, q = L.as_f32("ball_query", xyz), L.as_f32("ball_query", new_xyz)
-    b, n, _ = p.shape
-    m = q.shape[1]
-    idx_a = torch.empty((b, m, nsample_a), dtype=torch.int32, device=p.device)
-    idx_b = torch.empty((b, m, nsample_b), dtype=torch.int32, device=p.device)
-    with torch.cuda.device(p.device):
-        L.check(L.lib().v3d_ball_query(L.ptr(p), L.ptr(q), b, n, m, float(radius_a), int(nsample_a), L.ptr(idx_a),
-                                        float(radius_b), int(nsample_b), L.ptr(idx_b), L.stream_ptr()), "ball_query2")
+    idx_a = torch.empty((p.shape[0], q.shape[1], nsample_a), dtype=torch.int32, device=p.device)
+    idx_b = torch.empty((p.shape[0], q.shape[1], nsample_b), dtype=torch.int32, device=p.device)
+    _ball_query_call(p, q, radius_a, nsample_a, idx_a, radius_b, nsample_b, idx_b, "ball_query2")
     return idx_a, idx_b
 
 
