@@ -298,6 +298,12 @@ int v3d_group_points(const float* feat, const int32_t* idx, int B, int C, int N,
  * (B, K, 2) f32 = (x, y) in [-1, 1], out (B, C, K).  Same taps, weights and summation order as torch's kernel. */
 int v3d_bev_bilinear(const float* feature_map, const float* grid, int B, int C, int H, int W, int K, float* out,
                      v3d_stream_t stream);
+/* BEVFeatureGatherer.forward in one launch (detector/layers.py:29-47): grid coordinates from the keypoints by the module's own fp32
+ * statements (offset / pixel = its pixel_offset and base_pixel_size * STRIDES[-1], x and y), clamp, normalise, flip, then the
+ * bilinear lookup above.  keypoint_xyz (B, K, 3); out is POINT-major: out[(b * K + k) * ldo + c], ldo >= C.  Same values as
+ * v3d_bev_bilinear on the module's torch-computed grid, bit for bit. */
+int v3d_bev_gather_keypoints(const float* feature_map, const float* keypoint_xyz, int B, int C, int H, int W, int K, float offset_x,
+                             float offset_y, float pixel_x, float pixel_y, float* out, int ldo, v3d_stream_t stream);
 
 /* ---- T5: one layer of a set-abstraction shared MLP on gathered rows, exact fp32 on the matrix cores (csrc/sa_mlp.hip).
  * Replaces, per scale of pointnet2_modules.PointnetSAModuleMSG (call sites detector/model.py:58-66, detector/roi_grid_pool.py:
@@ -307,9 +313,19 @@ int v3d_bev_bilinear(const float* feature_map, const float* grid, int B, int C, 
  *                row = [xyz[i] - new_xyz[m], 0 | feat[i, :]], W (4 + Kf, Nout) row-major (row 3 multiplies the zero);
  *   later layers (idx == NULL, xyz == new_xyz == NULL): feat (rows, Kf) = the previous layer's output, N must equal M*ns, W (Kf, Nout).
  * out[row, :] = act(row @ W + bias); pool != 0: out (B*M, Nout) = max over the ns rows of each (b, m) (ns = 16 or 32).
- * Kf % 4 == 0, Nout in {16, 32, 64, 96, 128, 192, 256}; BatchNorm(eval) is folded into W / bias by the caller. */
+ * Kf % 4 == 0, Nout in {16, 32, 64, 96, 128, 192, 256}; BatchNorm(eval) is folded into W / bias by the caller.
+ * ldo = row stride of `out` in floats (0: Nout), n_store = columns stored (0: Nout): a scale's pooled rows land directly in their
+ * column block of the (B*M, C_total) keypoint feature matrix -- no torch.cat of the scales / sources (model.py:72-74). */
 int v3d_sa_mlp_layer(const float* feat, const float* xyz, const float* new_xyz, const int32_t* idx, int B, int N, int M, int ns,
-                     int Kf, const float* W, const float* bias, int Nout, int relu, int pool, float* out, v3d_stream_t stream);
+                     int Kf, const float* W, const float* bias, int Nout, int relu, int pool, float* out, int ldo, int n_store,
+                     v3d_stream_t stream);
+/* The MLP tail of PV-RCNN on a hundred rows: out[r, n] = act(sum_k A[r * lda + k] * W[k * Nout + n] + bias[n]) for r < R,
+ * n < n_store (0: Nout), out row stride ldo (0: Nout).  Replaces nn.Linear (+ bias, + ReLU) of detector/layers.py:53-73 as used by
+ * the RoI-grid reduction (roi_grid_pool.py:64-72: 3 072 -> 256 -> 256) and the refinement head (refinement.py:47-50: 256 -> 128 -> 8).
+ * W is the Linear's weight TRANSPOSED (K, Nout), Nout padded to a multiple of 16 by the caller, K % 4 == 0, A 16-byte aligned.
+ * Exact fp32 products on the matrix cores, fixed summation order (K split over 8 waves, partial tiles added in wave order). */
+int v3d_linear_rows(const float* A, int lda, int R, int K, const float* W, const float* bias, int Nout, int relu, float* out, int ldo,
+                    int n_store, v3d_stream_t stream);
 
 /* ---- Fused sparse-backbone plan: voxelizer -> [rulebooks + sparse conv layers] -> .dense().
  * The native form of the sparse half of Second.feature_extract (detector/second.py:20-24,41-46 over

@@ -478,6 +478,103 @@ def test_ball_query_grid_workspace_is_checked():
     assert rc != 0
 
 
+@pytest.mark.parametrize("r,k,nout,bias,relu", [(100, 3072, 256, False, True), (100, 256, 256, False, True), (100, 256, 128, True, True),
+                                                (100, 128, 8, True, False), (1, 4, 16, True, False), (37, 260, 40, False, False),
+                                                (300, 1028, 96, True, True)])
+def test_linear_rows_matches_fp64(r, k, nout, bias, relu):
+    """csrc/sa_mlp.hip linear_rows_kernel (the reduction / refinement MLP layers of PV-RCNN: a hundred rows, K split over the waves)
+    against the same sums in float64; strided input rows, a column block as output, an output width that is not a multiple of 16."""
+    from vision3d_amd.pointnet2.pointnet2_utils import linear_rows
+    rng = np.random.default_rng(r + k + nout)
+    npad = -(-nout // 16) * 16
+    a = rng.standard_normal((r, k + 8)).astype(np.float32)
+    w = np.zeros((k, npad), np.float32)
+    w[:, :nout] = rng.standard_normal((k, nout)) / np.sqrt(k)
+    bv = np.zeros(npad, np.float32)
+    bv[:nout] = rng.standard_normal(nout) * 0.1
+    ref = a[:, :k].astype(np.float64) @ w[:, :nout].astype(np.float64) + (bv[:nout] if bias else 0)
+    if relu:
+        ref = np.maximum(ref, 0)
+    ad = dev(a)[:, :k]  # row stride k + 8
+    got = linear_rows(ad, dev(w), dev(bv) if bias else None, relu, n_store=nout)
+    assert got.shape == (r, nout)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+    wide = torch.full((r, nout + 7), -7.0, device="cuda")
+    linear_rows(ad, dev(w), dev(bv) if bias else None, relu, out=wide[:, 3:3 + nout], n_store=nout)
+    assert torch.equal(wide[:, 3:3 + nout], got) and (wide[:, :3] == -7).all() and (wide[:, 3 + nout:] == -7).all()
+    assert torch.equal(linear_rows(ad, dev(w), dev(bv) if bias else None, relu, n_store=nout), got)  # fixed summation order
+
+
+def test_mlp_native_forward_matches_the_torch_modules():
+    """detector/layers.py MLP: eval + no_grad runs v3d_linear_rows per layer (bias / ReLU in the epilogue), otherwise nn.Sequential;
+    the permuted first layer of RoiGridPool equals permuting the activations."""
+    from vision3d_amd.detector.layers import MLP
+    torch.manual_seed(3)
+    for channels, kw in (([3072, 256, 256], {}), ([256, 128, 8], dict(bias=True, relu=[True, False]))):
+        mlp = MLP(channels, **kw).cuda().eval()
+        for lin in (m for m in mlp if isinstance(m, torch.nn.Linear)):
+            torch.nn.init.normal_(lin.weight, std=channels[0] ** -0.5)
+            if lin.bias is not None:
+                torch.nn.init.normal_(lin.bias, std=0.1)
+        x = torch.randn(2, 50, channels[0], device="cuda")
+        with torch.no_grad():
+            got = mlp(x)
+            assert mlp.native_ok(x)
+            ref = torch.nn.Sequential.forward(mlp.double(), x.double())
+            mlp.float()
+        assert got.shape == ref.shape
+        torch.testing.assert_close(got.double(), ref, rtol=2e-5, atol=2e-5 * ref.abs().max().item())
+        x.requires_grad_(True)
+        assert not mlp.native_ok(x.detach()) or torch.is_grad_enabled()
+        mlp(x).sum().backward()  # autograd on: the torch modules
+        assert x.grad is not None
+    mlp = MLP([64, 32, 16]).cuda().eval()
+    x = torch.randn(7, 64, device="cuda")
+    perm = torch.randperm(64, device="cuda")
+    with torch.no_grad():
+        torch.testing.assert_close(mlp.native_forward(x[:, perm], first_rows=perm), mlp.native_forward(x), rtol=1e-5, atol=1e-6)
+
+
+def test_fused_keypoint_features_equal_the_op_by_op_path():
+    """PV_RCNN.point_feature_extract in inference writes every set-abstraction scale and the BEV lookup into ONE point-major matrix
+    (sa_mlp `ldo`, v3d_bev_gather_keypoints) and RoI-grid pooling reads point-major rows with a permuted first reduction layer:
+    keypoint features bit-identical to the cat / transpose path (same kernels, same summation order; the BEV grid by the same fp32
+    statements), pooled features equal up to the summation order of the first reduction layer."""
+    from gpu_util import randomize_bn
+    from vision3d_amd.core import AnchorGenerator, Preprocessor
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.detector import PV_RCNN
+    cfg = second_car_cfg()
+    torch.manual_seed(0)
+    model = PV_RCNN(cfg)
+    randomize_bn(model, 2)
+    model = model.cuda().eval()
+    clouds = [synth.make_cloud(0), synth.make_cloud(1)]
+    item = Preprocessor(cfg, seed=0)(dict(points=clouds, anchors=AnchorGenerator(cfg).anchors.cuda()))
+    with torch.no_grad():
+        model.cnn.pad_generator = torch.Generator(device="cuda").manual_seed(3)
+        item = model.proposal(item)
+        kp = item["keypoints"]
+        kp[0, 5] = 1e4  # keypoints outside the map: the clamp of the grid coordinates
+        kp[1, 7, :2] = -50.0
+        fused = model.point_feature_extract(item, item["_cnn_features"], item["_bev_map"])
+        assert fused.shape == (2, 512, 2048) and fused.transpose(1, 2).is_contiguous()
+        xyz, refl = item["points"].split([3, 1], dim=-1)
+        pooled = model._pointnets([(xyz, refl), *item["_cnn_features"]], kp)
+        plain = torch.cat([*pooled, model.bev.forward_torch(item["_bev_map"], kp)], dim=1)
+        assert torch.equal(fused, plain)
+        assert torch.equal(model.bev(item["_bev_map"], kp), model.bev.forward_torch(item["_bev_map"], kp))
+        props = torch.from_numpy(np.stack([synth.make_gt_boxes(0)[:20], synth.make_gt_boxes(1)[:20]])).cuda()
+        samples = torch.rand((2, 20, cfg.GRIDPOOL.NUM_GRIDPOINTS, 3), generator=torch.Generator().manual_seed(5)).cuda()
+        got = model.roi_grid_pool(props, kp, fused, samples)
+        pts = model.roi_grid_pool.sample_gridpoints(props, samples)
+        _, chan_major = model.roi_grid_pool.pnet(kp, plain.contiguous(), pts.reshape(2, -1, 3).contiguous())
+        per_box = chan_major.reshape(2, -1, 20, pts.shape[2]).permute(0, 2, 1, 3).reshape(2, 20, -1)
+        ref = torch.nn.Sequential.forward(model.roi_grid_pool.reduction.double(), per_box.double())
+        model.roi_grid_pool.reduction.float()
+        torch.testing.assert_close(got.double(), ref, rtol=2e-5, atol=2e-5 * ref.abs().max().item())
+
+
 def test_bev_bilinear_equals_grid_sample():
     """v3d_bev_bilinear == F.grid_sample(bilinear, zeros, align_corners=True) on a (B, 1, K, 2) grid, including points on and
     beyond the border (the gatherer clamps, the kernel must still zero-pad like torch)."""

@@ -797,6 +797,22 @@ extern "C" int v3d_ball_query_grid(const float* xyz, const float* new_xyz, int B
 // BEVFeatureGatherer calls it (vision3d/detector/layers.py:29-47): out (B, C, K).  torch's generic kernel walks the channels of
 // a point serially in one thread (153 us for 2 048 keypoints x 128 channels at 200 x 176); here a thread = (point, channel),
 // same tap order and weights (nw, ne, sw, se; weight = product of the distances to the opposite corner).
+// one lookup: the four taps of (gx, gy) in plane `plane`, torch's order and weights
+__device__ __forceinline__ float bev_tap4(const float* __restrict__ plane, int H, int W, float gx, float gy) {
+  const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1), iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+  const float nw = ((float)x1 - ix) * ((float)y1 - iy), ne = (ix - x0f) * ((float)y1 - iy);
+  const float sw = ((float)x1 - ix) * (iy - y0f), se = (ix - x0f) * (iy - y0f);
+  auto tap = [&](int y, int x) { return (y >= 0 && y < H && x >= 0 && x < W) ? plane[(size_t)y * W + x] : 0.f; };
+  float v = 0.f;
+  v += tap(y0, x0) * nw;
+  v += tap(y0, x1) * ne;
+  v += tap(y1, x0) * sw;
+  v += tap(y1, x1) * se;
+  return v;
+}
+
 __global__ __launch_bounds__(V3D_BLOCK) void bev_bilinear_kernel(const float* __restrict__ fmap, const float* __restrict__ grid,
                                                                  int C, int H, int W, int K, long long total,
                                                                  float* __restrict__ out) {
@@ -805,19 +821,7 @@ __global__ __launch_bounds__(V3D_BLOCK) void bev_bilinear_kernel(const float* __
     const long long bc = t / K;
     const int b = (int)(bc / C);
     const float gx = grid[((size_t)b * K + k) * 2], gy = grid[((size_t)b * K + k) * 2 + 1];
-    const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1), iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
-    const float x0f = floorf(ix), y0f = floorf(iy);
-    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
-    const float nw = ((float)x1 - ix) * ((float)y1 - iy), ne = (ix - x0f) * ((float)y1 - iy);
-    const float sw = ((float)x1 - ix) * (iy - y0f), se = (ix - x0f) * (iy - y0f);
-    const float* plane = fmap + (size_t)bc * H * W;
-    auto tap = [&](int y, int x) { return (y >= 0 && y < H && x >= 0 && x < W) ? plane[(size_t)y * W + x] : 0.f; };
-    float v = 0.f;
-    v += tap(y0, x0) * nw;
-    v += tap(y0, x1) * ne;
-    v += tap(y1, x0) * sw;
-    v += tap(y1, x1) * se;
-    out[t] = v;
+    out[t] = bev_tap4(fmap + (size_t)bc * H * W, H, W, gx, gy);
   }
 }
 
@@ -829,6 +833,44 @@ extern "C" int v3d_bev_bilinear(const float* feature_map, const float* grid, int
   if (!feature_map || !grid || !out) return V3D_EINVAL;
   hipLaunchKernelGGL(bev_bilinear_kernel, dim3((int)std::min<long long>(v3d_ceil_div(total, V3D_BLOCK), 8192)), dim3(V3D_BLOCK), 0,
                      (hipStream_t)stream, feature_map, grid, C, H, W, K, total, out);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+// BEVFeatureGatherer.forward in ONE launch (vision3d/detector/layers.py:29-47): the grid coordinates are computed from the keypoints
+// with the module's own fp32 statements, one IEEE operation each (-ffp-contract=off, correctly rounded division) --
+//     frac = (xy - offset) / pixel;  frac = min(max(frac, 0), [W - 1, H - 1]);  g = 2 * (frac / ([W - 1, H - 1] - 1)) - 1;  g = g.flip(-1)
+// (the flip and the "- 1" in the divisor are the reference's) -- and the lookup follows.  A thread = (keypoint,
+// channel), channel fastest: out is POINT-major, out[(b * K + k) * ldo + c] -- a column block of the keypoint feature rows the
+// RoI-grid pooling gathers.  Ten elementwise torch launches + the lookup before.
+__global__ __launch_bounds__(V3D_BLOCK) void bev_gather_keypoints_kernel(const float* __restrict__ fmap, const float* __restrict__ xyz,
+                                                                         int C, int H, int W, int K, long long total, float off_x,
+                                                                         float off_y, float pix_x, float pix_y, float* __restrict__ out,
+                                                                         int ldo) {
+  const float lim_x = (float)(W - 1), lim_y = (float)(H - 1);
+  for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * V3D_BLOCK) {
+    const int c = (int)(t % C);
+    const long long bk = t / C;
+    const int b = (int)(bk / K);
+    const float x = xyz[bk * 3], y = xyz[bk * 3 + 1];
+    float fx = (x - off_x) / pix_x, fy = (y - off_y) / pix_y;
+    // torch.clamp(min=0) then torch.min(., limit): both propagate NaN
+    fx = fx != fx ? fx : fminf(fmaxf(fx, 0.f), lim_x);
+    fy = fy != fy ? fy : fminf(fmaxf(fy, 0.f), lim_y);
+    const float nx = 2.f * (fx / (lim_x - 1.f)) - 1.f, ny = 2.f * (fy / (lim_y - 1.f)) - 1.f;
+    out[(size_t)bk * ldo + c] = bev_tap4(fmap + ((size_t)b * C + c) * H * W, H, W, /*flipped:*/ ny, nx);
+  }
+}
+
+extern "C" int v3d_bev_gather_keypoints(const float* feature_map, const float* keypoint_xyz, int B, int C, int H, int W, int K,
+                                        float offset_x, float offset_y, float pixel_x, float pixel_y, float* out, int ldo,
+                                        v3d_stream_t stream) {
+  if (B < 0 || C < 1 || H < 1 || W < 1 || K < 0 || ldo < C) return V3D_EINVAL;
+  const long long total = (long long)B * C * K;
+  if (total == 0) return V3D_OK;
+  if (!feature_map || !keypoint_xyz || !out) return V3D_EINVAL;
+  hipLaunchKernelGGL(bev_gather_keypoints_kernel, dim3((int)std::min<long long>(v3d_ceil_div(total, V3D_BLOCK), 8192)), dim3(V3D_BLOCK), 0,
+                     (hipStream_t)stream, feature_map, keypoint_xyz, C, H, W, K, total, offset_x, offset_y, pixel_x, pixel_y, out, ldo);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
 }

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
                                                                      const int* __restrict__ idx, int N, int M, int ns,
                                                                      int Kf, long long rows, const float* __restrict__ W,
                                                                      const float* __restrict__ bias, int relu, int pool,
-                                                                     float* __restrict__ out) {
+                                                                     float* __restrict__ out, int ldo, int n_store) {
   constexpr int NOUT = NB * 16;
   constexpr int LDW = NOUT + 4;  // row stride of the LDS weight chunk: the four k-rows a wave reads at once hit disjoint banks
   __shared__ float Ws[SAM_KC * LDW];
@@ -124,14 +124,14 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
         float v = acc[t][j][i] + bj;
         if (relu) v = fmaxf(v, 0.f);
         if (pool) mx = fmaxf(mx, v);
-        else if (rowb + i < rows) out[(size_t)(rowb + i) * NOUT + j * 16 + r] = v;
+        else if (rowb + i < rows && j * 16 + r < n_store) out[(size_t)(rowb + i) * ldo + j * 16 + r] = v;
       }
       if (pool) {
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));  // max over the tile's 16 rows, in every lane
         if (ns == 16) {
           const long long g = tile0 + t;  // one tile = one (b, m) group
-          if (q == 0 && g * 16 < rows) out[(size_t)g * NOUT + j * 16 + r] = mx;
+          if (q == 0 && g * 16 < rows && j * 16 + r < n_store) out[(size_t)g * ldo + j * 16 + r] = mx;
         } else {
           pooled[j] = fmaxf(pooled[j], mx);  // ns == 32: the wave's two tiles are one group
         }
@@ -141,17 +141,21 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
   if (pool && ns == 32 && q == 0 && tile0 * 16 < rows) {
     const long long g = tile0 / 2;
 #pragma unroll
-    for (int j = 0; j < NB; j++) out[(size_t)g * NOUT + j * 16 + r] = pooled[j];
+    for (int j = 0; j < NB; j++)
+      if (j * 16 + r < n_store) out[(size_t)g * ldo + j * 16 + r] = pooled[j];
   }
 }
 
 extern "C" int v3d_sa_mlp_layer(const float* feat, const float* xyz, const float* new_xyz, const int32_t* idx, int B, int N, int M,
                                 int ns, int Kf, const float* W, const float* bias, int Nout, int relu, int pool, float* out,
-                                v3d_stream_t stream) {
+                                int ldo, int n_store, v3d_stream_t stream) {
   if (B < 0 || N < 1 || M < 0 || ns < 1 || Kf < 0 || (Kf & 3) || Nout < 16 || (Nout & 15) || !W || !out) return V3D_EINVAL;
   if ((xyz == nullptr) != (new_xyz == nullptr)) return V3D_EINVAL;
   if (!feat && Kf > 0) return V3D_EINVAL;
   if (pool && ns != 16 && ns != 32) return V3D_EUNSUPPORTED;
+  if (n_store <= 0 || n_store > Nout) n_store = Nout;  // columns [0, n_store) are stored (the padded tail of Nout is not)
+  if (ldo <= 0) ldo = Nout;                            // row stride of `out` in floats (a column block of a wider matrix)
+  if (ldo < n_store) return V3D_EINVAL;
   const long long rows = (long long)B * M * ns;
   if (rows == 0) return V3D_OK;
   if (!idx && (long long)B * N != rows) return V3D_EINVAL;  // identity rows: the input IS the (B*M*ns, Kf) matrix
@@ -161,11 +165,94 @@ extern "C" int v3d_sa_mlp_layer(const float* feat, const float* xyz, const float
 #define SAM_CASE(NBV)                                                                                                      \
   if (Nout == NBV * 16) {                                                                                                  \
     hipLaunchKernelGGL(sa_mlp_layer_kernel<NBV>, dim3(blocks), dim3(SAM_WAVES * 64), 0, st, feat, xyz, new_xyz, idx, N, M, \
-                       ns, Kf, rows, W, bias, relu, pool, out);                                                            \
+                       ns, Kf, rows, W, bias, relu, pool, out, ldo, n_store);                                                            \
     V3D_CHECK_LAUNCH();                                                                                                    \
     return V3D_OK;                                                                                                         \
   }
   SAM_CASE(1) SAM_CASE(2) SAM_CASE(4) SAM_CASE(6) SAM_CASE(8) SAM_CASE(12) SAM_CASE(16)
 #undef SAM_CASE
   return V3D_EUNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------ few rows x wide K: the MLP tail
+// PV-RCNN's last matrices have a hundred rows (one per proposal): RoI-grid reduction 3 072 -> 256 -> 256 (detector/roi_grid_pool.py:
+// 64-72), refinement 256 -> 128 -> 8 (detector/refinement.py:47-50) -- nn.Linear upstream, i.e. four library GEMM launches (72 us per
+// frame in round 5's trace: 157 MFLOP).  sa_mlp_layer_kernel splits ROWS over workgroups (one workgroup here); this kernel splits
+// the 16-column blocks over workgroups and K over the 8 waves of a workgroup (contiguous K ranges, partial tiles summed in wave
+// order through LDS: a fixed summation order), exact fp32 on v_mfma_f32_16x16x4_f32 like the layers above.  Next A / W fragments are
+// requested before the current ones are multiplied.
+//   out[r, n] = act( sum_k A[r * lda + k] * W[k * Nout + n] + bias[n] ),  r < R, n < n_store;  K % 4 == 0, Nout % 16 == 0
+#define LIN_WAVES 8
+#define LIN_TPW 2  // 16-row tiles per workgroup (every wave multiplies both for its K range)
+__global__ __launch_bounds__(LIN_WAVES * 64) void linear_rows_kernel(const float* __restrict__ A, int lda, int R, int K,
+                                                                    const float* __restrict__ W, const float* __restrict__ bias,
+                                                                    int Nout, int relu, float* __restrict__ out, int ldo, int n_store) {
+  __shared__ float part[LIN_WAVES][LIN_TPW][4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int col0 = blockIdx.x * 16, row0 = blockIdx.y * (16 * LIN_TPW);
+  const int kper = ((K + 16 * LIN_WAVES - 1) / (16 * LIN_WAVES)) * 16;  // K range of a wave: a multiple of 16
+  const int kb = wave * kper, ke = min(K, kb + kper);
+  const float* arow[LIN_TPW];
+#pragma unroll
+  for (int t = 0; t < LIN_TPW; t++) arow[t] = row0 + t * 16 + r < R ? A + (size_t)(row0 + t * 16 + r) * lda : nullptr;
+  const float* wcol = W + col0 + r;
+  auto load = [&](int k0, f32x4 (&a)[LIN_TPW], float (&bv)[4]) {
+    const int kg = k0 + 4 * q;
+#pragma unroll
+    for (int t = 0; t < LIN_TPW; t++) a[t] = (arow[t] && kg < ke) ? *reinterpret_cast<const f32x4*>(arow[t] + kg) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; s++) bv[s] = kg + s < ke ? wcol[(size_t)(kg + s) * Nout] : 0.f;
+  };
+  f32x4 acc[LIN_TPW];
+#pragma unroll
+  for (int t = 0; t < LIN_TPW; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 a0[LIN_TPW], a1[LIN_TPW];
+  float b0[4], b1[4];
+  if (kb < ke) load(kb, a0, b0);
+  for (int k0 = kb; k0 < ke; k0 += 32) {
+    if (k0 + 16 < ke) load(k0 + 16, a1, b1);
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+      for (int t = 0; t < LIN_TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t][s], b0[s], acc[t], 0, 0, 0);
+    if (k0 + 16 < ke) {
+      if (k0 + 32 < ke) load(k0 + 32, a0, b0);
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int t = 0; t < LIN_TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t][s], b1[s], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < LIN_TPW; t++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) part[wave][t][i][lane] = acc[t][i];
+  __syncthreads();
+  // D[row = 4 q + i][col = r]: the 2 x 4 x 64 values of the workgroup, one per thread
+  {
+    const int t = tid >> 8, i = (tid >> 6) & 3, l = tid & 63;
+    float v = part[0][t][i][l];
+#pragma unroll
+    for (int w = 1; w < LIN_WAVES; w++) v += part[w][t][i][l];
+    const int row = row0 + t * 16 + 4 * (l >> 4) + i, col = col0 + (l & 15);
+    if (bias) v += bias[col];
+    if (relu) v = fmaxf(v, 0.f);
+    if (row < R && col < n_store) out[(size_t)row * ldo + col] = v;
+  }
+}
+
+extern "C" int v3d_linear_rows(const float* A, int lda, int R, int K, const float* W, const float* bias, int Nout, int relu, float* out,
+                               int ldo, int n_store, v3d_stream_t stream) {
+  if (R < 0 || K < 4 || (K & 3) || lda < K || (lda & 3) || Nout < 16 || (Nout & 15)) return V3D_EINVAL;
+  if (R == 0) return V3D_OK;
+  if (!A || !W || !out || ((uintptr_t)A & 15)) return V3D_EINVAL;
+  if (n_store <= 0 || n_store > Nout) n_store = Nout;
+  if (ldo <= 0) ldo = Nout;
+  if (ldo < n_store) return V3D_EINVAL;
+  static_assert(LIN_WAVES * 64 == LIN_TPW * 4 * 64, "one output value per thread in the epilogue");
+  hipLaunchKernelGGL(linear_rows_kernel, dim3(Nout / 16, v3d_ceil_div(R, 16 * LIN_TPW)), dim3(LIN_WAVES * 64), 0, (hipStream_t)stream, A, lda, R,
+                     K, W, bias, Nout, relu, out, ldo, n_store);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
 }

@@ -56,11 +56,47 @@ class BEVFeatureGatherer(nn.Module):
     def compute_bev_indices(self, keypoint_xyz, H, W):
         return self._to_grid(keypoint_xyz[:, None, :, :2], H, W)
 
+    def _native(self, feature_map, keypoint_xyz):
+        return (feature_map.is_cuda and feature_map.dtype == torch.float32 and feature_map.is_contiguous()
+                and keypoint_xyz.dtype == torch.float32
+                and not (torch.is_grad_enabled() and (feature_map.requires_grad or keypoint_xyz.requires_grad)))
+
+    def gather_point_major(self, feature_map, keypoint_xyz, out_pm=None):
+        """The whole forward in ONE launch (csrc/pointops.hip v3d_bev_gather_keypoints: the statements of `_to_grid` on the device, one
+        IEEE operation each, then the bilinear lookup): -> (B, K, C) POINT-major, or written into `out_pm` (a (B, K, >= C) view with
+        unit channel stride, frames back to back: a column block of the keypoint feature matrix).  Same values as `forward`."""
+        from .. import _lib as L
+        b, c, height, width = feature_map.shape
+        xyz = keypoint_xyz.contiguous()
+        k = xyz.shape[1]
+        consts = self.__dict__.setdefault("_host_consts", {})
+        key = (str(feature_map.device),)
+        if key not in consts:  # the module's own fp32 arithmetic, once, on the host: pixel = base_pixel_size * STRIDES[-1]
+            pixel = (self.base_pixel_size.detach().cpu().float() * self.cfg.STRIDES[-1]).tolist()
+            consts[key] = (self.pixel_offset.detach().cpu().float().tolist(), pixel)
+        (off_x, off_y), (pix_x, pix_y) = consts[key]
+        if out_pm is None:
+            out_pm = torch.empty((b, k, c), dtype=torch.float32, device=feature_map.device)
+        if out_pm.shape[:2] != (b, k) or out_pm.shape[2] < c or out_pm.stride(2) != 1 or out_pm.stride(0) != k * out_pm.stride(1):
+            raise RuntimeError("gather_point_major: out_pm must be a (B, K, >= C) view with unit channel stride and frames back to back")
+        with torch.cuda.device(feature_map.device):
+            L.check(L.lib().v3d_bev_gather_keypoints(L.ptr(feature_map), L.ptr(xyz), b, c, height, width, k, off_x, off_y, pix_x, pix_y,
+                                                     L.ptr(out_pm), out_pm.stride(1), L.stream_ptr()), "bev_gather_keypoints")
+        return out_pm[:, :, :c]
+
     def forward(self, feature_map, keypoint_xyz):
+        if self._native(feature_map, keypoint_xyz):
+            return self.gather_point_major(feature_map, keypoint_xyz).transpose(1, 2)  # (B, C, K), a view of point-major rows
         height, width = feature_map.shape[-2:]
         grid = self._to_grid(keypoint_xyz[:, None, :, :2], height, width)
-        if (feature_map.is_cuda and feature_map.dtype == torch.float32 and feature_map.is_contiguous()
-                and not (torch.is_grad_enabled() and (feature_map.requires_grad or grid.requires_grad))):
+        return F.grid_sample(feature_map, grid, align_corners=True).squeeze(2)
+
+    def forward_torch(self, feature_map, keypoint_xyz):
+        """The reference's statements op by op (torch elementwise launches + v3d_bev_bilinear / grid_sample): the cross-check of the
+        fused launch in the tests."""
+        height, width = feature_map.shape[-2:]
+        grid = self._to_grid(keypoint_xyz[:, None, :, :2], height, width)
+        if self._native(feature_map, keypoint_xyz):
             from .. import _lib as L  # the same lookup, a thread per (keypoint, channel): csrc/pointops.hip
             b, c = feature_map.shape[:2]
             k = grid.shape[2]
@@ -99,3 +135,65 @@ class MLP(nn.Sequential):
             if use_relu:
                 layers[f"relu_{i}"] = nn.ReLU(inplace=True)
         super().__init__(layers)
+
+    # ---- inference on csrc/sa_mlp.hip linear_rows_kernel: the reduction / refinement MLPs have a hundred rows (one per proposal) and
+    #      ran as four library GEMM launches + bias / ReLU launches; one launch per layer, exact fp32 products, fixed summation order
+    def native_ok(self, x):
+        if self.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32:
+            return False
+        mods = list(self)
+        if any(not isinstance(m, (nn.Linear, nn.ReLU)) for m in mods):  # (BatchNorm1d layers: the torch modules)
+            return False
+        return all(m.in_features % 4 == 0 for m in mods if isinstance(m, nn.Linear))
+
+    def _packed(self, first_rows=None):
+        """[(W^T (K, Nout padded to 16), bias padded or None, relu, Nout)] per Linear, cached until a parameter changes.  `first_rows`:
+        a permutation of the FIRST layer's input features (the caller holds them in another order: RoiGridPool's point-major rows)."""
+        mods = list(self)
+        lins = [m for m in mods if isinstance(m, nn.Linear)]
+        stamp = tuple((t.data_ptr(), t._version) for l in lins for t in (l.weight, l.bias) if t is not None)
+        cache = self.__dict__.setdefault("_pack_cache", {})
+        key = None if first_rows is None else (first_rows.data_ptr(), first_rows.numel())
+        if key in cache and cache[key][0] == stamp:
+            return cache[key][1]
+        packed, k_pad = [], None
+        with torch.no_grad():
+            for i, m in enumerate(mods):
+                if not isinstance(m, nn.Linear):
+                    continue
+                wt = m.weight.detach().float().t()  # (K, Nout)
+                if not packed and first_rows is not None:
+                    wt = wt[first_rows]
+                nout = m.out_features
+                npad = -(-nout // 16) * 16
+                kk = wt.shape[0] if k_pad is None else k_pad  # (a padded predecessor hands over zero columns: zero rows here)
+                full = wt.new_zeros((kk, npad))
+                full[:wt.shape[0], :nout] = wt
+                bias = None
+                if m.bias is not None:
+                    bias = wt.new_zeros(npad)
+                    bias[:nout] = m.bias.detach().float()
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                packed.append((full.contiguous(), bias, relu, nout))
+                k_pad = npad
+        cache[key] = (stamp, packed)
+        return packed
+
+    def native_forward(self, x, first_rows=None):
+        """x (..., K) -> (..., Nout_last) through v3d_linear_rows, one launch per Linear (+ bias + ReLU)."""
+        from ..pointnet2.pointnet2_utils import linear_rows
+        lead = x.shape[:-1]
+        a = x.reshape(-1, x.shape[-1])
+        if a.stride(1) != 1:
+            a = a.contiguous()
+        packed = self._packed(first_rows)
+        for li, (w, bias, relu, nout) in enumerate(packed):
+            # intermediate layers keep their padded width (zero columns: the next layer's zero rows); the last one stores nout columns
+            a = linear_rows(a, w, bias, relu, n_store=nout if li == len(packed) - 1 else None)
+        return a.reshape(*lead, a.shape[-1])
+
+    def forward(self, x):
+        if self.native_ok(x):
+            return self.native_forward(x)
+        return super().forward(x)
+

@@ -69,8 +69,30 @@ class PV_RCNN(nn.Module):
         """Keypoint features: set abstraction over every source concatenated with the BEV lookup (B, C_total, K)."""
         keypoints = item["keypoints"]
         xyz, reflectance = item["points"].split([3, 1], dim=-1)
-        pooled = self._pointnets([(xyz, reflectance), *cnn_features], keypoints)
+        sources = [(xyz, reflectance), *cnn_features]
+        if self._fused_features_ok(sources, bev_map, keypoints):
+            return self._point_features_fused(sources, bev_map, keypoints)
+        pooled = self._pointnets(sources, keypoints)
         return torch.cat([*pooled, self.bev(bev_map, keypoints)], dim=1)
+
+    # ---- inference: ONE (B, K, C_total) point-major matrix, every set-abstraction scale and the BEV lookup write their column block
+    #      (csrc/sa_mlp.hip `ldo`, csrc/pointops.hip v3d_bev_gather_keypoints): no torch.cat per module, per source and at the end, no
+    #      transposes to channel-major and back -- RoI-grid pooling gathers point-major rows.  The return value is the (B, C_total, K)
+    #      VIEW of that matrix (the reference's layout, model.py:72-74); same values as the op-by-op path.
+    def _fused_features_ok(self, sources, bev_map, keypoints):
+        return (not torch.is_grad_enabled() and not self.training and keypoints.is_cuda and keypoints.dtype == torch.float32
+                and all(p._fusable(f) for p, (_, f) in zip(self.pnets, sources)) and self.bev._native(bev_map, keypoints))
+
+    def _point_features_fused(self, sources, bev_map, keypoints):
+        b, k = keypoints.shape[:2]
+        widths = [sum(p.out_channels()) for p in self.pnets] + [bev_map.shape[1]]
+        feats = torch.empty((b, k, sum(widths)), dtype=torch.float32, device=keypoints.device)
+        col = 0
+        for pnet, (xyz, features), w in zip(self.pnets, sources, widths):
+            pnet.fused_forward(xyz, features, keypoints, out_pm=feats[:, :, col:col + w])
+            col += w
+        self.bev.gather_point_major(bev_map, keypoints, out_pm=feats[:, :, col:])
+        return feats.transpose(1, 2)
 
     def proposal(self, item):
         """Stage 1.  Adds keypoints, P_cls, P_reg (and the CNN outputs under `_cnn_features` / `_bev_map` for the

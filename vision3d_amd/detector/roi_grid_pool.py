@@ -52,6 +52,24 @@ class RoiGridPool(nn.Module):
         b, n = proposals.shape[:2]
         points = self.sample_gridpoints(proposals, samples)
         m = points.shape[2]
-        _, pooled = self.pnet(keypoint_xyz, keypoint_features, points.reshape(b, n * m, 3).contiguous())  # (b, C, n*m)
+        new_xyz = points.reshape(b, n * m, 3).contiguous()
+        pm = keypoint_features.transpose(1, 2)  # (b, K, C): contiguous when the features came from PV_RCNN's fused extraction
+        if self.pnet._fusable(pm) and self.reduction.native_ok(pm):
+            # inference: the pooled rows stay point-major -- (b, n * m, C) read as (b, n, m * C) IS the per-box row, in (grid point,
+            # channel) order instead of the reference's (channel, grid point): the first reduction layer's weight rows are permuted
+            # once instead of the activations every frame (roi_grid_pool.py:64-72)
+            pooled = self.pnet.fused_forward(keypoint_xyz, pm, new_xyz)  # (b, n * m, C)
+            c = pooled.shape[2]
+            return self.reduction.native_forward(pooled.reshape(b, n, m * c), first_rows=self._first_rows(m, c, pooled.device))
+        _, pooled = self.pnet(keypoint_xyz, keypoint_features, new_xyz)  # (b, C, n*m)
         per_box = pooled.reshape(b, -1, n, m).permute(0, 2, 1, 3).reshape(b, n, -1)
         return self.reduction(per_box)
+
+    def _first_rows(self, m, c, device):
+        """Row j * C + ch of the point-major per-box vector is feature ch * m + j of the reference's (channel, grid point) order."""
+        cache = self.__dict__.setdefault("_rows_cache", {})
+        key = (m, c, str(device))
+        if key not in cache:
+            j, ch = torch.meshgrid(torch.arange(m), torch.arange(c), indexing="ij")
+            cache[key] = (ch * m + j).reshape(-1).to(device)
+        return cache[key]

@@ -101,29 +101,43 @@ class PointnetSAModuleMSG(nn.Module):
         cache[k] = (stamp, packed)
         return packed
 
-    def fused_forward(self, xyz, features_pm, new_xyz):
-        """features_pm (B, N, C) POINT-major -> (B, sum(mlps[k][-1]), M)."""
+    def out_channels(self):
+        """Output channels per scale (the last convolution of every scale's MLP)."""
+        return [[mod for mod in mlp if isinstance(mod, nn.Conv2d)][-1].out_channels for mlp in self.mlps]
+
+    def fused_forward(self, xyz, features_pm, new_xyz, out_pm=None):
+        """features_pm (B, N, C) POINT-major -> (B, M, sum(mlps[k][-1])) POINT-major: every scale's last layer writes its pooled rows
+        straight into its column block (no torch.cat of the scales).  `out_pm`: a (B, M, >= that many) view with unit channel stride
+        to write into -- a column block of the caller's keypoint feature matrix (detector/model.py point_feature_extract)."""
         b, n, c = features_pm.shape
         m = new_xyz.shape[1]
         kf = -(-c // 4) * 4
         feat = features_pm.contiguous() if kf == c else torch.nn.functional.pad(features_pm, (0, kf - c)).contiguous()
         xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
-        outs = []
-        if len(self.groupers) == 2:  # both scales in one scan of the database
+        couts = self.out_channels()
+        if out_pm is None:
+            out_pm = torch.empty((b, m, sum(couts)), dtype=torch.float32, device=feat.device)
+        if (out_pm.shape[:2] != (b, m) or out_pm.shape[2] < sum(couts) or out_pm.stride(2) != 1 or out_pm.stride(0) != m * out_pm.stride(1)):
+            raise RuntimeError("fused_forward: out_pm must be a (B, M, >= C_out) view with unit channel stride and frames back to back")
+        rows = out_pm.as_strided((b * m, out_pm.shape[2]), (out_pm.stride(1), 1), out_pm.storage_offset())
+        if len(self.groupers) == 2:  # both scales in one pass over the database
             ga, gb = self.groupers
             neighbours = PU.ball_query_pair(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, new_xyz)
         else:
             neighbours = [PU.ball_query(g.radius, g.nsample, xyz, new_xyz) for g in self.groupers]
+        col = 0
         for k, grouper in enumerate(self.groupers):
             layers = self._packed_layers(k)
             ns = grouper.nsample
             idx = neighbours[k]
-            x = PU.sa_mlp_layer(feat, layers[0][0], layers[0][1], True, len(layers) == 1, xyz=xyz, new_xyz=new_xyz, idx=idx)
+            last = dict(out=rows[:, col:col + couts[k]], n_store=couts[k])
+            x = PU.sa_mlp_layer(feat, layers[0][0], layers[0][1], True, len(layers) == 1, xyz=xyz, new_xyz=new_xyz, idx=idx,
+                                **(last if len(layers) == 1 else {}))
             for li in range(1, len(layers)):
-                x = PU.sa_mlp_layer(x, layers[li][0], layers[li][1], True, li == len(layers) - 1, groups=(b, m, ns))
-            cout = [mod for mod in self.mlps[k] if isinstance(mod, nn.Conv2d)][-1].out_channels
-            outs.append(x.view(b, m, -1)[:, :, :cout])
-        return torch.cat(outs, dim=2).transpose(1, 2).contiguous()
+                x = PU.sa_mlp_layer(x, layers[li][0], layers[li][1], True, li == len(layers) - 1, groups=(b, m, ns),
+                                    **(last if li == len(layers) - 1 else {}))
+            col += couts[k]
+        return out_pm[:, :, :col]
 
     def forward(self, xyz, features=None, new_xyz=None, features_pm=None):
         """xyz (B,N,3), features (B,C,N), new_xyz (B,M,3) -> (new_xyz, (B, sum(mlps[k][-1]), M)).  `features_pm` (B,N,C) may
@@ -135,7 +149,7 @@ class PointnetSAModuleMSG(nn.Module):
             features = features_pm.transpose(1, 2).contiguous()
         if self._fusable(features if features is not None else features_pm):
             pm = features_pm if features_pm is not None else features.transpose(1, 2)
-            return new_xyz, self.fused_forward(xyz, pm, new_xyz)
+            return new_xyz, self.fused_forward(xyz, pm, new_xyz).transpose(1, 2)  # (a view: the kernels write point-major rows)
         outs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             g = mlp(grouper(xyz, new_xyz, features))  # (B, C', M, ns)

@@ -154,13 +154,23 @@ class QueryAndGroup(nn.Module):
         return torch.cat([grouped_xyz, grouped], dim=1) if self.use_xyz else grouped
 
 
-def sa_mlp_layer(feat, w, bias, relu=True, pool=False, xyz=None, new_xyz=None, idx=None, groups=None):
+def _strided_rows(name, out, rows, cols):
+    """(rows, >= cols) float32 view with unit column stride -> (tensor, row stride): a column block of a wider matrix."""
+    if (out.dtype != torch.float32 or out.dim() != 2 or out.shape[0] != rows or out.shape[1] < cols or out.stride(1) != 1
+            or out.stride(0) < cols):
+        raise RuntimeError(f"{name}: `out` must be a ({rows}, >= {cols}) float32 view with contiguous columns")
+    return out, out.stride(0)
+
+
+def sa_mlp_layer(feat, w, bias, relu=True, pool=False, xyz=None, new_xyz=None, idx=None, groups=None, out=None, n_store=None):
     """One layer of a set-abstraction shared MLP on the matrix cores (csrc/sa_mlp.hip, exact fp32 MFMA).
 
     first layer:  feat (B, N, Kf) point-major, xyz (B, N, 3), new_xyz (B, M, 3), idx (B, M, ns) int32;
                   row (b, m, s) = [xyz[i] - new_xyz[m], 0 | feat[i]] with i = idx[b, m, s], w is (4 + Kf, Nout)
     later layers: feat (B*M*ns, Kf) (the previous layer's output), groups = (B, M, ns), w is (Kf, Nout)
-    Kf % 4 == 0, Nout % 16 == 0.  Returns (B*M*ns, Nout), or (B*M, Nout) = max over the ns rows of a group with pool=True."""
+    Kf % 4 == 0, Nout % 16 == 0.  Returns (B*M*ns, Nout), or (B*M, Nout) = max over the ns rows of a group with pool=True.
+    `out`: a (rows, >= n_store) view with unit column stride to write into (e.g. a column block of the keypoint feature matrix);
+    `n_store`: only the first n_store output columns are stored (default Nout)."""
     L.require_gpu("sa_mlp_layer", feat, w)
     f, wf = L.as_f32("sa_mlp_layer", feat), L.as_f32("sa_mlp_layer", w)
     bf = None if bias is None else L.as_f32("sa_mlp_layer", bias)
@@ -177,8 +187,37 @@ def sa_mlp_layer(feat, w, bias, relu=True, pool=False, xyz=None, new_xyz=None, i
     nout = wf.shape[1]
     if wf.shape[0] != kf + (4 if idx is not None else 0):
         raise RuntimeError("sa_mlp_layer: weight rows do not match the input width")
-    out = torch.empty((b * m if pool else b * m * ns, nout), dtype=torch.float32, device=f.device)
+    rows = b * m if pool else b * m * ns
+    cols = nout if n_store is None else int(n_store)
+    if out is None:
+        out, ldo = torch.empty((rows, cols), dtype=torch.float32, device=f.device), cols
+    else:
+        out, ldo = _strided_rows("sa_mlp_layer", out, rows, cols)
     with torch.cuda.device(f.device):
         L.check(L.lib().v3d_sa_mlp_layer(L.ptr(f), L.ptr(x), L.ptr(q), L.ptr(ii), b, n, m, ns, kf, L.ptr(wf), L.ptr(bf), nout,
-                                         int(bool(relu)), int(bool(pool)), L.ptr(out), L.stream_ptr()), "sa_mlp_layer")
+                                         int(bool(relu)), int(bool(pool)), L.ptr(out), ldo, cols, L.stream_ptr()), "sa_mlp_layer")
+    return out
+
+
+def linear_rows(a, w, bias=None, relu=False, out=None, n_store=None):
+    """act(a @ w + bias) for a matrix of FEW rows (csrc/sa_mlp.hip linear_rows_kernel: columns over workgroups, K over the waves):
+    a (R, K) float32 with unit column stride (rows may be strided), w (K, Nout) = the nn.Linear weight transposed, Nout % 16 == 0,
+    K % 4 == 0.  -> (R, n_store) (default Nout), or written into `out` (a (R, >= n_store) view with unit column stride)."""
+    L.require_gpu("linear_rows", a, w)
+    wf = L.as_f32("linear_rows", w)
+    bf = None if bias is None else L.as_f32("linear_rows", bias)
+    if a.dtype != torch.float32 or a.dim() != 2 or a.stride(1) != 1:
+        raise RuntimeError("linear_rows: `a` must be a 2-D float32 matrix with contiguous columns")
+    r, k = a.shape
+    nout = wf.shape[1]
+    if wf.shape[0] != k:
+        raise RuntimeError("linear_rows: weight rows do not match the input width")
+    cols = nout if n_store is None else int(n_store)
+    if out is None:
+        out, ldo = torch.empty((r, cols), dtype=torch.float32, device=a.device), cols
+    else:
+        out, ldo = _strided_rows("linear_rows", out, r, cols)
+    with torch.cuda.device(a.device):
+        L.check(L.lib().v3d_linear_rows(L.ptr(a), a.stride(0) if r > 1 else max(a.stride(0), k), r, k, L.ptr(wf), L.ptr(bf), nout,
+                                        int(bool(relu)), L.ptr(out), ldo, cols, L.stream_ptr()), "linear_rows")
     return out
