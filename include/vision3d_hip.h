@@ -291,6 +291,16 @@ int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M, 
 size_t v3d_ball_query_grid_workspace(int B, int N);
 int v3d_ball_query_grid(const float* xyz, const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a, int32_t* idx_a,
                         float radius_b, int nsample_b, int32_t* idx_b, void* workspace, size_t workspace_bytes, v3d_stream_t stream);
+/* The two halves on their own.  build: the grids of up to 8 databases in ONE launch (a workgroup per database and frame; host arrays
+ * of n_db entries: xyz[i] (B, N[i], 3), radius_max[i] = the largest radius that will be asked of grid i, workspace[i] of
+ * v3d_ball_query_grid_workspace(B, N[i]) bytes) -- the six databases of a PV-RCNN frame (raw points, four voxel levels, keypoints:
+ * detector/model.py:58-66, roi_grid_pool.py:64-72) cost one launch instead of six.  query: any radii <= radius_max of the build,
+ * as often as wanted; same results as v3d_ball_query.  V3D_EUNSUPPORTED: N too large for the query's LDS bitmaps (use the scan). */
+int v3d_ball_query_grid_build(int n_db, const float* const* xyz, const int32_t* N, const float* radius_max, void* const* workspace,
+                              const size_t* workspace_bytes, int B, v3d_stream_t stream);
+int v3d_ball_query_grid_query(const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a, int32_t* idx_a,
+                              float radius_b, int nsample_b, int32_t* idx_b, const void* workspace, size_t workspace_bytes,
+                              v3d_stream_t stream);
 int v3d_group_points(const float* feat, const int32_t* idx, int B, int C, int N, int M, int nsample, float* out,
                      v3d_stream_t stream);
 /* Bilinear lookup of BEV features at keypoints: F.grid_sample(feature_map, grid, bilinear, zeros, align_corners=True) for a

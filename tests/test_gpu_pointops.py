@@ -466,6 +466,35 @@ def test_ball_query_grid_equals_scan_ragged_and_degenerate(n, m, ra, nsa, rb, ns
     assert torch.equal(sa, ga) and torch.equal(sb, gb)
 
 
+def test_ball_query_grids_of_several_databases_in_one_launch():
+    """PU.ball_query_grids: the grids of several databases (different sizes, different radii, two frames) from ONE launch, each then
+    queried more than once (any radius up to the one it was built for) -- equal to the scan kernel; a grid refuses another tensor, a
+    changed tensor and a larger radius."""
+    from vision3d_amd.pointnet2 import pointnet2_utils as PU
+    g = torch.Generator().manual_seed(11)
+    dbs = [(torch.rand(2, n, 3, generator=g) * torch.tensor([70.0, 80.0, 4.0])).cuda() for n in (16384, 13001, 4612, 2048, 1, 300, 9000)]
+    radii = [0.8, 0.8, 4.8, 1.6, 1.0, 2.0, 2.4]
+    grids = PU.ball_query_grids(list(zip(dbs, radii)))
+    q = dbs[0][:, torch.randint(0, 16384, (700,), generator=g)].contiguous() + 0.03
+    for db, r, grid in zip(dbs, radii, grids):
+        for ra, rb in ((r / 2, r), (r, r / 3)):
+            old, PU.BALL_QUERY_ALGO = PU.BALL_QUERY_ALGO, "scan"
+            try:
+                sa, sb = PU.ball_query_pair(ra, 16, rb, 32, db, q)
+            finally:
+                PU.BALL_QUERY_ALGO = old
+            ga, gb = PU.ball_query_pair(ra, 16, rb, 32, db, q, grid=grid)
+            assert torch.equal(sa, ga) and torch.equal(sb, gb), (db.shape, ra, rb)
+            assert torch.equal(PU.ball_query(rb, 32, db, q, grid=grid), gb)
+    with pytest.raises(RuntimeError):
+        PU.ball_query(radii[0] * 1.5, 16, dbs[0], q, grid=grids[0])
+    with pytest.raises(RuntimeError):
+        PU.ball_query(radii[0], 16, dbs[0].clone(), q, grid=grids[0])
+    dbs[0].add_(1.0)
+    with pytest.raises(RuntimeError):
+        PU.ball_query(radii[0], 16, dbs[0], q, grid=grids[0])
+
+
 def test_ball_query_grid_workspace_is_checked():
     from vision3d_amd import _lib as L
     xyz = torch.rand(1, 100, 3).cuda()

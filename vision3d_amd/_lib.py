@@ -64,6 +64,8 @@ _SIGNATURES = {
     "v3d_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _f, _i, _vp, _vp]),
     "v3d_ball_query_grid_workspace": (_sz, [_i, _i]),
     "v3d_ball_query_grid": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _f, _i, _vp, _vp, _sz, _vp]),
+    "v3d_ball_query_grid_build": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "v3d_ball_query_grid_query": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _f, _i, _vp, _vp, _sz, _vp]),
     "v3d_group_points": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "v3d_bev_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "v3d_sa_mlp_layer": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),

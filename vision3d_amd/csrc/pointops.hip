@@ -536,37 +536,56 @@ extern "C" int v3d_ball_query(const float* xyz, const float* new_xyz, int B, int
 //     popcount prefix over the lanes' word runs, the lanes below nsample emit their bits.
 // Same results as v3d_ball_query for every input (tests/test_gpu_pointops.py: equality with the scan kernel at full size, with the
 // CPU oracle at small sizes, non-finite coordinates, queries far outside the database).
-#define BQG_MAX_CELLS 8192
+#define BQG_MAX_KEYS 32768  // (index chunk, cell) keys of the LDS histogram: 128 KB of the build workgroup's LDS
+#define BQG_MAX_CHUNKS 8
+#define BQG_MAX_JOBS 8
 #define BQG_BUILD_THREADS 1024
 #define BQG_HEADER_BYTES 32
 #define BQG_WAVES 4
+#define BQG_RPL 8                  // records per lane requested before the first is looked at
+#define BQG_BATCH (BQG_RPL * 64)
 
+// INDEX CHUNKS.  A ball in a dense region holds hundreds of points but only the `nsample` lowest indices are wanted.  The records are
+// therefore sorted by (index chunk, cell): chunk = index / ceil(N / nch), nch <= 8 as the histogram allows.  A query walks the chunks
+// in order and stops once every radius has nsample hits among the chunks it has finished -- later chunks hold larger indices only.
 struct BqGrid {  // first words of a frame's workspace, written by the build kernel
   float x0, y0, inv_c;
-  int nx, ny;
+  int nx, ny, nch, chunk;  // cells along x / y, index chunks, points per chunk
 };
 
-__host__ __device__ static inline size_t bqg_sorted_offset() { return (BQG_HEADER_BYTES + (BQG_MAX_CELLS + 1) * 4 + 15) / 16 * 16; }
+__host__ __device__ static inline size_t bqg_sorted_offset() { return (BQG_HEADER_BYTES + (BQG_MAX_KEYS + 1) * 4 + 15) / 16 * 16; }
 __host__ __device__ static inline size_t bqg_frame_bytes(int N) { return bqg_sorted_offset() + (size_t)N * 16; }
 
 // Cell coordinate of x along an axis that starts at x0: the SAME expression for database points and queries.  Two values less
-// than r apart differ by less than r * inv_c <= 1 / 1.01 before rounding and by at most 2 * 8192 * 2^-23 ~ 0.002 more after it
-// (two roundings each, at most BQG_MAX_CELLS cells along an axis): their floors differ by at most one.
+// than r apart differ by less than r * inv_c <= 1 / 1.01 before rounding and by at most 2 * 32768 * 2^-23 ~ 0.008 more after it
+// (two roundings each, at most BQG_MAX_KEYS cells along an axis): their floors differ by at most one.
 __device__ __forceinline__ float bq_cell(float x, float x0, float inv_c) { return floorf((x - x0) * inv_c); }
 
-// PPT > 0: N <= PPT * BQG_BUILD_THREADS and every thread keeps its points in registers (ONE trip to memory instead of three: a
-// workgroup alone on its compute unit has nothing to hide a trip behind -- 15 -> ~6 us at 16 384 points); PPT == 0: any N, the
-// points are read again in every pass.
+struct BqBuildJob {
+  const float* xyz;   // (B, N, 3)
+  unsigned char* ws;  // B frames of bqg_frame_bytes(N)
+  int N;
+  float cell_min;
+};
+struct BqBuildJobs {
+  BqBuildJob j[BQG_MAX_JOBS];
+};
+
+// One workgroup per (database, frame).  PPT > 0: N <= PPT * BQG_BUILD_THREADS for every job and a thread keeps its points in
+// registers (ONE trip to memory instead of three: a workgroup alone on its compute unit has nothing to hide a trip behind);
+// PPT == 0: any N, the points are read again in every pass.
 template <int PPT>
-__global__ __launch_bounds__(BQG_BUILD_THREADS) void bq_grid_build_kernel(const float* __restrict__ xyz, int N, float cell_min,
-                                                                          unsigned char* __restrict__ ws, size_t ws_stride) {
+__global__ __launch_bounds__(BQG_BUILD_THREADS) void bq_grid_build_kernel(const BqBuildJobs jobs) {
+  extern __shared__ int bq_cnt[];  // [BQG_MAX_KEYS]
   __shared__ float red[4][BQG_BUILD_THREADS / V3D_WAVE];
-  __shared__ int cnt[BQG_MAX_CELLS];
   __shared__ int wsum[BQG_BUILD_THREADS / V3D_WAVE];
   __shared__ BqGrid g;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* p = xyz + (size_t)b * N * 3;
-  unsigned char* w = ws + (size_t)b * ws_stride;
+  int* cnt = bq_cnt;
+  const BqBuildJob job = jobs.j[blockIdx.x];
+  const int N = job.N;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* p = job.xyz + (size_t)b * N * 3;
+  unsigned char* w = job.ws + (size_t)b * bqg_frame_bytes(N);
   int* cell_start = reinterpret_cast<int*>(w + BQG_HEADER_BYTES);
   float4* sorted = reinterpret_cast<float4*>(w + bqg_sorted_offset());
   const float inf = __builtin_huge_valf();
@@ -602,7 +621,6 @@ __global__ __launch_bounds__(BQG_BUILD_THREADS) void bq_grid_build_kernel(const 
   xlo = -v3d_dpp_max_f32<true>(-xlo), xhi = v3d_dpp_max_f32<true>(xhi);
   ylo = -v3d_dpp_max_f32<true>(-ylo), yhi = v3d_dpp_max_f32<true>(yhi);
   if (lane == 0) red[0][wave] = xlo, red[1][wave] = xhi, red[2][wave] = ylo, red[3][wave] = yhi;
-  for (int i = tid; i < BQG_MAX_CELLS; i += BQG_BUILD_THREADS) cnt[i] = 0;
   __syncthreads();
   if (tid == 0) {
     for (int i = 1; i < BQG_BUILD_THREADS / V3D_WAVE; i++) {
@@ -610,34 +628,44 @@ __global__ __launch_bounds__(BQG_BUILD_THREADS) void bq_grid_build_kernel(const 
       ylo = fminf(ylo, red[2][i]), yhi = fmaxf(yhi, red[3][i]);
     }
     BqGrid t;
-    t.x0 = xlo, t.y0 = ylo, t.inv_c = 0.f, t.nx = 0, t.ny = 0;
+    t.x0 = xlo, t.y0 = ylo, t.inv_c = 0.f, t.nx = 0, t.ny = 0, t.nch = 1, t.chunk = N > 0 ? N : 1;
     if (xlo <= xhi) {  // at least one finite point
-      float c = cell_min;
+      float c = job.cell_min;
       for (;;) {  // cells no smaller than asked for, grown until the grid fits the LDS histogram
         t.inv_c = 1.f / c;
         const float fx = bq_cell(xhi, xlo, t.inv_c), fy = bq_cell(yhi, ylo, t.inv_c);  // (the largest cell along each axis)
-        if (fx < (float)BQG_MAX_CELLS && fy < (float)BQG_MAX_CELLS && ((long long)fx + 1) * ((long long)fy + 1) <= BQG_MAX_CELLS) {
+        if (fx < (float)BQG_MAX_KEYS && fy < (float)BQG_MAX_KEYS && ((long long)fx + 1) * ((long long)fy + 1) <= BQG_MAX_KEYS) {
           t.nx = (int)fx + 1, t.ny = (int)fy + 1;
           break;
         }
         c *= 1.5f;
       }
+      t.nch = min(BQG_MAX_CHUNKS, BQG_MAX_KEYS / (t.nx * t.ny));
+      t.chunk = (N + t.nch - 1) / t.nch;
     }
     g = t;
     *reinterpret_cast<BqGrid*>(w) = t;
   }
   __syncthreads();
   const BqGrid gg = g;
-  const int ncell = gg.nx * gg.ny;
-  auto cell_of = [&](float x, float y) { return (int)bq_cell(y, gg.y0, gg.inv_c) * gg.nx + (int)bq_cell(x, gg.x0, gg.inv_c); };
-  // (b) histogram
-  for_points([&](int, float x, float y, float) { atomicAdd(&cnt[cell_of(x, y)], 1); });
+  const int ncell = gg.nx * gg.ny, nkeys = ncell * gg.nch;
+  // keys per thread of the scan below: covers nkeys + 1, odd (thread t walks the words [t * kpt, (t + 1) * kpt): an odd stride is
+  // conflict-free)
+  const int kpt = ((nkeys + BQG_BUILD_THREADS) / BQG_BUILD_THREADS) | 1;
+  for (int i = tid; i < kpt * BQG_BUILD_THREADS; i += BQG_BUILD_THREADS)
+    if (i < BQG_MAX_KEYS) cnt[i] = 0;
   __syncthreads();
-  // (c) exclusive scan: BQG_MAX_CELLS / BQG_BUILD_THREADS consecutive cells per thread
-  constexpr int CPT = BQG_MAX_CELLS / BQG_BUILD_THREADS;
-  int own[CPT], sum = 0;
-#pragma unroll
-  for (int k = 0; k < CPT; k++) own[k] = cnt[tid * CPT + k], sum += own[k];
+  auto key_of = [&](int i, float x, float y) {
+    return (i / gg.chunk) * ncell + (int)bq_cell(y, gg.y0, gg.inv_c) * gg.nx + (int)bq_cell(x, gg.x0, gg.inv_c);
+  };
+  // (b) histogram
+  for_points([&](int i, float x, float y, float) { atomicAdd(&cnt[key_of(i, x, y)], 1); });
+  __syncthreads();
+  // (c) exclusive scan over the keys: kpt consecutive keys per thread, in place (the counts become the keys' write cursors)
+  const int k_lo = tid * kpt;
+  int sum = 0;
+  for (int k = 0; k < kpt; k++)
+    if (k_lo + k < BQG_MAX_KEYS) sum += cnt[k_lo + k];
   int incl = sum;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -646,20 +674,24 @@ __global__ __launch_bounds__(BQG_BUILD_THREADS) void bq_grid_build_kernel(const 
   }
   if (lane == 63) wsum[wave] = incl;
   __syncthreads();
-  int base = 0;
-  for (int i = 0; i < wave; i++) base += wsum[i];
-  int run = base + incl - sum;
-#pragma unroll
-  for (int k = 0; k < CPT; k++) {
-    const int c = tid * CPT + k;
-    cnt[c] = run;  // from here on: the cell's write cursor
-    if (c <= ncell) cell_start[c] = run;  // (entry ncell = the number of binned points)
-    run += own[k];
+  int run = incl - sum;
+  for (int i = 0; i < wave; i++) run += wsum[i];
+  for (int k = 0; k < kpt; k++) {
+    const int c = k_lo + k;
+    if (c < BQG_MAX_KEYS) {
+      const int own = cnt[c];
+      cnt[c] = run;
+      run += own;
+    }
   }
-  if (tid == BQG_BUILD_THREADS - 1 && ncell == BQG_MAX_CELLS) cell_start[ncell] = run;
+  if (tid == BQG_BUILD_THREADS - 1) wsum[0] = run;  // the number of binned points
   __syncthreads();
-  // (d) scatter (the order inside a cell is whatever the atomics give: the queries do not depend on it)
-  for_points([&](int i, float x, float y, float z) { sorted[atomicAdd(&cnt[cell_of(x, y)], 1)] = make_float4(x, y, z, __int_as_float(i)); });
+  // the table as the queries read it: coalesced, not a thread's kpt consecutive words (the scan's layout: one 64-byte line per lane
+  // and store instruction -- 30 us of a 45 us build at 26 000 keys); entry nkeys = the number of binned points
+  for (int c = tid; c <= nkeys; c += BQG_BUILD_THREADS) cell_start[c] = c < nkeys ? cnt[c] : wsum[0];
+  __syncthreads();
+  // (d) scatter (the order inside a key's run is whatever the atomics give: the queries do not depend on it)
+  for_points([&](int i, float x, float y, float z) { sorted[atomicAdd(&cnt[key_of(i, x, y)], 1)] = make_float4(x, y, z, __int_as_float(i)); });
 }
 
 // the first `ns` set bits of a wave's bitmap in ascending order -> o[0, ns) (empty slots repeat the first hit; no hit: 0), the
@@ -709,6 +741,8 @@ __global__ __launch_bounds__(BQG_WAVES * 64) void bq_grid_query_kernel(const flo
   const BqGrid g = *reinterpret_cast<const BqGrid*>(w);
   const int* cell_start = reinterpret_cast<const int*>(w + BQG_HEADER_BYTES);
   const float4* sorted = reinterpret_cast<const float4*>(w + bqg_sorted_offset());
+  const int ncell = g.nx * g.ny;
+  const float nanf_ = __builtin_nanf("");
   for (int q = blockIdx.x * waves + wave; q < M; q += gridDim.x * waves) {
     const float* qp = new_xyz + ((size_t)b * M + q) * 3;
     const float qx = qp[0], qy = qp[1], qz = qp[2];
@@ -718,34 +752,56 @@ __global__ __launch_bounds__(BQG_WAVES * 64) void bq_grid_query_kernel(const flo
     if (tx >= -1.f && tx <= (float)g.nx && ty >= -1.f && ty <= (float)g.ny) {
       const int cx = (int)tx, cy = (int)ty;
       const int c0 = max(cx - 1, 0), c1 = min(cx + 1, g.nx - 1);
-      int s[3], e[3];
-#pragma unroll
-      for (int d = 0; d < 3; d++) {  // the three cells of a row are one run of records
-        const int row = cy - 1 + d;
-        const bool ok = row >= 0 && row < g.ny && c0 <= c1;
-        s[d] = ok ? cell_start[row * g.nx + c0] : 0;
-        e[d] = ok ? cell_start[row * g.nx + c1 + 1] : 0;
+      // lane 3 * chunk + d: the run of row cy - 1 + d in that chunk (the three cells of a row are one run of records)
+      int s_run = 0, len = 0;
+      if (lane < 3 * g.nch) {
+        const int ch = lane / 3, row = cy - 1 + lane % 3;
+        if (row >= 0 && row < g.ny && c0 <= c1) {
+          s_run = cell_start[ch * ncell + row * g.nx + c0];
+          len = cell_start[ch * ncell + row * g.nx + c1 + 1] - s_run;
+        }
       }
-      // the three runs as ONE index space, four records per lane requested before the first is looked at (a wave alone on its
-      // query has one trip to the L2 per loop pass: 576 candidates were nine trips)
-      const int l0 = e[0] - s[0], l01 = l0 + e[1] - s[1], total = l01 + e[2] - s[2];
-      const float nanf_ = __builtin_nanf("");
-      for (int t0 = 0; t0 < total; t0 += 256) {
-        float4 pt[4];
+      int pre = len;  // inclusive prefix over the runs: positions in the query's candidate sequence
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int t = t0 + u * 64 + lane;
-          const int i = t < l0 ? s[0] + t : (t < l01 ? s[1] + (t - l0) : s[2] + (t - l01));
-          pt[u] = t < total ? sorted[i] : make_float4(nanf_, nanf_, nanf_, 0.f);  // (NaN: inside no ball)
-        }
+      for (int d = 1; d < 32; d <<= 1) {
+        const int up = __shfl_up(pre, d);
+        if (lane >= d) pre += up;
+      }
+      int cnt_a = 0, cnt_b = 0;
+      for (int ch0 = 0; ch0 < g.nch;) {
+        // a group of whole chunks: at least BQG_BATCH candidates (BQG_RPL records per lane in flight) or all that is left
+        const int base = ch0 ? __shfl(pre, 3 * ch0 - 1) : 0;
+        int ch1 = ch0 + 1, gend = __shfl(pre, 3 * ch1 - 1);
+        while (ch1 < g.nch && gend - base < BQG_BATCH) ch1++, gend = __shfl(pre, 3 * ch1 - 1);
+        for (int t0 = base; t0 < gend; t0 += BQG_BATCH) {
+          int rec[BQG_RPL];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const float dx = qx - pt[u].x, dy = qy - pt[u].y, dz = qz - pt[u].z;
-          const float d2 = dx * dx + dy * dy + dz * dz;
-          const int id = __float_as_int(pt[u].w);
-          if (d2 < r2a) atomicOr(&ba[id >> 5], 1u << (id & 31));
-          if (idxb && d2 < r2b) atomicOr(&bb[id >> 5], 1u << (id & 31));
+          for (int u = 0; u < BQG_RPL; u++) rec[u] = -1;
+          for (int r = 3 * ch0; r < 3 * ch1; r++) {  // which run holds candidate t (wave-uniform walk over the group's runs)
+            const int pe = __shfl(pre, r), ln = __shfl(len, r), sr = __shfl(s_run, r);
+#pragma unroll
+            for (int u = 0; u < BQG_RPL; u++) {
+              const int t = t0 + u * 64 + lane;
+              if (t < pe && t >= pe - ln) rec[u] = sr + (t - (pe - ln));
+            }
+          }
+          float4 pt[BQG_RPL];
+#pragma unroll
+          for (int u = 0; u < BQG_RPL; u++) pt[u] = rec[u] >= 0 ? sorted[rec[u]] : make_float4(nanf_, nanf_, nanf_, 0.f);  // (NaN: inside no ball)
+#pragma unroll
+          for (int u = 0; u < BQG_RPL; u++) {
+            const float dx = qx - pt[u].x, dy = qy - pt[u].y, dz = qz - pt[u].z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            const int id = __float_as_int(pt[u].w);
+            const bool ha = d2 < r2a, hb = idxb && d2 < r2b;
+            if (ha) atomicOr(&ba[id >> 5], 1u << (id & 31));
+            if (hb) atomicOr(&bb[id >> 5], 1u << (id & 31));
+            cnt_a += __popcll(__ballot(ha));
+            cnt_b += __popcll(__ballot(hb));
+          }
         }
+        if (cnt_a >= nsa && (!idxb || cnt_b >= nsb)) break;  // the lowest nsample indices lie in the chunks walked so far
+        ch0 = ch1;
       }
     }
     __threadfence_block();  // (the wave's own LDS atomics before its reads)
@@ -759,37 +815,77 @@ extern "C" size_t v3d_ball_query_grid_workspace(int B, int N) {
   return (size_t)B * bqg_frame_bytes(N);
 }
 
+// per-wave bitmaps of the query kernel: words per lane (odd) and waves per workgroup that fit 64 KB of LDS; waves = 0: N too large
+static void bqg_bitmap_shape(int N, int& wpl, int& waves) {
+  wpl = v3d_ceil_div(v3d_ceil_div(N, 32), 64) | 1;
+  waves = (int)std::min<size_t>(BQG_WAVES, (size_t)64 * 1024 / ((size_t)2 * 64 * wpl * sizeof(unsigned)));
+}
+
+extern "C" int v3d_ball_query_grid_build(int n_db, const float* const* xyz, const int32_t* N, const float* radius_max,
+                                         void* const* workspace, const size_t* workspace_bytes, int B, v3d_stream_t stream) {
+  if (n_db < 0 || n_db > BQG_MAX_JOBS || B < 0) return V3D_EINVAL;
+  if (n_db == 0 || B == 0) return V3D_OK;
+  if (!xyz || !N || !radius_max || !workspace || !workspace_bytes) return V3D_EINVAL;
+  BqBuildJobs jobs;
+  int n_max = 0;
+  for (int i = 0; i < n_db; i++) {
+    const float r = fabsf(radius_max[i]);
+    if (N[i] < 1 || !xyz[i] || !(r > 0.f) || !(r < 1e30f)) return V3D_EINVAL;
+    if (!workspace[i] || ((uintptr_t)workspace[i] & 15) || workspace_bytes[i] < v3d_ball_query_grid_workspace(B, N[i])) return V3D_EINVAL;
+    jobs.j[i] = BqBuildJob{xyz[i], (unsigned char*)workspace[i], N[i], r * 1.01f};
+    n_max = std::max(n_max, N[i]);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)BQG_MAX_KEYS * sizeof(int);
+#define BQG_BUILD(PPT)                                                                                                        \
+  {                                                                                                                           \
+    V3D_CHECK_HIP(hipFuncSetAttribute((const void*)bq_grid_build_kernel<PPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(bq_grid_build_kernel<PPT>, dim3(n_db, B), dim3(BQG_BUILD_THREADS), lds, st, jobs);                      \
+  }
+  if (n_max <= 4 * BQG_BUILD_THREADS) BQG_BUILD(4)
+  else if (n_max <= 12 * BQG_BUILD_THREADS) BQG_BUILD(12)
+  else if (n_max <= 20 * BQG_BUILD_THREADS) BQG_BUILD(20)
+  else BQG_BUILD(0)
+#undef BQG_BUILD
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
+extern "C" int v3d_ball_query_grid_query(const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a, int32_t* idx_a,
+                                         float radius_b, int nsample_b, int32_t* idx_b, const void* workspace, size_t workspace_bytes,
+                                         v3d_stream_t stream) {
+  if (B < 0 || N < 1 || M < 0 || nsample_a < 1 || (idx_b && nsample_b < 1)) return V3D_EINVAL;
+  if (B == 0 || M == 0) return V3D_OK;
+  if (!new_xyz || !idx_a || !workspace || ((uintptr_t)workspace & 15) || workspace_bytes < v3d_ball_query_grid_workspace(B, N)) return V3D_EINVAL;
+  int wpl, waves;
+  bqg_bitmap_shape(N, wpl, waves);
+  if (waves < 1) return V3D_EUNSUPPORTED;
+  const size_t per_wave = (size_t)2 * 64 * wpl * sizeof(unsigned);
+  const int blocks = std::min(v3d_ceil_div(M, waves), 4096);
+  hipLaunchKernelGGL(bq_grid_query_kernel, dim3(blocks, B), dim3(waves * 64), waves * per_wave, (hipStream_t)stream, new_xyz, M,
+                     radius_a * radius_a, nsample_a, idx_a, radius_b * radius_b, nsample_b, idx_b, (const unsigned char*)workspace,
+                     bqg_frame_bytes(N), wpl);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 // v3d_ball_query through a cell grid of the database (same arguments, same results; `workspace` = v3d_ball_query_grid_workspace(B, N)
-// bytes, 16-byte aligned, contents need not be kept).  Databases too large for the per-wave LDS bitmaps (N > ~250 000) take the scan.
+// bytes, 16-byte aligned, contents need not be kept): build + query.  Databases too large for the per-wave LDS bitmaps
+// (N > ~250 000) take the scan.
 extern "C" int v3d_ball_query_grid(const float* xyz, const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a,
                                    int32_t* idx_a, float radius_b, int nsample_b, int32_t* idx_b, void* workspace,
                                    size_t workspace_bytes, v3d_stream_t stream) {
   if (B < 0 || N < 1 || M < 0 || nsample_a < 1 || (idx_b && nsample_b < 1)) return V3D_EINVAL;
   if (B == 0 || M == 0) return V3D_OK;
   if (!xyz || !new_xyz || !idx_a) return V3D_EINVAL;
-  const int words = v3d_ceil_div(N, 32);
-  const int wpl = v3d_ceil_div(words, 64) | 1;  // odd
-  const size_t per_wave = (size_t)2 * 64 * wpl * sizeof(unsigned);
-  const int waves = (int)std::min<size_t>(BQG_WAVES, (size_t)64 * 1024 / per_wave);
+  int wpl, waves;
+  bqg_bitmap_shape(N, wpl, waves);
   const float rmax = idx_b ? std::max(fabsf(radius_a), fabsf(radius_b)) : fabsf(radius_a);
   if (waves < 1 || !(rmax > 0.f) || !(rmax < 1e30f))
     return v3d_ball_query(xyz, new_xyz, B, N, M, radius_a, nsample_a, idx_a, radius_b, nsample_b, idx_b, stream);
-  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < v3d_ball_query_grid_workspace(B, N)) return V3D_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const size_t stride = bqg_frame_bytes(N);
-#define BQG_BUILD(PPT) \
-  hipLaunchKernelGGL(bq_grid_build_kernel<PPT>, dim3(B), dim3(BQG_BUILD_THREADS), 0, st, xyz, N, rmax * 1.01f, (unsigned char*)workspace, stride)
-  if (N <= 4 * BQG_BUILD_THREADS) BQG_BUILD(4);
-  else if (N <= 12 * BQG_BUILD_THREADS) BQG_BUILD(12);
-  else if (N <= 20 * BQG_BUILD_THREADS) BQG_BUILD(20);
-  else BQG_BUILD(0);
-#undef BQG_BUILD
-  V3D_CHECK_LAUNCH();
-  const int blocks = std::min(v3d_ceil_div(M, waves), 4096);
-  hipLaunchKernelGGL(bq_grid_query_kernel, dim3(blocks, B), dim3(waves * 64), waves * per_wave, st, new_xyz, M, radius_a * radius_a, nsample_a,
-                     idx_a, radius_b * radius_b, nsample_b, idx_b, (const unsigned char*)workspace, stride, wpl);
-  V3D_CHECK_LAUNCH();
-  return V3D_OK;
+  int rc = v3d_ball_query_grid_build(1, &xyz, &N, &rmax, &workspace, &workspace_bytes, B, stream);
+  if (rc) return rc;
+  return v3d_ball_query_grid_query(new_xyz, B, N, M, radius_a, nsample_a, idx_a, radius_b, nsample_b, idx_b, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------ bilinear BEV lookup

@@ -70,6 +70,25 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
 #pragma unroll
     for (int j = 0; j < NB; j++) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // A: four contiguous floats of this lane's row, k = kb + 4 q .. + 3 (kb a multiple of 16).  The fragments of block kb + 16 are
+  // requested BEFORE the MFMAs of block kb (a gathered row is a trip to the L2: with two waves per SIMD and 4 NB dependent matrix
+  // instructions per block the trip was not hidden -- round 6: 140 -> see profiles/ us at 51 200 rows x 516 -> 192).
+  auto load_a = [&](int kb, f32x4 (&a)[SAM_TPW]) {
+    const int kg = kb + 4 * q;
+#pragma unroll
+    for (int t = 0; t < SAM_TPW; t++) {
+      a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (frow[t]) {
+        if (has_xyz && kg == 0) a[t] = rel[t];
+        else {
+          const int fo = kg - (has_xyz ? 4 : 0);
+          if (fo < Kf) a[t] = *reinterpret_cast<const f32x4*>(frow[t] + fo);
+        }
+      }
+    }
+  };
+  f32x4 a[SAM_TPW], an[SAM_TPW];
+  load_a(0, a);
   for (int k0 = 0; k0 < Kp; k0 += SAM_KC) {
     const int kc = min(SAM_KC, Kp - k0);
     __syncthreads();  // the previous chunk has been consumed
@@ -81,20 +100,7 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
     }
     __syncthreads();
     for (int kb = 0; kb < kc; kb += 16) {  // kc is a multiple of 4; rows beyond it are zero in LDS
-      // A: four contiguous floats of this lane's row, k = k0 + kb + 4 q .. + 3
-      f32x4 a[SAM_TPW];
-      const int kg = k0 + kb + 4 * q;
-#pragma unroll
-      for (int t = 0; t < SAM_TPW; t++) {
-        a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (frow[t]) {
-          if (has_xyz && kg == 0) a[t] = rel[t];
-          else {
-            const int fo = kg - (has_xyz ? 4 : 0);
-            if (fo < Kf) a[t] = *reinterpret_cast<const f32x4*>(frow[t] + fo);
-          }
-        }
-      }
+      if (k0 + kb + 16 < Kp) load_a(k0 + kb + 16, an);
       const float* wq = Ws + (kb + 4 * q) * LDW + r;
 #pragma unroll
       for (int s = 0; s < 4; s++) {
@@ -105,6 +111,8 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
           for (int t = 0; t < SAM_TPW; t++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], b, acc[t][j], 0, 0, 0);
         }
       }
+#pragma unroll
+      for (int t = 0; t < SAM_TPW; t++) a[t] = an[t];
     }
   }
 

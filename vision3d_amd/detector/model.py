@@ -87,12 +87,22 @@ class PV_RCNN(nn.Module):
         b, k = keypoints.shape[:2]
         widths = [sum(p.out_channels()) for p in self.pnets] + [bev_map.shape[1]]
         feats = torch.empty((b, k, sum(widths)), dtype=torch.float32, device=keypoints.device)
+        # the ball-query grids of every database of the frame in ONE launch: the five sources, and the keypoints themselves for
+        # the RoI-grid pooling that follows (handed over on the returned tensor: RoiGridPool.forward looks for it)
+        xyzs = [xyz.contiguous() for xyz, _ in sources]
+        kp = keypoints.contiguous()
+        grids = None
+        if pn2.BALL_QUERY_ALGO == "grid":
+            grids = pn2.ball_query_grids([(x, p.max_radius()) for x, p in zip(xyzs, self.pnets)] + [(kp, self.roi_grid_pool.pnet.max_radius())])
         col = 0
-        for pnet, (xyz, features), w in zip(self.pnets, sources, widths):
-            pnet.fused_forward(xyz, features, keypoints, out_pm=feats[:, :, col:col + w])
+        for i, (pnet, (_, features), w) in enumerate(zip(self.pnets, sources, widths)):
+            pnet.fused_forward(xyzs[i], features, kp, out_pm=feats[:, :, col:col + w], grid=grids[i] if grids else None)
             col += w
-        self.bev.gather_point_major(bev_map, keypoints, out_pm=feats[:, :, col:])
-        return feats.transpose(1, 2)
+        self.bev.gather_point_major(bev_map, kp, out_pm=feats[:, :, col:])
+        out = feats.transpose(1, 2)
+        if grids:
+            out._v3d_keypoint_grid = grids[-1]
+        return out
 
     def proposal(self, item):
         """Stage 1.  Adds keypoints, P_cls, P_reg (and the CNN outputs under `_cnn_features` / `_bev_map` for the

@@ -58,7 +58,11 @@ class RoiGridPool(nn.Module):
             # inference: the pooled rows stay point-major -- (b, n * m, C) read as (b, n, m * C) IS the per-box row, in (grid point,
             # channel) order instead of the reference's (channel, grid point): the first reduction layer's weight rows are permuted
             # once instead of the activations every frame (roi_grid_pool.py:64-72)
-            pooled = self.pnet.fused_forward(keypoint_xyz, pm, new_xyz)  # (b, n * m, C)
+            grid = getattr(keypoint_features, "_v3d_keypoint_grid", None)  # built with the frame's other grids (PV_RCNN._point_features_fused)
+            kp = keypoint_xyz.contiguous()
+            if grid is not None and not grid.matches(kp, self.pnet.max_radius()):
+                grid = None
+            pooled = self.pnet.fused_forward(kp, pm, new_xyz, grid=grid)  # (b, n * m, C)
             c = pooled.shape[2]
             return self.reduction.native_forward(pooled.reshape(b, n, m * c), first_rows=self._first_rows(m, c, pooled.device))
         _, pooled = self.pnet(keypoint_xyz, keypoint_features, new_xyz)  # (b, C, n*m)

@@ -101,14 +101,18 @@ class PointnetSAModuleMSG(nn.Module):
         cache[k] = (stamp, packed)
         return packed
 
+    def max_radius(self):
+        return max(abs(float(g.radius)) for g in self.groupers)
+
     def out_channels(self):
         """Output channels per scale (the last convolution of every scale's MLP)."""
         return [[mod for mod in mlp if isinstance(mod, nn.Conv2d)][-1].out_channels for mlp in self.mlps]
 
-    def fused_forward(self, xyz, features_pm, new_xyz, out_pm=None):
+    def fused_forward(self, xyz, features_pm, new_xyz, out_pm=None, grid=None):
         """features_pm (B, N, C) POINT-major -> (B, M, sum(mlps[k][-1])) POINT-major: every scale's last layer writes its pooled rows
         straight into its column block (no torch.cat of the scales).  `out_pm`: a (B, M, >= that many) view with unit channel stride
-        to write into -- a column block of the caller's keypoint feature matrix (detector/model.py point_feature_extract)."""
+        to write into -- a column block of the caller's keypoint feature matrix (detector/model.py point_feature_extract).  `grid`: the
+        ball-query grid of `xyz` when the caller built it beforehand (PU.ball_query_grids: several databases in one launch)."""
         b, n, c = features_pm.shape
         m = new_xyz.shape[1]
         kf = -(-c // 4) * 4
@@ -122,9 +126,9 @@ class PointnetSAModuleMSG(nn.Module):
         rows = out_pm.as_strided((b * m, out_pm.shape[2]), (out_pm.stride(1), 1), out_pm.storage_offset())
         if len(self.groupers) == 2:  # both scales in one pass over the database
             ga, gb = self.groupers
-            neighbours = PU.ball_query_pair(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, new_xyz)
+            neighbours = PU.ball_query_pair(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, new_xyz, grid=grid)
         else:
-            neighbours = [PU.ball_query(g.radius, g.nsample, xyz, new_xyz) for g in self.groupers]
+            neighbours = [PU.ball_query(g.radius, g.nsample, xyz, new_xyz, grid=grid) for g in self.groupers]
         col = 0
         for k, grouper in enumerate(self.groupers):
             layers = self._packed_layers(k)

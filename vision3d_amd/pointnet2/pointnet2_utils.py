@@ -79,11 +79,56 @@ def _gather_forward(features, idx):
 BALL_QUERY_ALGO = "grid"
 
 
-def _ball_query_call(p, q, radius_a, nsample_a, idx_a, radius_b, nsample_b, idx_b, what):
+class BallQueryGrid:
+    """The cell grid of one database (csrc/pointops.hip: records sorted by (index chunk, (x, y) cell)), built for radii up to
+    `radius_max`; holds its workspace.  `matches(xyz)`: was it built from this tensor as it is now."""
+
+    def __init__(self, xyz, radius_max, workspace):
+        self.workspace, self.radius_max = workspace, float(radius_max)
+        self.shape, self.stamp = tuple(xyz.shape), (xyz.data_ptr(), xyz._version)
+
+    def matches(self, xyz, radius):
+        return (tuple(xyz.shape) == self.shape and (xyz.data_ptr(), xyz._version) == self.stamp
+                and abs(float(radius)) <= self.radius_max)
+
+
+def ball_query_grids(databases):
+    """[(xyz (B, N, 3) float32 contiguous, radius_max)] (same B) -> [BallQueryGrid], ALL grids in one launch (a workgroup per database
+    and frame): the six databases of a PV-RCNN frame cost one build instead of six."""
+    import ctypes as C
+    out = []
+    for i in range(0, len(databases), 8):
+        part = databases[i:i + 8]
+        for xyz, r in part:
+            L.require_gpu("ball_query_grids", xyz)
+            if xyz.dtype != torch.float32 or not xyz.is_contiguous() or xyz.dim() != 3 or xyz.shape[2] != 3 or xyz.shape[0] != part[0][0].shape[0]:
+                raise RuntimeError("ball_query_grids: databases must be contiguous float32 (B, N, 3) with one B")
+            if not abs(float(r)) > 0:
+                raise RuntimeError("ball_query_grids: radius_max must be non-zero")
+        b, n_db = part[0][0].shape[0], len(part)
+        dev = part[0][0].device
+        sizes = [int(L.lib().v3d_ball_query_grid_workspace(b, xyz.shape[1])) for xyz, _ in part]
+        wss = [torch.empty(max(sz, 16), dtype=torch.uint8, device=dev) for sz in sizes]
+        with torch.cuda.device(dev):
+            L.check(L.lib().v3d_ball_query_grid_build(
+                n_db, (C.c_void_p * n_db)(*[xyz.data_ptr() for xyz, _ in part]), (C.c_int32 * n_db)(*[xyz.shape[1] for xyz, _ in part]),
+                (C.c_float * n_db)(*[abs(float(r)) for _, r in part]), (C.c_void_p * n_db)(*[w.data_ptr() for w in wss]),
+                (C.c_size_t * n_db)(*[w.numel() for w in wss]), b, L.stream_ptr()), "ball_query_grid_build")
+        out += [BallQueryGrid(xyz, abs(float(r)), w) for (xyz, r), w in zip(part, wss)]
+    return out
+
+
+def _ball_query_call(p, q, radius_a, nsample_a, idx_a, radius_b, nsample_b, idx_b, what, grid=None):
     b, n, _ = p.shape
     m = q.shape[1]
     with torch.cuda.device(p.device):
-        if BALL_QUERY_ALGO == "grid":
+        if grid is not None and BALL_QUERY_ALGO == "grid":
+            if not grid.matches(p, max(abs(radius_a), abs(radius_b) if idx_b is not None else 0.0)):
+                raise RuntimeError(f"{what}: the grid was built from another database (or for a smaller radius)")
+            L.check(L.lib().v3d_ball_query_grid_query(L.ptr(q), b, n, m, float(radius_a), int(nsample_a), L.ptr(idx_a), float(radius_b),
+                                                      int(nsample_b), L.ptr(idx_b), L.ptr(grid.workspace), grid.workspace.numel(),
+                                                      L.stream_ptr()), what)
+        elif BALL_QUERY_ALGO == "grid":
             nbytes = L.lib().v3d_ball_query_grid_workspace(b, n)
             ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=p.device)
             L.check(L.lib().v3d_ball_query_grid(L.ptr(p), L.ptr(q), b, n, m, float(radius_a), int(nsample_a), L.ptr(idx_a),
@@ -96,24 +141,25 @@ def _ball_query_call(p, q, radius_a, nsample_a, idx_a, radius_b, nsample_b, idx_
             raise ValueError(f"BALL_QUERY_ALGO must be 'grid' or 'scan', not {BALL_QUERY_ALGO!r}")
 
 
-def ball_query(radius, nsample, xyz, new_xyz):
+def ball_query(radius, nsample, xyz, new_xyz, grid=None):
     """xyz (B, N, 3), new_xyz (B, M, 3) -> idx (B, M, nsample) int32: the first `nsample` points (index
-    order) with d^2 < r^2, empty slots filled with the first hit, no hit -> 0."""
+    order) with d^2 < r^2, empty slots filled with the first hit, no hit -> 0.  `grid`: a BallQueryGrid of `xyz` built beforehand
+    (`ball_query_grids`); default: built here."""
     L.require_gpu("ball_query", xyz, new_xyz)
     p, q = L.as_f32("ball_query", xyz), L.as_f32("ball_query", new_xyz)
     idx = torch.empty((p.shape[0], q.shape[1], nsample), dtype=torch.int32, device=p.device)
-    _ball_query_call(p, q, radius, nsample, idx, 0.0, 0, None, "ball_query")
+    _ball_query_call(p, q, radius, nsample, idx, 0.0, 0, None, "ball_query", grid)
     return idx
 
 
-def ball_query_pair(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz):
+def ball_query_pair(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz, grid=None):
     """Two ball queries around the same `new_xyz` in one pass over `xyz` (the two scales of a multi-scale set-abstraction module):
     -> (idx_a (B, M, nsample_a), idx_b (B, M, nsample_b)), each exactly what `ball_query` returns for its radius."""
     L.require_gpu("ball_query", xyz, new_xyz)
     p, q = L.as_f32("ball_query", xyz), L.as_f32("ball_query", new_xyz)
     idx_a = torch.empty((p.shape[0], q.shape[1], nsample_a), dtype=torch.int32, device=p.device)
     idx_b = torch.empty((p.shape[0], q.shape[1], nsample_b), dtype=torch.int32, device=p.device)
-    _ball_query_call(p, q, radius_a, nsample_a, idx_a, radius_b, nsample_b, idx_b, "ball_query2")
+    _ball_query_call(p, q, radius_a, nsample_a, idx_a, radius_b, nsample_b, idx_b, "ball_query2", grid)
     return idx_a, idx_b
 
 
