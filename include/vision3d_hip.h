@@ -329,6 +329,14 @@ int v3d_bev_gather_keypoints(const float* feature_map, const float* keypoint_xyz
 int v3d_sa_mlp_layer(const float* feat, const float* xyz, const float* new_xyz, const int32_t* idx, int B, int N, int M, int ns,
                      int Kf, const float* W, const float* bias, int Nout, int relu, int pool, float* out, int ldo, int n_store,
                      v3d_stream_t stream);
+/* The first TWO layers of a scale in one launch.  The first layer is linear in [xyz[i] - new_xyz[m], 0 | feat[i]] and its feature
+ * part depends on the gathered point alone: the caller computes P (B, N, K1) = feat @ W1[4:] once per DATABASE point
+ * (v3d_linear_rows; N rows instead of M * ns), and this kernel rebuilds relu(P[i] + rel . W1[0:3] + b1) as the operand rows of the
+ * second layer W (K1, Nout) -- 37x less matrix work at RoI-grid pooling (2 048 keypoints, 76 800 grouped rows, roi_grid_pool.py:64-72),
+ * and the (rows, K1) intermediate is never written.  wx (3, K1) = W1[0:3], b1 (K1); K1 % 4 == 0, K1 <= 256; the rest as above. */
+int v3d_sa_mlp_pair(const float* P, const float* xyz, const float* new_xyz, const int32_t* idx, int B, int N, int M, int ns, int K1,
+                    const float* wx, const float* b1, const float* W, const float* bias, int Nout, int relu, int pool, float* out,
+                    int ldo, int n_store, v3d_stream_t stream);
 /* The MLP tail of PV-RCNN on a hundred rows: out[r, n] = act(sum_k A[r * lda + k] * W[k * Nout + n] + bias[n]) for r < R,
  * n < n_store (0: Nout), out row stride ldo (0: Nout).  Replaces nn.Linear (+ bias, + ReLU) of detector/layers.py:53-73 as used by
  * the RoI-grid reduction (roi_grid_pool.py:64-72: 3 072 -> 256 -> 256) and the refinement head (refinement.py:47-50: 256 -> 128 -> 8).

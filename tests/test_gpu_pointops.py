@@ -564,6 +564,38 @@ def test_mlp_native_forward_matches_the_torch_modules():
         torch.testing.assert_close(mlp.native_forward(x[:, perm], first_rows=perm), mlp.native_forward(x), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("kf,n1,n2,ns", [(4, 16, 16, 16), (32, 32, 32, 32), (64, 64, 64, 16), (512, 192, 96, 32), (512, 192, 96, 16)])
+def test_sa_mlp_pair_matches_fp64_and_the_two_layer_path(kf, n1, n2, ns):
+    """csrc/sa_mlp.hip PAIR: feature part of the first layer once per database point (linear_rows) + v3d_sa_mlp_pair, against float64
+    and against the launch-per-layer path (equal up to the summation order of the first layer)."""
+    from vision3d_amd.pointnet2.pointnet2_utils import ball_query, linear_rows, sa_mlp_layer, sa_mlp_pair
+    rng = np.random.default_rng(kf + n1 + ns)
+    b, n, m = 2, 3000, 333
+    xyz = np.stack([synth.make_cloud(4)[:n, :3], synth.make_cloud(5)[:n, :3]])
+    new_xyz = np.ascontiguousarray(xyz[:, ::9][:, :m])
+    feat = rng.standard_normal((b, n, kf)).astype(np.float32)
+    w1 = (rng.standard_normal((4 + kf, n1)) / np.sqrt(4 + kf)).astype(np.float32)
+    w1[3] = 0
+    b1 = (rng.standard_normal(n1) * 0.1).astype(np.float32)
+    w2 = (rng.standard_normal((n1, n2)) / np.sqrt(n1)).astype(np.float32)
+    b2 = (rng.standard_normal(n2) * 0.1).astype(np.float32)
+    idx = ball_query(1.2, ns, dev(xyz), dev(new_xyz))
+    ii = idx.cpu().numpy().astype(np.int64)
+    bidx = np.arange(b)[:, None, None]
+    rel32 = (xyz[bidx, ii] - new_xyz[:, :, None, :]).astype(np.float64)
+    rows = np.concatenate([rel32, np.zeros(rel32.shape[:3] + (1,)), feat[bidx, ii].astype(np.float64)], -1).reshape(-1, 4 + kf)
+    h = np.maximum(rows @ w1.astype(np.float64) + b1, 0)
+    ref = np.maximum(h @ w2.astype(np.float64) + b2, 0)
+    p = linear_rows(dev(feat).reshape(b * n, kf), dev(np.ascontiguousarray(w1[4:]))).view(b, n, n1)
+    got = sa_mlp_pair(p, dev(xyz), dev(new_xyz), idx, dev(np.ascontiguousarray(w1[:3])), dev(b1), dev(w2), dev(b2), True, False)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=3e-5, atol=3e-5 * np.abs(ref).max())
+    gotp = sa_mlp_pair(p, dev(xyz), dev(new_xyz), idx, dev(np.ascontiguousarray(w1[:3])), dev(b1), dev(w2), dev(b2), True, True)
+    np.testing.assert_allclose(gotp.cpu().numpy(), ref.reshape(b * m, ns, n2).max(1), rtol=3e-5, atol=3e-5 * np.abs(ref).max())
+    x = sa_mlp_layer(dev(feat), dev(w1), dev(b1), True, False, xyz=dev(xyz), new_xyz=dev(new_xyz), idx=idx)
+    two = sa_mlp_layer(x, dev(w2), dev(b2), True, True, groups=(b, m, ns))
+    torch.testing.assert_close(gotp, two, rtol=3e-5, atol=3e-5 * float(np.abs(ref).max()))
+
+
 def test_fused_keypoint_features_equal_the_op_by_op_path():
     """PV_RCNN.point_feature_extract in inference writes every set-abstraction scale and the BEV lookup into ONE point-major matrix
     (sa_mlp `ldo`, v3d_bev_gather_keypoints) and RoI-grid pooling reads point-major rows with a permuted first reduction layer:

@@ -27,21 +27,34 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SAM_TPW 2     // 16-row tiles per wave
 #define SAM_KC 64     // k-rows of W per LDS chunk
 
-template <int NB>
+// PAIR (the first TWO layers of a scale in one launch, v3d_sa_mlp_pair): the first layer is linear in its input row
+// [xyz[i] - new_xyz[m], 0 | feat[i]], and its feature part depends on the gathered point i alone: P = feat @ W1[4:] is computed ONCE per
+// database point by the caller (N rows instead of M * ns: 2 048 instead of 76 800 at RoI-grid pooling -- 37x less matrix work), and
+// this kernel rebuilds the first layer's output row where the second layer consumes it,
+//     h[row, k] = relu( P[i, k] + ((rel.x * Wx[0, k] + rel.y * Wx[1, k]) + rel.z * Wx[2, k]) + b1[k] ),    i = idx[row]
+// as the A fragments of  out[row, :] = act(h[row, :] @ W + bias)  (+ max over the samples): the (rows, K) intermediate is never
+// written.  `feat` = P (B, N, Kf), Kf = the first layer's padded width, `wx` (3, Kf) = W1[0:3], `b1` (Kf).
+template <int NB, bool PAIR = false>
 __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const float* __restrict__ feat,
                                                                      const float* __restrict__ xyz,
                                                                      const float* __restrict__ new_xyz,
                                                                      const int* __restrict__ idx, int N, int M, int ns,
                                                                      int Kf, long long rows, const float* __restrict__ W,
                                                                      const float* __restrict__ bias, int relu, int pool,
-                                                                     float* __restrict__ out, int ldo, int n_store) {
+                                                                     float* __restrict__ out, int ldo, int n_store,
+                                                                     const float* __restrict__ wx, const float* __restrict__ b1) {
   constexpr int NOUT = NB * 16;
   constexpr int LDW = NOUT + 4;  // row stride of the LDS weight chunk: the four k-rows a wave reads at once hit disjoint banks
   __shared__ float Ws[SAM_KC * LDW];
+  __shared__ __attribute__((aligned(16))) float Wx[PAIR ? 4 * 256 : 4];  // PAIR: rows x, y, z of the first layer's weight, its bias
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const bool has_xyz = xyz != nullptr;
+  const bool has_xyz = !PAIR && xyz != nullptr;
   const int Kp = Kf + (has_xyz ? 4 : 0);
+  if constexpr (PAIR) {
+    for (int e = tid; e < 4 * Kf; e += SAM_WAVES * 64) Wx[e] = e < 3 * Kf ? wx[e] : b1[e - 3 * Kf];
+    __syncthreads();
+  }
   const long long tile0 = ((long long)blockIdx.x * SAM_WAVES + wave) * SAM_TPW;
 
   // this lane's row in each of the wave's tiles: source row pointer and the xyz offset of the first layer
@@ -57,7 +70,7 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
       const int b = (int)(bm / M);
       const long long src = idx ? (long long)b * N + idx[row] : row;
       frow[t] = feat + src * Kf;
-      if (has_xyz) {
+      if (has_xyz || PAIR) {
         const float* p = xyz + src * 3;
         const float* c = new_xyz + bm * 3;
         rel[t] = f32x4{p[0] - c[0], p[1] - c[1], p[2] - c[2], 0.f};
@@ -79,7 +92,15 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
     for (int t = 0; t < SAM_TPW; t++) {
       a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (frow[t]) {
-        if (has_xyz && kg == 0) a[t] = rel[t];
+        if constexpr (PAIR) {
+          if (kg < Kf) {
+            const f32x4 p4 = *reinterpret_cast<const f32x4*>(frow[t] + kg);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wx + kg), w1 = *reinterpret_cast<const f32x4*>(Wx + Kf + kg);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(Wx + 2 * Kf + kg), bb = *reinterpret_cast<const f32x4*>(Wx + 3 * Kf + kg);
+#pragma unroll
+            for (int c = 0; c < 4; c++) a[t][c] = fmaxf(p4[c] + ((rel[t].x * w0[c] + rel[t].y * w1[c]) + rel[t].z * w2[c]) + bb[c], 0.f);
+          }
+        } else if (has_xyz && kg == 0) a[t] = rel[t];
         else {
           const int fo = kg - (has_xyz ? 4 : 0);
           if (fo < Kf) a[t] = *reinterpret_cast<const f32x4*>(frow[t] + fo);
@@ -101,15 +122,26 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
     __syncthreads();
     for (int kb = 0; kb < kc; kb += 16) {  // kc is a multiple of 4; rows beyond it are zero in LDS
       if (k0 + kb + 16 < Kp) load_a(k0 + kb + 16, an);
+      // B[k = 4 q + s][n = 16 j + r]: the NB words of step s + 1 are read while step s multiplies (read, wait, four MFMAs, read ...
+      // left the matrix pipe idle for an LDS round trip per four instructions: one wave per SIMD ran at half rate)
       const float* wq = Ws + (kb + 4 * q) * LDW + r;
+      float bc[NB], bn[NB];
+#pragma unroll
+      for (int j = 0; j < NB; j++) bc[j] = wq[j * 16];
 #pragma unroll
       for (int s = 0; s < 4; s++) {
+        if (s < 3) {
 #pragma unroll
-        for (int j = 0; j < NB; j++) {
-          const float b = wq[s * LDW + j * 16];  // B[k = 4 q + s][n = 16 j + r]
-#pragma unroll
-          for (int t = 0; t < SAM_TPW; t++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], b, acc[t][j], 0, 0, 0);
+          for (int j = 0; j < NB; j++) bn[j] = wq[(s + 1) * LDW + j * 16];
         }
+        __builtin_amdgcn_sched_barrier(0);  // (left alone the scheduler sinks every read next to its use again)
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+#pragma unroll
+          for (int t = 0; t < SAM_TPW; t++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], bc[j], acc[t][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NB; j++) bc[j] = bn[j];
       }
 #pragma unroll
       for (int t = 0; t < SAM_TPW; t++) a[t] = an[t];
@@ -173,9 +205,37 @@ extern "C" int v3d_sa_mlp_layer(const float* feat, const float* xyz, const float
 #define SAM_CASE(NBV)                                                                                                      \
   if (Nout == NBV * 16) {                                                                                                  \
     hipLaunchKernelGGL(sa_mlp_layer_kernel<NBV>, dim3(blocks), dim3(SAM_WAVES * 64), 0, st, feat, xyz, new_xyz, idx, N, M, \
-                       ns, Kf, rows, W, bias, relu, pool, out, ldo, n_store);                                                            \
+                       ns, Kf, rows, W, bias, relu, pool, out, ldo, n_store, nullptr, nullptr);                                                            \
     V3D_CHECK_LAUNCH();                                                                                                    \
     return V3D_OK;                                                                                                         \
+  }
+  SAM_CASE(1) SAM_CASE(2) SAM_CASE(4) SAM_CASE(6) SAM_CASE(8) SAM_CASE(12) SAM_CASE(16)
+#undef SAM_CASE
+  return V3D_EUNSUPPORTED;
+}
+
+// The first two layers of a scale in one launch (see the PAIR note at the kernel): P (B, N, K1) = feat @ W1[4:] from the caller
+// (v3d_linear_rows on the database's feature rows), wx (3, K1) = W1[0:3], b1 (K1), then layer 2: W (K1, Nout), bias, relu, pool as
+// in v3d_sa_mlp_layer.  K1 % 4 == 0, K1 <= 256.
+extern "C" int v3d_sa_mlp_pair(const float* P, const float* xyz, const float* new_xyz, const int32_t* idx, int B, int N, int M, int ns,
+                               int K1, const float* wx, const float* b1, const float* W, const float* bias, int Nout, int relu, int pool,
+                               float* out, int ldo, int n_store, v3d_stream_t stream) {
+  if (B < 0 || N < 1 || M < 0 || ns < 1 || K1 < 4 || (K1 & 3) || K1 > 256 || Nout < 16 || (Nout & 15)) return V3D_EINVAL;
+  if (!P || !xyz || !new_xyz || !idx || !wx || !b1 || !W || !out || ((uintptr_t)P & 15)) return V3D_EINVAL;
+  if (pool && ns != 16 && ns != 32) return V3D_EUNSUPPORTED;
+  if (n_store <= 0 || n_store > Nout) n_store = Nout;
+  if (ldo <= 0) ldo = Nout;
+  if (ldo < n_store) return V3D_EINVAL;
+  const long long rows = (long long)B * M * ns;
+  if (rows == 0) return V3D_OK;
+  const int blocks = v3d_ceil_div(rows, 16 * SAM_TPW * SAM_WAVES);
+  hipStream_t st = (hipStream_t)stream;
+#define SAM_CASE(NBV)                                                                                                            \
+  if (Nout == NBV * 16) {                                                                                                        \
+    hipLaunchKernelGGL((sa_mlp_layer_kernel<NBV, true>), dim3(blocks), dim3(SAM_WAVES * 64), 0, st, P, xyz, new_xyz, idx, N, M, ns, \
+                       K1, rows, W, bias, relu, pool, out, ldo, n_store, wx, b1);                                                \
+    V3D_CHECK_LAUNCH();                                                                                                          \
+    return V3D_OK;                                                                                                               \
   }
   SAM_CASE(1) SAM_CASE(2) SAM_CASE(4) SAM_CASE(6) SAM_CASE(8) SAM_CASE(12) SAM_CASE(16)
 #undef SAM_CASE

@@ -59,6 +59,16 @@ class PointnetSAModuleMSG(nn.Module):
                 i += 1
         return True
 
+    PAIR_FIRST_LAYERS = True  # two-layer scales: v3d_linear_rows on the database + v3d_sa_mlp_pair (False: a launch per layer)
+
+    def _pair_pieces(self, k, layers):
+        """(W1[4:] (Kf, N1), W1[0:3] (3, N1)) of scale k as contiguous tensors, cached with the packed layers."""
+        cache = self.__dict__.setdefault("_pair_cache", {})
+        w1 = layers[0][0]
+        if k not in cache or cache[k][0] is not w1:
+            cache[k] = (w1, w1[4:].contiguous(), w1[0:3].contiguous())
+        return cache[k][1], cache[k][2]
+
     FUSED_WIDTHS = (16, 32, 64, 96, 128, 192, 256)  # padded Nout of csrc/sa_mlp.hip:sa_mlp_layer_kernel<Nout/16>
 
     def _packed_layers(self, k):
@@ -135,6 +145,14 @@ class PointnetSAModuleMSG(nn.Module):
             ns = grouper.nsample
             idx = neighbours[k]
             last = dict(out=rows[:, col:col + couts[k]], n_store=couts[k])
+            if self.PAIR_FIRST_LAYERS and len(layers) == 2 and layers[0][0].shape[1] <= 256:
+                # the first layer's feature part once per DATABASE point (N rows, not M * ns), the rest of it rebuilt inside the
+                # second layer's launch (csrc/sa_mlp.hip PAIR)
+                w1f, wx = self._pair_pieces(k, layers)
+                p = PU.linear_rows(feat.reshape(b * n, kf), w1f).view(b, n, -1)
+                PU.sa_mlp_pair(p, xyz, new_xyz, idx, wx, layers[0][1], layers[1][0], layers[1][1], True, True, **last)
+                col += couts[k]
+                continue
             x = PU.sa_mlp_layer(feat, layers[0][0], layers[0][1], True, len(layers) == 1, xyz=xyz, new_xyz=new_xyz, idx=idx,
                                 **(last if len(layers) == 1 else {}))
             for li in range(1, len(layers)):

@@ -245,6 +245,33 @@ def sa_mlp_layer(feat, w, bias, relu=True, pool=False, xyz=None, new_xyz=None, i
     return out
 
 
+def sa_mlp_pair(p, xyz, new_xyz, idx, wx, b1, w, bias, relu=True, pool=True, out=None, n_store=None):
+    """The first two layers of a set-abstraction scale in one launch (csrc/sa_mlp.hip PAIR): p (B, N, K1) = feat @ W1[4:] (the first
+    layer's feature part, once per database point: `linear_rows`), wx (3, K1) = W1[0:3], b1 (K1); the kernel rebuilds
+    relu(p[i] + rel_xyz . wx + b1) for every grouped row and multiplies it by w (K1, Nout) (+ bias, ReLU, max over the samples)."""
+    L.require_gpu("sa_mlp_pair", p, w)
+    pf, wf = L.as_f32("sa_mlp_pair", p), L.as_f32("sa_mlp_pair", w)
+    x, q, ii = L.as_f32("sa_mlp_pair", xyz), L.as_f32("sa_mlp_pair", new_xyz), L.as_i32("sa_mlp_pair", idx)
+    wxf, b1f = L.as_f32("sa_mlp_pair", wx), L.as_f32("sa_mlp_pair", b1)
+    bf = None if bias is None else L.as_f32("sa_mlp_pair", bias)
+    b, n, k1 = pf.shape
+    _, m, ns = ii.shape
+    nout = wf.shape[1]
+    if wf.shape[0] != k1 or tuple(wxf.shape) != (3, k1) or b1f.numel() != k1:
+        raise RuntimeError("sa_mlp_pair: weight shapes do not match the first layer's width")
+    rows = b * m if pool else b * m * ns
+    cols = nout if n_store is None else int(n_store)
+    if out is None:
+        out, ldo = torch.empty((rows, cols), dtype=torch.float32, device=pf.device), cols
+    else:
+        out, ldo = _strided_rows("sa_mlp_pair", out, rows, cols)
+    with torch.cuda.device(pf.device):
+        L.check(L.lib().v3d_sa_mlp_pair(L.ptr(pf), L.ptr(x), L.ptr(q), L.ptr(ii), b, n, m, ns, k1, L.ptr(wxf), L.ptr(b1f), L.ptr(wf),
+                                        L.ptr(bf), nout, int(bool(relu)), int(bool(pool)), L.ptr(out), ldo, cols, L.stream_ptr()),
+                "sa_mlp_pair")
+    return out
+
+
 def linear_rows(a, w, bias=None, relu=False, out=None, n_store=None):
     """act(a @ w + bias) for a matrix of FEW rows (csrc/sa_mlp.hip linear_rows_kernel: columns over workgroups, K over the waves):
     a (R, K) float32 with unit column stride (rows may be strided), w (K, Nout) = the nn.Linear weight transposed, Nout % 16 == 0,
