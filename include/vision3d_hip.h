@@ -315,6 +315,12 @@ int v3d_bev_bilinear(const float* feature_map, const float* grid, int B, int C, 
 int v3d_bev_gather_keypoints(const float* feature_map, const float* keypoint_xyz, int B, int C, int H, int W, int K, float offset_x,
                              float offset_y, float pixel_x, float pixel_y, float* out, int ldo, v3d_stream_t stream);
 
+/* RoiGridPool.sample_gridpoints in one launch (detector/roi_grid_pool.py:52-62): points[b, n, j] = centre + Rz(yaw) (size * (sample - 0.5))
+ * with the module's own fp32 statements, one IEEE operation each; boxes (B*n, 7) = x, y, z, w, l, h, yaw, samples (B*n, m, 3) in
+ * [0, 1), cos_yaw / sin_yaw (B*n) from the caller (torch's cos / sin: the same values as the op-by-op path), out (B*n, m, 3). */
+int v3d_roi_grid_points(const float* boxes, const float* samples, const float* cos_yaw, const float* sin_yaw, int n_boxes, int m,
+                        float* out, v3d_stream_t stream);
+
 /* ---- T5: one layer of a set-abstraction shared MLP on gathered rows, exact fp32 on the matrix cores (csrc/sa_mlp.hip).
  * Replaces, per scale of pointnet2_modules.PointnetSAModuleMSG (call sites detector/model.py:58-66, detector/roi_grid_pool.py:
  * 64-72), grouping_operation + SharedMLP (Conv2d 1x1, no bias + BatchNorm2d + ReLU per layer) + max over the samples, without the
@@ -333,10 +339,11 @@ int v3d_sa_mlp_layer(const float* feat, const float* xyz, const float* new_xyz, 
  * part depends on the gathered point alone: the caller computes P (B, N, K1) = feat @ W1[4:] once per DATABASE point
  * (v3d_linear_rows; N rows instead of M * ns), and this kernel rebuilds relu(P[i] + rel . W1[0:3] + b1) as the operand rows of the
  * second layer W (K1, Nout) -- 37x less matrix work at RoI-grid pooling (2 048 keypoints, 76 800 grouped rows, roi_grid_pool.py:64-72),
- * and the (rows, K1) intermediate is never written.  wx (3, K1) = W1[0:3], b1 (K1); K1 % 4 == 0, K1 <= 256; the rest as above. */
+ * and the (rows, K1) intermediate is never written.  wx (3, K1) = W1[0:3], b1 (K1); K1 % 4 == 0, K1 <= 256; ldp = row stride of P in
+ * floats (0: K1; the two scales of a module share one product with concatenated weights); the rest as above. */
 int v3d_sa_mlp_pair(const float* P, const float* xyz, const float* new_xyz, const int32_t* idx, int B, int N, int M, int ns, int K1,
-                    const float* wx, const float* b1, const float* W, const float* bias, int Nout, int relu, int pool, float* out,
-                    int ldo, int n_store, v3d_stream_t stream);
+                    int ldp, const float* wx, const float* b1, const float* W, const float* bias, int Nout, int relu, int pool,
+                    float* out, int ldo, int n_store, v3d_stream_t stream);
 /* The MLP tail of PV-RCNN on a hundred rows: out[r, n] = act(sum_k A[r * lda + k] * W[k * Nout + n] + bias[n]) for r < R,
  * n < n_store (0: Nout), out row stride ldo (0: Nout).  Replaces nn.Linear (+ bias, + ReLU) of detector/layers.py:53-73 as used by
  * the RoI-grid reduction (roi_grid_pool.py:64-72: 3 072 -> 256 -> 256) and the refinement head (refinement.py:47-50: 256 -> 128 -> 8).

@@ -589,6 +589,10 @@ def test_sa_mlp_pair_matches_fp64_and_the_two_layer_path(kf, n1, n2, ns):
     p = linear_rows(dev(feat).reshape(b * n, kf), dev(np.ascontiguousarray(w1[4:]))).view(b, n, n1)
     got = sa_mlp_pair(p, dev(xyz), dev(new_xyz), idx, dev(np.ascontiguousarray(w1[:3])), dev(b1), dev(w2), dev(b2), True, False)
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=3e-5, atol=3e-5 * np.abs(ref).max())
+    wide = torch.zeros((b, n, n1 + 32), device="cuda")  # P as a column block of a wider matrix
+    wide[:, :, 16:16 + n1] = p
+    assert torch.equal(sa_mlp_pair(wide[:, :, 16:16 + n1], dev(xyz), dev(new_xyz), idx, dev(np.ascontiguousarray(w1[:3])), dev(b1), dev(w2),
+                                   dev(b2), True, False), got)
     gotp = sa_mlp_pair(p, dev(xyz), dev(new_xyz), idx, dev(np.ascontiguousarray(w1[:3])), dev(b1), dev(w2), dev(b2), True, True)
     np.testing.assert_allclose(gotp.cpu().numpy(), ref.reshape(b * m, ns, n2).max(1), rtol=3e-5, atol=3e-5 * np.abs(ref).max())
     x = sa_mlp_layer(dev(feat), dev(w1), dev(b1), True, False, xyz=dev(xyz), new_xyz=dev(new_xyz), idx=idx)
@@ -629,6 +633,7 @@ def test_fused_keypoint_features_equal_the_op_by_op_path():
         samples = torch.rand((2, 20, cfg.GRIDPOOL.NUM_GRIDPOINTS, 3), generator=torch.Generator().manual_seed(5)).cuda()
         got = model.roi_grid_pool(props, kp, fused, samples)
         pts = model.roi_grid_pool.sample_gridpoints(props, samples)
+        assert torch.equal(pts, model.roi_grid_pool.sample_gridpoints_torch(props, samples))  # v3d_roi_grid_points == the torch statements
         _, chan_major = model.roi_grid_pool.pnet(kp, plain.contiguous(), pts.reshape(2, -1, 3).contiguous())
         per_box = chan_major.reshape(2, -1, 20, pts.shape[2]).permute(0, 2, 1, 3).reshape(2, 20, -1)
         ref = torch.nn.Sequential.forward(model.roi_grid_pool.reduction.double(), per_box.double())

@@ -971,6 +971,37 @@ extern "C" int v3d_bev_gather_keypoints(const float* feature_map, const float* k
   return V3D_OK;
 }
 
+// ------------------------------------------------------------------------------------------ RoI grid points
+// RoiGridPool.sample_gridpoints (vision3d/detector/roi_grid_pool.py:52-62) statement by statement, every operation rounded on its own
+// (-ffp-contract=off): local = size * (sample - 0.5); rotated = (cos * lx - sin * ly, sin * lx + cos * ly, lz); point = centre + rotated.
+// cos / sin of the yaw come from the caller (torch's functions: the op-by-op path's values).  Nine elementwise launches and a stack before.
+__global__ __launch_bounds__(V3D_BLOCK) void roi_grid_points_kernel(const float* __restrict__ boxes, const float* __restrict__ samples,
+                                                                    const float* __restrict__ cs, const float* __restrict__ sn,
+                                                                    long long total, int m, float* __restrict__ out) {
+  for (long long t = (long long)blockIdx.x * V3D_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * V3D_BLOCK) {
+    const long long bx = t / m;
+    const float* bp = boxes + bx * 7;
+    const float* sp = samples + t * 3;
+    const float lx = bp[3] * (sp[0] - 0.5f), ly = bp[4] * (sp[1] - 0.5f), lz = bp[5] * (sp[2] - 0.5f);
+    const float c = cs[bx], s = sn[bx];
+    out[t * 3] = bp[0] + (c * lx - s * ly);
+    out[t * 3 + 1] = bp[1] + (s * lx + c * ly);
+    out[t * 3 + 2] = bp[2] + lz;
+  }
+}
+
+extern "C" int v3d_roi_grid_points(const float* boxes, const float* samples, const float* cos_yaw, const float* sin_yaw, int n_boxes,
+                                   int m, float* out, v3d_stream_t stream) {
+  if (n_boxes < 0 || m < 0) return V3D_EINVAL;
+  const long long total = (long long)n_boxes * m;
+  if (total == 0) return V3D_OK;
+  if (!boxes || !samples || !cos_yaw || !sin_yaw || !out) return V3D_EINVAL;
+  hipLaunchKernelGGL(roi_grid_points_kernel, dim3((int)std::min<long long>(v3d_ceil_div(total, V3D_BLOCK), 4096)), dim3(V3D_BLOCK), 0,
+                     (hipStream_t)stream, boxes, samples, cos_yaw, sin_yaw, total, m, out);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 // ------------------------------------------------------------------------------------------ grouping
 __global__ void group_points_kernel(const float* __restrict__ feat, const int* __restrict__ idx, int C, int N, int M,
                                     int ns, long long total, float* __restrict__ out) {

@@ -42,7 +42,8 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
                                                                      int Kf, long long rows, const float* __restrict__ W,
                                                                      const float* __restrict__ bias, int relu, int pool,
                                                                      float* __restrict__ out, int ldo, int n_store,
-                                                                     const float* __restrict__ wx, const float* __restrict__ b1) {
+                                                                     const float* __restrict__ wx, const float* __restrict__ b1,
+                                                                     int ldp) {
   constexpr int NOUT = NB * 16;
   constexpr int LDW = NOUT + 4;  // row stride of the LDS weight chunk: the four k-rows a wave reads at once hit disjoint banks
   __shared__ float Ws[SAM_KC * LDW];
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
       const long long bm = row / ns;
       const int b = (int)(bm / M);
       const long long src = idx ? (long long)b * N + idx[row] : row;
-      frow[t] = feat + src * Kf;
+      frow[t] = feat + src * (PAIR ? ldp : Kf);
       if (has_xyz || PAIR) {
         const float* p = xyz + src * 3;
         const float* c = new_xyz + bm * 3;
@@ -205,7 +206,7 @@ extern "C" int v3d_sa_mlp_layer(const float* feat, const float* xyz, const float
 #define SAM_CASE(NBV)                                                                                                      \
   if (Nout == NBV * 16) {                                                                                                  \
     hipLaunchKernelGGL(sa_mlp_layer_kernel<NBV>, dim3(blocks), dim3(SAM_WAVES * 64), 0, st, feat, xyz, new_xyz, idx, N, M, \
-                       ns, Kf, rows, W, bias, relu, pool, out, ldo, n_store, nullptr, nullptr);                                                            \
+                       ns, Kf, rows, W, bias, relu, pool, out, ldo, n_store, nullptr, nullptr, 0);                                                            \
     V3D_CHECK_LAUNCH();                                                                                                    \
     return V3D_OK;                                                                                                         \
   }
@@ -216,11 +217,13 @@ extern "C" int v3d_sa_mlp_layer(const float* feat, const float* xyz, const float
 
 // The first two layers of a scale in one launch (see the PAIR note at the kernel): P (B, N, K1) = feat @ W1[4:] from the caller
 // (v3d_linear_rows on the database's feature rows), wx (3, K1) = W1[0:3], b1 (K1), then layer 2: W (K1, Nout), bias, relu, pool as
-// in v3d_sa_mlp_layer.  K1 % 4 == 0, K1 <= 256.
+// in v3d_sa_mlp_layer.  K1 % 4 == 0, K1 <= 256; ldp = row stride of P (0: K1).
 extern "C" int v3d_sa_mlp_pair(const float* P, const float* xyz, const float* new_xyz, const int32_t* idx, int B, int N, int M, int ns,
-                               int K1, const float* wx, const float* b1, const float* W, const float* bias, int Nout, int relu, int pool,
-                               float* out, int ldo, int n_store, v3d_stream_t stream) {
+                               int K1, int ldp, const float* wx, const float* b1, const float* W, const float* bias, int Nout, int relu,
+                               int pool, float* out, int ldo, int n_store, v3d_stream_t stream) {
   if (B < 0 || N < 1 || M < 0 || ns < 1 || K1 < 4 || (K1 & 3) || K1 > 256 || Nout < 16 || (Nout & 15)) return V3D_EINVAL;
+  if (ldp <= 0) ldp = K1;  // row stride of P in floats (a column block of a wider matrix: both scales of a module from one product)
+  if (ldp < K1 || (ldp & 3)) return V3D_EINVAL;
   if (!P || !xyz || !new_xyz || !idx || !wx || !b1 || !W || !out || ((uintptr_t)P & 15)) return V3D_EINVAL;
   if (pool && ns != 16 && ns != 32) return V3D_EUNSUPPORTED;
   if (n_store <= 0 || n_store > Nout) n_store = Nout;
@@ -233,7 +236,7 @@ extern "C" int v3d_sa_mlp_pair(const float* P, const float* xyz, const float* ne
 #define SAM_CASE(NBV)                                                                                                            \
   if (Nout == NBV * 16) {                                                                                                        \
     hipLaunchKernelGGL((sa_mlp_layer_kernel<NBV, true>), dim3(blocks), dim3(SAM_WAVES * 64), 0, st, P, xyz, new_xyz, idx, N, M, ns, \
-                       K1, rows, W, bias, relu, pool, out, ldo, n_store, wx, b1);                                                \
+                       K1, rows, W, bias, relu, pool, out, ldo, n_store, wx, b1, ldp);                                                \
     V3D_CHECK_LAUNCH();                                                                                                          \
     return V3D_OK;                                                                                                               \
   }

@@ -45,6 +45,23 @@ class RoiGridPool(nn.Module):
         b, n = boxes.shape[:2]
         if samples is None:
             samples = torch.rand((b, n, self.cfg.GRIDPOOL.NUM_GRIDPOINTS, 3), device=boxes.device, generator=self.generator)
+        if (boxes.is_cuda and boxes.dtype == torch.float32 and samples.dtype == torch.float32 and boxes.shape[-1] == 7
+                and not (torch.is_grad_enabled() and (boxes.requires_grad or samples.requires_grad))):
+            # the statements below in one launch (csrc/pointops.hip v3d_roi_grid_points; cos / sin stay torch's): same values
+            from .. import _lib as L
+            bx, sm = boxes.contiguous(), samples.contiguous()
+            yaw = bx[..., 6]
+            cos, sin = yaw.cos().contiguous(), yaw.sin().contiguous()
+            out = torch.empty_like(sm)
+            with torch.cuda.device(bx.device):
+                L.check(L.lib().v3d_roi_grid_points(L.ptr(bx), L.ptr(sm), L.ptr(cos), L.ptr(sin), b * n, sm.shape[2], L.ptr(out),
+                                                    L.stream_ptr()), "roi_grid_points")
+            return out
+        centre, size, yaw = boxes[..., None, 0:3], boxes[..., None, 3:6], boxes[..., 6]
+        return centre + yaw_rotate(size * (samples - 0.5), yaw)
+
+    def sample_gridpoints_torch(self, boxes, samples):
+        """The reference's statements op by op (the cross-check of the fused launch in the tests)."""
         centre, size, yaw = boxes[..., None, 0:3], boxes[..., None, 3:6], boxes[..., 6]
         return centre + yaw_rotate(size * (samples - 0.5), yaw)
 

@@ -61,13 +61,17 @@ class PointnetSAModuleMSG(nn.Module):
 
     PAIR_FIRST_LAYERS = True  # two-layer scales: v3d_linear_rows on the database + v3d_sa_mlp_pair (False: a launch per layer)
 
-    def _pair_pieces(self, k, layers):
-        """(W1[4:] (Kf, N1), W1[0:3] (3, N1)) of scale k as contiguous tensors, cached with the packed layers."""
+    def _pair_pieces(self, packed):
+        """([W1_k[4:]] side by side (Kf, sum N1_k), [W1_k[0:3] (3, N1_k)], column offsets) of the packed scales, cached with them."""
         cache = self.__dict__.setdefault("_pair_cache", {})
-        w1 = layers[0][0]
-        if k not in cache or cache[k][0] is not w1:
-            cache[k] = (w1, w1[4:].contiguous(), w1[0:3].contiguous())
-        return cache[k][1], cache[k][2]
+        firsts = tuple(ly[0][0] for ly in packed)
+        if cache.get("key") is None or len(cache["key"]) != len(firsts) or any(a is not b for a, b in zip(cache["key"], firsts)):
+            offs = [0]
+            for w1 in firsts:
+                offs.append(offs[-1] + w1.shape[1])
+            cache.update(key=firsts, w1f=torch.cat([w1[4:] for w1 in firsts], dim=1).contiguous(),
+                         wxs=[w1[0:3].contiguous() for w1 in firsts], offs=offs)
+        return cache["w1f"], cache["wxs"], cache["offs"]
 
     FUSED_WIDTHS = (16, 32, 64, 96, 128, 192, 256)  # padded Nout of csrc/sa_mlp.hip:sa_mlp_layer_kernel<Nout/16>
 
@@ -140,17 +144,21 @@ class PointnetSAModuleMSG(nn.Module):
         else:
             neighbours = [PU.ball_query(g.radius, g.nsample, xyz, new_xyz, grid=grid) for g in self.groupers]
         col = 0
+        packed = [self._packed_layers(k) for k in range(len(self.groupers))]
+        pair = self.PAIR_FIRST_LAYERS and all(len(ly) == 2 and ly[0][0].shape[1] <= 256 for ly in packed)
+        if pair:
+            # the first layers' feature parts once per DATABASE point (N rows, not M * ns), all scales in ONE product (their weights
+            # side by side); the rest of a first layer is rebuilt inside its second layer's launch (csrc/sa_mlp.hip PAIR)
+            w1f, wxs, offs = self._pair_pieces(packed)
+            p_all = PU.linear_rows(feat.reshape(b * n, kf), w1f).view(b, n, -1)
         for k, grouper in enumerate(self.groupers):
-            layers = self._packed_layers(k)
+            layers = packed[k]
             ns = grouper.nsample
             idx = neighbours[k]
             last = dict(out=rows[:, col:col + couts[k]], n_store=couts[k])
-            if self.PAIR_FIRST_LAYERS and len(layers) == 2 and layers[0][0].shape[1] <= 256:
-                # the first layer's feature part once per DATABASE point (N rows, not M * ns), the rest of it rebuilt inside the
-                # second layer's launch (csrc/sa_mlp.hip PAIR)
-                w1f, wx = self._pair_pieces(k, layers)
-                p = PU.linear_rows(feat.reshape(b * n, kf), w1f).view(b, n, -1)
-                PU.sa_mlp_pair(p, xyz, new_xyz, idx, wx, layers[0][1], layers[1][0], layers[1][1], True, True, **last)
+            if pair:
+                PU.sa_mlp_pair(p_all[:, :, offs[k]:offs[k + 1]], xyz, new_xyz, idx, wxs[k], layers[0][1], layers[1][0], layers[1][1],
+                               True, True, **last)
                 col += couts[k]
                 continue
             x = PU.sa_mlp_layer(feat, layers[0][0], layers[0][1], True, len(layers) == 1, xyz=xyz, new_xyz=new_xyz, idx=idx,

@@ -247,14 +247,17 @@ def sa_mlp_layer(feat, w, bias, relu=True, pool=False, xyz=None, new_xyz=None, i
 
 def sa_mlp_pair(p, xyz, new_xyz, idx, wx, b1, w, bias, relu=True, pool=True, out=None, n_store=None):
     """The first two layers of a set-abstraction scale in one launch (csrc/sa_mlp.hip PAIR): p (B, N, K1) = feat @ W1[4:] (the first
-    layer's feature part, once per database point: `linear_rows`), wx (3, K1) = W1[0:3], b1 (K1); the kernel rebuilds
-    relu(p[i] + rel_xyz . wx + b1) for every grouped row and multiplies it by w (K1, Nout) (+ bias, ReLU, max over the samples)."""
+    layer's feature part, once per database point: `linear_rows`; may be a column block of a wider (B, N, >= K1) matrix), wx (3, K1)
+    = W1[0:3], b1 (K1); the kernel rebuilds relu(p[i] + rel_xyz . wx + b1) for every grouped row and multiplies it by w (K1, Nout)
+    (+ bias, ReLU, max over the samples)."""
     L.require_gpu("sa_mlp_pair", p, w)
-    pf, wf = L.as_f32("sa_mlp_pair", p), L.as_f32("sa_mlp_pair", w)
+    wf = L.as_f32("sa_mlp_pair", w)
     x, q, ii = L.as_f32("sa_mlp_pair", xyz), L.as_f32("sa_mlp_pair", new_xyz), L.as_i32("sa_mlp_pair", idx)
     wxf, b1f = L.as_f32("sa_mlp_pair", wx), L.as_f32("sa_mlp_pair", b1)
     bf = None if bias is None else L.as_f32("sa_mlp_pair", bias)
-    b, n, k1 = pf.shape
+    b, n, k1 = p.shape
+    if p.dtype != torch.float32 or p.stride(2) != 1 or p.stride(0) != n * p.stride(1):
+        raise RuntimeError("sa_mlp_pair: p must be a float32 (B, N, K1) view with unit channel stride and frames back to back")
     _, m, ns = ii.shape
     nout = wf.shape[1]
     if wf.shape[0] != k1 or tuple(wxf.shape) != (3, k1) or b1f.numel() != k1:
@@ -262,13 +265,13 @@ def sa_mlp_pair(p, xyz, new_xyz, idx, wx, b1, w, bias, relu=True, pool=True, out
     rows = b * m if pool else b * m * ns
     cols = nout if n_store is None else int(n_store)
     if out is None:
-        out, ldo = torch.empty((rows, cols), dtype=torch.float32, device=pf.device), cols
+        out, ldo = torch.empty((rows, cols), dtype=torch.float32, device=p.device), cols
     else:
         out, ldo = _strided_rows("sa_mlp_pair", out, rows, cols)
-    with torch.cuda.device(pf.device):
-        L.check(L.lib().v3d_sa_mlp_pair(L.ptr(pf), L.ptr(x), L.ptr(q), L.ptr(ii), b, n, m, ns, k1, L.ptr(wxf), L.ptr(b1f), L.ptr(wf),
-                                        L.ptr(bf), nout, int(bool(relu)), int(bool(pool)), L.ptr(out), ldo, cols, L.stream_ptr()),
-                "sa_mlp_pair")
+    with torch.cuda.device(p.device):
+        L.check(L.lib().v3d_sa_mlp_pair(L.ptr(p), L.ptr(x), L.ptr(q), L.ptr(ii), b, n, m, ns, k1, p.stride(1), L.ptr(wxf), L.ptr(b1f),
+                                        L.ptr(wf), L.ptr(bf), nout, int(bool(relu)), int(bool(pool)), L.ptr(out), ldo, cols,
+                                        L.stream_ptr()), "sa_mlp_pair")
     return out
 
 
