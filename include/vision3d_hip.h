@@ -315,6 +315,11 @@ int v3d_bev_bilinear(const float* feature_map, const float* grid, int B, int C, 
 int v3d_bev_gather_keypoints(const float* feature_map, const float* keypoint_xyz, int B, int C, int H, int W, int K, float offset_x,
                              float offset_y, float pixel_x, float pixel_y, float* out, int ldo, v3d_stream_t stream);
 
+/* SparseCNNBase.to_global in one launch (detector/sparse_cnn.py:91-105): out (n, 3) = (x, y, z) = float(indices[:, (3, 2, 1)]) *
+ * scale + offset, one conversion, one multiply and one add per coordinate; indices (n, 4) i32 = (b, z, y, x), 16-byte aligned;
+ * scale = base_voxel_size * stride as the caller rounded it in fp32. */
+int v3d_voxel_centers(const int32_t* indices, int n, float scale_x, float scale_y, float scale_z, float offset_x, float offset_y,
+                      float offset_z, float* out, v3d_stream_t stream);
 /* RoiGridPool.sample_gridpoints in one launch (detector/roi_grid_pool.py:52-62): points[b, n, j] = centre + Rz(yaw) (size * (sample - 0.5))
  * with the module's own fp32 statements, one IEEE operation each; boxes (B*n, 7) = x, y, z, w, l, h, yaw, samples (B*n, m, 3) in
  * [0, 1), cos_yaw / sin_yaw (B*n) from the caller (torch's cos / sin: the same values as the op-by-op path), out (B*n, m, 3). */

@@ -641,6 +641,24 @@ def test_fused_keypoint_features_equal_the_op_by_op_path():
         torch.testing.assert_close(got.double(), ref, rtol=2e-5, atol=2e-5 * ref.abs().max().item())
 
 
+def test_voxel_centers_equal_the_torch_statements():
+    """SparseCNNBase.to_global on v3d_voxel_centers == flip / float / multiply / add op by op, every stride of the config."""
+    from vision3d_amd import spconv
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.detector import sparse_cnn
+    cfg = second_car_cfg()
+    cnn = sparse_cnn.CNN_FACTORY[cfg.CNN](cfg).cuda()
+    g = torch.Generator().manual_seed(0)
+    ind = torch.stack([torch.zeros(5000, dtype=torch.int32), torch.randint(0, 41, (5000,), generator=g, dtype=torch.int32),
+                       torch.randint(0, 1600, (5000,), generator=g, dtype=torch.int32),
+                       torch.randint(0, 1408, (5000,), generator=g, dtype=torch.int32)], dim=1).cuda()
+    vol = spconv.SparseConvTensor(torch.randn(5000, 16, device="cuda"), ind, cnn.grid_shape, 1)
+    for stride in cfg.STRIDES:
+        xyz, feat = cnn.to_global(stride, vol)
+        ref_xyz, ref_feat = cnn.to_global_torch(stride, vol)
+        assert torch.equal(xyz, ref_xyz) and torch.equal(feat, ref_feat)
+
+
 def test_bev_bilinear_equals_grid_sample():
     """v3d_bev_bilinear == F.grid_sample(bilinear, zeros, align_corners=True) on a (B, 1, K, 2) grid, including points on and
     beyond the border (the gatherer clamps, the kernel must still zero-pad like torch)."""

@@ -971,6 +971,31 @@ extern "C" int v3d_bev_gather_keypoints(const float* feature_map, const float* k
   return V3D_OK;
 }
 
+// ------------------------------------------------------------------------------------------ voxel sites -> metric positions
+// SparseCNNBase.to_global (vision3d/detector/sparse_cnn.py:91-105): xyz = indices.flip(1)[:, :3].float() * (base_voxel_size * stride) +
+// voxel_offset -- an int -> float conversion, one multiply, one add per coordinate (each rounded on its own), five torch launches per
+// level before.  indices (n, 4) = (b, z, y, x); `scale` = base_voxel_size * stride as the caller computed it in fp32.
+__global__ __launch_bounds__(V3D_BLOCK) void voxel_centers_kernel(const int* __restrict__ indices, int n, float sx, float sy, float sz,
+                                                                  float ox, float oy, float oz, float* __restrict__ out) {
+  for (int i = blockIdx.x * V3D_BLOCK + threadIdx.x; i < n; i += gridDim.x * V3D_BLOCK) {
+    const int4 c = reinterpret_cast<const int4*>(indices)[i];  // (b, z, y, x)
+    out[3 * (size_t)i] = (float)c.w * sx + ox;
+    out[3 * (size_t)i + 1] = (float)c.z * sy + oy;
+    out[3 * (size_t)i + 2] = (float)c.y * sz + oz;
+  }
+}
+
+extern "C" int v3d_voxel_centers(const int32_t* indices, int n, float scale_x, float scale_y, float scale_z, float offset_x,
+                                 float offset_y, float offset_z, float* out, v3d_stream_t stream) {
+  if (n < 0) return V3D_EINVAL;
+  if (n == 0) return V3D_OK;
+  if (!indices || !out || ((uintptr_t)indices & 15)) return V3D_EINVAL;
+  hipLaunchKernelGGL(voxel_centers_kernel, dim3(std::min(v3d_ceil_div(n, V3D_BLOCK), 4096)), dim3(V3D_BLOCK), 0, (hipStream_t)stream,
+                     indices, n, scale_x, scale_y, scale_z, offset_x, offset_y, offset_z, out);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 // ------------------------------------------------------------------------------------------ RoI grid points
 // RoiGridPool.sample_gridpoints (vision3d/detector/roi_grid_pool.py:52-62) statement by statement, every operation rounded on its own
 // (-ffp-contract=off): local = size * (sample - 0.5); rotated = (cos * lx - sin * ly, sin * lx + cos * ly, lz); point = centre + rotated.

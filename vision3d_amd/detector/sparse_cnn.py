@@ -133,6 +133,27 @@ class SparseCNNBase(nn.Module):
     def to_global(self, stride, volume):
         """Active sites of one level -> (metric xyz of the cell corner, features), padded per frame
         (sparse_cnn.py:91-105).  indices are (b, z, y, x); flipped they read (x, y, z, b)."""
+        ind = volume.indices
+        if ind.is_cuda and ind.dtype == torch.int32 and ind.dim() == 2 and ind.shape[1] == 4 and ind.is_contiguous() and ind.data_ptr() % 16 == 0:
+            # the statements below in one launch (csrc/pointops.hip v3d_voxel_centers): same values
+            from .. import _lib as L
+            consts = self.__dict__.setdefault("_global_consts", {})
+            if stride not in consts:  # base_voxel_size * stride rounded in fp32 like the tensor product, once, on the host
+                consts[stride] = ((self.base_voxel_size.detach().cpu().float() * stride).tolist(), self.voxel_offset.detach().cpu().float().tolist())
+            (sx, sy, sz), (ox, oy, oz) = consts[stride]
+            xyz = torch.empty((ind.shape[0], 3), dtype=torch.float32, device=ind.device)
+            with torch.cuda.device(ind.device):
+                L.check(L.lib().v3d_voxel_centers(L.ptr(ind), ind.shape[0], sx, sy, sz, ox, oy, oz, L.ptr(xyz), L.stream_ptr()), "voxel_centers")
+            frame = ind[:, 0]
+        else:
+            xyzb = ind.flip(1)
+            frame = xyzb[:, 3]
+            xyz = xyzb[:, :3].float() * (self.base_voxel_size * stride) + self.voxel_offset
+        return (self.pad_batch(xyz, frame, volume.batch_size),
+                self.pad_batch(volume.features, frame, volume.batch_size))
+
+    def to_global_torch(self, stride, volume):
+        """The reference's statements op by op (the cross-check of the fused launch in the tests)."""
         xyzb = volume.indices.flip(1)
         frame = xyzb[:, 3]
         xyz = xyzb[:, :3].float() * (self.base_voxel_size * stride) + self.voxel_offset
