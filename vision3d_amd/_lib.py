@@ -5,6 +5,7 @@ is missing or a tensor is not on the GPU, the call raises -- the product path ne
 CPU implementation (oracle/ is test infrastructure and is not importable from here).
 """
 import ctypes as C
+import contextlib
 import os
 
 import torch
@@ -204,8 +205,27 @@ def check(code, what):
         raise RuntimeError(f"{what} failed: {msg} (code {code})")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """The current HIP stream of the current device as an integer handle (tools/mb_host_call.py: 2.75 us through
+    torch.cuda.current_stream(), 0.3 us through the raw accessor -- an eager PV-RCNN frame makes ~100 operator calls)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+_NULL_GUARD = contextlib.nullcontext()
+
+
+def device_guard(device):
+    """`with device_guard(t.device):` -- torch.cuda.device(device) only when it is not the current device already (the usual case:
+    0.4 instead of 1.3 us per operator call)."""
+    index = device.index if isinstance(device, torch.device) else torch.device(device).index
+    if index is None or index == torch.cuda.current_device():
+        return _NULL_GUARD
+    return torch.cuda.device(index)
 
 
 def ptr(t):

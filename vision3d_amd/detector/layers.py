@@ -79,7 +79,7 @@ class BEVFeatureGatherer(nn.Module):
             out_pm = torch.empty((b, k, c), dtype=torch.float32, device=feature_map.device)
         if out_pm.shape[:2] != (b, k) or out_pm.shape[2] < c or out_pm.stride(2) != 1 or out_pm.stride(0) != k * out_pm.stride(1):
             raise RuntimeError("gather_point_major: out_pm must be a (B, K, >= C) view with unit channel stride and frames back to back")
-        with torch.cuda.device(feature_map.device):
+        with L.device_guard(feature_map.device):
             L.check(L.lib().v3d_bev_gather_keypoints(L.ptr(feature_map), L.ptr(xyz), b, c, height, width, k, off_x, off_y, pix_x, pix_y,
                                                      L.ptr(out_pm), out_pm.stride(1), L.stream_ptr()), "bev_gather_keypoints")
         return out_pm[:, :, :c]
@@ -102,7 +102,7 @@ class BEVFeatureGatherer(nn.Module):
             k = grid.shape[2]
             g = grid.reshape(b, k, 2).contiguous()
             out = torch.empty((b, c, k), dtype=torch.float32, device=feature_map.device)
-            with torch.cuda.device(feature_map.device):
+            with L.device_guard(feature_map.device):
                 L.check(L.lib().v3d_bev_bilinear(L.ptr(feature_map), L.ptr(g), b, c, height, width, k, L.ptr(out), L.stream_ptr()),
                         "bev_bilinear")
             return out

@@ -153,7 +153,7 @@ class ProposalLayer(nn.Module):
         lib = L.lib()
         ws = L.workspace(lib.v3d_proposals_workspace(B, n_cls, self.TOPK), dev)
         thresh = L.host_f32([a["score_thresh"] for a in cfg.ANCHORS[:n_cls]])
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             L.check(lib.v3d_proposals_flag(L.ptr(maps), L.ptr(anc), B, n_cls, n_yaw, H, W, self.TOPK, thresh, 0.01, L.ptr(boxes),
                                            L.ptr(batch_idx), L.ptr(class_idx), L.ptr(scores), L.ptr(n_out), L.ptr(overflow_flag),
                                            L.ptr(ws), ws.numel(), L.stream_ptr()), "proposals")
@@ -174,7 +174,7 @@ class ProposalLayer(nn.Module):
         scores = torch.empty((B, n_cls * self.TOPK), dtype=torch.float32, device=maps.device)
         lib = L.lib()
         ws = L.workspace(lib.v3d_proposals_workspace(B, n_cls, self.TOPK), maps.device)
-        with torch.cuda.device(maps.device):
+        with L.device_guard(maps.device):
             L.check(lib.v3d_proposals_topk(L.ptr(maps), L.ptr(anc), B, n_cls, n_yaw, H, W, self.TOPK, L.ptr(boxes), L.ptr(scores), L.ptr(ws),
                                            ws.numel(), L.stream_ptr()), "proposals_topk")
         assert N == boxes.shape[0] * boxes.shape[1]
@@ -202,7 +202,7 @@ class ProposalLayer(nn.Module):
         lib = L.lib()
         ws = L.workspace(lib.v3d_refine_nms_workspace(B, n_cls, self.TOPK), dev)
         thresh = L.host_f32([a["score_thresh"] for a in cfg.ANCHORS[:n_cls]])
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             L.check(lib.v3d_refine_nms(L.ptr(d), L.ptr(p), L.ptr(c), B, n_cls, self.TOPK, thresh, float(iou_threshold), L.ptr(refined),
                                        L.ptr(boxes), L.ptr(batch_idx), L.ptr(class_idx), L.ptr(scores), L.ptr(n_out), L.ptr(ws), ws.numel(),
                                        L.stream_ptr()), "refine_nms")
@@ -306,7 +306,7 @@ class FusedProposalLossFunction(torch.autograd.Function):
         dmaps = torch.empty_like(maps)
         lib = L.lib()
         ws = L.workspace(lib.v3d_proposal_loss_workspace(), maps.device)
-        with torch.cuda.device(maps.device):
+        with L.device_guard(maps.device):
             L.check(lib.v3d_proposal_loss_fwd_bwd(L.ptr(maps), L.ptr(g_cls), L.ptr(m_cls), L.ptr(g_reg), L.ptr(m_reg), b, n_cls, n_yaw, h, w,
                                                   float(alpha), float(gamma), L.ptr(losses), L.ptr(dmaps), L.ptr(ws), ws.numel(),
                                                   L.stream_ptr()), "proposal_loss_fwd_bwd")
@@ -322,7 +322,7 @@ class FusedProposalLossFunction(torch.autograd.Function):
             raise RuntimeError("fused proposal loss: backward called twice (the gradient buffer is consumed by the first call)")
         gc = g_cls_loss.to(torch.float32).contiguous()
         gr = g_reg_loss.to(torch.float32).contiguous()
-        with torch.cuda.device(dmaps.device):
+        with L.device_guard(dmaps.device):
             L.check(L.lib().v3d_proposal_loss_scale(L.ptr(dmaps), *ctx.geom, L.ptr(gc), L.ptr(gr), L.stream_ptr()), "proposal_loss_scale")
         return (dmaps,) + (None,) * 8
 

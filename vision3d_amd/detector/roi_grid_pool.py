@@ -53,7 +53,7 @@ class RoiGridPool(nn.Module):
             yaw = bx[..., 6]
             cos, sin = yaw.cos().contiguous(), yaw.sin().contiguous()
             out = torch.empty_like(sm)
-            with torch.cuda.device(bx.device):
+            with L.device_guard(bx.device):
                 L.check(L.lib().v3d_roi_grid_points(L.ptr(bx), L.ptr(sm), L.ptr(cos), L.ptr(sin), b * n, sm.shape[2], L.ptr(out),
                                                     L.stream_ptr()), "roi_grid_points")
             return out

@@ -142,7 +142,7 @@ class SparseCNNBase(nn.Module):
                 consts[stride] = ((self.base_voxel_size.detach().cpu().float() * stride).tolist(), self.voxel_offset.detach().cpu().float().tolist())
             (sx, sy, sz), (ox, oy, oz) = consts[stride]
             xyz = torch.empty((ind.shape[0], 3), dtype=torch.float32, device=ind.device)
-            with torch.cuda.device(ind.device):
+            with L.device_guard(ind.device):
                 L.check(L.lib().v3d_voxel_centers(L.ptr(ind), ind.shape[0], sx, sy, sz, ox, oy, oz, L.ptr(xyz), L.stream_ptr()), "voxel_centers")
             frame = ind[:, 0]
         else:

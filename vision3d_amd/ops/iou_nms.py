@@ -19,7 +19,7 @@ def box_iou_rotated(boxes1, boxes2):
         raise RuntimeError("box_iou_rotated: expected (M,5) and (N,5)")
     m, n = b1.shape[0], b2.shape[0]
     out = torch.empty((m, n), dtype=torch.float32, device=b1.device)
-    with torch.cuda.device(b1.device):
+    with L.device_guard(b1.device):
         L.check(L.lib().v3d_box_iou_rotated(L.ptr(b1), m, L.ptr(b2), n, L.ptr(out), L.stream_ptr()), "box_iou_rotated")
     return out
 
@@ -35,7 +35,7 @@ def box_iou_rotated_3d(boxes1, boxes2):
         raise RuntimeError("box_iou_rotated_3d: expected (M,7) and (N,7)")
     m, n = b1.shape[0], b2.shape[0]
     out = torch.empty((m, n), dtype=torch.float32, device=b1.device)
-    with torch.cuda.device(b1.device):
+    with L.device_guard(b1.device):
         L.check(L.lib().v3d_box_iou_rotated_3d(L.ptr(b1), m, L.ptr(b2), n, L.ptr(out), L.stream_ptr()), "box_iou_rotated_3d")
     return out
 
@@ -66,7 +66,7 @@ def nms_rotated_padded(boxes, scores, iou_threshold, rule="cpu"):
     if n:
         lib = L.lib()
         ws = L.workspace(lib.v3d_nms_rotated_workspace(n), b.device)
-        with torch.cuda.device(b.device):
+        with L.device_guard(b.device):
             L.check(lib.v3d_nms_rotated(L.ptr(b), L.ptr(s), n, float(iou_threshold), L.ptr(keep), L.ptr(n_keep),
                                         L.ptr(ws), ws.numel(), L.stream_ptr()), "nms_rotated")
     return keep, n_keep

@@ -13,7 +13,7 @@ def furthest_point_sample(xyz, npoint):
     p = L.as_f32("furthest_point_sample", xyz)
     b, n, _ = p.shape
     idx = torch.empty((b, npoint), dtype=torch.int32, device=p.device)
-    with torch.cuda.device(p.device):
+    with L.device_guard(p.device):
         L.check(L.lib().v3d_furthest_point_sample(L.ptr(p), b, n, int(npoint), L.ptr(idx), 0, 0, L.stream_ptr()),
                 "furthest_point_sample")
     return idx
@@ -68,7 +68,7 @@ def _gather_forward(features, idx):
     b, c, n = f.shape
     k = i.shape[1]
     out = torch.empty((b, c, k), dtype=torch.float32, device=f.device)
-    with torch.cuda.device(f.device):
+    with L.device_guard(f.device):
         L.check(L.lib().v3d_gather_points(L.ptr(f), L.ptr(i), b, c, n, k, L.ptr(out), L.stream_ptr()), "gather_points")
     return out
 
@@ -109,7 +109,7 @@ def ball_query_grids(databases):
         dev = part[0][0].device
         sizes = [int(L.lib().v3d_ball_query_grid_workspace(b, xyz.shape[1])) for xyz, _ in part]
         wss = [torch.empty(max(sz, 16), dtype=torch.uint8, device=dev) for sz in sizes]
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             L.check(L.lib().v3d_ball_query_grid_build(
                 n_db, (C.c_void_p * n_db)(*[xyz.data_ptr() for xyz, _ in part]), (C.c_int32 * n_db)(*[xyz.shape[1] for xyz, _ in part]),
                 (C.c_float * n_db)(*[abs(float(r)) for _, r in part]), (C.c_void_p * n_db)(*[w.data_ptr() for w in wss]),
@@ -121,7 +121,7 @@ def ball_query_grids(databases):
 def _ball_query_call(p, q, radius_a, nsample_a, idx_a, radius_b, nsample_b, idx_b, what, grid=None):
     b, n, _ = p.shape
     m = q.shape[1]
-    with torch.cuda.device(p.device):
+    with L.device_guard(p.device):
         if grid is not None and BALL_QUERY_ALGO == "grid":
             if not grid.matches(p, max(abs(radius_a), abs(radius_b) if idx_b is not None else 0.0)):
                 raise RuntimeError(f"{what}: the grid was built from another database (or for a smaller radius)")
@@ -176,7 +176,7 @@ def _group_forward(features, idx):
     b, c, n = f.shape
     _, m, ns = i.shape
     out = torch.empty((b, c, m, ns), dtype=torch.float32, device=f.device)
-    with torch.cuda.device(f.device):
+    with L.device_guard(f.device):
         L.check(L.lib().v3d_group_points(L.ptr(f), L.ptr(i), b, c, n, m, ns, L.ptr(out), L.stream_ptr()),
                 "group_points")
     return out
@@ -239,7 +239,7 @@ def sa_mlp_layer(feat, w, bias, relu=True, pool=False, xyz=None, new_xyz=None, i
         out, ldo = torch.empty((rows, cols), dtype=torch.float32, device=f.device), cols
     else:
         out, ldo = _strided_rows("sa_mlp_layer", out, rows, cols)
-    with torch.cuda.device(f.device):
+    with L.device_guard(f.device):
         L.check(L.lib().v3d_sa_mlp_layer(L.ptr(f), L.ptr(x), L.ptr(q), L.ptr(ii), b, n, m, ns, kf, L.ptr(wf), L.ptr(bf), nout,
                                          int(bool(relu)), int(bool(pool)), L.ptr(out), ldo, cols, L.stream_ptr()), "sa_mlp_layer")
     return out
@@ -268,7 +268,7 @@ def sa_mlp_pair(p, xyz, new_xyz, idx, wx, b1, w, bias, relu=True, pool=True, out
         out, ldo = torch.empty((rows, cols), dtype=torch.float32, device=p.device), cols
     else:
         out, ldo = _strided_rows("sa_mlp_pair", out, rows, cols)
-    with torch.cuda.device(p.device):
+    with L.device_guard(p.device):
         L.check(L.lib().v3d_sa_mlp_pair(L.ptr(p), L.ptr(x), L.ptr(q), L.ptr(ii), b, n, m, ns, k1, p.stride(1), L.ptr(wxf), L.ptr(b1f),
                                         L.ptr(wf), L.ptr(bf), nout, int(bool(relu)), int(bool(pool)), L.ptr(out), ldo, cols,
                                         L.stream_ptr()), "sa_mlp_pair")
@@ -293,7 +293,7 @@ def linear_rows(a, w, bias=None, relu=False, out=None, n_store=None):
         out, ldo = torch.empty((r, cols), dtype=torch.float32, device=a.device), cols
     else:
         out, ldo = _strided_rows("linear_rows", out, r, cols)
-    with torch.cuda.device(a.device):
+    with L.device_guard(a.device):
         L.check(L.lib().v3d_linear_rows(L.ptr(a), a.stride(0) if r > 1 else max(a.stride(0), k), r, k, L.ptr(wf), L.ptr(bf), nout,
                                         int(bool(relu)), L.ptr(out), ldo, cols, L.stream_ptr()), "linear_rows")
     return out

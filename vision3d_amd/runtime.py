@@ -109,7 +109,7 @@ class BackbonePlan(object):
         c.max_batch, c.max_points, c.n_layers, c.growth = self.max_batch, self.max_points, len(self.layers), float(growth)
         c.conv_algo = int(conv_algo)
         self._handle = C.c_void_p()
-        with torch.cuda.device(self.device):
+        with L.device_guard(self.device):
             L.check(L.lib().v3d_backbone_create(C.byref(c), descs, C.byref(self._handle)), "backbone_create")
         self.precision = None
         self.set_precision(precision)
@@ -195,7 +195,7 @@ class BackbonePlan(object):
             self._calib = "need"
         lib = L.lib()
         keep = []
-        with torch.cuda.device(self.device), torch.no_grad():
+        with L.device_guard(self.device), torch.no_grad():
             for i, (conv, bn, _) in enumerate(self.layers):
                 w = conv.weight.detach().to(self.device, torch.float32).reshape(-1, conv.in_channels, conv.out_channels).contiguous()
                 scale = shift = None
@@ -230,7 +230,7 @@ class BackbonePlan(object):
         d, h, w = self.out_shape
         if out is None:
             out = torch.empty((b, self.out_channels * d, h, w), dtype=torch.float32, device=pts.device)
-        with torch.cuda.device(pts.device):
+        with L.device_guard(pts.device):
             L.check(L.lib().v3d_backbone_forward(self._handle, L.ptr(pts), pts.shape[0], L.host_i32(frame_offsets), b,
                                                  L.ptr(out), None, None, L.stream_ptr()), "backbone_forward")
         if self._maybe_tune():
@@ -303,7 +303,7 @@ class BackbonePlan(object):
         b = len(frame_offsets) - 1
         d, h, w = self.out_shape
         hi, lo = self.own_planes(b) if persistent else self._tag(*split_planes_like(b, h, w, self.out_channels * d, pts.device))
-        with torch.cuda.device(pts.device):
+        with L.device_guard(pts.device):
             L.check(L.lib().v3d_backbone_forward(self._handle, L.ptr(pts), pts.shape[0], L.host_i32(frame_offsets), b, 0,
                                                   L.ptr(hi), L.ptr(lo), L.stream_ptr()), "backbone_forward2")
         if self._maybe_tune():  # once: kernels are now picked by the observed sparsity
@@ -315,7 +315,7 @@ class BackbonePlan(object):
         voxelizer, no rulebook build); same planes as forward_split returned."""
         d, h, w = self.out_shape
         hi, lo = self._tag(*split_planes_like(int(batch_size), h, w, self.out_channels * d, device))
-        with torch.cuda.device(device):
+        with L.device_guard(device):
             L.check(L.lib().v3d_backbone_forward_reuse(self._handle, int(batch_size), 0, L.ptr(hi), L.ptr(lo), L.stream_ptr()),
                     "backbone_forward_reuse")
         return hi, lo
@@ -331,7 +331,7 @@ class BackbonePlan(object):
             raise RuntimeError("backbone: voxel_mean (M, C_IN) / coordinates (M, 4) expected")
         d, h, w = self.out_shape
         hi, lo = self._tag(*split_planes_like(int(batch_size), h, w, self.out_channels * d, mean.device))
-        with torch.cuda.device(mean.device):
+        with L.device_guard(mean.device):
             L.check(L.lib().v3d_backbone_forward_voxels(self._handle, L.ptr(mean), L.ptr(coords), m, int(batch_size), 0,
                                                         L.ptr(hi), L.ptr(lo), L.stream_ptr()), "backbone_forward_voxels")
         if self._maybe_tune():
@@ -350,7 +350,7 @@ class BackbonePlan(object):
         d, h, w = self.out_shape
         if out is None:
             out = torch.empty((int(batch_size), self.out_channels * d, h, w), dtype=torch.float32, device=mean.device)
-        with torch.cuda.device(mean.device):
+        with L.device_guard(mean.device):
             L.check(L.lib().v3d_backbone_forward_voxels(self._handle, L.ptr(mean), L.ptr(coords), m, int(batch_size), L.ptr(out),
                                                         None, None, L.stream_ptr()), "backbone_forward_voxels")
         if self._maybe_tune():
@@ -420,7 +420,7 @@ class BackbonePlan(object):
         else:
             out = torch.empty((b, self.out_channels * d, h, w), dtype=torch.float32, device=mean.device)
         io = self._train_io()
-        with torch.cuda.device(mean.device):
+        with L.device_guard(mean.device):
             if not self.__dict__.get("_tuned") and not torch.cuda.is_current_stream_capturing():
                 # first step: a coordinate-only pass picks the kernels from the row counts BEFORE the step runs (the step
                 # itself is not repeatable: it updates the running statistics)
@@ -492,7 +492,7 @@ class BackbonePlan(object):
             grads.append(flat[off:off + p.numel()].view(p.shape))
             off += p.numel()
         io = self._train_io(grads)
-        with torch.cuda.device(g.device):
+        with L.device_guard(g.device):
             L.check(L.lib().v3d_backbone_train_backward(self._handle, 0 if nhwc else L.ptr(g), L.ptr(g) if nhwc else 0,
                                                         int(batch_size), io, L.stream_ptr()), "backbone_train_backward")
         return grads
@@ -569,7 +569,7 @@ class _DevMem(object):
 
 def _view(ptr, shape, dtype, device):
     typestr = {torch.float32: "<f4", torch.int32: "<i4", torch.int16: "<i2"}[dtype]
-    with torch.cuda.device(device):
+    with L.device_guard(device):
         return torch.as_tensor(_DevMem(ptr, shape, typestr), device=device)
 
 
@@ -612,7 +612,7 @@ def conv2d_split(x_hi, x_lo, image, bias, relu, cin, cout, ksize, out_split=True
         y = torch.empty((b, cout, h, w), dtype=torch.float32, device=dev)
     skipping = occ is not None and bg is not None
     ref, keep = _prec_struct(pr)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         # reset = (int32 tensor, words): OTHER call sites' counters this launch zeroes before its tiles run (words may be 0) instead
         # of resetting its own pair at its end (v3d_conv2d_nhwc_split; DenseHeadPlan.forward chains the layers)
         L.check(L.lib().v3d_conv2d_nhwc_split(L.ptr(x_hi), L.ptr(x_lo), L.ptr(image), L.ptr(bias), int(bool(relu)), b, h, w, cin, cout,
@@ -634,7 +634,7 @@ def pack_conv_weight(weight, scale=None, precision="bf16x3"):
     lib = L.lib()
     img = torch.empty(int(lib.v3d_conv2d_weight_image_bytes(cin, cout, k)), dtype=torch.uint8, device=w.device)
     sc = None if scale is None else scale.detach().to(torch.float32).contiguous()
-    with torch.cuda.device(w.device):
+    with L.device_guard(w.device):
         L.check(lib.v3d_conv2d_pack_weights(L.ptr(w), L.ptr(sc), cout, cin, k, L.PRECISIONS[precision], L.ptr(img), L.stream_ptr()),
                 "conv2d_pack_weights")
     return img
@@ -644,7 +644,7 @@ def act_entry_from_tensor(x, headroom_bits=0):
     """(4,) device entry {s, 1/s, limit, max} from the EXACT maximum of a float32 tensor (v3d_act_scale_from_rows)."""
     x = L.as_f32("act_entry_from_tensor", x)
     entry = torch.empty(4, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with L.device_guard(x.device):
         L.check(L.lib().v3d_act_scale_from_rows(L.ptr(x), None, x.numel(), 1, int(headroom_bits), L.ptr(entry),
                                                  L.ptr(L.scale_scratch(x.device)), L.stream_ptr()), "act_scale_from_rows")
     return entry
@@ -656,7 +656,7 @@ def rows_split(rows, precision="fp32", entry=None):
     x = L.as_f32("rows_split", rows)
     n, c = x.shape
     out = torch.empty((n, 2 * c), dtype=torch.int16, device=x.device)
-    with torch.cuda.device(x.device):
+    with L.device_guard(x.device):
         L.check(L.lib().v3d_sparse_rows_split(L.ptr(x), None, max(n, 1), c, L.PRECISIONS[precision], L.ptr(entry), L.ptr(out), L.stream_ptr()),
                 "sparse_rows_split")
     return out
@@ -677,7 +677,7 @@ def to_split_nhwc(x, precision="bf16x3"):
     hi, lo = split_planes_like(b, h, w, c, x.device)
     f16s = L.PRECISIONS[precision] == L.PREC_F16S
     entry = act_entry_from_tensor(x) if f16s else None
-    with torch.cuda.device(x.device):
+    with L.device_guard(x.device):
         L.check(L.lib().v3d_nchw_to_split_nhwc(L.ptr(x), b, c, h, w, L.ptr(hi), L.ptr(lo), L.PRECISIONS[precision], L.ptr(entry),
                                                 L.stream_ptr()), "nchw_to_split_nhwc")
     tag_planes(hi, entry)
@@ -925,7 +925,7 @@ class DenseHeadPlan(object):
                 b, h, w, _ = x_hi.shape
                 maps = torch.empty((b, head["cout"], h, w), dtype=torch.float32, device=x_hi.device)
                 ref, keep = _prec_struct(self._pr(i, in_entry, range_flag))
-                with torch.cuda.device(x_hi.device):
+                with L.device_guard(x_hi.device):
                     L.check(L.lib().v3d_conv2d_1x1_head_fused(L.ptr(x_hi), L.ptr(x_lo), L.ptr(ly["img"]), L.ptr(ly["bias"]),
                                                                int(bool(ly["relu"])), L.ptr(head["img"]), L.ptr(head["bias"]),
                                                                int(bool(head["relu"])), b, h, w, 128, head["cout"], L.ptr(maps),

@@ -32,7 +32,7 @@ def build_subm_rulebook(x, ksize):
     if n:
         lib = L.lib()
         ws = L.workspace(lib.v3d_rulebook_workspace(n, n, k), dev)
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             L.check(lib.v3d_rulebook_subm(L.ptr(x.indices), L.ptr(x.n_dev), n, L.host_i32(x.spatial_shape),
                                           L.host_i32(ksize), L.ptr(nbr), L.ptr(ws), ws.numel(), L.stream_ptr()),
                     "rulebook_subm")
@@ -57,7 +57,7 @@ def build_sparse_rulebook(x, ksize, stride, padding):
     if n:
         lib = L.lib()
         ws = L.workspace(lib.v3d_rulebook_workspace(n, cap_out, k), dev)
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             L.check(lib.v3d_rulebook_sparse(L.ptr(x.indices), L.ptr(x.n_dev), n, L.host_i32(x.spatial_shape),
                                             L.host_i32(ksize), L.host_i32(stride), L.host_i32(padding),
                                             L.ptr(coords_out), L.ptr(n_out), cap_out, L.ptr(nbr), L.ptr(overflow),
@@ -94,7 +94,7 @@ def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False
         img = packed if packed is not None else pack_sparse_weight(w, k, cin, cout, precision)
         prec = L.PRECISIONS[precision]
         entry = None
-        with torch.cuda.device(feat.device):
+        with L.device_guard(feat.device):
             if prec == L.PREC_F16S:
                 entry = torch.empty(4, dtype=torch.float32, device=feat.device)
                 L.check(L.lib().v3d_act_scale_from_rows(L.ptr(feat), None, feat.shape[0], cin, 0, L.ptr(entry),
@@ -104,7 +104,7 @@ def sparse_conv_forward(features, weight, rb, scale=None, shift=None, relu=False
                                                         -int(variant) if variant else int(rb.n), prec, L.ptr(entry), None, None, None, None,
                                                         L.stream_ptr()), "sparse_conv_fwd_packed")
         return out
-    with torch.cuda.device(feat.device):
+    with L.device_guard(feat.device):
         L.check(L.lib().v3d_sparse_conv_fwd(L.ptr(feat), L.ptr(w), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k, cin,
                                             cout, L.ptr(sc), L.ptr(sh), int(bool(relu)), L.ptr(out), int(algo),
                                             L.stream_ptr()), "sparse_conv_fwd")
@@ -115,7 +115,7 @@ def pack_sparse_weight(w_flat, k, cin, cout, precision="bf16x3"):
     """(K,Cin,Cout) fp32 -> split 16-bit fragments in MFMA order (csrc/spconv.hip spconv_pack_weights_kernel) for the arithmetic."""
     lib = L.lib()
     img = torch.empty(int(lib.v3d_sparse_conv_weight_image_bytes(k, cin, cout)), dtype=torch.uint8, device=w_flat.device)
-    with torch.cuda.device(w_flat.device):
+    with L.device_guard(w_flat.device):
         L.check(lib.v3d_sparse_conv_pack_weights(L.ptr(w_flat), k, cin, cout, L.PRECISIONS[precision], L.ptr(img), L.stream_ptr()),
                 "sparse_conv_pack_weights")
     return img

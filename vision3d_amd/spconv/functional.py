@@ -19,7 +19,7 @@ def sparse_conv_bwd_weight(features, grad_out, rb, k, cin, cout):
     if rb.n == 0:
         return dw.zero_()
     ws = L.workspace(lib.v3d_sparse_conv_bwd_weight_workspace(k, cin, cout), x.device)
-    with torch.cuda.device(x.device):
+    with L.device_guard(x.device):
         L.check(lib.v3d_sparse_conv_bwd_weight(L.ptr(x), L.ptr(g), L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k, cin, cout,
                                                L.ptr(dw), L.ptr(ws), ws.numel(), L.stream_ptr()), "sparse_conv_bwd_weight")
     return dw
@@ -30,7 +30,7 @@ def transpose_rulebook(rb, n_in, device):
     k = rb.nbr.shape[0]
     cap_in = max(n_in, 1)
     nbr_t = torch.empty((k, cap_in), dtype=torch.int32, device=device)
-    with torch.cuda.device(device):
+    with L.device_guard(device):
         L.check(L.lib().v3d_rulebook_transpose(L.ptr(rb.nbr), L.ptr(rb.n_dev), rb.cap, k, cap_in, L.ptr(nbr_t), L.stream_ptr()),
                 "rulebook_transpose")
     n_dev = torch.tensor([n_in], dtype=torch.int32, device=device)
@@ -100,7 +100,7 @@ class SparseBatchNormReLUFunction(torch.autograd.Function):
         y = torch.empty_like(xf)
         stats = torch.empty((3, c), dtype=torch.float32, device=dev)  # save_mean | save_invstd | unbiased variance
         ws = _sbn_workspace(dev)
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             L.check(lib.v3d_sparse_bn_relu_fwd(xf.data_ptr(), n, c, weight.data_ptr(), bias.data_ptr(), float(eps), int(bool(relu)),
                                                y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
                                                L.ptr(running_mean), L.ptr(running_var), float(momentum),
@@ -120,7 +120,7 @@ class SparseBatchNormReLUFunction(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
         ws = _sbn_workspace(dev)
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             L.check(lib.v3d_sparse_bn_relu_bwd(x.data_ptr(), g.data_ptr(), n, c, weight.data_ptr(), bias.data_ptr(),
                                                stats[0].data_ptr(), stats[1].data_ptr(), int(ctx.relu), dx.data_ptr(),
                                                dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(), ws.numel(), L.stream_ptr()),

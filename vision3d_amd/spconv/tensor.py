@@ -70,7 +70,7 @@ class SparseConvTensor(object):
         out = torch.empty((self.batch_size, c, d, h, w), dtype=torch.float32, device=feat.device)
         if n == 0:
             return out.zero_() if channels_first else out.zero_().permute(0, 2, 3, 4, 1).contiguous()
-        with torch.cuda.device(feat.device):
+        with L.device_guard(feat.device):
             L.check(L.lib().v3d_densify(L.ptr(feat), L.ptr(self.indices), L.ptr(self.n_dev), n, self.batch_size, c,
                                         L.host_i32(self.spatial_shape), L.ptr(out), L.stream_ptr()), "densify")
         return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
