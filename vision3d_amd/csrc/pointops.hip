@@ -768,17 +768,20 @@ __global__ __launch_bounds__(BQG_WAVES * 64) void bq_grid_query_kernel(const flo
         if (lane >= d) pre += up;
       }
       int cnt_a = 0, cnt_b = 0;
+      // (run r of the walk below is wave-uniform: v_readlane, not a trip through the LDS crossbar per value -- 72 of them per sparse query)
+      auto lane_of = [](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
       for (int ch0 = 0; ch0 < g.nch;) {
         // a group of whole chunks: at least BQG_BATCH candidates (BQG_RPL records per lane in flight) or all that is left
-        const int base = ch0 ? __shfl(pre, 3 * ch0 - 1) : 0;
-        int ch1 = ch0 + 1, gend = __shfl(pre, 3 * ch1 - 1);
-        while (ch1 < g.nch && gend - base < BQG_BATCH) ch1++, gend = __shfl(pre, 3 * ch1 - 1);
+        const int base = ch0 ? lane_of(pre, 3 * ch0 - 1) : 0;
+        int ch1 = ch0 + 1, gend = lane_of(pre, 3 * ch1 - 1);
+        while (ch1 < g.nch && gend - base < BQG_BATCH) ch1++, gend = lane_of(pre, 3 * ch1 - 1);
         for (int t0 = base; t0 < gend; t0 += BQG_BATCH) {
           int rec[BQG_RPL];
 #pragma unroll
           for (int u = 0; u < BQG_RPL; u++) rec[u] = -1;
           for (int r = 3 * ch0; r < 3 * ch1; r++) {  // which run holds candidate t (wave-uniform walk over the group's runs)
-            const int pe = __shfl(pre, r), ln = __shfl(len, r), sr = __shfl(s_run, r);
+            const int pe = lane_of(pre, r), ln = lane_of(len, r), sr = lane_of(s_run, r);
+            if (ln == 0) continue;
 #pragma unroll
             for (int u = 0; u < BQG_RPL; u++) {
               const int t = t0 + u * 64 + lane;

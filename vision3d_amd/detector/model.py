@@ -157,7 +157,11 @@ class PV_RCNN(nn.Module):
         dev = next(self.parameters()).device
         key = (str(dev), int(batch_size), int(max_points), int(slot))  # slot: frames in flight keep their levels in arenas of their own
         # the arithmetic of THIS model's sparse modules (set per instance by set_precision, or by hand on the modules), not the class default
-        precision = next((m.precision for m in self.cnn.modules() if isinstance(m, _SparseConvBase)), _SparseConvBase.precision)
+        first = self.__dict__.get("_first_sparse_conv")
+        if first is None or first[0] != id(self.cnn):
+            first = (id(self.cnn), next((m for m in self.cnn.modules() if isinstance(m, _SparseConvBase)), None))
+            self.__dict__["_first_sparse_conv"] = first
+        precision = first[1].precision if first[1] is not None else _SparseConvBase.precision
         if key not in plans:
             plans[key] = BackbonePlan(self.cnn, self.cfg, max_batch=batch_size, max_points=max_points, device=dev,
                                       growth=self.__dict__.get("plan_growth", 2.0), precision=precision)
@@ -199,10 +203,14 @@ class PV_RCNN(nn.Module):
                 seen[tkey] = (vm.clone(), co.clone())
             elif slot != 0:
                 plan.forward_voxels(seen[tkey][0], seen[tkey][1], b)
-        ends, k = [], 0  # index of the last layer of every stage in the plan's flat layer list
-        for stage in self.cnn.blocks:
-            k += sum(1 for m in stage.modules() if isinstance(m, spconv.conv._SparseConvBase))
-            ends.append(k - 1)
+        ends = self.__dict__.get("_stage_ends")  # index of the last layer of every stage in the plan's flat layer list (walked once:
+        if ends is None or ends[0] != id(self.cnn):  # the module tree of the CNN is ~60 modules)
+            ends, k = [id(self.cnn)], 0
+            for stage in self.cnn.blocks:
+                k += sum(1 for m in stage.modules() if isinstance(m, spconv.conv._SparseConvBase))
+                ends.append(k - 1)
+            self.__dict__["_stage_ends"] = ends
+        ends = ends[1:]
         bev_map = plan.forward_voxels(vm, co, b)
         outs = [plan.layer_output(e) for e in ends[:-1]]
         words = torch.cat([n for _, _, n, _ in outs] + [plan.overflow_any()])

@@ -35,6 +35,15 @@ class PointnetSAModuleMSG(nn.Module):
     def _fusable(self, features):
         if self.training or torch.is_grad_enabled() or features is None or not features.is_cuda or self.pool_method != "max_pool":
             return False
+        # the structural half depends on the module objects alone: judged once per set of children (an eager PV-RCNN frame asks six
+        # times; the walk below was 15 us of host time each)
+        key = tuple(id(m) for mlp in self.mlps for m in mlp) + tuple((g.nsample, g.use_xyz) for g in self.groupers)
+        cache = self.__dict__.setdefault("_fusable_cache", {})
+        if cache.get("key") != key:
+            cache["key"], cache["ok"] = key, self._fusable_structure()
+        return cache["ok"]
+
+    def _fusable_structure(self):
         for g, mlp in zip(self.groupers, self.mlps):
             if not g.use_xyz or g.nsample not in (16, 32):
                 return False
@@ -80,11 +89,16 @@ class PointnetSAModuleMSG(nn.Module):
         layer: xyz rows 0-2, a zero row, then the feature rows; channel counts padded with zeros to multiples of 4 / 16),
         cached until a parameter or running statistic changes."""
         mods = list(self.mlps[k])
-        convs = [m for m in mods if isinstance(m, nn.Conv2d)]
-        bns = [m for m in mods if isinstance(m, nn.BatchNorm2d)]
-        tensors = [t for c in convs for t in (c.weight, c.bias) if t is not None]
-        tensors += [t for b in bns for t in (b.weight, b.bias, b.running_mean, b.running_var)]
-        stamp = tuple((t.data_ptr(), t._version) for t in tensors)
+        lists = self.__dict__.setdefault("_pack_tensors", {})
+        mkey = tuple(id(m) for m in mods)
+        if k not in lists or lists[k][0] != mkey:  # (the parameter objects of these children, looked up once: nn.Module.__getattr__ is slow)
+            convs = [m for m in mods if isinstance(m, nn.Conv2d)]
+            bns = [m for m in mods if isinstance(m, nn.BatchNorm2d)]
+            lists[k] = (mkey, convs, bns, [(c, "weight") for c in convs] + [(c, "bias") for c in convs if c.bias is not None] +
+                        [(b, n) for b in bns for n in ("weight", "bias", "running_mean", "running_var")])
+        _, convs, bns, names = lists[k]
+        # (a Parameter may be REPLACED on its module -- .cuda(), load_state_dict(assign=True): read it through the module's dicts)
+        stamp = tuple((t.data_ptr(), t._version) for t in (m._parameters.get(n, None) if n in m._parameters else m._buffers[n] for m, n in names))
         cache = self.__dict__.setdefault("_pack_cache", {})
         if k in cache and cache[k][0] == stamp:
             return cache[k][1]
@@ -120,7 +134,12 @@ class PointnetSAModuleMSG(nn.Module):
 
     def out_channels(self):
         """Output channels per scale (the last convolution of every scale's MLP)."""
-        return [[mod for mod in mlp if isinstance(mod, nn.Conv2d)][-1].out_channels for mlp in self.mlps]
+        key = tuple(id(m) for mlp in self.mlps for m in mlp)
+        cache = self.__dict__.setdefault("_couts_cache", {})
+        if cache.get("key") != key:
+            cache["key"] = key
+            cache["couts"] = [[mod for mod in mlp if isinstance(mod, nn.Conv2d)][-1].out_channels for mlp in self.mlps]
+        return cache["couts"]
 
     def fused_forward(self, xyz, features_pm, new_xyz, out_pm=None, grid=None):
         """features_pm (B, N, C) POINT-major -> (B, M, sum(mlps[k][-1])) POINT-major: every scale's last layer writes its pooled rows
