@@ -301,6 +301,13 @@ int v3d_ball_query_grid_build(int n_db, const float* const* xyz, const int32_t* 
 int v3d_ball_query_grid_query(const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a, int32_t* idx_a,
                               float radius_b, int nsample_b, int32_t* idx_b, const void* workspace, size_t workspace_bytes,
                               v3d_stream_t stream);
+/* query_many: up to 8 queries around the SAME new_xyz (B, M, 3), each in its own database / grid with its own radii, in one launch
+ * (host arrays of n_jobs entries; idx_b[i] NULL: one radius for job i) -- the five set-abstraction modules of a PV-RCNN frame all
+ * ask around the frame's keypoints (detector/model.py:58-66). */
+int v3d_ball_query_grid_query_many(int n_jobs, const float* new_xyz, int B, int M, const int32_t* N, const float* radius_a,
+                                   const int32_t* nsample_a, int32_t* const* idx_a, const float* radius_b, const int32_t* nsample_b,
+                                   int32_t* const* idx_b, const void* const* workspace, const size_t* workspace_bytes,
+                                   v3d_stream_t stream);
 int v3d_group_points(const float* feat, const int32_t* idx, int B, int C, int N, int M, int nsample, float* out,
                      v3d_stream_t stream);
 /* Bilinear lookup of BEV features at keypoints: F.grid_sample(feature_map, grid, bilinear, zeros, align_corners=True) for a
@@ -356,6 +363,10 @@ int v3d_sa_mlp_pair(const float* P, const float* xyz, const float* new_xyz, cons
  * Exact fp32 products on the matrix cores, fixed summation order (K split over 8 waves, partial tiles added in wave order). */
 int v3d_linear_rows(const float* A, int lda, int R, int K, const float* W, const float* bias, int Nout, int relu, float* out, int ldo,
                     int n_store, v3d_stream_t stream);
+/* up to 8 such products in one launch (host arrays of n_jobs entries; bias / relu / ldo / n_store arrays may be NULL = none / 0). */
+int v3d_linear_rows_many(int n_jobs, const float* const* A, const int32_t* lda, const int32_t* R, const int32_t* K, const float* const* W,
+                         const float* const* bias, const int32_t* Nout, const int32_t* relu, float* const* out, const int32_t* ldo,
+                         const int32_t* n_store, v3d_stream_t stream);
 
 /* ---- Fused sparse-backbone plan: voxelizer -> [rulebooks + sparse conv layers] -> .dense().
  * The native form of the sparse half of Second.feature_extract (detector/second.py:20-24,41-46 over

@@ -495,6 +495,25 @@ def test_ball_query_grids_of_several_databases_in_one_launch():
         PU.ball_query(radii[0], 16, dbs[0], q, grid=grids[0])
 
 
+def test_many_queries_and_many_products_in_one_launch_equal_the_single_calls():
+    """PU.ball_query_pairs_many (several databases, the same queries, one launch) == ball_query_pair per database; PU.linear_rows_many
+    == linear_rows per product (different shapes in one launch)."""
+    from vision3d_amd.pointnet2 import pointnet2_utils as PU
+    g = torch.Generator().manual_seed(21)
+    dbs = [(torch.rand(2, n, 3, generator=g) * torch.tensor([70.0, 80.0, 4.0])).cuda() for n in (16384, 13001, 17000, 4612, 300)]
+    radii = [(0.4, 0.8), (0.4, 0.8), (0.8, 1.2), (2.4, 4.8), (1.0, 0.5)]
+    grids = PU.ball_query_grids([(d, max(r)) for d, r in zip(dbs, radii)])
+    q = dbs[0][:, torch.randint(0, 16384, (2048,), generator=g)].contiguous() + 0.03
+    outs = PU.ball_query_pairs_many([(gr, d, ra, 16, rb, 32) for gr, d, (ra, rb) in zip(grids, dbs, radii)], q)
+    for (ia, ib), gr, d, (ra, rb) in zip(outs, grids, dbs, radii):
+        sa, sb = PU.ball_query_pair(ra, 16, rb, 32, d, q, grid=gr)
+        assert torch.equal(ia, sa) and torch.equal(ib, sb)
+    jobs = [(torch.randn(r, k, device="cuda"), torch.randn(k, n, device="cuda") / k ** 0.5)
+            for r, k, n in ((16384, 4, 32), (13001, 16, 16), (777, 64, 128), (100, 3072, 256), (1, 4, 16))]
+    for got, (a, w) in zip(PU.linear_rows_many(jobs), jobs):
+        assert torch.equal(got, PU.linear_rows(a, w))
+
+
 def test_ball_query_grid_workspace_is_checked():
     from vision3d_amd import _lib as L
     xyz = torch.rand(1, 100, 3).cuda()

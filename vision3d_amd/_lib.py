@@ -66,6 +66,7 @@ _SIGNATURES = {
     "v3d_ball_query_grid_workspace": (_sz, [_i, _i]),
     "v3d_ball_query_grid": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _f, _i, _vp, _vp, _sz, _vp]),
     "v3d_ball_query_grid_build": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "v3d_ball_query_grid_query_many": (_i, [_i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "v3d_ball_query_grid_query": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _f, _i, _vp, _vp, _sz, _vp]),
     "v3d_group_points": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "v3d_bev_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -73,6 +74,7 @@ _SIGNATURES = {
     "v3d_sa_mlp_pair": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "v3d_voxel_centers": (_i, [_vp, _i, _f, _f, _f, _f, _f, _f, _vp, _vp]),
     "v3d_roi_grid_points": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "v3d_linear_rows_many": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "v3d_linear_rows": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _vp]),
     "v3d_bev_gather_keypoints": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _i, _vp]),
     "v3d_backbone_create": (_i, [_vp, _vp, _vp]),

@@ -728,16 +728,33 @@ __device__ __forceinline__ void bq_bitmap_emit(unsigned* __restrict__ bm, int wp
   }
 }
 
-__global__ __launch_bounds__(BQG_WAVES * 64) void bq_grid_query_kernel(const float* __restrict__ new_xyz, int M, float r2a, int nsa,
-                                                                       int* __restrict__ idxa, float r2b, int nsb,
-                                                                       int* __restrict__ idxb, const unsigned char* __restrict__ ws,
-                                                                       size_t ws_stride, int wpl) {
+struct BqQueryJob {
+  const unsigned char* ws;  // B frames of bqg_frame_bytes(N)
+  int* idxa;
+  int* idxb;                // nullable: one radius
+  size_t ws_stride;
+  float r2a, r2b;
+  int nsa, nsb;
+};
+struct BqQueryJobs {
+  BqQueryJob j[BQG_MAX_JOBS];
+};
+
+// grid: (query blocks, frame, job) -- the jobs share the queries (the set-abstraction modules of a PV-RCNN frame all ask around the
+// same keypoints, each in its own database: five dependent ~18 us launches as one)
+__global__ __launch_bounds__(BQG_WAVES * 64) void bq_grid_query_kernel(const float* __restrict__ new_xyz, int M, const BqQueryJobs jobs,
+                                                                       int wpl) {
   extern __shared__ unsigned bq_bits[];  // [waves][2][64 * wpl]
+  const BqQueryJob job = jobs.j[blockIdx.z];
+  const float r2a = job.r2a, r2b = job.r2b;
+  const int nsa = job.nsa, nsb = job.nsb;
+  int* __restrict__ idxa = job.idxa;
+  int* __restrict__ idxb = job.idxb;
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
   unsigned* ba = bq_bits + (size_t)wave * 2 * 64 * wpl;
   unsigned* bb = ba + 64 * wpl;
   for (int k = lane; k < 2 * 64 * wpl; k += 64) ba[k] = 0u;
-  const unsigned char* w = ws + (size_t)b * ws_stride;
+  const unsigned char* w = job.ws + (size_t)b * job.ws_stride;
   const BqGrid g = *reinterpret_cast<const BqGrid*>(w);
   const int* cell_start = reinterpret_cast<const int*>(w + BQG_HEADER_BYTES);
   const float4* sorted = reinterpret_cast<const float4*>(w + bqg_sorted_offset());
@@ -854,22 +871,40 @@ extern "C" int v3d_ball_query_grid_build(int n_db, const float* const* xyz, cons
   return V3D_OK;
 }
 
+extern "C" int v3d_ball_query_grid_query_many(int n_jobs, const float* new_xyz, int B, int M, const int32_t* N, const float* radius_a,
+                                              const int32_t* nsample_a, int32_t* const* idx_a, const float* radius_b,
+                                              const int32_t* nsample_b, int32_t* const* idx_b, const void* const* workspace,
+                                              const size_t* workspace_bytes, v3d_stream_t stream) {
+  if (n_jobs < 0 || n_jobs > BQG_MAX_JOBS || B < 0 || M < 0) return V3D_EINVAL;
+  if (n_jobs == 0 || B == 0 || M == 0) return V3D_OK;
+  if (!new_xyz || !N || !radius_a || !nsample_a || !idx_a || !workspace || !workspace_bytes) return V3D_EINVAL;
+  BqQueryJobs jobs;
+  int wpl = 1, waves = BQG_WAVES;
+  for (int i = 0; i < n_jobs; i++) {
+    const bool two = idx_b && idx_b[i];
+    if (N[i] < 1 || nsample_a[i] < 1 || !idx_a[i] || (two && (!radius_b || !nsample_b || nsample_b[i] < 1))) return V3D_EINVAL;
+    if (!workspace[i] || ((uintptr_t)workspace[i] & 15) || workspace_bytes[i] < v3d_ball_query_grid_workspace(B, N[i])) return V3D_EINVAL;
+    int wp, wv;
+    bqg_bitmap_shape(N[i], wp, wv);
+    if (wv < 1) return V3D_EUNSUPPORTED;
+    wpl = std::max(wpl, wp), waves = std::min(waves, wv);  // (a bitmap of the largest database serves every job)
+    jobs.j[i] = BqQueryJob{(const unsigned char*)workspace[i], idx_a[i], two ? idx_b[i] : nullptr, bqg_frame_bytes(N[i]),
+                           radius_a[i] * radius_a[i], two ? radius_b[i] * radius_b[i] : 0.f, nsample_a[i], two ? nsample_b[i] : 0};
+  }
+  const size_t per_wave = (size_t)2 * 64 * wpl * sizeof(unsigned);
+  const int blocks = std::min(v3d_ceil_div(M, waves), 4096);
+  hipLaunchKernelGGL(bq_grid_query_kernel, dim3(blocks, B, n_jobs), dim3(waves * 64), waves * per_wave, (hipStream_t)stream, new_xyz, M, jobs,
+                     wpl);
+  V3D_CHECK_LAUNCH();
+  return V3D_OK;
+}
+
 extern "C" int v3d_ball_query_grid_query(const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a, int32_t* idx_a,
                                          float radius_b, int nsample_b, int32_t* idx_b, const void* workspace, size_t workspace_bytes,
                                          v3d_stream_t stream) {
-  if (B < 0 || N < 1 || M < 0 || nsample_a < 1 || (idx_b && nsample_b < 1)) return V3D_EINVAL;
-  if (B == 0 || M == 0) return V3D_OK;
-  if (!new_xyz || !idx_a || !workspace || ((uintptr_t)workspace & 15) || workspace_bytes < v3d_ball_query_grid_workspace(B, N)) return V3D_EINVAL;
-  int wpl, waves;
-  bqg_bitmap_shape(N, wpl, waves);
-  if (waves < 1) return V3D_EUNSUPPORTED;
-  const size_t per_wave = (size_t)2 * 64 * wpl * sizeof(unsigned);
-  const int blocks = std::min(v3d_ceil_div(M, waves), 4096);
-  hipLaunchKernelGGL(bq_grid_query_kernel, dim3(blocks, B), dim3(waves * 64), waves * per_wave, (hipStream_t)stream, new_xyz, M,
-                     radius_a * radius_a, nsample_a, idx_a, radius_b * radius_b, nsample_b, idx_b, (const unsigned char*)workspace,
-                     bqg_frame_bytes(N), wpl);
-  V3D_CHECK_LAUNCH();
-  return V3D_OK;
+  if (N < 1 || nsample_a < 1 || (idx_b && nsample_b < 1)) return V3D_EINVAL;
+  return v3d_ball_query_grid_query_many(1, new_xyz, B, M, &N, &radius_a, &nsample_a, &idx_a, &radius_b, &nsample_b, &idx_b, &workspace,
+                                        &workspace_bytes, stream);
 }
 
 // v3d_ball_query through a cell grid of the database (same arguments, same results; `workspace` = v3d_ball_query_grid_workspace(B, N)

@@ -19,6 +19,8 @@
 // Tiling: a wave owns two 16-row tiles and all Nout columns (accumulators in registers); a workgroup of 8 waves (256 rows)
 // streams W through LDS in chunks of 64 k-rows shared by its 16 tiles.  The MFMA reduction index is permuted so that lane
 // (r, q) feeds four CONTIGUOUS floats of row r per 16-wide k block (one 16-byte load; A and B agree on the permutation).
+#include <algorithm>
+
 #include "v3d_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -255,9 +257,28 @@ extern "C" int v3d_sa_mlp_pair(const float* P, const float* xyz, const float* ne
 //   out[r, n] = act( sum_k A[r * lda + k] * W[k * Nout + n] + bias[n] ),  r < R, n < n_store;  K % 4 == 0, Nout % 16 == 0
 #define LIN_WAVES 8
 #define LIN_TPW 2  // 16-row tiles per workgroup (every wave multiplies both for its K range)
-__global__ __launch_bounds__(LIN_WAVES * 64) void linear_rows_kernel(const float* __restrict__ A, int lda, int R, int K,
-                                                                    const float* __restrict__ W, const float* __restrict__ bias,
-                                                                    int Nout, int relu, float* __restrict__ out, int ldo, int n_store) {
+#define LIN_MAX_JOBS 8
+struct LinJob {
+  const float* A;
+  const float* W;
+  const float* bias;
+  float* out;
+  int lda, R, K, Nout, relu, ldo, n_store;
+};
+struct LinJobs {
+  LinJob j[LIN_MAX_JOBS];
+};
+
+// grid: (column blocks, row blocks, job), sized for the largest job (a workgroup beyond its job's extent leaves): the first-layer
+// products of the five set-abstraction modules of a PV-RCNN frame are one launch
+__global__ __launch_bounds__(LIN_WAVES * 64) void linear_rows_kernel(const LinJobs jobs) {
+  const LinJob jb = jobs.j[blockIdx.z];
+  const float* __restrict__ A = jb.A;
+  const float* __restrict__ W = jb.W;
+  const float* __restrict__ bias = jb.bias;
+  float* __restrict__ out = jb.out;
+  const int lda = jb.lda, R = jb.R, K = jb.K, Nout = jb.Nout, relu = jb.relu, ldo = jb.ldo, n_store = jb.n_store;
+  if ((int)blockIdx.x * 16 >= Nout || (int)blockIdx.y * (16 * LIN_TPW) >= R) return;
   __shared__ float part[LIN_WAVES][LIN_TPW][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -313,17 +334,34 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void linear_rows_kernel(const float
   }
 }
 
-extern "C" int v3d_linear_rows(const float* A, int lda, int R, int K, const float* W, const float* bias, int Nout, int relu, float* out,
-                               int ldo, int n_store, v3d_stream_t stream) {
-  if (R < 0 || K < 4 || (K & 3) || lda < K || (lda & 3) || Nout < 16 || (Nout & 15)) return V3D_EINVAL;
-  if (R == 0) return V3D_OK;
-  if (!A || !W || !out || ((uintptr_t)A & 15)) return V3D_EINVAL;
-  if (n_store <= 0 || n_store > Nout) n_store = Nout;
-  if (ldo <= 0) ldo = Nout;
-  if (ldo < n_store) return V3D_EINVAL;
+extern "C" int v3d_linear_rows_many(int n_jobs, const float* const* A, const int32_t* lda, const int32_t* R, const int32_t* K,
+                                    const float* const* W, const float* const* bias, const int32_t* Nout, const int32_t* relu,
+                                    float* const* out, const int32_t* ldo, const int32_t* n_store, v3d_stream_t stream) {
+  if (n_jobs < 0 || n_jobs > LIN_MAX_JOBS) return V3D_EINVAL;
+  if (n_jobs == 0) return V3D_OK;
+  if (!A || !lda || !R || !K || !W || !Nout || !out) return V3D_EINVAL;
+  LinJobs jobs;
+  int gx = 0, gy = 0, n = 0;
+  for (int i = 0; i < n_jobs; i++) {
+    if (R[i] < 0 || K[i] < 4 || (K[i] & 3) || lda[i] < K[i] || (lda[i] & 3) || Nout[i] < 16 || (Nout[i] & 15)) return V3D_EINVAL;
+    if (R[i] == 0) continue;
+    if (!A[i] || !W[i] || !out[i] || ((uintptr_t)A[i] & 15)) return V3D_EINVAL;
+    LinJob& j = jobs.j[n++];
+    j = LinJob{A[i], W[i], bias ? bias[i] : nullptr, out[i], lda[i], R[i], K[i], Nout[i], relu ? relu[i] : 0, ldo ? ldo[i] : 0,
+               n_store ? n_store[i] : 0};
+    if (j.n_store <= 0 || j.n_store > j.Nout) j.n_store = j.Nout;
+    if (j.ldo <= 0) j.ldo = j.Nout;
+    if (j.ldo < j.n_store) return V3D_EINVAL;
+    gx = std::max(gx, j.Nout / 16), gy = std::max(gy, v3d_ceil_div(j.R, 16 * LIN_TPW));
+  }
+  if (n == 0) return V3D_OK;
   static_assert(LIN_WAVES * 64 == LIN_TPW * 4 * 64, "one output value per thread in the epilogue");
-  hipLaunchKernelGGL(linear_rows_kernel, dim3(Nout / 16, v3d_ceil_div(R, 16 * LIN_TPW)), dim3(LIN_WAVES * 64), 0, (hipStream_t)stream, A, lda, R,
-                     K, W, bias, Nout, relu, out, ldo, n_store);
+  hipLaunchKernelGGL(linear_rows_kernel, dim3(gx, gy, n), dim3(LIN_WAVES * 64), 0, (hipStream_t)stream, jobs);
   V3D_CHECK_LAUNCH();
   return V3D_OK;
+}
+
+extern "C" int v3d_linear_rows(const float* A, int lda, int R, int K, const float* W, const float* bias, int Nout, int relu, float* out,
+                               int ldo, int n_store, v3d_stream_t stream) {
+  return v3d_linear_rows_many(1, &A, &lda, &R, &K, &W, &bias, &Nout, &relu, &out, &ldo, &n_store, stream);
 }

@@ -94,9 +94,20 @@ class PV_RCNN(nn.Module):
         grids = None
         if pn2.BALL_QUERY_ALGO == "grid":
             grids = pn2.ball_query_grids([(x, p.max_radius()) for x, p in zip(xyzs, self.pnets)] + [(kp, self.roi_grid_pool.pnet.max_radius())])
+        # one launch for the ball queries of all sources (they all ask around the keypoints), one for their first-layer products
+        nbrs = prods = None
+        plans = [p.pair_plan() for p in self.pnets] if grids else None
+        if grids and len(self.pnets) <= 8 and all(pl is not None and len(p.groupers) == 2 for p, pl in zip(self.pnets, plans)):
+            nbrs = pn2.ball_query_pairs_many([(grids[i], xyzs[i], p.groupers[0].radius, p.groupers[0].nsample, p.groupers[1].radius,
+                                               p.groupers[1].nsample) for i, p in enumerate(self.pnets)], kp)
+            prepped = [p.prep_features(f) for p, (_, f) in zip(self.pnets, sources)]
+            prods = pn2.linear_rows_many([(f.reshape(-1, f.shape[2]), pl[0]) for f, pl in zip(prepped, plans)])
+            sources = [(x, f) for (x, _), f in zip(sources, prepped)]
         col = 0
         for i, (pnet, (_, features), w) in enumerate(zip(self.pnets, sources, widths)):
-            pnet.fused_forward(xyzs[i], features, kp, out_pm=feats[:, :, col:col + w], grid=grids[i] if grids else None)
+            pnet.fused_forward(xyzs[i], features, kp, out_pm=feats[:, :, col:col + w], grid=grids[i] if grids else None,
+                               neighbours=nbrs[i] if nbrs else None, plan=plans[i] if prods else False,
+                               p_all=prods[i].view(features.shape[0], features.shape[1], -1) if prods else None)
             col += w
         self.bev.gather_point_major(bev_map, kp, out_pm=feats[:, :, col:])
         out = feats.transpose(1, 2)

@@ -141,15 +141,32 @@ class PointnetSAModuleMSG(nn.Module):
             cache["couts"] = [[mod for mod in mlp if isinstance(mod, nn.Conv2d)][-1].out_channels for mlp in self.mlps]
         return cache["couts"]
 
-    def fused_forward(self, xyz, features_pm, new_xyz, out_pm=None, grid=None):
+    def prep_features(self, features_pm):
+        """(B, N, C) point-major features -> contiguous, channels padded with zeros to a multiple of 4 (what the kernels read)."""
+        c = features_pm.shape[2]
+        kf = -(-c // 4) * 4
+        return features_pm.contiguous() if kf == c else torch.nn.functional.pad(features_pm, (0, kf - c)).contiguous()
+
+    def pair_plan(self):
+        """(W1 feature parts side by side (Kf, sum N1), [W1[0:3]], column offsets, packed layers) when every scale is a two-layer MLP
+        the PAIR kernel covers, else None."""
+        packed = [self._packed_layers(k) for k in range(len(self.groupers))]
+        if not (self.PAIR_FIRST_LAYERS and all(len(ly) == 2 and ly[0][0].shape[1] <= 256 for ly in packed)):
+            return None
+        return (*self._pair_pieces(packed), packed)
+
+    def fused_forward(self, xyz, features_pm, new_xyz, out_pm=None, grid=None, neighbours=None, p_all=None, plan=False):
         """features_pm (B, N, C) POINT-major -> (B, M, sum(mlps[k][-1])) POINT-major: every scale's last layer writes its pooled rows
         straight into its column block (no torch.cat of the scales).  `out_pm`: a (B, M, >= that many) view with unit channel stride
         to write into -- a column block of the caller's keypoint feature matrix (detector/model.py point_feature_extract).  `grid`: the
-        ball-query grid of `xyz` when the caller built it beforehand (PU.ball_query_grids: several databases in one launch)."""
+        ball-query grid of `xyz` when the caller built it beforehand (PU.ball_query_grids: several databases in one launch);
+        `neighbours` / `p_all`: the ball-query indices per scale / the first-layer products (B, N, sum N1) when the caller computed
+        them with the other modules' in one launch each (PU.ball_query_pairs_many, PU.linear_rows_many on `prep_features`); `plan`:
+        the caller's `pair_plan()` of this module (False: looked up here)."""
         b, n, c = features_pm.shape
         m = new_xyz.shape[1]
         kf = -(-c // 4) * 4
-        feat = features_pm.contiguous() if kf == c else torch.nn.functional.pad(features_pm, (0, kf - c)).contiguous()
+        feat = self.prep_features(features_pm)
         xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
         couts = self.out_channels()
         if out_pm is None:
@@ -157,19 +174,24 @@ class PointnetSAModuleMSG(nn.Module):
         if (out_pm.shape[:2] != (b, m) or out_pm.shape[2] < sum(couts) or out_pm.stride(2) != 1 or out_pm.stride(0) != m * out_pm.stride(1)):
             raise RuntimeError("fused_forward: out_pm must be a (B, M, >= C_out) view with unit channel stride and frames back to back")
         rows = out_pm.as_strided((b * m, out_pm.shape[2]), (out_pm.stride(1), 1), out_pm.storage_offset())
-        if len(self.groupers) == 2:  # both scales in one pass over the database
-            ga, gb = self.groupers
-            neighbours = PU.ball_query_pair(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, new_xyz, grid=grid)
-        else:
-            neighbours = [PU.ball_query(g.radius, g.nsample, xyz, new_xyz, grid=grid) for g in self.groupers]
+        if neighbours is None:
+            if len(self.groupers) == 2:  # both scales in one pass over the database
+                ga, gb = self.groupers
+                neighbours = PU.ball_query_pair(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, new_xyz, grid=grid)
+            else:
+                neighbours = [PU.ball_query(g.radius, g.nsample, xyz, new_xyz, grid=grid) for g in self.groupers]
         col = 0
-        packed = [self._packed_layers(k) for k in range(len(self.groupers))]
-        pair = self.PAIR_FIRST_LAYERS and all(len(ly) == 2 and ly[0][0].shape[1] <= 256 for ly in packed)
+        if plan is False:
+            plan = self.pair_plan()
+        pair = plan is not None
         if pair:
             # the first layers' feature parts once per DATABASE point (N rows, not M * ns), all scales in ONE product (their weights
             # side by side); the rest of a first layer is rebuilt inside its second layer's launch (csrc/sa_mlp.hip PAIR)
-            w1f, wxs, offs = self._pair_pieces(packed)
-            p_all = PU.linear_rows(feat.reshape(b * n, kf), w1f).view(b, n, -1)
+            w1f, wxs, offs, packed = plan
+            if p_all is None:
+                p_all = PU.linear_rows(feat.reshape(b * n, kf), w1f).view(b, n, -1)
+        else:
+            packed = [self._packed_layers(k) for k in range(len(self.groupers))]
         for k, grouper in enumerate(self.groupers):
             layers = packed[k]
             ns = grouper.nsample

@@ -163,6 +163,50 @@ def ball_query_pair(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz, grid
     return idx_a, idx_b
 
 
+def ball_query_pairs_many(jobs, new_xyz):
+    """Several two-radius ball queries around the SAME new_xyz (B, M, 3), each in its own database, in ONE launch
+    (v3d_ball_query_grid_query_many): jobs = [(grid: BallQueryGrid, xyz, radius_a, nsample_a, radius_b, nsample_b)] (at most 8)
+    -> [(idx_a, idx_b)], each pair exactly what `ball_query_pair` returns."""
+    import ctypes as C
+    L.require_gpu("ball_query_many", new_xyz)
+    q = L.as_f32("ball_query_many", new_xyz)
+    b, m, _ = q.shape
+    n_jobs = len(jobs)
+    outs = []
+    for grid, xyz, ra, nsa, rb, nsb in jobs:
+        if not grid.matches(xyz, max(abs(ra), abs(rb))) or xyz.shape[0] != b:
+            raise RuntimeError("ball_query_many: a grid was built from another database (or for a smaller radius)")
+        outs.append((torch.empty((b, m, nsa), dtype=torch.int32, device=q.device), torch.empty((b, m, nsb), dtype=torch.int32, device=q.device)))
+    vp, i32, f32 = C.c_void_p * n_jobs, C.c_int32 * n_jobs, C.c_float * n_jobs
+    with L.device_guard(q.device):
+        L.check(L.lib().v3d_ball_query_grid_query_many(
+            n_jobs, L.ptr(q), b, m, i32(*[j[1].shape[1] for j in jobs]), f32(*[float(j[2]) for j in jobs]), i32(*[int(j[3]) for j in jobs]),
+            vp(*[o[0].data_ptr() for o in outs]), f32(*[float(j[4]) for j in jobs]), i32(*[int(j[5]) for j in jobs]),
+            vp(*[o[1].data_ptr() for o in outs]), vp(*[j[0].workspace.data_ptr() for j in jobs]),
+            (C.c_size_t * n_jobs)(*[j[0].workspace.numel() for j in jobs]), L.stream_ptr()), "ball_query_grid_query_many")
+    return outs
+
+
+def linear_rows_many(jobs):
+    """[(a (R, K), w (K, Nout))] (at most 8) -> [a @ w], all products in ONE launch (v3d_linear_rows_many; no bias, no ReLU: the
+    first-layer feature products of the set-abstraction modules of a frame)."""
+    import ctypes as C
+    n_jobs = len(jobs)
+    outs = []
+    for a, w in jobs:
+        L.require_gpu("linear_rows_many", a, w)
+        if a.dtype != torch.float32 or a.dim() != 2 or a.stride(1) != 1 or w.dtype != torch.float32 or not w.is_contiguous() or w.shape[0] != a.shape[1]:
+            raise RuntimeError("linear_rows_many: (R, K) float32 rows with contiguous columns and contiguous (K, Nout) weights")
+        outs.append(torch.empty((a.shape[0], w.shape[1]), dtype=torch.float32, device=a.device))
+    vp, i32 = C.c_void_p * n_jobs, C.c_int32 * n_jobs
+    with L.device_guard(jobs[0][0].device):
+        L.check(L.lib().v3d_linear_rows_many(
+            n_jobs, vp(*[a.data_ptr() for a, _ in jobs]), i32(*[a.stride(0) if a.shape[0] > 1 else max(a.stride(0), a.shape[1]) for a, _ in jobs]),
+            i32(*[a.shape[0] for a, _ in jobs]), i32(*[a.shape[1] for a, _ in jobs]), vp(*[w.data_ptr() for _, w in jobs]), None,
+            i32(*[w.shape[1] for _, w in jobs]), None, vp(*[o.data_ptr() for o in outs]), None, None, L.stream_ptr()), "linear_rows_many")
+    return outs
+
+
 def grouping_operation(features, idx):
     """features (B, C, N), idx (B, M, ns) int32 -> (B, C, M, ns); differentiable in `features`."""
     if torch.is_grad_enabled() and features.requires_grad:
