@@ -356,6 +356,12 @@ int v3d_sa_mlp_layer(const float* feat, const float* xyz, const float* new_xyz, 
 int v3d_sa_mlp_pair(const float* P, const float* xyz, const float* new_xyz, const int32_t* idx, int B, int N, int M, int ns, int K1,
                     int ldp, const float* wx, const float* b1, const float* W, const float* bias, int Nout, int relu, int pool,
                     float* out, int ldo, int n_store, v3d_stream_t stream);
+/* v3d_sa_mlp_pair for the two scales of a module in ONE launch (same K1 and Nout; per scale: its column block of P, neighbour list,
+ * sample count, wx / b1, W / bias and the column block of `out` it writes): fills the chip where two launches left it half empty. */
+int v3d_sa_mlp_pair2(const float* P_a, const float* P_b, const float* xyz, const float* new_xyz, const int32_t* idx_a, const int32_t* idx_b,
+                     int B, int N, int M, int ns_a, int ns_b, int K1, int ldp, const float* wx_a, const float* b1_a, const float* wx_b,
+                     const float* b1_b, const float* W_a, const float* bias_a, const float* W_b, const float* bias_b, int Nout, int relu,
+                     int pool, float* out_a, float* out_b, int ldo, int n_store, v3d_stream_t stream);
 /* The MLP tail of PV-RCNN on a hundred rows: out[r, n] = act(sum_k A[r * lda + k] * W[k * Nout + n] + bias[n]) for r < R,
  * n < n_store (0: Nout), out row stride ldo (0: Nout).  Replaces nn.Linear (+ bias, + ReLU) of detector/layers.py:53-73 as used by
  * the RoI-grid reduction (roi_grid_pool.py:64-72: 3 072 -> 256 -> 256) and the refinement head (refinement.py:47-50: 256 -> 128 -> 8).

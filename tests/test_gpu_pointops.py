@@ -619,6 +619,26 @@ def test_sa_mlp_pair_matches_fp64_and_the_two_layer_path(kf, n1, n2, ns):
     torch.testing.assert_close(gotp, two, rtol=3e-5, atol=3e-5 * float(np.abs(ref).max()))
 
 
+def test_both_scales_in_one_launch_equal_a_launch_per_scale():
+    """PointnetSAModuleMSG with two scales of the same widths: v3d_sa_mlp_pair2 (one launch) == v3d_sa_mlp_pair per scale, bit for bit
+    (the same kernel body per scale), at RoI-grid pooling's shape and a small one."""
+    from gpu_util import randomize_bn
+    from vision3d_amd.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    torch.manual_seed(6)
+    for c, mlp, n, m in ((512, [512, 192, 96], 2048, 1600), (16, [16, 32, 32], 5000, 333)):
+        sa = PointnetSAModuleMSG(npoint=-1, radii=[0.8, 1.6], nsamples=[16, 32], mlps=[list(mlp), list(mlp)], use_xyz=True)
+        randomize_bn(sa, 3)
+        sa = sa.cuda().eval()
+        xyz = torch.from_numpy(np.stack([synth.make_cloud(6)[:n, :3], synth.make_cloud(7)[:n, :3]])).cuda()
+        new_xyz = (xyz[:, :m] + 0.1).contiguous()
+        feat = torch.randn(2, n, c, device="cuda")
+        with torch.no_grad():
+            both = sa.fused_forward(xyz, feat, new_xyz).clone()
+            sa.PAIR_BOTH_SCALES = False
+            each = sa.fused_forward(xyz, feat, new_xyz)
+        assert torch.equal(both, each) and both.shape == (2, m, 2 * mlp[-1])
+
+
 def test_fused_keypoint_features_equal_the_op_by_op_path():
     """PV_RCNN.point_feature_extract in inference writes every set-abstraction scale and the BEV lookup into ONE point-major matrix
     (sa_mlp `ldo`, v3d_bev_gather_keypoints) and RoI-grid pooling reads point-major rows with a permuted first reduction layer:

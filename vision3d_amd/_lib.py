@@ -73,6 +73,8 @@ _SIGNATURES = {
     "v3d_sa_mlp_layer": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "v3d_sa_mlp_pair": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "v3d_voxel_centers": (_i, [_vp, _i, _f, _f, _f, _f, _f, _f, _vp, _vp]),
+    "v3d_sa_mlp_pair2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
+                              _vp, _vp, _i, _i, _vp]),
     "v3d_roi_grid_points": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "v3d_linear_rows_many": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "v3d_linear_rows": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _vp]),

@@ -36,16 +36,39 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //     h[row, k] = relu( P[i, k] + ((rel.x * Wx[0, k] + rel.y * Wx[1, k]) + rel.z * Wx[2, k]) + b1[k] ),    i = idx[row]
 // as the A fragments of  out[row, :] = act(h[row, :] @ W + bias)  (+ max over the samples): the (rows, K) intermediate is never
 // written.  `feat` = P (B, N, Kf), Kf = the first layer's padded width, `wx` (3, Kf) = W1[0:3], `b1` (Kf).
+// A SECOND scale in the same launch (gridDim.y == 2; v3d_sa_mlp_pair2): the scales of a multi-scale module have the same widths and
+// differ in their neighbour lists, sample counts and weights -- one launch fills the chip where two left it half empty (RoI-grid
+// pooling: 100 + 200 workgroups on 256 compute units) and the chain is one dependent launch shorter per module.
+struct SamScale {
+  const float* feat;  // PAIR: this scale's column block of P
+  const int* idx;
+  const float* W;
+  const float* bias;
+  const float* wx;
+  const float* b1;
+  float* out;
+  long long rows;
+  int ns, n_store;
+};
+
 template <int NB, bool PAIR = false>
-__global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const float* __restrict__ feat,
-                                                                     const float* __restrict__ xyz,
-                                                                     const float* __restrict__ new_xyz,
-                                                                     const int* __restrict__ idx, int N, int M, int ns,
-                                                                     int Kf, long long rows, const float* __restrict__ W,
-                                                                     const float* __restrict__ bias, int relu, int pool,
-                                                                     float* __restrict__ out, int ldo, int n_store,
-                                                                     const float* __restrict__ wx, const float* __restrict__ b1,
-                                                                     int ldp) {
+__global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const float* feat_0, const float* __restrict__ xyz,
+                                                                     const float* __restrict__ new_xyz, const int* idx_0, int N, int M,
+                                                                     int ns_0, int Kf, long long rows_0, const float* W_0,
+                                                                     const float* bias_0, int relu, int pool, float* out_0, int ldo,
+                                                                     int n_store_0, const float* wx_0, const float* b1_0, int ldp,
+                                                                     const SamScale alt) {
+  const bool second = blockIdx.y == 1;
+  const float* __restrict__ feat = second ? alt.feat : feat_0;
+  const int* __restrict__ idx = second ? alt.idx : idx_0;
+  const float* __restrict__ W = second ? alt.W : W_0;
+  const float* __restrict__ bias = second ? alt.bias : bias_0;
+  const float* __restrict__ wx = second ? alt.wx : wx_0;
+  const float* __restrict__ b1 = second ? alt.b1 : b1_0;
+  float* __restrict__ out = second ? alt.out : out_0;
+  const long long rows = second ? alt.rows : rows_0;
+  const int ns = second ? alt.ns : ns_0, n_store = second ? alt.n_store : n_store_0;
+  if ((long long)blockIdx.x * (16 * SAM_TPW * SAM_WAVES) >= rows) return;  // (the grid is sized for the scale with more rows)
   constexpr int NOUT = NB * 16;
   constexpr int LDW = NOUT + 4;  // row stride of the LDS weight chunk: the four k-rows a wave reads at once hit disjoint banks
   __shared__ float Ws[SAM_KC * LDW];
@@ -208,7 +231,7 @@ extern "C" int v3d_sa_mlp_layer(const float* feat, const float* xyz, const float
 #define SAM_CASE(NBV)                                                                                                      \
   if (Nout == NBV * 16) {                                                                                                  \
     hipLaunchKernelGGL(sa_mlp_layer_kernel<NBV>, dim3(blocks), dim3(SAM_WAVES * 64), 0, st, feat, xyz, new_xyz, idx, N, M, \
-                       ns, Kf, rows, W, bias, relu, pool, out, ldo, n_store, nullptr, nullptr, 0);                                                            \
+                       ns, Kf, rows, W, bias, relu, pool, out, ldo, n_store, nullptr, nullptr, 0, SamScale{});                                                            \
     V3D_CHECK_LAUNCH();                                                                                                    \
     return V3D_OK;                                                                                                         \
   }
@@ -238,9 +261,43 @@ extern "C" int v3d_sa_mlp_pair(const float* P, const float* xyz, const float* ne
 #define SAM_CASE(NBV)                                                                                                            \
   if (Nout == NBV * 16) {                                                                                                        \
     hipLaunchKernelGGL((sa_mlp_layer_kernel<NBV, true>), dim3(blocks), dim3(SAM_WAVES * 64), 0, st, P, xyz, new_xyz, idx, N, M, ns, \
-                       K1, rows, W, bias, relu, pool, out, ldo, n_store, wx, b1, ldp);                                                \
+                       K1, rows, W, bias, relu, pool, out, ldo, n_store, wx, b1, ldp, SamScale{});                                                \
     V3D_CHECK_LAUNCH();                                                                                                          \
     return V3D_OK;                                                                                                               \
+  }
+  SAM_CASE(1) SAM_CASE(2) SAM_CASE(4) SAM_CASE(6) SAM_CASE(8) SAM_CASE(12) SAM_CASE(16)
+#undef SAM_CASE
+  return V3D_EUNSUPPORTED;
+}
+
+// v3d_sa_mlp_pair for the TWO scales of a module in one launch: P_a / P_b = the scales' column blocks of one (B, N, ldp) product,
+// the same K1 and Nout (multi-scale modules repeat their widths), per scale: neighbour list + sample count, wx / b1, W / bias, and
+// the column block of `out` (row stride ldo) it writes.
+extern "C" int v3d_sa_mlp_pair2(const float* P_a, const float* P_b, const float* xyz, const float* new_xyz, const int32_t* idx_a,
+                                const int32_t* idx_b, int B, int N, int M, int ns_a, int ns_b, int K1, int ldp, const float* wx_a,
+                                const float* b1_a, const float* wx_b, const float* b1_b, const float* W_a, const float* bias_a,
+                                const float* W_b, const float* bias_b, int Nout, int relu, int pool, float* out_a, float* out_b, int ldo,
+                                int n_store, v3d_stream_t stream) {
+  if (B < 0 || N < 1 || M < 0 || ns_a < 1 || ns_b < 1 || K1 < 4 || (K1 & 3) || K1 > 256 || Nout < 16 || (Nout & 15)) return V3D_EINVAL;
+  if (ldp <= 0) ldp = K1;
+  if (ldp < K1 || (ldp & 3)) return V3D_EINVAL;
+  if (!P_a || !P_b || !xyz || !new_xyz || !idx_a || !idx_b || !wx_a || !b1_a || !wx_b || !b1_b || !W_a || !W_b || !out_a || !out_b) return V3D_EINVAL;
+  if (((uintptr_t)P_a & 15) || ((uintptr_t)P_b & 15)) return V3D_EINVAL;
+  if (pool && ((ns_a != 16 && ns_a != 32) || (ns_b != 16 && ns_b != 32))) return V3D_EUNSUPPORTED;
+  if (n_store <= 0 || n_store > Nout) n_store = Nout;
+  if (ldo <= 0) ldo = Nout;
+  if (ldo < n_store) return V3D_EINVAL;
+  const long long rows_a = (long long)B * M * ns_a, rows_b = (long long)B * M * ns_b;
+  if (rows_a == 0) return V3D_OK;
+  const int blocks = v3d_ceil_div(std::max(rows_a, rows_b), 16 * SAM_TPW * SAM_WAVES);
+  const SamScale alt{P_b, idx_b, W_b, bias_b, wx_b, b1_b, out_b, rows_b, ns_b, n_store};
+  hipStream_t st = (hipStream_t)stream;
+#define SAM_CASE(NBV)                                                                                                               \
+  if (Nout == NBV * 16) {                                                                                                           \
+    hipLaunchKernelGGL((sa_mlp_layer_kernel<NBV, true>), dim3(blocks, 2), dim3(SAM_WAVES * 64), 0, st, P_a, xyz, new_xyz, idx_a, N, M, \
+                       ns_a, K1, rows_a, W_a, bias_a, relu, pool, out_a, ldo, n_store, wx_a, b1_a, ldp, alt);                       \
+    V3D_CHECK_LAUNCH();                                                                                                             \
+    return V3D_OK;                                                                                                                  \
   }
   SAM_CASE(1) SAM_CASE(2) SAM_CASE(4) SAM_CASE(6) SAM_CASE(8) SAM_CASE(12) SAM_CASE(16)
 #undef SAM_CASE

@@ -68,6 +68,7 @@ class PointnetSAModuleMSG(nn.Module):
                 i += 1
         return True
 
+    PAIR_BOTH_SCALES = True   # two scales of the same widths: one v3d_sa_mlp_pair2 launch (False: a v3d_sa_mlp_pair launch per scale)
     PAIR_FIRST_LAYERS = True  # two-layer scales: v3d_linear_rows on the database + v3d_sa_mlp_pair (False: a launch per layer)
 
     def _pair_pieces(self, packed):
@@ -192,6 +193,13 @@ class PointnetSAModuleMSG(nn.Module):
                 p_all = PU.linear_rows(feat.reshape(b * n, kf), w1f).view(b, n, -1)
         else:
             packed = [self._packed_layers(k) for k in range(len(self.groupers))]
+        if (pair and self.PAIR_BOTH_SCALES and len(self.groupers) == 2 and couts[0] == couts[1] and packed[0][0][0].shape[1] == packed[1][0][0].shape[1]
+                and packed[0][1][0].shape == packed[1][1][0].shape and all(t.is_contiguous() for ly in packed for pr in ly for t in pr)):
+            # both scales in ONE launch (the same widths: csrc/sa_mlp.hip v3d_sa_mlp_pair2)
+            PU.sa_mlp_pair2(p_all[:, :, offs[0]:offs[1]], p_all[:, :, offs[1]:offs[2]], xyz, new_xyz, neighbours[0], neighbours[1],
+                            wxs[0], packed[0][0][1], wxs[1], packed[1][0][1], packed[0][1][0], packed[0][1][1], packed[1][1][0],
+                            packed[1][1][1], rows[:, 0:couts[0]], rows[:, couts[0]:2 * couts[0]], couts[0])
+            return out_pm[:, :, :2 * couts[0]]
         for k, grouper in enumerate(self.groupers):
             layers = packed[k]
             ns = grouper.nsample

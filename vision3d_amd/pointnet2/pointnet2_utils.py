@@ -319,6 +319,31 @@ def sa_mlp_pair(p, xyz, new_xyz, idx, wx, b1, w, bias, relu=True, pool=True, out
     return out
 
 
+def sa_mlp_pair2(p_a, p_b, xyz, new_xyz, idx_a, idx_b, wx_a, b1_a, wx_b, b1_b, w_a, bias_a, w_b, bias_b, out_a, out_b, n_store):
+    """`sa_mlp_pair` (ReLU, max over the samples) for the TWO scales of a module in one launch: p_a / p_b (B, N, K1) column blocks of one
+    product, the same K1 and Nout, out_a / out_b (B*M, >= n_store) column blocks of one matrix (the same row stride)."""
+    L.require_gpu("sa_mlp_pair2", p_a, w_a)
+    x, q = L.as_f32("sa_mlp_pair2", xyz), L.as_f32("sa_mlp_pair2", new_xyz)
+    ia, ib = L.as_i32("sa_mlp_pair2", idx_a), L.as_i32("sa_mlp_pair2", idx_b)
+    b, n, k1 = p_a.shape
+    _, m, ns_a = ia.shape
+    ns_b = ib.shape[2]
+    nout = w_a.shape[1]
+    for p in (p_a, p_b):
+        if p.dtype != torch.float32 or tuple(p.shape) != (b, n, k1) or p.stride(2) != 1 or p.stride(0) != n * p.stride(1) or p.stride(1) != p_a.stride(1):
+            raise RuntimeError("sa_mlp_pair2: p_a / p_b must be (B, N, K1) column blocks of one float32 matrix")
+    if tuple(w_a.shape) != (k1, nout) or tuple(w_b.shape) != (k1, nout) or tuple(wx_a.shape) != (3, k1) or tuple(wx_b.shape) != (3, k1):
+        raise RuntimeError("sa_mlp_pair2: the two scales must have the same widths")
+    oa, ldo = _strided_rows("sa_mlp_pair2", out_a, b * m, n_store)
+    ob, ldo_b = _strided_rows("sa_mlp_pair2", out_b, b * m, n_store)
+    if ldo != ldo_b:
+        raise RuntimeError("sa_mlp_pair2: out_a / out_b must be column blocks of one matrix")
+    with L.device_guard(p_a.device):
+        L.check(L.lib().v3d_sa_mlp_pair2(L.ptr(p_a), L.ptr(p_b), L.ptr(x), L.ptr(q), L.ptr(ia), L.ptr(ib), b, n, m, ns_a, ns_b, k1, p_a.stride(1),
+                                         L.ptr(wx_a), L.ptr(b1_a), L.ptr(wx_b), L.ptr(b1_b), L.ptr(w_a), L.ptr(bias_a), L.ptr(w_b), L.ptr(bias_b),
+                                         nout, 1, 1, L.ptr(oa), L.ptr(ob), ldo, int(n_store), L.stream_ptr()), "sa_mlp_pair2")
+
+
 def linear_rows(a, w, bias=None, relu=False, out=None, n_store=None):
     """act(a @ w + bias) for a matrix of FEW rows (csrc/sa_mlp.hip linear_rows_kernel: columns over workgroups, K over the waves):
     a (R, K) float32 with unit column stride (rows may be strided), w (K, Nout) = the nn.Linear weight transposed, Nout % 16 == 0,
