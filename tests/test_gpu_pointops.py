@@ -528,7 +528,8 @@ def test_ball_query_grid_workspace_is_checked():
 
 @pytest.mark.parametrize("r,k,nout,bias,relu", [(100, 3072, 256, False, True), (100, 256, 256, False, True), (100, 256, 128, True, True),
                                                 (100, 128, 8, True, False), (1, 4, 16, True, False), (37, 260, 40, False, False),
-                                                (300, 1028, 96, True, True)])
+                                                (300, 1028, 96, True, True), (10540, 64, 128, False, False), (16384, 4, 32, True, True),
+                                                (2048, 512, 384, False, False), (777, 36, 48, True, False)])
 def test_linear_rows_matches_fp64(r, k, nout, bias, relu):
     """csrc/sa_mlp.hip linear_rows_kernel (the reduction / refinement MLP layers of PV-RCNN: a hundred rows, K split over the waves)
     against the same sums in float64; strided input rows, a column block as output, an output width that is not a multiple of 16."""

@@ -321,6 +321,7 @@ struct LinJob {
   const float* bias;
   float* out;
   int lda, R, K, Nout, relu, ldo, n_store;
+  int ksplit;  // 1: the 8 waves share 32 rows and split K (few rows x wide K); 0: a wave per 32 rows, all of K (many rows x narrow K)
 };
 struct LinJobs {
   LinJob j[LIN_MAX_JOBS];
@@ -335,13 +336,15 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void linear_rows_kernel(const LinJo
   const float* __restrict__ bias = jb.bias;
   float* __restrict__ out = jb.out;
   const int lda = jb.lda, R = jb.R, K = jb.K, Nout = jb.Nout, relu = jb.relu, ldo = jb.ldo, n_store = jb.n_store;
-  if ((int)blockIdx.x * 16 >= Nout || (int)blockIdx.y * (16 * LIN_TPW) >= R) return;
+  const bool split = jb.ksplit != 0;
+  const int wg_rows = split ? 16 * LIN_TPW : 16 * LIN_TPW * LIN_WAVES;
+  if ((int)blockIdx.x * 16 >= Nout || (int)blockIdx.y * wg_rows >= R) return;
   __shared__ float part[LIN_WAVES][LIN_TPW][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int col0 = blockIdx.x * 16, row0 = blockIdx.y * (16 * LIN_TPW);
+  const int col0 = blockIdx.x * 16, row0 = blockIdx.y * wg_rows + (split ? 0 : wave * (16 * LIN_TPW));
   const int kper = ((K + 16 * LIN_WAVES - 1) / (16 * LIN_WAVES)) * 16;  // K range of a wave: a multiple of 16
-  const int kb = wave * kper, ke = min(K, kb + kper);
+  const int kb = split ? wave * kper : 0, ke = split ? min(K, kb + kper) : K;
   const float* arow[LIN_TPW];
 #pragma unroll
   for (int t = 0; t < LIN_TPW; t++) arow[t] = row0 + t * 16 + r < R ? A + (size_t)(row0 + t * 16 + r) * lda : nullptr;
@@ -372,6 +375,20 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void linear_rows_kernel(const LinJo
 #pragma unroll
         for (int t = 0; t < LIN_TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t][s], b1[s], acc[t], 0, 0, 0);
     }
+  }
+  if (!split) {  // (workgroup-uniform) a wave's own tiles: D[row = 4 q + i][col = r]
+    const int col = col0 + r;
+    const float bj = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int t = 0; t < LIN_TPW; t++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float v = acc[t][i] + bj;
+        if (relu) v = fmaxf(v, 0.f);
+        const int row = row0 + t * 16 + 4 * q + i;
+        if (row < R && col < n_store) out[(size_t)row * ldo + col] = v;
+      }
+    return;
   }
 #pragma unroll
   for (int t = 0; t < LIN_TPW; t++)
@@ -405,11 +422,14 @@ extern "C" int v3d_linear_rows_many(int n_jobs, const float* const* A, const int
     if (!A[i] || !W[i] || !out[i] || ((uintptr_t)A[i] & 15)) return V3D_EINVAL;
     LinJob& j = jobs.j[n++];
     j = LinJob{A[i], W[i], bias ? bias[i] : nullptr, out[i], lda[i], R[i], K[i], Nout[i], relu ? relu[i] : 0, ldo ? ldo[i] : 0,
-               n_store ? n_store[i] : 0};
+               n_store ? n_store[i] : 0, 1};
     if (j.n_store <= 0 || j.n_store > j.Nout) j.n_store = j.Nout;
     if (j.ldo <= 0) j.ldo = j.Nout;
     if (j.ldo < j.n_store) return V3D_EINVAL;
-    gx = std::max(gx, j.Nout / 16), gy = std::max(gy, v3d_ceil_div(j.R, 16 * LIN_TPW));
+    // many rows x narrow K (the first-layer products of the set-abstraction modules: 4 600-17 800 rows, K = 4-64): K split over the
+    // waves left seven of eight idle and cost eight times the workgroups
+    j.ksplit = (j.K >= 256 || j.R <= 16 * LIN_TPW * 4) ? 1 : 0;
+    gx = std::max(gx, j.Nout / 16), gy = std::max(gy, v3d_ceil_div(j.R, j.ksplit ? 16 * LIN_TPW : 16 * LIN_TPW * LIN_WAVES));
   }
   if (n == 0) return V3D_OK;
   static_assert(LIN_WAVES * 64 == LIN_TPW * 4 * 64, "one output value per thread in the epilogue");
