@@ -1,3 +1,5 @@
+# On the GPU box (gpurun -- bash tools/prof_ball_query.sh): rocprofv3 kernel statistics of one bench / microbenchmark command, top kernels printed;
+# the csv lands in gpurun_out/.
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/bqp; rocprofv3 --kernel-trace --output-format csv -d /tmp/bqp -- python $GRAFT_REPO_ROOT/tools/mb_ball_query.py > /tmp/bqp.out 2>/tmp/bqp.err
 cd $GRAFT_REPO_ROOT

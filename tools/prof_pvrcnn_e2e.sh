@@ -1,3 +1,5 @@
+# On the GPU box (gpurun -- bash tools/prof_pvrcnn_e2e.sh): rocprofv3 kernel statistics of one bench / microbenchmark command, top kernels printed;
+# the csv lands in gpurun_out/.
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/e2e; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/e2e -- python $GRAFT_REPO_ROOT/bench.py --mode pvrcnn --end-to-end --steps 64 --warmup 8 --no-cpu-baseline --no-roofline > /tmp/e2e.json 2>/tmp/e2e.err
 cd $GRAFT_REPO_ROOT

@@ -1,3 +1,5 @@
+# On the GPU box (gpurun -- bash tools/prof_pvrcnn_stage2.sh): rocprofv3 kernel statistics of one bench / microbenchmark command, top kernels printed;
+# the csv lands in gpurun_out/.
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pvp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pvp -- python $GRAFT_REPO_ROOT/bench.py --mode pvrcnn --steps 64 --warmup 8 --no-cpu-baseline --no-roofline > /tmp/pvp.json 2>/tmp/pvp.err
 cd $GRAFT_REPO_ROOT
