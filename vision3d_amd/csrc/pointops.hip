@@ -8,8 +8,9 @@
 //     once).  Arg-max per step = wave64 shuffle reduction on a packed (distance, ~index) key + one LDS
 //     exchange between the 16 waves; ties resolve to the LOWEST index (the reference's block
 //     reduction leaves ties unspecified).
-//   * ball query: one WAVE per query (ballot = hit mask, popcount prefix = slot), database points streamed through
-//     LDS tiles shared by the workgroup; first-nsample-in-index-order semantics with first-hit prefill.
+//   * ball query: the scan form -- one WAVE per query (ballot = hit mask, popcount prefix = slot), database points streamed
+//     through LDS tiles shared by the workgroup; first-nsample-in-index-order semantics with first-hit prefill -- and, since
+//     round 6, the form the package calls: a cell grid of the database + per-wave LDS bitmaps (same indices; see further down).
 #include <algorithm>
 #include <cmath>
 

@@ -110,8 +110,9 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
     for (int j = 0; j < NB; j++) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // A: four contiguous floats of this lane's row, k = kb + 4 q .. + 3 (kb a multiple of 16).  The fragments of block kb + 16 are
-  // requested BEFORE the MFMAs of block kb (a gathered row is a trip to the L2: with two waves per SIMD and 4 NB dependent matrix
-  // instructions per block the trip was not hidden -- round 6: 140 -> see profiles/ us at 51 200 rows x 516 -> 192).
+  // requested BEFORE the MFMAs of block kb (a gathered row is a trip to the L2); measured on the direct first layer of RoI-grid
+  // pooling (51 200 rows x 516 -> 192): 134 -> 129 us with the B operands read a step ahead as well -- that layer's real fix was not
+  // to compute it per grouped row at all (PAIR, docs/rounds/round6.md G.2).
   auto load_a = [&](int kb, f32x4 (&a)[SAM_TPW]) {
     const int kg = kb + 4 * q;
 #pragma unroll
