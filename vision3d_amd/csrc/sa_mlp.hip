@@ -51,8 +51,10 @@ struct SamScale {
   int ns, n_store;
 };
 
-template <int NB, bool PAIR = false>
-__global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const float* feat_0, const float* __restrict__ xyz,
+// WAVES = 8 (256 rows per workgroup) or 4 (128): a launch whose 256-row workgroups number between one and ~2.5 per compute unit runs
+// as long as its unluckiest unit's TWO workgroups (RoI-grid pooling: 300 on 256 units); half-size workgroups spread evenly (sam_waves).
+template <int NB, bool PAIR = false, int WAVES = SAM_WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sa_mlp_layer_kernel(const float* feat_0, const float* __restrict__ xyz,
                                                                      const float* __restrict__ new_xyz, const int* idx_0, int N, int M,
                                                                      int ns_0, int Kf, long long rows_0, const float* W_0,
                                                                      const float* bias_0, int relu, int pool, float* out_0, int ldo,
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
   float* __restrict__ out = second ? alt.out : out_0;
   const long long rows = second ? alt.rows : rows_0;
   const int ns = second ? alt.ns : ns_0, n_store = second ? alt.n_store : n_store_0;
-  if ((long long)blockIdx.x * (16 * SAM_TPW * SAM_WAVES) >= rows) return;  // (the grid is sized for the scale with more rows)
+  if ((long long)blockIdx.x * (16 * SAM_TPW * WAVES) >= rows) return;  // (the grid is sized for the scale with more rows)
   constexpr int NOUT = NB * 16;
   constexpr int LDW = NOUT + 4;  // row stride of the LDS weight chunk: the four k-rows a wave reads at once hit disjoint banks
   __shared__ float Ws[SAM_KC * LDW];
@@ -78,10 +80,10 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
   const bool has_xyz = !PAIR && xyz != nullptr;
   const int Kp = Kf + (has_xyz ? 4 : 0);
   if constexpr (PAIR) {
-    for (int e = tid; e < 4 * Kf; e += SAM_WAVES * 64) Wx[e] = e < 3 * Kf ? wx[e] : b1[e - 3 * Kf];
+    for (int e = tid; e < 4 * Kf; e += WAVES * 64) Wx[e] = e < 3 * Kf ? wx[e] : b1[e - 3 * Kf];
     __syncthreads();
   }
-  const long long tile0 = ((long long)blockIdx.x * SAM_WAVES + wave) * SAM_TPW;
+  const long long tile0 = ((long long)blockIdx.x * WAVES + wave) * SAM_TPW;
 
   // this lane's row in each of the wave's tiles: source row pointer and the xyz offset of the first layer
   const float* frow[SAM_TPW];
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
   for (int k0 = 0; k0 < Kp; k0 += SAM_KC) {
     const int kc = min(SAM_KC, Kp - k0);
     __syncthreads();  // the previous chunk has been consumed
-    for (int e = tid; e < SAM_KC * (NOUT / 4); e += SAM_WAVES * 64) {
+    for (int e = tid; e < SAM_KC * (NOUT / 4); e += WAVES * 64) {
       const int kr = e / (NOUT / 4), c4 = e % (NOUT / 4);
       f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
       if (kr < kc) w = *reinterpret_cast<const f32x4*>(W + (size_t)(k0 + kr) * NOUT + c4 * 4);
@@ -213,6 +215,14 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sa_mlp_layer_kernel(const floa
   }
 }
 
+// waves per workgroup of a launch over `rows` rows (x `scales` grids): 4 when the 8-wave workgroups would number between one and 2.5
+// per compute unit
+static int sam_waves(long long rows, int scales) {
+  const long long wgs = (rows + 16 * SAM_TPW * SAM_WAVES - 1) / (16 * SAM_TPW * SAM_WAVES) * scales;
+  const int cus = std::max(v3d_device_cu_count(), 1);
+  return (wgs > cus && wgs * 2 < (long long)cus * 5) ? 4 : SAM_WAVES;
+}
+
 extern "C" int v3d_sa_mlp_layer(const float* feat, const float* xyz, const float* new_xyz, const int32_t* idx, int B, int N, int M,
                                 int ns, int Kf, const float* W, const float* bias, int Nout, int relu, int pool, float* out,
                                 int ldo, int n_store, v3d_stream_t stream) {
@@ -227,17 +237,20 @@ extern "C" int v3d_sa_mlp_layer(const float* feat, const float* xyz, const float
   if (rows == 0) return V3D_OK;
   if (!idx && (long long)B * N != rows) return V3D_EINVAL;  // identity rows: the input IS the (B*M*ns, Kf) matrix
   if (Kf + (xyz ? 4 : 0) < 4) return V3D_EINVAL;
-  const int blocks = v3d_ceil_div(rows, 16 * SAM_TPW * SAM_WAVES);
+  const int waves = sam_waves(rows, 1);
+  const int blocks = v3d_ceil_div(rows, 16 * SAM_TPW * waves);
   hipStream_t st = (hipStream_t)stream;
-#define SAM_CASE(NBV)                                                                                                      \
-  if (Nout == NBV * 16) {                                                                                                  \
-    hipLaunchKernelGGL(sa_mlp_layer_kernel<NBV>, dim3(blocks), dim3(SAM_WAVES * 64), 0, st, feat, xyz, new_xyz, idx, N, M, \
-                       ns, Kf, rows, W, bias, relu, pool, out, ldo, n_store, nullptr, nullptr, 0, SamScale{});                                                            \
-    V3D_CHECK_LAUNCH();                                                                                                    \
-    return V3D_OK;                                                                                                         \
+#define SAM_ARGS feat, xyz, new_xyz, idx, N, M, ns, Kf, rows, W, bias, relu, pool, out, ldo, n_store, nullptr, nullptr, 0, SamScale{}
+#define SAM_CASE(NBV)                                                                                                       \
+  if (Nout == NBV * 16) {                                                                                                   \
+    if (waves == 4) hipLaunchKernelGGL((sa_mlp_layer_kernel<NBV, false, 4>), dim3(blocks), dim3(4 * 64), 0, st, SAM_ARGS);  \
+    else hipLaunchKernelGGL((sa_mlp_layer_kernel<NBV, false, SAM_WAVES>), dim3(blocks), dim3(SAM_WAVES * 64), 0, st, SAM_ARGS); \
+    V3D_CHECK_LAUNCH();                                                                                                     \
+    return V3D_OK;                                                                                                          \
   }
   SAM_CASE(1) SAM_CASE(2) SAM_CASE(4) SAM_CASE(6) SAM_CASE(8) SAM_CASE(12) SAM_CASE(16)
 #undef SAM_CASE
+#undef SAM_ARGS
   return V3D_EUNSUPPORTED;
 }
 
@@ -257,17 +270,20 @@ extern "C" int v3d_sa_mlp_pair(const float* P, const float* xyz, const float* ne
   if (ldo < n_store) return V3D_EINVAL;
   const long long rows = (long long)B * M * ns;
   if (rows == 0) return V3D_OK;
-  const int blocks = v3d_ceil_div(rows, 16 * SAM_TPW * SAM_WAVES);
+  const int waves = sam_waves(rows, 1);
+  const int blocks = v3d_ceil_div(rows, 16 * SAM_TPW * waves);
   hipStream_t st = (hipStream_t)stream;
-#define SAM_CASE(NBV)                                                                                                            \
-  if (Nout == NBV * 16) {                                                                                                        \
-    hipLaunchKernelGGL((sa_mlp_layer_kernel<NBV, true>), dim3(blocks), dim3(SAM_WAVES * 64), 0, st, P, xyz, new_xyz, idx, N, M, ns, \
-                       K1, rows, W, bias, relu, pool, out, ldo, n_store, wx, b1, ldp, SamScale{});                                                \
-    V3D_CHECK_LAUNCH();                                                                                                          \
-    return V3D_OK;                                                                                                               \
+#define SAM_ARGS P, xyz, new_xyz, idx, N, M, ns, K1, rows, W, bias, relu, pool, out, ldo, n_store, wx, b1, ldp, SamScale{}
+#define SAM_CASE(NBV)                                                                                                      \
+  if (Nout == NBV * 16) {                                                                                                  \
+    if (waves == 4) hipLaunchKernelGGL((sa_mlp_layer_kernel<NBV, true, 4>), dim3(blocks), dim3(4 * 64), 0, st, SAM_ARGS);  \
+    else hipLaunchKernelGGL((sa_mlp_layer_kernel<NBV, true, SAM_WAVES>), dim3(blocks), dim3(SAM_WAVES * 64), 0, st, SAM_ARGS); \
+    V3D_CHECK_LAUNCH();                                                                                                    \
+    return V3D_OK;                                                                                                         \
   }
   SAM_CASE(1) SAM_CASE(2) SAM_CASE(4) SAM_CASE(6) SAM_CASE(8) SAM_CASE(12) SAM_CASE(16)
 #undef SAM_CASE
+#undef SAM_ARGS
   return V3D_EUNSUPPORTED;
 }
 
@@ -290,18 +306,21 @@ extern "C" int v3d_sa_mlp_pair2(const float* P_a, const float* P_b, const float*
   if (ldo < n_store) return V3D_EINVAL;
   const long long rows_a = (long long)B * M * ns_a, rows_b = (long long)B * M * ns_b;
   if (rows_a == 0) return V3D_OK;
-  const int blocks = v3d_ceil_div(std::max(rows_a, rows_b), 16 * SAM_TPW * SAM_WAVES);
+  const int waves = sam_waves((rows_a + rows_b) / 2, 2);
+  const int blocks = v3d_ceil_div(std::max(rows_a, rows_b), 16 * SAM_TPW * waves);
   const SamScale alt{P_b, idx_b, W_b, bias_b, wx_b, b1_b, out_b, rows_b, ns_b, n_store};
   hipStream_t st = (hipStream_t)stream;
-#define SAM_CASE(NBV)                                                                                                               \
-  if (Nout == NBV * 16) {                                                                                                           \
-    hipLaunchKernelGGL((sa_mlp_layer_kernel<NBV, true>), dim3(blocks, 2), dim3(SAM_WAVES * 64), 0, st, P_a, xyz, new_xyz, idx_a, N, M, \
-                       ns_a, K1, rows_a, W_a, bias_a, relu, pool, out_a, ldo, n_store, wx_a, b1_a, ldp, alt);                       \
-    V3D_CHECK_LAUNCH();                                                                                                             \
-    return V3D_OK;                                                                                                                  \
+#define SAM_ARGS P_a, xyz, new_xyz, idx_a, N, M, ns_a, K1, rows_a, W_a, bias_a, relu, pool, out_a, ldo, n_store, wx_a, b1_a, ldp, alt
+#define SAM_CASE(NBV)                                                                                                          \
+  if (Nout == NBV * 16) {                                                                                                      \
+    if (waves == 4) hipLaunchKernelGGL((sa_mlp_layer_kernel<NBV, true, 4>), dim3(blocks, 2), dim3(4 * 64), 0, st, SAM_ARGS);   \
+    else hipLaunchKernelGGL((sa_mlp_layer_kernel<NBV, true, SAM_WAVES>), dim3(blocks, 2), dim3(SAM_WAVES * 64), 0, st, SAM_ARGS); \
+    V3D_CHECK_LAUNCH();                                                                                                        \
+    return V3D_OK;                                                                                                             \
   }
   SAM_CASE(1) SAM_CASE(2) SAM_CASE(4) SAM_CASE(6) SAM_CASE(8) SAM_CASE(12) SAM_CASE(16)
 #undef SAM_CASE
+#undef SAM_ARGS
   return V3D_EUNSUPPORTED;
 }
 
