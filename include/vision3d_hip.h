@@ -329,7 +329,8 @@ int v3d_voxel_centers(const int32_t* indices, int n, float scale_x, float scale_
                       float offset_z, float* out, v3d_stream_t stream);
 /* RoiGridPool.sample_gridpoints in one launch (detector/roi_grid_pool.py:52-62): points[b, n, j] = centre + Rz(yaw) (size * (sample - 0.5))
  * with the module's own fp32 statements, one IEEE operation each; boxes (B*n, 7) = x, y, z, w, l, h, yaw, samples (B*n, m, 3) in
- * [0, 1), cos_yaw / sin_yaw (B*n) from the caller (torch's cos / sin: the same values as the op-by-op path), out (B*n, m, 3). */
+ * [0, 1), cos_yaw / sin_yaw (B*n) from the caller (torch's cos / sin: the same values as the op-by-op path) or both NULL (cosf / sinf
+ * of the device library inside the launch: equal to torch's on this stack, which the GPU tests check), out (B*n, m, 3). */
 int v3d_roi_grid_points(const float* boxes, const float* samples, const float* cos_yaw, const float* sin_yaw, int n_boxes, int m,
                         float* out, v3d_stream_t stream);
 

@@ -681,6 +681,39 @@ def test_fused_keypoint_features_equal_the_op_by_op_path():
         torch.testing.assert_close(got.double(), ref, rtol=2e-5, atol=2e-5 * ref.abs().max().item())
 
 
+def test_roi_grid_points_trig_equals_torch():
+    """v3d_roi_grid_points with the yaw's cos / sin computed inside the launch (cosf / sinf of the device library) against torch.cos /
+    torch.sin: bit-identical over a million yaws, large arguments and the special values -- what lets RoiGridPool.sample_gridpoints
+    drop its two trig launches; and the module's grid points equal the op-by-op statements."""
+    import math
+    from vision3d_amd import _lib as L
+    g = torch.Generator().manual_seed(0)
+    yaw = torch.cat([(torch.rand(1 << 20, generator=g) * 2 - 1) * math.pi, (torch.rand(1 << 18, generator=g) * 2 - 1) * 100.0,
+                     torch.tensor([0.0, -0.0, math.pi, -math.pi, math.pi / 2, 1e-8, 1e6, -3e4, float("inf"), float("nan")])]).cuda()
+    nb = yaw.numel()
+    boxes = torch.zeros(nb, 7, device="cuda")
+    boxes[:, 3] = 1
+    boxes[:, 4] = 1
+    boxes[:, 6] = yaw
+    # local offsets (1, 0, 0) and (0, 1, 0): the points are then (cos, sin, 0) and (-sin, cos, 0) exactly
+    smp = torch.tensor([[1.5, 0.5, 0.5], [0.5, 1.5, 0.5]], device="cuda").expand(nb, 2, 3).contiguous()
+    out = torch.empty(nb, 2, 3, device="cuda")
+    L.check(L.lib().v3d_roi_grid_points(L.ptr(boxes), L.ptr(smp), None, None, nb, 2, L.ptr(out), L.stream_ptr()), "roi_grid_points")
+    c, s = torch.cos(yaw), torch.sin(yaw)
+    for got, ref in ((out[:, 0, 0], c), (out[:, 0, 1], s), (out[:, 1, 0], 0 - s), (out[:, 1, 1], c)):
+        assert ((got == ref) | (got.isnan() & ref.isnan())).all()
+    from vision3d_amd.core.config import second_car_cfg
+    from vision3d_amd.detector.roi_grid_pool import RoiGridPool
+    pool = RoiGridPool(second_car_cfg()).cuda().eval()
+    props = torch.from_numpy(np.stack([synth.make_gt_boxes(0)[:20], synth.make_gt_boxes(1)[:20]])).cuda()
+    samples = torch.rand((2, 20, 16, 3), generator=g).cuda()
+    with torch.no_grad():
+        pts = pool.sample_gridpoints(props, samples)
+        assert torch.equal(pts, pool.sample_gridpoints_torch(props, samples))
+        pool.TORCH_TRIG = True
+        assert torch.equal(pts, pool.sample_gridpoints(props, samples))
+
+
 def test_voxel_centers_equal_the_torch_statements():
     """SparseCNNBase.to_global on v3d_voxel_centers == flip / float / multiply / add op by op, every stride of the config."""
     from vision3d_amd import spconv

@@ -1047,7 +1047,9 @@ __global__ __launch_bounds__(V3D_BLOCK) void roi_grid_points_kernel(const float*
     const float* bp = boxes + bx * 7;
     const float* sp = samples + t * 3;
     const float lx = bp[3] * (sp[0] - 0.5f), ly = bp[4] * (sp[1] - 0.5f), lz = bp[5] * (sp[2] - 0.5f);
-    const float c = cs[bx], s = sn[bx];
+    // cs == NULL: cosf / sinf of the yaw here (the device library's functions: tests/test_gpu_pointops.py checks them against
+    // torch.cos / torch.sin bit for bit -- two launches less per frame)
+    const float c = cs ? cs[bx] : cosf(bp[6]), s = sn ? sn[bx] : sinf(bp[6]);
     out[t * 3] = bp[0] + (c * lx - s * ly);
     out[t * 3 + 1] = bp[1] + (s * lx + c * ly);
     out[t * 3 + 2] = bp[2] + lz;
@@ -1059,7 +1061,7 @@ extern "C" int v3d_roi_grid_points(const float* boxes, const float* samples, con
   if (n_boxes < 0 || m < 0) return V3D_EINVAL;
   const long long total = (long long)n_boxes * m;
   if (total == 0) return V3D_OK;
-  if (!boxes || !samples || !cos_yaw || !sin_yaw || !out) return V3D_EINVAL;
+  if (!boxes || !samples || !out || ((cos_yaw == nullptr) != (sin_yaw == nullptr))) return V3D_EINVAL;
   hipLaunchKernelGGL(roi_grid_points_kernel, dim3((int)std::min<long long>(v3d_ceil_div(total, V3D_BLOCK), 4096)), dim3(V3D_BLOCK), 0,
                      (hipStream_t)stream, boxes, samples, cos_yaw, sin_yaw, total, m, out);
   V3D_CHECK_LAUNCH();

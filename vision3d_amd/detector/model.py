@@ -71,7 +71,9 @@ class PV_RCNN(nn.Module):
         xyz, reflectance = item["points"].split([3, 1], dim=-1)
         sources = [(xyz, reflectance), *cnn_features]
         if self._fused_features_ok(sources, bev_map, keypoints):
-            return self._point_features_fused(sources, bev_map, keypoints)
+            pts = item["points"]
+            cloud = pts if (pts.dim() == 3 and pts.shape[2] == 4 and pts.is_contiguous() and pts.dtype == torch.float32) else None
+            return self._point_features_fused(sources, bev_map, keypoints, cloud)
         pooled = self._pointnets(sources, keypoints)
         return torch.cat([*pooled, self.bev(bev_map, keypoints)], dim=1)
 
@@ -83,7 +85,8 @@ class PV_RCNN(nn.Module):
         return (not torch.is_grad_enabled() and not self.training and keypoints.is_cuda and keypoints.dtype == torch.float32
                 and all(p._fusable(f) for p, (_, f) in zip(self.pnets, sources)) and self.bev._native(bev_map, keypoints))
 
-    def _point_features_fused(self, sources, bev_map, keypoints):
+    def _point_features_fused(self, sources, bev_map, keypoints, cloud=None):
+        """`cloud`: the (B, N, 4) points whose columns 0-2 / 3 are sources[0]'s xyz / its one feature channel (when contiguous)."""
         b, k = keypoints.shape[:2]
         widths = [sum(p.out_channels()) for p in self.pnets] + [bev_map.shape[1]]
         feats = torch.empty((b, k, sum(widths)), dtype=torch.float32, device=keypoints.device)
@@ -100,7 +103,9 @@ class PV_RCNN(nn.Module):
         if grids and len(self.pnets) <= 8 and all(pl is not None and len(p.groupers) == 2 for p, pl in zip(self.pnets, plans)):
             nbrs = pn2.ball_query_pairs_many([(grids[i], xyzs[i], p.groupers[0].radius, p.groupers[0].nsample, p.groupers[1].radius,
                                                p.groupers[1].nsample) for i, p in enumerate(self.pnets)], kp)
-            prepped = [p.prep_features(f) for p, (_, f) in zip(self.pnets, sources)]
+            prepped = [p.prep_features(f) if i or cloud is None else cloud for i, (p, (_, f)) in enumerate(zip(self.pnets, sources))]
+            if cloud is not None:  # the raw source's reflectance read out of the (B, N, 4) cloud itself (column 3): no padded copy
+                plans[0] = self.pnets[0].pair_plan(feat_cols=(3,), width=4)
             prods = pn2.linear_rows_many([(f.reshape(-1, f.shape[2]), pl[0]) for f, pl in zip(prepped, plans)])
             sources = [(x, f) for (x, _), f in zip(sources, prepped)]
         col = 0

@@ -38,6 +38,7 @@ class RoiGridPool(nn.Module):
                                    mlps=copy.deepcopy(cfg.GRIDPOOL.MLPS_PN), use_xyz=True)
 
     rotate_z = staticmethod(yaw_rotate)
+    TORCH_TRIG = False  # sample_gridpoints: cos / sin of the yaw from torch (two more launches) instead of inside v3d_roi_grid_points
 
     def sample_gridpoints(self, boxes, samples=None):
         """boxes (b, n, 7) -> (b, n, m, 3) points uniform in each box: unit-cube draws scaled by (w, l, h), rotated
@@ -47,11 +48,15 @@ class RoiGridPool(nn.Module):
             samples = torch.rand((b, n, self.cfg.GRIDPOOL.NUM_GRIDPOINTS, 3), device=boxes.device, generator=self.generator)
         if (boxes.is_cuda and boxes.dtype == torch.float32 and samples.dtype == torch.float32 and boxes.shape[-1] == 7
                 and not (torch.is_grad_enabled() and (boxes.requires_grad or samples.requires_grad))):
-            # the statements below in one launch (csrc/pointops.hip v3d_roi_grid_points; cos / sin stay torch's): same values
+            # the statements below in one launch (csrc/pointops.hip v3d_roi_grid_points): same values.  The yaw's cos / sin are the
+            # device library's cosf / sinf inside that launch -- on this stack bit-identical to torch.cos / torch.sin
+            # (tests/test_gpu_pointops.py::test_roi_grid_points_trig_equals_torch); TORCH_TRIG: hand torch's values in instead
             from .. import _lib as L
             bx, sm = boxes.contiguous(), samples.contiguous()
-            yaw = bx[..., 6]
-            cos, sin = yaw.cos().contiguous(), yaw.sin().contiguous()
+            cos = sin = None
+            if self.TORCH_TRIG:
+                yaw = bx[..., 6]
+                cos, sin = yaw.cos().contiguous(), yaw.sin().contiguous()
             out = torch.empty_like(sm)
             with L.device_guard(bx.device):
                 L.check(L.lib().v3d_roi_grid_points(L.ptr(bx), L.ptr(sm), L.ptr(cos), L.ptr(sin), b * n, sm.shape[2], L.ptr(out),

@@ -148,13 +148,26 @@ class PointnetSAModuleMSG(nn.Module):
         kf = -(-c // 4) * 4
         return features_pm.contiguous() if kf == c else torch.nn.functional.pad(features_pm, (0, kf - c)).contiguous()
 
-    def pair_plan(self):
+    def pair_plan(self, feat_cols=None, width=None):
         """(W1 feature parts side by side (Kf, sum N1), [W1[0:3]], column offsets, packed layers) when every scale is a two-layer MLP
-        the PAIR kernel covers, else None."""
+        the PAIR kernel covers, else None.  `feat_cols` / `width`: the caller's feature matrix has `width` columns and the module's
+        channel j lives in column feat_cols[j] (PV-RCNN's raw-point source: the reflectance is column 3 of the (B, N, 4) cloud
+        itself) -- the weight rows are laid out for THAT matrix (zero rows for the other columns: exact zeros in every sum), so that
+        no padded copy of the features is made."""
         packed = [self._packed_layers(k) for k in range(len(self.groupers))]
         if not (self.PAIR_FIRST_LAYERS and all(len(ly) == 2 and ly[0][0].shape[1] <= 256 for ly in packed)):
             return None
-        return (*self._pair_pieces(packed), packed)
+        w1f, wxs, offs = self._pair_pieces(packed)
+        if feat_cols is not None:
+            cache = self.__dict__.setdefault("_pair_cols_cache", {})
+            key = (tuple(feat_cols), int(width))
+            if key not in cache or cache[key][0] is not w1f:
+                wide = w1f.new_zeros((int(width), w1f.shape[1]))
+                for j, col in enumerate(feat_cols):
+                    wide[col] = w1f[j]
+                cache[key] = (w1f, wide.contiguous())
+            w1f = cache[key][1]
+        return w1f, wxs, offs, packed
 
     def fused_forward(self, xyz, features_pm, new_xyz, out_pm=None, grid=None, neighbours=None, p_all=None, plan=False):
         """features_pm (B, N, C) POINT-major -> (B, M, sum(mlps[k][-1])) POINT-major: every scale's last layer writes its pooled rows
@@ -167,7 +180,8 @@ class PointnetSAModuleMSG(nn.Module):
         b, n, c = features_pm.shape
         m = new_xyz.shape[1]
         kf = -(-c // 4) * 4
-        feat = self.prep_features(features_pm)
+        # (with the first-layer products handed in, the features themselves are not read again: no padded copy is made)
+        feat = features_pm if (p_all is not None and plan) else self.prep_features(features_pm)
         xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
         couts = self.out_channels()
         if out_pm is None:
